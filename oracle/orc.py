@@ -109,6 +109,9 @@ class Sim:
         if not self.h:
             raise RuntimeError("sim_create failed")
         g("sim_step").argtypes = [C.c_void_p]
+        g("sim_control").argtypes = [C.c_void_p]
+        g("sim_observe").argtypes = [C.c_void_p]
+        g("sim_observe").restype = None
         g("sim_true").argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         g("sim_last_obs").argtypes = [C.c_void_p] * 8
         g("sim_destroy").argtypes = [C.c_void_p]
@@ -117,6 +120,12 @@ class Sim:
 
     def step(self):
         return getattr(self.L, self.pfx + "sim_step")(self.h)
+
+    def control(self):
+        return getattr(self.L, self.pfx + "sim_control")(self.h)
+
+    def observe(self):
+        getattr(self.L, self.pfx + "sim_observe")(self.h)
 
     def true_pose(self):
         x = np.zeros(3, f32)

@@ -409,9 +409,9 @@ void *ref_sim_create(int argc, char **argv) {
 
 void ref_sim_destroy(void *h) { delete (RefSim *) h; }
 
-// One iteration of the wrapper main loop.  Returns -1 finished, 0 control step without observation,
-// 1 control step with an observation update.
-int ref_sim_step(void *h) {
+// First half of one wrapper-loop iteration: control() + predict (fastslam2wrapper.cpp:54-66).
+// Returns -1 finished, 0 no observation due, 1 observation due (call ref_sim_observe next).
+int ref_sim_control(void *h) {
     RefSim *s = (RefSim *) h;
     Conf *c = &s->conf;
     // slamwrapper.cpp:174-238 control()
@@ -430,21 +430,38 @@ int ref_sim_step(void *h) {
     if (s->method == 1) s->fs1.predict(s->particles, s->xTrue, s->Vnoisy, s->Gnoisy, s->Qe, s->dt);
 
     s->dtSum += s->dt;
-    bool observe = false;
     if (s->dtSum >= c->DT_OBSERVE) {
-        observe = true;
         s->dtSum = 0;
-        s->visible = vector<int>(s->landmarkIdentifiers);
-        s->z = getObservations(s->landmarks, s->xTrue, s->visible, c->MAX_RANGE);
-        if (c->SWITCH_SENSOR_NOISE) addObservationNoise(s->z, s->R);
-        if (s->method != 0) {
-            unsigned long Nf = s->particles[0].landmarkXs().size();
-            dataAssociationKnown(s->z, s->visible, s->table, Nf, s->zf, s->idf, s->zn);
-            if (s->method == 2) s->fs2.update(s->particles, s->zf, s->zn, s->idf, s->z, s->table, s->Re);
-            if (s->method == 1) s->fs1.update(s->particles, s->zf, s->zn, s->idf, s->visible, s->table, s->Re);
-        }
-        s->obsSteps++;
+        return 1;
     }
+    return 0;
+}
+
+// Second half (fastslam2wrapper.cpp:72-90): observe, add noise, associate, update.
+void ref_sim_observe(void *h) {
+    RefSim *s = (RefSim *) h;
+    Conf *c = &s->conf;
+    s->visible = vector<int>(s->landmarkIdentifiers);
+    s->z = getObservations(s->landmarks, s->xTrue, s->visible, c->MAX_RANGE);
+    if (c->SWITCH_SENSOR_NOISE) addObservationNoise(s->z, s->R);
+    if (s->method != 0) {
+        unsigned long Nf = s->particles[0].landmarkXs().size();
+        dataAssociationKnown(s->z, s->visible, s->table, Nf, s->zf, s->idf, s->zn);
+        if (s->method == 2) s->fs2.update(s->particles, s->zf, s->zn, s->idf, s->z, s->table, s->Re);
+        if (s->method == 1) s->fs1.update(s->particles, s->zf, s->zn, s->idf, s->visible, s->table, s->Re);
+    }
+    s->obsSteps++;
+}
+
+// One iteration of the wrapper main loop.  Returns -1 finished, 0 control step without observation,
+// 1 control step with an observation update.
+int ref_sim_step(void *h) {
+    RefSim *s = (RefSim *) h;
+    Conf *c = &s->conf;
+    int r = ref_sim_control(h);
+    if (r < 0) return r;
+    bool observe = r == 1;
+    if (observe) ref_sim_observe(h);
     if (s->method == 0) {
         // ekfslamwrapper.cpp:81-84 (zf/idf/zn/table are by-value scratch inside sim)
         vector<VectorXf> zf, zn;

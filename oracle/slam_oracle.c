@@ -1318,6 +1318,8 @@ static void associate_known(orc_sim *s, int Nf) {
     free(idn);
 }
 
+static void orc_ekf_step(orc_sim *s, int observe_flag);
+
 orc_sim *orc_sim_create(int argc, char **argv) {
     orc_sim *s = (orc_sim *) calloc(1, sizeof *s);
     kv_t *kv = (kv_t *) calloc(1, sizeof *kv);
@@ -1416,7 +1418,7 @@ void orc_sim_set_rng(orc_sim *s, int rng_mode, uint64_t seed) {
     s->seed = seed;
 }
 
-int orc_sim_step(orc_sim *s) {
+int orc_sim_control(orc_sim *s) {
     conf_t *c = &s->conf;
     /* slamwrapper.cpp:174-238 */
     if (s->iwp == -1) return -1;
@@ -1449,29 +1451,39 @@ int orc_sim_step(orc_sim *s) {
         orc_predict(s->P, &s->algo, s->Vnoisy, s->Gnoisy, s->Qe, s->dt, s->xTrue[2], nz);
     }
     s->dtSum += s->dt;
-    int observed = 0;
     if (s->dtSum >= c->DT_OBSERVE) {
-        observed = 1;
         s->dtSum = 0;
-        observe(s);
-        if (s->method != 0) {
-            int N = s->P->N;
-            associate_known(s, s->P->nf);
-            s->obs_step++;
-            int need_normals = (s->method == 2) && (s->m > 0 || s->n > 0);
-            if (s->rng_mode == 0) {
-                /* reference draw order: 4 rand() per particle inside the particle loop, then N for the strata */
-                if (need_normals)
-                    for (int i = 0; i < N; i++) orc_randn(3, 1, s->normals + 3 * i);
-                orc_stratified_random(N, s->sel);
-            } else {
-                orc_philox_update_tape(s->seed, s->obs_step, 0, N, N, need_normals ? s->normals : NULL, s->sel);
-            }
-            orc_update(s->P, &s->algo, s->zf, s->idf, s->m, s->zn, s->n, s->Re, s->normals, s->sel, NULL,
-                       &s->last_neff, &s->last_resampled);
-        }
+        return 1;
     }
-    return observed;
+    return 0;
+}
+
+void orc_sim_observe(orc_sim *s) {
+    observe(s);
+    if (s->method != 0) {
+        int N = s->P->N;
+        associate_known(s, s->P->nf);
+        s->obs_step++;
+        int need_normals = (s->method == 2) && (s->m > 0 || s->n > 0);
+        if (s->rng_mode == 0) {
+            /* reference draw order: 4 rand() per particle inside the particle loop, then N for the strata */
+            if (need_normals)
+                for (int i = 0; i < N; i++) orc_randn(3, 1, s->normals + 3 * i);
+            orc_stratified_random(N, s->sel);
+        } else {
+            orc_philox_update_tape(s->seed, s->obs_step, 0, N, N, need_normals ? s->normals : NULL, s->sel);
+        }
+        orc_update(s->P, &s->algo, s->zf, s->idf, s->m, s->zn, s->n, s->Re, s->normals, s->sel, NULL, &s->last_neff,
+                   &s->last_resampled);
+    }
+}
+
+int orc_sim_step(orc_sim *s) {
+    int r = orc_sim_control(s);
+    if (r < 0) return r;
+    if (r == 1) orc_sim_observe(s);
+    if (s->method == 0) orc_ekf_step(s, r == 1);
+    return r;
 }
 
 orc_particles *orc_sim_particles(orc_sim *s) { return s->P; }
@@ -1514,10 +1526,15 @@ void orc_sim_noise(const orc_sim *s, float *Q4, float *R4, float *dt) {
     if (dt) *dt = s->dt;
 }
 
+static void orc_ekf_step(orc_sim *s, int observe_flag) {
+    (void) s;
+    (void) observe_flag; /* TODO(config 1): EKF restatement */
+}
+
 int orc_sim_ekf_state(const orc_sim *s, float *x, float *P, int cap) {
     (void) s;
     (void) x;
     (void) P;
     (void) cap;
-    return 0; /* EKF restatement lives in slam_oracle_ekf.c (config 1) */
+    return 0;
 }

@@ -106,6 +106,8 @@ void orc_sim_destroy(orc_sim *s);
  *          1: control/observation noise from libc rand(), particle noise from Philox(seed,step). */
 void orc_sim_set_rng(orc_sim *s, int rng_mode, uint64_t seed);
 int orc_sim_step(orc_sim *s);        /* -1 finished, 0 control step, 1 control step + observation update */
+int orc_sim_control(orc_sim *s);     /* first half: control + predict; -1 finished, 1 = observation due */
+void orc_sim_observe(orc_sim *s);    /* second half: observe + associate + update */
 orc_particles *orc_sim_particles(orc_sim *s);
 int orc_sim_nlandmarks(const orc_sim *s);
 void orc_sim_true(const orc_sim *s, float *x3, float *VnGn);
