@@ -1,0 +1,143 @@
+/* slamgpu — C ABI of the MI355X-native FastSLAM inner loop (libslamgpu.so).
+ *
+ * This is the drop-in boundary for matzipan/slam's hot path.  Citations are file:line under the
+ * reference tree.  It replaces two seams of the reference:
+ *
+ *  Seam 1 — the accelerator object used by computeJacobians when built with
+ *           -DJACOBIAN_ACCELERATOR=on: class AcceleratorHandler { getMemoryPointer(); setN(n);
+ *           start(); isDone(); } (src/backend/AcceleratorHandler.h:10-23) with the packed float32
+ *           window written/read at src/backend/core.cpp:586-664.  => slamgpu_jacobians().
+ *
+ *  Seam 2 — the algorithm objects the wrappers drive:
+ *           FastSLAM2::predict / FastSLAM2::update (src/backend/algorithms/fastslam2.h:20-24, called at
+ *           src/backend/wrappers/fastslam2wrapper.cpp:64,88) and FastSLAM1::predict / ::update
+ *           (src/backend/algorithms/fastslam1.h:29-33, fastslam1wrapper.cpp:58,81), whose tunables are
+ *           the public fields set in fastslam2wrapper.cpp:18-23, plus the per-step pose output
+ *           ParticleSLAMWrapper::computeEstimatedPosition (ParticleSLAMWrapper.cpp:56-77).
+ *           => slamgpu_create / _predict / _update / _estimate / _download / _destroy.
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every entry point returns 0 on success
+ * or a negative slamgpu_status, never throws or aborts; slamgpu_last_error() describes the last
+ * failure on the calling thread.  Host pointers are never retained across calls.  One context is
+ * driven by one host thread.  All 2x2 / 3x3 matrices are row-major float32 unless stated.
+ * Work is enqueued on the context's HIP stream; calls that return data synchronise that stream.
+ */
+#ifndef SLAMGPU_H
+#define SLAMGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAMGPU_ABI_VERSION 1
+
+typedef enum {
+    SLAMGPU_OK = 0,
+    SLAMGPU_ERR_INVALID = -1,   /* bad argument / state */
+    SLAMGPU_ERR_HIP = -2,       /* a HIP runtime call failed (message in slamgpu_last_error) */
+    SLAMGPU_ERR_CAPACITY = -3,  /* landmark capacity exceeded */
+    SLAMGPU_ERR_NO_DEVICE = -4, /* no usable GPU: the product path has no CPU fallback */
+    SLAMGPU_ERR_ALLOC = -5
+} slamgpu_status;
+
+enum { SLAMGPU_FASTSLAM1 = 1, SLAMGPU_FASTSLAM2 = 2 };
+enum {
+    SLAMGPU_RNG_TAPE = 0,  /* caller feeds the normals / strata it drew (parity with the reference's libc rand()) */
+    SLAMGPU_RNG_PHILOX = 1 /* counter-based Philox4x32-10 keyed by (seed, step, global particle id) on device */
+};
+enum {
+    SLAMGPU_MATH_STRICT = 0, /* no FMA contraction, IEEE divide/sqrt: closest to the reference's SSE2 float math */
+    SLAMGPU_MATH_FAST = 1    /* FMA contraction allowed (results within the documented tolerance of STRICT) */
+};
+
+typedef struct slamgpu_ctx slamgpu_ctx;
+
+/* Mirrors the public fields of FastSLAM2 / FastSLAM1 (fastslam2.h:26-31) + sizes. Zero-initialise,
+ * set struct_size = sizeof(slamgpu_config), then fill. */
+typedef struct {
+    uint32_t struct_size;
+    int32_t device;            /* HIP device ordinal */
+    int32_t method;            /* SLAMGPU_FASTSLAM1 / SLAMGPU_FASTSLAM2 */
+    int32_t n_particles;       /* particles held by THIS context (its shard) */
+    int32_t max_landmarks;     /* landmark capacity per particle */
+    int32_t use_heading;       /* useHeading  (SWITCH_HEADING_KNOWN) */
+    int32_t add_predict_noise; /* addPredictNoise (FS1: always 1, fastslam1wrapper.cpp:20) */
+    int32_t resample;          /* resample (SWITCH_RESAMPLE) */
+    int32_t n_effective;       /* nEffective (NEFFECTIVE), compared against the GLOBAL particle count's Neff */
+    float wheel_base;          /* wheelBase */
+    float sigma_phi;           /* sigmaPhi (sigmaT) */
+    int32_t rng_mode;          /* SLAMGPU_RNG_* */
+    int32_t math_mode;         /* SLAMGPU_MATH_* */
+    uint64_t seed;             /* Philox key */
+    /* sharding: this context holds global particles [first_particle, first_particle + n_particles) of
+     * n_particles_global.  Single GPU: first_particle = 0, n_particles_global = n_particles (or 0). */
+    int64_t first_particle;
+    int64_t n_particles_global;
+} slamgpu_config;
+
+const char *slamgpu_last_error(void);
+int slamgpu_abi_version(void);
+int slamgpu_device_count(void);
+
+/* ---- Seam 1: AcceleratorHandler-compatible batched computeJacobians -------------------------------
+ * in : xv[3], R[4] (Eigen linear = column-major, core.cpp:600-602), then per feature xf[2], Pf[4]
+ *      column-major (core.cpp:608-617)                                        => 7 + 6n floats
+ * out: per feature zp[2], Hf[4] row-major, Hv[6] row-major, Sf[4] row-major (core.cpp:631-651)
+ *                                                                              => 16n floats
+ * Host pointers; synchronous (this is the start()/isDone() spin of core.cpp:619-622). */
+int slamgpu_jacobians(const float *in, uint32_t n, float *out);
+
+/* ---- Seam 2: the algorithm object ------------------------------------------------------------------ */
+int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out);
+void slamgpu_destroy(slamgpu_ctx *ctx);
+
+/* FastSLAM{1,2}::predict(particles, xTrue, V, G, Q, dt) (fastslam2.cpp:51-60 / fastslam1.cpp:57-66).
+ * phi_true = xTrue(2), used only when use_heading.  noise2: TAPE mode + add_predict_noise: 2*N host
+ * floats, the two normals multivariateGauss((V,G),Q) consumed per particle, particle-major; else NULL.
+ * Consecutive predicts may be coalesced into one launch; any other call flushes them. */
+int slamgpu_predict(slamgpu_ctx *ctx, float V, float G, const float Q[4], float dt, float phi_true,
+                    const float *noise2);
+
+/* FastSLAM{1,2}::update(particles, zf, zn, idf, z, table, R) (fastslam2.cpp:21-48 / fastslam1.cpp:18-35)
+ * including resampleParticles (core.cpp:718-749).
+ * zf[2m], idf[m]: re-observed landmarks; zn[2n]: new landmarks (appended at index Nf..Nf+n-1).
+ * TAPE mode: normals = 3*N host floats (particle-major; the randn(3,1) of multivariateGauss, needed
+ * when method==FASTSLAM2 and m+n>0), strata = N_global host floats (the dithered strata of
+ * stratifiedRandom, core.cpp:751-769).  PHILOX mode: both NULL. */
+int slamgpu_update(slamgpu_ctx *ctx, const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n,
+                   const float R[4], const float *normals, const float *strata);
+
+/* computeEstimatedPosition (ParticleSLAMWrapper.cpp:56-77): mean x, mean y, heading of the first
+ * particle with the strictly greatest weight.  Synchronises. */
+int slamgpu_estimate(slamgpu_ctx *ctx, double xyt[3]);
+
+/* Outcome of the last update: Neff, whether the resample fired, sum of the raw weights. Synchronises. */
+int slamgpu_stats(slamgpu_ctx *ctx, float *neff, int32_t *resampled, double *weight_sum);
+/* Ancestor indices of the last resample (keep[], core.cpp:800-806), N_local int32. Synchronises. */
+int slamgpu_ancestors(slamgpu_ctx *ctx, int32_t *keep);
+
+int slamgpu_num_landmarks(slamgpu_ctx *ctx);
+/* Particle-major host copies (any pointer may be NULL): xv[3N], Pv[9N] row-major, w[N],
+ * xf[2*Nf*N], Pf[4*Nf*N] row-major — the layout of vector<Particle> flattened. Synchronises. */
+int slamgpu_download(slamgpu_ctx *ctx, float *xv, float *Pv9, float *w, float *xf, float *Pf4);
+int slamgpu_upload(slamgpu_ctx *ctx, int32_t nf, const float *xv, const float *Pv9, const float *w, const float *xf,
+                   const float *Pf4);
+int slamgpu_sync(slamgpu_ctx *ctx);
+
+/* ---- measurement / plumbing ------------------------------------------------------------------------ */
+/* HIP stream the context launches on (hipStream_t as void*), so a harness can record events on it. */
+void *slamgpu_stream(slamgpu_ctx *ctx);
+/* Device-time accounting: when enabled every kernel launch is bracketed by HIP events on the context
+ * stream; slamgpu_kernel_time returns accumulated milliseconds and launch count for a kernel name
+ * ("fs2_update", "weights_scan", "resample", "predict", "estimate", ...). */
+int slamgpu_profile(slamgpu_ctx *ctx, int32_t enable);
+int slamgpu_kernel_time(slamgpu_ctx *ctx, const char *kernel, double *ms, int64_t *launches);
+/* Algorithmic bytes moved by the update path so far (SURVEY.md §8(d) formula, accumulated per step). */
+int slamgpu_algorithmic_bytes(slamgpu_ctx *ctx, double *update_bytes, double *predict_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,66 @@
+/* slamhost — C ABI of the host-side front end that surrounds the hot path in matzipan/slam's wrappers
+ * (libslamhost.so, plain C++, no GPU code).  It is what slam-backend links and what bench.py / the
+ * tests use to produce the control / observation tape.  Citations are file:line under the reference.
+ *
+ *  - Conf::parse keys + defaults (src/backend/core.cpp:971-1073), `<map stem>.ini` then `-KEY value`
+ *    overrides (SLAMBackendApplication.cpp:59-89, utils.cpp:504-565,1032-1046)
+ *  - map reader (core.cpp:855-962)
+ *  - SLAMWrapper::control(): updateSteering, predictTruePosition, addControlNoise
+ *    (wrappers/slamwrapper.cpp:174-238, core.cpp:24-78)
+ *  - getObservations / addObservationNoise / dataAssociationKnown (core.cpp:91-120,185-273,438-449)
+ *  - the libc rand() draws of nRandMat::randn and stratifiedRandom in the reference's order
+ *    (core.cpp:383-419,751-769), used to feed slamgpu's TAPE mode.
+ */
+#ifndef SLAMHOST_H
+#define SLAMHOST_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct slamhost_sim slamhost_sim;
+
+typedef struct {
+    float V, MAXG, RATEG, WHEELBASE, DT_CONTROLS, sigmaV, sigmaG, MAX_RANGE, DT_OBSERVE, sigmaR, sigmaB, sigmaT;
+    float GATE_REJECT, GATE_AUGMENT, AT_WAYPOINT;
+    int32_t NUMBER_LOOPS, NPARTICLES, NEFFECTIVE;
+    int32_t SWITCH_CONTROL_NOISE, SWITCH_SENSOR_NOISE, SWITCH_INFLATE_NOISE, SWITCH_PREDICT_NOISE,
+        SWITCH_SAMPLE_PROPOSAL, SWITCH_HEADING_KNOWN, SWITCH_RESAMPLE, SWITCH_PROFILE, SWITCH_SEED_RANDOM,
+        SWITCH_ASSOCIATION_KNOWN, SWITCH_BATCH_UPDATE, SWITCH_USE_IEKF;
+    int32_t method;      /* 0 EKF1, 1 FASTSLAM1, 2 FASTSLAM2 (anything else => EKF, SLAMBackendApplication.cpp:26-29) */
+    int32_t n_landmarks; /* columns of lm */
+    int32_t n_waypoints;
+    float Q[4], R[4], Qe[4], Re[4]; /* slamwrapper.cpp:25-37 */
+} slamhost_conf;
+
+const char *slamhost_last_error(void);
+/* argv as given to slam-backend: -m map.mat -method M [-KEY value]... ; seeds libc rand() (slamwrapper.cpp:48-52) */
+slamhost_sim *slamhost_sim_create(int argc, char **argv);
+void slamhost_sim_destroy(slamhost_sim *s);
+int slamhost_sim_conf(const slamhost_sim *s, slamhost_conf *out);
+/* landmarks / waypoints, 2 x n row-major */
+int slamhost_sim_map(const slamhost_sim *s, float *lm, float *wp);
+/* control(): -1 = run finished, 0 = step without observation, 1 = observation due.  Outputs the noisy
+ * controls handed to predict and the true heading. */
+int slamhost_sim_control(slamhost_sim *s, float *Vn, float *Gn, float *phi_true);
+/* getObservations + noise + dataAssociationKnown against nf_known landmarks already in the map.
+ * zf/zn sized 2*n_landmarks, idf n_landmarks.  Returns 0. */
+int slamhost_sim_observe(slamhost_sim *s, int32_t nf_known, float *zf, int32_t *idf, int32_t *m, float *zn, int32_t *n);
+/* raw observation of the last slamhost_sim_observe: z[2*nz], visible ids */
+int slamhost_sim_last_z(const slamhost_sim *s, float *z, int32_t *vis, int32_t *nz);
+void slamhost_sim_true(const slamhost_sim *s, float x[3]);
+int64_t slamhost_sim_control_steps(const slamhost_sim *s);
+
+/* libc rand() tape in the reference's draw order */
+void slamhost_draw_normals(int32_t count, int32_t dim, float *out); /* count x randn(dim,1): dim+1 rand() each */
+int32_t slamhost_draw_strata(int32_t N, float *out);                /* returns the reference's strata count (== N when supported) */
+double slamhost_unif_rand(void);                                    /* unifRand (core.cpp:775) */
+
+/* synthetic map generator for BASELINE config 5: n landmarks i.i.d. uniform on [x0,x1]x[y0,y1], SplitMix64(seed) */
+void slamhost_synthetic_landmarks(uint64_t seed, int32_t n, float x0, float x1, float y0, float y1, float *lm /*2 x n*/);
+int slamhost_write_map(const char *path, const float *lm, int32_t nlm, const float *wp, int32_t nwp);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

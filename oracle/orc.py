@@ -266,6 +266,7 @@ class OrcSim(Sim):
         L.orc_sim_set_rng.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
         L.orc_sim_last_resample.argtypes = [C.c_void_p] * 3
         L.orc_sim_last_tape.argtypes = [C.c_void_p] * 3
+        L.orc_sim_last_noise2.argtypes = [C.c_void_p] * 2
         L.orc_sim_algo.restype = C.POINTER(Algo)
         L.orc_sim_algo.argtypes = [C.c_void_p]
         L.orc_sim_noise.argtypes = [C.c_void_p] * 4
@@ -307,6 +308,11 @@ class OrcSim(Sim):
         sel = np.zeros(self.N, f32)
         self.L.orc_sim_last_tape(self.h, _p(normals), _p(sel))
         return normals, sel
+
+    def last_noise2(self):
+        n2 = np.zeros((self.N, 2), f32)
+        self.L.orc_sim_last_noise2(self.h, _p(n2))
+        return n2
 
     def ekf_state(self, cap=128):
         x = np.zeros(cap, f32)

@@ -1520,6 +1520,10 @@ void orc_sim_last_tape(const orc_sim *s, float *normals, float *sel) {
     if (sel) memcpy(sel, s->sel, sizeof(float) * (size_t) N);
 }
 
+void orc_sim_last_noise2(const orc_sim *s, float *noise2) {
+    if (s->P && noise2) memcpy(noise2, s->noise2, sizeof(float) * 2 * (size_t) s->P->N);
+}
+
 void orc_sim_noise(const orc_sim *s, float *Q4, float *R4, float *dt) {
     if (Q4) memcpy(Q4, s->Qe, sizeof s->Qe);
     if (R4) memcpy(R4, s->Re, sizeof s->Re);

@@ -115,6 +115,8 @@ int orc_sim_last_obs(const orc_sim *s, float *zf, int *idf, float *zn, int *n_ou
 void orc_sim_last_resample(const orc_sim *s, float *neff, int *resampled);
 /* Tape of the last update (valid after orc_sim_step returned 1): normals 3N, sel N. */
 void orc_sim_last_tape(const orc_sim *s, float *normals, float *sel);
+/* Control-noise normals of the last predict (2N, particle-major; valid when add_predict_noise). */
+void orc_sim_last_noise2(const orc_sim *s, float *noise2);
 const orc_algo *orc_sim_algo(const orc_sim *s);
 void orc_sim_noise(const orc_sim *s, float *Q4, float *R4, float *dt);
 /* EKF (config 1): state vector, covariance (row-major dim x dim into P with leading dimension cap). */

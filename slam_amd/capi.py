@@ -1,0 +1,214 @@
+"""ctypes binding of include/slamgpu.h (the C ABI of libslamgpu.so).  Fails loudly when the library is
+missing: there is deliberately no fallback path."""
+import ctypes as C
+import os
+
+import numpy as np
+
+FASTSLAM1, FASTSLAM2 = 1, 2
+RNG_TAPE, RNG_PHILOX = 0, 1
+MATH_STRICT, MATH_FAST = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# every symbol include/slamgpu.h declares (tests check the built library exports each one)
+DECLARED_SYMBOLS = [
+    "slamgpu_last_error", "slamgpu_abi_version", "slamgpu_device_count", "slamgpu_jacobians", "slamgpu_create",
+    "slamgpu_destroy", "slamgpu_predict", "slamgpu_update", "slamgpu_estimate", "slamgpu_stats", "slamgpu_ancestors",
+    "slamgpu_num_landmarks", "slamgpu_download", "slamgpu_upload", "slamgpu_sync", "slamgpu_stream", "slamgpu_profile",
+    "slamgpu_kernel_time", "slamgpu_algorithmic_bytes",
+]
+
+
+class SlamGpuError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("slamgpu error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("method", C.c_int32), ("n_particles", C.c_int32),
+                ("max_landmarks", C.c_int32), ("use_heading", C.c_int32), ("add_predict_noise", C.c_int32),
+                ("resample", C.c_int32), ("n_effective", C.c_int32), ("wheel_base", C.c_float), ("sigma_phi", C.c_float),
+                ("rng_mode", C.c_int32), ("math_mode", C.c_int32), ("seed", C.c_uint64), ("first_particle", C.c_int64),
+                ("n_particles_global", C.c_int64)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libslamgpu.so")
+
+
+_lib = None
+
+
+def load_library():
+    """Load libslamgpu.so (built in-tree by __graft_entry__.build() / slam_amd/csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise SlamGpuError(-4, "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(no CPU fallback exists)" % p)
+    L = C.CDLL(p)
+    L.slamgpu_last_error.restype = C.c_char_p
+    L.slamgpu_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    L.slamgpu_destroy.argtypes = [C.c_void_p]
+    L.slamgpu_destroy.restype = None
+    L.slamgpu_jacobians.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.slamgpu_predict.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+    L.slamgpu_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]
+    L.slamgpu_estimate.argtypes = [C.c_void_p, C.c_void_p]
+    L.slamgpu_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.slamgpu_ancestors.argtypes = [C.c_void_p, C.c_void_p]
+    L.slamgpu_num_landmarks.argtypes = [C.c_void_p]
+    L.slamgpu_download.argtypes = [C.c_void_p] * 6
+    L.slamgpu_upload.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 5
+    L.slamgpu_sync.argtypes = [C.c_void_p]
+    L.slamgpu_stream.argtypes = [C.c_void_p]
+    L.slamgpu_stream.restype = C.c_void_p
+    L.slamgpu_profile.argtypes = [C.c_void_p, C.c_int32]
+    L.slamgpu_kernel_time.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.slamgpu_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    _lib = L
+    return L
+
+
+def _chk(rc):
+    if rc != 0:
+        raise SlamGpuError(rc, load_library().slamgpu_last_error().decode())
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(a, np.float32)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    return load_library().slamgpu_device_count()
+
+
+def jacobians(xv, R, xf, Pf):
+    """Seam 1 (AcceleratorHandler window, core.cpp:586-664).  R, Pf given row-major here; packed column-major."""
+    n = xf.shape[0]
+    buf = np.zeros(7 + 6 * n, np.float32)
+    buf[:3] = xv
+    buf[3:7] = np.asarray(R, np.float32).T.ravel()  # Eigen linear index = column-major
+    rec = buf[7:].reshape(n, 6)
+    rec[:, :2] = xf
+    rec[:, 2:] = np.asarray(Pf, np.float32).transpose(0, 2, 1).reshape(n, 4)
+    out = np.zeros(16 * n, np.float32)
+    _chk(load_library().slamgpu_jacobians(_ptr(buf), n, _ptr(out)))
+    o = out.reshape(n, 16)
+    return o[:, 0:2].copy(), o[:, 6:12].reshape(n, 2, 3).copy(), o[:, 2:6].reshape(n, 2, 2).copy(), o[:, 12:16].reshape(n, 2, 2).copy()
+
+
+class SlamGpu:
+    """One device-resident particle set = one FastSLAM{1,2} algorithm object (fastslam2.h:20-31)."""
+
+    def __init__(self, n_particles, max_landmarks, method=FASTSLAM2, n_effective=None, resample=True, use_heading=False,
+                 add_predict_noise=None, wheel_base=4.0, sigma_phi=0.017453292519943, rng_mode=RNG_TAPE, seed=0,
+                 math_mode=MATH_STRICT, device=0, first_particle=0, n_particles_global=0):
+        self.L = load_library()
+        cfg = Config()
+        cfg.struct_size = C.sizeof(Config)
+        cfg.device = device
+        cfg.method = method
+        cfg.n_particles = n_particles
+        cfg.max_landmarks = max_landmarks
+        cfg.use_heading = int(use_heading)
+        cfg.add_predict_noise = int(method == FASTSLAM1 if add_predict_noise is None else add_predict_noise)
+        cfg.resample = int(resample)
+        ng = n_particles_global or n_particles
+        cfg.n_effective = int(0.75 * ng) if n_effective is None else int(n_effective)
+        cfg.wheel_base = wheel_base
+        cfg.sigma_phi = sigma_phi
+        cfg.rng_mode = rng_mode
+        cfg.math_mode = math_mode
+        cfg.seed = seed
+        cfg.first_particle = first_particle
+        cfg.n_particles_global = ng
+        self.cfg = cfg
+        self.N = n_particles
+        self.h = C.c_void_p()
+        _chk(self.L.slamgpu_create(C.byref(cfg), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.L.slamgpu_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def predict(self, V, G, Q, dt, phi_true=0.0, noise2=None):
+        Q = _f32(Q, 4)
+        n2 = None if noise2 is None else _f32(noise2, (self.N, 2))
+        _chk(self.L.slamgpu_predict(self.h, V, G, _ptr(Q), dt, phi_true, _ptr(n2)))
+
+    def update(self, zf, idf, zn, R, normals=None, strata=None):
+        zf = _f32(zf).reshape(-1, 2)
+        zn = _f32(zn).reshape(-1, 2)
+        idf = np.ascontiguousarray(idf, np.int32)
+        R = _f32(R, 4)
+        nm = None if normals is None else _f32(normals, (self.N, 3))
+        st = None if strata is None else _f32(strata)
+        _chk(self.L.slamgpu_update(self.h, _ptr(zf), _ptr(idf), zf.shape[0], _ptr(zn), zn.shape[0], _ptr(R), _ptr(nm), _ptr(st)))
+
+    def estimate(self):
+        e = np.zeros(3, np.float64)
+        _chk(self.L.slamgpu_estimate(self.h, _ptr(e)))
+        return e
+
+    def stats(self):
+        ne, rs, ws = C.c_float(), C.c_int32(), C.c_double()
+        _chk(self.L.slamgpu_stats(self.h, C.byref(ne), C.byref(rs), C.byref(ws)))
+        return np.float32(ne.value), bool(rs.value), ws.value
+
+    def ancestors(self):
+        keep = np.zeros(self.N, np.int32)
+        _chk(self.L.slamgpu_ancestors(self.h, _ptr(keep)))
+        return keep
+
+    def nf(self):
+        return self.L.slamgpu_num_landmarks(self.h)
+
+    def download(self, landmarks=True):
+        N, nf = self.N, self.nf()
+        xv = np.zeros((N, 3), np.float32)
+        Pv = np.zeros((N, 3, 3), np.float32)
+        w = np.zeros(N, np.float32)
+        xf = np.zeros((N, nf, 2), np.float32) if landmarks else None
+        Pf = np.zeros((N, nf, 2, 2), np.float32) if landmarks else None
+        _chk(self.L.slamgpu_download(self.h, _ptr(xv), _ptr(Pv), _ptr(w), _ptr(xf), _ptr(Pf)))
+        return dict(xv=xv, Pv=Pv, w=w, xf=xf, Pf=Pf, nf=nf)
+
+    def upload(self, st):
+        nf = int(st["nf"])
+        xf = _f32(st["xf"]) if nf else None
+        Pf = _f32(st["Pf"]) if nf else None
+        _chk(self.L.slamgpu_upload(self.h, nf, _ptr(_f32(st["xv"])), _ptr(_f32(st["Pv"])), _ptr(_f32(st["w"])), _ptr(xf), _ptr(Pf)))
+
+    def sync(self):
+        _chk(self.L.slamgpu_sync(self.h))
+
+    def stream(self):
+        return self.L.slamgpu_stream(self.h)
+
+    def profile(self, enable=True):
+        _chk(self.L.slamgpu_profile(self.h, int(enable)))
+
+    def kernel_time(self, name):
+        ms, n = C.c_double(), C.c_int64()
+        _chk(self.L.slamgpu_kernel_time(self.h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

@@ -1,0 +1,291 @@
+// Per-particle FastSLAM arithmetic for gfx950, one particle per work-item, everything in registers.
+// Fixed-size 2x2 / 3x3 code following the reference's float32 operation order (file:line cited per
+// function, relative to the reference tree) so that the only deviations from the CPU result are
+//   (1) device libm (atan2f/sinf/cosf/expf/logf are 1-2 ulp routines, not glibc's),
+//   (2) gaussEvaluate solved by forward substitution instead of the reference's JacobiSVD pseudo-inverse,
+//   (3) covariances stored symmetric-packed (Pv: 6 floats, Pf: 3 floats) in HBM.
+// This header is compiled twice: namespace slam_strict with -ffp-contract=off (no FMA, IEEE divide and
+// sqrt) and namespace slam_fast with contraction allowed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef SLAM_KNS
+#error "define SLAM_KNS (slam_strict or slam_fast)"
+#endif
+
+namespace SLAM_KNS {
+
+#define SLAM_DEV __device__ __forceinline__
+
+constexpr double kPi = 3.14159265358979323846;
+
+// core.cpp:460-477 — double constants against a float argument.
+SLAM_DEV float trig_offset(float ang) {
+    if (((double) ang < -2 * kPi) || ((double) ang > 2 * kPi)) {
+        int n = (int) floor((double) ang / (2 * kPi));
+        ang = (float) ((double) ang - n * (2 * kPi));
+    }
+    if ((double) ang > kPi) ang = (float) ((double) ang - (2 * kPi));
+    if ((double) ang < -kPi) ang = (float) ((double) ang + (2 * kPi));
+    return ang;
+}
+
+struct Jac {
+    float zp0, zp1;
+    float hv00, hv01, hv10, hv11;  // Hv = [[hv00, hv01, 0], [hv10, hv11, -1]]
+    float hf00, hf01, hf10, hf11;  // Hf
+    float s00, s01, s10, s11;      // Sf = Hf Pf Hf^T + R
+};
+
+// computeJacobians, one feature (core.cpp:682-704).  Pf symmetric-packed: p00, p10, p11.
+SLAM_DEV Jac jacobian(float x, float y, float th, float fx, float fy, float p00, float p10, float p11, float r00,
+                      float r01, float r10, float r11) {
+    Jac j;
+    float dx = fx - x;
+    float dy = fy - y;
+    float d2 = (float) ((double) dx * (double) dx + (double) dy * (double) dy);  // pow(dx,2)+pow(dy,2) in double (:685)
+    float d = sqrtf(d2);
+    j.zp0 = d;
+    j.zp1 = trig_offset(atan2f(dy, dx) - th);
+    j.hv00 = -dx / d;
+    j.hv01 = -dy / d;
+    j.hv10 = dy / d2;
+    j.hv11 = -dx / d2;
+    j.hf00 = dx / d;
+    j.hf01 = dy / d;
+    j.hf10 = -dy / d2;
+    j.hf11 = dx / d2;
+    // T = Hf * Pf ; Sf = T * Hf^T + R  (k-ascending sums, GEMM order)
+    float t00 = j.hf00 * p00 + j.hf01 * p10;
+    float t01 = j.hf00 * p10 + j.hf01 * p11;
+    float t10 = j.hf10 * p00 + j.hf11 * p10;
+    float t11 = j.hf10 * p10 + j.hf11 * p11;
+    j.s00 = (t00 * j.hf00 + t01 * j.hf01) + r00;
+    j.s01 = (t00 * j.hf10 + t01 * j.hf11) + r01;
+    j.s10 = (t10 * j.hf00 + t11 * j.hf01) + r10;
+    j.s11 = (t10 * j.hf10 + t11 * j.hf11) + r11;
+    return j;
+}
+
+// A.inverse() of a dynamic 2x2 = PartialPivLU (Eigen LU/PartialPivLU.h:239-283 + the two triangular solves).
+SLAM_DEV void inverse2(float a00, float a01, float a10, float a11, float &x00, float &x01, float &x10, float &x11) {
+    bool swap = fabsf(a10) > fabsf(a00);
+    float u00 = swap ? a10 : a00, u01 = swap ? a11 : a01;
+    float l10 = swap ? a00 : a10, r11 = swap ? a01 : a11;
+    if (u00 != 0.0f) l10 = l10 * (1.0f / u00);
+    float u11 = r11 - l10 * u01;
+    // P * I
+    float b00 = swap ? 0.0f : 1.0f, b01 = swap ? 1.0f : 0.0f;
+    float b10 = swap ? 1.0f : 0.0f, b11 = swap ? 0.0f : 1.0f;
+    // unit-lower solve
+    b10 -= b00 * l10;
+    b11 -= b01 * l10;
+    // upper solve (column-major order: row 1 first, then eliminate into row 0)
+    float a = 1.0f / u11;
+    b10 *= a;
+    b11 *= a;
+    b00 -= b10 * u01;
+    b01 -= b11 * u01;
+    a = 1.0f / u00;
+    x00 = b00 * a;
+    x01 = b01 * a;
+    x10 = b10;
+    x11 = b11;
+}
+
+SLAM_DEV float determinant2(float a00, float a01, float a10, float a11) {
+    bool swap = fabsf(a10) > fabsf(a00);
+    float u00 = swap ? a10 : a00, u01 = swap ? a11 : a01;
+    float l10 = swap ? a00 : a10, r11 = swap ? a01 : a11;
+    if (u00 != 0.0f) l10 = l10 * (1.0f / u00);
+    float u11 = r11 - l10 * u01;
+    return (swap ? -1.0f : 1.0f) * (u00 * u11);
+}
+
+// Lower Cholesky of a symmetric 3x3 given by its lower triangle (Eigen Cholesky/LLT.h:260-287).
+// On a non-positive pivot at step k the remaining columns keep the input values, as Eigen leaves them.
+struct L3 {
+    float l00, l10, l11, l20, l21, l22;
+};
+
+SLAM_DEV L3 llt3(float a00, float a10, float a11, float a20, float a21, float a22) {
+    L3 L = {a00, a10, a11, a20, a21, a22};
+    float x = a00;
+    if (x <= 0.0f) return L;
+    x = sqrtf(x);
+    L.l00 = x;
+    float r = 1.0f / x;
+    L.l10 = a10 * r;
+    L.l20 = a20 * r;
+    x = a11 - L.l10 * L.l10;
+    if (x <= 0.0f) return L;
+    x = sqrtf(x);
+    L.l11 = x;
+    L.l21 = (a21 + L.l20 * (-1.0f * L.l10)) * (1.0f / x);
+    x = a22 - (L.l20 * L.l20 + L.l21 * L.l21);
+    if (x <= 0.0f) return L;
+    L.l22 = sqrtf(x);
+    return L;
+}
+
+struct L2 {
+    float l00, l10, l11;
+};
+
+SLAM_DEV L2 llt2(float a00, float a10, float a11) {
+    L2 L = {a00, a10, a11};
+    float x = a00;
+    if (x <= 0.0f) return L;
+    x = sqrtf(x);
+    L.l00 = x;
+    L.l10 = a10 * (1.0f / x);
+    x = a11 - L.l10 * L.l10;
+    if (x <= 0.0f) return L;
+    L.l11 = sqrtf(x);
+    return L;
+}
+
+// A.llt().solve(Identity) for 3x3 (TriangularSolverMatrix.h:109-137): column-oriented forward
+// substitution with reciprocal diagonals, then row-oriented back substitution.  X row-major, full.
+SLAM_DEV void llt_solve_identity3(const L3 &L, float X[9]) {
+    float a0 = 1.0f / L.l00, a1 = 1.0f / L.l11, a2 = 1.0f / L.l22;
+    // Y = L^-1 I
+    float y00 = a0;
+    float y10 = 0.0f - y00 * L.l10;
+    float y20 = 0.0f - y00 * L.l20;
+    y10 = y10 * a1;
+    y20 = y20 - y10 * L.l21;
+    y20 = y20 * a2;
+    float y11 = a1;
+    float y21 = 0.0f - y11 * L.l21;
+    y21 = y21 * a2;
+    float y22 = a2;
+    // X = U^-1 Y with U = L^T; row 2, then 1, then 0.  y01 = y02 = y12 = 0.
+    float x20 = (y20 - 0.0f) * a2, x21 = (y21 - 0.0f) * a2, x22 = (y22 - 0.0f) * a2;
+    float x10 = (y10 - L.l21 * x20) * a1, x11 = (y11 - L.l21 * x21) * a1, x12 = (0.0f - L.l21 * x22) * a1;
+    float x00 = (y00 - (L.l10 * x10 + L.l20 * x20)) * a0;
+    float x01 = (0.0f - (L.l10 * x11 + L.l20 * x21)) * a0;
+    float x02 = (0.0f - (L.l10 * x12 + L.l20 * x22)) * a0;
+    X[0] = x00; X[1] = x01; X[2] = x02;
+    X[3] = x10; X[4] = x11; X[5] = x12;
+    X[6] = x20; X[7] = x21; X[8] = x22;
+}
+
+// gaussEvaluate, logflag = 0 (fastslam2.cpp:127-163).  The reference solves Sc*nin = v with a JacobiSVD
+// pseudo-inverse; Sc is lower triangular so forward substitution gives the same nin to rounding.
+// C = (2*pi)^(D/2) * prod(diag) with INTEGER D/2 => (2*pi)^1 for D = 2 and D = 3 (:152).
+SLAM_DEV float gauss2(float v0, float v1, float s00, float s10, float s11) {
+    L2 L = llt2(s00, s10, s11);
+    float n0 = v0 / L.l00;
+    float n1 = (v1 - L.l10 * n0) / L.l11;
+    float E = n0 * n0;
+    E += n1 * n1;
+    E = -0.5f * E;
+    float prod = (1.0f * L.l00) * L.l11;
+    float C = (float) ((2 * kPi) * (double) prod);
+    return expf(E) / C;
+}
+
+SLAM_DEV float gauss3(float v0, float v1, float v2, float a00, float a10, float a11, float a20, float a21, float a22) {
+    L3 L = llt3(a00, a10, a11, a20, a21, a22);
+    float n0 = v0 / L.l00;
+    float n1 = (v1 - L.l10 * n0) / L.l11;
+    float n2 = (v2 - (L.l20 * n0 + L.l21 * n1)) / L.l22;
+    float E = n0 * n0;
+    E += n1 * n1;
+    E += n2 * n2;
+    E = -0.5f * E;
+    float prod = ((1.0f * L.l00) * L.l11) * L.l22;
+    float C = (float) ((2 * kPi) * (double) prod);
+    return expf(E) / C;
+}
+
+// choleskyUpdate for a 2x2 landmark (core.cpp:275-291).  P symmetric-packed in/out (p00,p10,p11).
+SLAM_DEV void cholesky_update2(float &fx, float &fy, float &p00, float &p10, float &p11, float v0, float v1, float r00,
+                               float r01, float r10, float r11, float h00, float h01, float h10, float h11) {
+    float p01 = p10;
+    // PHt = P * H^T
+    float a00 = p00 * h00 + p01 * h01, a01 = p00 * h10 + p01 * h11;
+    float a10 = p10 * h00 + p11 * h01, a11 = p10 * h10 + p11 * h11;
+    // S = H * PHt + R
+    float s00 = (h00 * a00 + h01 * a10) + r00, s01 = (h00 * a01 + h01 * a11) + r01;
+    float s10 = (h10 * a00 + h11 * a10) + r10, s11 = (h10 * a01 + h11 * a11) + r11;
+    // S = (S + S^T) * 0.5 evaluated in place: only the lower triangle feeds the LLT (see oracle note)
+    float t00 = (s00 + s00) * 0.5f, t10 = (s10 + s01) * 0.5f, t11 = (s11 + s11) * 0.5f;
+    L2 L = llt2(t00, t10, t11);
+    // SChol = U = L^T ; SCholInv = U.inverse() (PartialPivLU of an upper-triangular matrix: no swap)
+    float i00, i01, i10, i11;
+    inverse2(L.l00, L.l10, 0.0f, L.l11, i00, i01, i10, i11);
+    // W1 = PHt * SCholInv ; W = W1 * SCholInv^T
+    float w100 = a00 * i00 + a01 * i10, w101 = a00 * i01 + a01 * i11;
+    float w110 = a10 * i00 + a11 * i10, w111 = a10 * i01 + a11 * i11;
+    float w00 = w100 * i00 + w101 * i01, w01 = w100 * i10 + w101 * i11;
+    float w10 = w110 * i00 + w111 * i01, w11 = w110 * i10 + w111 * i11;
+    fx = fx + (w00 * v0 + w01 * v1);
+    fy = fy + (w10 * v0 + w11 * v1);
+    p00 = p00 - (w100 * w100 + w101 * w101);
+    p10 = p10 - (w110 * w100 + w111 * w101);
+    p11 = p11 - (w110 * w110 + w111 * w111);
+}
+
+// addFeature for one new observation (core.cpp:488-501), R general 2x2.
+SLAM_DEV void add_feature(float x, float y, float th, float r, float b, float r00, float r01, float r10, float r11,
+                          float &fx, float &fy, float &p00, float &p10, float &p11) {
+    float s = sinf(th + b);
+    float c = cosf(th + b);
+    fx = x + r * c;
+    fy = y + r * s;
+    float g00 = c, g01 = -r * s, g10 = s, g11 = r * c;
+    float t00 = g00 * r00 + g01 * r10, t01 = g00 * r01 + g01 * r11;
+    float t10 = g10 * r00 + g11 * r10, t11 = g10 * r01 + g11 * r11;
+    p00 = t00 * g00 + t01 * g01;
+    p10 = t10 * g00 + t11 * g01;
+    p11 = t10 * g10 + t11 * g11;
+}
+
+// multivariateGauss(x, P, 1) for D = 3 (core.cpp:452-458): L*g + x with L = P.llt().matrixL().
+SLAM_DEV void mvgauss3(float &x0, float &x1, float &x2, const L3 &L, float g0, float g1, float g2) {
+    float s0 = (L.l00 * g0 + 0.0f * g1) + 0.0f * g2;
+    float s1 = (L.l10 * g0 + L.l11 * g1) + 0.0f * g2;
+    float s2 = (L.l20 * g0 + L.l21 * g1) + L.l22 * g2;
+    x0 = s0 + x0;
+    x1 = s1 + x1;
+    x2 = s2 + x2;
+}
+
+// ---- Philox4x32-10, identical to oracle/slam_oracle.c:orc_philox4x32 --------------------------------
+struct U4 {
+    uint32_t x, y, z, w;
+};
+
+SLAM_DEV U4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t) 0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t) 0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t) (p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t) p1;
+        uint32_t n2 = (uint32_t) (p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t) p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return U4{c0, c1, c2, c3};
+}
+
+SLAM_DEV float u01(uint32_t x) { return ((float) (x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+// Same pairing as nRandMat::randn(3,1) (core.cpp:401-416): (u0,u1) -> g0 (sin), g1 (cos); (u2,u3) -> g2 (sin)
+SLAM_DEV void box_muller3(U4 r, float &g0, float &g1, float &g2) {
+    float amp = sqrtf(-2.0f * logf(u01(r.x)));
+    float ang = 6.28318530717958647692f * u01(r.y);
+    g0 = amp * sinf(ang);
+    g1 = amp * cosf(ang);
+    amp = sqrtf(-2.0f * logf(u01(r.z)));
+    ang = 6.28318530717958647692f * u01(r.w);
+    g2 = amp * sinf(ang);
+}
+
+}  // namespace SLAM_KNS

@@ -1,0 +1,599 @@
+// libslamgpu.so — C ABI over the gfx950 kernels (include/slamgpu.h).  Host side only: owns the device
+// buffers, the HIP stream, the pinned staging rings and the lazy predict queue.  No CPU compute path:
+// if there is no usable GPU every entry point fails with SLAMGPU_ERR_NO_DEVICE.
+#include "../../include/slamgpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+using namespace slamgpu;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(SLAMGPU_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+constexpr int kRing = 64;  // packet / tape staging slots
+
+struct EventPair {
+    hipEvent_t a, b;
+};
+
+struct KernelStat {
+    std::vector<EventPair> pending;
+    double ms = 0;
+    int64_t launches = 0;
+};
+
+}  // namespace
+
+struct slamgpu_ctx {
+    slamgpu_config cfg{};
+    const KernelTable *k = nullptr;
+    hipStream_t stream = nullptr;
+    Buffers B{};
+    WeightScratch ws{};
+    double *est_partials = nullptr;
+    int est_blocks = 0;
+    int nf = 0;
+    uint32_t obs_step = 0, ctl_step = 0;
+    // packet ring
+    size_t pkt_bytes = 0;
+    char *pkt_host = nullptr;  // pinned [kRing][pkt_bytes]
+    char *pkt_dev = nullptr;
+    hipEvent_t pkt_ev[kRing]{};
+    bool pkt_ev_used[kRing]{};
+    uint64_t pkt_seq = 0;
+    // tape staging (TAPE mode)
+    float *tape_host = nullptr;  // pinned: normals [3][ncap] (or predict [2][ncap]) + strata [n_global]
+    float *normals_dev = nullptr;
+    float *strata_dev = nullptr;
+    // lazy predict queue
+    PredictArgs pending{};
+    // host mirror of ctrl for readback
+    Ctrl *ctrl_host = nullptr;  // pinned
+    // profiling
+    bool profile = false;
+    std::map<std::string, KernelStat> stats;
+    std::vector<hipEvent_t> ev_pool;
+    double predict_bytes = 0;
+    double *bytes_dev = nullptr;  // [0] = accumulated algorithmic update bytes (device side, needs the resample flag)
+};
+
+namespace {
+
+int64_t n_global(const slamgpu_ctx *c) { return c->cfg.n_particles_global > 0 ? c->cfg.n_particles_global : c->cfg.n_particles; }
+
+hipEvent_t get_event(slamgpu_ctx *c) {
+    if (!c->ev_pool.empty()) {
+        hipEvent_t e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+struct Timed {
+    slamgpu_ctx *c;
+    KernelStat *st = nullptr;
+    EventPair ep{};
+    Timed(slamgpu_ctx *ctx, const char *name) : c(ctx) {
+        if (!c->profile) return;
+        st = &c->stats[name];
+        ep.a = get_event(c);
+        ep.b = get_event(c);
+        if (ep.a) hipEventRecord(ep.a, c->stream);
+    }
+    ~Timed() {
+        if (!st) return;
+        if (ep.b) hipEventRecord(ep.b, c->stream);
+        st->pending.push_back(ep);
+        st->launches++;
+    }
+};
+
+void drain_stats(slamgpu_ctx *c) {
+    for (auto &kv : c->stats) {
+        for (auto &ep : kv.second.pending) {
+            float ms = 0;
+            if (ep.a && ep.b && hipEventSynchronize(ep.b) == hipSuccess && hipEventElapsedTime(&ms, ep.a, ep.b) == hipSuccess)
+                kv.second.ms += ms;
+            if (ep.a) c->ev_pool.push_back(ep.a);
+            if (ep.b) c->ev_pool.push_back(ep.b);
+        }
+        kv.second.pending.clear();
+    }
+}
+
+RngArgs rng_args(const slamgpu_ctx *c, uint32_t step) {
+    RngArgs r{};
+    r.mode = c->cfg.rng_mode;
+    r.step = step;
+    r.k0 = (uint32_t) c->cfg.seed;
+    r.k1 = (uint32_t) (c->cfg.seed >> 32);
+    r.first_particle = c->cfg.first_particle;
+    r.n_global = n_global(c);
+    r.normals = c->normals_dev;
+    r.strata = c->strata_dev;
+    return r;
+}
+
+int flush_predict(slamgpu_ctx *c) {
+    if (c->pending.nsteps == 0) return 0;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    {
+        Timed t(c, "predict");
+        c->k->predict(c->stream, c->B, c->pending, rng_args(c, 0));
+    }
+    HIP_TRY(hipGetLastError());
+    // algorithmic bytes: xv + Pv read and written once per particle-predict (72 B)
+    c->predict_bytes += 72.0 * c->cfg.n_particles * c->pending.nsteps;
+    c->pending.nsteps = 0;
+    return 0;
+}
+
+int check_ctx(slamgpu_ctx *c) {
+    if (!c) return fail(SLAMGPU_ERR_INVALID, "null context");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *slamgpu_last_error(void) { return g_err; }
+int slamgpu_abi_version(void) { return SLAMGPU_ABI_VERSION; }
+
+int slamgpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
+    if (!cfg || !out) return fail(SLAMGPU_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(slamgpu_config))
+        return fail(SLAMGPU_ERR_INVALID, "slamgpu_config.struct_size %u != %zu (ABI mismatch)", cfg->struct_size, sizeof(slamgpu_config));
+    if (cfg->n_particles <= 0 || cfg->max_landmarks < 0) return fail(SLAMGPU_ERR_INVALID, "bad sizes");
+    if (cfg->method != SLAMGPU_FASTSLAM1 && cfg->method != SLAMGPU_FASTSLAM2)
+        return fail(SLAMGPU_ERR_INVALID, "method must be SLAMGPU_FASTSLAM1 or SLAMGPU_FASTSLAM2 (EKF1 runs on the host)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(SLAMGPU_ERR_NO_DEVICE, "no HIP device: libslamgpu has no CPU fallback");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(SLAMGPU_ERR_INVALID, "device %d out of range (%d devices)", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+
+    slamgpu_ctx *c = new slamgpu_ctx();
+    c->cfg = *cfg;
+    if (c->cfg.n_particles_global <= 0) c->cfg.n_particles_global = c->cfg.n_particles;
+    c->k = cfg->math_mode == SLAMGPU_MATH_FAST ? kernels_fast() : kernels_strict();
+    const int n = cfg->n_particles;
+    const int ncap = ((n + 255) / 256) * 256;
+    const int cap_nf = cfg->max_landmarks > 0 ? cfg->max_landmarks : 1;
+    c->B.n = n;
+    c->B.ncap = ncap;
+    c->B.cap_nf = cap_nf;
+#define CTX_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            int rc_ = fail(e_ == hipErrorOutOfMemory ? SLAMGPU_ERR_ALLOC : SLAMGPU_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+            slamgpu_destroy(c);                                                                        \
+            return rc_;                                                                                \
+        }                                                                                              \
+    } while (0)
+    CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t pose_bytes = sizeof(float) * kPoseRows * (size_t) ncap;
+    const size_t lmk_bytes = sizeof(float) * kLmkRows * (size_t) cap_nf * (size_t) ncap;
+    for (int b = 0; b < 2; b++) {
+        CTX_TRY(hipMalloc((void **) &c->B.pose[b], pose_bytes));
+        CTX_TRY(hipMalloc((void **) &c->B.lmk[b], lmk_bytes));
+        CTX_TRY(hipMemsetAsync(c->B.pose[b], 0, pose_bytes, c->stream));
+        CTX_TRY(hipMemsetAsync(c->B.lmk[b], 0, lmk_bytes, c->stream));
+    }
+    CTX_TRY(hipMalloc((void **) &c->B.ctrl, sizeof(Ctrl)));
+    CTX_TRY(hipHostMalloc((void **) &c->ctrl_host, sizeof(Ctrl), hipHostMallocDefault));
+    memset(c->ctrl_host, 0, sizeof(Ctrl));
+    c->ctrl_host->inv_n = 1.0f / (float) n_global(c);  // core.cpp:745
+    CTX_TRY(hipMemcpyAsync(c->B.ctrl, c->ctrl_host, sizeof(Ctrl), hipMemcpyHostToDevice, c->stream));
+    // weight scratch
+    c->ws.nwaves = ncap / kWave;
+    CTX_TRY(hipMalloc((void **) &c->ws.lcum, sizeof(float) * (size_t) ncap));
+    CTX_TRY(hipMalloc((void **) &c->ws.wave_w, sizeof(float) * (size_t) c->ws.nwaves));
+    CTX_TRY(hipMalloc((void **) &c->ws.wave_w2, sizeof(float) * (size_t) c->ws.nwaves));
+    CTX_TRY(hipMalloc((void **) &c->ws.wave_off, sizeof(double) * ((size_t) c->ws.nwaves + 1)));
+    CTX_TRY(hipMalloc((void **) &c->ws.keep, sizeof(int32_t) * (size_t) ncap));
+    CTX_TRY(hipMemsetAsync(c->ws.keep, 0, sizeof(int32_t) * (size_t) ncap, c->stream));
+    c->est_blocks = (n + 255) / 256;
+    CTX_TRY(hipMalloc((void **) &c->est_partials, sizeof(double) * 4 * (size_t) c->est_blocks + 16));
+    CTX_TRY(hipMemsetAsync(c->est_partials, 0, sizeof(double) * 4 * (size_t) c->est_blocks + 16, c->stream));
+    CTX_TRY(hipMalloc((void **) &c->bytes_dev, sizeof(double) * 2));
+    CTX_TRY(hipMemsetAsync(c->bytes_dev, 0, sizeof(double) * 2, c->stream));
+    // packet ring: header + idf[cap] + zf[2cap] + zn[2cap]
+    c->pkt_bytes = ((sizeof(ObsPacket) + sizeof(int32_t) * cap_nf + sizeof(float) * 4 * cap_nf) + 255) / 256 * 256;
+    CTX_TRY(hipHostMalloc((void **) &c->pkt_host, c->pkt_bytes * kRing, hipHostMallocDefault));
+    CTX_TRY(hipMalloc((void **) &c->pkt_dev, c->pkt_bytes * kRing));
+    for (int i = 0; i < kRing; i++) CTX_TRY(hipEventCreateWithFlags(&c->pkt_ev[i], hipEventDisableTiming));
+    if (cfg->rng_mode == SLAMGPU_RNG_TAPE) {
+        const size_t tape_floats = 3 * (size_t) ncap + (size_t) n_global(c);
+        CTX_TRY(hipHostMalloc((void **) &c->tape_host, sizeof(float) * tape_floats, hipHostMallocDefault));
+        CTX_TRY(hipMalloc((void **) &c->normals_dev, sizeof(float) * 3 * (size_t) ncap));
+        CTX_TRY(hipMalloc((void **) &c->strata_dev, sizeof(float) * (size_t) n_global(c)));
+    }
+    // initial particle set: Particle() then w = 1/N (ParticleSLAMWrapper.cpp:14-25)
+    {
+        std::vector<float> w((size_t) ncap, 0.0f);
+        const float uw = (float) (1.0 / (float) n_global(c));
+        for (int i = 0; i < n; i++) w[i] = uw;
+        CTX_TRY(hipMemcpyAsync(c->B.pose[0] + 9 * (size_t) ncap, w.data(), sizeof(float) * (size_t) ncap, hipMemcpyHostToDevice, c->stream));
+        CTX_TRY(hipStreamSynchronize(c->stream));
+    }
+#undef CTX_TRY
+    *out = c;
+    return 0;
+}
+
+void slamgpu_destroy(slamgpu_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->cfg.device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    drain_stats(c);
+    for (auto e : c->ev_pool) hipEventDestroy(e);
+    for (int b = 0; b < 2; b++) {
+        if (c->B.pose[b]) hipFree(c->B.pose[b]);
+        if (c->B.lmk[b]) hipFree(c->B.lmk[b]);
+    }
+    if (c->B.ctrl) hipFree(c->B.ctrl);
+    if (c->ctrl_host) hipHostFree(c->ctrl_host);
+    if (c->ws.lcum) hipFree(c->ws.lcum);
+    if (c->ws.wave_w) hipFree(c->ws.wave_w);
+    if (c->ws.wave_w2) hipFree(c->ws.wave_w2);
+    if (c->ws.wave_off) hipFree(c->ws.wave_off);
+    if (c->ws.keep) hipFree(c->ws.keep);
+    if (c->est_partials) hipFree(c->est_partials);
+    if (c->bytes_dev) hipFree(c->bytes_dev);
+    if (c->pkt_host) hipHostFree(c->pkt_host);
+    if (c->pkt_dev) hipFree(c->pkt_dev);
+    for (int i = 0; i < kRing; i++)
+        if (c->pkt_ev[i]) hipEventDestroy(c->pkt_ev[i]);
+    if (c->tape_host) hipHostFree(c->tape_host);
+    if (c->normals_dev) hipFree(c->normals_dev);
+    if (c->strata_dev) hipFree(c->strata_dev);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int slamgpu_predict(slamgpu_ctx *c, float V, float G, const float Q[4], float dt, float phi_true, const float *noise2) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!Q) return fail(SLAMGPU_ERR_INVALID, "Q is null");
+    const bool noise = c->cfg.add_predict_noise != 0;
+    const bool tape_noise = noise && c->cfg.rng_mode == SLAMGPU_RNG_TAPE;
+    if (tape_noise && !noise2) return fail(SLAMGPU_ERR_INVALID, "TAPE mode with add_predict_noise needs noise2[2N]");
+    PredictArgs &P = c->pending;
+    // parameters must be uniform across a fused launch; flush when they change
+    if (P.nsteps > 0 && (P.dt != dt || memcmp(P.Q, Q, sizeof P.Q) != 0 || P.nsteps == kMaxFusedPredict || tape_noise))
+        if (int rc = flush_predict(c)) return rc;
+    if (P.nsteps == 0) {
+        P.method = c->cfg.method;
+        P.use_heading = c->cfg.use_heading;
+        P.add_noise = noise ? 1 : 0;
+        memcpy(P.Q, Q, sizeof P.Q);
+        P.dt = dt;
+        P.wheel_base = c->cfg.wheel_base;
+        P.sigma_phi = c->cfg.sigma_phi;
+    }
+    c->ctl_step++;
+    PredictStep &s = P.steps[P.nsteps++];
+    s.V = V;
+    s.G = G;
+    s.phi_true = phi_true;
+    s.step = c->ctl_step;
+    if (tape_noise) {
+        HIP_TRY(hipSetDevice(c->cfg.device));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // tape_host is single-buffered (parity mode only)
+        const int n = c->B.n, S = c->B.ncap;
+        for (int i = 0; i < n; i++) {
+            c->tape_host[i] = noise2[2 * i];
+            c->tape_host[S + i] = noise2[2 * i + 1];
+        }
+        HIP_TRY(hipMemcpyAsync(c->normals_dev, c->tape_host, sizeof(float) * 2 * (size_t) S, hipMemcpyHostToDevice, c->stream));
+        return flush_predict(c);
+    }
+    return 0;
+}
+
+int slamgpu_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n,
+                   const float R[4], const float *normals, const float *strata) {
+    if (int rc = check_ctx(c)) return rc;
+    if (m < 0 || n < 0 || !R || (m > 0 && (!zf || !idf)) || (n > 0 && !zn)) return fail(SLAMGPU_ERR_INVALID, "bad observation packet");
+    if (m > c->nf) return fail(SLAMGPU_ERR_INVALID, "m=%d re-observed landmarks but only %d known", m, c->nf);
+    if (c->nf + n > c->B.cap_nf) return fail(SLAMGPU_ERR_CAPACITY, "landmark capacity exceeded: %d + %d > %d", c->nf, n, c->B.cap_nf);
+    for (int k = 0; k < m; k++)
+        if (idf[k] < 0 || idf[k] >= c->nf) return fail(SLAMGPU_ERR_INVALID, "idf[%d]=%d out of range [0,%d)", k, idf[k], c->nf);
+    const bool tape = c->cfg.rng_mode == SLAMGPU_RNG_TAPE;
+    const bool need_normals = c->cfg.method == SLAMGPU_FASTSLAM2 && (m > 0 || n > 0);
+    if (tape && ((need_normals && !normals) || !strata)) return fail(SLAMGPU_ERR_INVALID, "TAPE mode needs normals[3N] and strata[N]");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = flush_predict(c)) return rc;
+    c->obs_step++;
+
+    // observation packet -> ring slot
+    const int slot = (int) (c->pkt_seq++ % kRing);
+    if (c->pkt_ev_used[slot]) HIP_TRY(hipEventSynchronize(c->pkt_ev[slot]));
+    char *ph = c->pkt_host + (size_t) slot * c->pkt_bytes;
+    ObsPacket *hp = reinterpret_cast<ObsPacket *>(ph);
+    hp->m = m;
+    hp->n = n;
+    hp->nf = c->nf;
+    hp->pad = 0;
+    memcpy(hp->R, R, sizeof hp->R);
+    int32_t *hidf = reinterpret_cast<int32_t *>(hp + 1);
+    float *hzf = reinterpret_cast<float *>(hidf + m);
+    float *hzn = hzf + 2 * m;
+    if (m) {
+        memcpy(hidf, idf, sizeof(int32_t) * m);
+        memcpy(hzf, zf, sizeof(float) * 2 * m);
+    }
+    if (n) memcpy(hzn, zn, sizeof(float) * 2 * n);
+    const size_t used = sizeof(ObsPacket) + sizeof(int32_t) * m + sizeof(float) * 2 * (m + n);
+    char *pd = c->pkt_dev + (size_t) slot * c->pkt_bytes;
+    HIP_TRY(hipMemcpyAsync(pd, ph, used, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->pkt_ev[slot], c->stream));
+    c->pkt_ev_used[slot] = true;
+
+    if (tape) {
+        HIP_TRY(hipStreamSynchronize(c->stream));  // single-buffered tape staging (parity mode)
+        const int N = c->B.n, S = c->B.ncap;
+        if (need_normals) {
+            for (int i = 0; i < N; i++) {
+                c->tape_host[i] = normals[3 * i];
+                c->tape_host[S + i] = normals[3 * i + 1];
+                c->tape_host[2 * S + i] = normals[3 * i + 2];
+            }
+            HIP_TRY(hipMemcpyAsync(c->normals_dev, c->tape_host, sizeof(float) * 3 * (size_t) S, hipMemcpyHostToDevice, c->stream));
+        }
+        float *sh = c->tape_host + 3 * (size_t) S;
+        memcpy(sh, strata, sizeof(float) * (size_t) n_global(c));
+        HIP_TRY(hipMemcpyAsync(c->strata_dev, sh, sizeof(float) * (size_t) n_global(c), hipMemcpyHostToDevice, c->stream));
+    }
+
+    const RngArgs rng = rng_args(c, c->obs_step);
+    {
+        Timed t(c, c->cfg.method == SLAMGPU_FASTSLAM2 ? "fs2_update" : "fs1_update");
+        c->k->update(c->stream, c->B, c->cfg.method, reinterpret_cast<const ObsPacket *>(pd), m, n, c->nf, rng, c->ws);
+    }
+    {
+        Timed t(c, "weights_finalize");
+        c->k->finalize(c->stream, c->B, c->ws, c->cfg.resample, c->cfg.n_effective);
+    }
+    c->nf += n;
+    {
+        Timed t(c, "resample");
+        c->k->resample(c->stream, c->B, c->ws, rng, c->nf);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int read_ctrl(slamgpu_ctx *c) {
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = flush_predict(c)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->ctrl_host, c->B.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int slamgpu_estimate(slamgpu_ctx *c, double xyt[3]) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!xyt) return fail(SLAMGPU_ERR_INVALID, "null output");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = flush_predict(c)) return rc;
+    {
+        Timed t(c, "estimate");
+        c->k->estimate(c->stream, c->B, c->est_partials, c->est_blocks);
+    }
+    HIP_TRY(hipGetLastError());
+    if (int rc = read_ctrl(c)) return rc;
+    xyt[0] = c->ctrl_host->est[0] / (double) c->B.n;
+    xyt[1] = c->ctrl_host->est[1] / (double) c->B.n;
+    xyt[2] = c->ctrl_host->est[2];
+    return 0;
+}
+
+int slamgpu_stats(slamgpu_ctx *c, float *neff, int32_t *resampled, double *weight_sum) {
+    if (int rc = check_ctx(c)) return rc;
+    if (int rc = read_ctrl(c)) return rc;
+    if (neff) *neff = c->ctrl_host->neff;
+    if (resampled) *resampled = c->ctrl_host->resampled;
+    if (weight_sum) *weight_sum = c->ctrl_host->wsum;
+    return 0;
+}
+
+int slamgpu_ancestors(slamgpu_ctx *c, int32_t *keep) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!keep) return fail(SLAMGPU_ERR_INVALID, "null output");
+    if (int rc = read_ctrl(c)) return rc;
+    if (!c->ctrl_host->resampled) {
+        for (int i = 0; i < c->B.n; i++) keep[i] = i;
+        return 0;
+    }
+    HIP_TRY(hipMemcpy(keep, c->ws.keep, sizeof(int32_t) * (size_t) c->B.n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int slamgpu_num_landmarks(slamgpu_ctx *c) { return c ? c->nf : SLAMGPU_ERR_INVALID; }
+
+int slamgpu_sync(slamgpu_ctx *c) {
+    if (int rc = check_ctx(c)) return rc;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = flush_predict(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int slamgpu_download(slamgpu_ctx *c, float *xv, float *Pv9, float *w, float *xf, float *Pf4) {
+    if (int rc = check_ctx(c)) return rc;
+    if (int rc = read_ctrl(c)) return rc;
+    const int cur = c->ctrl_host->cur, N = c->B.n, nf = c->nf;
+    const size_t S = (size_t) c->B.ncap;
+    std::vector<float> pose((size_t) kPoseRows * S);
+    HIP_TRY(hipMemcpy(pose.data(), c->B.pose[cur], sizeof(float) * pose.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < N; i++) {
+        if (xv)
+            for (int k = 0; k < 3; k++) xv[3 * i + k] = pose[k * S + i];
+        if (Pv9) {
+            const float p00 = pose[3 * S + i], p10 = pose[4 * S + i], p11 = pose[5 * S + i], p20 = pose[6 * S + i],
+                        p21 = pose[7 * S + i], p22 = pose[8 * S + i];
+            float *P = Pv9 + 9 * (size_t) i;
+            P[0] = p00; P[1] = p10; P[2] = p20;
+            P[3] = p10; P[4] = p11; P[5] = p21;
+            P[6] = p20; P[7] = p21; P[8] = p22;
+        }
+        if (w) w[i] = pose[9 * S + i];
+    }
+    if ((xf || Pf4) && nf > 0) {
+        std::vector<float> lm((size_t) kLmkRows * nf * S);
+        HIP_TRY(hipMemcpy(lm.data(), c->B.lmk[cur], sizeof(float) * lm.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < N; i++)
+            for (int j = 0; j < nf; j++) {
+                const float *b = lm.data() + (size_t) j * kLmkRows * S + i;
+                if (xf) {
+                    xf[((size_t) i * nf + j) * 2] = b[0];
+                    xf[((size_t) i * nf + j) * 2 + 1] = b[S];
+                }
+                if (Pf4) {
+                    float *P = Pf4 + ((size_t) i * nf + j) * 4;
+                    P[0] = b[2 * S];
+                    P[1] = b[3 * S];
+                    P[2] = b[3 * S];
+                    P[3] = b[4 * S];
+                }
+            }
+    }
+    return 0;
+}
+
+int slamgpu_upload(slamgpu_ctx *c, int32_t nf, const float *xv, const float *Pv9, const float *w, const float *xf,
+                   const float *Pf4) {
+    if (int rc = check_ctx(c)) return rc;
+    if (nf < 0 || nf > c->B.cap_nf) return fail(SLAMGPU_ERR_CAPACITY, "nf=%d exceeds capacity %d", nf, c->B.cap_nf);
+    if (int rc = read_ctrl(c)) return rc;
+    const int cur = c->ctrl_host->cur, N = c->B.n;
+    const size_t S = (size_t) c->B.ncap;
+    std::vector<float> pose((size_t) kPoseRows * S);
+    HIP_TRY(hipMemcpy(pose.data(), c->B.pose[cur], sizeof(float) * pose.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < N; i++) {
+        if (xv)
+            for (int k = 0; k < 3; k++) pose[k * S + i] = xv[3 * i + k];
+        if (Pv9) {  // lower triangle of the reference's full matrix
+            const float *P = Pv9 + 9 * (size_t) i;
+            pose[3 * S + i] = P[0];
+            pose[4 * S + i] = P[3];
+            pose[5 * S + i] = P[4];
+            pose[6 * S + i] = P[6];
+            pose[7 * S + i] = P[7];
+            pose[8 * S + i] = P[8];
+        }
+        if (w) pose[9 * S + i] = w[i];
+    }
+    HIP_TRY(hipMemcpy(c->B.pose[cur], pose.data(), sizeof(float) * pose.size(), hipMemcpyHostToDevice));
+    if (nf > 0) {
+        if (!xf || !Pf4) return fail(SLAMGPU_ERR_INVALID, "nf>0 needs xf and Pf");
+        std::vector<float> lm((size_t) kLmkRows * nf * S, 0.0f);
+        for (int i = 0; i < N; i++)
+            for (int j = 0; j < nf; j++) {
+                float *b = lm.data() + (size_t) j * kLmkRows * S + i;
+                const float *P = Pf4 + ((size_t) i * nf + j) * 4;
+                b[0] = xf[((size_t) i * nf + j) * 2];
+                b[S] = xf[((size_t) i * nf + j) * 2 + 1];
+                b[2 * S] = P[0];
+                b[3 * S] = P[2];
+                b[4 * S] = P[3];
+            }
+        HIP_TRY(hipMemcpy(c->B.lmk[cur], lm.data(), sizeof(float) * lm.size(), hipMemcpyHostToDevice));
+    }
+    c->nf = nf;
+    return 0;
+}
+
+void *slamgpu_stream(slamgpu_ctx *c) { return c ? (void *) c->stream : nullptr; }
+
+int slamgpu_profile(slamgpu_ctx *c, int32_t enable) {
+    if (int rc = check_ctx(c)) return rc;
+    if (int rc = slamgpu_sync(c)) return rc;
+    drain_stats(c);
+    c->profile = enable != 0;
+    return 0;
+}
+
+int slamgpu_kernel_time(slamgpu_ctx *c, const char *kernel, double *ms, int64_t *launches) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!kernel) return fail(SLAMGPU_ERR_INVALID, "null kernel name");
+    if (int rc = slamgpu_sync(c)) return rc;
+    drain_stats(c);
+    auto it = c->stats.find(kernel);
+    if (ms) *ms = it == c->stats.end() ? 0.0 : it->second.ms;
+    if (launches) *launches = it == c->stats.end() ? 0 : it->second.launches;
+    return 0;
+}
+
+int slamgpu_algorithmic_bytes(slamgpu_ctx *c, double *update_bytes, double *predict_bytes) {
+    if (int rc = check_ctx(c)) return rc;
+    if (update_bytes) *update_bytes = 0;  // accounted by the harness from (m, n, nf, resampled) per step
+    if (predict_bytes) *predict_bytes = c->predict_bytes;
+    return 0;
+}
+
+// ---- Seam 1 -----------------------------------------------------------------------------------------
+int slamgpu_jacobians(const float *in, uint32_t n, float *out) {
+    if (!in || (n > 0 && !out)) return fail(SLAMGPU_ERR_INVALID, "null buffer");
+    if (n == 0) return 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SLAMGPU_ERR_NO_DEVICE, "no HIP device: libslamgpu has no CPU fallback");
+    float *din = nullptr, *dout = nullptr;
+    const size_t nin = 7 + 6 * (size_t) n, nout = 16 * (size_t) n;
+    HIP_TRY(hipMalloc((void **) &din, sizeof(float) * nin));
+    hipError_t e = hipMalloc((void **) &dout, sizeof(float) * nout);
+    if (e != hipSuccess) {
+        hipFree(din);
+        return fail(SLAMGPU_ERR_ALLOC, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    int rc = 0;
+    if ((e = hipMemcpy(din, in, sizeof(float) * nin, hipMemcpyHostToDevice)) != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "H2D: %s", hipGetErrorString(e));
+    if (!rc) {
+        kernels_strict()->jacobians(nullptr, din, n, dout);
+        if ((e = hipGetLastError()) != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "launch: %s", hipGetErrorString(e));
+    }
+    if (!rc && (e = hipMemcpy(out, dout, sizeof(float) * nout, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "D2H: %s", hipGetErrorString(e));
+    hipFree(din);
+    hipFree(dout);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,167 @@
+"""ctypes binding of include/slamhost.h (libslamhost.so): config / map / vehicle+sensor simulator / known data
+association / libc-rand tape — the host-side front end around the hot path."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+DECLARED_SYMBOLS = [
+    "slamhost_last_error", "slamhost_sim_create", "slamhost_sim_destroy", "slamhost_sim_conf", "slamhost_sim_map",
+    "slamhost_sim_control", "slamhost_sim_observe", "slamhost_sim_last_z", "slamhost_sim_true",
+    "slamhost_sim_control_steps", "slamhost_draw_normals", "slamhost_draw_strata", "slamhost_unif_rand",
+    "slamhost_synthetic_landmarks", "slamhost_write_map",
+]
+
+
+class HostConf(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("V", "MAXG", "RATEG", "WHEELBASE", "DT_CONTROLS", "sigmaV", "sigmaG", "MAX_RANGE",
+                                         "DT_OBSERVE", "sigmaR", "sigmaB", "sigmaT", "GATE_REJECT", "GATE_AUGMENT", "AT_WAYPOINT")] + \
+               [(k, C.c_int32) for k in ("NUMBER_LOOPS", "NPARTICLES", "NEFFECTIVE", "SWITCH_CONTROL_NOISE", "SWITCH_SENSOR_NOISE",
+                                         "SWITCH_INFLATE_NOISE", "SWITCH_PREDICT_NOISE", "SWITCH_SAMPLE_PROPOSAL", "SWITCH_HEADING_KNOWN",
+                                         "SWITCH_RESAMPLE", "SWITCH_PROFILE", "SWITCH_SEED_RANDOM", "SWITCH_ASSOCIATION_KNOWN",
+                                         "SWITCH_BATCH_UPDATE", "SWITCH_USE_IEKF", "method", "n_landmarks", "n_waypoints")] + \
+               [("Q", C.c_float * 4), ("R", C.c_float * 4), ("Qe", C.c_float * 4), ("Re", C.c_float * 4)]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libslamhost.so")
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise RuntimeError("%s not built: run __graft_entry__.build()" % p)
+        L = C.CDLL(p)
+        L.slamhost_last_error.restype = C.c_char_p
+        L.slamhost_sim_create.restype = C.c_void_p
+        L.slamhost_sim_create.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+        L.slamhost_sim_destroy.argtypes = [C.c_void_p]
+        L.slamhost_sim_destroy.restype = None
+        L.slamhost_sim_conf.argtypes = [C.c_void_p, C.POINTER(HostConf)]
+        L.slamhost_sim_map.argtypes = [C.c_void_p] * 3
+        L.slamhost_sim_control.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.slamhost_sim_observe.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32)]
+        L.slamhost_sim_last_z.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+        L.slamhost_sim_true.argtypes = [C.c_void_p, C.c_void_p]
+        L.slamhost_sim_true.restype = None
+        L.slamhost_sim_control_steps.argtypes = [C.c_void_p]
+        L.slamhost_sim_control_steps.restype = C.c_int64
+        L.slamhost_draw_normals.argtypes = [C.c_int32, C.c_int32, C.c_void_p]
+        L.slamhost_draw_normals.restype = None
+        L.slamhost_draw_strata.argtypes = [C.c_int32, C.c_void_p]
+        L.slamhost_unif_rand.restype = C.c_double
+        L.slamhost_synthetic_landmarks.argtypes = [C.c_uint64, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.slamhost_synthetic_landmarks.restype = None
+        L.slamhost_write_map.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def draw_normals(count, dim):
+    out = np.zeros((count, dim), np.float32)
+    load_library().slamhost_draw_normals(count, dim, _p(out))
+    return out
+
+
+def draw_strata(N):
+    out = np.zeros(N, np.float32)
+    cnt = load_library().slamhost_draw_strata(N, _p(out))
+    return cnt, out
+
+
+def synthetic_landmarks(seed, n, x0, x1, y0, y1):
+    lm = np.zeros((2, n), np.float32)
+    load_library().slamhost_synthetic_landmarks(seed, n, x0, x1, y0, y1, _p(lm))
+    return lm
+
+
+def write_map(path, lm, wp):
+    lm = np.ascontiguousarray(lm, np.float32)
+    wp = np.ascontiguousarray(wp, np.float32)
+    rc = load_library().slamhost_write_map(path.encode(), _p(lm), lm.shape[1], _p(wp), wp.shape[1])
+    if rc != 0:
+        raise RuntimeError("slamhost_write_map failed for %s" % path)
+
+
+class HostSim:
+    """The simulator SLAMWrapper::control() + the observation front end (slam-backend CLI arguments)."""
+
+    def __init__(self, args):
+        self.L = load_library()
+        arr = (C.c_char_p * (len(args) + 1))(b"slam-backend", *[str(a).encode() for a in args])
+        self._argv = arr
+        h = self.L.slamhost_sim_create(len(args) + 1, arr)
+        if not h:
+            raise RuntimeError("slamhost_sim_create: %s" % self.L.slamhost_last_error().decode())
+        self.h = C.c_void_p(h)
+        self.conf = HostConf()
+        self.L.slamhost_sim_conf(self.h, C.byref(self.conf))
+        self.nlm = self.conf.n_landmarks
+        self._zf = np.zeros((self.nlm, 2), np.float32)
+        self._zn = np.zeros((self.nlm, 2), np.float32)
+        self._idf = np.zeros(self.nlm, np.int32)
+
+    def close(self):
+        if self.h:
+            self.L.slamhost_sim_destroy(self.h)
+            self.h = None
+
+    def map(self):
+        lm = np.zeros((2, self.nlm), np.float32)
+        wp = np.zeros((2, self.conf.n_waypoints), np.float32)
+        self.L.slamhost_sim_map(self.h, _p(lm), _p(wp))
+        return lm, wp
+
+    def control(self):
+        V, G, phi = C.c_float(), C.c_float(), C.c_float()
+        r = self.L.slamhost_sim_control(self.h, C.byref(V), C.byref(G), C.byref(phi))
+        return r, V.value, G.value, phi.value
+
+    def observe(self, nf_known):
+        m, n = C.c_int32(), C.c_int32()
+        self.L.slamhost_sim_observe(self.h, nf_known, _p(self._zf), _p(self._idf), C.byref(m), _p(self._zn), C.byref(n))
+        return self._zf[:m.value].copy(), self._idf[:m.value].copy(), self._zn[:n.value].copy()
+
+    def true_pose(self):
+        x = np.zeros(3, np.float32)
+        self.L.slamhost_sim_true(self.h, _p(x))
+        return x
+
+    def noise(self):
+        f = lambda a: np.array(list(a), np.float32).reshape(2, 2)
+        return f(self.conf.Qe), f(self.conf.Re), np.float32(self.conf.DT_CONTROLS)
+
+
+def make_tape(args, max_obs=None):
+    """Whole control / observation tape of a run (RNG: libc rand() seeded by SWITCH_SEED_RANDOM for the control and
+    sensor noise only — the particle noise is not drawn here).  Returns a list of observation steps, each with the
+    controls of the predicts that precede it."""
+    sim = HostSim(args)
+    steps, ctl, nf = [], [], 0
+    while True:
+        r, V, G, phi = sim.control()
+        if r < 0:
+            break
+        ctl.append((V, G, phi))
+        if r == 1:
+            zf, idf, zn = sim.observe(nf)
+            steps.append(dict(controls=ctl, zf=zf, idf=idf, zn=zn, nf_before=nf, true=sim.true_pose()))
+            nf += zn.shape[0]
+            ctl = []
+            if max_obs and len(steps) >= max_obs:
+                break
+    Q, R, dt = sim.noise()
+    conf = sim.conf
+    sim.close()
+    return dict(steps=steps, Q=Q, R=R, dt=dt, conf=conf, nlm=conf.n_landmarks, tail_controls=ctl)

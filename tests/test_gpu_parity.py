@@ -1,0 +1,231 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (include/slamgpu.h), against
+ (a) the golden vectors generated from the reference's own objects (tests/golden/), and
+ (b) the oracle on the same seeded inputs (the oracle is bit-pinned to the reference).
+
+Tolerances (float32; the GPU differs from the CPU reference only by device libm, forward substitution
+instead of the JacobiSVD solve inside gaussEvaluate, symmetric-packed covariance storage and the
+parallel (wave-scan) order of the weight sums):
+  pose / landmark means   : 2e-4 absolute (metres / radians) per update from identical pre-state
+                            (measured on MI355X: <= 4e-5, median 0 = bit-identical)
+  covariances             : 1e-3 relative to the matrix scale
+  weights, FastSLAM1      : 1e-3 relative (measured max 1.4e-4)
+  weights, FastSLAM2      : median <= 1e-3, 99th percentile <= 5e-2, max <= 0.3 relative, and total-variation
+                            distance of the normalised weight vectors <= 2e-2.  FastSLAM2's weight multiplies
+                            gaussEvaluate(xv0 - xvs, Pv0) / gaussEvaluate(xv - xvs, Pv) (fastslam2.cpp:360-367) where Pv0,
+                            eight predicts after being zeroed, is nearly rank 2 (upstream TODO at fastslam2.cpp:84):
+                            its float32 Cholesky has l22 ~ 1e-3, so a 1e-6 m difference in the sampled pose (one ulp
+                            of atan2f upstream) moves the weight by ~1e-2.  The reference's own float32 value is
+                            up to 26 % away from a float64 evaluation of the same formula (tools note in DESIGN.md),
+                            so a tighter bound would test rounding noise, not the kernel.  Measured: median 1.4e-4,
+                            p99 1.1e-2, max 7.4e-2.
+  Neff                    : 2e-2 relative (FastSLAM1: 1e-4);  resample decision identical
+  ancestors               : follow from the weights: <= 4 % of particles may pick a neighbouring ancestor
+                            (FastSLAM1: identical)
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, sim_args
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+RM = np.array([[0.1 ** 2, 0], [0, 0.017453292519943 ** 2]], f32)
+
+POSE_ATOL = 2e-4
+COV_RTOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def sg():
+    import slam_amd
+    assert slam_amd.device_count() >= 1, "GPU tests need a HIP device"
+    return slam_amd
+
+
+def close_cov(a, b, rtol=COV_RTOL):
+    scale = max(np.abs(b).max(), 1e-12)
+    return np.abs(a.astype(np.float64) - b.astype(np.float64)).max() <= rtol * scale
+
+
+def sym(P):
+    """GPU storage is symmetric-packed (lower triangle); compare against the reference's lower triangle mirrored."""
+    L = np.tril(P)
+    return L + np.swapaxes(np.tril(P, -1), -1, -2)
+
+
+def compare_weights(got, exp, fs2, tag=""):
+    rel = np.abs(got.astype(np.float64) / exp.astype(np.float64) - 1.0)
+    if not fs2:
+        assert rel.max() <= 1e-3, (tag, rel.max())
+        return
+    assert np.median(rel) <= 1e-3 and np.quantile(rel, 0.99) <= 5e-2 and rel.max() <= 0.3, (tag, np.median(rel), rel.max())
+    pg, pe = got.astype(np.float64) / got.sum(dtype=np.float64), exp.astype(np.float64) / exp.sum(dtype=np.float64)
+    assert 0.5 * np.abs(pg - pe).sum() <= 2e-2, (tag, "TV distance", 0.5 * np.abs(pg - pe).sum())
+
+
+def compare_state(got, exp, fs2=True, tag=""):
+    assert got["nf"] == exp["xf"].shape[1], tag
+    assert np.abs(got["xv"] - exp["xv"]).max() <= POSE_ATOL, (tag, np.abs(got["xv"] - exp["xv"]).max())
+    assert close_cov(got["Pv"], sym(exp["Pv"])), (tag, "Pv")
+    compare_weights(got["w"], exp["w"], fs2, tag)
+    if got["nf"]:
+        assert np.abs(got["xf"] - exp["xf"]).max() <= POSE_ATOL * 5, (tag, np.abs(got["xf"] - exp["xf"]).max())
+        assert close_cov(got["Pf"], sym(exp["Pf"])), (tag, "Pf")
+
+
+def test_jacobians_seam1(sg, kat):
+    """slamgpu_jacobians in the AcceleratorHandler window layout vs the reference's computeJacobians KAT."""
+    n = kat["jac_xv"].shape[0]
+    for i in range(0, n, 7):
+        zp, Hv, Hf, Sf = sg.jacobians(kat["jac_xv"][i], RM, kat["jac_xf"][i:i + 1], kat["jac_Pf"][i:i + 1])
+        np.testing.assert_allclose(zp[0], kat["jac_zp"][i], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(Hv[0], kat["jac_Hv"][i], rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(Hf[0], kat["jac_Hf"][i], rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(Sf[0], kat["jac_Sf"][i], rtol=1e-5, atol=1e-9)
+    # batched: all features against one pose
+    xv = kat["jac_xv"][0]
+    zp, Hv, Hf, Sf = sg.jacobians(xv, RM, kat["jac_xf"], kat["jac_Pf"])
+    assert zp.shape == (n, 2) and np.isfinite(Sf).all()
+
+
+@pytest.mark.parametrize("name,method", [("traj_fs2_webmap_N100_s7", 2), ("traj_fs1_webmap_N100_s7", 1),
+                                         ("traj_fs2_webmap_N1000_s1", 2), ("traj_fs2_loop1_N50_s3", 2)])
+def test_teacher_forced_update_vs_golden(sg, name, method):
+    """Upload the reference's pre-update particle set, run ONE slamgpu_update with the reference's tape,
+    compare with the reference's post-update particle set."""
+    g = load_golden(name)
+    for k in g["snap_steps"]:
+        pre = {key: g["snap%d_pre_%s" % (k, key)] for key in ("xv", "Pv", "w", "xf", "Pf")}
+        exp = {key: g["snap%d_post_%s" % (k, key)] for key in ("xv", "Pv", "w", "xf", "Pf")}
+        N = pre["w"].shape[0]
+        pre["nf"] = pre["xf"].shape[1]
+        s = sg.SlamGpu(N, 40, method=method, n_effective=int(g["meta_n_effective"]), use_heading=bool(g["meta_use_heading"]),
+                       wheel_base=float(g["meta_wheel_base"]), sigma_phi=float(g["meta_sigma_phi"]), rng_mode=sg.RNG_TAPE)
+        s.upload(pre)
+        m, n = g["m"][k - 1], g["n"][k - 1]
+        s.update(g["zf"][k - 1, :m], g["idf"][k - 1, :m], g["zn"][k - 1, :n], g["meta_R"], g["snap%d_normals" % k], g["snap%d_sel" % k])
+        neff, did, wsum = s.stats()
+        assert did == bool(g["resampled"][k - 1]), (name, k)
+        np.testing.assert_allclose(neff, g["neff"][k - 1], rtol=2e-2 if method == 2 else 1e-4)
+        got = s.download()
+        if did:
+            # ancestors may differ at cumulative-sum boundaries: compare through the GPU's own ancestor list
+            keep = s.ancestors()
+            assert np.all(np.diff(keep) >= 0)
+            assert np.allclose(got["w"], 1.0 / N)
+            # reference ancestors recovered from the oracle-free identity: post particle k == some pre particle;
+            # check the bulk of the particles agree with the reference post state
+            bad = np.abs(got["xv"] - exp["xv"]).max(axis=1) > POSE_ATOL
+            assert bad.mean() <= (0.04 if method == 2 else 0.0), (name, k, bad.mean())
+            ok = ~bad
+            assert np.abs(got["xf"][ok] - exp["xf"][ok]).max() <= POSE_ATOL * 5
+        else:
+            compare_state(got, exp, fs2=method == 2, tag="%s step %d" % (name, k))
+        s.close()
+
+
+def test_teacher_forced_predict_vs_golden(sg):
+    for name in ("traj_fs2_webmap_N100_s7", "traj_fs2_loop1_N50_s3"):
+        g = load_golden(name)
+        for c in g["pred_steps"]:
+            xv, Pv = g["pred%d_pre_xv" % c], g["pred%d_pre_Pv" % c]
+            N = xv.shape[0]
+            s = sg.SlamGpu(N, 1, method=2, use_heading=bool(g["meta_use_heading"]), wheel_base=float(g["meta_wheel_base"]),
+                           sigma_phi=float(g["meta_sigma_phi"]))
+            s.upload(dict(nf=0, xv=xv, Pv=Pv, w=np.full(N, 1.0 / N, f32), xf=None, Pf=None))
+            V, G = g["pred%d_VG" % c]
+            s.predict(float(V), float(G), g["meta_Q"], float(g["meta_dt"]), float(g["pred%d_phi" % c][0]))
+            got = s.download(landmarks=False)
+            assert np.abs(got["xv"] - g["pred%d_post_xv" % c]).max() <= 1e-5
+            assert close_cov(got["Pv"], sym(g["pred%d_post_Pv" % c]), 1e-4)
+            s.close()
+
+
+def drive_pair(sg, oracle, mapname, method, N, seed, nobs, math_mode=0, per_step=None):
+    """Run the oracle simulation; feed the GPU context the same controls, observations and RNG tape; at each
+    observation step re-synchronise the GPU state to the oracle's (teacher forcing) after comparing."""
+    from oracle import orc  # noqa: F401  (checker only)
+    o = oracle.sim(sim_args(mapname, method, N, seed))
+    algo = o.algo()
+    Q, R, dt = o.noise()
+    m_id = 2 if method == "FASTSLAM2" else 1
+    s = sg.SlamGpu(N, o.nlm, method=m_id, n_effective=algo.n_effective, use_heading=bool(algo.use_heading),
+                   add_predict_noise=bool(algo.add_predict_noise), wheel_base=algo.wheel_base, sigma_phi=algo.sigma_phi,
+                   rng_mode=sg.RNG_TAPE, math_mode=math_mode)
+    k = 0
+    out = []
+    while k < nobs:
+        a = o.control()
+        assert a >= 0
+        x, vg = o.true_pose()
+        noise2 = None
+        if algo.add_predict_noise:
+            noise2 = o.last_noise2()
+        s.predict(float(vg[0]), float(vg[1]), Q, float(dt), float(x[2]), noise2)
+        if a == 1:
+            o.observe()
+            ob = o.last_obs()
+            normals, sel = o.last_tape()
+            s.update(ob["zf"], ob["idf"], ob["zn"], R, normals, sel)
+            k += 1
+            got = s.download()
+            exp = o.particles()
+            ne_o, did_o = o.last_resample()
+            ne_g, did_g, _ = s.stats()
+            out.append(dict(k=k, got=got, exp=exp, neff=(ne_g, ne_o), did=(did_g, did_o), est=(s.estimate(), o.estimate()),
+                            keep=s.ancestors() if did_g else None, m=ob["zf"].shape[0], n=ob["zn"].shape[0]))
+            if per_step:
+                per_step(out[-1])
+            s.upload(exp)  # teacher forcing: continue from the oracle's state
+    s.close()
+    o.close()
+    return out
+
+
+@pytest.mark.parametrize("method,N,seed,nobs", [("FASTSLAM2", 100, 7, 120), ("FASTSLAM2", 1000, 1, 40),
+                                                ("FASTSLAM1", 100, 7, 60), ("FASTSLAM2", 5000, 12345, 10)])
+def test_stepwise_vs_oracle(sg, oracle, method, N, seed, nobs):
+    def check(r):
+        tag = "%s N=%d obs %d (m=%d n=%d)" % (method, N, r["k"], r["m"], r["n"])
+        assert r["did"][0] == r["did"][1], tag
+        fs2 = method == "FASTSLAM2"
+        np.testing.assert_allclose(r["neff"][0], r["neff"][1], rtol=2e-2 if fs2 else 1e-4, err_msg=tag)
+        if r["did"][0]:
+            bad = np.abs(r["got"]["xv"] - r["exp"]["xv"]).max(axis=1) > POSE_ATOL
+            assert bad.mean() <= (0.04 if fs2 else 0.0), (tag, bad.mean())
+        else:
+            compare_state(r["got"], r["exp"], fs2=fs2, tag=tag)
+        np.testing.assert_allclose(r["est"][0][:2], r["est"][1][:2], atol=5e-4, err_msg=tag)
+    drive_pair(sg, oracle, "example_webmap", method, N, seed, nobs, per_step=check)
+
+
+def test_free_running_statistics(sg, oracle):
+    """Free-running (no teacher forcing) GPU run driven by the oracle front end's controls/observations and tape:
+    trajectories decorrelate after the first differing ancestor, so this checks the filter's behaviour, not bits:
+    the estimated path must track the true path as well as the reference's does."""
+    N, seed = 100, 7
+    o = oracle.sim(sim_args("example_webmap", "FASTSLAM2", N, seed))
+    algo = o.algo()
+    Q, R, dt = o.noise()
+    s = sg.SlamGpu(N, o.nlm, method=2, n_effective=algo.n_effective, wheel_base=algo.wheel_base, rng_mode=sg.RNG_TAPE)
+    err_g, err_o, first_div = [], [], None
+    k = 0
+    while k < 400:
+        a = o.control()
+        x, vg = o.true_pose()
+        s.predict(float(vg[0]), float(vg[1]), Q, float(dt), float(x[2]))
+        if a == 1:
+            o.observe()
+            ob = o.last_obs()
+            normals, sel = o.last_tape()
+            s.update(ob["zf"], ob["idf"], ob["zn"], R, normals, sel)
+            k += 1
+            eg, eo = s.estimate(), o.estimate()
+            err_g.append(np.hypot(eg[0] - x[0], eg[1] - x[1]))
+            err_o.append(np.hypot(eo[0] - x[0], eo[1] - x[1]))
+            if first_div is None and np.hypot(eg[0] - eo[0], eg[1] - eo[1]) > 1e-3:
+                first_div = k
+    s.close()
+    o.close()
+    assert first_div is None or first_div > 3, first_div  # identical (to 1 mm) at least until ancestors first differ
+    assert np.mean(err_g) < 1.5 * np.mean(err_o) + 0.05, (np.mean(err_g), np.mean(err_o))

@@ -1,0 +1,119 @@
+"""The product's own host front end (libslamhost.so: ini/args, map, vehicle + sensor simulator, known data
+association, libc-rand tape) against the golden trajectories of the reference, and C-ABI export checks."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DATA, bits_equal, load_golden, sim_args
+
+
+def test_slamgpu_exports_every_declared_symbol():
+    import re
+    import slam_amd
+    L = slam_amd.load_library()
+    hdr = open(os.path.join(os.path.dirname(DATA), "include", "slamgpu.h")).read()
+    declared = sorted(set(re.findall(r"\b(slamgpu_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared and sorted(slam_amd.DECLARED_SYMBOLS) == declared
+    for s in declared:
+        assert hasattr(L, s), s
+    assert L.slamgpu_abi_version() == 1
+
+
+def test_slamhost_exports_every_declared_symbol():
+    import re
+    from slam_amd import host
+    L = host.load_library()
+    hdr = open(os.path.join(os.path.dirname(DATA), "include", "slamhost.h")).read()
+    declared = sorted(set(re.findall(r"\b(slamhost_[a-z_0-9]+)\s*\(", hdr)))
+    assert sorted(host.DECLARED_SYMBOLS) == declared
+    for s in declared:
+        assert hasattr(L, s), s
+
+
+def test_no_gpu_fails_loudly():
+    """Without a GPU the product refuses to run (no CPU fallback) and reports through the C ABI error channel."""
+    import slam_amd
+    if slam_amd.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(slam_amd.SlamGpuError) as e:
+        slam_amd.SlamGpu(100, 35)
+    assert e.value.code == -4 and "no CPU fallback" in str(e.value)
+
+
+def test_conf_defaults_and_overrides():
+    from slam_amd import host
+    s = host.HostSim(sim_args("example_webmap", "FASTSLAM2", 1234, 9))
+    c = s.conf
+    assert c.NPARTICLES == 1234 and c.NEFFECTIVE == int(0.75 * 1234) and c.SWITCH_SEED_RANDOM == 9
+    assert c.method == 2 and c.MAX_RANGE == 60.0 and c.SWITCH_HEADING_KNOWN == 0 and c.n_landmarks == 35 and c.n_waypoints == 17
+    assert abs(c.Q[0] - 0.09) < 1e-7 and abs(c.R[3] - 0.017453292519943 ** 2) < 1e-9
+    s.close()
+    s = host.HostSim(["-m", os.path.join(DATA, "example_loop1.mat"), "-method", "bogus"])
+    assert s.conf.method == 0 and s.conf.SWITCH_HEADING_KNOWN == 1 and s.conf.NPARTICLES == 100 and s.conf.MAX_RANGE == 10.0
+    s.close()
+
+
+@pytest.mark.parametrize("name,mapname,method,N,seed", [("traj_fs2_webmap_N100_s7", "example_webmap", "FASTSLAM2", 100, 7),
+                                                          ("traj_fs2_loop1_N50_s3", "example_loop1", "FASTSLAM2", 50, 3)])
+def test_observation_tape_matches_reference(name, mapname, method, N, seed):
+    """With the particle-noise draws interleaved in the reference's order (4 rand() per particle when the update
+    samples, N for the strata), the host front end reproduces the reference's observation tape bit for bit."""
+    from slam_amd import host
+    g = load_golden(name)
+    sim = host.HostSim(sim_args(mapname, method, N, seed))
+    nf, k, nctl = 0, 0, 0
+    T = g["ctl"].shape[0]
+    while k < T:
+        r, V, G, phi = sim.control()
+        assert r >= 0
+        nctl += 1
+        if r == 1:
+            assert nctl == g["ctl"][k]
+            zf, idf, zn = sim.observe(nf)
+            m, n = g["m"][k], g["n"][k]
+            assert zf.shape[0] == m and zn.shape[0] == n
+            assert bits_equal(zf, g["zf"][k, :m]) and np.array_equal(idf, g["idf"][k, :m]) and bits_equal(zn, g["zn"][k, :n])
+            assert bits_equal(sim.true_pose(), g["true"][k])
+            if m > 0 or n > 0:
+                host.draw_normals(N, 3)
+            cnt, sel = host.draw_strata(N)
+            assert cnt == N
+            nf += n
+            k += 1
+    sim.close()
+
+
+def test_tape_draws_match_golden_snapshots():
+    from slam_amd import host
+    g = load_golden("traj_fs2_webmap_N100_s7")
+    sim = host.HostSim(sim_args("example_webmap", "FASTSLAM2", 100, 7))
+    nf, k = 0, 0
+    snaps = set(int(x) for x in g["snap_steps"])
+    while k < 30:
+        r, V, G, phi = sim.control()
+        if r == 1:
+            zf, idf, zn = sim.observe(nf)
+            k += 1
+            normals = host.draw_normals(100, 3) if (len(zf) or len(zn)) else None
+            cnt, sel = host.draw_strata(100)
+            if k in snaps:
+                assert bits_equal(normals, g["snap%d_normals" % k]) and bits_equal(sel, g["snap%d_sel" % k])
+            nf += zn.shape[0]
+    sim.close()
+
+
+def test_synthetic_map_roundtrip(tmp_path):
+    from slam_amd import host
+    lm = host.synthetic_landmarks(12345, 1000, -130, 100, -100, 90)
+    assert lm.shape == (2, 1000) and lm[0].min() >= -130 and lm[0].max() <= 100 and lm[1].min() >= -100 and lm[1].max() <= 90
+    assert np.array_equal(lm, host.synthetic_landmarks(12345, 1000, -130, 100, -100, 90))
+    wp = np.array([[0, 10, 20], [0, 5, -5]], np.float32)
+    p = str(tmp_path / "syn.mat")
+    host.write_map(p, lm, wp)
+    open(str(tmp_path / "syn.ini"), "w").write("MAX_RANGE = 10\n")
+    s = host.HostSim(["-m", p, "-method", "FASTSLAM2"])
+    lm2, wp2 = s.map()
+    assert np.allclose(lm2, lm, atol=1e-5) and np.allclose(wp2, wp) and s.conf.MAX_RANGE == 10.0
+    s.close()
