@@ -113,6 +113,11 @@ int slamgpu_update(slamgpu_ctx *ctx, const float *zf, const int32_t *idf, int32_
  * particle with the strictly greatest weight.  Synchronises. */
 int slamgpu_estimate(slamgpu_ctx *ctx, double xyt[3]);
 
+/* Same estimate, asynchronous: enqueue the reduction into a device-side history (capacity 4096 entries) and read
+ * the whole history later (one synchronisation for many steps).  xyt holds 3 doubles per entry. */
+int slamgpu_estimate_async(slamgpu_ctx *ctx);
+int slamgpu_estimate_fetch(slamgpu_ctx *ctx, double *xyt, int32_t max_count, int32_t *count);
+
 /* Outcome of the last update: Neff, whether the resample fired, sum of the raw weights. Synchronises. */
 int slamgpu_stats(slamgpu_ctx *ctx, float *neff, int32_t *resampled, double *weight_sum);
 /* Ancestor indices of the last resample (keep[], core.cpp:800-806), N_local int32. Synchronises. */

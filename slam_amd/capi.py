@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # every symbol include/slamgpu.h declares (tests check the built library exports each one)
 DECLARED_SYMBOLS = [
     "slamgpu_last_error", "slamgpu_abi_version", "slamgpu_device_count", "slamgpu_jacobians", "slamgpu_create",
-    "slamgpu_destroy", "slamgpu_predict", "slamgpu_update", "slamgpu_estimate", "slamgpu_stats", "slamgpu_ancestors",
+    "slamgpu_destroy", "slamgpu_predict", "slamgpu_update", "slamgpu_estimate", "slamgpu_estimate_async", "slamgpu_estimate_fetch", "slamgpu_stats", "slamgpu_ancestors",
     "slamgpu_num_landmarks", "slamgpu_download", "slamgpu_upload", "slamgpu_sync", "slamgpu_stream", "slamgpu_profile",
     "slamgpu_kernel_time", "slamgpu_algorithmic_bytes",
 ]
@@ -60,6 +60,8 @@ def load_library():
     L.slamgpu_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p]
     L.slamgpu_estimate.argtypes = [C.c_void_p, C.c_void_p]
+    L.slamgpu_estimate_async.argtypes = [C.c_void_p]
+    L.slamgpu_estimate_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.slamgpu_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.slamgpu_ancestors.argtypes = [C.c_void_p, C.c_void_p]
     L.slamgpu_num_landmarks.argtypes = [C.c_void_p]
@@ -169,6 +171,15 @@ class SlamGpu:
         e = np.zeros(3, np.float64)
         _chk(self.L.slamgpu_estimate(self.h, _ptr(e)))
         return e
+
+    def estimate_async(self):
+        _chk(self.L.slamgpu_estimate_async(self.h))
+
+    def estimate_fetch(self, max_count=4096):
+        out = np.zeros((max_count, 3), np.float64)
+        n = C.c_int32()
+        _chk(self.L.slamgpu_estimate_fetch(self.h, _ptr(out), max_count, C.byref(n)))
+        return out[:n.value].copy()
 
     def stats(self):
         ne, rs, ws = C.c_float(), C.c_int32(), C.c_double()

@@ -6,23 +6,27 @@
 namespace slamgpu {
 
 // ---- HBM layout ---------------------------------------------------------------------------------------
-// Structure-of-arrays, particle index fastest, so that a wave's 64 particles read 256 contiguous bytes
-// per component:
-//   pose  : float[10][Ncap]   rows 0-2 xv (x, y, theta), rows 3-8 Pv lower triangle (p00,p10,p11,p20,p21,p22),
-//                             row 9 weight w
-//   lmk   : float[cap_nf][5][Ncap]   per landmark: xf.x, xf.y, Pf p00, p10, p11
-// Two copies of each (ping-pong for the resampling gather); Ctrl.cur says which one is live and is only
-// ever changed on the device, so no host round trip is needed to know whether a resample fired.
-constexpr int kPoseRows = 10;
-constexpr int kLmkRows = 5;
+// Array-of-16-byte-chunks, particle index fastest: every wave-instruction moves 64 x 16 B = 1 KiB
+// contiguous (the widest coalesced access on gfx950), and the resampling gather fetches whole 16-B
+// chunks per ancestor instead of 4-B words from many rows.
+//   poseA : float4[Ncap]          x, y, theta, w
+//   poseB : float4[Ncap]          Pv lower triangle p00, p10, p11, p20
+//   poseC : float2[Ncap]          p21, p22                                      (40 B per particle)
+//   lmkA  : float4[cap_nf][Ncap]  xf.x, xf.y, Pf p00, p10
+//   lmkB  : float [cap_nf][Ncap]  Pf p11                                         (20 B per landmark)
+// Two copies of everything (ping-pong for the resampling gather); Ctrl.cur says which one is live and is
+// only ever changed on the device, so no host round trip is needed to know whether a resample fired.
 constexpr int kWave = 64;
+constexpr int kBlock = 256;
 constexpr int kMaxFusedPredict = 16;
+constexpr int kSmallObs = 12;       // observation packets up to this many zf / zn travel as kernel arguments
+constexpr int kMaxScanBlocks = 8192;  // block totals scanned inside every resample block (LDS)
 
 struct Ctrl {
     int32_t cur;          // live buffer (0/1)
     int32_t resampled;    // 1 if the last update resampled
-    uint32_t done;        // block-arrival counter for the last-block-flips-cur protocol
-    int32_t pad;
+    uint32_t done;        // block-arrival counter (last block flips cur / finishes the estimate)
+    uint32_t est_done;    // same, for the stand-alone estimate kernel
     float neff;           // Neff of the last update
     float inv_n;          // 1/N_global
     double wsum;          // sum of raw weights (global)
@@ -31,33 +35,42 @@ struct Ctrl {
 };
 
 struct Buffers {
-    float *pose[2];
-    float *lmk[2];
+    float4 *poseA[2];
+    float4 *poseB[2];
+    float2 *poseC[2];
+    float4 *lmkA[2];
+    float *lmkB[2];
     Ctrl *ctrl;
     int32_t n;        // local particles
-    int32_t ncap;     // row stride (>= n, multiple of 64)
+    int32_t ncap;     // row stride (>= n, multiple of 256)
     int32_t cap_nf;
 };
 
-struct ObsPacket {          // lives in device memory, uploaded once per update
+struct ObsPacket {          // big packets live in device memory, uploaded once per update
     int32_t m, n, nf, pad;  // re-observed, new, landmarks before this update
     float R[4];
     // followed by: int32 idf[m]; float zf[2m]; float zn[2n]   (offsets computed from m, n)
 };
 
+struct SmallObs {           // small packets travel in the kernel argument segment
+    int32_t idf[kSmallObs];
+    float zf[2 * kSmallObs];
+    float zn[2 * kSmallObs];
+};
+
 struct RngArgs {
     int32_t mode;            // 0 tape, 1 philox
-    uint32_t step;           // observation-step (update) or control-step (predict) counter
+    uint32_t step;           // observation-step counter
     uint32_t k0, k1;         // philox key = seed
     int64_t first_particle;  // global id of local particle 0
     int64_t n_global;
-    const float *normals;    // tape: [3][n] device (update) or [2][n] (predict), component-major
+    const float *normals;    // tape: [3][ncap] device (update) or [2][ncap] (predict), component-major
     const float *strata;     // tape: [n_global] device
 };
 
 struct PredictStep {
     float V, G, phi_true;
-    uint32_t step;
+    uint32_t step;           // control-step counter (philox stream)
 };
 
 struct PredictArgs {
@@ -68,26 +81,38 @@ struct PredictArgs {
     PredictStep steps[kMaxFusedPredict];
 };
 
+struct UpdateArgs {
+    int32_t method, m, n, nf;
+    float R[4];
+    const ObsPacket *big;    // null => use `small`
+    SmallObs small;
+};
+
 struct WeightScratch {
-    float *lcum;      // [ncap]  inclusive in-wave prefix of the raw weights
-    float *wave_w;    // [nwaves] wave totals of w
-    float *wave_w2;   // [nwaves] wave totals of w^2
-    double *wave_off; // [nwaves+1] exclusive prefix of wave totals
-    int32_t *keep;    // [ncap] ancestors of the last resample (local index of global ancestor on this shard)
-    int32_t nwaves;
+    float *lcum;        // [ncap]    inclusive in-block (256 particles) prefix of the raw weights
+    float *blk_w;       // [nblocks] block totals of w
+    float *blk_w2;      // [nblocks] block totals of w^2
+    double *est_part;   // [nblocks][4] pose-estimate partials (sum x, sum y, heading, max w)
+    int32_t *keep;      // [ncap] ancestors of the last resample
+    int32_t nblocks;
+};
+
+struct ResampleArgs {
+    int32_t nf;             // landmarks after this update
+    int32_t do_resample;    // SWITCH_RESAMPLE
+    int32_t n_effective;    // NEFFECTIVE
+    double *hist;           // pose-estimate history slot (4 doubles) or null
 };
 
 struct KernelTable {
-    void (*update)(hipStream_t, const Buffers &, int method, const ObsPacket *pkt_dev, int m, int n, int nf,
-                   const RngArgs &, const WeightScratch &);
-    void (*finalize)(hipStream_t, const Buffers &, const WeightScratch &, int do_resample, int n_effective);
-    void (*resample)(hipStream_t, const Buffers &, const WeightScratch &, const RngArgs &, int nf);
+    // K1: [fused predicts] + per-particle observation update + in-block weight prefix / totals
+    void (*update)(hipStream_t, const Buffers &, const PredictArgs &, const UpdateArgs &, const RngArgs &,
+                   const WeightScratch &);
+    // K3: Neff + decision, normalise or stratified-resample gather, pose estimate, flip
+    void (*resample)(hipStream_t, const Buffers &, const WeightScratch &, const RngArgs &, const ResampleArgs &);
     void (*predict)(hipStream_t, const Buffers &, const PredictArgs &, const RngArgs &);
-    void (*estimate)(hipStream_t, const Buffers &, double *partials, int nblocks);
+    void (*estimate)(hipStream_t, const Buffers &, const WeightScratch &, double *hist);
     void (*jacobians)(hipStream_t, const float *in_dev, uint32_t n, float *out_dev);
-    void (*pack)(hipStream_t, const Buffers &, int nf, float *xv, float *Pv9, float *w, float *xf, float *Pf4);
-    void (*unpack)(hipStream_t, const Buffers &, int nf, const float *xv, const float *Pv9, const float *w,
-                   const float *xf, const float *Pf4);
 };
 
 const KernelTable *kernels_strict();

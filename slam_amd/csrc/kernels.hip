@@ -1,5 +1,5 @@
-// gfx950 kernels of the FastSLAM observation update: one particle per work-item, SoA state in HBM,
-// wave64 shuffles for the weight prefix-sum / reductions, device-resident resample decision.
+// gfx950 kernels of the FastSLAM observation update: one particle per work-item, 16-byte-chunk state in
+// HBM, wave64 shuffles for the weight prefix-sum / reductions, device-resident resample decision.
 // Compiled twice (see Makefile): -DSLAM_KNS=slam_strict -ffp-contract=off and -DSLAM_KNS=slam_fast.
 #include "kernels.h"
 #include "device_math.h"
@@ -7,364 +7,25 @@
 namespace SLAM_KNS {
 using namespace slamgpu;
 
-constexpr int kBlock = 256;
-
-SLAM_DEV const int32_t *pkt_idf(const ObsPacket *p) { return reinterpret_cast<const int32_t *>(p + 1); }
-
 // ---------------------------------------------------------------------------------------------------
-// K1: per-particle observation update.  FastSLAM2::update body (fastslam2.cpp:26-45): sampleProposal
-// (:290-368) + likelihoodGivenXv (:370-400) fused with featureUpdate (core.cpp:132-175, the Jacobians
-// of both are evaluated at the same sampled pose) + addFeature (core.cpp:479-509); or FastSLAM1::update
-// body (fastslam1.cpp:21-32).  Ends with the in-wave inclusive prefix of the raw weights and the wave
-// totals of w and w^2 (resampleParticles' normalisation / Neff inputs, core.cpp:726-729,781-788).
+// predictState x nsteps with the pose in registers: FastSLAM2::predictState (fastslam2.cpp:70-105)
+// [+ observeHeading -> josephUpdate (fastslam2.cpp:113-125, core.cpp:294-317)] or
+// FastSLAM1::predictState (fastslam1.cpp:37-54).  P is the full 3x3 (the reference's Pv is not kept
+// symmetric by its own float arithmetic; only the stored form is packed).
 // ---------------------------------------------------------------------------------------------------
-template <int METHOD>
-__global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, const ObsPacket *__restrict__ pkt, int m, int n,
-                                                         int nf, RngArgs rng, WeightScratch ws) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    const int lane = threadIdx.x & (kWave - 1);
-    const size_t S = (size_t) B.ncap;
-    const int cur = B.ctrl->cur;
-    float *__restrict__ pose = B.pose[cur];
-    float *__restrict__ lmk = B.lmk[cur];
-    const bool active = i < B.n;
-    float w = 0.0f;
-
-    if (active) {
-        const int32_t *__restrict__ idf = pkt_idf(pkt);
-        const float *__restrict__ zf = reinterpret_cast<const float *>(idf + m);
-        const float *__restrict__ zn = zf + 2 * m;
-        const float r00 = pkt->R[0], r01 = pkt->R[1], r10 = pkt->R[2], r11 = pkt->R[3];
-
-        float x = pose[0 * S + i], y = pose[1 * S + i], th = pose[2 * S + i];
-        w = pose[9 * S + i];
-
-        if (METHOD == 2) {
-            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-            if (m > 0 || n > 0) {
-                if (rng.mode == 0) {
-                    g0 = rng.normals[0 * S + i];
-                    g1 = rng.normals[1 * S + i];
-                    g2 = rng.normals[2 * S + i];
-                } else {
-                    U4 r = philox4x32((uint32_t) (rng.first_particle + i), rng.step, 0u, 0u, rng.k0, rng.k1);
-                    box_muller3(r, g0, g1, g2);
-                }
-            }
-            // Pv lower triangle as stored
-            float q00 = pose[3 * S + i], q10 = pose[4 * S + i], q11 = pose[5 * S + i];
-            float q20 = pose[6 * S + i], q21 = pose[7 * S + i], q22 = pose[8 * S + i];
-            if (m > 0) {
-                const float x0 = x, y0 = y, th0 = th;
-                // running proposal covariance, full 3x3 (the reference's Pv stays a full matrix inside the loop)
-                float P[9] = {q00, q10, q20, q10, q11, q21, q20, q21, q22};
-                for (int k = 0; k < m; k++) {
-                    const size_t lb = (size_t) idf[k] * kLmkRows * S + i;
-                    const float fx = lmk[lb], fy = lmk[lb + S], p00 = lmk[lb + 2 * S], p10 = lmk[lb + 3 * S],
-                                p11 = lmk[lb + 4 * S];
-                    // Jacobians at the running mean (fastslam2.cpp:320,:348)
-                    Jac j = jacobian(x, y, th, fx, fy, p00, p10, p11, r00, r01, r10, r11);
-                    float s00, s01, s10, s11;
-                    inverse2(j.s00, j.s01, j.s10, j.s11, s00, s01, s10, s11);  // Sfi (:324)
-                    const float v0 = zf[2 * k] - j.zp0;
-                    const float v1 = trig_offset(zf[2 * k + 1] - j.zp1);
-                    float Pinv[9];
-                    llt_solve_identity3(llt3(P[0], P[3], P[4], P[6], P[7], P[8]), Pinv);  // (:335)
-                    // T1 = Hv^T * Sfi (3x2), T2 = T1 * Hv (3x3); Hv = [[hv00 hv01 0],[hv10 hv11 -1]]
-                    const float t00 = j.hv00 * s00 + j.hv10 * s10, t01 = j.hv00 * s01 + j.hv10 * s11;
-                    const float t10 = j.hv01 * s00 + j.hv11 * s10, t11 = j.hv01 * s01 + j.hv11 * s11;
-                    const float t20 = -s10, t21 = -s11;
-                    P[0] = (t00 * j.hv00 + t01 * j.hv10) + Pinv[0];
-                    P[1] = (t00 * j.hv01 + t01 * j.hv11) + Pinv[1];
-                    P[2] = (-t01) + Pinv[2];
-                    P[3] = (t10 * j.hv00 + t11 * j.hv10) + Pinv[3];
-                    P[4] = (t10 * j.hv01 + t11 * j.hv11) + Pinv[4];
-                    P[5] = (-t11) + Pinv[5];
-                    P[6] = (t20 * j.hv00 + t21 * j.hv10) + Pinv[6];
-                    P[7] = (t20 * j.hv01 + t21 * j.hv11) + Pinv[7];
-                    P[8] = (-t21) + Pinv[8];
-                    llt_solve_identity3(llt3(P[0], P[3], P[4], P[6], P[7], P[8]), P);  // (:341)
-                    // xv += ((Pv * Hv^T) * Sfi) * v   (:345)
-                    float c[3];
-#pragma unroll
-                    for (int r = 0; r < 3; r++) {
-                        const float a0 = P[3 * r] * j.hv00 + P[3 * r + 1] * j.hv01;
-                        const float a1 = (P[3 * r] * j.hv10 + P[3 * r + 1] * j.hv11) + P[3 * r + 2] * -1.0f;
-                        const float b0 = a0 * s00 + a1 * s10;
-                        const float b1 = a0 * s01 + a1 * s11;
-                        c[r] = b0 * v0 + b1 * v1;
-                    }
-                    x = x + c[0];
-                    y = y + c[1];
-                    th = th + c[2];
-                }
-                // sample from the proposal (:353) ; weight terms (:360-367)
-                const L3 Lp = llt3(P[0], P[3], P[4], P[6], P[7], P[8]);
-                float xs = x, ys = y, ths = th;
-                mvgauss3(xs, ys, ths, Lp, g0, g1, g2);
-                const float a0 = x0 - xs, a1 = y0 - ys, a2 = trig_offset(th0 - ths);
-                const float b0 = x - xs, b1 = y - ys, b2 = trig_offset(th - ths);
-                float lik = 1.0f;
-                for (int k = 0; k < m; k++) {
-                    const size_t lb = (size_t) idf[k] * kLmkRows * S + i;
-                    float fx = lmk[lb], fy = lmk[lb + S], p00 = lmk[lb + 2 * S], p10 = lmk[lb + 3 * S],
-                          p11 = lmk[lb + 4 * S];
-                    Jac j = jacobian(xs, ys, ths, fx, fy, p00, p10, p11, r00, r01, r10, r11);
-                    const float v0 = zf[2 * k] - j.zp0;
-                    const float v1 = trig_offset(zf[2 * k + 1] - j.zp1);
-                    lik = lik * gauss2(v0, v1, j.s00, j.s10, j.s11);
-                    cholesky_update2(fx, fy, p00, p10, p11, v0, v1, r00, r01, r10, r11, j.hf00, j.hf01, j.hf10, j.hf11);
-                    lmk[lb] = fx;
-                    lmk[lb + S] = fy;
-                    lmk[lb + 2 * S] = p00;
-                    lmk[lb + 3 * S] = p10;
-                    lmk[lb + 4 * S] = p11;
-                }
-                const float prior = gauss3(a0, a1, a2, q00, q10, q11, q20, q21, q22);
-                const float prop = gauss3(b0, b1, b2, P[0], P[3], P[4], P[6], P[7], P[8]);
-                w = w * lik * prior / prop;
-                x = xs;
-                y = ys;
-                th = ths;
-                q00 = q10 = q11 = q20 = q21 = q22 = 0.0f;
-            } else if (n > 0) {
-                // no re-observed landmark: sample the pose from the predicted Gaussian (fastslam2.cpp:36-42)
-                mvgauss3(x, y, th, llt3(q00, q10, q11, q20, q21, q22), g0, g1, g2);
-                q00 = q10 = q11 = q20 = q21 = q22 = 0.0f;
-            }
-            if (m > 0 || n > 0) {
-                pose[0 * S + i] = x;
-                pose[1 * S + i] = y;
-                pose[2 * S + i] = th;
-                pose[3 * S + i] = q00;
-                pose[4 * S + i] = q10;
-                pose[5 * S + i] = q11;
-                pose[6 * S + i] = q20;
-                pose[7 * S + i] = q21;
-                pose[8 * S + i] = q22;
-            }
-        } else {
-            // FastSLAM 1: computeWeight (fastslam1.cpp:91-118) + featureUpdate at the particle pose
-            if (m > 0) {
-                float wp = 1.0f;
-                for (int k = 0; k < m; k++) {
-                    const size_t lb = (size_t) idf[k] * kLmkRows * S + i;
-                    float fx = lmk[lb], fy = lmk[lb + S], p00 = lmk[lb + 2 * S], p10 = lmk[lb + 3 * S],
-                          p11 = lmk[lb + 4 * S];
-                    Jac j = jacobian(x, y, th, fx, fy, p00, p10, p11, r00, r01, r10, r11);
-                    const float v0 = zf[2 * k] - j.zp0;
-                    const float v1 = trig_offset(zf[2 * k + 1] - j.zp1);
-                    const float den = (float) (2 * kPi * (double) sqrtf(determinant2(j.s00, j.s01, j.s10, j.s11)));
-                    float i00, i01, i10, i11;
-                    inverse2(j.s00, j.s01, j.s10, j.s11, i00, i01, i10, i11);
-                    const float t0 = -0.5f * (v0 * i00 + v1 * i10);
-                    const float t1 = -0.5f * (v0 * i01 + v1 * i11);
-                    const float num = expf(t0 * v0 + t1 * v1);
-                    wp = wp * num / den;
-                    cholesky_update2(fx, fy, p00, p10, p11, v0, v1, r00, r01, r10, r11, j.hf00, j.hf01, j.hf10, j.hf11);
-                    lmk[lb] = fx;
-                    lmk[lb + S] = fy;
-                    lmk[lb + 2 * S] = p00;
-                    lmk[lb + 3 * S] = p10;
-                    lmk[lb + 4 * S] = p11;
-                }
-                w = w * wp;
-            }
-        }
-        // addFeature (core.cpp:479-509): new landmarks appended at nf, nf+1, ...
-        for (int k = 0; k < n; k++) {
-            float fx, fy, p00, p10, p11;
-            add_feature(x, y, th, zn[2 * k], zn[2 * k + 1], r00, r01, r10, r11, fx, fy, p00, p10, p11);
-            const size_t lb = (size_t) (nf + k) * kLmkRows * S + i;
-            lmk[lb] = fx;
-            lmk[lb + S] = fy;
-            lmk[lb + 2 * S] = p00;
-            lmk[lb + 3 * S] = p10;
-            lmk[lb + 4 * S] = p11;
-        }
-        pose[9 * S + i] = w;
-    }
-
-    // in-wave inclusive prefix of w, wave totals of w and w^2
-    float s = w;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const float t = __shfl_up(s, d, kWave);
-        if (lane >= d) s += t;
-    }
-    float s2 = w * w;
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) s2 += __shfl_xor(s2, d, kWave);
-    if (i < B.ncap) ws.lcum[i] = s;
-    const int wave = i / kWave;
-    if (lane == kWave - 1 && wave < ws.nwaves) {
-        ws.wave_w[wave] = s;
-        ws.wave_w2[wave] = s2;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// K2: one block.  Exclusive prefix of the wave totals (double), sum w, sum w^2, Neff and the resample
-// decision `doResample && Neff < nMin` (core.cpp:739), all left in device memory.
-// ---------------------------------------------------------------------------------------------------
-constexpr int kFinBlock = 1024;
-
-__global__ void __launch_bounds__(kFinBlock) finalize_kernel(Buffers B, WeightScratch ws, int do_resample,
-                                                              int n_effective) {
-    __shared__ double sh_sum[kFinBlock];
-    __shared__ double sh_sq[kFinBlock];
-    const int t = threadIdx.x;
-    const int P = ws.nwaves;
-    const int per = (P + kFinBlock - 1) / kFinBlock;
-    const int lo = t * per, hi = min(P, lo + per);
-    double a = 0.0, q = 0.0;
-    for (int k = lo; k < hi; k++) {
-        a += (double) ws.wave_w[k];
-        q += (double) ws.wave_w2[k];
-    }
-    sh_sum[t] = a;
-    sh_sq[t] = q;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 thread totals
-    for (int d = 1; d < kFinBlock; d <<= 1) {
-        double va = 0.0, vq = 0.0;
-        if (t >= d) {
-            va = sh_sum[t - d];
-            vq = sh_sq[t - d];
-        }
-        __syncthreads();
-        sh_sum[t] += va;
-        sh_sq[t] += vq;
-        __syncthreads();
-    }
-    double run = sh_sum[t] - a;  // exclusive prefix of this thread's segment
-    for (int k = lo; k < hi; k++) {
-        ws.wave_off[k] = run;
-        run += (double) ws.wave_w[k];
-    }
-    if (t == kFinBlock - 1) {
-        const double W = sh_sum[t], Q = sh_sq[t];
-        ws.wave_off[P] = W;
-        Ctrl *c = B.ctrl;
-        c->wsum = W;
-        c->wsq = Q;
-        // Neff = 1 / sum((w/W)^2)  (core.cpp:784-788)
-        const float neff = (float) ((W * W) / Q);
-        c->neff = neff;
-        c->resampled = (do_resample && (neff < (float) n_effective)) ? 1 : 0;
-        c->done = 0;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// K3: normalise or resample.  No resample: w_i /= sum(w) (core.cpp:726-729).  Resample: stratified
-// ancestor of output particle k = min{ i : select_k < cumsum_i } (core.cpp:800-806), gather-copy of the
-// whole particle (pose + nf landmarks) from the live buffer into the other one, w = 1/N (:744-747); the
-// last block to finish flips Ctrl.cur.  blockIdx.y splits the landmark rows.
-// ---------------------------------------------------------------------------------------------------
-constexpr int kLmkPerBlockY = 32;
-
-__global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScratch ws, RngArgs rng, int nf) {
-    Ctrl *ctrl = B.ctrl;
-    const int cur = ctrl->cur;
-    const int k = blockIdx.x * kBlock + threadIdx.x;
-    const size_t S = (size_t) B.ncap;
-    if (!ctrl->resampled) {
-        if (blockIdx.y == 0 && k < B.n) {
-            float *pose = B.pose[cur];
-            pose[9 * S + k] = pose[9 * S + k] / (float) ctrl->wsum;
-        }
-        return;
-    }
-    if (k < B.n) {
-        const int64_t gid = rng.first_particle + k;
-        float sel;
-        if (rng.mode == 0) {
-            sel = rng.strata[gid];
-        } else {
-            U4 r = philox4x32((uint32_t) gid, rng.step, 1u, 0u, rng.k0, rng.k1);
-            const double u = ((double) (r.x >> 8) + 0.5) * (1.0 / 16777216.0);
-            sel = (float) (((double) gid + u) / (double) rng.n_global);
-        }
-        const double target = (double) sel * ctrl->wsum;
-        // wave containing the ancestor: first b with wave_off[b+1] > target
-        int lo = 0, hi = ws.nwaves;  // answer in [lo, hi]
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (ws.wave_off[mid + 1] > target) hi = mid; else lo = mid + 1;
-        }
-        int a;
-        if (lo >= ws.nwaves) {
-            a = B.n - 1;  // select beyond the last cumulative weight: undefined upstream (keep = -1), clamp
-        } else {
-            const double off = ws.wave_off[lo];
-            const float *lc = ws.lcum + (size_t) lo * kWave;
-            int l0 = 0, l1 = kWave - 1;  // first lane with off + lc > target; lane 63 if rounding hides it
-            while (l0 < l1) {
-                const int mid = (l0 + l1) >> 1;
-                if (off + (double) lc[mid] > target) l1 = mid; else l0 = mid + 1;
-            }
-            a = min(lo * kWave + l0, B.n - 1);
-        }
-        const float *__restrict__ sp = B.pose[cur];
-        float *__restrict__ dp = B.pose[cur ^ 1];
-        if (blockIdx.y == 0) {
-#pragma unroll
-            for (int c = 0; c < 9; c++) dp[c * S + k] = sp[c * S + a];
-            dp[9 * S + k] = ctrl->inv_n;
-            ws.keep[k] = a;
-        }
-        const float *__restrict__ sl = B.lmk[cur];
-        float *__restrict__ dl = B.lmk[cur ^ 1];
-        const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(nf, j0 + kLmkPerBlockY);
-        for (int j = j0; j < j1; j++) {
-            const size_t lb = (size_t) j * kLmkRows * S;
-#pragma unroll
-            for (int c = 0; c < kLmkRows; c++) dl[lb + c * S + k] = sl[lb + c * S + a];
-        }
-    }
-    // last block flips the live buffer (every other block has finished reading Ctrl.cur's buffers by then)
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned total = gridDim.x * gridDim.y;
-        if (atomicAdd(&ctrl->done, 1u) == total - 1) {
-            ctrl->cur = cur ^ 1;
-            ctrl->done = 0;
-            __threadfence();
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Predict: FastSLAM2::predictState (fastslam2.cpp:70-105) [+ observeHeading -> josephUpdate
-// (fastslam2.cpp:113-125, core.cpp:294-317)] or FastSLAM1::predictState (fastslam1.cpp:37-54), up to
-// kMaxFusedPredict consecutive control steps with the state held in registers.
-// ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) predict_kernel(Buffers B, PredictArgs A, RngArgs rng) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= B.n) return;
-    const size_t S = (size_t) B.ncap;
-    float *__restrict__ pose = B.pose[B.ctrl->cur];
-    float x = pose[0 * S + i], y = pose[1 * S + i], th = pose[2 * S + i];
-    float P[9];
+SLAM_DEV void predict_steps(float &x, float &y, float &th, float P[9], const PredictArgs &A, const RngArgs &rng, int i,
+                            size_t S) {
     const bool fs2 = A.method == 2;
-    if (fs2) {
-        const float q00 = pose[3 * S + i], q10 = pose[4 * S + i], q11 = pose[5 * S + i];
-        const float q20 = pose[6 * S + i], q21 = pose[7 * S + i], q22 = pose[8 * S + i];
-        P[0] = q00; P[1] = q10; P[2] = q20;
-        P[3] = q10; P[4] = q11; P[5] = q21;
-        P[6] = q20; P[7] = q21; P[8] = q22;
-    }
     const float dt = A.dt, wb = A.wheel_base;
     const float Q00 = A.Q[0], Q01 = A.Q[1], Q10 = A.Q[2], Q11 = A.Q[3];
     for (int s = 0; s < A.nsteps; s++) {
         float V = A.steps[s].V, G = A.steps[s].G;
         if (fs2) {
             // Gv, Gu (fastslam2.cpp:78-79)
-            const float gv02 = -V * dt * sinf(G + th), gv12 = V * dt * cosf(G + th);
-            const float gu00 = dt * cosf(G + th), gu01 = -V * dt * sinf(G + th);
-            const float gu10 = dt * sinf(G + th), gu11 = V * dt * cosf(G + th);
+            const float sn = sinf(G + th), cs = cosf(G + th);
+            const float gv02 = -V * dt * sn, gv12 = V * dt * cs;
+            const float gu00 = dt * cs, gu01 = -V * dt * sn;
+            const float gu10 = dt * sn, gu11 = V * dt * cs;
             const float gu20 = dt * sinf(G) / wb, gu21 = V * dt * cosf(G) / wb;
             // T = Gv * Pv ; A = T * Gv^T   (Gv = [[1,0,gv02],[0,1,gv12],[0,0,1]])
             float T[9], N9[9];
@@ -453,79 +114,486 @@ __global__ void __launch_bounds__(kBlock) predict_kernel(Buffers B, PredictArgs 
             }
         }
     }
-    pose[0 * S + i] = x;
-    pose[1 * S + i] = y;
-    pose[2 * S + i] = th;
+}
+
+__global__ void __launch_bounds__(kBlock) predict_kernel(Buffers B, PredictArgs A, RngArgs rng) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B.n) return;
+    const int cur = B.ctrl->cur;
+    float4 a = B.poseA[cur][i];
+    float P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const bool fs2 = A.method == 2;
     if (fs2) {
-        pose[3 * S + i] = P[0];
-        pose[4 * S + i] = P[3];
-        pose[5 * S + i] = P[4];
-        pose[6 * S + i] = P[6];
-        pose[7 * S + i] = P[7];
-        pose[8 * S + i] = P[8];
+        const float4 b = B.poseB[cur][i];
+        const float2 c = B.poseC[cur][i];
+        P[0] = b.x; P[1] = b.y; P[2] = b.w;
+        P[3] = b.y; P[4] = b.z; P[5] = c.x;
+        P[6] = b.w; P[7] = c.x; P[8] = c.y;
+    }
+    predict_steps(a.x, a.y, a.z, P, A, rng, i, (size_t) B.ncap);
+    B.poseA[cur][i] = a;
+    if (fs2) {
+        B.poseB[cur][i] = make_float4(P[0], P[3], P[4], P[6]);
+        B.poseC[cur][i] = make_float2(P[7], P[8]);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Pose estimate (ParticleSLAMWrapper.cpp:56-77): sum x, sum y (double), heading of the first particle
-// with the strictly greatest weight.  Block partials, reduced by the last block to arrive.
+// K1: [pending predicts] + per-particle observation update.  FastSLAM2::update body
+// (fastslam2.cpp:26-45): sampleProposal (:290-368) + likelihoodGivenXv (:370-400) fused with
+// featureUpdate (core.cpp:132-175; both evaluate their Jacobians at the same sampled pose) + addFeature
+// (core.cpp:479-509); or FastSLAM1::update body (fastslam1.cpp:21-32).  Ends with the in-block inclusive
+// prefix of the raw weights and the block totals of w and w^2 (inputs of resampleParticles'
+// normalisation / Neff / cumulative sum, core.cpp:726-729,781-788,813-824).
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) estimate_kernel(Buffers B, double *partials, unsigned *counter) {
-    __shared__ double sx[kBlock], sy[kBlock];
-    __shared__ float sw[kBlock], st[kBlock];
-    __shared__ int si[kBlock];
-    __shared__ bool last;
+template <int METHOD>
+__global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs PA, UpdateArgs U, RngArgs rng,
+                                                         WeightScratch ws) {
+    __shared__ float sh_w[kBlock / kWave], sh_w2[kBlock / kWave];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const size_t S = (size_t) B.ncap;
+    const int cur = B.ctrl->cur;
+    float4 *__restrict__ lmkA = B.lmkA[cur];
+    float *__restrict__ lmkB = B.lmkB[cur];
+    const bool active = i < B.n;
+    const int m = U.m, n = U.n, nf = U.nf;
+    float w = 0.0f;
+
+    if (active) {
+        const int32_t *__restrict__ idf;
+        const float *__restrict__ zf, *__restrict__ zn;
+        if (U.big) {
+            idf = reinterpret_cast<const int32_t *>(U.big + 1);
+            zf = reinterpret_cast<const float *>(idf + m);
+            zn = zf + 2 * m;
+        } else {
+            idf = U.small.idf;
+            zf = U.small.zf;
+            zn = U.small.zn;
+        }
+        const float r00 = U.R[0], r01 = U.R[1], r10 = U.R[2], r11 = U.R[3];
+
+        float4 pa = B.poseA[cur][i];
+        float x = pa.x, y = pa.y, th = pa.z;
+        w = pa.w;
+        float q00 = 0.f, q10 = 0.f, q11 = 0.f, q20 = 0.f, q21 = 0.f, q22 = 0.f;
+        bool pose_dirty = false;
+        if (METHOD == 2) {
+            const float4 pb = B.poseB[cur][i];
+            const float2 pc = B.poseC[cur][i];
+            q00 = pb.x; q10 = pb.y; q11 = pb.z; q20 = pb.w; q21 = pc.x; q22 = pc.y;
+        }
+        if (PA.nsteps > 0) {
+            float P[9] = {q00, q10, q20, q10, q11, q21, q20, q21, q22};
+            predict_steps(x, y, th, P, PA, rng, i, S);
+            q00 = P[0]; q10 = P[3]; q11 = P[4]; q20 = P[6]; q21 = P[7]; q22 = P[8];
+            pose_dirty = true;
+        }
+
+        if (METHOD == 2) {
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+            if (m > 0 || n > 0) {
+                if (rng.mode == 0) {
+                    g0 = rng.normals[0 * S + i];
+                    g1 = rng.normals[1 * S + i];
+                    g2 = rng.normals[2 * S + i];
+                } else {
+                    U4 r = philox4x32((uint32_t) (rng.first_particle + i), rng.step, 0u, 0u, rng.k0, rng.k1);
+                    box_muller3(r, g0, g1, g2);
+                }
+            }
+            if (m > 0) {
+                const float x0 = x, y0 = y, th0 = th;
+                // running proposal covariance, full 3x3 (the reference's Pv stays a full matrix inside the loop)
+                float P[9] = {q00, q10, q20, q10, q11, q21, q20, q21, q22};
+                for (int k = 0; k < m; k++) {
+                    const size_t li = (size_t) idf[k] * S + i;
+                    const float4 la = lmkA[li];
+                    const float lb = lmkB[li];
+                    // Jacobians at the running mean (fastslam2.cpp:320,:348)
+                    Jac j = jacobian(x, y, th, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
+                    float s00, s01, s10, s11;
+                    inverse2(j.s00, j.s01, j.s10, j.s11, s00, s01, s10, s11);  // Sfi (:324)
+                    const float v0 = zf[2 * k] - j.zp0;
+                    const float v1 = trig_offset(zf[2 * k + 1] - j.zp1);
+                    float Pinv[9];
+                    llt_solve_identity3(llt3(P[0], P[3], P[4], P[6], P[7], P[8]), Pinv);  // (:335)
+                    // T1 = Hv^T * Sfi (3x2), T2 = T1 * Hv (3x3); Hv = [[hv00 hv01 0],[hv10 hv11 -1]]
+                    const float t00 = j.hv00 * s00 + j.hv10 * s10, t01 = j.hv00 * s01 + j.hv10 * s11;
+                    const float t10 = j.hv01 * s00 + j.hv11 * s10, t11 = j.hv01 * s01 + j.hv11 * s11;
+                    const float t20 = -s10, t21 = -s11;
+                    P[0] = (t00 * j.hv00 + t01 * j.hv10) + Pinv[0];
+                    P[1] = (t00 * j.hv01 + t01 * j.hv11) + Pinv[1];
+                    P[2] = (-t01) + Pinv[2];
+                    P[3] = (t10 * j.hv00 + t11 * j.hv10) + Pinv[3];
+                    P[4] = (t10 * j.hv01 + t11 * j.hv11) + Pinv[4];
+                    P[5] = (-t11) + Pinv[5];
+                    P[6] = (t20 * j.hv00 + t21 * j.hv10) + Pinv[6];
+                    P[7] = (t20 * j.hv01 + t21 * j.hv11) + Pinv[7];
+                    P[8] = (-t21) + Pinv[8];
+                    llt_solve_identity3(llt3(P[0], P[3], P[4], P[6], P[7], P[8]), P);  // (:341)
+                    // xv += ((Pv * Hv^T) * Sfi) * v   (:345)
+                    float c[3];
+#pragma unroll
+                    for (int r = 0; r < 3; r++) {
+                        const float a0 = P[3 * r] * j.hv00 + P[3 * r + 1] * j.hv01;
+                        const float a1 = (P[3 * r] * j.hv10 + P[3 * r + 1] * j.hv11) + P[3 * r + 2] * -1.0f;
+                        const float b0 = a0 * s00 + a1 * s10;
+                        const float b1 = a0 * s01 + a1 * s11;
+                        c[r] = b0 * v0 + b1 * v1;
+                    }
+                    x = x + c[0];
+                    y = y + c[1];
+                    th = th + c[2];
+                }
+                // sample from the proposal (:353) ; weight terms (:360-367)
+                const L3 Lp = llt3(P[0], P[3], P[4], P[6], P[7], P[8]);
+                float xs = x, ys = y, ths = th;
+                mvgauss3(xs, ys, ths, Lp, g0, g1, g2);
+                const float a0 = x0 - xs, a1 = y0 - ys, a2 = trig_offset(th0 - ths);
+                const float b0 = x - xs, b1 = y - ys, b2 = trig_offset(th - ths);
+                float lik = 1.0f;
+                for (int k = 0; k < m; k++) {
+                    const size_t li = (size_t) idf[k] * S + i;
+                    float4 la = lmkA[li];
+                    float lb = lmkB[li];
+                    Jac j = jacobian(xs, ys, ths, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
+                    const float v0 = zf[2 * k] - j.zp0;
+                    const float v1 = trig_offset(zf[2 * k + 1] - j.zp1);
+                    lik = lik * gauss2(v0, v1, j.s00, j.s10, j.s11);
+                    cholesky_update2(la.x, la.y, la.z, la.w, lb, v0, v1, r00, r01, r10, r11, j.hf00, j.hf01, j.hf10, j.hf11);
+                    lmkA[li] = la;
+                    lmkB[li] = lb;
+                }
+                const float prior = gauss3(a0, a1, a2, q00, q10, q11, q20, q21, q22);
+                const float prop = gauss3(b0, b1, b2, P[0], P[3], P[4], P[6], P[7], P[8]);
+                w = w * lik * prior / prop;
+                x = xs;
+                y = ys;
+                th = ths;
+                q00 = q10 = q11 = q20 = q21 = q22 = 0.0f;
+                pose_dirty = true;
+            } else if (n > 0) {
+                // no re-observed landmark: sample the pose from the predicted Gaussian (fastslam2.cpp:36-42)
+                mvgauss3(x, y, th, llt3(q00, q10, q11, q20, q21, q22), g0, g1, g2);
+                q00 = q10 = q11 = q20 = q21 = q22 = 0.0f;
+                pose_dirty = true;
+            }
+        } else {
+            // FastSLAM 1: computeWeight (fastslam1.cpp:91-118) + featureUpdate at the particle pose
+            if (m > 0) {
+                float wp = 1.0f;
+                for (int k = 0; k < m; k++) {
+                    const size_t li = (size_t) idf[k] * S + i;
+                    float4 la = lmkA[li];
+                    float lb = lmkB[li];
+                    Jac j = jacobian(x, y, th, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
+                    const float v0 = zf[2 * k] - j.zp0;
+                    const float v1 = trig_offset(zf[2 * k + 1] - j.zp1);
+                    const float den = (float) (2 * kPi * (double) sqrtf(determinant2(j.s00, j.s01, j.s10, j.s11)));
+                    float i00, i01, i10, i11;
+                    inverse2(j.s00, j.s01, j.s10, j.s11, i00, i01, i10, i11);
+                    const float t0 = -0.5f * (v0 * i00 + v1 * i10);
+                    const float t1 = -0.5f * (v0 * i01 + v1 * i11);
+                    const float num = expf(t0 * v0 + t1 * v1);
+                    wp = wp * num / den;
+                    cholesky_update2(la.x, la.y, la.z, la.w, lb, v0, v1, r00, r01, r10, r11, j.hf00, j.hf01, j.hf10, j.hf11);
+                    lmkA[li] = la;
+                    lmkB[li] = lb;
+                }
+                w = w * wp;
+            }
+        }
+        // addFeature (core.cpp:479-509): new landmarks appended at nf, nf+1, ...
+        for (int k = 0; k < n; k++) {
+            float4 la;
+            float lb;
+            add_feature(x, y, th, zn[2 * k], zn[2 * k + 1], r00, r01, r10, r11, la.x, la.y, la.z, la.w, lb);
+            const size_t li = (size_t) (nf + k) * S + i;
+            lmkA[li] = la;
+            lmkB[li] = lb;
+        }
+        B.poseA[cur][i] = make_float4(x, y, th, w);
+        if (METHOD == 2 && pose_dirty) {
+            B.poseB[cur][i] = make_float4(q00, q10, q11, q20);
+            B.poseC[cur][i] = make_float2(q21, q22);
+        }
+    }
+
+    // in-block inclusive prefix of w; block totals of w and w^2 (fixed association: deterministic)
+    float s = w;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const float t = __shfl_up(s, d, kWave);
+        if (lane >= d) s += t;
+    }
+    float s2 = w * w;
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) s2 += __shfl_xor(s2, d, kWave);
+    if (lane == kWave - 1) {
+        sh_w[wv] = s;
+        sh_w2[wv] = s2;
+    }
+    __syncthreads();
+    float base = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kBlock / kWave; k++)
+        if (k < wv) base += sh_w[k];
+    ws.lcum[i] = base + s;
+    if (threadIdx.x == kBlock - 1) {
+        ws.blk_w[blockIdx.x] = base + s;
+        ws.blk_w2[blockIdx.x] = ((sh_w2[0] + sh_w2[1]) + sh_w2[2]) + sh_w2[3];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// block-level helpers
+// ---------------------------------------------------------------------------------------------------
+struct EstItem {
+    double sx, sy;
+    float w, th;
+    int idx;
+};
+
+SLAM_DEV void est_combine(EstItem &a, const EstItem &b) {
+    a.sx += b.sx;
+    a.sy += b.sy;
+    if (b.w > a.w || (b.w == a.w && b.idx < a.idx)) {
+        a.w = b.w;
+        a.th = b.th;
+        a.idx = b.idx;
+    }
+}
+
+// reduce over the 256 threads of a block; result valid in thread 0
+SLAM_DEV EstItem block_reduce_est(EstItem v, EstItem *sh) {
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        EstItem o;
+        o.sx = __shfl_down(v.sx, d, kWave);
+        o.sy = __shfl_down(v.sy, d, kWave);
+        o.w = __shfl_down(v.w, d, kWave);
+        o.th = __shfl_down(v.th, d, kWave);
+        o.idx = __shfl_down(v.idx, d, kWave);
+        est_combine(v, o);
+    }
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 1; k < kBlock / kWave; k++) est_combine(v, sh[k]);
+    }
+    return v;
+}
+
+// Final stage run by the last block to arrive: parallel reduction of the per-block partials
+// (sum x, sum y in block order is not needed: doubles, tree order fixed by the launch geometry).
+SLAM_DEV void finish_estimate(const Buffers &B, const WeightScratch &ws, double *hist, EstItem *sh) {
+    EstItem v{0.0, 0.0, -3.0e38f, 0.0f, 0x7fffffff};
+    for (int b = threadIdx.x; b < ws.nblocks; b += kBlock) {
+        const double *p = ws.est_part + (size_t) b * 4;
+        EstItem o{p[0], p[1], (float) p[3], (float) p[2], b};
+        est_combine(v, o);
+    }
+    __syncthreads();
+    v = block_reduce_est(v, sh);
+    if (threadIdx.x == 0) {
+        Ctrl *c = B.ctrl;
+        c->est[0] = v.sx;
+        c->est[1] = v.sy;
+        c->est[2] = (double) v.th;
+        c->est[3] = (double) v.w;
+        if (hist) {
+            hist[0] = v.sx;
+            hist[1] = v.sy;
+            hist[2] = (double) v.th;
+            hist[3] = (double) v.w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3: resampleParticles (core.cpp:718-749) + the per-step pose estimate (ParticleSLAMWrapper.cpp:56-77).
+// Every block redundantly scans the block totals (LDS, double) => sum w, sum w^2, Neff and the decision
+// `doResample && Neff < nMin` without a separate launch or a host round trip.
+//   no resample: w_i /= sum(w) (core.cpp:726-729)
+//   resample   : ancestor of output k = min{ i : select_k < cumsum_i } (core.cpp:800-806) by a two-level
+//                binary search (block offsets in LDS, in-block prefix in HBM), gather-copy of the whole
+//                particle from the live buffers into the other set, w = 1/N (:744-747); blockIdx.y splits
+//                the landmarks.  The last block to finish reduces the estimate partials and flips Ctrl.cur.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kLmkPerBlockY = 8;
+
+__global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScratch ws, RngArgs rng, ResampleArgs ra) {
+    extern __shared__ double off[];  // [nblocks + 1] exclusive prefix of the block totals
+    __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
+    __shared__ EstItem sh_est[kBlock / kWave];
+    Ctrl *ctrl = B.ctrl;
+    const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
+    const int nb = ws.nblocks;
+    const int cur = ctrl->cur;
+
+    // ---- scan of the block totals --------------------------------------------------------------------
+    const int per = (nb + kBlock - 1) / kBlock;
+    const int lo = min(nb, t * per), hi = min(nb, lo + per);
+    double a = 0.0, q = 0.0;
+    for (int k = lo; k < hi; k++) {
+        a += (double) ws.blk_w[k];
+        q += (double) ws.blk_w2[k];
+    }
+    double sa = a;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const double v = __shfl_up(sa, d, kWave);
+        if (lane >= d) sa += v;
+    }
+    double sq = q;
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) sq += __shfl_xor(sq, d, kWave);
+    if (lane == kWave - 1) sh_a[wv] = sa;
+    if (lane == 0) sh_q[wv] = sq;
+    __syncthreads();
+    double base = 0.0;
+#pragma unroll
+    for (int k = 0; k < kBlock / kWave; k++)
+        if (k < wv) base += sh_a[k];
+    double run = base + sa - a;  // exclusive prefix of this thread's segment
+    for (int k = lo; k < hi; k++) {
+        off[k] = run;
+        run += (double) ws.blk_w[k];
+    }
+    const double W = ((sh_a[0] + sh_a[1]) + sh_a[2]) + sh_a[3];
+    const double Q = ((sh_q[0] + sh_q[1]) + sh_q[2]) + sh_q[3];
+    if (t == 0) off[nb] = W;
+    // Neff = 1 / sum((w/W)^2)  (core.cpp:784-788)
+    const float neff = (float) ((W * W) / Q);
+    const bool resample = ra.do_resample && (neff < (float) ra.n_effective);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) {
+        ctrl->wsum = W;
+        ctrl->wsq = Q;
+        ctrl->neff = neff;
+        ctrl->resampled = resample ? 1 : 0;
+    }
+    if (!resample && blockIdx.y != 0) return;
+    __syncthreads();
+
+    const int k = blockIdx.x * kBlock + t;
+    const bool active = k < B.n;
+    EstItem ei{0.0, 0.0, -3.0e38f, 0.0f, 0x7fffffff};
+    if (!resample) {
+        if (active) {
+            float4 pa = B.poseA[cur][k];
+            pa.w = pa.w / (float) W;
+            B.poseA[cur][k] = pa;
+            ei = EstItem{(double) pa.x, (double) pa.y, pa.w, pa.z, k};
+        }
+    } else if (active) {
+        const int64_t gid = rng.first_particle + k;
+        float sel;
+        if (rng.mode == 0) {
+            sel = rng.strata[gid];
+        } else {
+            U4 r = philox4x32((uint32_t) gid, rng.step, 1u, 0u, rng.k0, rng.k1);
+            const double u = ((double) (r.x >> 8) + 0.5) * (1.0 / 16777216.0);
+            sel = (float) (((double) gid + u) / (double) rng.n_global);
+        }
+        const double target = (double) sel * W;
+        // block holding the ancestor: first b with off[b+1] > target
+        int b0 = 0, b1 = nb;
+        while (b0 < b1) {
+            const int mid = (b0 + b1) >> 1;
+            if (off[mid + 1] > target) b1 = mid; else b0 = mid + 1;
+        }
+        int anc;
+        if (b0 >= nb) {
+            anc = B.n - 1;  // select beyond the last cumulative weight: undefined upstream (keep = -1), clamp
+        } else {
+            const double o = off[b0];
+            const float *lc = ws.lcum + (size_t) b0 * kBlock;
+            int l0 = 0, l1 = kBlock - 1;  // first slot with o + lc > target; the last slot if rounding hides it
+            while (l0 < l1) {
+                const int mid = (l0 + l1) >> 1;
+                if (o + (double) lc[mid] > target) l1 = mid; else l0 = mid + 1;
+            }
+            anc = min(b0 * kBlock + l0, B.n - 1);
+        }
+        const size_t S = (size_t) B.ncap;
+        if (blockIdx.y == 0) {
+            float4 pa = B.poseA[cur][anc];
+            pa.w = ctrl->inv_n;
+            B.poseA[cur ^ 1][k] = pa;
+            B.poseB[cur ^ 1][k] = B.poseB[cur][anc];
+            B.poseC[cur ^ 1][k] = B.poseC[cur][anc];
+            ws.keep[k] = anc;
+            ei = EstItem{(double) pa.x, (double) pa.y, pa.w, pa.z, k};
+        }
+        const float4 *__restrict__ sA = B.lmkA[cur];
+        const float *__restrict__ sB = B.lmkB[cur];
+        float4 *__restrict__ dA = B.lmkA[cur ^ 1];
+        float *__restrict__ dB = B.lmkB[cur ^ 1];
+        const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(ra.nf, j0 + kLmkPerBlockY);
+        for (int j = j0; j < j1; j += 4) {
+            // four landmarks per trip: issue all the gathers before the first store
+            const int c1 = min(j + 1, j1 - 1), c2 = min(j + 2, j1 - 1), c3 = min(j + 3, j1 - 1);
+            const float4 a0 = sA[(size_t) j * S + anc], a1 = sA[(size_t) c1 * S + anc];
+            const float4 a2 = sA[(size_t) c2 * S + anc], a3 = sA[(size_t) c3 * S + anc];
+            const float e0 = sB[(size_t) j * S + anc], e1 = sB[(size_t) c1 * S + anc];
+            const float e2 = sB[(size_t) c2 * S + anc], e3 = sB[(size_t) c3 * S + anc];
+            dA[(size_t) j * S + k] = a0;
+            dB[(size_t) j * S + k] = e0;
+            dA[(size_t) c1 * S + k] = a1;
+            dB[(size_t) c1 * S + k] = e1;
+            dA[(size_t) c2 * S + k] = a2;
+            dB[(size_t) c2 * S + k] = e2;
+            dA[(size_t) c3 * S + k] = a3;
+            dB[(size_t) c3 * S + k] = e3;
+        }
+    }
+
+    // ---- estimate partial of this block (row y == 0 only); reduced + committed by finish_kernel ----------
+    // (no in-kernel hand-off: an agent-scope release per block = an L2 write-back per block on gfx950,
+    //  which costs far more than the one kernel boundary it would save)
+    if (blockIdx.y == 0) {
+        ei = block_reduce_est(ei, sh_est);
+        if (t == 0) {
+            double *p = ws.est_part + (size_t) blockIdx.x * 4;
+            p[0] = ei.sx;
+            p[1] = ei.sy;
+            p[2] = (double) ei.th;
+            p[3] = (double) ei.w;
+        }
+    }
+}
+
+// One block: reduces the estimate partials (-> Ctrl.est, history slot) and, after a resample, commits the
+// buffer flip.  Runs behind resample_kernel / estimate_kernel on the same stream.
+__global__ void __launch_bounds__(kBlock) finish_kernel(Buffers B, WeightScratch ws, double *hist, int commit_flip) {
+    __shared__ EstItem sh_est[kBlock / kWave];
+    finish_estimate(B, ws, hist, sh_est);
+    if (threadIdx.x == 0 && commit_flip && B.ctrl->resampled) B.ctrl->cur ^= 1;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Stand-alone pose estimate (used when the particle set changed since the last update, e.g. after predicts)
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) estimate_kernel(Buffers B, WeightScratch ws) {
+    __shared__ EstItem sh_est[kBlock / kWave];
     const int t = threadIdx.x;
     const int i = blockIdx.x * kBlock + t;
-    const size_t S = (size_t) B.ncap;
-    const float *pose = B.pose[B.ctrl->cur];
-    const bool act = i < B.n;
-    sx[t] = act ? (double) pose[0 * S + i] : 0.0;
-    sy[t] = act ? (double) pose[1 * S + i] : 0.0;
-    sw[t] = act ? pose[9 * S + i] : -3.0e38f;
-    st[t] = act ? pose[2 * S + i] : 0.0f;
-    si[t] = act ? i : 0x7fffffff;
-    __syncthreads();
-    for (int d = kBlock / 2; d > 0; d >>= 1) {
-        if (t < d) {
-            sx[t] += sx[t + d];
-            sy[t] += sy[t + d];
-            if (sw[t + d] > sw[t] || (sw[t + d] == sw[t] && si[t + d] < si[t])) {
-                sw[t] = sw[t + d];
-                st[t] = st[t + d];
-                si[t] = si[t + d];
-            }
-        }
-        __syncthreads();
+    EstItem ei{0.0, 0.0, -3.0e38f, 0.0f, 0x7fffffff};
+    if (i < B.n) {
+        const float4 pa = B.poseA[B.ctrl->cur][i];
+        ei = EstItem{(double) pa.x, (double) pa.y, pa.w, pa.z, i};
     }
+    ei = block_reduce_est(ei, sh_est);
     if (t == 0) {
-        double *p = partials + (size_t) blockIdx.x * 4;
-        p[0] = sx[0];
-        p[1] = sy[0];
-        p[2] = (double) st[0];
-        p[3] = (double) sw[0];
-        __threadfence();
-        last = atomicAdd(counter, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (last && t == 0) {
-        __threadfence();
-        double ax = 0.0, ay = 0.0, bt = 0.0, bw = -1e300;
-        for (unsigned b = 0; b < gridDim.x; b++) {  // block order == particle order: first strict maximum wins
-            const volatile double *p = partials + (size_t) b * 4;
-            ax += p[0];
-            ay += p[1];
-            if (p[3] > bw) {
-                bw = p[3];
-                bt = p[2];
-            }
-        }
-        Ctrl *c = B.ctrl;
-        c->est[0] = ax;
-        c->est[1] = ay;
-        c->est[2] = bt;
-        c->est[3] = bw;
-        *counter = 0;
+        double *p = ws.est_part + (size_t) blockIdx.x * 4;
+        p[0] = ei.sx;
+        p[1] = ei.sy;
+        p[2] = (double) ei.th;
+        p[3] = (double) ei.w;
     }
 }
 
@@ -552,42 +620,37 @@ __global__ void __launch_bounds__(kBlock) jacobians_kernel(const float *__restri
 // ---------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------
-static inline int blocks_for(int n) { return (n + kBlock - 1) / kBlock; }
-
-static void launch_update(hipStream_t st, const Buffers &B, int method, const ObsPacket *pkt, int m, int n, int nf,
+static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &PA, const UpdateArgs &U,
                           const RngArgs &rng, const WeightScratch &ws) {
-    const int grid = blocks_for(B.ncap);
-    if (method == 2)
-        hipLaunchKernelGGL(update_kernel<2>, dim3(grid), dim3(kBlock), 0, st, B, pkt, m, n, nf, rng, ws);
+    const int grid = B.ncap / kBlock;
+    if (U.method == 2)
+        hipLaunchKernelGGL(update_kernel<2>, dim3(grid), dim3(kBlock), 0, st, B, PA, U, rng, ws);
     else
-        hipLaunchKernelGGL(update_kernel<1>, dim3(grid), dim3(kBlock), 0, st, B, pkt, m, n, nf, rng, ws);
+        hipLaunchKernelGGL(update_kernel<1>, dim3(grid), dim3(kBlock), 0, st, B, PA, U, rng, ws);
 }
 
-static void launch_finalize(hipStream_t st, const Buffers &B, const WeightScratch &ws, int do_resample,
-                            int n_effective) {
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(kFinBlock), 0, st, B, ws, do_resample, n_effective);
-}
-
-static void launch_resample(hipStream_t st, const Buffers &B, const WeightScratch &ws, const RngArgs &rng, int nf) {
-    const int gy = nf > 0 ? (nf + kLmkPerBlockY - 1) / kLmkPerBlockY : 1;
-    hipLaunchKernelGGL(resample_kernel, dim3(blocks_for(B.n), gy), dim3(kBlock), 0, st, B, ws, rng, nf);
+static void launch_resample(hipStream_t st, const Buffers &B, const WeightScratch &ws, const RngArgs &rng,
+                            const ResampleArgs &ra) {
+    const int gy = ra.nf > 0 ? (ra.nf + kLmkPerBlockY - 1) / kLmkPerBlockY : 1;
+    const size_t lds = sizeof(double) * ((size_t) ws.nblocks + 1);
+    hipLaunchKernelGGL(resample_kernel, dim3(ws.nblocks, gy), dim3(kBlock), lds, st, B, ws, rng, ra);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, B, ws, ra.hist, 1);
 }
 
 static void launch_predict(hipStream_t st, const Buffers &B, const PredictArgs &A, const RngArgs &rng) {
-    hipLaunchKernelGGL(predict_kernel, dim3(blocks_for(B.n)), dim3(kBlock), 0, st, B, A, rng);
+    hipLaunchKernelGGL(predict_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B, A, rng);
 }
 
-static void launch_estimate(hipStream_t st, const Buffers &B, double *partials, int nblocks) {
-    unsigned *counter = reinterpret_cast<unsigned *>(partials + (size_t) nblocks * 4);
-    hipLaunchKernelGGL(estimate_kernel, dim3(nblocks), dim3(kBlock), 0, st, B, partials, counter);
+static void launch_estimate(hipStream_t st, const Buffers &B, const WeightScratch &ws, double *hist) {
+    hipLaunchKernelGGL(estimate_kernel, dim3(ws.nblocks), dim3(kBlock), 0, st, B, ws);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, B, ws, hist, 0);
 }
 
 static void launch_jacobians(hipStream_t st, const float *in, uint32_t n, float *out) {
     hipLaunchKernelGGL(jacobians_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, in, n, out);
 }
 
-static const KernelTable kTable = {launch_update, launch_finalize, launch_resample, launch_predict,
-                                   launch_estimate, launch_jacobians};
+static const KernelTable kTable = {launch_update, launch_resample, launch_predict, launch_estimate, launch_jacobians};
 
 }  // namespace SLAM_KNS
 

@@ -36,7 +36,8 @@ int fail(int code, const char *fmt, ...) {
             return fail(SLAMGPU_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-constexpr int kRing = 64;  // packet / tape staging slots
+constexpr int kRing = 64;       // big-packet staging slots
+constexpr int kHistCap = 4096;  // asynchronous pose-estimate history entries
 
 struct EventPair {
     hipEvent_t a, b;
@@ -56,11 +57,9 @@ struct slamgpu_ctx {
     hipStream_t stream = nullptr;
     Buffers B{};
     WeightScratch ws{};
-    double *est_partials = nullptr;
-    int est_blocks = 0;
     int nf = 0;
     uint32_t obs_step = 0, ctl_step = 0;
-    // packet ring
+    // big-packet ring (observation packets that do not fit the kernel-argument form)
     size_t pkt_bytes = 0;
     char *pkt_host = nullptr;  // pinned [kRing][pkt_bytes]
     char *pkt_dev = nullptr;
@@ -75,12 +74,15 @@ struct slamgpu_ctx {
     PredictArgs pending{};
     // host mirror of ctrl for readback
     Ctrl *ctrl_host = nullptr;  // pinned
+    // pose-estimate history
+    double *hist_dev = nullptr;  // [kHistCap][4]
+    int hist_n = 0;
+    bool est_fresh = false;  // Ctrl.est / hist slot hist_n were written by the last update and nothing changed since
     // profiling
     bool profile = false;
     std::map<std::string, KernelStat> stats;
     std::vector<hipEvent_t> ev_pool;
     double predict_bytes = 0;
-    double *bytes_dev = nullptr;  // [0] = accumulated algorithmic update bytes (device side, needs the resample flag)
 };
 
 namespace {
@@ -107,11 +109,11 @@ struct Timed {
         st = &c->stats[name];
         ep.a = get_event(c);
         ep.b = get_event(c);
-        if (ep.a) hipEventRecord(ep.a, c->stream);
+        if (ep.a) (void) hipEventRecord(ep.a, c->stream);
     }
     ~Timed() {
         if (!st) return;
-        if (ep.b) hipEventRecord(ep.b, c->stream);
+        if (ep.b) (void) hipEventRecord(ep.b, c->stream);
         st->pending.push_back(ep);
         st->launches++;
     }
@@ -154,11 +156,20 @@ int flush_predict(slamgpu_ctx *c) {
     // algorithmic bytes: xv + Pv read and written once per particle-predict (72 B)
     c->predict_bytes += 72.0 * c->cfg.n_particles * c->pending.nsteps;
     c->pending.nsteps = 0;
+    c->est_fresh = false;
     return 0;
 }
 
 int check_ctx(slamgpu_ctx *c) {
     if (!c) return fail(SLAMGPU_ERR_INVALID, "null context");
+    return 0;
+}
+
+int read_ctrl(slamgpu_ctx *c) {
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = flush_predict(c)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->ctrl_host, c->B.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -187,14 +198,16 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(SLAMGPU_ERR_NO_DEVICE, "no HIP device: libslamgpu has no CPU fallback");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(SLAMGPU_ERR_INVALID, "device %d out of range (%d devices)", cfg->device, ndev);
+    const int n = cfg->n_particles;
+    const int ncap = ((n + kBlock - 1) / kBlock) * kBlock;
+    if (ncap / kBlock > kMaxScanBlocks)
+        return fail(SLAMGPU_ERR_INVALID, "n_particles %d exceeds %d per context (shard across contexts)", n, kMaxScanBlocks * kBlock);
     HIP_TRY(hipSetDevice(cfg->device));
 
     slamgpu_ctx *c = new slamgpu_ctx();
     c->cfg = *cfg;
     if (c->cfg.n_particles_global <= 0) c->cfg.n_particles_global = c->cfg.n_particles;
     c->k = cfg->math_mode == SLAMGPU_MATH_FAST ? kernels_fast() : kernels_strict();
-    const int n = cfg->n_particles;
-    const int ncap = ((n + 255) / 256) * 256;
     const int cap_nf = cfg->max_landmarks > 0 ? cfg->max_landmarks : 1;
     c->B.n = n;
     c->B.ncap = ncap;
@@ -209,13 +222,18 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
         }                                                                                              \
     } while (0)
     CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    const size_t pose_bytes = sizeof(float) * kPoseRows * (size_t) ncap;
-    const size_t lmk_bytes = sizeof(float) * kLmkRows * (size_t) cap_nf * (size_t) ncap;
+    const size_t S = (size_t) ncap;
     for (int b = 0; b < 2; b++) {
-        CTX_TRY(hipMalloc((void **) &c->B.pose[b], pose_bytes));
-        CTX_TRY(hipMalloc((void **) &c->B.lmk[b], lmk_bytes));
-        CTX_TRY(hipMemsetAsync(c->B.pose[b], 0, pose_bytes, c->stream));
-        CTX_TRY(hipMemsetAsync(c->B.lmk[b], 0, lmk_bytes, c->stream));
+        CTX_TRY(hipMalloc((void **) &c->B.poseA[b], sizeof(float4) * S));
+        CTX_TRY(hipMalloc((void **) &c->B.poseB[b], sizeof(float4) * S));
+        CTX_TRY(hipMalloc((void **) &c->B.poseC[b], sizeof(float2) * S));
+        CTX_TRY(hipMalloc((void **) &c->B.lmkA[b], sizeof(float4) * S * cap_nf));
+        CTX_TRY(hipMalloc((void **) &c->B.lmkB[b], sizeof(float) * S * cap_nf));
+        CTX_TRY(hipMemsetAsync(c->B.poseA[b], 0, sizeof(float4) * S, c->stream));
+        CTX_TRY(hipMemsetAsync(c->B.poseB[b], 0, sizeof(float4) * S, c->stream));
+        CTX_TRY(hipMemsetAsync(c->B.poseC[b], 0, sizeof(float2) * S, c->stream));
+        CTX_TRY(hipMemsetAsync(c->B.lmkA[b], 0, sizeof(float4) * S * cap_nf, c->stream));
+        CTX_TRY(hipMemsetAsync(c->B.lmkB[b], 0, sizeof(float) * S * cap_nf, c->stream));
     }
     CTX_TRY(hipMalloc((void **) &c->B.ctrl, sizeof(Ctrl)));
     CTX_TRY(hipHostMalloc((void **) &c->ctrl_host, sizeof(Ctrl), hipHostMallocDefault));
@@ -223,35 +241,31 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     c->ctrl_host->inv_n = 1.0f / (float) n_global(c);  // core.cpp:745
     CTX_TRY(hipMemcpyAsync(c->B.ctrl, c->ctrl_host, sizeof(Ctrl), hipMemcpyHostToDevice, c->stream));
     // weight scratch
-    c->ws.nwaves = ncap / kWave;
-    CTX_TRY(hipMalloc((void **) &c->ws.lcum, sizeof(float) * (size_t) ncap));
-    CTX_TRY(hipMalloc((void **) &c->ws.wave_w, sizeof(float) * (size_t) c->ws.nwaves));
-    CTX_TRY(hipMalloc((void **) &c->ws.wave_w2, sizeof(float) * (size_t) c->ws.nwaves));
-    CTX_TRY(hipMalloc((void **) &c->ws.wave_off, sizeof(double) * ((size_t) c->ws.nwaves + 1)));
-    CTX_TRY(hipMalloc((void **) &c->ws.keep, sizeof(int32_t) * (size_t) ncap));
-    CTX_TRY(hipMemsetAsync(c->ws.keep, 0, sizeof(int32_t) * (size_t) ncap, c->stream));
-    c->est_blocks = (n + 255) / 256;
-    CTX_TRY(hipMalloc((void **) &c->est_partials, sizeof(double) * 4 * (size_t) c->est_blocks + 16));
-    CTX_TRY(hipMemsetAsync(c->est_partials, 0, sizeof(double) * 4 * (size_t) c->est_blocks + 16, c->stream));
-    CTX_TRY(hipMalloc((void **) &c->bytes_dev, sizeof(double) * 2));
-    CTX_TRY(hipMemsetAsync(c->bytes_dev, 0, sizeof(double) * 2, c->stream));
-    // packet ring: header + idf[cap] + zf[2cap] + zn[2cap]
+    c->ws.nblocks = ncap / kBlock;
+    CTX_TRY(hipMalloc((void **) &c->ws.lcum, sizeof(float) * S));
+    CTX_TRY(hipMalloc((void **) &c->ws.blk_w, sizeof(float) * (size_t) c->ws.nblocks));
+    CTX_TRY(hipMalloc((void **) &c->ws.blk_w2, sizeof(float) * (size_t) c->ws.nblocks));
+    CTX_TRY(hipMalloc((void **) &c->ws.est_part, sizeof(double) * 4 * (size_t) c->ws.nblocks));
+    CTX_TRY(hipMalloc((void **) &c->ws.keep, sizeof(int32_t) * S));
+    CTX_TRY(hipMemsetAsync(c->ws.keep, 0, sizeof(int32_t) * S, c->stream));
+    CTX_TRY(hipMalloc((void **) &c->hist_dev, sizeof(double) * 4 * (size_t) kHistCap));
+    // big-packet ring: header + idf[cap] + zf[2cap] + zn[2cap]
     c->pkt_bytes = ((sizeof(ObsPacket) + sizeof(int32_t) * cap_nf + sizeof(float) * 4 * cap_nf) + 255) / 256 * 256;
     CTX_TRY(hipHostMalloc((void **) &c->pkt_host, c->pkt_bytes * kRing, hipHostMallocDefault));
     CTX_TRY(hipMalloc((void **) &c->pkt_dev, c->pkt_bytes * kRing));
     for (int i = 0; i < kRing; i++) CTX_TRY(hipEventCreateWithFlags(&c->pkt_ev[i], hipEventDisableTiming));
     if (cfg->rng_mode == SLAMGPU_RNG_TAPE) {
-        const size_t tape_floats = 3 * (size_t) ncap + (size_t) n_global(c);
+        const size_t tape_floats = 3 * S + (size_t) n_global(c);
         CTX_TRY(hipHostMalloc((void **) &c->tape_host, sizeof(float) * tape_floats, hipHostMallocDefault));
-        CTX_TRY(hipMalloc((void **) &c->normals_dev, sizeof(float) * 3 * (size_t) ncap));
+        CTX_TRY(hipMalloc((void **) &c->normals_dev, sizeof(float) * 3 * S));
         CTX_TRY(hipMalloc((void **) &c->strata_dev, sizeof(float) * (size_t) n_global(c)));
     }
     // initial particle set: Particle() then w = 1/N (ParticleSLAMWrapper.cpp:14-25)
     {
-        std::vector<float> w((size_t) ncap, 0.0f);
+        std::vector<float4> a(S, make_float4(0.f, 0.f, 0.f, 0.f));
         const float uw = (float) (1.0 / (float) n_global(c));
-        for (int i = 0; i < n; i++) w[i] = uw;
-        CTX_TRY(hipMemcpyAsync(c->B.pose[0] + 9 * (size_t) ncap, w.data(), sizeof(float) * (size_t) ncap, hipMemcpyHostToDevice, c->stream));
+        for (int i = 0; i < n; i++) a[i].w = uw;
+        CTX_TRY(hipMemcpyAsync(c->B.poseA[0], a.data(), sizeof(float4) * S, hipMemcpyHostToDevice, c->stream));
         CTX_TRY(hipStreamSynchronize(c->stream));
     }
 #undef CTX_TRY
@@ -261,31 +275,33 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
 
 void slamgpu_destroy(slamgpu_ctx *c) {
     if (!c) return;
-    hipSetDevice(c->cfg.device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    (void) hipSetDevice(c->cfg.device);
+    if (c->stream) (void) hipStreamSynchronize(c->stream);
     drain_stats(c);
-    for (auto e : c->ev_pool) hipEventDestroy(e);
+    for (auto e : c->ev_pool) (void) hipEventDestroy(e);
     for (int b = 0; b < 2; b++) {
-        if (c->B.pose[b]) hipFree(c->B.pose[b]);
-        if (c->B.lmk[b]) hipFree(c->B.lmk[b]);
+        if (c->B.poseA[b]) (void) hipFree(c->B.poseA[b]);
+        if (c->B.poseB[b]) (void) hipFree(c->B.poseB[b]);
+        if (c->B.poseC[b]) (void) hipFree(c->B.poseC[b]);
+        if (c->B.lmkA[b]) (void) hipFree(c->B.lmkA[b]);
+        if (c->B.lmkB[b]) (void) hipFree(c->B.lmkB[b]);
     }
-    if (c->B.ctrl) hipFree(c->B.ctrl);
-    if (c->ctrl_host) hipHostFree(c->ctrl_host);
-    if (c->ws.lcum) hipFree(c->ws.lcum);
-    if (c->ws.wave_w) hipFree(c->ws.wave_w);
-    if (c->ws.wave_w2) hipFree(c->ws.wave_w2);
-    if (c->ws.wave_off) hipFree(c->ws.wave_off);
-    if (c->ws.keep) hipFree(c->ws.keep);
-    if (c->est_partials) hipFree(c->est_partials);
-    if (c->bytes_dev) hipFree(c->bytes_dev);
-    if (c->pkt_host) hipHostFree(c->pkt_host);
-    if (c->pkt_dev) hipFree(c->pkt_dev);
+    if (c->B.ctrl) (void) hipFree(c->B.ctrl);
+    if (c->ctrl_host) (void) hipHostFree(c->ctrl_host);
+    if (c->ws.lcum) (void) hipFree(c->ws.lcum);
+    if (c->ws.blk_w) (void) hipFree(c->ws.blk_w);
+    if (c->ws.blk_w2) (void) hipFree(c->ws.blk_w2);
+    if (c->ws.est_part) (void) hipFree(c->ws.est_part);
+    if (c->ws.keep) (void) hipFree(c->ws.keep);
+    if (c->hist_dev) (void) hipFree(c->hist_dev);
+    if (c->pkt_host) (void) hipHostFree(c->pkt_host);
+    if (c->pkt_dev) (void) hipFree(c->pkt_dev);
     for (int i = 0; i < kRing; i++)
-        if (c->pkt_ev[i]) hipEventDestroy(c->pkt_ev[i]);
-    if (c->tape_host) hipHostFree(c->tape_host);
-    if (c->normals_dev) hipFree(c->normals_dev);
-    if (c->strata_dev) hipFree(c->strata_dev);
-    if (c->stream) hipStreamDestroy(c->stream);
+        if (c->pkt_ev[i]) (void) hipEventDestroy(c->pkt_ev[i]);
+    if (c->tape_host) (void) hipHostFree(c->tape_host);
+    if (c->normals_dev) (void) hipFree(c->normals_dev);
+    if (c->strata_dev) (void) hipFree(c->strata_dev);
+    if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -296,7 +312,7 @@ int slamgpu_predict(slamgpu_ctx *c, float V, float G, const float Q[4], float dt
     const bool tape_noise = noise && c->cfg.rng_mode == SLAMGPU_RNG_TAPE;
     if (tape_noise && !noise2) return fail(SLAMGPU_ERR_INVALID, "TAPE mode with add_predict_noise needs noise2[2N]");
     PredictArgs &P = c->pending;
-    // parameters must be uniform across a fused launch; flush when they change
+    // parameters must be uniform across a fused launch; flush when they change or the queue is full
     if (P.nsteps > 0 && (P.dt != dt || memcmp(P.Q, Q, sizeof P.Q) != 0 || P.nsteps == kMaxFusedPredict || tape_noise))
         if (int rc = flush_predict(c)) return rc;
     if (P.nsteps == 0) {
@@ -314,6 +330,7 @@ int slamgpu_predict(slamgpu_ctx *c, float V, float G, const float Q[4], float dt
     s.G = G;
     s.phi_true = phi_true;
     s.step = c->ctl_step;
+    c->est_fresh = false;
     if (tape_noise) {
         HIP_TRY(hipSetDevice(c->cfg.device));
         HIP_TRY(hipStreamSynchronize(c->stream));  // tape_host is single-buffered (parity mode only)
@@ -340,32 +357,59 @@ int slamgpu_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t 
     const bool need_normals = c->cfg.method == SLAMGPU_FASTSLAM2 && (m > 0 || n > 0);
     if (tape && ((need_normals && !normals) || !strata)) return fail(SLAMGPU_ERR_INVALID, "TAPE mode needs normals[3N] and strata[N]");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    if (int rc = flush_predict(c)) return rc;
     c->obs_step++;
 
-    // observation packet -> ring slot
-    const int slot = (int) (c->pkt_seq++ % kRing);
-    if (c->pkt_ev_used[slot]) HIP_TRY(hipEventSynchronize(c->pkt_ev[slot]));
-    char *ph = c->pkt_host + (size_t) slot * c->pkt_bytes;
-    ObsPacket *hp = reinterpret_cast<ObsPacket *>(ph);
-    hp->m = m;
-    hp->n = n;
-    hp->nf = c->nf;
-    hp->pad = 0;
-    memcpy(hp->R, R, sizeof hp->R);
-    int32_t *hidf = reinterpret_cast<int32_t *>(hp + 1);
-    float *hzf = reinterpret_cast<float *>(hidf + m);
-    float *hzn = hzf + 2 * m;
-    if (m) {
-        memcpy(hidf, idf, sizeof(int32_t) * m);
-        memcpy(hzf, zf, sizeof(float) * 2 * m);
+    UpdateArgs U{};
+    U.method = c->cfg.method;
+    U.m = m;
+    U.n = n;
+    U.nf = c->nf;
+    memcpy(U.R, R, sizeof U.R);
+    if (m <= kSmallObs && n <= kSmallObs) {
+        // small packet: rides in the kernel-argument segment, no staging copy on the stream
+        for (int k = 0; k < m; k++) {
+            U.small.idf[k] = idf[k];
+            U.small.zf[2 * k] = zf[2 * k];
+            U.small.zf[2 * k + 1] = zf[2 * k + 1];
+        }
+        for (int k = 0; k < n; k++) {
+            U.small.zn[2 * k] = zn[2 * k];
+            U.small.zn[2 * k + 1] = zn[2 * k + 1];
+        }
+        U.big = nullptr;
+    } else {
+        const int slot = (int) (c->pkt_seq++ % kRing);
+        if (c->pkt_ev_used[slot]) HIP_TRY(hipEventSynchronize(c->pkt_ev[slot]));
+        char *ph = c->pkt_host + (size_t) slot * c->pkt_bytes;
+        ObsPacket *hp = reinterpret_cast<ObsPacket *>(ph);
+        hp->m = m;
+        hp->n = n;
+        hp->nf = c->nf;
+        hp->pad = 0;
+        memcpy(hp->R, R, sizeof hp->R);
+        int32_t *hidf = reinterpret_cast<int32_t *>(hp + 1);
+        float *hzf = reinterpret_cast<float *>(hidf + m);
+        float *hzn = hzf + 2 * m;
+        if (m) {
+            memcpy(hidf, idf, sizeof(int32_t) * m);
+            memcpy(hzf, zf, sizeof(float) * 2 * m);
+        }
+        if (n) memcpy(hzn, zn, sizeof(float) * 2 * n);
+        const size_t used = sizeof(ObsPacket) + sizeof(int32_t) * m + sizeof(float) * 2 * (m + n);
+        char *pd = c->pkt_dev + (size_t) slot * c->pkt_bytes;
+        HIP_TRY(hipMemcpyAsync(pd, ph, used, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->pkt_ev[slot], c->stream));
+        c->pkt_ev_used[slot] = true;
+        U.big = reinterpret_cast<const ObsPacket *>(pd);
     }
-    if (n) memcpy(hzn, zn, sizeof(float) * 2 * n);
-    const size_t used = sizeof(ObsPacket) + sizeof(int32_t) * m + sizeof(float) * 2 * (m + n);
-    char *pd = c->pkt_dev + (size_t) slot * c->pkt_bytes;
-    HIP_TRY(hipMemcpyAsync(pd, ph, used, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipEventRecord(c->pkt_ev[slot], c->stream));
-    c->pkt_ev_used[slot] = true;
+
+    // pending predicts ride inside the update launch (state stays in registers) unless their noise is a host tape
+    PredictArgs PA{};
+    if (c->pending.nsteps > 0) {
+        PA = c->pending;
+        c->predict_bytes += 72.0 * c->cfg.n_particles * c->pending.nsteps;
+        c->pending.nsteps = 0;
+    }
 
     if (tape) {
         HIP_TRY(hipStreamSynchronize(c->stream));  // single-buffered tape staging (parity mode)
@@ -386,26 +430,20 @@ int slamgpu_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t 
     const RngArgs rng = rng_args(c, c->obs_step);
     {
         Timed t(c, c->cfg.method == SLAMGPU_FASTSLAM2 ? "fs2_update" : "fs1_update");
-        c->k->update(c->stream, c->B, c->cfg.method, reinterpret_cast<const ObsPacket *>(pd), m, n, c->nf, rng, c->ws);
-    }
-    {
-        Timed t(c, "weights_finalize");
-        c->k->finalize(c->stream, c->B, c->ws, c->cfg.resample, c->cfg.n_effective);
+        c->k->update(c->stream, c->B, PA, U, rng, c->ws);
     }
     c->nf += n;
+    ResampleArgs ra{};
+    ra.nf = c->nf;
+    ra.do_resample = c->cfg.resample;
+    ra.n_effective = c->cfg.n_effective;
+    ra.hist = c->hist_n < kHistCap ? c->hist_dev + 4 * (size_t) c->hist_n : nullptr;
     {
         Timed t(c, "resample");
-        c->k->resample(c->stream, c->B, c->ws, rng, c->nf);
+        c->k->resample(c->stream, c->B, c->ws, rng, ra);
     }
+    c->est_fresh = ra.hist != nullptr;
     HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-static int read_ctrl(slamgpu_ctx *c) {
-    HIP_TRY(hipSetDevice(c->cfg.device));
-    if (int rc = flush_predict(c)) return rc;
-    HIP_TRY(hipMemcpyAsync(c->ctrl_host, c->B.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -414,15 +452,51 @@ int slamgpu_estimate(slamgpu_ctx *c, double xyt[3]) {
     if (!xyt) return fail(SLAMGPU_ERR_INVALID, "null output");
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = flush_predict(c)) return rc;
-    {
+    if (!c->est_fresh) {
         Timed t(c, "estimate");
-        c->k->estimate(c->stream, c->B, c->est_partials, c->est_blocks);
+        c->k->estimate(c->stream, c->B, c->ws, nullptr);
     }
     HIP_TRY(hipGetLastError());
     if (int rc = read_ctrl(c)) return rc;
     xyt[0] = c->ctrl_host->est[0] / (double) c->B.n;
     xyt[1] = c->ctrl_host->est[1] / (double) c->B.n;
     xyt[2] = c->ctrl_host->est[2];
+    return 0;
+}
+
+int slamgpu_estimate_async(slamgpu_ctx *c) {
+    if (int rc = check_ctx(c)) return rc;
+    if (c->hist_n >= kHistCap) return fail(SLAMGPU_ERR_CAPACITY, "estimate history full (%d): call slamgpu_estimate_fetch", kHistCap);
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = flush_predict(c)) return rc;
+    if (!c->est_fresh) {
+        // the particle set changed since the last update (predicts / upload): reduce it now
+        Timed t(c, "estimate");
+        c->k->estimate(c->stream, c->B, c->ws, c->hist_dev + 4 * (size_t) c->hist_n);
+        HIP_TRY(hipGetLastError());
+    }
+    // else: the update's resample kernel already left this step's estimate in slot hist_n
+    c->hist_n++;
+    c->est_fresh = false;
+    return 0;
+}
+
+int slamgpu_estimate_fetch(slamgpu_ctx *c, double *xyt, int32_t max_count, int32_t *count) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!count) return fail(SLAMGPU_ERR_INVALID, "null count");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int n = c->hist_n < max_count ? c->hist_n : max_count;
+    std::vector<double> h((size_t) 4 * (n > 0 ? n : 1));
+    if (n > 0) HIP_TRY(hipMemcpy(h.data(), c->hist_dev, sizeof(double) * 4 * (size_t) n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n && xyt; i++) {
+        xyt[3 * i] = h[4 * (size_t) i] / (double) c->B.n;
+        xyt[3 * i + 1] = h[4 * (size_t) i + 1] / (double) c->B.n;
+        xyt[3 * i + 2] = h[4 * (size_t) i + 2];
+    }
+    *count = n;
+    c->hist_n = 0;
+    c->est_fresh = false;
     return 0;
 }
 
@@ -462,37 +536,45 @@ int slamgpu_download(slamgpu_ctx *c, float *xv, float *Pv9, float *w, float *xf,
     if (int rc = read_ctrl(c)) return rc;
     const int cur = c->ctrl_host->cur, N = c->B.n, nf = c->nf;
     const size_t S = (size_t) c->B.ncap;
-    std::vector<float> pose((size_t) kPoseRows * S);
-    HIP_TRY(hipMemcpy(pose.data(), c->B.pose[cur], sizeof(float) * pose.size(), hipMemcpyDeviceToHost));
+    std::vector<float4> pa(S), pb(S);
+    std::vector<float2> pc(S);
+    HIP_TRY(hipMemcpy(pa.data(), c->B.poseA[cur], sizeof(float4) * S, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pb.data(), c->B.poseB[cur], sizeof(float4) * S, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pc.data(), c->B.poseC[cur], sizeof(float2) * S, hipMemcpyDeviceToHost));
     for (int i = 0; i < N; i++) {
-        if (xv)
-            for (int k = 0; k < 3; k++) xv[3 * i + k] = pose[k * S + i];
+        if (xv) {
+            xv[3 * i] = pa[i].x;
+            xv[3 * i + 1] = pa[i].y;
+            xv[3 * i + 2] = pa[i].z;
+        }
         if (Pv9) {
-            const float p00 = pose[3 * S + i], p10 = pose[4 * S + i], p11 = pose[5 * S + i], p20 = pose[6 * S + i],
-                        p21 = pose[7 * S + i], p22 = pose[8 * S + i];
+            const float p00 = pb[i].x, p10 = pb[i].y, p11 = pb[i].z, p20 = pb[i].w, p21 = pc[i].x, p22 = pc[i].y;
             float *P = Pv9 + 9 * (size_t) i;
             P[0] = p00; P[1] = p10; P[2] = p20;
             P[3] = p10; P[4] = p11; P[5] = p21;
             P[6] = p20; P[7] = p21; P[8] = p22;
         }
-        if (w) w[i] = pose[9 * S + i];
+        if (w) w[i] = pa[i].w;
     }
     if ((xf || Pf4) && nf > 0) {
-        std::vector<float> lm((size_t) kLmkRows * nf * S);
-        HIP_TRY(hipMemcpy(lm.data(), c->B.lmk[cur], sizeof(float) * lm.size(), hipMemcpyDeviceToHost));
+        std::vector<float4> la(S * nf);
+        std::vector<float> lb(S * nf);
+        HIP_TRY(hipMemcpy(la.data(), c->B.lmkA[cur], sizeof(float4) * la.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(lb.data(), c->B.lmkB[cur], sizeof(float) * lb.size(), hipMemcpyDeviceToHost));
         for (int i = 0; i < N; i++)
             for (int j = 0; j < nf; j++) {
-                const float *b = lm.data() + (size_t) j * kLmkRows * S + i;
+                const float4 a = la[(size_t) j * S + i];
+                const float b = lb[(size_t) j * S + i];
                 if (xf) {
-                    xf[((size_t) i * nf + j) * 2] = b[0];
-                    xf[((size_t) i * nf + j) * 2 + 1] = b[S];
+                    xf[((size_t) i * nf + j) * 2] = a.x;
+                    xf[((size_t) i * nf + j) * 2 + 1] = a.y;
                 }
                 if (Pf4) {
                     float *P = Pf4 + ((size_t) i * nf + j) * 4;
-                    P[0] = b[2 * S];
-                    P[1] = b[3 * S];
-                    P[2] = b[3 * S];
-                    P[3] = b[4 * S];
+                    P[0] = a.z;
+                    P[1] = a.w;
+                    P[2] = a.w;
+                    P[3] = b;
                 }
             }
     }
@@ -503,42 +585,45 @@ int slamgpu_upload(slamgpu_ctx *c, int32_t nf, const float *xv, const float *Pv9
                    const float *Pf4) {
     if (int rc = check_ctx(c)) return rc;
     if (nf < 0 || nf > c->B.cap_nf) return fail(SLAMGPU_ERR_CAPACITY, "nf=%d exceeds capacity %d", nf, c->B.cap_nf);
+    if (nf > 0 && (!xf || !Pf4)) return fail(SLAMGPU_ERR_INVALID, "nf>0 needs xf and Pf");
     if (int rc = read_ctrl(c)) return rc;
     const int cur = c->ctrl_host->cur, N = c->B.n;
     const size_t S = (size_t) c->B.ncap;
-    std::vector<float> pose((size_t) kPoseRows * S);
-    HIP_TRY(hipMemcpy(pose.data(), c->B.pose[cur], sizeof(float) * pose.size(), hipMemcpyDeviceToHost));
+    std::vector<float4> pa(S), pb(S);
+    std::vector<float2> pc(S);
+    HIP_TRY(hipMemcpy(pa.data(), c->B.poseA[cur], sizeof(float4) * S, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pb.data(), c->B.poseB[cur], sizeof(float4) * S, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pc.data(), c->B.poseC[cur], sizeof(float2) * S, hipMemcpyDeviceToHost));
     for (int i = 0; i < N; i++) {
-        if (xv)
-            for (int k = 0; k < 3; k++) pose[k * S + i] = xv[3 * i + k];
+        if (xv) {
+            pa[i].x = xv[3 * i];
+            pa[i].y = xv[3 * i + 1];
+            pa[i].z = xv[3 * i + 2];
+        }
         if (Pv9) {  // lower triangle of the reference's full matrix
             const float *P = Pv9 + 9 * (size_t) i;
-            pose[3 * S + i] = P[0];
-            pose[4 * S + i] = P[3];
-            pose[5 * S + i] = P[4];
-            pose[6 * S + i] = P[6];
-            pose[7 * S + i] = P[7];
-            pose[8 * S + i] = P[8];
+            pb[i] = make_float4(P[0], P[3], P[4], P[6]);
+            pc[i] = make_float2(P[7], P[8]);
         }
-        if (w) pose[9 * S + i] = w[i];
+        if (w) pa[i].w = w[i];
     }
-    HIP_TRY(hipMemcpy(c->B.pose[cur], pose.data(), sizeof(float) * pose.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->B.poseA[cur], pa.data(), sizeof(float4) * S, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->B.poseB[cur], pb.data(), sizeof(float4) * S, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->B.poseC[cur], pc.data(), sizeof(float2) * S, hipMemcpyHostToDevice));
     if (nf > 0) {
-        if (!xf || !Pf4) return fail(SLAMGPU_ERR_INVALID, "nf>0 needs xf and Pf");
-        std::vector<float> lm((size_t) kLmkRows * nf * S, 0.0f);
+        std::vector<float4> la(S * nf, make_float4(0.f, 0.f, 0.f, 0.f));
+        std::vector<float> lb(S * nf, 0.0f);
         for (int i = 0; i < N; i++)
             for (int j = 0; j < nf; j++) {
-                float *b = lm.data() + (size_t) j * kLmkRows * S + i;
                 const float *P = Pf4 + ((size_t) i * nf + j) * 4;
-                b[0] = xf[((size_t) i * nf + j) * 2];
-                b[S] = xf[((size_t) i * nf + j) * 2 + 1];
-                b[2 * S] = P[0];
-                b[3 * S] = P[2];
-                b[4 * S] = P[3];
+                la[(size_t) j * S + i] = make_float4(xf[((size_t) i * nf + j) * 2], xf[((size_t) i * nf + j) * 2 + 1], P[0], P[2]);
+                lb[(size_t) j * S + i] = P[3];
             }
-        HIP_TRY(hipMemcpy(c->B.lmk[cur], lm.data(), sizeof(float) * lm.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->B.lmkA[cur], la.data(), sizeof(float4) * la.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->B.lmkB[cur], lb.data(), sizeof(float) * lb.size(), hipMemcpyHostToDevice));
     }
     c->nf = nf;
+    c->est_fresh = false;
     return 0;
 }
 
@@ -581,7 +666,7 @@ int slamgpu_jacobians(const float *in, uint32_t n, float *out) {
     HIP_TRY(hipMalloc((void **) &din, sizeof(float) * nin));
     hipError_t e = hipMalloc((void **) &dout, sizeof(float) * nout);
     if (e != hipSuccess) {
-        hipFree(din);
+        (void) hipFree(din);
         return fail(SLAMGPU_ERR_ALLOC, "hipMalloc: %s", hipGetErrorString(e));
     }
     int rc = 0;
@@ -591,8 +676,8 @@ int slamgpu_jacobians(const float *in, uint32_t n, float *out) {
         if ((e = hipGetLastError()) != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "launch: %s", hipGetErrorString(e));
     }
     if (!rc && (e = hipMemcpy(out, dout, sizeof(float) * nout, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "D2H: %s", hipGetErrorString(e));
-    hipFree(din);
-    hipFree(dout);
+    (void) hipFree(din);
+    (void) hipFree(dout);
     return rc;
 }
 

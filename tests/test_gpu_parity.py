@@ -195,7 +195,8 @@ def test_stepwise_vs_oracle(sg, oracle, method, N, seed, nobs):
             assert bad.mean() <= (0.04 if fs2 else 0.0), (tag, bad.mean())
         else:
             compare_state(r["got"], r["exp"], fs2=fs2, tag=tag)
-        np.testing.assert_allclose(r["est"][0][:2], r["est"][1][:2], atol=5e-4, err_msg=tag)
+        # after a resample a few particles may descend from a neighbouring ancestor (see header): mean moves by <= frac * spread
+        np.testing.assert_allclose(r["est"][0][:2], r["est"][1][:2], atol=1e-2 if r["did"][0] else 5e-4, err_msg=tag)
     drive_pair(sg, oracle, "example_webmap", method, N, seed, nobs, per_step=check)
 
 
