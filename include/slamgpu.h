@@ -75,6 +75,9 @@ typedef struct {
      * n_particles_global.  Single GPU: first_particle = 0, n_particles_global = n_particles (or 0). */
     int64_t first_particle;
     int64_t n_particles_global;
+    /* 0: the context creates its own HIP stream.  Otherwise a hipStream_t owned by the caller (e.g. the stream
+     * the caller's RCCL collectives are ordered on); the context launches on it and never destroys it. */
+    uint64_t external_stream;
 } slamgpu_config;
 
 const char *slamgpu_last_error(void);
@@ -130,6 +133,57 @@ int slamgpu_download(slamgpu_ctx *ctx, float *xv, float *Pv9, float *w, float *x
 int slamgpu_upload(slamgpu_ctx *ctx, int32_t nf, const float *xv, const float *Pv9, const float *w, const float *xf,
                    const float *Pf4);
 int slamgpu_sync(slamgpu_ctx *ctx);
+
+/* ---- sharded operation: particles partitioned over contexts (one per GPU) ---------------------------
+ * The reference has no multi-device path; this is the build's data-parallel extension of
+ * resampleParticles (core.cpp:718-824).  Shard g holds the contiguous global particles
+ * [g*n, (g+1)*n), n a multiple of 256.  The collectives belong to the caller (RCCL through
+ * torch.distributed in bench.py; any transport works, the buffers are plain device pointers):
+ *
+ *   1. slamgpu_shard_update        per-particle update only (the update half of slamgpu_update)
+ *   2. slamgpu_shard_block_totals  -> device pointers of this shard's per-256-particle totals of w and w^2;
+ *                                  ALL-GATHER them (4+4 B per 256 particles) into gblk_w / gblk_w2
+ *   3. slamgpu_shard_plan          every shard runs the same scan of the gathered totals => identical
+ *                                  sum w, Neff, decision and offspring boundaries K[0..G] on every shard
+ *                                  (results are independent of the number of shards)
+ *   4a. no resample: slamgpu_shard_finish normalises the weights
+ *   4b. resample   : slamgpu_shard_pack gathers this shard's offspring K[g]..K[g+1] into per-destination
+ *                    blocks; ALL-TO-ALL (send_counts/recv_counts in records of slamgpu_shard_record_floats
+ *                    floats); slamgpu_shard_unpack scatters what arrived; slamgpu_shard_finish commits
+ *   5. slamgpu_shard_estimate      local sum x, sum y, heading and weight of the local max-weight particle;
+ *                                  combine across shards in shard order (sum; strict > for the maximum)
+ */
+typedef struct {
+    double wsum, wsq;
+    float neff;
+    int32_t resampled;
+    int64_t K[65]; /* K[r] = first global output particle whose ancestor lives on shard r; K[G] = N */
+} slamgpu_shard_plan_t;
+
+int slamgpu_shard_update(slamgpu_ctx *ctx, const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n,
+                         const float R[4], const float *normals, const float *strata);
+int slamgpu_shard_block_totals(slamgpu_ctx *ctx, const float **blk_w_dev, const float **blk_w2_dev, int32_t *nblocks);
+int slamgpu_shard_plan(slamgpu_ctx *ctx, const float *gblk_w_dev, const float *gblk_w2_dev, int32_t nb_global,
+                       int32_t n_shards, slamgpu_shard_plan_t *out);
+int slamgpu_shard_record_floats(slamgpu_ctx *ctx);
+int slamgpu_shard_pack(slamgpu_ctx *ctx, const float *gblk_w_dev, const float *gblk_w2_dev, int32_t nb_global,
+                       int32_t n_shards, int32_t shard, const slamgpu_shard_plan_t *plan, float *send_dev,
+                       int64_t *send_counts, int64_t *recv_counts);
+int slamgpu_shard_unpack(slamgpu_ctx *ctx, const float *recv_dev, int32_t n_shards, int32_t shard,
+                         const slamgpu_shard_plan_t *plan);
+int slamgpu_shard_finish(slamgpu_ctx *ctx, const slamgpu_shard_plan_t *plan);
+int slamgpu_shard_estimate(slamgpu_ctx *ctx, double out[4]);
+/* asynchronous form: the 4 raw doubles (sum x, sum y, heading, max w) of each call are kept in the device-side
+ * history and fetched together (one synchronisation + one all-gather for many steps) */
+int slamgpu_shard_estimate_async(slamgpu_ctx *ctx);
+int slamgpu_shard_estimate_fetch(slamgpu_ctx *ctx, double *raw4, int32_t max_count, int32_t *count);
+/* Plain device-memory helpers for callers that have no allocator of their own (tests, the C++ host): buffers
+ * for the gathered block totals and the send / receive records.  copy is device-to-device, ordered on the
+ * context's stream and synchronised before returning. */
+int slamgpu_dev_alloc(slamgpu_ctx *ctx, uint64_t bytes, void **ptr);
+int slamgpu_dev_free(slamgpu_ctx *ctx, void *ptr);
+int slamgpu_dev_copy(slamgpu_ctx *ctx, void *dst, const void *src, uint64_t bytes);
+int slamgpu_dev_copy_async(slamgpu_ctx *ctx, void *dst, const void *src, uint64_t bytes); /* ordered on the stream, no wait */
 
 /* ---- measurement / plumbing ------------------------------------------------------------------------ */
 /* HIP stream the context launches on (hipStream_t as void*), so a harness can record events on it. */

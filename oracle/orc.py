@@ -203,6 +203,7 @@ class Particles:
         L.orc_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.orc_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_update_local.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         self.owned = handle is None
         self.h = C.c_void_p(L.orc_particles_create(N, cap)) if handle is None else handle
         self.N = L.orc_particles_n(self.h)
@@ -245,6 +246,13 @@ class Particles:
         self.L.orc_update(self.h, C.byref(algo), _p(zf), _p(idf), zf.shape[0], _p(zn), zn.shape[0],
                           _p(np.ascontiguousarray(R, f32)), _p(normals), _p(sel), _p(keep), C.byref(neff), C.byref(did))
         return keep, f32(neff.value), bool(did.value)
+
+    def update_local(self, algo, zf, idf, zn, R, normals):
+        zf = np.ascontiguousarray(zf, f32).reshape(-1, 2)
+        zn = np.ascontiguousarray(zn, f32).reshape(-1, 2)
+        idf = np.ascontiguousarray(idf, np.int32)
+        self.L.orc_update_local(self.h, C.byref(algo), _p(zf), _p(idf), zf.shape[0], _p(zn), zn.shape[0],
+                                _p(np.ascontiguousarray(R, f32)), _p(normals))
 
     def close(self):
         if self.owned and self.h:

@@ -906,9 +906,9 @@ void orc_predict(orc_particles *p, const orc_algo *a, float V, float G, const fl
     }
 }
 
-void orc_update(orc_particles *p, const orc_algo *a, const float *zf, const int *idf, int m, const float *zn, int n,
-                const float *R4, const float *normals, const float *sel, int *keep_out, float *neff_out,
-                int *resampled_out) {
+void orc_update_local(orc_particles *p, const orc_algo *a, const float *zf, const int *idf, int m, const float *zn, int n,
+                      const float *R4, const float *normals) {
+    /* the per-particle loop of FastSLAM{1,2}::update, without resampleParticles */
     int N = p->N;
     if (p->nf + n > p->cap) {
         fprintf(stderr, "orc_update: landmark capacity exceeded (%d + %d > %d)\n", p->nf, n, p->cap);
@@ -944,6 +944,13 @@ void orc_update(orc_particles *p, const orc_algo *a, const float *zf, const int 
         }
     }
     p->nf += n;
+}
+
+void orc_update(orc_particles *p, const orc_algo *a, const float *zf, const int *idf, int m, const float *zn, int n,
+                const float *R4, const float *normals, const float *sel, int *keep_out, float *neff_out,
+                int *resampled_out) {
+    int N = p->N;
+    orc_update_local(p, a, zf, idf, m, zn, n, R4, normals);
 
     /* resampleParticles (core.cpp:718-749) */
     float *w = (float *) malloc(sizeof(float) * (size_t) N);

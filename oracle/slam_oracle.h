@@ -97,6 +97,10 @@ void orc_update(orc_particles *p, const orc_algo *a, const float *zf, const int 
                 const float *R4, const float *normals, const float *sel, int *keep_out, float *neff_out,
                 int *resampled_out);
 
+/* The per-particle loop of the update only (no resampleParticles): used by the sharded-path tests. */
+void orc_update_local(orc_particles *p, const orc_algo *a, const float *zf, const int *idf, int m, const float *zn, int n,
+                      const float *R4, const float *normals);
+
 /* ---- host front end (simulator) ----------------------------------------------------------- */
 typedef struct orc_sim orc_sim;
 /* Same CLI surface as slam-backend: -m map -method M -KEY value ... (SLAMBackendApplication.cpp:59-89). */

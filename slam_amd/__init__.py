@@ -3,8 +3,8 @@ include/slamgpu.h).  This Python package is only the test/bench binding over tha
 is slam_amd/libslamgpu.so (+ the C++ host driver slam_amd/bin/slam-backend).  There is no CPU or
 PyTorch fallback: importing works anywhere, but every compute call needs the built library and a GPU.
 """
-from .capi import (Config, SlamGpu, SlamGpuError, FASTSLAM1, FASTSLAM2, RNG_TAPE, RNG_PHILOX, MATH_STRICT, MATH_FAST,
+from .capi import (Config, ShardPlan, SlamGpu, SlamGpuError, FASTSLAM1, FASTSLAM2, RNG_TAPE, RNG_PHILOX, MATH_STRICT, MATH_FAST,
                    lib_path, load_library, jacobians, device_count, DECLARED_SYMBOLS)
 
-__all__ = ["Config", "SlamGpu", "SlamGpuError", "FASTSLAM1", "FASTSLAM2", "RNG_TAPE", "RNG_PHILOX", "MATH_STRICT",
+__all__ = ["Config", "ShardPlan", "SlamGpu", "SlamGpuError", "FASTSLAM1", "FASTSLAM2", "RNG_TAPE", "RNG_PHILOX", "MATH_STRICT",
            "MATH_FAST", "lib_path", "load_library", "jacobians", "device_count", "DECLARED_SYMBOLS"]

@@ -16,7 +16,10 @@ DECLARED_SYMBOLS = [
     "slamgpu_last_error", "slamgpu_abi_version", "slamgpu_device_count", "slamgpu_jacobians", "slamgpu_create",
     "slamgpu_destroy", "slamgpu_predict", "slamgpu_update", "slamgpu_estimate", "slamgpu_estimate_async", "slamgpu_estimate_fetch", "slamgpu_stats", "slamgpu_ancestors",
     "slamgpu_num_landmarks", "slamgpu_download", "slamgpu_upload", "slamgpu_sync", "slamgpu_stream", "slamgpu_profile",
-    "slamgpu_kernel_time", "slamgpu_algorithmic_bytes",
+    "slamgpu_kernel_time", "slamgpu_algorithmic_bytes", "slamgpu_shard_update", "slamgpu_shard_block_totals", "slamgpu_shard_plan",
+    "slamgpu_shard_record_floats", "slamgpu_shard_pack", "slamgpu_shard_unpack", "slamgpu_shard_finish", "slamgpu_shard_estimate",
+    "slamgpu_dev_alloc", "slamgpu_dev_free", "slamgpu_dev_copy", "slamgpu_dev_copy_async", "slamgpu_shard_estimate_async",
+    "slamgpu_shard_estimate_fetch",
 ]
 
 
@@ -31,7 +34,12 @@ class Config(C.Structure):
                 ("max_landmarks", C.c_int32), ("use_heading", C.c_int32), ("add_predict_noise", C.c_int32),
                 ("resample", C.c_int32), ("n_effective", C.c_int32), ("wheel_base", C.c_float), ("sigma_phi", C.c_float),
                 ("rng_mode", C.c_int32), ("math_mode", C.c_int32), ("seed", C.c_uint64), ("first_particle", C.c_int64),
-                ("n_particles_global", C.c_int64)]
+                ("n_particles_global", C.c_int64), ("external_stream", C.c_uint64)]
+
+
+class ShardPlan(C.Structure):
+    """slamgpu_shard_plan_t"""
+    _fields_ = [("wsum", C.c_double), ("wsq", C.c_double), ("neff", C.c_float), ("resampled", C.c_int32), ("K", C.c_int64 * 65)]
 
 
 def lib_path():
@@ -73,6 +81,21 @@ def load_library():
     L.slamgpu_profile.argtypes = [C.c_void_p, C.c_int32]
     L.slamgpu_kernel_time.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.slamgpu_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.slamgpu_shard_update.argtypes = L.slamgpu_update.argtypes
+    L.slamgpu_shard_block_totals.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
+    L.slamgpu_shard_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(ShardPlan)]
+    L.slamgpu_shard_record_floats.argtypes = [C.c_void_p]
+    L.slamgpu_shard_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(ShardPlan), C.c_void_p,
+                                     C.c_void_p, C.c_void_p]
+    L.slamgpu_shard_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(ShardPlan)]
+    L.slamgpu_shard_finish.argtypes = [C.c_void_p, C.POINTER(ShardPlan)]
+    L.slamgpu_shard_estimate.argtypes = [C.c_void_p, C.c_void_p]
+    L.slamgpu_dev_alloc.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+    L.slamgpu_dev_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.slamgpu_dev_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.slamgpu_dev_copy_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.slamgpu_shard_estimate_async.argtypes = [C.c_void_p]
+    L.slamgpu_shard_estimate_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     _lib = L
     return L
 
@@ -117,7 +140,7 @@ class SlamGpu:
 
     def __init__(self, n_particles, max_landmarks, method=FASTSLAM2, n_effective=None, resample=True, use_heading=False,
                  add_predict_noise=None, wheel_base=4.0, sigma_phi=0.017453292519943, rng_mode=RNG_TAPE, seed=0,
-                 math_mode=MATH_STRICT, device=0, first_particle=0, n_particles_global=0):
+                 math_mode=MATH_STRICT, device=0, first_particle=0, n_particles_global=0, external_stream=0):
         self.L = load_library()
         cfg = Config()
         cfg.struct_size = C.sizeof(Config)
@@ -137,6 +160,7 @@ class SlamGpu:
         cfg.seed = seed
         cfg.first_particle = first_particle
         cfg.n_particles_global = ng
+        cfg.external_stream = external_stream
         self.cfg = cfg
         self.N = n_particles
         self.h = C.c_void_p()
@@ -212,6 +236,69 @@ class SlamGpu:
 
     def sync(self):
         _chk(self.L.slamgpu_sync(self.h))
+
+    # ---- sharded operation (include/slamgpu.h "sharded operation") ----
+    def shard_update(self, zf, idf, zn, R, normals=None, strata=None):
+        zf = _f32(zf).reshape(-1, 2)
+        zn = _f32(zn).reshape(-1, 2)
+        idf = np.ascontiguousarray(idf, np.int32)
+        R = _f32(R, 4)
+        nm = None if normals is None else _f32(normals, (self.N, 3))
+        st = None if strata is None else _f32(strata)
+        _chk(self.L.slamgpu_shard_update(self.h, _ptr(zf), _ptr(idf), zf.shape[0], _ptr(zn), zn.shape[0], _ptr(R), _ptr(nm), _ptr(st)))
+
+    def shard_block_totals(self):
+        w, w2, nb = C.c_void_p(), C.c_void_p(), C.c_int32()
+        _chk(self.L.slamgpu_shard_block_totals(self.h, C.byref(w), C.byref(w2), C.byref(nb)))
+        return w.value, w2.value, nb.value
+
+    def shard_plan(self, gw_ptr, gw2_ptr, nb_global, n_shards):
+        plan = ShardPlan()
+        _chk(self.L.slamgpu_shard_plan(self.h, gw_ptr, gw2_ptr, nb_global, n_shards, C.byref(plan)))
+        return plan
+
+    def record_floats(self):
+        return self.L.slamgpu_shard_record_floats(self.h)
+
+    def shard_pack(self, gw_ptr, gw2_ptr, nb_global, n_shards, shard, plan, send_ptr):
+        sc = np.zeros(n_shards, np.int64)
+        rc = np.zeros(n_shards, np.int64)
+        _chk(self.L.slamgpu_shard_pack(self.h, gw_ptr, gw2_ptr, nb_global, n_shards, shard, C.byref(plan), send_ptr, _ptr(sc), _ptr(rc)))
+        return sc, rc
+
+    def shard_unpack(self, recv_ptr, n_shards, shard, plan):
+        _chk(self.L.slamgpu_shard_unpack(self.h, recv_ptr, n_shards, shard, C.byref(plan)))
+
+    def shard_finish(self, plan):
+        _chk(self.L.slamgpu_shard_finish(self.h, C.byref(plan)))
+
+    def shard_estimate(self):
+        e = np.zeros(4, np.float64)
+        _chk(self.L.slamgpu_shard_estimate(self.h, _ptr(e)))
+        return e
+
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        _chk(self.L.slamgpu_dev_alloc(self.h, nbytes, C.byref(p)))
+        return p.value
+
+    def dev_free(self, ptr):
+        _chk(self.L.slamgpu_dev_free(self.h, ptr))
+
+    def dev_copy(self, dst, src, nbytes, wait=True):
+        if wait:
+            _chk(self.L.slamgpu_dev_copy(self.h, dst, src, nbytes))
+        else:
+            _chk(self.L.slamgpu_dev_copy_async(self.h, dst, src, nbytes))
+
+    def shard_estimate_async(self):
+        _chk(self.L.slamgpu_shard_estimate_async(self.h))
+
+    def shard_estimate_fetch(self, max_count=4096):
+        out = np.zeros((max_count, 4), np.float64)
+        n = C.c_int32()
+        _chk(self.L.slamgpu_shard_estimate_fetch(self.h, _ptr(out), max_count, C.byref(n)))
+        return out[:n.value].copy()
 
     def stream(self):
         return self.L.slamgpu_stream(self.h)

@@ -104,6 +104,37 @@ struct ResampleArgs {
     double *hist;           // pose-estimate history slot (4 doubles) or null
 };
 
+// ---- sharded resampling (see kernels.hip) ---------------------------------------------------------------
+constexpr int kMaxShards = 64;
+
+struct ShardPlan {           // written by shard_plan_kernel, read back by the host
+    double wsum, wsq;
+    float neff;
+    int32_t resampled;
+    int64_t K[kMaxShards + 1];  // K[r] = first global output particle whose ancestor lives on shard r
+};
+
+struct ShardPlanArgs {
+    const float *gblk_w, *gblk_w2;  // all-gathered block totals [nb_global]
+    int32_t nb_global, nb_per_shard, n_shards;
+    int32_t do_resample, n_effective;
+};
+
+struct ShardPackArgs {
+    const float *gblk_w, *gblk_w2;
+    int32_t nb_global, first_block;  // this shard's first block in the global numbering
+    int64_t k_lo, k_hi;              // offspring [K[g], K[g+1]) of this shard
+    int64_t n_per_shard;
+    int32_t nf, fields;              // fields = 10 + 5*nf floats per record
+    float *send;                     // device buffer, (k_hi-k_lo)*fields floats
+};
+
+struct ShardUnpackArgs {
+    const float *recv;               // device buffer, n_local*fields floats, blocks in source-shard order
+    int32_t n_shards, nf, fields, pad;
+    int64_t src_lo[kMaxShards + 1];  // local output index boundaries per source shard
+};
+
 struct KernelTable {
     // K1: [fused predicts] + per-particle observation update + in-block weight prefix / totals
     void (*update)(hipStream_t, const Buffers &, const PredictArgs &, const UpdateArgs &, const RngArgs &,
@@ -113,6 +144,10 @@ struct KernelTable {
     void (*predict)(hipStream_t, const Buffers &, const PredictArgs &, const RngArgs &);
     void (*estimate)(hipStream_t, const Buffers &, const WeightScratch &, double *hist);
     void (*jacobians)(hipStream_t, const float *in_dev, uint32_t n, float *out_dev);
+    void (*shard_plan)(hipStream_t, const ShardPlanArgs &, const RngArgs &, ShardPlan *out_dev);
+    void (*shard_pack)(hipStream_t, const Buffers &, const WeightScratch &, const ShardPackArgs &, const RngArgs &);
+    void (*shard_unpack)(hipStream_t, const Buffers &, const WeightScratch &, const ShardUnpackArgs &);
+    void (*shard_finish)(hipStream_t, const Buffers &, double W, double Q, float neff, int resampled);
 };
 
 const KernelTable *kernels_strict();

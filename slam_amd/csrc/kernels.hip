@@ -414,34 +414,18 @@ SLAM_DEV void finish_estimate(const Buffers &B, const WeightScratch &ws, double 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// K3: resampleParticles (core.cpp:718-749) + the per-step pose estimate (ParticleSLAMWrapper.cpp:56-77).
-// Every block redundantly scans the block totals (LDS, double) => sum w, sum w^2, Neff and the decision
-// `doResample && Neff < nMin` without a separate launch or a host round trip.
-//   no resample: w_i /= sum(w) (core.cpp:726-729)
-//   resample   : ancestor of output k = min{ i : select_k < cumsum_i } (core.cpp:800-806) by a two-level
-//                binary search (block offsets in LDS, in-block prefix in HBM), gather-copy of the whole
-//                particle from the live buffers into the other set, w = 1/N (:744-747); blockIdx.y splits
-//                the landmarks.  The last block to finish reduces the estimate partials and flips Ctrl.cur.
-// ---------------------------------------------------------------------------------------------------
-constexpr int kLmkPerBlockY = 8;
-
-__global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScratch ws, RngArgs rng, ResampleArgs ra) {
-    extern __shared__ double off[];  // [nblocks + 1] exclusive prefix of the block totals
-    __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
-    __shared__ EstItem sh_est[kBlock / kWave];
-    Ctrl *ctrl = B.ctrl;
+// Exclusive prefix (double) of the block totals into LDS `off[0..nb]`, plus sum w and sum w^2.  Every block of
+// every kernel (and every rank of a sharded run, which sees the same all-gathered totals) executes exactly
+// this association, so W, Q, Neff, the resample decision and all ancestors are identical everywhere.
+SLAM_DEV void scan_block_totals(const float *__restrict__ blk_w, const float *__restrict__ blk_w2, int nb, double *off,
+                                double *sh_a, double *sh_q, double &W, double &Q) {
     const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
-    const int nb = ws.nblocks;
-    const int cur = ctrl->cur;
-
-    // ---- scan of the block totals --------------------------------------------------------------------
     const int per = (nb + kBlock - 1) / kBlock;
     const int lo = min(nb, t * per), hi = min(nb, lo + per);
     double a = 0.0, q = 0.0;
     for (int k = lo; k < hi; k++) {
-        a += (double) ws.blk_w[k];
-        q += (double) ws.blk_w2[k];
+        a += (double) blk_w[k];
+        q += (double) blk_w2[k];
     }
     double sa = a;
 #pragma unroll
@@ -462,11 +446,65 @@ __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScrat
     double run = base + sa - a;  // exclusive prefix of this thread's segment
     for (int k = lo; k < hi; k++) {
         off[k] = run;
-        run += (double) ws.blk_w[k];
+        run += (double) blk_w[k];
     }
-    const double W = ((sh_a[0] + sh_a[1]) + sh_a[2]) + sh_a[3];
-    const double Q = ((sh_q[0] + sh_q[1]) + sh_q[2]) + sh_q[3];
+    W = ((sh_a[0] + sh_a[1]) + sh_a[2]) + sh_a[3];
+    Q = ((sh_q[0] + sh_q[1]) + sh_q[2]) + sh_q[3];
     if (t == 0) off[nb] = W;
+}
+
+// stratum of global output particle gid: the caller's tape, or (gid + u)/N with u from Philox stream 1
+SLAM_DEV float stratum(const RngArgs &rng, int64_t gid) {
+    if (rng.mode == 0) return rng.strata[gid];
+    U4 r = philox4x32((uint32_t) gid, rng.step, 1u, 0u, rng.k0, rng.k1);
+    const double u = ((double) (r.x >> 8) + 0.5) * (1.0 / 16777216.0);
+    return (float) (((double) gid + u) / (double) rng.n_global);
+}
+
+// ancestor (global particle index) of a stratum: min{ i : target < cumsum_i }, two-level binary search
+SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const float *__restrict__ lcum_local,
+                               int first_block, int nb_local, int64_t n_global) {
+    int b0 = 0, b1 = nb;
+    while (b0 < b1) {
+        const int mid = (b0 + b1) >> 1;
+        if (off[mid + 1] > target) b1 = mid; else b0 = mid + 1;
+    }
+    if (b0 >= nb) return n_global - 1;  // select beyond the last cumulative weight: undefined upstream (keep = -1), clamp
+    // the in-block prefix is only resident for this shard's blocks; callers only ask for strata they own
+    const int lb = min(max(b0 - first_block, 0), nb_local - 1);
+    const double o = off[b0];
+    const float *lc = lcum_local + (size_t) lb * kBlock;
+    int l0 = 0, l1 = kBlock - 1;  // first slot with o + lc > target; the last slot if rounding hides it
+    while (l0 < l1) {
+        const int mid = (l0 + l1) >> 1;
+        if (o + (double) lc[mid] > target) l1 = mid; else l0 = mid + 1;
+    }
+    return min((int64_t) b0 * kBlock + l0, n_global - 1);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K3: resampleParticles (core.cpp:718-749) + the per-step pose estimate (ParticleSLAMWrapper.cpp:56-77).
+// Every block redundantly scans the block totals (LDS, double) => sum w, sum w^2, Neff and the decision
+// `doResample && Neff < nMin` without a separate launch or a host round trip.
+//   no resample: w_i /= sum(w) (core.cpp:726-729)
+//   resample   : ancestor of output k = min{ i : select_k < cumsum_i } (core.cpp:800-806) by a two-level
+//                binary search (block offsets in LDS, in-block prefix in HBM), gather-copy of the whole
+//                particle from the live buffers into the other set, w = 1/N (:744-747); blockIdx.y splits
+//                the landmarks.  The last block to finish reduces the estimate partials and flips Ctrl.cur.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kLmkPerBlockY = 8;
+
+__global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScratch ws, RngArgs rng, ResampleArgs ra) {
+    extern __shared__ double off[];  // [nblocks + 1] exclusive prefix of the block totals
+    __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
+    __shared__ EstItem sh_est[kBlock / kWave];
+    Ctrl *ctrl = B.ctrl;
+    const int t = threadIdx.x;
+    const int nb = ws.nblocks;
+    const int cur = ctrl->cur;
+
+    double W, Q;
+    scan_block_totals(ws.blk_w, ws.blk_w2, nb, off, sh_a, sh_q, W, Q);
     // Neff = 1 / sum((w/W)^2)  (core.cpp:784-788)
     const float neff = (float) ((W * W) / Q);
     const bool resample = ra.do_resample && (neff < (float) ra.n_effective);
@@ -490,35 +528,8 @@ __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScrat
             ei = EstItem{(double) pa.x, (double) pa.y, pa.w, pa.z, k};
         }
     } else if (active) {
-        const int64_t gid = rng.first_particle + k;
-        float sel;
-        if (rng.mode == 0) {
-            sel = rng.strata[gid];
-        } else {
-            U4 r = philox4x32((uint32_t) gid, rng.step, 1u, 0u, rng.k0, rng.k1);
-            const double u = ((double) (r.x >> 8) + 0.5) * (1.0 / 16777216.0);
-            sel = (float) (((double) gid + u) / (double) rng.n_global);
-        }
-        const double target = (double) sel * W;
-        // block holding the ancestor: first b with off[b+1] > target
-        int b0 = 0, b1 = nb;
-        while (b0 < b1) {
-            const int mid = (b0 + b1) >> 1;
-            if (off[mid + 1] > target) b1 = mid; else b0 = mid + 1;
-        }
-        int anc;
-        if (b0 >= nb) {
-            anc = B.n - 1;  // select beyond the last cumulative weight: undefined upstream (keep = -1), clamp
-        } else {
-            const double o = off[b0];
-            const float *lc = ws.lcum + (size_t) b0 * kBlock;
-            int l0 = 0, l1 = kBlock - 1;  // first slot with o + lc > target; the last slot if rounding hides it
-            while (l0 < l1) {
-                const int mid = (l0 + l1) >> 1;
-                if (o + (double) lc[mid] > target) l1 = mid; else l0 = mid + 1;
-            }
-            anc = min(b0 * kBlock + l0, B.n - 1);
-        }
+        const double target = (double) stratum(rng, (int64_t) k) * W;
+        const int anc = (int) min(find_ancestor(target, off, nb, ws.lcum, 0, nb, (int64_t) B.n), (int64_t) B.n - 1);
         const size_t S = (size_t) B.ncap;
         if (blockIdx.y == 0) {
             float4 pa = B.poseA[cur][anc];
@@ -618,8 +629,152 @@ __global__ void __launch_bounds__(kBlock) jacobians_kernel(const float *__restri
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Sharded resampling (particles partitioned over contexts / GPUs in contiguous blocks of 256).  The host
+// layer all-gathers the per-block totals (4 B + 4 B per 256 particles); every shard then runs the same
+// scan, so the decision and every ancestor are independent of the number of shards.
+//   shard_plan   : W, Q, Neff, decision and K[r] = first output particle whose ancestor lives on shard r
+//   shard_pack   : offspring k in [K[g], K[g+1]) of this shard, gathered into per-destination blocks
+//                  [dst][field][slot] (field-major => coalesced on both sides), fields = 10 + 5*nf floats
+//   shard_unpack : blocks received from each source shard scattered into the spare buffers, w = 1/N
+//   shard_normalize : no resample: w /= W
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) shard_plan_kernel(ShardPlanArgs A, RngArgs rng, ShardPlan *out) {
+    extern __shared__ double off[];
+    __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
+    double W, Q;
+    scan_block_totals(A.gblk_w, A.gblk_w2, A.nb_global, off, sh_a, sh_q, W, Q);
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t == 0) {
+        const float neff = (float) ((W * W) / Q);
+        out->wsum = W;
+        out->wsq = Q;
+        out->neff = neff;
+        out->resampled = (A.do_resample && (neff < (float) A.n_effective)) ? 1 : 0;
+    }
+    // K[r] = #{ k : stratum_k * W < C_r },  C_r = off[r * nb_per_shard]; strata are increasing in k
+    for (int r = t; r <= A.n_shards; r += kBlock) {
+        int64_t lo = 0, hi = rng.n_global;
+        if (r == 0) {
+            hi = 0;
+        } else if (r == A.n_shards) {
+            lo = hi;
+        } else {
+            const double C = off[min(r * A.nb_per_shard, A.nb_global)];
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if ((double) stratum(rng, mid) * W < C) lo = mid + 1; else hi = mid;
+            }
+        }
+        out->K[r] = lo;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) shard_pack_kernel(Buffers B, WeightScratch ws, ShardPackArgs A, RngArgs rng) {
+    extern __shared__ double off[];
+    __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
+    double W, Q;
+    scan_block_totals(A.gblk_w, A.gblk_w2, A.nb_global, off, sh_a, sh_q, W, Q);
+    __syncthreads();
+    const int64_t j = (int64_t) blockIdx.x * kBlock + threadIdx.x;  // offspring slot of this shard
+    const int64_t k = A.k_lo + j;
+    if (k >= A.k_hi) return;
+    const int cur = B.ctrl->cur;
+    const size_t S = (size_t) B.ncap;
+    const double target = (double) stratum(rng, k) * W;
+    const int64_t ganc = find_ancestor(target, off, A.nb_global, ws.lcum, A.first_block, ws.nblocks, rng.n_global);
+    const int anc = (int) min(max(ganc - rng.first_particle, (int64_t) 0), (int64_t) B.n - 1);
+    // destination block: d = k / n_per_shard ; slot within it = k - max(K_lo, d*n_per_shard)
+    const int d = (int) (k / A.n_per_shard);
+    const int64_t blk_lo = max(A.k_lo, (int64_t) d * A.n_per_shard);
+    const int64_t blk_hi = min(A.k_hi, (int64_t) (d + 1) * A.n_per_shard);
+    const int64_t cnt = blk_hi - blk_lo, slot = k - blk_lo;
+    float *__restrict__ dst = A.send + (size_t) (blk_lo - A.k_lo) * A.fields + slot;  // block base = records before it
+    if (blockIdx.y == 0) {
+        const float4 pa = B.poseA[cur][anc], pb = B.poseB[cur][anc];
+        const float2 pc = B.poseC[cur][anc];
+        dst[0 * cnt] = pa.x; dst[1 * cnt] = pa.y; dst[2 * cnt] = pa.z;
+        dst[3 * cnt] = pb.x; dst[4 * cnt] = pb.y; dst[5 * cnt] = pb.z; dst[6 * cnt] = pb.w;
+        dst[7 * cnt] = pc.x; dst[8 * cnt] = pc.y;
+        dst[9 * cnt] = __int_as_float((int) ganc);  // ancestor id (keep[]); the weight is reset to 1/N on arrival
+    }
+    const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(A.nf, j0 + kLmkPerBlockY);
+    for (int l = j0; l < j1; l++) {
+        const float4 la = B.lmkA[cur][(size_t) l * S + anc];
+        const float lb = B.lmkB[cur][(size_t) l * S + anc];
+        float *f = dst + (size_t) (10 + 5 * l) * cnt;
+        f[0] = la.x; f[cnt] = la.y; f[2 * cnt] = la.z; f[3 * cnt] = la.w; f[4 * cnt] = lb;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightScratch ws, ShardUnpackArgs A) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;  // local output particle
+    if (i >= B.n) return;
+    const int cur = B.ctrl->cur;
+    const size_t S = (size_t) B.ncap;
+    // source block: the s with src_lo[s] <= i < src_lo[s+1] (local output index boundaries, increasing)
+    int s = 0;
+    while (s + 1 < A.n_shards && i >= A.src_lo[s + 1]) s++;
+    const int64_t cnt = A.src_lo[s + 1] - A.src_lo[s], slot = i - A.src_lo[s];
+    const float *__restrict__ src = A.recv + (size_t) A.src_lo[s] * A.fields + slot;
+    if (blockIdx.y == 0) {
+        B.poseA[cur ^ 1][i] = make_float4(src[0], src[cnt], src[2 * cnt], B.ctrl->inv_n);
+        B.poseB[cur ^ 1][i] = make_float4(src[3 * cnt], src[4 * cnt], src[5 * cnt], src[6 * cnt]);
+        B.poseC[cur ^ 1][i] = make_float2(src[7 * cnt], src[8 * cnt]);
+        ws.keep[i] = __float_as_int(src[9 * cnt]);
+    }
+    const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(A.nf, j0 + kLmkPerBlockY);
+    for (int l = j0; l < j1; l++) {
+        const float *f = src + (size_t) (10 + 5 * l) * cnt;
+        B.lmkA[cur ^ 1][(size_t) l * S + i] = make_float4(f[0], f[cnt], f[2 * cnt], f[3 * cnt]);
+        B.lmkB[cur ^ 1][(size_t) l * S + i] = f[4 * cnt];
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) shard_normalize_kernel(Buffers B, double W) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B.n) return;
+    float4 *pa = B.poseA[B.ctrl->cur] + i;
+    pa->w = pa->w / (float) W;
+}
+
+// records the outcome of a sharded update in Ctrl (and commits the flip after an unpack)
+__global__ void shard_commit_kernel(Buffers B, double W, double Q, float neff, int resampled) {
+    Ctrl *c = B.ctrl;
+    c->wsum = W;
+    c->wsq = Q;
+    c->neff = neff;
+    c->resampled = resampled;
+    if (resampled) c->cur ^= 1;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------
+static void launch_shard_plan(hipStream_t st, const ShardPlanArgs &A, const RngArgs &rng, ShardPlan *out) {
+    const size_t lds = sizeof(double) * ((size_t) A.nb_global + 1);
+    hipLaunchKernelGGL(shard_plan_kernel, dim3(1), dim3(kBlock), lds, st, A, rng, out);
+}
+
+static void launch_shard_pack(hipStream_t st, const Buffers &B, const WeightScratch &ws, const ShardPackArgs &A,
+                              const RngArgs &rng) {
+    const int64_t cnt = A.k_hi - A.k_lo;
+    if (cnt <= 0) return;
+    const int gy = A.nf > 0 ? (A.nf + kLmkPerBlockY - 1) / kLmkPerBlockY : 1;
+    const size_t lds = sizeof(double) * ((size_t) A.nb_global + 1);
+    hipLaunchKernelGGL(shard_pack_kernel, dim3((unsigned) ((cnt + kBlock - 1) / kBlock), gy), dim3(kBlock), lds, st, B, ws, A, rng);
+}
+
+static void launch_shard_unpack(hipStream_t st, const Buffers &B, const WeightScratch &ws, const ShardUnpackArgs &A) {
+    const int gy = A.nf > 0 ? (A.nf + kLmkPerBlockY - 1) / kLmkPerBlockY : 1;
+    hipLaunchKernelGGL(shard_unpack_kernel, dim3(B.ncap / kBlock, gy), dim3(kBlock), 0, st, B, ws, A);
+}
+
+static void launch_shard_finish(hipStream_t st, const Buffers &B, double W, double Q, float neff, int resampled) {
+    if (!resampled) hipLaunchKernelGGL(shard_normalize_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B, W);
+    hipLaunchKernelGGL(shard_commit_kernel, dim3(1), dim3(1), 0, st, B, W, Q, neff, resampled);
+}
+
 static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &PA, const UpdateArgs &U,
                           const RngArgs &rng, const WeightScratch &ws) {
     const int grid = B.ncap / kBlock;
@@ -650,7 +805,8 @@ static void launch_jacobians(hipStream_t st, const float *in, uint32_t n, float 
     hipLaunchKernelGGL(jacobians_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, in, n, out);
 }
 
-static const KernelTable kTable = {launch_update, launch_resample, launch_predict, launch_estimate, launch_jacobians};
+static const KernelTable kTable = {launch_update, launch_resample, launch_predict, launch_estimate, launch_jacobians,
+                                   launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish};
 
 }  // namespace SLAM_KNS
 

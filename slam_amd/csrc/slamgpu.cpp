@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -83,6 +84,8 @@ struct slamgpu_ctx {
     std::map<std::string, KernelStat> stats;
     std::vector<hipEvent_t> ev_pool;
     double predict_bytes = 0;
+    bool own_stream = true;
+    ShardPlan *plan_dev = nullptr, *plan_host = nullptr;  // sharded resampling plan (device + pinned mirror)
 };
 
 namespace {
@@ -221,7 +224,14 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
             return rc_;                                                                                \
         }                                                                                              \
     } while (0)
-    CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (cfg->external_stream) {
+        c->stream = reinterpret_cast<hipStream_t>(cfg->external_stream);
+        c->own_stream = false;
+    } else {
+        CTX_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    }
+    CTX_TRY(hipMalloc((void **) &c->plan_dev, sizeof(ShardPlan)));
+    CTX_TRY(hipHostMalloc((void **) &c->plan_host, sizeof(ShardPlan), hipHostMallocDefault));
     const size_t S = (size_t) ncap;
     for (int b = 0; b < 2; b++) {
         CTX_TRY(hipMalloc((void **) &c->B.poseA[b], sizeof(float4) * S));
@@ -301,7 +311,9 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     if (c->tape_host) (void) hipHostFree(c->tape_host);
     if (c->normals_dev) (void) hipFree(c->normals_dev);
     if (c->strata_dev) (void) hipFree(c->strata_dev);
-    if (c->stream) (void) hipStreamDestroy(c->stream);
+    if (c->plan_dev) (void) hipFree(c->plan_dev);
+    if (c->plan_host) (void) hipHostFree(c->plan_host);
+    if (c->stream && c->own_stream) (void) hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -345,9 +357,13 @@ int slamgpu_predict(slamgpu_ctx *c, float V, float G, const float Q[4], float dt
     return 0;
 }
 
-int slamgpu_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n,
-                   const float R[4], const float *normals, const float *strata) {
-    if (int rc = check_ctx(c)) return rc;
+}  // extern "C"
+
+namespace {
+
+// FastSLAM{1,2}::update: the per-particle stage, then (single-context case) the resampling stage
+int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n,
+              const float R[4], const float *normals, const float *strata, bool sharded) {
     if (m < 0 || n < 0 || !R || (m > 0 && (!zf || !idf)) || (n > 0 && !zn)) return fail(SLAMGPU_ERR_INVALID, "bad observation packet");
     if (m > c->nf) return fail(SLAMGPU_ERR_INVALID, "m=%d re-observed landmarks but only %d known", m, c->nf);
     if (c->nf + n > c->B.cap_nf) return fail(SLAMGPU_ERR_CAPACITY, "landmark capacity exceeded: %d + %d > %d", c->nf, n, c->B.cap_nf);
@@ -433,6 +449,12 @@ int slamgpu_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t 
         c->k->update(c->stream, c->B, PA, U, rng, c->ws);
     }
     c->nf += n;
+    if (sharded) {
+        // the resampling stage is driven by the caller through slamgpu_shard_* (needs collectives)
+        c->est_fresh = false;
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     ResampleArgs ra{};
     ra.nf = c->nf;
     ra.do_resample = c->cfg.resample;
@@ -444,6 +466,213 @@ int slamgpu_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t 
     }
     c->est_fresh = ra.hist != nullptr;
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int slamgpu_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n,
+                   const float R[4], const float *normals, const float *strata) {
+    if (int rc = check_ctx(c)) return rc;
+    if (c->cfg.n_particles_global != c->cfg.n_particles)
+        return fail(SLAMGPU_ERR_INVALID, "this context is a shard (%d of %lld particles): use slamgpu_shard_update + slamgpu_shard_*",
+                    c->cfg.n_particles, (long long) c->cfg.n_particles_global);
+    return do_update(c, zf, idf, m, zn, n, R, normals, strata, false);
+}
+
+// ---- sharded operation -------------------------------------------------------------------------------
+int slamgpu_shard_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n,
+                         const float R[4], const float *normals, const float *strata) {
+    if (int rc = check_ctx(c)) return rc;
+    if (c->cfg.n_particles % kBlock != 0 || c->cfg.first_particle % kBlock != 0)
+        return fail(SLAMGPU_ERR_INVALID, "shards must hold a multiple of %d particles", kBlock);
+    return do_update(c, zf, idf, m, zn, n, R, normals, strata, true);
+}
+
+int slamgpu_shard_block_totals(slamgpu_ctx *c, const float **blk_w_dev, const float **blk_w2_dev, int32_t *nblocks) {
+    if (int rc = check_ctx(c)) return rc;
+    if (blk_w_dev) *blk_w_dev = c->ws.blk_w;
+    if (blk_w2_dev) *blk_w2_dev = c->ws.blk_w2;
+    if (nblocks) *nblocks = c->ws.nblocks;
+    return 0;
+}
+
+int slamgpu_shard_record_floats(slamgpu_ctx *c) { return c ? 10 + 5 * c->nf : SLAMGPU_ERR_INVALID; }
+
+int slamgpu_shard_plan(slamgpu_ctx *c, const float *gw, const float *gw2, int32_t nb_global, int32_t n_shards,
+                       slamgpu_shard_plan_t *out) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!gw || !gw2 || !out) return fail(SLAMGPU_ERR_INVALID, "null argument");
+    if (n_shards < 1 || n_shards > kMaxShards) return fail(SLAMGPU_ERR_INVALID, "n_shards %d out of range [1,%d]", n_shards, kMaxShards);
+    if (nb_global > kMaxScanBlocks || nb_global % n_shards != 0 || (int64_t) nb_global * kBlock != n_global(c))
+        return fail(SLAMGPU_ERR_INVALID, "nb_global %d inconsistent with %lld particles over %d shards", nb_global, (long long) n_global(c), n_shards);
+    static_assert(sizeof(slamgpu_shard_plan_t) == sizeof(ShardPlan), "public / device plan layout");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    ShardPlanArgs A{};
+    A.gblk_w = gw;
+    A.gblk_w2 = gw2;
+    A.nb_global = nb_global;
+    A.nb_per_shard = nb_global / n_shards;
+    A.n_shards = n_shards;
+    A.do_resample = c->cfg.resample;
+    A.n_effective = c->cfg.n_effective;
+    {
+        Timed t(c, "shard_plan");
+        c->k->shard_plan(c->stream, A, rng_args(c, c->obs_step), c->plan_dev);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->plan_host, c->plan_dev, sizeof(ShardPlan), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    memcpy(out, c->plan_host, sizeof(ShardPlan));
+    return 0;
+}
+
+int slamgpu_shard_pack(slamgpu_ctx *c, const float *gw, const float *gw2, int32_t nb_global, int32_t n_shards,
+                       int32_t shard, const slamgpu_shard_plan_t *plan, float *send_dev, int64_t *send_counts,
+                       int64_t *recv_counts) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!gw || !gw2 || !plan || !send_counts || !recv_counts) return fail(SLAMGPU_ERR_INVALID, "null argument");
+    if (shard < 0 || shard >= n_shards || n_shards > kMaxShards) return fail(SLAMGPU_ERR_INVALID, "bad shard index");
+    const int64_t n = c->cfg.n_particles;
+    const int64_t k_lo = plan->K[shard], k_hi = plan->K[shard + 1];
+    // records this shard sends to d / receives from s: overlaps of offspring ranges with output ranges
+    for (int d = 0; d < n_shards; d++) {
+        const int64_t a = std::max(k_lo, (int64_t) d * n), b = std::min(k_hi, (int64_t) (d + 1) * n);
+        send_counts[d] = b > a ? b - a : 0;
+        const int64_t ra = std::max(plan->K[d], (int64_t) shard * n), rb = std::min(plan->K[d + 1], (int64_t) (shard + 1) * n);
+        recv_counts[d] = rb > ra ? rb - ra : 0;
+    }
+    if (k_hi > k_lo && !send_dev) return fail(SLAMGPU_ERR_INVALID, "null send buffer");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    ShardPackArgs A{};
+    A.gblk_w = gw;
+    A.gblk_w2 = gw2;
+    A.nb_global = nb_global;
+    A.first_block = (int32_t) (c->cfg.first_particle / kBlock);
+    A.k_lo = k_lo;
+    A.k_hi = k_hi;
+    A.n_per_shard = n;
+    A.nf = c->nf;
+    A.fields = 10 + 5 * c->nf;
+    A.send = send_dev;
+    {
+        Timed t(c, "shard_pack");
+        c->k->shard_pack(c->stream, c->B, c->ws, A, rng_args(c, c->obs_step));
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int slamgpu_shard_unpack(slamgpu_ctx *c, const float *recv_dev, int32_t n_shards, int32_t shard,
+                         const slamgpu_shard_plan_t *plan) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!recv_dev || !plan) return fail(SLAMGPU_ERR_INVALID, "null argument");
+    if (shard < 0 || shard >= n_shards || n_shards > kMaxShards) return fail(SLAMGPU_ERR_INVALID, "bad shard index");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const int64_t n = c->cfg.n_particles, first = (int64_t) shard * n;
+    ShardUnpackArgs A{};
+    A.recv = recv_dev;
+    A.n_shards = n_shards;
+    A.nf = c->nf;
+    A.fields = 10 + 5 * c->nf;
+    for (int s = 0; s <= n_shards; s++) A.src_lo[s] = std::min(std::max(plan->K[s] - first, (int64_t) 0), n);
+    {
+        Timed t(c, "shard_unpack");
+        c->k->shard_unpack(c->stream, c->B, c->ws, A);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int slamgpu_shard_finish(slamgpu_ctx *c, const slamgpu_shard_plan_t *plan) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!plan) return fail(SLAMGPU_ERR_INVALID, "null plan");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    {
+        Timed t(c, "shard_finish");
+        c->k->shard_finish(c->stream, c->B, plan->wsum, plan->wsq, plan->neff, plan->resampled);
+    }
+    c->est_fresh = false;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int slamgpu_dev_alloc(slamgpu_ctx *c, uint64_t bytes, void **ptr) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!ptr) return fail(SLAMGPU_ERR_INVALID, "null pointer");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    hipError_t e = hipMalloc(ptr, bytes ? bytes : 4);
+    if (e != hipSuccess) return fail(SLAMGPU_ERR_ALLOC, "hipMalloc(%llu): %s", (unsigned long long) bytes, hipGetErrorString(e));
+    return 0;
+}
+
+int slamgpu_dev_free(slamgpu_ctx *c, void *ptr) {
+    if (int rc = check_ctx(c)) return rc;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (ptr) HIP_TRY(hipFree(ptr));
+    return 0;
+}
+
+int slamgpu_dev_copy(slamgpu_ctx *c, void *dst, const void *src, uint64_t bytes) {
+    if (int rc = check_ctx(c)) return rc;
+    if (bytes == 0) return 0;
+    if (!dst || !src) return fail(SLAMGPU_ERR_INVALID, "null pointer");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int slamgpu_dev_copy_async(slamgpu_ctx *c, void *dst, const void *src, uint64_t bytes) {
+    if (int rc = check_ctx(c)) return rc;
+    if (bytes == 0) return 0;
+    if (!dst || !src) return fail(SLAMGPU_ERR_INVALID, "null pointer");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+int slamgpu_shard_estimate_async(slamgpu_ctx *c) {
+    if (int rc = check_ctx(c)) return rc;
+    if (c->hist_n >= kHistCap) return fail(SLAMGPU_ERR_CAPACITY, "estimate history full (%d)", kHistCap);
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = flush_predict(c)) return rc;
+    {
+        Timed t(c, "estimate");
+        c->k->estimate(c->stream, c->B, c->ws, c->hist_dev + 4 * (size_t) c->hist_n);
+    }
+    c->hist_n++;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int slamgpu_shard_estimate_fetch(slamgpu_ctx *c, double *raw4, int32_t max_count, int32_t *count) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!count) return fail(SLAMGPU_ERR_INVALID, "null count");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int n = c->hist_n < max_count ? c->hist_n : max_count;
+    if (n > 0 && raw4) HIP_TRY(hipMemcpy(raw4, c->hist_dev, sizeof(double) * 4 * (size_t) n, hipMemcpyDeviceToHost));
+    *count = n;
+    c->hist_n = 0;
+    c->est_fresh = false;
+    return 0;
+}
+
+int slamgpu_shard_estimate(slamgpu_ctx *c, double out[4]) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!out) return fail(SLAMGPU_ERR_INVALID, "null output");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = flush_predict(c)) return rc;
+    {
+        Timed t(c, "estimate");
+        c->k->estimate(c->stream, c->B, c->ws, nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    if (int rc = read_ctrl(c)) return rc;
+    for (int i = 0; i < 4; i++) out[i] = c->ctrl_host->est[i];
     return 0;
 }
 

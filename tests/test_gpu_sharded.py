@@ -1,0 +1,101 @@
+"""Sharded path on one GPU: G logical shards (G slamgpu contexts + LocalComm) must reproduce the single-context
+result exactly — same Neff, same decision, same ancestors, bit-identical particle state — for any G."""
+import numpy as np
+import pytest
+
+from conftest import sim_args
+
+pytestmark = pytest.mark.gpu
+N = 2048
+NOBS = 24
+
+
+@pytest.fixture(scope="module")
+def tape():
+    from slam_amd import host
+    return host.make_tape(sim_args("example_webmap", "FASTSLAM2", N, 7), max_obs=NOBS)
+
+
+def run_single(sg, tape, rng_mode, tapes=None):
+    s = sg.SlamGpu(N, tape["nlm"], method=sg.FASTSLAM2, n_effective=int(0.75 * N), rng_mode=rng_mode, seed=7)
+    out = []
+    for k, st in enumerate(tape["steps"]):
+        for (V, G, phi) in st["controls"]:
+            s.predict(V, G, tape["Q"], float(tape["dt"]), phi)
+        if tapes:
+            s.update(st["zf"], st["idf"], st["zn"], tape["R"], tapes[k][0], tapes[k][1])
+        else:
+            s.update(st["zf"], st["idf"], st["zn"], tape["R"])
+        ne, did, ws = s.stats()
+        d = s.download()
+        out.append(dict(neff=ne, res=did, wsum=ws, est=s.estimate(), keep=s.ancestors(), **d))
+    s.close()
+    return out
+
+
+def run_sharded(sg, tape, G, rng_mode, tapes=None):
+    from slam_amd.sharded import GpuEngine, LocalComm, ShardedFilter
+    n = N // G
+    eng = [GpuEngine(g, G, n, tape["nlm"], method=sg.FASTSLAM2, n_effective=int(0.75 * N), rng_mode=rng_mode, seed=7) for g in range(G)]
+    flt = ShardedFilter(eng, LocalComm(eng), G)
+    out = []
+    for k, st in enumerate(tape["steps"]):
+        for (V, Gs, phi) in st["controls"]:
+            flt.predict(V, Gs, tape["Q"], float(tape["dt"]), phi)
+        if tapes:
+            normals = [tapes[k][0][g * n:(g + 1) * n] for g in range(G)]
+            plan = flt.update(st["zf"], st["idf"], st["zn"], tape["R"], normals, tapes[k][1])
+        else:
+            plan = flt.update(st["zf"], st["idf"], st["zn"], tape["R"])
+        ds = [e.ctx.download() for e in eng]
+        cat = lambda key: np.concatenate([d[key] for d in ds])
+        keep = np.concatenate([e.ctx.ancestors() if plan.resampled else np.arange(g * n, (g + 1) * n, dtype=np.int32)
+                               for g, e in enumerate(eng)])
+        out.append(dict(neff=np.float32(plan.neff), res=bool(plan.resampled), wsum=plan.wsum, est=flt.estimate(), keep=keep,
+                        xv=cat("xv"), Pv=cat("Pv"), w=cat("w"), xf=cat("xf"), Pf=cat("Pf")))
+    moved = flt.exchanged_records
+    flt.close()
+    return out, moved
+
+
+@pytest.mark.parametrize("G", [2, 4, 8])
+def test_logical_shards_match_single_context_philox(tape, G):
+    import slam_amd as sg
+    ref = run_single(sg, tape, sg.RNG_PHILOX)
+    got, moved = run_sharded(sg, tape, G, sg.RNG_PHILOX)
+    assert any(r["res"] for r in ref) and moved > 0
+    for k, (a, b) in enumerate(zip(ref, got)):
+        assert a["res"] == b["res"] and a["neff"] == b["neff"] and a["wsum"] == b["wsum"], k
+        assert np.array_equal(a["keep"], b["keep"]), k
+        for key in ("xv", "Pv", "w", "xf", "Pf"):
+            assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), (k, key)
+        assert np.allclose(a["est"], b["est"], rtol=0, atol=1e-12), k
+
+
+def test_logical_shards_match_single_context_tape(tape):
+    import slam_amd as sg
+    rng = np.random.default_rng(5)
+    tapes = []
+    for st in tape["steps"]:
+        normals = rng.normal(size=(N, 3)).astype(np.float32)
+        sel = ((np.arange(N) + rng.uniform(size=N)) / N).astype(np.float32)
+        tapes.append((normals, sel))
+    ref = run_single(sg, tape, sg.RNG_TAPE, tapes)
+    got, _ = run_sharded(sg, tape, 4, sg.RNG_TAPE, tapes)
+    for k, (a, b) in enumerate(zip(ref, got)):
+        assert a["res"] == b["res"] and a["neff"] == b["neff"], k
+        assert np.array_equal(a["keep"], b["keep"]), k
+        for key in ("xv", "w", "xf"):
+            assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), (k, key)
+
+
+def test_torch_runtime_coexists():
+    """bench.py --gpus N imports torch (its bundled HIP runtime) BEFORE libslamgpu so that both share one runtime;
+    checked in a fresh process (this one has already initialised /opt/rocm's runtime through libslamgpu)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "coexist_check.py"), "torch_first"], cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "COEXIST_OK" in r.stdout, r.stdout + r.stderr
