@@ -230,3 +230,60 @@ def test_free_running_statistics(sg, oracle):
     o.close()
     assert first_div is None or first_div > 3, first_div  # identical (to 1 mm) at least until ancestors first differ
     assert np.mean(err_g) < 1.5 * np.mean(err_o) + 0.05, (np.mean(err_g), np.mean(err_o))
+
+
+def test_many_landmarks_big_packet_path(sg, oracle, tmp_path):
+    """BASELINE config 5 shape in miniature: a synthetic uniform map (400 landmarks on the webmap bounding box,
+    MAX_RANGE 60 => dozens of re-observed landmarks per step) drives the device-resident packet path (m, n > 12),
+    blockIdx.y > 1 in the resample gather, and landmark capacity growth; checked per step against the oracle."""
+    import shutil
+    from conftest import DATA
+    from slam_amd import host
+    import os
+    # NB the reference's float32 weight is a product of ~90 per re-observed landmark (1/(2*pi*sqrt(det R))): it overflows
+    # to inf (and normalises to NaN) beyond ~20 landmarks per step, so config 5's m ~ 1.3k is outside what the
+    # reference arithmetic can represent; this test stays in the representable range (m ~ 14) and treats any
+    # non-finite reference weight as "must be non-finite on the GPU too".
+    lm = host.synthetic_landmarks(12345, 1000, -130, 100, -100, 90)
+    _, wp = host.HostSim(sim_args("example_webmap", "FASTSLAM2", 100, 7)).map()
+    mp = str(tmp_path / "syn400.mat")
+    host.write_map(mp, lm, wp)
+    ini = open(os.path.join(DATA, "example_webmap.ini")).read().replace("MAX_RANGE           = 60.0", "MAX_RANGE           = 20.0")
+    open(str(tmp_path / "syn400.ini"), "w").write(ini)
+    N = 512
+    args = ["-m", mp, "-method", "FASTSLAM2", "-NPARTICLES", N, "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", 3]
+    o = oracle.sim(args)
+    algo = o.algo()
+    Q, R, dt = o.noise()
+    s = sg.SlamGpu(N, o.nlm, method=2, n_effective=algo.n_effective, wheel_base=algo.wheel_base, rng_mode=sg.RNG_TAPE)
+    k, max_m = 0, 0
+    while k < 10:
+        a = o.control()
+        x, vg = o.true_pose()
+        s.predict(float(vg[0]), float(vg[1]), Q, float(dt), float(x[2]))
+        if a == 1:
+            o.observe()
+            ob = o.last_obs()
+            normals, sel = o.last_tape()
+            s.update(ob["zf"], ob["idf"], ob["zn"], R, normals, sel)
+            k += 1
+            max_m = max(max_m, ob["zf"].shape[0], ob["zn"].shape[0])
+            got, exp = s.download(), o.particles()
+            ne_o, did_o = o.last_resample()
+            ne_g, did_g, _ = s.stats()
+            assert did_g == did_o and got["nf"] == exp["nf"], k
+            if did_g:
+                bad = np.abs(got["xv"] - exp["xv"]).max(axis=1) > POSE_ATOL
+                assert bad.mean() <= 0.05, (k, bad.mean())
+            else:
+                assert np.abs(got["xv"] - exp["xv"]).max() <= POSE_ATOL
+                assert np.abs(got["xf"] - exp["xf"]).max() <= 2e-3
+                fin = np.isfinite(exp["w"]) & (exp["w"] > 0)
+                assert np.array_equal(np.isfinite(got["w"]), np.isfinite(exp["w"])), k
+                if fin.any():
+                    rel = np.abs(got["w"][fin].astype(np.float64) / exp["w"][fin] - 1)
+                    assert np.median(rel) <= 5e-3, (k, np.median(rel))
+            s.upload(exp)
+    assert max_m > 12  # the big-packet path was exercised
+    s.close()
+    o.close()
