@@ -51,6 +51,14 @@ int slamhost_sim_last_z(const slamhost_sim *s, float *z, int32_t *vis, int32_t *
 void slamhost_sim_true(const slamhost_sim *s, float x[3]);
 int64_t slamhost_sim_control_steps(const slamhost_sim *s);
 
+/* EKF-SLAM on the host CPU (-method EKF1; BASELINE config 1): EKFSLAMWrapper::run's loop body
+ * (wrappers/ekfslamwrapper.cpp:50-84) = control(), observation when due, EKFSLAM::sim (algorithms/ekfslam.cpp:17-43). */
+typedef struct slamhost_ekf slamhost_ekf;
+slamhost_ekf *slamhost_ekf_create(const slamhost_sim *s);
+void slamhost_ekf_destroy(slamhost_ekf *e);
+int slamhost_ekf_step(slamhost_ekf *e, slamhost_sim *s); /* -1 finished, 0 control step, 1 with observation */
+int slamhost_ekf_state(const slamhost_ekf *e, float *x, float *P, int32_t cap); /* returns dim; P row-major, ld = cap */
+
 /* libc rand() tape in the reference's draw order */
 void slamhost_draw_normals(int32_t count, int32_t dim, float *out); /* count x randn(dim,1): dim+1 rand() each */
 int32_t slamhost_draw_strata(int32_t N, float *out);                /* returns the reference's strata count (== N when supported) */

@@ -1,6 +1,7 @@
 // Host-side front end: config, map, vehicle/sensor simulation, known data association, libc-rand tape.
 // float32 arithmetic in the reference's order (the observation tape must be reproducible draw for draw).
 #include "frontend.h"
+#include "ekfslam.h"
 
 #include <algorithm>
 #include <cctype>
@@ -487,6 +488,50 @@ int slamhost_sim_last_z(const slamhost_sim *s, float *z, int32_t *vis, int32_t *
 
 void slamhost_sim_true(const slamhost_sim *s, float x[3]) { memcpy(x, s->sim.xTrue, 3 * sizeof(float)); }
 int64_t slamhost_sim_control_steps(const slamhost_sim *s) { return s->sim.control_steps; }
+
+struct slamhost_ekf {
+    slamhost::EkfSlam ekf;
+    std::vector<float> table;
+};
+
+slamhost_ekf *slamhost_ekf_create(const slamhost_sim *s) {
+    if (!s) return nullptr;
+    slamhost_ekf *e = new slamhost_ekf();
+    const slamhost::Conf &c = s->sim.conf;
+    e->ekf.enableBatchUpdate = c.SWITCH_BATCH_UPDATE == 1;
+    e->ekf.useHeading = c.SWITCH_HEADING_KNOWN == 1;
+    e->ekf.wheelBase = c.WHEELBASE;
+    e->ekf.gateReject = c.GATE_REJECT;
+    e->ekf.gateAugment = c.GATE_AUGMENT;
+    e->ekf.associationKnown = c.SWITCH_ASSOCIATION_KNOWN;
+    e->ekf.sigmaPhi = c.sigmaT;
+    e->table.assign((size_t) s->sim.map.nlm, -1.0f);
+    return e;
+}
+
+void slamhost_ekf_destroy(slamhost_ekf *e) { delete e; }
+
+int slamhost_ekf_step(slamhost_ekf *e, slamhost_sim *s) {
+    if (!e || !s) return -1;
+    slamhost::Simulator &sim = s->sim;
+    const int r = sim.control();
+    if (r < 0) return r;
+    if (r == 1) sim.observe();
+    const float phi = (float) (sim.xTrue[2] + sim.conf.sigmaT * slamhost::unif_rand());
+    e->ekf.sim(sim.Vnoisy, sim.Gnoisy, sim.Qe, sim.dt, phi, sim.z, sim.vis, sim.Re, r == 1, sim.R, e->table);
+    return r;
+}
+
+int slamhost_ekf_state(const slamhost_ekf *e, float *x, float *P, int32_t cap) {
+    if (!e) return -1;
+    const int d = (int) e->ekf.x.size();
+    for (int i = 0; i < d && i < cap; i++) {
+        if (x) x[i] = e->ekf.x[i];
+        if (P)
+            for (int j = 0; j < d && j < cap; j++) P[(size_t) i * cap + j] = e->ekf.P(i, j);
+    }
+    return d;
+}
 
 void slamhost_draw_normals(int32_t count, int32_t dim, float *out) {
     for (int32_t i = 0; i < count; i++) slamhost::randn(dim, 1, out + (size_t) i * dim);

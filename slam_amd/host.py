@@ -11,7 +11,8 @@ DECLARED_SYMBOLS = [
     "slamhost_last_error", "slamhost_sim_create", "slamhost_sim_destroy", "slamhost_sim_conf", "slamhost_sim_map",
     "slamhost_sim_control", "slamhost_sim_observe", "slamhost_sim_last_z", "slamhost_sim_true",
     "slamhost_sim_control_steps", "slamhost_draw_normals", "slamhost_draw_strata", "slamhost_unif_rand",
-    "slamhost_synthetic_landmarks", "slamhost_write_map",
+    "slamhost_synthetic_landmarks", "slamhost_write_map", "slamhost_ekf_create", "slamhost_ekf_destroy", "slamhost_ekf_step",
+    "slamhost_ekf_state",
 ]
 
 
@@ -60,6 +61,12 @@ def load_library():
         L.slamhost_synthetic_landmarks.argtypes = [C.c_uint64, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]
         L.slamhost_synthetic_landmarks.restype = None
         L.slamhost_write_map.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.slamhost_ekf_create.restype = C.c_void_p
+        L.slamhost_ekf_create.argtypes = [C.c_void_p]
+        L.slamhost_ekf_destroy.argtypes = [C.c_void_p]
+        L.slamhost_ekf_destroy.restype = None
+        L.slamhost_ekf_step.argtypes = [C.c_void_p, C.c_void_p]
+        L.slamhost_ekf_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
         _lib = L
     return _lib
 
@@ -141,6 +148,28 @@ class HostSim:
     def noise(self):
         f = lambda a: np.array(list(a), np.float32).reshape(2, 2)
         return f(self.conf.Qe), f(self.conf.Re), np.float32(self.conf.DT_CONTROLS)
+
+
+class HostEkf:
+    """EKF-SLAM on the host CPU (-method EKF1): EKFSLAMWrapper's loop body over a HostSim."""
+
+    def __init__(self, sim):
+        self.L, self.sim = sim.L, sim
+        self.h = C.c_void_p(self.L.slamhost_ekf_create(sim.h))
+
+    def step(self):
+        return self.L.slamhost_ekf_step(self.h, self.sim.h)
+
+    def state(self, cap=128, want_P=True):
+        x = np.zeros(cap, np.float32)
+        P = np.zeros((cap, cap), np.float32) if want_P else None
+        d = self.L.slamhost_ekf_state(self.h, _p(x), _p(P), cap)
+        return x[:d].copy(), (P[:d, :d].copy() if want_P else None)
+
+    def close(self):
+        if self.h:
+            self.L.slamhost_ekf_destroy(self.h)
+            self.h = None
 
 
 def make_tape(args, max_obs=None):

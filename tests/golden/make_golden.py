@@ -297,6 +297,31 @@ def main():
     a = args("example_loop1", "FASTSLAM2", 50, 3)
     ref, snaps, preds, meta = run_pair(R, O, a, {2, 30}, 400, pred_snaps={1, 2, 30})
     save_traj("traj_fs2_loop1_N50_s3", ref, snaps, preds, meta)
+    make_ekf(R, "traj_ekf_loop1_s3", "example_loop1", 3)
+    make_ekf(R, "traj_ekf_webmap_s7", "example_webmap", 7)
+
+
+def make_ekf(R, name, mapname, seed, extra=()):
+    """EKF-SLAM (config 1) reference run: pose, state dimension and trace(P) after every control step."""
+    a = ["-m", os.path.join(ROOT, "data", mapname + ".mat"), "-method", "EKF1", "-SWITCH_SEED_RANDOM", seed] + list(extra)
+    r = R.sim(a)
+    xs, dims, trs, obs, true = [], [], [], [], []
+    while True:
+        k = r.step()
+        if k < 0:
+            break
+        x, P = r.ekf_state()
+        xs.append(x[:3].copy())
+        dims.append(x.shape[0])
+        trs.append(float(np.trace(P.astype(np.float64))))
+        obs.append(k)
+        true.append(r.true_pose()[0])
+    x, P = r.ekf_state()
+    r.close()
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, x=np.stack(xs).astype(f32), dim=np.array(dims, np.int32), trace=np.array(trs), observed=np.array(obs, np.int8),
+                        true=np.stack(true).astype(f32), final_x=x, final_P=P)
+    print(name, "control steps", len(xs), "final dim", dims[-1], "%.0f KB" % (os.path.getsize(path) / 1024))
 
 
 if __name__ == "__main__":

@@ -117,3 +117,47 @@ def test_synthetic_map_roundtrip(tmp_path):
     lm2, wp2 = s.map()
     assert np.allclose(lm2, lm, atol=1e-5) and np.allclose(wp2, wp) and s.conf.MAX_RANGE == 10.0
     s.close()
+
+
+@pytest.mark.parametrize("name,mapname,seed", [("traj_ekf_loop1_s3", "example_loop1", 3), ("traj_ekf_webmap_s7", "example_webmap", 7)])
+def test_host_ekf_matches_reference(name, mapname, seed):
+    """BASELINE config 1 (EKF1, CPU path): the host EKF (slam_amd/csrc/host/ekfslam.cpp) against the reference's
+    EKFSLAM run, every control step of the whole run.  Measured: pose within 1.4e-4, identical state dimension
+    (= identical gated nearest-neighbour association decisions), trace(P) within 1.3e-5 relative."""
+    from slam_amd import host
+    g = load_golden(name)
+    sim = host.HostSim(["-m", os.path.join(DATA, mapname + ".mat"), "-method", "EKF1", "-SWITCH_SEED_RANDOM", seed])
+    ekf = host.HostEkf(sim)
+    k = 0
+    while True:
+        r = ekf.step()
+        if r < 0:
+            break
+        assert r == g["observed"][k]
+        x, P = ekf.state(want_P=(k % 50 == 0))
+        assert x.shape[0] == g["dim"][k], k
+        assert np.abs(x[:3] - g["x"][k]).max() <= 1e-3, k
+        if k % 50 == 0:
+            tr = np.trace(P.astype(np.float64))
+            assert abs(tr - g["trace"][k]) <= 1e-3 * max(g["trace"][k], 1e-9), k
+        k += 1
+    assert k == g["x"].shape[0]
+    x, P = ekf.state()
+    assert np.abs(x - g["final_x"]).max() <= 2e-3 and np.abs(P - g["final_P"]).max() <= 1e-3 * np.abs(g["final_P"]).max()
+    ekf.close()
+    sim.close()
+
+
+def test_slam_backend_cli_ekf_and_loud_failure_without_gpu():
+    import subprocess
+    import slam_amd
+    root = os.path.dirname(DATA)
+    exe = os.path.join(root, "slam_amd", "bin", "slam-backend")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    r = subprocess.run([exe, "-m", os.path.join(DATA, "example_loop1.mat"), "-method", "EKF1", "-SWITCH_SEED_RANDOM", "3", "-maxsteps", "2000"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "EKFSLAM" in r.stdout and "control steps 2000" in r.stdout, r.stdout[-500:] + r.stderr
+    assert "-h  (print usage)" in subprocess.run([exe, "-h"], capture_output=True, text=True).stdout
+    if slam_amd.device_count() == 0:
+        r = subprocess.run([exe, "-m", os.path.join(DATA, "example_webmap.mat"), "-method", "FASTSLAM2"], capture_output=True, text=True, timeout=60)
+        assert r.returncode != 0 and "no CPU fallback" in r.stderr
