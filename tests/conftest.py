@@ -29,7 +29,8 @@ def kat():
 
 
 def load_golden(name):
-    return np.load(os.path.join(GOLDEN, name + ".npz"))
+    # materialised: an NpzFile re-reads and decompresses the member on every [] access
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
 
 
 def sim_args(mapname, method, N, seed, extra=()):

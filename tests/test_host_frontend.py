@@ -125,7 +125,7 @@ def test_host_ekf_matches_reference(name, mapname, seed):
     EKFSLAM run, every control step of the whole run.  Measured: pose within 1.4e-4, identical state dimension
     (= identical gated nearest-neighbour association decisions), trace(P) within 1.3e-5 relative."""
     from slam_amd import host
-    g = load_golden(name)
+    g = dict(load_golden(name))  # NpzFile decompresses on every access: materialise once
     sim = host.HostSim(["-m", os.path.join(DATA, mapname + ".mat"), "-method", "EKF1", "-SWITCH_SEED_RANDOM", seed])
     ekf = host.HostEkf(sim)
     k = 0
