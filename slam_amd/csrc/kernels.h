@@ -71,6 +71,11 @@ struct RngArgs {
 struct PredictStep {
     float V, G, phi_true;
     uint32_t step;           // control-step counter (philox stream)
+    // particle-independent trigonometry of the control, evaluated once on the host with the same float libm
+    // calls the reference makes (sin(G), cos(G): fastslam2.cpp:79; sin(G/wheelBase): :103) — only valid when the
+    // control is not perturbed per particle (add_noise == 0)
+    float sinG, cosG, sinGw;
+    uint32_t pad;
 };
 
 struct PredictArgs {

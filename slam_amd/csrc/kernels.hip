@@ -20,13 +20,14 @@ SLAM_DEV void predict_steps(float &x, float &y, float &th, float P[9], const Pre
     const float Q00 = A.Q[0], Q01 = A.Q[1], Q10 = A.Q[2], Q11 = A.Q[3];
     for (int s = 0; s < A.nsteps; s++) {
         float V = A.steps[s].V, G = A.steps[s].G;
+        float sn, cs;
+        sincosf(G + th, &sn, &cs);  // one range reduction for both
         if (fs2) {
-            // Gv, Gu (fastslam2.cpp:78-79)
-            const float sn = sinf(G + th), cs = cosf(G + th);
+            // Gv, Gu (fastslam2.cpp:78-79); sin(G), cos(G) are particle-independent: host-evaluated
             const float gv02 = -V * dt * sn, gv12 = V * dt * cs;
             const float gu00 = dt * cs, gu01 = -V * dt * sn;
             const float gu10 = dt * sn, gu11 = V * dt * cs;
-            const float gu20 = dt * sinf(G) / wb, gu21 = V * dt * cosf(G) / wb;
+            const float gu20 = dt * A.steps[s].sinG / wb, gu21 = V * dt * A.steps[s].cosG / wb;
             // T = Gv * Pv ; A = T * Gv^T   (Gv = [[1,0,gv02],[0,1,gv12],[0,0,1]])
             float T[9], N9[9];
 #pragma unroll
@@ -70,10 +71,12 @@ SLAM_DEV void predict_steps(float &x, float &y, float &th, float P[9], const Pre
             const float ng = (L.l10 * g0 + L.l11 * g1) + G;
             V = nv;
             G = ng;
+            sincosf(G + th, &sn, &cs);
         }
-        const float nx = x + V * dt * cosf(G + th);
-        const float ny = y + V * dt * sinf(G + th);
-        const float nth = trig_offset(th + V * dt * sinf(G / wb));  // sin(G/wheelBase): upstream quirk (:103)
+        const float sgw = A.add_noise ? sinf(G / wb) : A.steps[s].sinGw;
+        const float nx = x + V * dt * cs;
+        const float ny = y + V * dt * sn;
+        const float nth = trig_offset(th + V * dt * sgw);  // sin(G/wheelBase): upstream quirk (:103)
         x = nx;
         y = ny;
         th = nth;
@@ -146,10 +149,16 @@ __global__ void __launch_bounds__(kBlock) predict_kernel(Buffers B, PredictArgs 
 // prefix of the raw weights and the block totals of w and w^2 (inputs of resampleParticles'
 // normalisation / Neff / cumulative sum, core.cpp:726-729,781-788,813-824).
 // ---------------------------------------------------------------------------------------------------
+constexpr int kStage = 8;  // landmarks per particle kept in LDS between the two passes (40 KB per block)
+
 template <int METHOD>
 __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs PA, UpdateArgs U, RngArgs rng,
                                                          WeightScratch ws) {
     __shared__ float sh_w[kBlock / kWave], sh_w2[kBlock / kWave];
+    // landmarks re-observed this step, staged between the proposal pass and the likelihood/feature-update pass
+    // (each thread only touches its own column: no barrier, no bank conflict: consecutive lanes, consecutive slots)
+    __shared__ float4 shA[METHOD == 2 ? kStage : 1][kBlock];
+    __shared__ float shB[METHOD == 2 ? kStage : 1][kBlock];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const size_t S = (size_t) B.ncap;
@@ -207,10 +216,19 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 const float x0 = x, y0 = y, th0 = th;
                 // running proposal covariance, full 3x3 (the reference's Pv stays a full matrix inside the loop)
                 float P[9] = {q00, q10, q20, q10, q11, q21, q20, q21, q22};
+                float4 la_next = lmkA[(size_t) idf[0] * S + i];
+                float lb_next = lmkB[(size_t) idf[0] * S + i];
                 for (int k = 0; k < m; k++) {
-                    const size_t li = (size_t) idf[k] * S + i;
-                    const float4 la = lmkA[li];
-                    const float lb = lmkB[li];
+                    const float4 la = la_next;
+                    const float lb = lb_next;
+                    if (k + 1 < m) {  // software prefetch: the next landmark's HBM latency hides under this one's solves
+                        la_next = lmkA[(size_t) idf[k + 1] * S + i];
+                        lb_next = lmkB[(size_t) idf[k + 1] * S + i];
+                    }
+                    if (k < kStage) {  // staged for the second pass (likelihood + feature update): one HBM read per landmark
+                        shA[k][threadIdx.x] = la;
+                        shB[k][threadIdx.x] = lb;
+                    }
                     // Jacobians at the running mean (fastslam2.cpp:320,:348)
                     Jac j = jacobian(x, y, th, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
                     float s00, s01, s10, s11;
@@ -256,8 +274,15 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 float lik = 1.0f;
                 for (int k = 0; k < m; k++) {
                     const size_t li = (size_t) idf[k] * S + i;
-                    float4 la = lmkA[li];
-                    float lb = lmkB[li];
+                    float4 la;
+                    float lb;
+                    if (k < kStage) {
+                        la = shA[k][threadIdx.x];
+                        lb = shB[k][threadIdx.x];
+                    } else {
+                        la = lmkA[li];
+                        lb = lmkB[li];
+                    }
                     Jac j = jacobian(xs, ys, ths, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
                     const float v0 = zf[2 * k] - j.zp0;
                     const float v1 = trig_offset(zf[2 * k + 1] - j.zp1);

@@ -342,6 +342,10 @@ int slamgpu_predict(slamgpu_ctx *c, float V, float G, const float Q[4], float dt
     s.G = G;
     s.phi_true = phi_true;
     s.step = c->ctl_step;
+    s.sinG = sinf(G);
+    s.cosG = cosf(G);
+    s.sinGw = sinf(G / c->cfg.wheel_base);
+    s.pad = 0;
     c->est_fresh = false;
     if (tape_noise) {
         HIP_TRY(hipSetDevice(c->cfg.device));
