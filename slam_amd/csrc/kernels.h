@@ -131,13 +131,14 @@ struct ShardPackArgs {
     int64_t k_lo, k_hi;              // offspring [K[g], K[g+1]) of this shard
     int64_t n_per_shard;
     int32_t nf, fields;              // fields = 10 + 5*nf floats per record
-    float *send;                     // device buffer, (k_hi-k_lo)*fields floats
+    int32_t shard, pad;              // offspring whose output slot is on this shard are gathered in place, not sent
+    float *send;                     // device buffer: the offspring bound for OTHER shards, per-destination blocks
 };
 
 struct ShardUnpackArgs {
     const float *recv;               // device buffer, n_local*fields floats, blocks in source-shard order
-    int32_t n_shards, nf, fields, pad;
-    int64_t src_lo[kMaxShards + 1];  // local output index boundaries per source shard
+    int32_t n_shards, nf, fields, shard;
+    int64_t src_lo[kMaxShards + 1];  // local output index boundaries per source shard (own block: written by pack)
 };
 
 struct KernelTable {

@@ -714,7 +714,30 @@ __global__ void __launch_bounds__(kBlock) shard_pack_kernel(Buffers B, WeightScr
     const int64_t blk_lo = max(A.k_lo, (int64_t) d * A.n_per_shard);
     const int64_t blk_hi = min(A.k_hi, (int64_t) (d + 1) * A.n_per_shard);
     const int64_t cnt = blk_hi - blk_lo, slot = k - blk_lo;
-    float *__restrict__ dst = A.send + (size_t) (blk_lo - A.k_lo) * A.fields + slot;  // block base = records before it
+    if (d == A.shard) {
+        // the output slot lives on this shard too: gather straight into the spare buffers (no exchange);
+        // with balanced weights this is almost every offspring
+        const int o = (int) (k - (int64_t) d * A.n_per_shard);
+        if (blockIdx.y == 0) {
+            float4 pa = B.poseA[cur][anc];
+            pa.w = B.ctrl->inv_n;
+            B.poseA[cur ^ 1][o] = pa;
+            B.poseB[cur ^ 1][o] = B.poseB[cur][anc];
+            B.poseC[cur ^ 1][o] = B.poseC[cur][anc];
+            ws.keep[o] = (int32_t) ganc;
+        }
+        const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(A.nf, j0 + kLmkPerBlockY);
+        for (int l = j0; l < j1; l++) {
+            B.lmkA[cur ^ 1][(size_t) l * S + o] = B.lmkA[cur][(size_t) l * S + anc];
+            B.lmkB[cur ^ 1][(size_t) l * S + o] = B.lmkB[cur][(size_t) l * S + anc];
+        }
+        return;
+    }
+    // records before this block in the send buffer = offspring before it, minus the ones kept local
+    const int64_t self_lo = max(A.k_lo, (int64_t) A.shard * A.n_per_shard);
+    const int64_t self_hi = min(A.k_hi, (int64_t) (A.shard + 1) * A.n_per_shard);
+    const int64_t kept_before = (d > A.shard && self_hi > self_lo) ? (self_hi - self_lo) : 0;
+    float *__restrict__ dst = A.send + (size_t) (blk_lo - A.k_lo - kept_before) * A.fields + slot;
     if (blockIdx.y == 0) {
         const float4 pa = B.poseA[cur][anc], pb = B.poseB[cur][anc];
         const float2 pc = B.poseC[cur][anc];
@@ -740,8 +763,12 @@ __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightS
     // source block: the s with src_lo[s] <= i < src_lo[s+1] (local output index boundaries, increasing)
     int s = 0;
     while (s + 1 < A.n_shards && i >= A.src_lo[s + 1]) s++;
+    if (s == A.shard) return;  // written directly by this shard's own pack kernel
     const int64_t cnt = A.src_lo[s + 1] - A.src_lo[s], slot = i - A.src_lo[s];
-    const float *__restrict__ src = A.recv + (size_t) A.src_lo[s] * A.fields + slot;
+    // records before this block in the receive buffer = outputs before it, minus the locally produced ones
+    const int64_t own = A.src_lo[A.shard + 1] - A.src_lo[A.shard];
+    const int64_t before = A.src_lo[s] - (s > A.shard ? own : 0);
+    const float *__restrict__ src = A.recv + (size_t) before * A.fields + slot;
     if (blockIdx.y == 0) {
         B.poseA[cur ^ 1][i] = make_float4(src[0], src[cnt], src[2 * cnt], B.ctrl->inv_n);
         B.poseB[cur ^ 1][i] = make_float4(src[3 * cnt], src[4 * cnt], src[5 * cnt], src[6 * cnt]);

@@ -544,11 +544,13 @@ int slamgpu_shard_pack(slamgpu_ctx *c, const float *gw, const float *gw2, int32_
     // records this shard sends to d / receives from s: overlaps of offspring ranges with output ranges
     for (int d = 0; d < n_shards; d++) {
         const int64_t a = std::max(k_lo, (int64_t) d * n), b = std::min(k_hi, (int64_t) (d + 1) * n);
-        send_counts[d] = b > a ? b - a : 0;
+        send_counts[d] = (b > a && d != shard) ? b - a : 0;  // own offspring are gathered in place by the pack kernel
         const int64_t ra = std::max(plan->K[d], (int64_t) shard * n), rb = std::min(plan->K[d + 1], (int64_t) (shard + 1) * n);
-        recv_counts[d] = rb > ra ? rb - ra : 0;
+        recv_counts[d] = (rb > ra && d != shard) ? rb - ra : 0;
     }
-    if (k_hi > k_lo && !send_dev) return fail(SLAMGPU_ERR_INVALID, "null send buffer");
+    int64_t to_send = 0;
+    for (int d = 0; d < n_shards; d++) to_send += send_counts[d];
+    if (to_send > 0 && !send_dev) return fail(SLAMGPU_ERR_INVALID, "null send buffer");
     HIP_TRY(hipSetDevice(c->cfg.device));
     ShardPackArgs A{};
     A.gblk_w = gw;
@@ -560,6 +562,7 @@ int slamgpu_shard_pack(slamgpu_ctx *c, const float *gw, const float *gw2, int32_
     A.n_per_shard = n;
     A.nf = c->nf;
     A.fields = 10 + 5 * c->nf;
+    A.shard = shard;
     A.send = send_dev;
     {
         Timed t(c, "shard_pack");
@@ -572,15 +575,23 @@ int slamgpu_shard_pack(slamgpu_ctx *c, const float *gw, const float *gw2, int32_
 int slamgpu_shard_unpack(slamgpu_ctx *c, const float *recv_dev, int32_t n_shards, int32_t shard,
                          const slamgpu_shard_plan_t *plan) {
     if (int rc = check_ctx(c)) return rc;
-    if (!recv_dev || !plan) return fail(SLAMGPU_ERR_INVALID, "null argument");
+    if (!plan) return fail(SLAMGPU_ERR_INVALID, "null argument");
     if (shard < 0 || shard >= n_shards || n_shards > kMaxShards) return fail(SLAMGPU_ERR_INVALID, "bad shard index");
     HIP_TRY(hipSetDevice(c->cfg.device));
     const int64_t n = c->cfg.n_particles, first = (int64_t) shard * n;
+    {
+        // nothing to scatter when every output slot of this shard was produced locally
+        const int64_t own_lo = std::min(std::max(plan->K[shard] - first, (int64_t) 0), n);
+        const int64_t own_hi = std::min(std::max(plan->K[shard + 1] - first, (int64_t) 0), n);
+        if (own_lo == 0 && own_hi == n) return 0;
+        if (!recv_dev) return fail(SLAMGPU_ERR_INVALID, "null receive buffer");
+    }
     ShardUnpackArgs A{};
     A.recv = recv_dev;
     A.n_shards = n_shards;
     A.nf = c->nf;
     A.fields = 10 + 5 * c->nf;
+    A.shard = shard;
     for (int s = 0; s <= n_shards; s++) A.src_lo[s] = std::min(std::max(plan->K[s] - first, (int64_t) 0), n);
     {
         Timed t(c, "shard_unpack");

@@ -236,8 +236,11 @@ class ShardedFilter:
                 s_, r_ = e.pack(c, self.gw[i], self.gw2[i], self.nb_global, plans[i], self.send[i])
                 sc.append(s_ * fields)
                 rc.append(r_ * fields)
-                self.exchanged_records += int(s_.sum() - s_[e.shard])
-            c.all_to_all(self.send, sc, self.recv, rc)
+                self.exchanged_records += int(s_.sum())
+            # offspring whose output slot is on their own shard never leave it; skip the collective when the plan
+            # (identical on every shard) says that nothing crosses a shard boundary
+            if any(int(plan.K[r]) != r * self.n for r in range(1, self.G)):
+                c.all_to_all(self.send, sc, self.recv, rc)
             for i, e in enumerate(E):
                 e.unpack(c, self.recv[i], plans[i])
         for i, e in enumerate(E):

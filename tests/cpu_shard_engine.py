@@ -107,10 +107,14 @@ class CpuEngine:
         return np.stack(rec).astype(f32)  # [fields][n]
 
     def pack(self, comm, gw, gw2, nb_global, plan, send):
+        """Offspring whose output slot is on this shard are kept (self._local); the rest goes to the send buffer in
+        per-destination blocks — the same split the device pack kernel makes."""
         k_lo, k_hi = plan.K[self.shard], plan.K[self.shard + 1]
         G, n = self.n_shards, self.n
-        sc = np.array([max(0, min(k_hi, (d + 1) * n) - max(k_lo, d * n)) for d in range(G)], np.int64)
-        rc = np.array([max(0, min(plan.K[d + 1], (self.shard + 1) * n) - max(plan.K[d], self.shard * n)) for d in range(G)], np.int64)
+        sc = np.array([max(0, min(k_hi, (d + 1) * n) - max(k_lo, d * n)) if d != self.shard else 0 for d in range(G)], np.int64)
+        rc = np.array([max(0, min(plan.K[d + 1], (self.shard + 1) * n) - max(plan.K[d], self.shard * n)) if d != self.shard else 0
+                       for d in range(G)], np.int64)
+        self._local = None
         if k_hi > k_lo:
             target = self._sel(k_lo, k_hi - k_lo) * plan.wsum
             fb = self.first // BLOCK
@@ -118,27 +122,39 @@ class CpuEngine:
             anc = np.minimum(np.searchsorted(cum, target, side="right"), self.n - 1)
             rec = self._records()[:, anc]  # [fields][cnt]
             rec[9] = (anc + self.first).astype(np.int32).view(f32)
-            out = self._np(comm, send)
+            out = self._np(comm, send) if send is not None else None
             fields = rec.shape[0]
             pos = 0
             for d in range(G):
                 a, b = max(k_lo, d * n) - k_lo, min(k_hi, (d + 1) * n) - k_lo
-                if b > a:
+                if b <= a:
+                    continue
+                if d == self.shard:
+                    self._local = (max(k_lo, d * n) - self.first, rec[:, a:b].copy())
+                else:
                     out[pos * fields:(pos + (b - a)) * fields] = rec[:, a:b].ravel()
                     pos += b - a
         return sc, rc
 
     def unpack(self, comm, recv, plan):
-        buf = self._np(comm, recv)
         nf = self.P.nf()
         fields = 10 + 5 * nf
         n = self.n
         lo = [min(max(plan.K[s] - self.first, 0), n) for s in range(self.n_shards + 1)]
         rec = np.zeros((fields, n), f32)
+        pos = 0
         for s in range(self.n_shards):
             cnt = lo[s + 1] - lo[s]
-            if cnt > 0:
-                rec[:, lo[s]:lo[s + 1]] = buf[lo[s] * fields:(lo[s] + cnt) * fields].reshape(fields, cnt)
+            if cnt <= 0:
+                continue
+            if s == self.shard:
+                o, r = self._local
+                assert o == lo[s] and r.shape[1] == cnt
+                rec[:, lo[s]:lo[s + 1]] = r
+            else:
+                buf = self._np(comm, recv)
+                rec[:, lo[s]:lo[s + 1]] = buf[pos * fields:(pos + cnt) * fields].reshape(fields, cnt)
+                pos += cnt
         st = dict(nf=nf, xv=np.stack([rec[0], rec[1], rec[2]], 1), w=np.full(n, f32(1.0) / f32(self.N), f32))
         Pv = np.zeros((n, 3, 3), f32)
         Pv[:, 0, 0], Pv[:, 1, 0], Pv[:, 1, 1], Pv[:, 2, 0], Pv[:, 2, 1], Pv[:, 2, 2] = rec[3], rec[4], rec[5], rec[6], rec[7], rec[8]
