@@ -141,8 +141,9 @@ int slamgpu_sync(slamgpu_ctx *ctx);
  * torch.distributed in bench.py; any transport works, the buffers are plain device pointers):
  *
  *   1. slamgpu_shard_update        per-particle update only (the update half of slamgpu_update)
- *   2. slamgpu_shard_block_totals  -> device pointers of this shard's per-256-particle totals of w and w^2;
- *                                  ALL-GATHER them (4+4 B per 256 particles) into gblk_w / gblk_w2
+ *   2. slamgpu_shard_block_totals  -> device pointer of this shard's per-256-particle totals, one contiguous
+ *                                  block [w(nb) | w^2(nb)]; ALL-GATHER it (8 B per 256 particles) so that every
+ *                                  shard holds gtot = [shard 0: w|w2][shard 1: w|w2]...
  *   3. slamgpu_shard_plan          every shard runs the same scan of the gathered totals => identical
  *                                  sum w, Neff, decision and offspring boundaries K[0..G] on every shard
  *                                  (results are independent of the number of shards)
@@ -162,13 +163,11 @@ typedef struct {
 
 int slamgpu_shard_update(slamgpu_ctx *ctx, const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n,
                          const float R[4], const float *normals, const float *strata);
-int slamgpu_shard_block_totals(slamgpu_ctx *ctx, const float **blk_w_dev, const float **blk_w2_dev, int32_t *nblocks);
-int slamgpu_shard_plan(slamgpu_ctx *ctx, const float *gblk_w_dev, const float *gblk_w2_dev, int32_t nb_global,
-                       int32_t n_shards, slamgpu_shard_plan_t *out);
+int slamgpu_shard_block_totals(slamgpu_ctx *ctx, const float **totals_dev, int32_t *nblocks);
+int slamgpu_shard_plan(slamgpu_ctx *ctx, const float *gtot_dev, int32_t nb_global, int32_t n_shards, slamgpu_shard_plan_t *out);
 int slamgpu_shard_record_floats(slamgpu_ctx *ctx);
-int slamgpu_shard_pack(slamgpu_ctx *ctx, const float *gblk_w_dev, const float *gblk_w2_dev, int32_t nb_global,
-                       int32_t n_shards, int32_t shard, const slamgpu_shard_plan_t *plan, float *send_dev,
-                       int64_t *send_counts, int64_t *recv_counts);
+int slamgpu_shard_pack(slamgpu_ctx *ctx, const float *gtot_dev, int32_t nb_global, int32_t n_shards, int32_t shard,
+                       const slamgpu_shard_plan_t *plan, float *send_dev, int64_t *send_counts, int64_t *recv_counts);
 int slamgpu_shard_unpack(slamgpu_ctx *ctx, const float *recv_dev, int32_t n_shards, int32_t shard,
                          const slamgpu_shard_plan_t *plan);
 int slamgpu_shard_finish(slamgpu_ctx *ctx, const slamgpu_shard_plan_t *plan);

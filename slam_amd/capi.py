@@ -82,10 +82,10 @@ def load_library():
     L.slamgpu_kernel_time.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.slamgpu_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.slamgpu_shard_update.argtypes = L.slamgpu_update.argtypes
-    L.slamgpu_shard_block_totals.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
-    L.slamgpu_shard_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(ShardPlan)]
+    L.slamgpu_shard_block_totals.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
+    L.slamgpu_shard_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(ShardPlan)]
     L.slamgpu_shard_record_floats.argtypes = [C.c_void_p]
-    L.slamgpu_shard_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(ShardPlan), C.c_void_p,
+    L.slamgpu_shard_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(ShardPlan), C.c_void_p,
                                      C.c_void_p, C.c_void_p]
     L.slamgpu_shard_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(ShardPlan)]
     L.slamgpu_shard_finish.argtypes = [C.c_void_p, C.POINTER(ShardPlan)]
@@ -248,22 +248,23 @@ class SlamGpu:
         _chk(self.L.slamgpu_shard_update(self.h, _ptr(zf), _ptr(idf), zf.shape[0], _ptr(zn), zn.shape[0], _ptr(R), _ptr(nm), _ptr(st)))
 
     def shard_block_totals(self):
-        w, w2, nb = C.c_void_p(), C.c_void_p(), C.c_int32()
-        _chk(self.L.slamgpu_shard_block_totals(self.h, C.byref(w), C.byref(w2), C.byref(nb)))
-        return w.value, w2.value, nb.value
+        """device pointer of this shard's [w(nb) | w2(nb)] block totals, nb"""
+        t, nb = C.c_void_p(), C.c_int32()
+        _chk(self.L.slamgpu_shard_block_totals(self.h, C.byref(t), C.byref(nb)))
+        return t.value, nb.value
 
-    def shard_plan(self, gw_ptr, gw2_ptr, nb_global, n_shards):
+    def shard_plan(self, gtot_ptr, nb_global, n_shards):
         plan = ShardPlan()
-        _chk(self.L.slamgpu_shard_plan(self.h, gw_ptr, gw2_ptr, nb_global, n_shards, C.byref(plan)))
+        _chk(self.L.slamgpu_shard_plan(self.h, gtot_ptr, nb_global, n_shards, C.byref(plan)))
         return plan
 
     def record_floats(self):
         return self.L.slamgpu_shard_record_floats(self.h)
 
-    def shard_pack(self, gw_ptr, gw2_ptr, nb_global, n_shards, shard, plan, send_ptr):
+    def shard_pack(self, gtot_ptr, nb_global, n_shards, shard, plan, send_ptr):
         sc = np.zeros(n_shards, np.int64)
         rc = np.zeros(n_shards, np.int64)
-        _chk(self.L.slamgpu_shard_pack(self.h, gw_ptr, gw2_ptr, nb_global, n_shards, shard, C.byref(plan), send_ptr, _ptr(sc), _ptr(rc)))
+        _chk(self.L.slamgpu_shard_pack(self.h, gtot_ptr, nb_global, n_shards, shard, C.byref(plan), send_ptr, _ptr(sc), _ptr(rc)))
         return sc, rc
 
     def shard_unpack(self, recv_ptr, n_shards, shard, plan):

@@ -95,8 +95,8 @@ struct UpdateArgs {
 
 struct WeightScratch {
     float *lcum;        // [ncap]    inclusive in-block (256 particles) prefix of the raw weights
-    float *blk_w;       // [nblocks] block totals of w
-    float *blk_w2;      // [nblocks] block totals of w^2
+    float *blk_w;       // [nblocks] block totals of w        } one allocation: blk_w2 == blk_w + nblocks, so a
+    float *blk_w2;      // [nblocks] block totals of w^2      } shard's totals travel as one contiguous message
     double *est_part;   // [nblocks][4] pose-estimate partials (sum x, sum y, heading, max w)
     int32_t *keep;      // [ncap] ancestors of the last resample
     int32_t nblocks;
@@ -120,14 +120,15 @@ struct ShardPlan {           // written by shard_plan_kernel, read back by the h
 };
 
 struct ShardPlanArgs {
-    const float *gblk_w, *gblk_w2;  // all-gathered block totals [nb_global]
+    const float *gblk;  // all-gathered block totals, shard-major [G][w(nb_per_shard) | w2(nb_per_shard)]
     int32_t nb_global, nb_per_shard, n_shards;
     int32_t do_resample, n_effective;
 };
 
 struct ShardPackArgs {
-    const float *gblk_w, *gblk_w2;
+    const float *gblk;
     int32_t nb_global, first_block;  // this shard's first block in the global numbering
+    int32_t nb_per_shard, pad0;
     int64_t k_lo, k_hi;              // offspring [K[g], K[g+1]) of this shard
     int64_t n_per_shard;
     int32_t nf, fields;              // fields = 10 + 5*nf floats per record

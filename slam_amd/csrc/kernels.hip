@@ -442,15 +442,18 @@ SLAM_DEV void finish_estimate(const Buffers &B, const WeightScratch &ws, double 
 // Exclusive prefix (double) of the block totals into LDS `off[0..nb]`, plus sum w and sum w^2.  Every block of
 // every kernel (and every rank of a sharded run, which sees the same all-gathered totals) executes exactly
 // this association, so W, Q, Neff, the resample decision and all ancestors are identical everywhere.
-SLAM_DEV void scan_block_totals(const float *__restrict__ blk_w, const float *__restrict__ blk_w2, int nb, double *off,
-                                double *sh_a, double *sh_q, double &W, double &Q) {
+// Layout of the totals: shard-major records [w(nbl) | w2(nbl)] (what one all-gather of each shard's contiguous
+// [w | w2] block produces): total k of shard k/nbl sits at (k/nbl)*2*nbl + k%nbl, its square sum nbl further.
+SLAM_DEV void scan_block_totals(const float *__restrict__ tot, int nb, int nbl, double *off, double *sh_a, double *sh_q,
+                                double &W, double &Q) {
     const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
     const int per = (nb + kBlock - 1) / kBlock;
     const int lo = min(nb, t * per), hi = min(nb, lo + per);
     double a = 0.0, q = 0.0;
     for (int k = lo; k < hi; k++) {
-        a += (double) blk_w[k];
-        q += (double) blk_w2[k];
+        const int at = (k / nbl) * 2 * nbl + (k % nbl);
+        a += (double) tot[at];
+        q += (double) tot[at + nbl];
     }
     double sa = a;
 #pragma unroll
@@ -471,7 +474,7 @@ SLAM_DEV void scan_block_totals(const float *__restrict__ blk_w, const float *__
     double run = base + sa - a;  // exclusive prefix of this thread's segment
     for (int k = lo; k < hi; k++) {
         off[k] = run;
-        run += (double) blk_w[k];
+        run += (double) tot[(k / nbl) * 2 * nbl + (k % nbl)];
     }
     W = ((sh_a[0] + sh_a[1]) + sh_a[2]) + sh_a[3];
     Q = ((sh_q[0] + sh_q[1]) + sh_q[2]) + sh_q[3];
@@ -529,7 +532,7 @@ __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScrat
     const int cur = ctrl->cur;
 
     double W, Q;
-    scan_block_totals(ws.blk_w, ws.blk_w2, nb, off, sh_a, sh_q, W, Q);
+    scan_block_totals(ws.blk_w, nb, nb, off, sh_a, sh_q, W, Q);  // one shard: [w(nb) | w2(nb)] contiguous
     // Neff = 1 / sum((w/W)^2)  (core.cpp:784-788)
     const float neff = (float) ((W * W) / Q);
     const bool resample = ra.do_resample && (neff < (float) ra.n_effective);
@@ -667,7 +670,7 @@ __global__ void __launch_bounds__(kBlock) shard_plan_kernel(ShardPlanArgs A, Rng
     extern __shared__ double off[];
     __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
     double W, Q;
-    scan_block_totals(A.gblk_w, A.gblk_w2, A.nb_global, off, sh_a, sh_q, W, Q);
+    scan_block_totals(A.gblk, A.nb_global, A.nb_per_shard, off, sh_a, sh_q, W, Q);
     __syncthreads();
     const int t = threadIdx.x;
     if (t == 0) {
@@ -699,7 +702,7 @@ __global__ void __launch_bounds__(kBlock) shard_pack_kernel(Buffers B, WeightScr
     extern __shared__ double off[];
     __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
     double W, Q;
-    scan_block_totals(A.gblk_w, A.gblk_w2, A.nb_global, off, sh_a, sh_q, W, Q);
+    scan_block_totals(A.gblk, A.nb_global, A.nb_per_shard, off, sh_a, sh_q, W, Q);
     __syncthreads();
     const int64_t j = (int64_t) blockIdx.x * kBlock + threadIdx.x;  // offspring slot of this shard
     const int64_t k = A.k_lo + j;

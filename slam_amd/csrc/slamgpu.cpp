@@ -253,8 +253,8 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     // weight scratch
     c->ws.nblocks = ncap / kBlock;
     CTX_TRY(hipMalloc((void **) &c->ws.lcum, sizeof(float) * S));
-    CTX_TRY(hipMalloc((void **) &c->ws.blk_w, sizeof(float) * (size_t) c->ws.nblocks));
-    CTX_TRY(hipMalloc((void **) &c->ws.blk_w2, sizeof(float) * (size_t) c->ws.nblocks));
+    CTX_TRY(hipMalloc((void **) &c->ws.blk_w, sizeof(float) * 2 * (size_t) c->ws.nblocks));  // [w | w2] contiguous
+    c->ws.blk_w2 = c->ws.blk_w + c->ws.nblocks;
     CTX_TRY(hipMalloc((void **) &c->ws.est_part, sizeof(double) * 4 * (size_t) c->ws.nblocks));
     CTX_TRY(hipMalloc((void **) &c->ws.keep, sizeof(int32_t) * S));
     CTX_TRY(hipMemsetAsync(c->ws.keep, 0, sizeof(int32_t) * S, c->stream));
@@ -300,7 +300,6 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     if (c->ctrl_host) (void) hipHostFree(c->ctrl_host);
     if (c->ws.lcum) (void) hipFree(c->ws.lcum);
     if (c->ws.blk_w) (void) hipFree(c->ws.blk_w);
-    if (c->ws.blk_w2) (void) hipFree(c->ws.blk_w2);
     if (c->ws.est_part) (void) hipFree(c->ws.est_part);
     if (c->ws.keep) (void) hipFree(c->ws.keep);
     if (c->hist_dev) (void) hipFree(c->hist_dev);
@@ -495,28 +494,25 @@ int slamgpu_shard_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, in
     return do_update(c, zf, idf, m, zn, n, R, normals, strata, true);
 }
 
-int slamgpu_shard_block_totals(slamgpu_ctx *c, const float **blk_w_dev, const float **blk_w2_dev, int32_t *nblocks) {
+int slamgpu_shard_block_totals(slamgpu_ctx *c, const float **totals_dev, int32_t *nblocks) {
     if (int rc = check_ctx(c)) return rc;
-    if (blk_w_dev) *blk_w_dev = c->ws.blk_w;
-    if (blk_w2_dev) *blk_w2_dev = c->ws.blk_w2;
+    if (totals_dev) *totals_dev = c->ws.blk_w;  // [w(nblocks) | w2(nblocks)]
     if (nblocks) *nblocks = c->ws.nblocks;
     return 0;
 }
 
 int slamgpu_shard_record_floats(slamgpu_ctx *c) { return c ? 10 + 5 * c->nf : SLAMGPU_ERR_INVALID; }
 
-int slamgpu_shard_plan(slamgpu_ctx *c, const float *gw, const float *gw2, int32_t nb_global, int32_t n_shards,
-                       slamgpu_shard_plan_t *out) {
+int slamgpu_shard_plan(slamgpu_ctx *c, const float *gtot, int32_t nb_global, int32_t n_shards, slamgpu_shard_plan_t *out) {
     if (int rc = check_ctx(c)) return rc;
-    if (!gw || !gw2 || !out) return fail(SLAMGPU_ERR_INVALID, "null argument");
+    if (!gtot || !out) return fail(SLAMGPU_ERR_INVALID, "null argument");
     if (n_shards < 1 || n_shards > kMaxShards) return fail(SLAMGPU_ERR_INVALID, "n_shards %d out of range [1,%d]", n_shards, kMaxShards);
     if (nb_global > kMaxScanBlocks || nb_global % n_shards != 0 || (int64_t) nb_global * kBlock != n_global(c))
         return fail(SLAMGPU_ERR_INVALID, "nb_global %d inconsistent with %lld particles over %d shards", nb_global, (long long) n_global(c), n_shards);
     static_assert(sizeof(slamgpu_shard_plan_t) == sizeof(ShardPlan), "public / device plan layout");
     HIP_TRY(hipSetDevice(c->cfg.device));
     ShardPlanArgs A{};
-    A.gblk_w = gw;
-    A.gblk_w2 = gw2;
+    A.gblk = gtot;
     A.nb_global = nb_global;
     A.nb_per_shard = nb_global / n_shards;
     A.n_shards = n_shards;
@@ -533,11 +529,11 @@ int slamgpu_shard_plan(slamgpu_ctx *c, const float *gw, const float *gw2, int32_
     return 0;
 }
 
-int slamgpu_shard_pack(slamgpu_ctx *c, const float *gw, const float *gw2, int32_t nb_global, int32_t n_shards,
-                       int32_t shard, const slamgpu_shard_plan_t *plan, float *send_dev, int64_t *send_counts,
-                       int64_t *recv_counts) {
+int slamgpu_shard_pack(slamgpu_ctx *c, const float *gtot, int32_t nb_global, int32_t n_shards, int32_t shard,
+                       const slamgpu_shard_plan_t *plan, float *send_dev, int64_t *send_counts, int64_t *recv_counts) {
     if (int rc = check_ctx(c)) return rc;
-    if (!gw || !gw2 || !plan || !send_counts || !recv_counts) return fail(SLAMGPU_ERR_INVALID, "null argument");
+    if (!gtot || !plan || !send_counts || !recv_counts) return fail(SLAMGPU_ERR_INVALID, "null argument");
+    if (n_shards < 1 || nb_global % n_shards != 0) return fail(SLAMGPU_ERR_INVALID, "bad shard geometry");
     if (shard < 0 || shard >= n_shards || n_shards > kMaxShards) return fail(SLAMGPU_ERR_INVALID, "bad shard index");
     const int64_t n = c->cfg.n_particles;
     const int64_t k_lo = plan->K[shard], k_hi = plan->K[shard + 1];
@@ -553,9 +549,9 @@ int slamgpu_shard_pack(slamgpu_ctx *c, const float *gw, const float *gw2, int32_
     if (to_send > 0 && !send_dev) return fail(SLAMGPU_ERR_INVALID, "null send buffer");
     HIP_TRY(hipSetDevice(c->cfg.device));
     ShardPackArgs A{};
-    A.gblk_w = gw;
-    A.gblk_w2 = gw2;
+    A.gblk = gtot;
     A.nb_global = nb_global;
+    A.nb_per_shard = nb_global / n_shards;
     A.first_block = (int32_t) (c->cfg.first_particle / kBlock);
     A.k_lo = k_lo;
     A.k_hi = k_hi;

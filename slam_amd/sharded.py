@@ -36,12 +36,10 @@ class GpuEngine:
     def local_update(self, zf, idf, zn, R, normals, strata):
         self.ctx.shard_update(zf, idf, zn, R, normals, strata)
 
-    def block_totals_into(self, comm, buf_w, buf_w2):
-        w, w2, nb = self.ctx.shard_block_totals()
+    def block_totals_into(self, comm, buf):
+        t, nb = self.ctx.shard_block_totals()
         # a comm whose collectives are ordered on this context's stream needs no host wait here
-        wait = not getattr(comm, "stream_ordered", False)
-        self.ctx.dev_copy(comm.ptr(buf_w), w, 4 * nb, wait)
-        self.ctx.dev_copy(comm.ptr(buf_w2), w2, 4 * nb, wait)
+        self.ctx.dev_copy(comm.ptr(buf), t, 8 * nb, not getattr(comm, "stream_ordered", False))
 
     def estimate_async(self):
         self.ctx.shard_estimate_async()
@@ -52,14 +50,14 @@ class GpuEngine:
     def nblocks(self):
         return self.n // 256
 
-    def plan(self, comm, gw, gw2, nb_global):
-        return self.ctx.shard_plan(comm.ptr(gw), comm.ptr(gw2), nb_global, self.n_shards)
+    def plan(self, comm, gtot, nb_global):
+        return self.ctx.shard_plan(comm.ptr(gtot), nb_global, self.n_shards)
 
     def record_floats(self):
         return self.ctx.record_floats()
 
-    def pack(self, comm, gw, gw2, nb_global, plan, send):
-        return self.ctx.shard_pack(comm.ptr(gw), comm.ptr(gw2), nb_global, self.n_shards, self.shard, plan, comm.ptr(send))
+    def pack(self, comm, gtot, nb_global, plan, send):
+        return self.ctx.shard_pack(comm.ptr(gtot), nb_global, self.n_shards, self.shard, plan, comm.ptr(send))
 
     def unpack(self, comm, recv, plan):
         self.ctx.shard_unpack(comm.ptr(recv), self.n_shards, self.shard, plan)
@@ -190,10 +188,9 @@ class ShardedFilter:
         self.nb_global = self.nb_local * n_shards
         self.n = engines[0].n
         c = comm
-        self.loc_w = [c.alloc(e, self.nb_local) for e in engines]
-        self.loc_w2 = [c.alloc(e, self.nb_local) for e in engines]
-        self.gw = [c.alloc(e, self.nb_global) for e in engines]
-        self.gw2 = [c.alloc(e, self.nb_global) for e in engines]
+        # block totals: each shard contributes one contiguous [w(nb) | w2(nb)] message; gathered shard-major
+        self.loc = [c.alloc(e, 2 * self.nb_local) for e in engines]
+        self.gtot = [c.alloc(e, 2 * self.nb_global) for e in engines]
         self.send = [None] * len(engines)
         self.recv = [None] * len(engines)
         self.cap = 0
@@ -223,17 +220,16 @@ class ShardedFilter:
         for i, e in enumerate(E):
             e.local_update(zf, idf, zn, R, None if normals is None else normals[i], strata)
         for i, e in enumerate(E):
-            e.block_totals_into(c, self.loc_w[i], self.loc_w2[i])
-        c.all_gather(self.loc_w, self.nb_local, self.gw)
-        c.all_gather(self.loc_w2, self.nb_local, self.gw2)
-        plans = [e.plan(c, self.gw[i], self.gw2[i], self.nb_global) for i, e in enumerate(E)]
+            e.block_totals_into(c, self.loc[i])
+        c.all_gather(self.loc, 2 * self.nb_local, self.gtot)
+        plans = [e.plan(c, self.gtot[i], self.nb_global) for i, e in enumerate(E)]
         plan = plans[0]
         if plan.resampled:
             fields = E[0].record_floats()
             self._ensure(fields, plans)
             sc, rc = [], []
             for i, e in enumerate(E):
-                s_, r_ = e.pack(c, self.gw[i], self.gw2[i], self.nb_global, plans[i], self.send[i])
+                s_, r_ = e.pack(c, self.gtot[i], self.nb_global, plans[i], self.send[i])
                 sc.append(s_ * fields)
                 rc.append(r_ * fields)
                 self.exchanged_records += int(s_.sum())

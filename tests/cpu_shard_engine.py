@@ -65,9 +65,10 @@ class CpuEngine:
     def nblocks(self):
         return self.n // BLOCK
 
-    def block_totals_into(self, comm, buf_w, buf_w2):
-        self._np(comm, buf_w)[: self.nblocks()] = self.blk_w
-        self._np(comm, buf_w2)[: self.nblocks()] = self.blk_w2
+    def block_totals_into(self, comm, buf):
+        nb = self.nblocks()
+        self._np(comm, buf)[:nb] = self.blk_w
+        self._np(comm, buf)[nb:2 * nb] = self.blk_w2
 
     @staticmethod
     def _np(comm, buf):
@@ -79,9 +80,11 @@ class CpuEngine:
         _, sel = self.O.philox_update_tape(self.seed, self.step, k0, cnt, self.N, want_normals=False)
         return sel.astype(np.float64)
 
-    def plan(self, comm, gw, gw2, nb_global):
-        gw = self._np(comm, gw)[:nb_global].astype(np.float64)
-        gw2 = self._np(comm, gw2)[:nb_global].astype(np.float64)
+    def plan(self, comm, gtot, nb_global):
+        nbl0 = nb_global // self.n_shards
+        g = self._np(comm, gtot)[:2 * nb_global].reshape(self.n_shards, 2, nbl0)  # shard-major [w | w2]
+        gw = g[:, 0, :].ravel().astype(np.float64)
+        gw2 = g[:, 1, :].ravel().astype(np.float64)
         off = np.concatenate([[0.0], np.cumsum(gw)])
         p = Plan()
         p.wsum, p.wsq = float(off[-1]), float(np.sum(gw2))
@@ -106,7 +109,7 @@ class CpuEngine:
             rec += [st["xf"][:, l, 0], st["xf"][:, l, 1], st["Pf"][:, l, 0, 0], st["Pf"][:, l, 1, 0], st["Pf"][:, l, 1, 1]]
         return np.stack(rec).astype(f32)  # [fields][n]
 
-    def pack(self, comm, gw, gw2, nb_global, plan, send):
+    def pack(self, comm, gtot, nb_global, plan, send):
         """Offspring whose output slot is on this shard are kept (self._local); the rest goes to the send buffer in
         per-destination blocks — the same split the device pack kernel makes."""
         k_lo, k_hi = plan.K[self.shard], plan.K[self.shard + 1]

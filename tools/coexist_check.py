@@ -17,7 +17,7 @@ import numpy as np
 x = torch.arange(8, dtype=torch.float32, device="cuda")
 s = sg.SlamGpu(512, 4, rng_mode=sg.RNG_PHILOX, external_stream=torch.cuda.current_stream().cuda_stream)
 buf = torch.zeros(2, dtype=torch.float32, device="cuda")
-w, w2, nb = s.shard_block_totals()
+w, nb = s.shard_block_totals()
 s.predict(1.0, 0.0, np.eye(2, dtype=np.float32) * 0.01, 0.025)
 s.shard_update(np.zeros((0, 2), np.float32), np.zeros(0, np.int32), np.array([[5.0, 0.1]], np.float32), np.eye(2, dtype=np.float32) * 1e-2)
 s.dev_copy(buf.data_ptr(), w, 8)
