@@ -163,8 +163,13 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const size_t S = (size_t) B.ncap;
     const int cur = B.ctrl->cur;
-    float4 *__restrict__ lmkA = B.lmkA[cur];
-    float *__restrict__ lmkB = B.lmkB[cur];
+    // select (not index) the live buffers: an indexed read of the pointer table in the kernel-argument segment
+    // would be one more dependent scalar load at the head of every wave
+    float4 *__restrict__ lmkA = cur ? B.lmkA[1] : B.lmkA[0];
+    float *__restrict__ lmkB = cur ? B.lmkB[1] : B.lmkB[0];
+    float4 *__restrict__ poseA = cur ? B.poseA[1] : B.poseA[0];
+    float4 *__restrict__ poseB = cur ? B.poseB[1] : B.poseB[0];
+    float2 *__restrict__ poseC = cur ? B.poseC[1] : B.poseC[0];
     const bool active = i < B.n;
     const int m = U.m, n = U.n, nf = U.nf;
     float w = 0.0f;
@@ -183,14 +188,14 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         }
         const float r00 = U.R[0], r01 = U.R[1], r10 = U.R[2], r11 = U.R[3];
 
-        float4 pa = B.poseA[cur][i];
+        float4 pa = poseA[i];
         float x = pa.x, y = pa.y, th = pa.z;
         w = pa.w;
         float q00 = 0.f, q10 = 0.f, q11 = 0.f, q20 = 0.f, q21 = 0.f, q22 = 0.f;
         bool pose_dirty = false;
         if (METHOD == 2) {
-            const float4 pb = B.poseB[cur][i];
-            const float2 pc = B.poseC[cur][i];
+            const float4 pb = poseB[i];
+            const float2 pc = poseC[i];
             q00 = pb.x; q10 = pb.y; q11 = pb.z; q20 = pb.w; q21 = pc.x; q22 = pc.y;
         }
         if (PA.nsteps > 0) {
@@ -216,18 +221,35 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 const float x0 = x, y0 = y, th0 = th;
                 // running proposal covariance, full 3x3 (the reference's Pv stays a full matrix inside the loop)
                 float P[9] = {q00, q10, q20, q10, q11, q21, q20, q21, q22};
-                float4 la_next = lmkA[(size_t) idf[0] * S + i];
-                float lb_next = lmkB[(size_t) idf[0] * S + i];
-                for (int k = 0; k < m; k++) {
-                    const float4 la = la_next;
-                    const float lb = lb_next;
-                    if (k + 1 < m) {  // software prefetch: the next landmark's HBM latency hides under this one's solves
-                        la_next = lmkA[(size_t) idf[k + 1] * S + i];
-                        lb_next = lmkB[(size_t) idf[k + 1] * S + i];
+                // Stage the first kStage re-observed landmarks in LDS with all their loads in flight together
+                // (one HBM latency instead of one per landmark); both passes then read LDS.  Measured before this:
+                // 38 % of the wave's cycles were s_waitcnt stalls (profiles/rocprof_sq_counters_r01.txt).
+                {
+                    float4 ta[kStage];
+                    float tb[kStage];
+                    // unconditional (index clamped to the last landmark): no branch between the loads, so the
+                    // compiler issues all of them before the first s_waitcnt; duplicates are L1 hits
+#pragma unroll
+                    for (int k = 0; k < kStage; k++) {
+                        const size_t li = (size_t) idf[min(k, m - 1)] * S + i;
+                        ta[k] = lmkA[li];
+                        tb[k] = lmkB[li];
                     }
-                    if (k < kStage) {  // staged for the second pass (likelihood + feature update): one HBM read per landmark
-                        shA[k][threadIdx.x] = la;
-                        shB[k][threadIdx.x] = lb;
+#pragma unroll
+                    for (int k = 0; k < kStage; k++) {
+                        shA[k][threadIdx.x] = ta[k];
+                        shB[k][threadIdx.x] = tb[k];
+                    }
+                }
+                for (int k = 0; k < m; k++) {
+                    float4 la;
+                    float lb;
+                    if (k < kStage) {
+                        la = shA[k][threadIdx.x];
+                        lb = shB[k][threadIdx.x];
+                    } else {
+                        la = lmkA[(size_t) idf[k] * S + i];
+                        lb = lmkB[(size_t) idf[k] * S + i];
                     }
                     // Jacobians at the running mean (fastslam2.cpp:320,:348)
                     Jac j = jacobian(x, y, th, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
@@ -272,17 +294,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 const float a0 = x0 - xs, a1 = y0 - ys, a2 = trig_offset(th0 - ths);
                 const float b0 = x - xs, b1 = y - ys, b2 = trig_offset(th - ths);
                 float lik = 1.0f;
-                for (int k = 0; k < m; k++) {
+                auto second_pass = [&](int k, float4 la, float lb) {
                     const size_t li = (size_t) idf[k] * S + i;
-                    float4 la;
-                    float lb;
-                    if (k < kStage) {
-                        la = shA[k][threadIdx.x];
-                        lb = shB[k][threadIdx.x];
-                    } else {
-                        la = lmkA[li];
-                        lb = lmkB[li];
-                    }
                     Jac j = jacobian(xs, ys, ths, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
                     const float v0 = zf[2 * k] - j.zp0;
                     const float v1 = trig_offset(zf[2 * k + 1] - j.zp1);
@@ -290,7 +303,13 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                     cholesky_update2(la.x, la.y, la.z, la.w, lb, v0, v1, r00, r01, r10, r11, j.hf00, j.hf01, j.hf10, j.hf11);
                     lmkA[li] = la;
                     lmkB[li] = lb;
-                }
+                };
+                // two loops on purpose: the LDS-fed one issues only stores to HBM, so nothing in it has to wait for a
+                // store to land (a global load after a global store costs an s_waitcnt vmcnt(0) per iteration)
+                const int ms = min(m, kStage);
+                for (int k = 0; k < ms; k++) second_pass(k, shA[k][threadIdx.x], shB[k][threadIdx.x]);
+                for (int k = ms; k < m; k++)
+                    second_pass(k, lmkA[(size_t) idf[k] * S + i], lmkB[(size_t) idf[k] * S + i]);
                 const float prior = gauss3(a0, a1, a2, q00, q10, q11, q20, q21, q22);
                 const float prop = gauss3(b0, b1, b2, P[0], P[3], P[4], P[6], P[7], P[8]);
                 w = w * lik * prior / prop;
@@ -339,10 +358,10 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             lmkA[li] = la;
             lmkB[li] = lb;
         }
-        B.poseA[cur][i] = make_float4(x, y, th, w);
+        poseA[i] = make_float4(x, y, th, w);
         if (METHOD == 2 && pose_dirty) {
-            B.poseB[cur][i] = make_float4(q00, q10, q11, q20);
-            B.poseC[cur][i] = make_float2(q21, q22);
+            poseB[i] = make_float4(q00, q10, q11, q20);
+            poseC[i] = make_float2(q21, q22);
         }
     }
 
