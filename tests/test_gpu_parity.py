@@ -287,3 +287,47 @@ def test_many_landmarks_big_packet_path(sg, oracle, tmp_path):
     assert max_m > 12  # the big-packet path was exercised
     s.close()
     o.close()
+
+
+def test_full_size_philox_vs_oracle(sg, oracle):
+    """BASELINE configs[2] size (100 000 particles, example_webmap) in the throughput RNG mode: the device's
+    Philox4x32-10 + Box-Muller stream against the oracle's restatement of the same generator, teacher-forced for
+    the first observation steps, plus the size-independent invariants of the update."""
+    N = 100000
+    o = oracle.sim(sim_args("example_webmap", "FASTSLAM2", N, 7))
+    o.set_rng(1, 7)  # particle noise from Philox(seed 7); control / sensor noise from libc rand() as always
+    algo = o.algo()
+    Q, R, dt = o.noise()
+    s = sg.SlamGpu(N, o.nlm, method=2, n_effective=algo.n_effective, wheel_base=algo.wheel_base, rng_mode=sg.RNG_PHILOX, seed=7)
+    k = 0
+    while k < 5:
+        a = o.control()
+        x, vg = o.true_pose()
+        s.predict(float(vg[0]), float(vg[1]), Q, float(dt), float(x[2]))
+        if a == 1:
+            o.observe()
+            ob = o.last_obs()
+            s.update(ob["zf"], ob["idf"], ob["zn"], R)
+            k += 1
+            got, exp = s.download(), o.particles()
+            ne_o, did_o = o.last_resample()
+            ne_g, did_g, wsum = s.stats()
+            assert did_g == did_o, k
+            np.testing.assert_allclose(ne_g, ne_o, rtol=2e-2)
+            assert np.isfinite(got["w"]).all() and np.isfinite(got["xv"]).all()
+            np.testing.assert_allclose(got["w"].sum(dtype=np.float64), 1.0, rtol=1e-4)  # normalised (or N * 1/N)
+            if did_g:
+                keep = s.ancestors()
+                assert np.all(np.diff(keep) >= 0) and keep.min() >= 0 and keep.max() < N   # monotone ancestors
+                assert np.all(got["w"] == np.float32(1.0) / np.float32(N))
+                bad = np.abs(got["xv"] - exp["xv"]).max(axis=1) > POSE_ATOL
+                assert bad.mean() <= 0.05, (k, bad.mean())
+            else:
+                # same Philox bits; Box-Muller through device libm instead of glibc: poses agree to ~1e-5
+                assert np.abs(got["xv"] - exp["xv"]).max() <= 5e-4, (k, np.abs(got["xv"] - exp["xv"]).max())
+                rel = np.abs(got["w"].astype(np.float64) / exp["w"].astype(np.float64) - 1)
+                assert np.median(rel) <= 2e-3, (k, np.median(rel))
+            np.testing.assert_allclose(s.estimate()[:2], o.estimate()[:2], atol=2e-3)
+            s.upload(exp)
+    s.close()
+    o.close()
