@@ -20,6 +20,19 @@ namespace SLAM_KNS {
 
 constexpr double kPi = 3.14159265358979323846;
 
+// Division / reciprocal / square root.  strict: IEEE-rounded (what the reference's SSE2 code does; on gfx950 each
+// costs a 10-12 instruction v_div_scale / v_rcp / fma / v_div_fmas / v_div_fixup sequence, about a third of the
+// update kernel's instructions).  fast (-DSLAM_FAST_MATH): the 1-ulp hardware v_rcp_f32 / v_sqrt_f32.
+#ifdef SLAM_FAST_MATH
+SLAM_DEV float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+SLAM_DEV float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+SLAM_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+#else
+SLAM_DEV float frcp(float x) { return 1.0f / x; }
+SLAM_DEV float fdiv(float a, float b) { return a / b; }
+SLAM_DEV float fsqrt(float x) { return sqrtf(x); }
+#endif
+
 // core.cpp:460-477 — double constants against a float argument.
 SLAM_DEV float trig_offset(float ang) {
     if (((double) ang < -2 * kPi) || ((double) ang > 2 * kPi)) {
@@ -45,17 +58,17 @@ SLAM_DEV Jac jacobian(float x, float y, float th, float fx, float fy, float p00,
     float dx = fx - x;
     float dy = fy - y;
     float d2 = (float) ((double) dx * (double) dx + (double) dy * (double) dy);  // pow(dx,2)+pow(dy,2) in double (:685)
-    float d = sqrtf(d2);
+    float d = fsqrt(d2);
     j.zp0 = d;
     j.zp1 = trig_offset(atan2f(dy, dx) - th);
-    j.hv00 = -dx / d;
-    j.hv01 = -dy / d;
-    j.hv10 = dy / d2;
-    j.hv11 = -dx / d2;
-    j.hf00 = dx / d;
-    j.hf01 = dy / d;
-    j.hf10 = -dy / d2;
-    j.hf11 = dx / d2;
+    j.hv00 = fdiv(-dx, d);
+    j.hv01 = fdiv(-dy, d);
+    j.hv10 = fdiv(dy, d2);
+    j.hv11 = fdiv(-dx, d2);
+    j.hf00 = fdiv(dx, d);
+    j.hf01 = fdiv(dy, d);
+    j.hf10 = fdiv(-dy, d2);
+    j.hf11 = fdiv(dx, d2);
     // T = Hf * Pf ; Sf = T * Hf^T + R  (k-ascending sums, GEMM order)
     float t00 = j.hf00 * p00 + j.hf01 * p10;
     float t01 = j.hf00 * p10 + j.hf01 * p11;
@@ -73,7 +86,7 @@ SLAM_DEV void inverse2(float a00, float a01, float a10, float a11, float &x00, f
     bool swap = fabsf(a10) > fabsf(a00);
     float u00 = swap ? a10 : a00, u01 = swap ? a11 : a01;
     float l10 = swap ? a00 : a10, r11 = swap ? a01 : a11;
-    if (u00 != 0.0f) l10 = l10 * (1.0f / u00);
+    if (u00 != 0.0f) l10 = l10 * frcp(u00);
     float u11 = r11 - l10 * u01;
     // P * I
     float b00 = swap ? 0.0f : 1.0f, b01 = swap ? 1.0f : 0.0f;
@@ -82,12 +95,12 @@ SLAM_DEV void inverse2(float a00, float a01, float a10, float a11, float &x00, f
     b10 -= b00 * l10;
     b11 -= b01 * l10;
     // upper solve (column-major order: row 1 first, then eliminate into row 0)
-    float a = 1.0f / u11;
+    float a = frcp(u11);
     b10 *= a;
     b11 *= a;
     b00 -= b10 * u01;
     b01 -= b11 * u01;
-    a = 1.0f / u00;
+    a = frcp(u00);
     x00 = b00 * a;
     x01 = b01 * a;
     x10 = b10;
@@ -98,7 +111,7 @@ SLAM_DEV float determinant2(float a00, float a01, float a10, float a11) {
     bool swap = fabsf(a10) > fabsf(a00);
     float u00 = swap ? a10 : a00, u01 = swap ? a11 : a01;
     float l10 = swap ? a00 : a10, r11 = swap ? a01 : a11;
-    if (u00 != 0.0f) l10 = l10 * (1.0f / u00);
+    if (u00 != 0.0f) l10 = l10 * frcp(u00);
     float u11 = r11 - l10 * u01;
     return (swap ? -1.0f : 1.0f) * (u00 * u11);
 }
@@ -113,19 +126,19 @@ SLAM_DEV L3 llt3(float a00, float a10, float a11, float a20, float a21, float a2
     L3 L = {a00, a10, a11, a20, a21, a22};
     float x = a00;
     if (x <= 0.0f) return L;
-    x = sqrtf(x);
+    x = fsqrt(x);
     L.l00 = x;
-    float r = 1.0f / x;
+    float r = frcp(x);
     L.l10 = a10 * r;
     L.l20 = a20 * r;
     x = a11 - L.l10 * L.l10;
     if (x <= 0.0f) return L;
-    x = sqrtf(x);
+    x = fsqrt(x);
     L.l11 = x;
-    L.l21 = (a21 + L.l20 * (-1.0f * L.l10)) * (1.0f / x);
+    L.l21 = (a21 + L.l20 * (-1.0f * L.l10)) * frcp(x);
     x = a22 - (L.l20 * L.l20 + L.l21 * L.l21);
     if (x <= 0.0f) return L;
-    L.l22 = sqrtf(x);
+    L.l22 = fsqrt(x);
     return L;
 }
 
@@ -137,19 +150,19 @@ SLAM_DEV L2 llt2(float a00, float a10, float a11) {
     L2 L = {a00, a10, a11};
     float x = a00;
     if (x <= 0.0f) return L;
-    x = sqrtf(x);
+    x = fsqrt(x);
     L.l00 = x;
-    L.l10 = a10 * (1.0f / x);
+    L.l10 = a10 * frcp(x);
     x = a11 - L.l10 * L.l10;
     if (x <= 0.0f) return L;
-    L.l11 = sqrtf(x);
+    L.l11 = fsqrt(x);
     return L;
 }
 
 // A.llt().solve(Identity) for 3x3 (TriangularSolverMatrix.h:109-137): column-oriented forward
 // substitution with reciprocal diagonals, then row-oriented back substitution.  X row-major, full.
 SLAM_DEV void llt_solve_identity3(const L3 &L, float X[9]) {
-    float a0 = 1.0f / L.l00, a1 = 1.0f / L.l11, a2 = 1.0f / L.l22;
+    float a0 = frcp(L.l00), a1 = frcp(L.l11), a2 = frcp(L.l22);
     // Y = L^-1 I
     float y00 = a0;
     float y10 = 0.0f - y00 * L.l10;
@@ -177,28 +190,28 @@ SLAM_DEV void llt_solve_identity3(const L3 &L, float X[9]) {
 // C = (2*pi)^(D/2) * prod(diag) with INTEGER D/2 => (2*pi)^1 for D = 2 and D = 3 (:152).
 SLAM_DEV float gauss2(float v0, float v1, float s00, float s10, float s11) {
     L2 L = llt2(s00, s10, s11);
-    float n0 = v0 / L.l00;
-    float n1 = (v1 - L.l10 * n0) / L.l11;
+    float n0 = fdiv(v0, L.l00);
+    float n1 = fdiv(v1 - L.l10 * n0, L.l11);
     float E = n0 * n0;
     E += n1 * n1;
     E = -0.5f * E;
     float prod = (1.0f * L.l00) * L.l11;
     float C = (float) ((2 * kPi) * (double) prod);
-    return expf(E) / C;
+    return fdiv(expf(E), C);
 }
 
 SLAM_DEV float gauss3(float v0, float v1, float v2, float a00, float a10, float a11, float a20, float a21, float a22) {
     L3 L = llt3(a00, a10, a11, a20, a21, a22);
-    float n0 = v0 / L.l00;
-    float n1 = (v1 - L.l10 * n0) / L.l11;
-    float n2 = (v2 - (L.l20 * n0 + L.l21 * n1)) / L.l22;
+    float n0 = fdiv(v0, L.l00);
+    float n1 = fdiv(v1 - L.l10 * n0, L.l11);
+    float n2 = fdiv(v2 - (L.l20 * n0 + L.l21 * n1), L.l22);
     float E = n0 * n0;
     E += n1 * n1;
     E += n2 * n2;
     E = -0.5f * E;
     float prod = ((1.0f * L.l00) * L.l11) * L.l22;
     float C = (float) ((2 * kPi) * (double) prod);
-    return expf(E) / C;
+    return fdiv(expf(E), C);
 }
 
 // choleskyUpdate for a 2x2 landmark (core.cpp:275-291).  P symmetric-packed in/out (p00,p10,p11).

@@ -53,21 +53,26 @@ def sym(P):
     return L + np.swapaxes(np.tril(P, -1), -1, -2)
 
 
-def compare_weights(got, exp, fs2, tag=""):
+# median relative weight error allowed per build: the fast build's 1-ulp hardware reciprocal/sqrt roughly triples
+# the strict build's rounding noise through the same ill-conditioned proposal (measured median 4.3e-4, worst step 1.2e-3)
+W_MEDIAN_TOL = {0: 1e-3, 1: 3e-3}
+
+
+def compare_weights(got, exp, fs2, tag="", math_mode=0):
     rel = np.abs(got.astype(np.float64) / exp.astype(np.float64) - 1.0)
     if not fs2:
         assert rel.max() <= 1e-3, (tag, rel.max())
         return
-    assert np.median(rel) <= 1e-3 and np.quantile(rel, 0.99) <= 5e-2 and rel.max() <= 0.3, (tag, np.median(rel), rel.max())
+    assert np.median(rel) <= W_MEDIAN_TOL[math_mode] and np.quantile(rel, 0.99) <= 5e-2 and rel.max() <= 0.3, (tag, np.median(rel), rel.max())
     pg, pe = got.astype(np.float64) / got.sum(dtype=np.float64), exp.astype(np.float64) / exp.sum(dtype=np.float64)
     assert 0.5 * np.abs(pg - pe).sum() <= 2e-2, (tag, "TV distance", 0.5 * np.abs(pg - pe).sum())
 
 
-def compare_state(got, exp, fs2=True, tag=""):
+def compare_state(got, exp, fs2=True, tag="", math_mode=0):
     assert got["nf"] == exp["xf"].shape[1], tag
     assert np.abs(got["xv"] - exp["xv"]).max() <= POSE_ATOL, (tag, np.abs(got["xv"] - exp["xv"]).max())
     assert close_cov(got["Pv"], sym(exp["Pv"])), (tag, "Pv")
-    compare_weights(got["w"], exp["w"], fs2, tag)
+    compare_weights(got["w"], exp["w"], fs2, tag, math_mode)
     if got["nf"]:
         assert np.abs(got["xf"] - exp["xf"]).max() <= POSE_ATOL * 5, (tag, np.abs(got["xf"] - exp["xf"]).max())
         assert close_cov(got["Pf"], sym(exp["Pf"])), (tag, "Pf")
@@ -88,9 +93,10 @@ def test_jacobians_seam1(sg, kat):
     assert zp.shape == (n, 2) and np.isfinite(Sf).all()
 
 
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
 @pytest.mark.parametrize("name,method", [("traj_fs2_webmap_N100_s7", 2), ("traj_fs1_webmap_N100_s7", 1),
                                          ("traj_fs2_webmap_N1000_s1", 2), ("traj_fs2_loop1_N50_s3", 2)])
-def test_teacher_forced_update_vs_golden(sg, name, method):
+def test_teacher_forced_update_vs_golden(sg, name, method, math_mode):
     """Upload the reference's pre-update particle set, run ONE slamgpu_update with the reference's tape,
     compare with the reference's post-update particle set."""
     g = load_golden(name)
@@ -100,7 +106,8 @@ def test_teacher_forced_update_vs_golden(sg, name, method):
         N = pre["w"].shape[0]
         pre["nf"] = pre["xf"].shape[1]
         s = sg.SlamGpu(N, 40, method=method, n_effective=int(g["meta_n_effective"]), use_heading=bool(g["meta_use_heading"]),
-                       wheel_base=float(g["meta_wheel_base"]), sigma_phi=float(g["meta_sigma_phi"]), rng_mode=sg.RNG_TAPE)
+                       wheel_base=float(g["meta_wheel_base"]), sigma_phi=float(g["meta_sigma_phi"]), rng_mode=sg.RNG_TAPE,
+                       math_mode=math_mode)
         s.upload(pre)
         m, n = g["m"][k - 1], g["n"][k - 1]
         s.update(g["zf"][k - 1, :m], g["idf"][k - 1, :m], g["zn"][k - 1, :n], g["meta_R"], g["snap%d_normals" % k], g["snap%d_sel" % k])
@@ -120,7 +127,7 @@ def test_teacher_forced_update_vs_golden(sg, name, method):
             ok = ~bad
             assert np.abs(got["xf"][ok] - exp["xf"][ok]).max() <= POSE_ATOL * 5
         else:
-            compare_state(got, exp, fs2=method == 2, tag="%s step %d" % (name, k))
+            compare_state(got, exp, fs2=method == 2, tag="%s step %d" % (name, k), math_mode=math_mode)
         s.close()
 
 
@@ -182,9 +189,12 @@ def drive_pair(sg, oracle, mapname, method, N, seed, nobs, math_mode=0, per_step
     return out
 
 
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
 @pytest.mark.parametrize("method,N,seed,nobs", [("FASTSLAM2", 100, 7, 120), ("FASTSLAM2", 1000, 1, 40),
                                                 ("FASTSLAM1", 100, 7, 60), ("FASTSLAM2", 5000, 12345, 10)])
-def test_stepwise_vs_oracle(sg, oracle, method, N, seed, nobs):
+def test_stepwise_vs_oracle(sg, oracle, method, N, seed, nobs, math_mode):
+    """Both kernel builds (strict: no FMA contraction, IEEE divide/sqrt; fast: contraction + the 1-ulp hardware
+    v_rcp_f32 / v_sqrt_f32) meet the same stated tolerances, except the median weight error (W_MEDIAN_TOL)."""
     def check(r):
         tag = "%s N=%d obs %d (m=%d n=%d)" % (method, N, r["k"], r["m"], r["n"])
         assert r["did"][0] == r["did"][1], tag
@@ -194,10 +204,10 @@ def test_stepwise_vs_oracle(sg, oracle, method, N, seed, nobs):
             bad = np.abs(r["got"]["xv"] - r["exp"]["xv"]).max(axis=1) > POSE_ATOL
             assert bad.mean() <= (0.04 if fs2 else 0.0), (tag, bad.mean())
         else:
-            compare_state(r["got"], r["exp"], fs2=fs2, tag=tag)
+            compare_state(r["got"], r["exp"], fs2=fs2, tag=tag, math_mode=math_mode)
         # after a resample a few particles may descend from a neighbouring ancestor (see header): mean moves by <= frac * spread
         np.testing.assert_allclose(r["est"][0][:2], r["est"][1][:2], atol=1e-2 if r["did"][0] else 5e-4, err_msg=tag)
-    drive_pair(sg, oracle, "example_webmap", method, N, seed, nobs, per_step=check)
+    drive_pair(sg, oracle, "example_webmap", method, N, seed, nobs, math_mode=math_mode, per_step=check)
 
 
 def test_free_running_statistics(sg, oracle):
