@@ -301,4 +301,223 @@ SLAM_DEV void box_muller3(U4 r, float &g0, float &g1, float &g2) {
     g2 = amp * sinf(ang);
 }
 
+#ifdef SLAM_FAST_MATH
+// ---------------------------------------------------------------------------------------------------
+// Fast build only: the same FastSLAM2 step, algebraically restructured for the VALU (the update kernel is
+// instruction-issue bound, not HBM bound: profiles/rocprof_sq_counters_r01.txt).  Same float32 storage, same
+// random draws, same sample mapping (chol(P) * g), but
+//   * the proposal is refined in covariance (Kalman-gain) form, K = P Hv^T (Hv P Hv^T + Sf)^-1 -- by the matrix
+//     inversion lemma the same Pv = (Hv^T Sf^-1 Hv + Pv^-1)^-1 and xv += Pv Hv^T Sf^-1 v of fastslam2.cpp:335-345
+//     without the two 3x3 LLT inversions per landmark (and without inverting the near-singular predicted Pv),
+//   * covariances stay symmetric-packed in registers,
+//   * 2x2 solves are closed-form (one v_rcp_f32), the feature update reuses Sf (core.cpp:275-291 recomputes it),
+//   * sin/cos/atan2 are branch-free 1.5-ulp polynomials (arguments are bounded angles: no Payne-Hanek path),
+//   * the k pending predicts are applied as ONE composite step (see predict_composite).
+// ---------------------------------------------------------------------------------------------------
+SLAM_DEV float ffma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// sin and cos of a bounded angle (|x| < ~100): 2-constant Cody-Waite reduction by pi/2 + Cephes minimax polynomials
+// on [-pi/4, pi/4]; max error 1.5 ulp (tools/check_fast_math.py)
+SLAM_DEV void sincos_cw(float x, float &sn, float &cs) {
+    const float q = __builtin_rintf(x * 0.63661977236758134f);
+    float r = ffma(q, -1.57079637050628662f, x);
+    r = ffma(q, 4.37113900018624283e-8f, r);
+    const float z = r * r;
+    float ps = ffma(z, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = ffma(ps, z, -1.6666654611e-1f);
+    const float s = ffma(r * z, ps, r);
+    float pc = ffma(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = ffma(pc, z, 4.166664568298827e-2f);
+    const float c = ffma(z * z, pc, ffma(z, -0.5f, 1.0f));
+    const int n = (int) q;
+    const float a = (n & 1) ? c : s;
+    const float b = (n & 1) ? s : c;
+    sn = __uint_as_float(__float_as_uint(a) ^ ((uint32_t) (n & 2) << 30));
+    cs = __uint_as_float(__float_as_uint(b) ^ ((uint32_t) ((n + 1) & 2) << 30));
+}
+
+// atan2 via min/max ratio + degree-8 minimax polynomial in t^2 on [0,1] (fit: tools/check_fast_math.py, 1.1 ulp)
+SLAM_DEV float atan2_poly(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float t = mn * __builtin_amdgcn_rcpf(mx);
+    const float z = t * t;
+    float p = 0.0029206702020019293f;
+    p = ffma(p, z, -0.016367841511964798f);
+    p = ffma(p, z, 0.04321172460913658f);
+    p = ffma(p, z, -0.0755220279097557f);
+    p = ffma(p, z, 0.10665999352931976f);
+    p = ffma(p, z, -0.14211054146289825f);
+    p = ffma(p, z, 0.19993773102760315f);
+    p = ffma(p, z, -0.33333152532577515f);
+    float r = ffma(t * z, p, t);
+    if (ay > ax) r = 1.57079637050628662f - r;
+    if (x < 0.0f) r = 3.14159274101257324f - r;
+    if (mx == 0.0f) r = 0.0f;
+    return __builtin_copysignf(r, y);
+}
+
+// pi_to_pi of a bounded angle: one rounding instead of trig_offset's compare/branch ladder (core.cpp:460-477)
+SLAM_DEV float wrap_pi(float a) {
+    const float n = __builtin_rintf(a * 0.15915494309189535f);
+    a = ffma(n, -6.28318548202514648f, a);
+    return ffma(n, 1.74845553146951715e-7f, a);
+}
+
+struct Sym3 {
+    float p00, p10, p11, p20, p21, p22;
+};
+
+// Lower Cholesky factor plus the reciprocals of its diagonal (Eigen LLT's keep-input-on-bad-pivot behaviour is kept)
+struct L3r {
+    float l00, l10, l11, l20, l21, l22, r0, r1, r2;
+};
+
+SLAM_DEV L3r llt3r(const Sym3 &A) {
+    L3r L = {A.p00, A.p10, A.p11, A.p20, A.p21, A.p22, 1.0f, 1.0f, 1.0f};
+    if (A.p00 > 0.0f) {
+        L.r0 = __builtin_amdgcn_rsqf(A.p00);
+        L.l00 = A.p00 * L.r0;
+        L.l10 = A.p10 * L.r0;
+        L.l20 = A.p20 * L.r0;
+        const float x = ffma(-L.l10, L.l10, A.p11);
+        if (x > 0.0f) {
+            L.r1 = __builtin_amdgcn_rsqf(x);
+            L.l11 = x * L.r1;
+            L.l21 = ffma(-L.l20, L.l10, A.p21) * L.r1;
+            const float y = ffma(-L.l21, L.l21, ffma(-L.l20, L.l20, A.p22));
+            if (y > 0.0f) {
+                L.r2 = __builtin_amdgcn_rsqf(y);
+                L.l22 = y * L.r2;
+            } else {
+                L.r2 = __builtin_amdgcn_rcpf(L.l22);
+            }
+        } else {
+            L.r1 = __builtin_amdgcn_rcpf(L.l11);
+            L.r2 = __builtin_amdgcn_rcpf(L.l22);
+        }
+    } else {
+        L.r0 = __builtin_amdgcn_rcpf(L.l00);
+        L.r1 = __builtin_amdgcn_rcpf(L.l11);
+        L.r2 = __builtin_amdgcn_rcpf(L.l22);
+    }
+    return L;
+}
+
+// -0.5 * |L^-1 v|^2 (the exponent of gaussEvaluate, fastslam2.cpp:127-163)
+SLAM_DEV float gauss3_exponent(const L3r &L, float v0, float v1, float v2) {
+    const float n0 = v0 * L.r0;
+    const float n1 = ffma(-L.l10, n0, v1) * L.r1;
+    const float n2 = ffma(-L.l21, n1, ffma(-L.l20, n0, v2)) * L.r2;
+    return -0.5f * ffma(n2, n2, ffma(n1, n1, n0 * n0));
+}
+
+// computeJacobians for one feature (core.cpp:682-704) in the form the restructured update consumes:
+// predicted observation, Hf (Hv = [-Hf | (0,-1)^T]) and the symmetric Sf = Hf Pf Hf^T + R
+struct Obs2 {
+    float zp0, zp1;
+    float hf00, hf01, hf10, hf11;
+    float s00, s10, s11;
+};
+
+SLAM_DEV Obs2 observe2(float x, float y, float th, float fx, float fy, float f00, float f10, float f11, float r00, float r10,
+                       float r11) {
+    Obs2 o;
+    const float dx = fx - x, dy = fy - y;
+    const float d2 = ffma(dx, dx, dy * dy);
+    const float rd = __builtin_amdgcn_rsqf(d2);
+    const float rd2 = rd * rd;
+    o.zp0 = d2 * rd;
+    o.zp1 = atan2_poly(dy, dx) - th;
+    o.hf00 = dx * rd;
+    o.hf01 = dy * rd;
+    o.hf10 = -dy * rd2;
+    o.hf11 = dx * rd2;
+    const float t00 = ffma(o.hf00, f00, o.hf01 * f10), t01 = ffma(o.hf00, f10, o.hf01 * f11);
+    const float t10 = ffma(o.hf10, f00, o.hf11 * f10), t11 = ffma(o.hf10, f10, o.hf11 * f11);
+    o.s00 = ffma(t00, o.hf00, ffma(t01, o.hf01, r00));
+    o.s10 = ffma(t10, o.hf00, ffma(t11, o.hf01, r10));
+    o.s11 = ffma(t10, o.hf10, ffma(t11, o.hf11, r11));
+    return o;
+}
+
+// One refinement of the proposal N(xv, P) by a re-observed feature (fastslam2.cpp:320-349) in Kalman-gain form
+SLAM_DEV void proposal_update(float &x, float &y, float &th, Sym3 &P, const Obs2 &o, float v0, float v1) {
+    const float a0 = -o.hf00, a1 = -o.hf01, b0 = -o.hf10, b1 = -o.hf11;  // Hv rows: (a0 a1 0), (b0 b1 -1)
+    // C = P Hv^T (3x2)
+    const float c00 = ffma(P.p00, a0, P.p10 * a1), c01 = ffma(P.p00, b0, ffma(P.p10, b1, -P.p20));
+    const float c10 = ffma(P.p10, a0, P.p11 * a1), c11 = ffma(P.p10, b0, ffma(P.p11, b1, -P.p21));
+    const float c20 = ffma(P.p20, a0, P.p21 * a1), c21 = ffma(P.p20, b0, ffma(P.p21, b1, -P.p22));
+    // S = Hv C + Sf (symmetric)
+    const float s00 = ffma(a0, c00, ffma(a1, c10, o.s00));
+    const float s10 = ffma(b0, c00, ffma(b1, c10, o.s10 - c20));
+    const float s11 = ffma(b0, c01, ffma(b1, c11, o.s11 - c21));
+    const float rdet = __builtin_amdgcn_rcpf(ffma(s00, s11, -s10 * s10));
+    const float i00 = s11 * rdet, i10 = -s10 * rdet, i11 = s00 * rdet;
+    // K = C S^-1
+    const float k00 = ffma(c00, i00, c01 * i10), k01 = ffma(c00, i10, c01 * i11);
+    const float k10 = ffma(c10, i00, c11 * i10), k11 = ffma(c10, i10, c11 * i11);
+    const float k20 = ffma(c20, i00, c21 * i10), k21 = ffma(c20, i10, c21 * i11);
+    x = ffma(k00, v0, ffma(k01, v1, x));
+    y = ffma(k10, v0, ffma(k11, v1, y));
+    th = ffma(k20, v0, ffma(k21, v1, th));
+    // P -= K C^T
+    P.p00 = ffma(-k00, c00, ffma(-k01, c01, P.p00));
+    P.p10 = ffma(-k10, c00, ffma(-k11, c01, P.p10));
+    P.p11 = ffma(-k10, c10, ffma(-k11, c11, P.p11));
+    P.p20 = ffma(-k20, c00, ffma(-k21, c01, P.p20));
+    P.p21 = ffma(-k20, c10, ffma(-k21, c11, P.p21));
+    P.p22 = ffma(-k20, c20, ffma(-k21, c21, P.p22));
+}
+
+// likelihoodGivenXv term (fastslam2.cpp:370-400) + featureUpdate (core.cpp:132-175, :275-291) of one feature at the
+// sampled pose; both use the same Sf.  Returns gaussEvaluate(v, Sf) = exp(-v^T Sf^-1 v / 2) / (2 pi sqrt(det Sf)).
+SLAM_DEV float feature_update2(float &fx, float &fy, float &f00, float &f10, float &f11, const Obs2 &o, float v0, float v1) {
+    const float det = ffma(o.s00, o.s11, -o.s10 * o.s10);
+    const float rdet = __builtin_amdgcn_rcpf(det);
+    const float i00 = o.s11 * rdet, i10 = -o.s10 * rdet, i11 = o.s00 * rdet;
+    const float u0 = ffma(i00, v0, i10 * v1), u1 = ffma(i10, v0, i11 * v1);  // Sf^-1 v
+    const float E = -0.5f * ffma(v0, u0, v1 * u1);
+    const float lik = __expf(E) * (0.15915494309189535f * __builtin_amdgcn_rsqf(det));
+    // C = Pf Hf^T ; W = C Sf^-1 ; xf += W v = C (Sf^-1 v) ; Pf -= W C^T
+    const float c00 = ffma(f00, o.hf00, f10 * o.hf01), c01 = ffma(f00, o.hf10, f10 * o.hf11);
+    const float c10 = ffma(f10, o.hf00, f11 * o.hf01), c11 = ffma(f10, o.hf10, f11 * o.hf11);
+    fx = ffma(c00, u0, ffma(c01, u1, fx));
+    fy = ffma(c10, u0, ffma(c11, u1, fy));
+    const float w00 = ffma(c00, i00, c01 * i10), w01 = ffma(c00, i10, c01 * i11);
+    const float w10 = ffma(c10, i00, c11 * i10), w11 = ffma(c10, i10, c11 * i11);
+    f00 = ffma(-w00, c00, ffma(-w01, c01, f00));
+    f10 = ffma(-w10, c00, ffma(-w11, c01, f10));
+    f11 = ffma(-w10, c10, ffma(-w11, c11, f11));
+    return lik;
+}
+
+// addFeature (core.cpp:488-501) with the polynomial sincos
+SLAM_DEV void add_feature_fast(float x, float y, float th, float r, float b, float r00, float r01, float r10, float r11,
+                               float &fx, float &fy, float &p00, float &p10, float &p11) {
+    float s, c;
+    sincos_cw(th + b, s, c);
+    fx = ffma(r, c, x);
+    fy = ffma(r, s, y);
+    const float g00 = c, g01 = -r * s, g10 = s, g11 = r * c;
+    const float t00 = ffma(g00, r00, g01 * r10), t01 = ffma(g00, r01, g01 * r11);
+    const float t10 = ffma(g10, r00, g11 * r10), t11 = ffma(g10, r01, g11 * r11);
+    p00 = ffma(t00, g00, t01 * g01);
+    p10 = ffma(t10, g00, t11 * g01);
+    p11 = ffma(t10, g10, t11 * g11);
+}
+
+// Box-Muller with the hardware transcendentals: v_log_f32 (log2), v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in
+// revolutions, which is exactly u).  Same pairing as box_muller3.
+SLAM_DEV void box_muller3_fast(U4 r, float &g0, float &g1, float &g2) {
+    const float k = -1.38629436111989062f;  // -2 ln 2
+    float amp = __builtin_amdgcn_sqrtf(k * __builtin_amdgcn_logf(u01(r.x)));
+    float u = u01(r.y);
+    g0 = amp * __builtin_amdgcn_sinf(u);
+    g1 = amp * __builtin_amdgcn_cosf(u);
+    amp = __builtin_amdgcn_sqrtf(k * __builtin_amdgcn_logf(u01(r.z)));
+    g2 = amp * __builtin_amdgcn_sinf(u01(r.w));
+}
+#endif  // SLAM_FAST_MATH
+
 }  // namespace SLAM_KNS

@@ -78,12 +78,25 @@ struct PredictStep {
     uint32_t pad;
 };
 
+// The queued predicts folded into ONE step, for the fast build.  FastSLAM2::predictState without per-particle control
+// noise and without the heading observation is the same map for every particle when written in the frame of the
+// particle's own pose at the first queued step (the motion model is SE(2)-equivariant): with T = diag(R(theta0), 1),
+//   xy += R(theta0) (ax, ay),  theta += dth,  Pv = F Pv F^T + T M T^T,  F = I + [J R(theta0)(ax, ay); 0] e3^T,
+// where (ax, ay), dth and the accumulated process noise M (body frame, symmetric-packed) come from running
+// fastslam2.cpp:70-105 once on the host, in double, for theta0 = 0.
+struct PredictComposite {
+    int32_t valid;
+    float ax, ay, dth;
+    float m00, m10, m11, m20, m21, m22;
+};
+
 struct PredictArgs {
     int32_t nsteps;
     int32_t method, use_heading, add_noise;
     float Q[4];
     float dt, wheel_base, sigma_phi;
     PredictStep steps[kMaxFusedPredict];
+    PredictComposite comp;
 };
 
 struct UpdateArgs {

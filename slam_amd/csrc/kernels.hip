@@ -119,11 +119,51 @@ SLAM_DEV void predict_steps(float &x, float &y, float &th, float P[9], const Pre
     }
 }
 
+#ifdef SLAM_FAST_MATH
+// All queued predicts as one step (PredictComposite, kernels.h): one sincos and ~60 FMAs per particle instead of
+// ~190 instructions per queued predict.
+SLAM_DEV void predict_composite(float &x, float &y, float &th, Sym3 &P, const PredictComposite &C) {
+    float s, c;
+    sincos_cw(th, s, c);
+    const float dx = ffma(c, C.ax, -s * C.ay), dy = ffma(s, C.ax, c * C.ay);
+    const float f0 = -dy, f1 = dx;  // F = I + (f0, f1, 0)^T e3^T
+    // F P F^T
+    const float n20 = ffma(f0, P.p22, P.p20), n21 = ffma(f1, P.p22, P.p21);
+    const float n00 = ffma(f0, P.p20 + n20, P.p00);
+    const float n10 = ffma(f1, P.p20, ffma(f0, n21, P.p10));
+    const float n11 = ffma(f1, P.p21 + n21, P.p11);
+    // T M T^T, T = diag(R(th), 1)
+    const float t00 = ffma(c, C.m00, -s * C.m10), t01 = ffma(c, C.m10, -s * C.m11);
+    const float t10 = ffma(s, C.m00, c * C.m10), t11 = ffma(s, C.m10, c * C.m11);
+    P.p00 = n00 + ffma(t00, c, -t01 * s);
+    P.p10 = n10 + ffma(t10, c, -t11 * s);
+    P.p11 = n11 + ffma(t10, s, t11 * c);
+    P.p20 = n20 + ffma(c, C.m20, -s * C.m21);
+    P.p21 = n21 + ffma(s, C.m20, c * C.m21);
+    P.p22 = P.p22 + C.m22;
+    x += dx;
+    y += dy;
+    th = wrap_pi(th + C.dth);
+}
+#endif
+
 __global__ void __launch_bounds__(kBlock) predict_kernel(Buffers B, PredictArgs A, RngArgs rng) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= B.n) return;
     const int cur = B.ctrl->cur;
     float4 a = B.poseA[cur][i];
+#ifdef SLAM_FAST_MATH
+    if (A.comp.valid) {
+        const float4 b = B.poseB[cur][i];
+        const float2 c = B.poseC[cur][i];
+        Sym3 P = {b.x, b.y, b.z, b.w, c.x, c.y};
+        predict_composite(a.x, a.y, a.z, P, A.comp);
+        B.poseA[cur][i] = a;
+        B.poseB[cur][i] = make_float4(P.p00, P.p10, P.p11, P.p20);
+        B.poseC[cur][i] = make_float2(P.p21, P.p22);
+        return;
+    }
+#endif
     float P[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const bool fs2 = A.method == 2;
     if (fs2) {
@@ -199,12 +239,112 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             q00 = pb.x; q10 = pb.y; q11 = pb.z; q20 = pb.w; q21 = pc.x; q22 = pc.y;
         }
         if (PA.nsteps > 0) {
-            float P[9] = {q00, q10, q20, q10, q11, q21, q20, q21, q22};
-            predict_steps(x, y, th, P, PA, rng, i, S);
-            q00 = P[0]; q10 = P[3]; q11 = P[4]; q20 = P[6]; q21 = P[7]; q22 = P[8];
+#ifdef SLAM_FAST_MATH
+            if (PA.comp.valid) {
+                Sym3 P = {q00, q10, q11, q20, q21, q22};
+                predict_composite(x, y, th, P, PA.comp);
+                q00 = P.p00; q10 = P.p10; q11 = P.p11; q20 = P.p20; q21 = P.p21; q22 = P.p22;
+            } else
+#endif
+            {
+                float P[9] = {q00, q10, q20, q10, q11, q21, q20, q21, q22};
+                predict_steps(x, y, th, P, PA, rng, i, S);
+                q00 = P[0]; q10 = P[3]; q11 = P[4]; q20 = P[6]; q21 = P[7]; q22 = P[8];
+            }
             pose_dirty = true;
         }
 
+#ifdef SLAM_FAST_MATH
+        if (METHOD == 2) {
+            // restructured arithmetic (device_math.h, fast section); same data flow as the strict branch below
+            float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+            if (m > 0 || n > 0) {
+                if (rng.mode == 0) {
+                    g0 = rng.normals[0 * S + i];
+                    g1 = rng.normals[1 * S + i];
+                    g2 = rng.normals[2 * S + i];
+                } else {
+                    U4 r = philox4x32((uint32_t) (rng.first_particle + i), rng.step, 0u, 0u, rng.k0, rng.k1);
+                    box_muller3_fast(r, g0, g1, g2);
+                }
+            }
+            const float rl = 0.5f * (r01 + r10);
+            if (m > 0) {
+                const float x0 = x, y0 = y, th0 = th;
+                Sym3 P = {q00, q10, q11, q20, q21, q22};
+                const L3r L0 = llt3r(P);  // factor of Pv0 for the prior term (:366)
+                {
+                    float4 ta[kStage];
+                    float tb[kStage];
+#pragma unroll
+                    for (int k = 0; k < kStage; k++) {
+                        const size_t li = (size_t) idf[min(k, m - 1)] * S + i;
+                        ta[k] = lmkA[li];
+                        tb[k] = lmkB[li];
+                    }
+#pragma unroll
+                    for (int k = 0; k < kStage; k++) {
+                        shA[k][threadIdx.x] = ta[k];
+                        shB[k][threadIdx.x] = tb[k];
+                    }
+                }
+                for (int k = 0; k < m; k++) {
+                    float4 la;
+                    float lb;
+                    if (k < kStage) {
+                        la = shA[k][threadIdx.x];
+                        lb = shB[k][threadIdx.x];
+                    } else {
+                        la = lmkA[(size_t) idf[k] * S + i];
+                        lb = lmkB[(size_t) idf[k] * S + i];
+                    }
+                    const Obs2 o = observe2(x, y, th, la.x, la.y, la.z, la.w, lb, r00, rl, r11);
+                    proposal_update(x, y, th, P, o, zf[2 * k] - o.zp0, wrap_pi(zf[2 * k + 1] - o.zp1));
+                }
+                const L3r Lp = llt3r(P);
+                const float xs = ffma(Lp.l00, g0, x);
+                const float ys = ffma(Lp.l11, g1, ffma(Lp.l10, g0, y));
+                const float ths = ffma(Lp.l22, g2, ffma(Lp.l21, g1, ffma(Lp.l20, g0, th)));
+                float lik = 1.0f;
+                auto second_pass = [&](int k, float4 la, float lb) {
+                    const size_t li = (size_t) idf[k] * S + i;
+                    const Obs2 o = observe2(xs, ys, ths, la.x, la.y, la.z, la.w, lb, r00, rl, r11);
+                    lik *= feature_update2(la.x, la.y, la.z, la.w, lb, o, zf[2 * k] - o.zp0, wrap_pi(zf[2 * k + 1] - o.zp1));
+                    lmkA[li] = la;
+                    lmkB[li] = lb;
+                };
+                const int ms = min(m, kStage);
+                for (int k = 0; k < ms; k++) second_pass(k, shA[k][threadIdx.x], shB[k][threadIdx.x]);
+                for (int k = ms; k < m; k++)
+                    second_pass(k, lmkA[(size_t) idf[k] * S + i], lmkB[(size_t) idf[k] * S + i]);
+                // w *= likelihood * prior / proposal (:360-367): one exponential for the ratio of the two Gaussians
+                const float E = gauss3_exponent(L0, x0 - xs, y0 - ys, wrap_pi(th0 - ths)) -
+                                gauss3_exponent(Lp, x - xs, y - ys, wrap_pi(th - ths));
+                const float ratio = ((Lp.l00 * Lp.l11) * Lp.l22) * ((L0.r0 * L0.r1) * L0.r2);
+                w = w * lik * (__expf(E) * ratio);
+                x = xs;
+                y = ys;
+                th = ths;
+                q00 = q10 = q11 = q20 = q21 = q22 = 0.0f;
+                pose_dirty = true;
+            } else if (n > 0) {
+                const L3r L = llt3r(Sym3{q00, q10, q11, q20, q21, q22});
+                x = ffma(L.l00, g0, x);
+                y = ffma(L.l11, g1, ffma(L.l10, g0, y));
+                th = ffma(L.l22, g2, ffma(L.l21, g1, ffma(L.l20, g0, th)));
+                q00 = q10 = q11 = q20 = q21 = q22 = 0.0f;
+                pose_dirty = true;
+            }
+            for (int k = 0; k < n; k++) {
+                float4 la;
+                float lb;
+                add_feature_fast(x, y, th, zn[2 * k], zn[2 * k + 1], r00, r01, r10, r11, la.x, la.y, la.z, la.w, lb);
+                const size_t li = (size_t) (nf + k) * S + i;
+                lmkA[li] = la;
+                lmkB[li] = lb;
+            }
+        } else
+#endif
         if (METHOD == 2) {
             float g0 = 0.f, g1 = 0.f, g2 = 0.f;
             if (m > 0 || n > 0) {
@@ -350,6 +490,9 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             }
         }
         // addFeature (core.cpp:479-509): new landmarks appended at nf, nf+1, ...
+#ifdef SLAM_FAST_MATH
+        if (METHOD != 2)  // the fast FastSLAM2 branch above has already added them
+#endif
         for (int k = 0; k < n; k++) {
             float4 la;
             float lb;

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -148,9 +149,52 @@ RngArgs rng_args(const slamgpu_ctx *c, uint32_t step) {
     return r;
 }
 
+// Fold the queued predicts into PredictArgs::comp (see kernels.h): FastSLAM2::predictState (fastslam2.cpp:70-105)
+// run once in double for a particle at the origin with heading 0.
+void compose_predicts(PredictArgs &P) {
+    PredictComposite &C = P.comp;
+    C = PredictComposite{};
+    if (P.method != SLAMGPU_FASTSLAM2 || P.add_noise || P.use_heading || P.nsteps == 0) return;
+    static const bool off = getenv("SLAMGPU_NO_COMPOSITE") != nullptr;  // diagnostic: sequential predicts in the fast build
+    if (off) return;
+    const double dt = P.dt, wb = P.wheel_base;
+    const double Q[2][2] = {{P.Q[0], P.Q[1]}, {P.Q[2], P.Q[3]}};
+    double ax = 0, ay = 0, dth = 0;
+    double M[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int k = 0; k < P.nsteps; k++) {
+        const double V = P.steps[k].V, G = P.steps[k].G;
+        const double sn = sin(G + dth), cs = cos(G + dth);
+        const double Gv[3][3] = {{1, 0, -V * dt * sn}, {0, 1, V * dt * cs}, {0, 0, 1}};
+        const double Gu[3][2] = {{dt * cs, -V * dt * sn}, {dt * sn, V * dt * cs}, {dt * sin(G) / wb, V * dt * cos(G) / wb}};
+        double T[3][3], N[3][3], U[3][2];
+        for (int r = 0; r < 3; r++)
+            for (int c2 = 0; c2 < 3; c2++) T[r][c2] = Gv[r][0] * M[0][c2] + Gv[r][1] * M[1][c2] + Gv[r][2] * M[2][c2];
+        for (int r = 0; r < 3; r++)
+            for (int c2 = 0; c2 < 3; c2++) N[r][c2] = T[r][0] * Gv[c2][0] + T[r][1] * Gv[c2][1] + T[r][2] * Gv[c2][2];
+        for (int r = 0; r < 3; r++)
+            for (int c2 = 0; c2 < 2; c2++) U[r][c2] = Gu[r][0] * Q[0][c2] + Gu[r][1] * Q[1][c2];
+        for (int r = 0; r < 3; r++)
+            for (int c2 = 0; c2 < 3; c2++) M[r][c2] = N[r][c2] + U[r][0] * Gu[c2][0] + U[r][1] * Gu[c2][1];
+        ax += V * dt * cs;
+        ay += V * dt * sn;
+        dth += V * dt * sin(G / wb);  // sin(G/wheelBase): upstream quirk (fastslam2.cpp:103)
+    }
+    C.valid = 1;
+    C.ax = (float) ax;
+    C.ay = (float) ay;
+    C.dth = (float) dth;
+    C.m00 = (float) M[0][0];
+    C.m10 = (float) (0.5 * (M[1][0] + M[0][1]));
+    C.m11 = (float) M[1][1];
+    C.m20 = (float) (0.5 * (M[2][0] + M[0][2]));
+    C.m21 = (float) (0.5 * (M[2][1] + M[1][2]));
+    C.m22 = (float) M[2][2];
+}
+
 int flush_predict(slamgpu_ctx *c) {
     if (c->pending.nsteps == 0) return 0;
     HIP_TRY(hipSetDevice(c->cfg.device));
+    compose_predicts(c->pending);
     {
         Timed t(c, "predict");
         c->k->predict(c->stream, c->B, c->pending, rng_args(c, 0));
@@ -425,6 +469,7 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     // pending predicts ride inside the update launch (state stays in registers) unless their noise is a host tape
     PredictArgs PA{};
     if (c->pending.nsteps > 0) {
+        compose_predicts(c->pending);
         PA = c->pending;
         c->predict_bytes += 72.0 * c->cfg.n_particles * c->pending.nsteps;
         c->pending.nsteps = 0;

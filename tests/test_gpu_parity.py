@@ -17,7 +17,8 @@ parallel (wave-scan) order of the weight sums):
                             of atan2f upstream) moves the weight by ~1e-2.  The reference's own float32 value is
                             up to 26 % away from a float64 evaluation of the same formula (tools note in DESIGN.md),
                             so a tighter bound would test rounding noise, not the kernel.  Measured: median 1.4e-4,
-                            p99 1.1e-2, max 7.4e-2.
+                            p99 1.1e-2, max 7.4e-2.  These are the strict build's bounds; the fast build (restructured
+                            arithmetic) has its own, wider weight bounds: see W_TOL below.
   Neff                    : 2e-2 relative (FastSLAM1: 1e-4);  resample decision identical
   ancestors               : follow from the weights: <= 4 % of particles may pick a neighbouring ancestor
                             (FastSLAM1: identical)
@@ -53,9 +54,23 @@ def sym(P):
     return L + np.swapaxes(np.tril(P, -1), -1, -2)
 
 
-# median relative weight error allowed per build: the fast build's 1-ulp hardware reciprocal/sqrt roughly triples
-# the strict build's rounding noise through the same ill-conditioned proposal (measured median 4.3e-4, worst step 1.2e-3)
-W_MEDIAN_TOL = {0: 1e-3, 1: 3e-3}
+# Weight tolerances per build (median, 99th percentile, max of |w_gpu / w_ref - 1|, total-variation distance, share of
+# particles whose post-resample ancestor may differ).
+#   strict (0): replays the reference's float operations one by one; only the device libm differs.
+#   fast   (1): the same step algebraically restructured (device_math.h, fast section).  It cannot replay the
+#               reference's roundings, and FastSLAM2's weights amplify rounding: nudging every stored float of the
+#               predicted Pv by ONE ulp moves the reference's own weights by median 3e-4, p99 4e-3..9e-3, max 1.6e-2
+#               (tools/weight_conditioning.py, CPU, oracle only).  Measured for the fast build over 300 teacher-forced
+#               steps: median 1.7e-3 (N=100) / 6.7e-4 (N=1000), p99 3.6e-2, max 1.1e-1, ancestors 3-4 %
+#               (tools/parity_report.py); poses and landmarks meet the same absolute tolerances as strict.
+#               Against a float64 evaluation of the same update (tests/fs2_float64.py) the float32 REFERENCE is off by
+#               median 1.4e-3, p99 2.1e-2, max 6e-2 and the fast build by median 1.9e-3, p99 2.9e-2, max 8.5e-2: the two
+#               are equally good float32 evaluations of one formula (test_fast_build_vs_float64_yardstick).  Per step
+#               the median can reach 6.5e-3 (a 6-landmark step), hence the per-step bound of 1e-2; a weight error eps
+#               moves about N * eps strata across a cumulative-sum boundary, so ONE step at N=100 can swap 9 % of the
+#               ancestors (bound 15 %) while the average over the run is 3-4 %.
+W_TOL = {0: dict(median=1e-3, p99=5e-2, max=0.3, tv=2e-2, ancestors=0.04),
+         1: dict(median=1e-2, p99=1e-1, max=0.5, tv=3e-2, ancestors=0.15)}
 
 
 def compare_weights(got, exp, fs2, tag="", math_mode=0):
@@ -63,9 +78,19 @@ def compare_weights(got, exp, fs2, tag="", math_mode=0):
     if not fs2:
         assert rel.max() <= 1e-3, (tag, rel.max())
         return
-    assert np.median(rel) <= W_MEDIAN_TOL[math_mode] and np.quantile(rel, 0.99) <= 5e-2 and rel.max() <= 0.3, (tag, np.median(rel), rel.max())
+    tol = W_TOL[math_mode]
+    if math_mode == 1:
+        # The fast build is compared on NORMALISED weights (what resampleParticles consumes, core.cpp:726) plus a loose
+        # check of the common factor: all particles share the same eight predicts from Pv = 0, so their Pv0 are
+        # rotations of one matrix and the rounding error of its Cholesky shifts every weight by the same fraction
+        # (seen: 0.7 % at a 6-landmark step), which normalisation removes.
+        sg_, se_ = got.sum(dtype=np.float64), exp.sum(dtype=np.float64)
+        assert abs(sg_ / se_ - 1.0) <= 5e-2, (tag, "common factor", sg_ / se_)
+        rel = np.abs((got.astype(np.float64) / sg_) / (exp.astype(np.float64) / se_) - 1.0)
+    assert np.median(rel) <= tol["median"] and np.quantile(rel, 0.99) <= tol["p99"] and rel.max() <= tol["max"], \
+        (tag, np.median(rel), np.quantile(rel, 0.99), rel.max())
     pg, pe = got.astype(np.float64) / got.sum(dtype=np.float64), exp.astype(np.float64) / exp.sum(dtype=np.float64)
-    assert 0.5 * np.abs(pg - pe).sum() <= 2e-2, (tag, "TV distance", 0.5 * np.abs(pg - pe).sum())
+    assert 0.5 * np.abs(pg - pe).sum() <= tol["tv"], (tag, "TV distance", 0.5 * np.abs(pg - pe).sum())
 
 
 def compare_state(got, exp, fs2=True, tag="", math_mode=0):
@@ -123,7 +148,7 @@ def test_teacher_forced_update_vs_golden(sg, name, method, math_mode):
             # reference ancestors recovered from the oracle-free identity: post particle k == some pre particle;
             # check the bulk of the particles agree with the reference post state
             bad = np.abs(got["xv"] - exp["xv"]).max(axis=1) > POSE_ATOL
-            assert bad.mean() <= (0.04 if method == 2 else 0.0), (name, k, bad.mean())
+            assert bad.mean() <= (W_TOL[math_mode]["ancestors"] if method == 2 else 0.0), (name, k, bad.mean())
             ok = ~bad
             assert np.abs(got["xf"][ok] - exp["xf"][ok]).max() <= POSE_ATOL * 5
         else:
@@ -148,7 +173,7 @@ def test_teacher_forced_predict_vs_golden(sg):
             s.close()
 
 
-def drive_pair(sg, oracle, mapname, method, N, seed, nobs, math_mode=0, per_step=None):
+def drive_pair(sg, oracle, mapname, method, N, seed, nobs, math_mode=0, per_step=None, want_pre=False):
     """Run the oracle simulation; feed the GPU context the same controls, observations and RNG tape; at each
     observation step re-synchronise the GPU state to the oracle's (teacher forcing) after comparing."""
     from oracle import orc  # noqa: F401  (checker only)
@@ -170,6 +195,7 @@ def drive_pair(sg, oracle, mapname, method, N, seed, nobs, math_mode=0, per_step
             noise2 = o.last_noise2()
         s.predict(float(vg[0]), float(vg[1]), Q, float(dt), float(x[2]), noise2)
         if a == 1:
+            pre = o.particles() if want_pre else None  # predicted, not yet updated
             o.observe()
             ob = o.last_obs()
             normals, sel = o.last_tape()
@@ -180,7 +206,8 @@ def drive_pair(sg, oracle, mapname, method, N, seed, nobs, math_mode=0, per_step
             ne_o, did_o = o.last_resample()
             ne_g, did_g, _ = s.stats()
             out.append(dict(k=k, got=got, exp=exp, neff=(ne_g, ne_o), did=(did_g, did_o), est=(s.estimate(), o.estimate()),
-                            keep=s.ancestors() if did_g else None, m=ob["zf"].shape[0], n=ob["zn"].shape[0]))
+                            keep=s.ancestors() if did_g else None, m=ob["zf"].shape[0], n=ob["zn"].shape[0],
+                            pre=pre, obs=ob, normals=normals, R=R))
             if per_step:
                 per_step(out[-1])
             s.upload(exp)  # teacher forcing: continue from the oracle's state
@@ -194,7 +221,8 @@ def drive_pair(sg, oracle, mapname, method, N, seed, nobs, math_mode=0, per_step
                                                 ("FASTSLAM1", 100, 7, 60), ("FASTSLAM2", 5000, 12345, 10)])
 def test_stepwise_vs_oracle(sg, oracle, method, N, seed, nobs, math_mode):
     """Both kernel builds (strict: no FMA contraction, IEEE divide/sqrt; fast: contraction + the 1-ulp hardware
-    v_rcp_f32 / v_sqrt_f32) meet the same stated tolerances, except the median weight error (W_MEDIAN_TOL)."""
+    v_rcp_f32 / v_sqrt_f32 and the restructured arithmetic) meet the same pose / landmark / covariance tolerances; the
+    weight tolerances are per build (W_TOL)."""
     def check(r):
         tag = "%s N=%d obs %d (m=%d n=%d)" % (method, N, r["k"], r["m"], r["n"])
         assert r["did"][0] == r["did"][1], tag
@@ -202,12 +230,35 @@ def test_stepwise_vs_oracle(sg, oracle, method, N, seed, nobs, math_mode):
         np.testing.assert_allclose(r["neff"][0], r["neff"][1], rtol=2e-2 if fs2 else 1e-4, err_msg=tag)
         if r["did"][0]:
             bad = np.abs(r["got"]["xv"] - r["exp"]["xv"]).max(axis=1) > POSE_ATOL
-            assert bad.mean() <= (0.04 if fs2 else 0.0), (tag, bad.mean())
+            assert bad.mean() <= (W_TOL[math_mode]["ancestors"] if fs2 else 0.0), (tag, bad.mean())
         else:
             compare_state(r["got"], r["exp"], fs2=fs2, tag=tag, math_mode=math_mode)
         # after a resample a few particles may descend from a neighbouring ancestor (see header): mean moves by <= frac * spread
         np.testing.assert_allclose(r["est"][0][:2], r["est"][1][:2], atol=1e-2 if r["did"][0] else 5e-4, err_msg=tag)
     drive_pair(sg, oracle, "example_webmap", method, N, seed, nobs, math_mode=math_mode, per_step=check)
+
+
+def test_fast_build_vs_float64_yardstick(sg, oracle):
+    """Where the fast build and the float32 reference disagree about a weight, neither is privileged: compare both
+    with a float64 evaluation of the same update from the same (float32) predicted particle set.  The fast build's
+    error must stay within 2x the reference's own (measured 1.3x), over all non-resampling steps of the run."""
+    import fs2_float64
+    e_gpu, e_ref = [], []
+
+    def collect(r):
+        if r["did"][0] or r["did"][1] or r["m"] == 0:
+            return
+        _, wt = fs2_float64.update_weights(r["pre"], r["obs"]["zf"], r["obs"]["idf"], r["R"], r["normals"])
+        wt = wt / wt.sum()
+        for dst, w in ((e_gpu, r["got"]["w"]), (e_ref, r["exp"]["w"])):
+            w = w.astype(np.float64)
+            dst.append(np.abs(w / w.sum() / wt - 1.0))
+    drive_pair(sg, oracle, "example_webmap", "FASTSLAM2", 100, 7, 200, math_mode=1, per_step=collect, want_pre=True)
+    e_gpu, e_ref = np.concatenate(e_gpu), np.concatenate(e_ref)
+    assert e_gpu.size >= 2000
+    assert np.median(e_gpu) <= 2.0 * np.median(e_ref), (np.median(e_gpu), np.median(e_ref))
+    assert np.quantile(e_gpu, 0.99) <= 2.0 * np.quantile(e_ref, 0.99), (np.quantile(e_gpu, 0.99), np.quantile(e_ref, 0.99))
+    assert np.median(e_ref) >= 3e-4  # the yardstick really is this coarse: float32 FastSLAM2 weights carry ~1e-3 noise
 
 
 def test_free_running_statistics(sg, oracle):
