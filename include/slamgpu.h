@@ -112,6 +112,17 @@ int slamgpu_predict(slamgpu_ctx *ctx, float V, float G, const float Q[4], float 
 int slamgpu_update(slamgpu_ctx *ctx, const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n,
                    const float R[4], const float *normals, const float *strata);
 
+/* One whole filter step in one call: the body of the reference's per-observation loop iteration
+ * (FastSLAM2Wrapper.cpp / ParticleSLAMWrapper.cpp: k x predict at the control rate, then update, then
+ * computeEstimatedPosition): n_controls x slamgpu_predict(V, G, Q, dt, phi_true) with controls = [n_controls][3]
+ * host floats (V, G, phi_true), then slamgpu_update(zf, idf, m, zn, n, R, normals, strata), then, if
+ * record_estimate != 0, slamgpu_estimate_async.  Exactly equivalent to making those calls one by one (same launches,
+ * same results); it only saves the per-call overhead of a foreign-function boundary.  Not available with
+ * TAPE-mode predict noise (per-particle noise2 buffers): use slamgpu_predict for that. */
+int slamgpu_step(slamgpu_ctx *ctx, const float *controls, int32_t n_controls, const float Q[4], float dt,
+                 const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n, const float R[4],
+                 const float *normals, const float *strata, int32_t record_estimate);
+
 /* computeEstimatedPosition (ParticleSLAMWrapper.cpp:56-77): mean x, mean y, heading of the first
  * particle with the strictly greatest weight.  Synchronises. */
 int slamgpu_estimate(slamgpu_ctx *ctx, double xyt[3]);

@@ -67,6 +67,8 @@ def load_library():
     L.slamgpu_predict.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
     L.slamgpu_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p]
+    L.slamgpu_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int32,
+                               C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     L.slamgpu_estimate.argtypes = [C.c_void_p, C.c_void_p]
     L.slamgpu_estimate_async.argtypes = [C.c_void_p]
     L.slamgpu_estimate_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
@@ -190,6 +192,30 @@ class SlamGpu:
         nm = None if normals is None else _f32(normals, (self.N, 3))
         st = None if strata is None else _f32(strata)
         _chk(self.L.slamgpu_update(self.h, _ptr(zf), _ptr(idf), zf.shape[0], _ptr(zn), zn.shape[0], _ptr(R), _ptr(nm), _ptr(st)))
+
+    def prepare_step(self, controls, Q, dt, zf, idf, zn, R, normals=None, strata=None, record_estimate=True):
+        """Marshal one filter step (k predicts + update [+ estimate_async]) once; the returned callable makes the single
+        slamgpu_step call.  Lets a driver loop pay the numpy -> pointer conversions outside its timed region, the way a
+        C++ host that already holds plain arrays would."""
+        ctl = _f32(controls).reshape(-1, 3)
+        Q = _f32(Q, 4)
+        zf = _f32(zf).reshape(-1, 2)
+        zn = _f32(zn).reshape(-1, 2)
+        idf = np.ascontiguousarray(idf, np.int32)
+        R = _f32(R, 4)
+        nm = None if normals is None else _f32(normals, (self.N, 3))
+        st = None if strata is None else _f32(strata)
+        keep = (ctl, Q, zf, zn, idf, R, nm, st)  # the pointers below borrow these buffers
+        args = (self.h, _ptr(ctl), ctl.shape[0], _ptr(Q), C.c_float(dt), _ptr(zf), _ptr(idf), zf.shape[0], _ptr(zn), zn.shape[0],
+                _ptr(R), _ptr(nm), _ptr(st), 1 if record_estimate else 0)
+        fn = self.L.slamgpu_step
+
+        def call(_keep=keep):
+            _chk(fn(*args))
+        return call
+
+    def step(self, controls, Q, dt, zf, idf, zn, R, normals=None, strata=None, record_estimate=True):
+        self.prepare_step(controls, Q, dt, zf, idf, zn, R, normals, strata, record_estimate)()
 
     def estimate(self):
         e = np.zeros(3, np.float64)

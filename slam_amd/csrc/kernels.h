@@ -14,16 +14,24 @@ namespace slamgpu {
 //   poseC : float2[Ncap]          p21, p22                                      (40 B per particle)
 //   lmkA  : float4[cap_nf][Ncap]  xf.x, xf.y, Pf p00, p10
 //   lmkB  : float [cap_nf][Ncap]  Pf p11                                         (20 B per landmark)
-// Two copies of everything (ping-pong for the resampling gather); Ctrl.cur says which one is live and is
-// only ever changed on the device, so no host round trip is needed to know whether a resample fired.
+// Two copies of everything (ping-pong for the resampling gather).  Which one is live, and whether the live set
+// still has to be read through the ancestor list of the last resample, is device-resident state (Ctrl.live /
+// Ctrl.pend), so no host round trip is needed to know whether a resample fired.
 constexpr int kWave = 64;
 constexpr int kBlock = 256;
 constexpr int kMaxFusedPredict = 16;
 constexpr int kSmallObs = 12;       // observation packets up to this many zf / zn travel as kernel arguments
 constexpr int kMaxScanBlocks = 8192;  // block totals scanned inside every resample block (LDS)
 
+// Ctrl.live / Ctrl.pend are double-buffered by a host-side slot number (Buffers::slot): a kernel that changes the
+// live buffer writes the NEW state into slot^1 while every block of that launch still reads slot, and the host
+// flips its slot afterwards -- no block ever reads a word another block of the same launch writes.
+//   pend[slot] = 1: the last update resampled but nothing has been moved yet (lazy gather): particle k of the
+//   current set is particle keep[k] of buffer live[slot], with weight 1/N.  The next update kernel gathers while
+//   it computes (or gather_kernel materialises the set when something else needs it).
 struct Ctrl {
-    int32_t cur;          // live buffer (0/1)
+    int32_t live[2];      // live buffer (0/1), per slot
+    int32_t pend[2];      // lazy gather pending, per slot
     int32_t resampled;    // 1 if the last update resampled
     uint32_t done;        // block-arrival counter (last block flips cur / finishes the estimate)
     uint32_t est_done;    // same, for the stand-alone estimate kernel
@@ -44,6 +52,7 @@ struct Buffers {
     int32_t n;        // local particles
     int32_t ncap;     // row stride (>= n, multiple of 256)
     int32_t cap_nf;
+    int32_t slot;     // which Ctrl.live / Ctrl.pend entry this launch reads (host-tracked)
 };
 
 struct ObsPacket {          // big packets live in device memory, uploaded once per update
@@ -104,6 +113,9 @@ struct UpdateArgs {
     float R[4];
     const ObsPacket *big;    // null => use `small`
     SmallObs small;
+    int32_t lazy;            // 1: single-context pipeline (honour Ctrl.pend, launch the copy + finalise blocks)
+    int32_t finalize;        // 1: the extra block reduces the previous update's pose-estimate partials
+    double *finalize_hist;   // history slot of that estimate (4 doubles) or null
 };
 
 struct WeightScratch {
@@ -119,7 +131,6 @@ struct ResampleArgs {
     int32_t nf;             // landmarks after this update
     int32_t do_resample;    // SWITCH_RESAMPLE
     int32_t n_effective;    // NEFFECTIVE
-    double *hist;           // pose-estimate history slot (4 doubles) or null
 };
 
 // ---- sharded resampling (see kernels.hip) ---------------------------------------------------------------
@@ -156,11 +167,16 @@ struct ShardUnpackArgs {
 };
 
 struct KernelTable {
-    // K1: [fused predicts] + per-particle observation update + in-block weight prefix / totals
+    // K1: [lazy gather of the last resample] + [fused predicts] + per-particle observation update + in-block weight
+    //     prefix / totals  (+ the reduction of the previous update's pose-estimate partials)
     void (*update)(hipStream_t, const Buffers &, const PredictArgs &, const UpdateArgs &, const RngArgs &,
                    const WeightScratch &);
-    // K3: Neff + decision, normalise or stratified-resample gather, pose estimate, flip
+    // K2: Neff + decision; normalise, or the ancestors of a stratified resample (nothing is moved); estimate partials
     void (*resample)(hipStream_t, const Buffers &, const WeightScratch &, const RngArgs &, const ResampleArgs &);
+    // materialise a pending lazy gather (needed before anything but the next update touches the particle set)
+    void (*gather)(hipStream_t, const Buffers &, const WeightScratch &, int nf);
+    // reduce the estimate partials of the last update now (-> Ctrl.est, history slot)
+    void (*finish)(hipStream_t, const Buffers &, const WeightScratch &, double *hist);
     void (*predict)(hipStream_t, const Buffers &, const PredictArgs &, const RngArgs &);
     void (*estimate)(hipStream_t, const Buffers &, const WeightScratch &, double *hist);
     void (*jacobians)(hipStream_t, const float *in_dev, uint32_t n, float *out_dev);

@@ -150,7 +150,7 @@ SLAM_DEV void predict_composite(float &x, float &y, float &th, Sym3 &P, const Pr
 __global__ void __launch_bounds__(kBlock) predict_kernel(Buffers B, PredictArgs A, RngArgs rng) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= B.n) return;
-    const int cur = B.ctrl->cur;
+    const int cur = B.ctrl->live[B.slot];
     float4 a = B.poseA[cur][i];
 #ifdef SLAM_FAST_MATH
     if (A.comp.valid) {
@@ -182,6 +182,128 @@ __global__ void __launch_bounds__(kBlock) predict_kernel(Buffers B, PredictArgs 
 }
 
 // ---------------------------------------------------------------------------------------------------
+// block-level helpers
+// ---------------------------------------------------------------------------------------------------
+struct EstItem {
+    double sx, sy;
+    float w, th;
+    int idx;
+};
+
+SLAM_DEV void est_combine(EstItem &a, const EstItem &b) {
+    a.sx += b.sx;
+    a.sy += b.sy;
+    if (b.w > a.w || (b.w == a.w && b.idx < a.idx)) {
+        a.w = b.w;
+        a.th = b.th;
+        a.idx = b.idx;
+    }
+}
+
+// reduce over the 256 threads of a block; result valid in thread 0
+SLAM_DEV EstItem block_reduce_est(EstItem v, EstItem *sh) {
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        EstItem o;
+        o.sx = __shfl_down(v.sx, d, kWave);
+        o.sy = __shfl_down(v.sy, d, kWave);
+        o.w = __shfl_down(v.w, d, kWave);
+        o.th = __shfl_down(v.th, d, kWave);
+        o.idx = __shfl_down(v.idx, d, kWave);
+        est_combine(v, o);
+    }
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 1; k < kBlock / kWave; k++) est_combine(v, sh[k]);
+    }
+    return v;
+}
+
+// One block: parallel reduction of the per-block pose-estimate partials (doubles, tree order fixed by the launch
+// geometry) into Ctrl.est and a history slot.
+SLAM_DEV void finish_estimate(const Buffers &B, const WeightScratch &ws, double *hist, EstItem *sh) {
+    EstItem v{0.0, 0.0, -3.0e38f, 0.0f, 0x7fffffff};
+    for (int b = threadIdx.x; b < ws.nblocks; b += kBlock) {
+        const double *p = ws.est_part + (size_t) b * 4;
+        EstItem o{p[0], p[1], (float) p[3], (float) p[2], b};
+        est_combine(v, o);
+    }
+    __syncthreads();
+    v = block_reduce_est(v, sh);
+    if (threadIdx.x == 0) {
+        Ctrl *c = B.ctrl;
+        c->est[0] = v.sx;
+        c->est[1] = v.sy;
+        c->est[2] = (double) v.th;
+        c->est[3] = (double) v.w;
+        if (hist) {
+            hist[0] = v.sx;
+            hist[1] = v.sy;
+            hist[2] = (double) v.th;
+            hist[3] = (double) v.w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Lazy gather, copy role: after a resample nothing is moved until the next update kernel, whose compute blocks
+// read their particle through keep[] and write it (pose, re-observed and new landmarks) into the other buffer
+// set; these blocks move the landmarks that update does NOT touch, 8 landmarks x 256 particles per block, all
+// loads of a trip in flight before the first store.  They run beside the compute blocks, whose waves spend most
+// of their time waiting on dependent loads, so the copy (HBM-bound) hides the update (latency-bound) and
+// vice versa.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kLmkPerBlockY = 8;
+
+SLAM_DEV bool observed_now(const UpdateArgs &U, int j) {
+    const int m = U.m;
+    const int32_t *idf = U.big ? reinterpret_cast<const int32_t *>(U.big + 1) : U.small.idf;
+    bool hit = false;
+    for (int q = 0; q < m; q++) hit |= (idf[q] == j);
+    return hit;
+}
+
+SLAM_DEV void copy_unobserved(const Buffers &B, const UpdateArgs &U, const WeightScratch &ws, int cur, int role) {
+    const int bx = role % ws.nblocks, by = role / ws.nblocks;
+    const int k = bx * kBlock + threadIdx.x;
+    if (k >= B.n) return;
+    const size_t S = (size_t) B.ncap;
+    const int anc = ws.keep[k];
+    const float4 *__restrict__ sA = cur ? B.lmkA[1] : B.lmkA[0];
+    const float *__restrict__ sB = cur ? B.lmkB[1] : B.lmkB[0];
+    float4 *__restrict__ dA = cur ? B.lmkA[0] : B.lmkA[1];
+    float *__restrict__ dB = cur ? B.lmkB[0] : B.lmkB[1];
+    const int j0 = by * kLmkPerBlockY, j1 = min(U.nf, j0 + kLmkPerBlockY);
+    for (int j = j0; j < j1; j += 4) {
+        const int c1 = min(j + 1, j1 - 1), c2 = min(j + 2, j1 - 1), c3 = min(j + 3, j1 - 1);
+        const float4 a0 = sA[(size_t) j * S + anc], a1 = sA[(size_t) c1 * S + anc];
+        const float4 a2 = sA[(size_t) c2 * S + anc], a3 = sA[(size_t) c3 * S + anc];
+        const float e0 = sB[(size_t) j * S + anc], e1 = sB[(size_t) c1 * S + anc];
+        const float e2 = sB[(size_t) c2 * S + anc], e3 = sB[(size_t) c3 * S + anc];
+        // the compute blocks own the re-observed landmarks (uniform test: scalar compares)
+        if (!observed_now(U, j)) {
+            dA[(size_t) j * S + k] = a0;
+            dB[(size_t) j * S + k] = e0;
+        }
+        if (c1 > j && !observed_now(U, c1)) {
+            dA[(size_t) c1 * S + k] = a1;
+            dB[(size_t) c1 * S + k] = e1;
+        }
+        if (c2 > c1 && !observed_now(U, c2)) {
+            dA[(size_t) c2 * S + k] = a2;
+            dB[(size_t) c2 * S + k] = e2;
+        }
+        if (c3 > c2 && !observed_now(U, c3)) {
+            dA[(size_t) c3 * S + k] = a3;
+            dB[(size_t) c3 * S + k] = e3;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K1: [pending predicts] + per-particle observation update.  FastSLAM2::update body
 // (fastslam2.cpp:26-45): sampleProposal (:290-368) + likelihoodGivenXv (:370-400) fused with
 // featureUpdate (core.cpp:132-175; both evaluate their Jacobians at the same sampled pose) + addFeature
@@ -199,22 +321,44 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     // (each thread only touches its own column: no barrier, no bank conflict: consecutive lanes, consecutive slots)
     __shared__ float4 shA[METHOD == 2 ? kStage : 1][kBlock];
     __shared__ float shB[METHOD == 2 ? kStage : 1][kBlock];
+    const size_t S = (size_t) B.ncap;
+    const int cur = B.ctrl->live[B.slot];
+    // lazy gather: the previous update resampled but moved nothing; this launch reads particle keep[i] of the live
+    // buffer and writes particle i of the other one (observed landmarks updated, the rest copied by the copy blocks)
+    const bool pend = U.lazy && B.ctrl->pend[B.slot] != 0;
+    const int out = pend ? cur ^ 1 : cur;
+    if ((int) blockIdx.x >= ws.nblocks) {
+        // ---- helper blocks of the single-context pipeline ------------------------------------------------
+        if (blockIdx.x == gridDim.x - 1) {
+            // pose estimate of the PREVIOUS update: its partials were left by resample_kernel, the kernel boundary
+            // makes them visible, and this block runs beside the compute blocks instead of as a launch of its own
+            __shared__ EstItem sh_est[kBlock / kWave];
+            if (U.finalize) finish_estimate(B, ws, U.finalize_hist, sh_est);
+            return;
+        }
+        if (pend) copy_unobserved(B, U, ws, cur, blockIdx.x - ws.nblocks);
+        return;
+    }
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-    const size_t S = (size_t) B.ncap;
-    const int cur = B.ctrl->cur;
-    // select (not index) the live buffers: an indexed read of the pointer table in the kernel-argument segment
+    // select (not index) the buffers: an indexed read of the pointer table in the kernel-argument segment
     // would be one more dependent scalar load at the head of every wave
-    float4 *__restrict__ lmkA = cur ? B.lmkA[1] : B.lmkA[0];
-    float *__restrict__ lmkB = cur ? B.lmkB[1] : B.lmkB[0];
-    float4 *__restrict__ poseA = cur ? B.poseA[1] : B.poseA[0];
-    float4 *__restrict__ poseB = cur ? B.poseB[1] : B.poseB[0];
-    float2 *__restrict__ poseC = cur ? B.poseC[1] : B.poseC[0];
+    const float4 *__restrict__ lmkA = cur ? B.lmkA[1] : B.lmkA[0];
+    const float *__restrict__ lmkB = cur ? B.lmkB[1] : B.lmkB[0];
+    const float4 *__restrict__ poseA = cur ? B.poseA[1] : B.poseA[0];
+    const float4 *__restrict__ poseB = cur ? B.poseB[1] : B.poseB[0];
+    const float2 *__restrict__ poseC = cur ? B.poseC[1] : B.poseC[0];
+    float4 *__restrict__ lmkAo = out ? B.lmkA[1] : B.lmkA[0];
+    float *__restrict__ lmkBo = out ? B.lmkB[1] : B.lmkB[0];
+    float4 *__restrict__ poseAo = out ? B.poseA[1] : B.poseA[0];
+    float4 *__restrict__ poseBo = out ? B.poseB[1] : B.poseB[0];
+    float2 *__restrict__ poseCo = out ? B.poseC[1] : B.poseC[0];
     const bool active = i < B.n;
     const int m = U.m, n = U.n, nf = U.nf;
     float w = 0.0f;
 
     if (active) {
+        const int si = pend ? ws.keep[i] : i;  // where this particle's state is read from
         const int32_t *__restrict__ idf;
         const float *__restrict__ zf, *__restrict__ zn;
         if (U.big) {
@@ -228,14 +372,14 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         }
         const float r00 = U.R[0], r01 = U.R[1], r10 = U.R[2], r11 = U.R[3];
 
-        float4 pa = poseA[i];
+        float4 pa = poseA[si];
         float x = pa.x, y = pa.y, th = pa.z;
-        w = pa.w;
+        w = pend ? B.ctrl->inv_n : pa.w;  // resampled particles restart at 1/N (core.cpp:744-747)
         float q00 = 0.f, q10 = 0.f, q11 = 0.f, q20 = 0.f, q21 = 0.f, q22 = 0.f;
-        bool pose_dirty = false;
+        bool pose_dirty = pend;
         if (METHOD == 2) {
-            const float4 pb = poseB[i];
-            const float2 pc = poseC[i];
+            const float4 pb = poseB[si];
+            const float2 pc = poseC[si];
             q00 = pb.x; q10 = pb.y; q11 = pb.z; q20 = pb.w; q21 = pc.x; q22 = pc.y;
         }
         if (PA.nsteps > 0) {
@@ -278,7 +422,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                     float tb[kStage];
 #pragma unroll
                     for (int k = 0; k < kStage; k++) {
-                        const size_t li = (size_t) idf[min(k, m - 1)] * S + i;
+                        const size_t li = (size_t) idf[min(k, m - 1)] * S + si;
                         ta[k] = lmkA[li];
                         tb[k] = lmkB[li];
                     }
@@ -295,8 +439,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                         la = shA[k][threadIdx.x];
                         lb = shB[k][threadIdx.x];
                     } else {
-                        la = lmkA[(size_t) idf[k] * S + i];
-                        lb = lmkB[(size_t) idf[k] * S + i];
+                        la = lmkA[(size_t) idf[k] * S + si];
+                        lb = lmkB[(size_t) idf[k] * S + si];
                     }
                     const Obs2 o = observe2(x, y, th, la.x, la.y, la.z, la.w, lb, r00, rl, r11);
                     proposal_update(x, y, th, P, o, zf[2 * k] - o.zp0, wrap_pi(zf[2 * k + 1] - o.zp1));
@@ -307,16 +451,16 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 const float ths = ffma(Lp.l22, g2, ffma(Lp.l21, g1, ffma(Lp.l20, g0, th)));
                 float lik = 1.0f;
                 auto second_pass = [&](int k, float4 la, float lb) {
-                    const size_t li = (size_t) idf[k] * S + i;
+                    const size_t lo = (size_t) idf[k] * S + i;
                     const Obs2 o = observe2(xs, ys, ths, la.x, la.y, la.z, la.w, lb, r00, rl, r11);
                     lik *= feature_update2(la.x, la.y, la.z, la.w, lb, o, zf[2 * k] - o.zp0, wrap_pi(zf[2 * k + 1] - o.zp1));
-                    lmkA[li] = la;
-                    lmkB[li] = lb;
+                    lmkAo[lo] = la;
+                    lmkBo[lo] = lb;
                 };
                 const int ms = min(m, kStage);
                 for (int k = 0; k < ms; k++) second_pass(k, shA[k][threadIdx.x], shB[k][threadIdx.x]);
                 for (int k = ms; k < m; k++)
-                    second_pass(k, lmkA[(size_t) idf[k] * S + i], lmkB[(size_t) idf[k] * S + i]);
+                    second_pass(k, lmkA[(size_t) idf[k] * S + si], lmkB[(size_t) idf[k] * S + si]);
                 // w *= likelihood * prior / proposal (:360-367): one exponential for the ratio of the two Gaussians
                 const float E = gauss3_exponent(L0, x0 - xs, y0 - ys, wrap_pi(th0 - ths)) -
                                 gauss3_exponent(Lp, x - xs, y - ys, wrap_pi(th - ths));
@@ -339,9 +483,9 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 float4 la;
                 float lb;
                 add_feature_fast(x, y, th, zn[2 * k], zn[2 * k + 1], r00, r01, r10, r11, la.x, la.y, la.z, la.w, lb);
-                const size_t li = (size_t) (nf + k) * S + i;
-                lmkA[li] = la;
-                lmkB[li] = lb;
+                const size_t lo = (size_t) (nf + k) * S + i;
+                lmkAo[lo] = la;
+                lmkBo[lo] = lb;
             }
         } else
 #endif
@@ -371,7 +515,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                     // compiler issues all of them before the first s_waitcnt; duplicates are L1 hits
 #pragma unroll
                     for (int k = 0; k < kStage; k++) {
-                        const size_t li = (size_t) idf[min(k, m - 1)] * S + i;
+                        const size_t li = (size_t) idf[min(k, m - 1)] * S + si;
                         ta[k] = lmkA[li];
                         tb[k] = lmkB[li];
                     }
@@ -388,8 +532,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                         la = shA[k][threadIdx.x];
                         lb = shB[k][threadIdx.x];
                     } else {
-                        la = lmkA[(size_t) idf[k] * S + i];
-                        lb = lmkB[(size_t) idf[k] * S + i];
+                        la = lmkA[(size_t) idf[k] * S + si];
+                        lb = lmkB[(size_t) idf[k] * S + si];
                     }
                     // Jacobians at the running mean (fastslam2.cpp:320,:348)
                     Jac j = jacobian(x, y, th, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
@@ -435,21 +579,21 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 const float b0 = x - xs, b1 = y - ys, b2 = trig_offset(th - ths);
                 float lik = 1.0f;
                 auto second_pass = [&](int k, float4 la, float lb) {
-                    const size_t li = (size_t) idf[k] * S + i;
+                    const size_t lo = (size_t) idf[k] * S + i;
                     Jac j = jacobian(xs, ys, ths, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
                     const float v0 = zf[2 * k] - j.zp0;
                     const float v1 = trig_offset(zf[2 * k + 1] - j.zp1);
                     lik = lik * gauss2(v0, v1, j.s00, j.s10, j.s11);
                     cholesky_update2(la.x, la.y, la.z, la.w, lb, v0, v1, r00, r01, r10, r11, j.hf00, j.hf01, j.hf10, j.hf11);
-                    lmkA[li] = la;
-                    lmkB[li] = lb;
+                    lmkAo[lo] = la;
+                    lmkBo[lo] = lb;
                 };
                 // two loops on purpose: the LDS-fed one issues only stores to HBM, so nothing in it has to wait for a
                 // store to land (a global load after a global store costs an s_waitcnt vmcnt(0) per iteration)
                 const int ms = min(m, kStage);
                 for (int k = 0; k < ms; k++) second_pass(k, shA[k][threadIdx.x], shB[k][threadIdx.x]);
                 for (int k = ms; k < m; k++)
-                    second_pass(k, lmkA[(size_t) idf[k] * S + i], lmkB[(size_t) idf[k] * S + i]);
+                    second_pass(k, lmkA[(size_t) idf[k] * S + si], lmkB[(size_t) idf[k] * S + si]);
                 const float prior = gauss3(a0, a1, a2, q00, q10, q11, q20, q21, q22);
                 const float prop = gauss3(b0, b1, b2, P[0], P[3], P[4], P[6], P[7], P[8]);
                 w = w * lik * prior / prop;
@@ -469,9 +613,9 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             if (m > 0) {
                 float wp = 1.0f;
                 for (int k = 0; k < m; k++) {
-                    const size_t li = (size_t) idf[k] * S + i;
-                    float4 la = lmkA[li];
-                    float lb = lmkB[li];
+                    const size_t lo = (size_t) idf[k] * S + i;
+                    float4 la = lmkA[(size_t) idf[k] * S + si];
+                    float lb = lmkB[(size_t) idf[k] * S + si];
                     Jac j = jacobian(x, y, th, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
                     const float v0 = zf[2 * k] - j.zp0;
                     const float v1 = trig_offset(zf[2 * k + 1] - j.zp1);
@@ -483,8 +627,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                     const float num = expf(t0 * v0 + t1 * v1);
                     wp = wp * num / den;
                     cholesky_update2(la.x, la.y, la.z, la.w, lb, v0, v1, r00, r01, r10, r11, j.hf00, j.hf01, j.hf10, j.hf11);
-                    lmkA[li] = la;
-                    lmkB[li] = lb;
+                    lmkAo[lo] = la;
+                    lmkBo[lo] = lb;
                 }
                 w = w * wp;
             }
@@ -497,14 +641,14 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             float4 la;
             float lb;
             add_feature(x, y, th, zn[2 * k], zn[2 * k + 1], r00, r01, r10, r11, la.x, la.y, la.z, la.w, lb);
-            const size_t li = (size_t) (nf + k) * S + i;
-            lmkA[li] = la;
-            lmkB[li] = lb;
+            const size_t lo = (size_t) (nf + k) * S + i;
+            lmkAo[lo] = la;
+            lmkBo[lo] = lb;
         }
-        poseA[i] = make_float4(x, y, th, w);
+        poseAo[i] = make_float4(x, y, th, w);
         if (METHOD == 2 && pose_dirty) {
-            poseB[i] = make_float4(q00, q10, q11, q20);
-            poseC[i] = make_float2(q21, q22);
+            poseBo[i] = make_float4(q00, q10, q11, q20);
+            poseCo[i] = make_float2(q21, q22);
         }
     }
 
@@ -531,73 +675,6 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     if (threadIdx.x == kBlock - 1) {
         ws.blk_w[blockIdx.x] = base + s;
         ws.blk_w2[blockIdx.x] = ((sh_w2[0] + sh_w2[1]) + sh_w2[2]) + sh_w2[3];
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// block-level helpers
-// ---------------------------------------------------------------------------------------------------
-struct EstItem {
-    double sx, sy;
-    float w, th;
-    int idx;
-};
-
-SLAM_DEV void est_combine(EstItem &a, const EstItem &b) {
-    a.sx += b.sx;
-    a.sy += b.sy;
-    if (b.w > a.w || (b.w == a.w && b.idx < a.idx)) {
-        a.w = b.w;
-        a.th = b.th;
-        a.idx = b.idx;
-    }
-}
-
-// reduce over the 256 threads of a block; result valid in thread 0
-SLAM_DEV EstItem block_reduce_est(EstItem v, EstItem *sh) {
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) {
-        EstItem o;
-        o.sx = __shfl_down(v.sx, d, kWave);
-        o.sy = __shfl_down(v.sy, d, kWave);
-        o.w = __shfl_down(v.w, d, kWave);
-        o.th = __shfl_down(v.th, d, kWave);
-        o.idx = __shfl_down(v.idx, d, kWave);
-        est_combine(v, o);
-    }
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-    if (lane == 0) sh[wv] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int k = 1; k < kBlock / kWave; k++) est_combine(v, sh[k]);
-    }
-    return v;
-}
-
-// Final stage run by the last block to arrive: parallel reduction of the per-block partials
-// (sum x, sum y in block order is not needed: doubles, tree order fixed by the launch geometry).
-SLAM_DEV void finish_estimate(const Buffers &B, const WeightScratch &ws, double *hist, EstItem *sh) {
-    EstItem v{0.0, 0.0, -3.0e38f, 0.0f, 0x7fffffff};
-    for (int b = threadIdx.x; b < ws.nblocks; b += kBlock) {
-        const double *p = ws.est_part + (size_t) b * 4;
-        EstItem o{p[0], p[1], (float) p[3], (float) p[2], b};
-        est_combine(v, o);
-    }
-    __syncthreads();
-    v = block_reduce_est(v, sh);
-    if (threadIdx.x == 0) {
-        Ctrl *c = B.ctrl;
-        c->est[0] = v.sx;
-        c->est[1] = v.sy;
-        c->est[2] = (double) v.th;
-        c->est[3] = (double) v.w;
-        if (hist) {
-            hist[0] = v.sx;
-            hist[1] = v.sy;
-            hist[2] = (double) v.th;
-            hist[3] = (double) v.w;
-        }
     }
 }
 
@@ -682,8 +759,6 @@ SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const f
 //                particle from the live buffers into the other set, w = 1/N (:744-747); blockIdx.y splits
 //                the landmarks.  The last block to finish reduces the estimate partials and flips Ctrl.cur.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kLmkPerBlockY = 8;
-
 __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScratch ws, RngArgs rng, ResampleArgs ra) {
     extern __shared__ double off[];  // [nblocks + 1] exclusive prefix of the block totals
     __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
@@ -691,20 +766,24 @@ __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScrat
     Ctrl *ctrl = B.ctrl;
     const int t = threadIdx.x;
     const int nb = ws.nblocks;
-    const int cur = ctrl->cur;
+    // the buffer the update kernel of this step wrote: the other one if it performed a lazy gather
+    const int cur = ctrl->live[B.slot] ^ (ctrl->pend[B.slot] ? 1 : 0);
 
     double W, Q;
     scan_block_totals(ws.blk_w, nb, nb, off, sh_a, sh_q, W, Q);  // one shard: [w(nb) | w2(nb)] contiguous
     // Neff = 1 / sum((w/W)^2)  (core.cpp:784-788)
     const float neff = (float) ((W * W) / Q);
     const bool resample = ra.do_resample && (neff < (float) ra.n_effective);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) {
+    if (blockIdx.x == 0 && t == 0) {
         ctrl->wsum = W;
         ctrl->wsq = Q;
         ctrl->neff = neff;
         ctrl->resampled = resample ? 1 : 0;
+        // state for the next launch goes to the OTHER slot (see Ctrl): the set now lives in `cur`, and after a
+        // resample it is defined through keep[] until somebody gathers it
+        ctrl->live[B.slot ^ 1] = cur;
+        ctrl->pend[B.slot ^ 1] = resample ? 1 : 0;
     }
-    if (!resample && blockIdx.y != 0) return;
     __syncthreads();
 
     const int k = blockIdx.x * kBlock + t;
@@ -720,60 +799,75 @@ __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScrat
     } else if (active) {
         const double target = (double) stratum(rng, (int64_t) k) * W;
         const int anc = (int) min(find_ancestor(target, off, nb, ws.lcum, 0, nb, (int64_t) B.n), (int64_t) B.n - 1);
-        const size_t S = (size_t) B.ncap;
-        if (blockIdx.y == 0) {
-            float4 pa = B.poseA[cur][anc];
-            pa.w = ctrl->inv_n;
-            B.poseA[cur ^ 1][k] = pa;
-            B.poseB[cur ^ 1][k] = B.poseB[cur][anc];
-            B.poseC[cur ^ 1][k] = B.poseC[cur][anc];
-            ws.keep[k] = anc;
-            ei = EstItem{(double) pa.x, (double) pa.y, pa.w, pa.z, k};
-        }
-        const float4 *__restrict__ sA = B.lmkA[cur];
-        const float *__restrict__ sB = B.lmkB[cur];
-        float4 *__restrict__ dA = B.lmkA[cur ^ 1];
-        float *__restrict__ dB = B.lmkB[cur ^ 1];
-        const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(ra.nf, j0 + kLmkPerBlockY);
-        for (int j = j0; j < j1; j += 4) {
-            // four landmarks per trip: issue all the gathers before the first store
-            const int c1 = min(j + 1, j1 - 1), c2 = min(j + 2, j1 - 1), c3 = min(j + 3, j1 - 1);
-            const float4 a0 = sA[(size_t) j * S + anc], a1 = sA[(size_t) c1 * S + anc];
-            const float4 a2 = sA[(size_t) c2 * S + anc], a3 = sA[(size_t) c3 * S + anc];
-            const float e0 = sB[(size_t) j * S + anc], e1 = sB[(size_t) c1 * S + anc];
-            const float e2 = sB[(size_t) c2 * S + anc], e3 = sB[(size_t) c3 * S + anc];
-            dA[(size_t) j * S + k] = a0;
-            dB[(size_t) j * S + k] = e0;
-            dA[(size_t) c1 * S + k] = a1;
-            dB[(size_t) c1 * S + k] = e1;
-            dA[(size_t) c2 * S + k] = a2;
-            dB[(size_t) c2 * S + k] = e2;
-            dA[(size_t) c3 * S + k] = a3;
-            dB[(size_t) c3 * S + k] = e3;
-        }
+        ws.keep[k] = anc;
+        const float4 pa = B.poseA[cur][anc];
+        ei = EstItem{(double) pa.x, (double) pa.y, ctrl->inv_n, pa.z, k};
     }
 
-    // ---- estimate partial of this block (row y == 0 only); reduced + committed by finish_kernel ----------
+    // ---- estimate partial of this block; reduced by the next update launch's helper block or by finish_kernel
     // (no in-kernel hand-off: an agent-scope release per block = an L2 write-back per block on gfx950,
-    //  which costs far more than the one kernel boundary it would save)
-    if (blockIdx.y == 0) {
-        ei = block_reduce_est(ei, sh_est);
-        if (t == 0) {
-            double *p = ws.est_part + (size_t) blockIdx.x * 4;
-            p[0] = ei.sx;
-            p[1] = ei.sy;
-            p[2] = (double) ei.th;
-            p[3] = (double) ei.w;
-        }
+    //  which costs far more than the kernel boundary it would save)
+    ei = block_reduce_est(ei, sh_est);
+    if (t == 0) {
+        double *p = ws.est_part + (size_t) blockIdx.x * 4;
+        p[0] = ei.sx;
+        p[1] = ei.sy;
+        p[2] = (double) ei.th;
+        p[3] = (double) ei.w;
     }
 }
 
-// One block: reduces the estimate partials (-> Ctrl.est, history slot) and, after a resample, commits the
-// buffer flip.  Runs behind resample_kernel / estimate_kernel on the same stream.
-__global__ void __launch_bounds__(kBlock) finish_kernel(Buffers B, WeightScratch ws, double *hist, int commit_flip) {
+// Materialise a pending lazy gather: the whole particle (pose + every landmark) of keep[k] into slot k of the
+// other buffer set, w = 1/N (core.cpp:744-747).  Needed before anything but the next update reads the set
+// (download, stand-alone predict / estimate, sharded operation).  Every launch publishes the resulting state in
+// the other Ctrl slot; the host flips its slot afterwards.
+__global__ void __launch_bounds__(kBlock) gather_kernel(Buffers B, WeightScratch ws, int nf) {
+    Ctrl *ctrl = B.ctrl;
+    const int cur = ctrl->live[B.slot];
+    const bool pend = ctrl->pend[B.slot] != 0;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        ctrl->live[B.slot ^ 1] = pend ? cur ^ 1 : cur;
+        ctrl->pend[B.slot ^ 1] = 0;
+    }
+    if (!pend) return;
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= B.n) return;
+    const int anc = ws.keep[k];
+    const size_t S = (size_t) B.ncap;
+    if (blockIdx.y == 0) {
+        float4 pa = B.poseA[cur][anc];
+        pa.w = ctrl->inv_n;
+        B.poseA[cur ^ 1][k] = pa;
+        B.poseB[cur ^ 1][k] = B.poseB[cur][anc];
+        B.poseC[cur ^ 1][k] = B.poseC[cur][anc];
+    }
+    const float4 *__restrict__ sA = B.lmkA[cur];
+    const float *__restrict__ sB = B.lmkB[cur];
+    float4 *__restrict__ dA = B.lmkA[cur ^ 1];
+    float *__restrict__ dB = B.lmkB[cur ^ 1];
+    const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(nf, j0 + kLmkPerBlockY);
+    for (int j = j0; j < j1; j += 4) {
+        // four landmarks per trip: issue all the gathers before the first store
+        const int c1 = min(j + 1, j1 - 1), c2 = min(j + 2, j1 - 1), c3 = min(j + 3, j1 - 1);
+        const float4 a0 = sA[(size_t) j * S + anc], a1 = sA[(size_t) c1 * S + anc];
+        const float4 a2 = sA[(size_t) c2 * S + anc], a3 = sA[(size_t) c3 * S + anc];
+        const float e0 = sB[(size_t) j * S + anc], e1 = sB[(size_t) c1 * S + anc];
+        const float e2 = sB[(size_t) c2 * S + anc], e3 = sB[(size_t) c3 * S + anc];
+        dA[(size_t) j * S + k] = a0;
+        dB[(size_t) j * S + k] = e0;
+        dA[(size_t) c1 * S + k] = a1;
+        dB[(size_t) c1 * S + k] = e1;
+        dA[(size_t) c2 * S + k] = a2;
+        dB[(size_t) c2 * S + k] = e2;
+        dA[(size_t) c3 * S + k] = a3;
+        dB[(size_t) c3 * S + k] = e3;
+    }
+}
+
+// One block: reduces the estimate partials (-> Ctrl.est, history slot) on demand.
+__global__ void __launch_bounds__(kBlock) finish_kernel(Buffers B, WeightScratch ws, double *hist) {
     __shared__ EstItem sh_est[kBlock / kWave];
     finish_estimate(B, ws, hist, sh_est);
-    if (threadIdx.x == 0 && commit_flip && B.ctrl->resampled) B.ctrl->cur ^= 1;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -785,7 +879,7 @@ __global__ void __launch_bounds__(kBlock) estimate_kernel(Buffers B, WeightScrat
     const int i = blockIdx.x * kBlock + t;
     EstItem ei{0.0, 0.0, -3.0e38f, 0.0f, 0x7fffffff};
     if (i < B.n) {
-        const float4 pa = B.poseA[B.ctrl->cur][i];
+        const float4 pa = B.poseA[B.ctrl->live[B.slot]][i];
         ei = EstItem{(double) pa.x, (double) pa.y, pa.w, pa.z, i};
     }
     ei = block_reduce_est(ei, sh_est);
@@ -869,7 +963,7 @@ __global__ void __launch_bounds__(kBlock) shard_pack_kernel(Buffers B, WeightScr
     const int64_t j = (int64_t) blockIdx.x * kBlock + threadIdx.x;  // offspring slot of this shard
     const int64_t k = A.k_lo + j;
     if (k >= A.k_hi) return;
-    const int cur = B.ctrl->cur;
+    const int cur = B.ctrl->live[B.slot];
     const size_t S = (size_t) B.ncap;
     const double target = (double) stratum(rng, k) * W;
     const int64_t ganc = find_ancestor(target, off, A.nb_global, ws.lcum, A.first_block, ws.nblocks, rng.n_global);
@@ -923,7 +1017,7 @@ __global__ void __launch_bounds__(kBlock) shard_pack_kernel(Buffers B, WeightScr
 __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightScratch ws, ShardUnpackArgs A) {
     const int i = blockIdx.x * kBlock + threadIdx.x;  // local output particle
     if (i >= B.n) return;
-    const int cur = B.ctrl->cur;
+    const int cur = B.ctrl->live[B.slot];
     const size_t S = (size_t) B.ncap;
     // source block: the s with src_lo[s] <= i < src_lo[s+1] (local output index boundaries, increasing)
     int s = 0;
@@ -951,7 +1045,7 @@ __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightS
 __global__ void __launch_bounds__(kBlock) shard_normalize_kernel(Buffers B, double W) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= B.n) return;
-    float4 *pa = B.poseA[B.ctrl->cur] + i;
+    float4 *pa = B.poseA[B.ctrl->live[B.slot]] + i;
     pa->w = pa->w / (float) W;
 }
 
@@ -962,7 +1056,9 @@ __global__ void shard_commit_kernel(Buffers B, double W, double Q, float neff, i
     c->wsq = Q;
     c->neff = neff;
     c->resampled = resampled;
-    if (resampled) c->cur ^= 1;
+    // published in the other slot; the host flips its slot after this launch (see Ctrl)
+    c->live[B.slot ^ 1] = c->live[B.slot] ^ (resampled ? 1 : 0);
+    c->pend[B.slot ^ 1] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -994,7 +1090,10 @@ static void launch_shard_finish(hipStream_t st, const Buffers &B, double W, doub
 
 static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &PA, const UpdateArgs &U,
                           const RngArgs &rng, const WeightScratch &ws) {
-    const int grid = B.ncap / kBlock;
+    // compute blocks first (they are the long pole), then -- single-context pipeline only -- the copy blocks of a
+    // pending lazy gather (they exit at once when nothing is pending: the host cannot know) and one helper block
+    int grid = B.ncap / kBlock;
+    if (U.lazy) grid += ws.nblocks * ((U.nf + kLmkPerBlockY - 1) / kLmkPerBlockY) + 1;
     if (U.method == 2)
         hipLaunchKernelGGL(update_kernel<2>, dim3(grid), dim3(kBlock), 0, st, B, PA, U, rng, ws);
     else
@@ -1003,10 +1102,17 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
 
 static void launch_resample(hipStream_t st, const Buffers &B, const WeightScratch &ws, const RngArgs &rng,
                             const ResampleArgs &ra) {
-    const int gy = ra.nf > 0 ? (ra.nf + kLmkPerBlockY - 1) / kLmkPerBlockY : 1;
     const size_t lds = sizeof(double) * ((size_t) ws.nblocks + 1);
-    hipLaunchKernelGGL(resample_kernel, dim3(ws.nblocks, gy), dim3(kBlock), lds, st, B, ws, rng, ra);
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, B, ws, ra.hist, 1);
+    hipLaunchKernelGGL(resample_kernel, dim3(ws.nblocks), dim3(kBlock), lds, st, B, ws, rng, ra);
+}
+
+static void launch_gather(hipStream_t st, const Buffers &B, const WeightScratch &ws, int nf) {
+    const int gy = nf > 0 ? (nf + kLmkPerBlockY - 1) / kLmkPerBlockY : 1;
+    hipLaunchKernelGGL(gather_kernel, dim3(ws.nblocks, gy), dim3(kBlock), 0, st, B, ws, nf);
+}
+
+static void launch_finish(hipStream_t st, const Buffers &B, const WeightScratch &ws, double *hist) {
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, B, ws, hist);
 }
 
 static void launch_predict(hipStream_t st, const Buffers &B, const PredictArgs &A, const RngArgs &rng) {
@@ -1015,14 +1121,14 @@ static void launch_predict(hipStream_t st, const Buffers &B, const PredictArgs &
 
 static void launch_estimate(hipStream_t st, const Buffers &B, const WeightScratch &ws, double *hist) {
     hipLaunchKernelGGL(estimate_kernel, dim3(ws.nblocks), dim3(kBlock), 0, st, B, ws);
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, B, ws, hist, 0);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, B, ws, hist);
 }
 
 static void launch_jacobians(hipStream_t st, const float *in, uint32_t n, float *out) {
     hipLaunchKernelGGL(jacobians_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, in, n, out);
 }
 
-static const KernelTable kTable = {launch_update, launch_resample, launch_predict, launch_estimate, launch_jacobians,
+static const KernelTable kTable = {launch_update, launch_resample, launch_gather, launch_finish, launch_predict, launch_estimate, launch_jacobians,
                                    launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish};
 
 }  // namespace SLAM_KNS

@@ -87,6 +87,12 @@ struct slamgpu_ctx {
     double predict_bytes = 0;
     bool own_stream = true;
     ShardPlan *plan_dev = nullptr, *plan_host = nullptr;  // sharded resampling plan (device + pinned mirror)
+    // Ctrl.live / Ctrl.pend slot the next launch reads (kernels.h: Ctrl); flipped after every launch that may
+    // change the live buffer (resample_kernel, gather_kernel, shard_commit_kernel)
+    int slot = 0;
+    bool maybe_pending = false;   // the last update may have left a lazy gather (only the device knows)
+    bool est_deferred = false;    // est_part holds the partials of the last update, not reduced yet
+    double *deferred_hist = nullptr;  // history slot that reduction has to fill (or null)
 };
 
 namespace {
@@ -191,9 +197,40 @@ void compose_predicts(PredictArgs &P) {
     C.m22 = (float) M[2][2];
 }
 
+// Make the particle set plain again (particle k in slot k of the live buffers) if the last update may have left a
+// lazy gather: everything except the next update launch needs that.
+int materialize(slamgpu_ctx *c) {
+    if (!c->maybe_pending) return 0;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    c->B.slot = c->slot;
+    {
+        Timed t(c, "gather");
+        c->k->gather(c->stream, c->B, c->ws, c->nf);
+    }
+    HIP_TRY(hipGetLastError());
+    c->slot ^= 1;
+    c->B.slot = c->slot;
+    c->maybe_pending = false;
+    return 0;
+}
+
+// Reduce the pose-estimate partials of the last update now (normally the next update launch does it on the side).
+int finish_deferred(slamgpu_ctx *c) {
+    if (!c->est_deferred) return 0;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    {
+        Timed t(c, "finish");
+        c->k->finish(c->stream, c->B, c->ws, c->deferred_hist);
+    }
+    HIP_TRY(hipGetLastError());
+    c->est_deferred = false;
+    return 0;
+}
+
 int flush_predict(slamgpu_ctx *c) {
     if (c->pending.nsteps == 0) return 0;
     HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = materialize(c)) return rc;
     compose_predicts(c->pending);
     {
         Timed t(c, "predict");
@@ -212,9 +249,13 @@ int check_ctx(slamgpu_ctx *c) {
     return 0;
 }
 
-int read_ctrl(slamgpu_ctx *c) {
+// need_set: the caller is going to touch the particle buffers (not only the Ctrl words)
+int read_ctrl(slamgpu_ctx *c, bool need_set = false) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = flush_predict(c)) return rc;
+    if (need_set)
+        if (int rc = materialize(c)) return rc;
+    if (int rc = finish_deferred(c)) return rc;
     HIP_TRY(hipMemcpyAsync(c->ctrl_host, c->B.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
@@ -420,6 +461,11 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     const bool need_normals = c->cfg.method == SLAMGPU_FASTSLAM2 && (m > 0 || n > 0);
     if (tape && ((need_normals && !normals) || !strata)) return fail(SLAMGPU_ERR_INVALID, "TAPE mode needs normals[3N] and strata[N]");
     HIP_TRY(hipSetDevice(c->cfg.device));
+    if (sharded) {
+        // the sharded pipeline moves particles itself (pack / exchange / unpack): it starts from a plain set
+        if (int rc = materialize(c)) return rc;
+        if (int rc = finish_deferred(c)) return rc;
+    }
     c->obs_step++;
 
     UpdateArgs U{};
@@ -492,10 +538,15 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     }
 
     const RngArgs rng = rng_args(c, c->obs_step);
+    c->B.slot = c->slot;
+    U.lazy = sharded ? 0 : 1;
+    U.finalize = (!sharded && c->est_deferred) ? 1 : 0;
+    U.finalize_hist = c->deferred_hist;
     {
         Timed t(c, c->cfg.method == SLAMGPU_FASTSLAM2 ? "fs2_update" : "fs1_update");
         c->k->update(c->stream, c->B, PA, U, rng, c->ws);
     }
+    if (!sharded) c->est_deferred = false;  // reduced by the helper block of that launch
     c->nf += n;
     if (sharded) {
         // the resampling stage is driven by the caller through slamgpu_shard_* (needs collectives)
@@ -507,13 +558,20 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     ra.nf = c->nf;
     ra.do_resample = c->cfg.resample;
     ra.n_effective = c->cfg.n_effective;
-    ra.hist = c->hist_n < kHistCap ? c->hist_dev + 4 * (size_t) c->hist_n : nullptr;
     {
         Timed t(c, "resample");
         c->k->resample(c->stream, c->B, c->ws, rng, ra);
     }
-    c->est_fresh = ra.hist != nullptr;
     HIP_TRY(hipGetLastError());
+    // resample_kernel published the new live / pending state in the other slot
+    c->slot ^= 1;
+    c->B.slot = c->slot;
+    c->maybe_pending = true;
+    // this step's pose estimate exists as per-block partials; the next update launch (or finish_deferred) reduces
+    // them into Ctrl.est and this history slot
+    c->deferred_hist = c->hist_n < kHistCap ? c->hist_dev + 4 * (size_t) c->hist_n : nullptr;
+    c->est_deferred = true;
+    c->est_fresh = c->deferred_hist != nullptr;
     return 0;
 }
 
@@ -528,6 +586,20 @@ int slamgpu_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t 
         return fail(SLAMGPU_ERR_INVALID, "this context is a shard (%d of %lld particles): use slamgpu_shard_update + slamgpu_shard_*",
                     c->cfg.n_particles, (long long) c->cfg.n_particles_global);
     return do_update(c, zf, idf, m, zn, n, R, normals, strata, false);
+}
+
+int slamgpu_step(slamgpu_ctx *c, const float *controls, int32_t n_controls, const float Q[4], float dt, const float *zf,
+                 const int32_t *idf, int32_t m, const float *zn, int32_t n, const float R[4], const float *normals,
+                 const float *strata, int32_t record_estimate) {
+    if (int rc = check_ctx(c)) return rc;
+    if (n_controls < 0 || (n_controls > 0 && !controls)) return fail(SLAMGPU_ERR_INVALID, "bad control list");
+    if (n_controls > 0 && c->cfg.add_predict_noise && c->cfg.rng_mode == SLAMGPU_RNG_TAPE)
+        return fail(SLAMGPU_ERR_INVALID, "slamgpu_step cannot carry TAPE-mode predict noise: call slamgpu_predict per control");
+    for (int k = 0; k < n_controls; k++)
+        if (int rc = slamgpu_predict(c, controls[3 * k], controls[3 * k + 1], Q, dt, controls[3 * k + 2], nullptr)) return rc;
+    if (int rc = slamgpu_update(c, zf, idf, m, zn, n, R, normals, strata)) return rc;
+    if (record_estimate) return slamgpu_estimate_async(c);
+    return 0;
 }
 
 // ---- sharded operation -------------------------------------------------------------------------------
@@ -650,6 +722,8 @@ int slamgpu_shard_finish(slamgpu_ctx *c, const slamgpu_shard_plan_t *plan) {
         Timed t(c, "shard_finish");
         c->k->shard_finish(c->stream, c->B, plan->wsum, plan->wsq, plan->neff, plan->resampled);
     }
+    c->slot ^= 1;  // shard_commit_kernel published the (possibly flipped) live buffer in the other slot
+    c->B.slot = c->slot;
     c->est_fresh = false;
     HIP_TRY(hipGetLastError());
     return 0;
@@ -695,6 +769,8 @@ int slamgpu_shard_estimate_async(slamgpu_ctx *c) {
     if (c->hist_n >= kHistCap) return fail(SLAMGPU_ERR_CAPACITY, "estimate history full (%d)", kHistCap);
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = flush_predict(c)) return rc;
+    if (int rc = materialize(c)) return rc;
+    if (int rc = finish_deferred(c)) return rc;
     {
         Timed t(c, "estimate");
         c->k->estimate(c->stream, c->B, c->ws, c->hist_dev + 4 * (size_t) c->hist_n);
@@ -708,6 +784,7 @@ int slamgpu_shard_estimate_fetch(slamgpu_ctx *c, double *raw4, int32_t max_count
     if (int rc = check_ctx(c)) return rc;
     if (!count) return fail(SLAMGPU_ERR_INVALID, "null count");
     HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = finish_deferred(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     const int n = c->hist_n < max_count ? c->hist_n : max_count;
     if (n > 0 && raw4) HIP_TRY(hipMemcpy(raw4, c->hist_dev, sizeof(double) * 4 * (size_t) n, hipMemcpyDeviceToHost));
@@ -722,6 +799,8 @@ int slamgpu_shard_estimate(slamgpu_ctx *c, double out[4]) {
     if (!out) return fail(SLAMGPU_ERR_INVALID, "null output");
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = flush_predict(c)) return rc;
+    if (int rc = materialize(c)) return rc;
+    if (int rc = finish_deferred(c)) return rc;
     {
         Timed t(c, "estimate");
         c->k->estimate(c->stream, c->B, c->ws, nullptr);
@@ -738,6 +817,8 @@ int slamgpu_estimate(slamgpu_ctx *c, double xyt[3]) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = flush_predict(c)) return rc;
     if (!c->est_fresh) {
+        if (int rc = materialize(c)) return rc;
+        if (int rc = finish_deferred(c)) return rc;
         Timed t(c, "estimate");
         c->k->estimate(c->stream, c->B, c->ws, nullptr);
     }
@@ -756,11 +837,13 @@ int slamgpu_estimate_async(slamgpu_ctx *c) {
     if (int rc = flush_predict(c)) return rc;
     if (!c->est_fresh) {
         // the particle set changed since the last update (predicts / upload): reduce it now
+        if (int rc = materialize(c)) return rc;
+        if (int rc = finish_deferred(c)) return rc;
         Timed t(c, "estimate");
         c->k->estimate(c->stream, c->B, c->ws, c->hist_dev + 4 * (size_t) c->hist_n);
         HIP_TRY(hipGetLastError());
     }
-    // else: the update's resample kernel already left this step's estimate in slot hist_n
+    // else: slot hist_n is filled when the partials of the last update are reduced (next update launch / finish)
     c->hist_n++;
     c->est_fresh = false;
     return 0;
@@ -770,6 +853,7 @@ int slamgpu_estimate_fetch(slamgpu_ctx *c, double *xyt, int32_t max_count, int32
     if (int rc = check_ctx(c)) return rc;
     if (!count) return fail(SLAMGPU_ERR_INVALID, "null count");
     HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = finish_deferred(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     const int n = c->hist_n < max_count ? c->hist_n : max_count;
     std::vector<double> h((size_t) 4 * (n > 0 ? n : 1));
@@ -812,14 +896,15 @@ int slamgpu_sync(slamgpu_ctx *c) {
     if (int rc = check_ctx(c)) return rc;
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = flush_predict(c)) return rc;
+    if (int rc = finish_deferred(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 
 int slamgpu_download(slamgpu_ctx *c, float *xv, float *Pv9, float *w, float *xf, float *Pf4) {
     if (int rc = check_ctx(c)) return rc;
-    if (int rc = read_ctrl(c)) return rc;
-    const int cur = c->ctrl_host->cur, N = c->B.n, nf = c->nf;
+    if (int rc = read_ctrl(c, true)) return rc;
+    const int cur = c->ctrl_host->live[c->slot], N = c->B.n, nf = c->nf;
     const size_t S = (size_t) c->B.ncap;
     std::vector<float4> pa(S), pb(S);
     std::vector<float2> pc(S);
@@ -871,8 +956,8 @@ int slamgpu_upload(slamgpu_ctx *c, int32_t nf, const float *xv, const float *Pv9
     if (int rc = check_ctx(c)) return rc;
     if (nf < 0 || nf > c->B.cap_nf) return fail(SLAMGPU_ERR_CAPACITY, "nf=%d exceeds capacity %d", nf, c->B.cap_nf);
     if (nf > 0 && (!xf || !Pf4)) return fail(SLAMGPU_ERR_INVALID, "nf>0 needs xf and Pf");
-    if (int rc = read_ctrl(c)) return rc;
-    const int cur = c->ctrl_host->cur, N = c->B.n;
+    if (int rc = read_ctrl(c, true)) return rc;
+    const int cur = c->ctrl_host->live[c->slot], N = c->B.n;
     const size_t S = (size_t) c->B.ncap;
     std::vector<float4> pa(S), pb(S);
     std::vector<float2> pc(S);

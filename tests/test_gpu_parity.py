@@ -392,3 +392,33 @@ def test_full_size_philox_vs_oracle(sg, oracle):
             s.upload(exp)
     s.close()
     o.close()
+
+
+def test_step_call_equals_separate_calls(sg):
+    """slamgpu_step (k predicts + update + estimate_async in one C-ABI call) is the same launches as the separate
+    calls: states and estimate histories must be bit-identical, across resampling steps (lazy gather included)."""
+    import os
+    from slam_amd import host
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    N = 4096
+    tape = host.make_tape(["-m", os.path.join(root, "data", "example_webmap.mat"), "-method", "FASTSLAM2", "-NPARTICLES", N,
+                           "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", 3], max_obs=60)
+    runs = []
+    for mode in ("separate", "step"):
+        s = sg.SlamGpu(N, tape["nlm"], method=2, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=11, math_mode=1)
+        for st in tape["steps"]:
+            if mode == "separate":
+                for (V, G, phi) in st["controls"]:
+                    s.predict(V, G, tape["Q"], float(tape["dt"]), phi)
+                s.update(st["zf"], st["idf"], st["zn"], tape["R"])
+                s.estimate_async()
+            else:
+                s.step(np.array(st["controls"], f32).reshape(-1, 3), tape["Q"], float(tape["dt"]), st["zf"], st["idf"], st["zn"], tape["R"])
+        est = s.estimate_fetch()
+        runs.append((s.download(), est, s.stats()))
+        s.close()
+    (a, ea, sa), (b, eb, sb) = runs
+    assert ea.shape == eb.shape == (len(tape["steps"]), 3) and np.array_equal(ea, eb)
+    for key in ("xv", "Pv", "w", "xf", "Pf"):
+        assert np.array_equal(a[key], b[key]), key
+    assert sa == sb
