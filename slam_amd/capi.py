@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DECLARED_SYMBOLS = [
     "slamgpu_last_error", "slamgpu_abi_version", "slamgpu_device_count", "slamgpu_jacobians", "slamgpu_create",
     "slamgpu_destroy", "slamgpu_predict", "slamgpu_update", "slamgpu_estimate", "slamgpu_estimate_async", "slamgpu_estimate_fetch", "slamgpu_stats", "slamgpu_ancestors",
-    "slamgpu_num_landmarks", "slamgpu_download", "slamgpu_upload", "slamgpu_sync", "slamgpu_stream", "slamgpu_profile",
+    "slamgpu_num_landmarks", "slamgpu_download", "slamgpu_upload", "slamgpu_sync", "slamgpu_step", "slamgpu_stream", "slamgpu_profile",
     "slamgpu_kernel_time", "slamgpu_algorithmic_bytes", "slamgpu_shard_update", "slamgpu_shard_block_totals", "slamgpu_shard_plan",
     "slamgpu_shard_record_floats", "slamgpu_shard_pack", "slamgpu_shard_unpack", "slamgpu_shard_finish", "slamgpu_shard_estimate",
     "slamgpu_dev_alloc", "slamgpu_dev_free", "slamgpu_dev_copy", "slamgpu_dev_copy_async", "slamgpu_shard_estimate_async",
