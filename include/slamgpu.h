@@ -131,6 +131,12 @@ int slamgpu_estimate(slamgpu_ctx *ctx, double xyt[3]);
  * the whole history later (one synchronisation for many steps).  xyt holds 3 doubles per entry. */
 int slamgpu_estimate_async(slamgpu_ctx *ctx);
 int slamgpu_estimate_fetch(slamgpu_ctx *ctx, double *xyt, int32_t max_count, int32_t *count);
+/* The same history with the per-step resampling record: neff[i] = Neff of the update that produced entry i and
+ * resampled[i] = whether it resampled (core.cpp:781-788, :731).  Entries recorded after predicts only (no update
+ * since the previous entry) repeat the last update's values.  Any output pointer may be NULL.  Reading the record
+ * here, once per batch of steps, keeps the step loop free of host round trips (slamgpu_stats synchronises). */
+int slamgpu_history_fetch(slamgpu_ctx *ctx, double *xyt, float *neff, int32_t *resampled, int32_t max_count, int32_t *count);
+
 
 /* Outcome of the last update: Neff, whether the resample fired, sum of the raw weights. Synchronises. */
 int slamgpu_stats(slamgpu_ctx *ctx, float *neff, int32_t *resampled, double *weight_sum);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DECLARED_SYMBOLS = [
     "slamgpu_last_error", "slamgpu_abi_version", "slamgpu_device_count", "slamgpu_jacobians", "slamgpu_create",
     "slamgpu_destroy", "slamgpu_predict", "slamgpu_update", "slamgpu_estimate", "slamgpu_estimate_async", "slamgpu_estimate_fetch", "slamgpu_stats", "slamgpu_ancestors",
-    "slamgpu_num_landmarks", "slamgpu_download", "slamgpu_upload", "slamgpu_sync", "slamgpu_step", "slamgpu_stream", "slamgpu_profile",
+    "slamgpu_num_landmarks", "slamgpu_download", "slamgpu_upload", "slamgpu_sync", "slamgpu_step", "slamgpu_history_fetch", "slamgpu_stream", "slamgpu_profile",
     "slamgpu_kernel_time", "slamgpu_algorithmic_bytes", "slamgpu_shard_update", "slamgpu_shard_block_totals", "slamgpu_shard_plan",
     "slamgpu_shard_record_floats", "slamgpu_shard_pack", "slamgpu_shard_unpack", "slamgpu_shard_finish", "slamgpu_shard_estimate",
     "slamgpu_dev_alloc", "slamgpu_dev_free", "slamgpu_dev_copy", "slamgpu_dev_copy_async", "slamgpu_shard_estimate_async",
@@ -72,6 +72,7 @@ def load_library():
     L.slamgpu_estimate.argtypes = [C.c_void_p, C.c_void_p]
     L.slamgpu_estimate_async.argtypes = [C.c_void_p]
     L.slamgpu_estimate_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.slamgpu_history_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.slamgpu_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.slamgpu_ancestors.argtypes = [C.c_void_p, C.c_void_p]
     L.slamgpu_num_landmarks.argtypes = [C.c_void_p]
@@ -230,6 +231,15 @@ class SlamGpu:
         n = C.c_int32()
         _chk(self.L.slamgpu_estimate_fetch(self.h, _ptr(out), max_count, C.byref(n)))
         return out[:n.value].copy()
+
+    def history_fetch(self, max_count=4096):
+        """(xyt[k,3], neff[k], resampled[k]) of the estimate_async entries recorded since the last fetch."""
+        out = np.zeros((max_count, 3), np.float64)
+        ne = np.zeros(max_count, np.float32)
+        rs = np.zeros(max_count, np.int32)
+        n = C.c_int32()
+        _chk(self.L.slamgpu_history_fetch(self.h, _ptr(out), _ptr(ne), _ptr(rs), max_count, C.byref(n)))
+        return out[:n.value].copy(), ne[:n.value].copy(), rs[:n.value].astype(bool)
 
     def stats(self):
         ne, rs, ws = C.c_float(), C.c_int32(), C.c_double()

@@ -21,6 +21,7 @@ constexpr int kWave = 64;
 constexpr int kBlock = 256;
 constexpr int kMaxFusedPredict = 16;
 constexpr int kSmallObs = 12;       // observation packets up to this many zf / zn travel as kernel arguments
+constexpr int kHistStride = 6;      // doubles per pose-estimate history entry: sum x, sum y, heading, max w, Neff, resampled
 constexpr int kMaxScanBlocks = 8192;  // block totals scanned inside every resample block (LDS)
 
 // Ctrl.live / Ctrl.pend are double-buffered by a host-side slot number (Buffers::slot): a kernel that changes the
@@ -114,8 +115,9 @@ struct UpdateArgs {
     const ObsPacket *big;    // null => use `small`
     SmallObs small;
     int32_t lazy;            // 1: single-context pipeline (honour Ctrl.pend, launch the copy + finalise blocks)
+    int32_t copy_lo, copy_hi;  // copy roles (particle tile x 8 landmarks) of a pending lazy gather this launch carries
     int32_t finalize;        // 1: the extra block reduces the previous update's pose-estimate partials
-    double *finalize_hist;   // history slot of that estimate (4 doubles) or null
+    double *finalize_hist;   // history slot of that estimate (kHistStride doubles) or null
 };
 
 struct WeightScratch {
@@ -123,7 +125,8 @@ struct WeightScratch {
     float *blk_w;       // [nblocks] block totals of w        } one allocation: blk_w2 == blk_w + nblocks, so a
     float *blk_w2;      // [nblocks] block totals of w^2      } shard's totals travel as one contiguous message
     double *est_part;   // [nblocks][4] pose-estimate partials (sum x, sum y, heading, max w)
-    int32_t *keep;      // [ncap] ancestors of the last resample
+    int32_t *keep[2];   // [ncap] ancestors of the last resample, double-buffered by Buffers::slot: a launch reads the
+                        // pending gather through keep[slot] and writes new ancestors into keep[slot ^ 1]
     int32_t nblocks;
 };
 
@@ -172,7 +175,9 @@ struct KernelTable {
     void (*update)(hipStream_t, const Buffers &, const PredictArgs &, const UpdateArgs &, const RngArgs &,
                    const WeightScratch &);
     // K2: Neff + decision; normalise, or the ancestors of a stratified resample (nothing is moved); estimate partials
-    void (*resample)(hipStream_t, const Buffers &, const WeightScratch &, const RngArgs &, const ResampleArgs &);
+    //     (+ the second share of the copy roles of a pending lazy gather: UpdateArgs::copy_lo..copy_hi)
+    void (*resample)(hipStream_t, const Buffers &, const WeightScratch &, const RngArgs &, const ResampleArgs &,
+                     const UpdateArgs &);
     // materialise a pending lazy gather (needed before anything but the next update touches the particle set)
     void (*gather)(hipStream_t, const Buffers &, const WeightScratch &, int nf);
     // reduce the estimate partials of the last update now (-> Ctrl.est, history slot)

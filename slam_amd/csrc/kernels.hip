@@ -244,6 +244,10 @@ SLAM_DEV void finish_estimate(const Buffers &B, const WeightScratch &ws, double 
             hist[1] = v.sy;
             hist[2] = (double) v.th;
             hist[3] = (double) v.w;
+            // the resampling record of the update these partials belong to (its resample_kernel wrote them; the
+            // resample_kernel of the launch this block may be riding in has not run yet)
+            hist[4] = (double) c->neff;
+            hist[5] = (double) c->resampled;
         }
     }
 }
@@ -271,7 +275,7 @@ SLAM_DEV void copy_unobserved(const Buffers &B, const UpdateArgs &U, const Weigh
     const int k = bx * kBlock + threadIdx.x;
     if (k >= B.n) return;
     const size_t S = (size_t) B.ncap;
-    const int anc = ws.keep[k];
+    const int anc = ws.keep[B.slot][k];
     const float4 *__restrict__ sA = cur ? B.lmkA[1] : B.lmkA[0];
     const float *__restrict__ sB = cur ? B.lmkB[1] : B.lmkB[0];
     float4 *__restrict__ dA = cur ? B.lmkA[0] : B.lmkA[1];
@@ -336,7 +340,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             if (U.finalize) finish_estimate(B, ws, U.finalize_hist, sh_est);
             return;
         }
-        if (pend) copy_unobserved(B, U, ws, cur, blockIdx.x - ws.nblocks);
+        if (pend) copy_unobserved(B, U, ws, cur, U.copy_lo + (int) blockIdx.x - ws.nblocks);
         return;
     }
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -358,7 +362,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     float w = 0.0f;
 
     if (active) {
-        const int si = pend ? ws.keep[i] : i;  // where this particle's state is read from
+        const int si = pend ? ws.keep[B.slot][i] : i;  // where this particle's state is read from
         const int32_t *__restrict__ idf;
         const float *__restrict__ zf, *__restrict__ zn;
         if (U.big) {
@@ -759,13 +763,20 @@ SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const f
 //                particle from the live buffers into the other set, w = 1/N (:744-747); blockIdx.y splits
 //                the landmarks.  The last block to finish reduces the estimate partials and flips Ctrl.cur.
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScratch ws, RngArgs rng, ResampleArgs ra) {
+__global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScratch ws, RngArgs rng, ResampleArgs ra,
+                                                           UpdateArgs U) {
     extern __shared__ double off[];  // [nblocks + 1] exclusive prefix of the block totals
     __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
     __shared__ EstItem sh_est[kBlock / kWave];
     Ctrl *ctrl = B.ctrl;
     const int t = threadIdx.x;
     const int nb = ws.nblocks;
+    if ((int) blockIdx.x >= nb) {
+        // second share of the copy roles of the lazy gather this step's update kernel started: the planning blocks
+        // below are a chain of dependent loads (scan, binary search), these keep HBM busy meanwhile
+        if (ctrl->pend[B.slot]) copy_unobserved(B, U, ws, ctrl->live[B.slot], U.copy_lo + (int) blockIdx.x - nb);
+        return;
+    }
     // the buffer the update kernel of this step wrote: the other one if it performed a lazy gather
     const int cur = ctrl->live[B.slot] ^ (ctrl->pend[B.slot] ? 1 : 0);
 
@@ -799,7 +810,7 @@ __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScrat
     } else if (active) {
         const double target = (double) stratum(rng, (int64_t) k) * W;
         const int anc = (int) min(find_ancestor(target, off, nb, ws.lcum, 0, nb, (int64_t) B.n), (int64_t) B.n - 1);
-        ws.keep[k] = anc;
+        ws.keep[B.slot ^ 1][k] = anc;
         const float4 pa = B.poseA[cur][anc];
         ei = EstItem{(double) pa.x, (double) pa.y, ctrl->inv_n, pa.z, k};
     }
@@ -832,7 +843,7 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(Buffers B, WeightScratch
     if (!pend) return;
     const int k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= B.n) return;
-    const int anc = ws.keep[k];
+    const int anc = ws.keep[B.slot][k];
     const size_t S = (size_t) B.ncap;
     if (blockIdx.y == 0) {
         float4 pa = B.poseA[cur][anc];
@@ -983,7 +994,7 @@ __global__ void __launch_bounds__(kBlock) shard_pack_kernel(Buffers B, WeightScr
             B.poseA[cur ^ 1][o] = pa;
             B.poseB[cur ^ 1][o] = B.poseB[cur][anc];
             B.poseC[cur ^ 1][o] = B.poseC[cur][anc];
-            ws.keep[o] = (int32_t) ganc;
+            ws.keep[B.slot ^ 1][o] = (int32_t) ganc;
         }
         const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(A.nf, j0 + kLmkPerBlockY);
         for (int l = j0; l < j1; l++) {
@@ -1032,7 +1043,7 @@ __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightS
         B.poseA[cur ^ 1][i] = make_float4(src[0], src[cnt], src[2 * cnt], B.ctrl->inv_n);
         B.poseB[cur ^ 1][i] = make_float4(src[3 * cnt], src[4 * cnt], src[5 * cnt], src[6 * cnt]);
         B.poseC[cur ^ 1][i] = make_float2(src[7 * cnt], src[8 * cnt]);
-        ws.keep[i] = __float_as_int(src[9 * cnt]);
+        ws.keep[B.slot ^ 1][i] = __float_as_int(src[9 * cnt]);
     }
     const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(A.nf, j0 + kLmkPerBlockY);
     for (int l = j0; l < j1; l++) {
@@ -1093,7 +1104,7 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
     // compute blocks first (they are the long pole), then -- single-context pipeline only -- the copy blocks of a
     // pending lazy gather (they exit at once when nothing is pending: the host cannot know) and one helper block
     int grid = B.ncap / kBlock;
-    if (U.lazy) grid += ws.nblocks * ((U.nf + kLmkPerBlockY - 1) / kLmkPerBlockY) + 1;
+    if (U.lazy) grid += (U.copy_hi - U.copy_lo) + 1;
     if (U.method == 2)
         hipLaunchKernelGGL(update_kernel<2>, dim3(grid), dim3(kBlock), 0, st, B, PA, U, rng, ws);
     else
@@ -1101,9 +1112,9 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
 }
 
 static void launch_resample(hipStream_t st, const Buffers &B, const WeightScratch &ws, const RngArgs &rng,
-                            const ResampleArgs &ra) {
+                            const ResampleArgs &ra, const UpdateArgs &U) {
     const size_t lds = sizeof(double) * ((size_t) ws.nblocks + 1);
-    hipLaunchKernelGGL(resample_kernel, dim3(ws.nblocks), dim3(kBlock), lds, st, B, ws, rng, ra);
+    hipLaunchKernelGGL(resample_kernel, dim3(ws.nblocks + (U.copy_hi - U.copy_lo)), dim3(kBlock), lds, st, B, ws, rng, ra, U);
 }
 
 static void launch_gather(hipStream_t st, const Buffers &B, const WeightScratch &ws, int nf) {

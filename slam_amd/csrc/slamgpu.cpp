@@ -77,7 +77,7 @@ struct slamgpu_ctx {
     // host mirror of ctrl for readback
     Ctrl *ctrl_host = nullptr;  // pinned
     // pose-estimate history
-    double *hist_dev = nullptr;  // [kHistCap][4]
+    double *hist_dev = nullptr;  // [kHistCap][kHistStride]
     int hist_n = 0;
     bool est_fresh = false;  // Ctrl.est / hist slot hist_n were written by the last update and nothing changed since
     // profiling
@@ -90,6 +90,9 @@ struct slamgpu_ctx {
     // Ctrl.live / Ctrl.pend slot the next launch reads (kernels.h: Ctrl); flipped after every launch that may
     // change the live buffer (resample_kernel, gather_kernel, shard_commit_kernel)
     int slot = 0;
+    int keep_slot = 0;            // which WeightScratch::keep buffer holds the ancestors of the last update
+    float copy_split = 0.3f;      // share of a pending lazy gather's copy roles carried by the update launch (measured
+                                  // on MI355X at 100 000 particles: 0.0 26.4, 0.3 25.9, 0.5 26.2, 1.0 26.8 us/step)
     bool maybe_pending = false;   // the last update may have left a lazy gather (only the device knows)
     bool est_deferred = false;    // est_part holds the partials of the last update, not reduced yet
     double *deferred_hist = nullptr;  // history slot that reduction has to fill (or null)
@@ -296,6 +299,7 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     c->cfg = *cfg;
     if (c->cfg.n_particles_global <= 0) c->cfg.n_particles_global = c->cfg.n_particles;
     c->k = cfg->math_mode == SLAMGPU_MATH_FAST ? kernels_fast() : kernels_strict();
+    if (const char *e = getenv("SLAMGPU_COPY_SPLIT")) c->copy_split = std::min(1.0f, std::max(0.0f, (float) atof(e)));
     const int cap_nf = cfg->max_landmarks > 0 ? cfg->max_landmarks : 1;
     c->B.n = n;
     c->B.ncap = ncap;
@@ -341,9 +345,11 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     CTX_TRY(hipMalloc((void **) &c->ws.blk_w, sizeof(float) * 2 * (size_t) c->ws.nblocks));  // [w | w2] contiguous
     c->ws.blk_w2 = c->ws.blk_w + c->ws.nblocks;
     CTX_TRY(hipMalloc((void **) &c->ws.est_part, sizeof(double) * 4 * (size_t) c->ws.nblocks));
-    CTX_TRY(hipMalloc((void **) &c->ws.keep, sizeof(int32_t) * S));
-    CTX_TRY(hipMemsetAsync(c->ws.keep, 0, sizeof(int32_t) * S, c->stream));
-    CTX_TRY(hipMalloc((void **) &c->hist_dev, sizeof(double) * 4 * (size_t) kHistCap));
+    for (int b = 0; b < 2; b++) {
+        CTX_TRY(hipMalloc((void **) &c->ws.keep[b], sizeof(int32_t) * S));
+        CTX_TRY(hipMemsetAsync(c->ws.keep[b], 0, sizeof(int32_t) * S, c->stream));
+    }
+    CTX_TRY(hipMalloc((void **) &c->hist_dev, sizeof(double) * kHistStride * (size_t) kHistCap));
     // big-packet ring: header + idf[cap] + zf[2cap] + zn[2cap]
     c->pkt_bytes = ((sizeof(ObsPacket) + sizeof(int32_t) * cap_nf + sizeof(float) * 4 * cap_nf) + 255) / 256 * 256;
     CTX_TRY(hipHostMalloc((void **) &c->pkt_host, c->pkt_bytes * kRing, hipHostMallocDefault));
@@ -386,7 +392,8 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     if (c->ws.lcum) (void) hipFree(c->ws.lcum);
     if (c->ws.blk_w) (void) hipFree(c->ws.blk_w);
     if (c->ws.est_part) (void) hipFree(c->ws.est_part);
-    if (c->ws.keep) (void) hipFree(c->ws.keep);
+    for (int b = 0; b < 2; b++)
+        if (c->ws.keep[b]) (void) hipFree(c->ws.keep[b]);
     if (c->hist_dev) (void) hipFree(c->hist_dev);
     if (c->pkt_host) (void) hipHostFree(c->pkt_host);
     if (c->pkt_dev) (void) hipFree(c->pkt_dev);
@@ -540,6 +547,12 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     const RngArgs rng = rng_args(c, c->obs_step);
     c->B.slot = c->slot;
     U.lazy = sharded ? 0 : 1;
+    // copy roles of a pending lazy gather (one role = 256 particles x 8 landmarks known before this update), split
+    // between this launch and the resample launch so that neither waits for the other's share
+    const int roles = sharded ? 0 : c->ws.nblocks * ((U.nf + 7) / 8);
+    const int roles_k1 = (int) ((double) roles * c->copy_split + 0.5);
+    U.copy_lo = 0;
+    U.copy_hi = roles_k1;
     U.finalize = (!sharded && c->est_deferred) ? 1 : 0;
     U.finalize_hist = c->deferred_hist;
     {
@@ -558,18 +571,21 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     ra.nf = c->nf;
     ra.do_resample = c->cfg.resample;
     ra.n_effective = c->cfg.n_effective;
+    U.copy_lo = roles_k1;
+    U.copy_hi = roles;
     {
         Timed t(c, "resample");
-        c->k->resample(c->stream, c->B, c->ws, rng, ra);
+        c->k->resample(c->stream, c->B, c->ws, rng, ra, U);
     }
     HIP_TRY(hipGetLastError());
-    // resample_kernel published the new live / pending state in the other slot
+    // resample_kernel published the new live / pending state (and the new ancestors) in the other slot
+    c->keep_slot = c->slot ^ 1;
     c->slot ^= 1;
     c->B.slot = c->slot;
     c->maybe_pending = true;
     // this step's pose estimate exists as per-block partials; the next update launch (or finish_deferred) reduces
     // them into Ctrl.est and this history slot
-    c->deferred_hist = c->hist_n < kHistCap ? c->hist_dev + 4 * (size_t) c->hist_n : nullptr;
+    c->deferred_hist = c->hist_n < kHistCap ? c->hist_dev + kHistStride * (size_t) c->hist_n : nullptr;
     c->est_deferred = true;
     c->est_fresh = c->deferred_hist != nullptr;
     return 0;
@@ -722,6 +738,7 @@ int slamgpu_shard_finish(slamgpu_ctx *c, const slamgpu_shard_plan_t *plan) {
         Timed t(c, "shard_finish");
         c->k->shard_finish(c->stream, c->B, plan->wsum, plan->wsq, plan->neff, plan->resampled);
     }
+    c->keep_slot = c->slot ^ 1;  // pack / unpack wrote the ancestors there
     c->slot ^= 1;  // shard_commit_kernel published the (possibly flipped) live buffer in the other slot
     c->B.slot = c->slot;
     c->est_fresh = false;
@@ -773,7 +790,7 @@ int slamgpu_shard_estimate_async(slamgpu_ctx *c) {
     if (int rc = finish_deferred(c)) return rc;
     {
         Timed t(c, "estimate");
-        c->k->estimate(c->stream, c->B, c->ws, c->hist_dev + 4 * (size_t) c->hist_n);
+        c->k->estimate(c->stream, c->B, c->ws, c->hist_dev + kHistStride * (size_t) c->hist_n);
     }
     c->hist_n++;
     HIP_TRY(hipGetLastError());
@@ -787,7 +804,12 @@ int slamgpu_shard_estimate_fetch(slamgpu_ctx *c, double *raw4, int32_t max_count
     if (int rc = finish_deferred(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     const int n = c->hist_n < max_count ? c->hist_n : max_count;
-    if (n > 0 && raw4) HIP_TRY(hipMemcpy(raw4, c->hist_dev, sizeof(double) * 4 * (size_t) n, hipMemcpyDeviceToHost));
+    if (n > 0 && raw4) {
+        std::vector<double> h((size_t) kHistStride * n);
+        HIP_TRY(hipMemcpy(h.data(), c->hist_dev, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < 4; k++) raw4[4 * (size_t) i + k] = h[(size_t) kHistStride * i + k];
+    }
     *count = n;
     c->hist_n = 0;
     c->est_fresh = false;
@@ -840,7 +862,7 @@ int slamgpu_estimate_async(slamgpu_ctx *c) {
         if (int rc = materialize(c)) return rc;
         if (int rc = finish_deferred(c)) return rc;
         Timed t(c, "estimate");
-        c->k->estimate(c->stream, c->B, c->ws, c->hist_dev + 4 * (size_t) c->hist_n);
+        c->k->estimate(c->stream, c->B, c->ws, c->hist_dev + kHistStride * (size_t) c->hist_n);
         HIP_TRY(hipGetLastError());
     }
     // else: slot hist_n is filled when the partials of the last update are reduced (next update launch / finish)
@@ -849,24 +871,33 @@ int slamgpu_estimate_async(slamgpu_ctx *c) {
     return 0;
 }
 
-int slamgpu_estimate_fetch(slamgpu_ctx *c, double *xyt, int32_t max_count, int32_t *count) {
+int slamgpu_history_fetch(slamgpu_ctx *c, double *xyt, float *neff, int32_t *resampled, int32_t max_count, int32_t *count) {
     if (int rc = check_ctx(c)) return rc;
     if (!count) return fail(SLAMGPU_ERR_INVALID, "null count");
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = finish_deferred(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     const int n = c->hist_n < max_count ? c->hist_n : max_count;
-    std::vector<double> h((size_t) 4 * (n > 0 ? n : 1));
-    if (n > 0) HIP_TRY(hipMemcpy(h.data(), c->hist_dev, sizeof(double) * 4 * (size_t) n, hipMemcpyDeviceToHost));
-    for (int i = 0; i < n && xyt; i++) {
-        xyt[3 * i] = h[4 * (size_t) i] / (double) c->B.n;
-        xyt[3 * i + 1] = h[4 * (size_t) i + 1] / (double) c->B.n;
-        xyt[3 * i + 2] = h[4 * (size_t) i + 2];
+    std::vector<double> h((size_t) kHistStride * (n > 0 ? n : 1));
+    if (n > 0) HIP_TRY(hipMemcpy(h.data(), c->hist_dev, sizeof(double) * kHistStride * (size_t) n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+        const double *e = h.data() + (size_t) kHistStride * i;
+        if (xyt) {
+            xyt[3 * i] = e[0] / (double) c->B.n;
+            xyt[3 * i + 1] = e[1] / (double) c->B.n;
+            xyt[3 * i + 2] = e[2];
+        }
+        if (neff) neff[i] = (float) e[4];
+        if (resampled) resampled[i] = (int32_t) e[5];
     }
     *count = n;
     c->hist_n = 0;
     c->est_fresh = false;
     return 0;
+}
+
+int slamgpu_estimate_fetch(slamgpu_ctx *c, double *xyt, int32_t max_count, int32_t *count) {
+    return slamgpu_history_fetch(c, xyt, nullptr, nullptr, max_count, count);
 }
 
 int slamgpu_stats(slamgpu_ctx *c, float *neff, int32_t *resampled, double *weight_sum) {
@@ -886,7 +917,7 @@ int slamgpu_ancestors(slamgpu_ctx *c, int32_t *keep) {
         for (int i = 0; i < c->B.n; i++) keep[i] = i;
         return 0;
     }
-    HIP_TRY(hipMemcpy(keep, c->ws.keep, sizeof(int32_t) * (size_t) c->B.n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(keep, c->ws.keep[c->keep_slot], sizeof(int32_t) * (size_t) c->B.n, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -422,3 +422,31 @@ def test_step_call_equals_separate_calls(sg):
     for key in ("xv", "Pv", "w", "xf", "Pf"):
         assert np.array_equal(a[key], b[key]), key
     assert sa == sb
+
+
+def test_history_carries_the_resampling_record(sg):
+    """slamgpu_history_fetch: per-step Neff / resampled, identical to what slamgpu_stats reports step by step."""
+    import os
+    from slam_amd import host
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    N = 2048
+    tape = host.make_tape(["-m", os.path.join(root, "data", "example_webmap.mat"), "-method", "FASTSLAM2", "-NPARTICLES", N,
+                           "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", 5], max_obs=80)
+    logs = []
+    for with_stats in (True, False):
+        s = sg.SlamGpu(N, tape["nlm"], method=2, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=2)
+        per_step = []
+        for st in tape["steps"]:
+            s.step(np.array(st["controls"], f32).reshape(-1, 3), tape["Q"], float(tape["dt"]), st["zf"], st["idf"], st["zn"], tape["R"])
+            if with_stats:
+                ne, rs, _ = s.stats()
+                per_step.append((float(ne), bool(rs)))
+        xyt, ne, rs = s.history_fetch()
+        assert xyt.shape == (len(tape["steps"]), 3)
+        if with_stats:
+            assert [(float(a), bool(b)) for a, b in zip(ne, rs)] == per_step
+            assert 0 < rs.sum() < len(rs)
+        logs.append((xyt, ne, rs))
+        s.close()
+    for a, b in zip(logs[0], logs[1]):
+        assert np.array_equal(a, b)
