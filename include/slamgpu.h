@@ -180,6 +180,16 @@ typedef struct {
 
 int slamgpu_shard_update(slamgpu_ctx *ctx, const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n,
                          const float R[4], const float *normals, const float *strata);
+/* slamgpu_step for a shard: n_controls x slamgpu_predict, then slamgpu_shard_update (the per-particle half of the
+ * update); the caller continues with the slamgpu_shard_* resampling stage. */
+int slamgpu_shard_step(slamgpu_ctx *ctx, const float *controls, int32_t n_controls, const float Q[4], float dt,
+                       const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n, const float R[4],
+                       const float *normals, const float *strata);
+
+/* Optional: make the update kernel write this shard's [w(nb) | w2(nb)] block totals straight into a caller-owned device
+ * buffer (2*nb floats, e.g. the input tensor of the all-gather) instead of the context's own; NULL restores the default.
+ * Saves the per-step device copy between slamgpu_shard_block_totals and the collective. */
+int slamgpu_shard_set_totals_buffer(slamgpu_ctx *ctx, float *totals_dev);
 int slamgpu_shard_block_totals(slamgpu_ctx *ctx, const float **totals_dev, int32_t *nblocks);
 int slamgpu_shard_plan(slamgpu_ctx *ctx, const float *gtot_dev, int32_t nb_global, int32_t n_shards, slamgpu_shard_plan_t *out);
 int slamgpu_shard_record_floats(slamgpu_ctx *ctx);

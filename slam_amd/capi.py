@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DECLARED_SYMBOLS = [
     "slamgpu_last_error", "slamgpu_abi_version", "slamgpu_device_count", "slamgpu_jacobians", "slamgpu_create",
     "slamgpu_destroy", "slamgpu_predict", "slamgpu_update", "slamgpu_estimate", "slamgpu_estimate_async", "slamgpu_estimate_fetch", "slamgpu_stats", "slamgpu_ancestors",
-    "slamgpu_num_landmarks", "slamgpu_download", "slamgpu_upload", "slamgpu_sync", "slamgpu_step", "slamgpu_history_fetch", "slamgpu_stream", "slamgpu_profile",
+    "slamgpu_num_landmarks", "slamgpu_download", "slamgpu_upload", "slamgpu_sync", "slamgpu_step", "slamgpu_history_fetch", "slamgpu_shard_set_totals_buffer", "slamgpu_shard_step", "slamgpu_stream", "slamgpu_profile",
     "slamgpu_kernel_time", "slamgpu_algorithmic_bytes", "slamgpu_shard_update", "slamgpu_shard_block_totals", "slamgpu_shard_plan",
     "slamgpu_shard_record_floats", "slamgpu_shard_pack", "slamgpu_shard_unpack", "slamgpu_shard_finish", "slamgpu_shard_estimate",
     "slamgpu_dev_alloc", "slamgpu_dev_free", "slamgpu_dev_copy", "slamgpu_dev_copy_async", "slamgpu_shard_estimate_async",
@@ -69,6 +69,7 @@ def load_library():
                                  C.c_void_p, C.c_void_p]
     L.slamgpu_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int32,
                                C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    L.slamgpu_shard_step.argtypes = L.slamgpu_step.argtypes[:-1]
     L.slamgpu_estimate.argtypes = [C.c_void_p, C.c_void_p]
     L.slamgpu_estimate_async.argtypes = [C.c_void_p]
     L.slamgpu_estimate_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
@@ -85,6 +86,7 @@ def load_library():
     L.slamgpu_kernel_time.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.slamgpu_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.slamgpu_shard_update.argtypes = L.slamgpu_update.argtypes
+    L.slamgpu_shard_set_totals_buffer.argtypes = [C.c_void_p, C.c_void_p]
     L.slamgpu_shard_block_totals.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
     L.slamgpu_shard_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(ShardPlan)]
     L.slamgpu_shard_record_floats.argtypes = [C.c_void_p]
@@ -194,7 +196,7 @@ class SlamGpu:
         st = None if strata is None else _f32(strata)
         _chk(self.L.slamgpu_update(self.h, _ptr(zf), _ptr(idf), zf.shape[0], _ptr(zn), zn.shape[0], _ptr(R), _ptr(nm), _ptr(st)))
 
-    def prepare_step(self, controls, Q, dt, zf, idf, zn, R, normals=None, strata=None, record_estimate=True):
+    def prepare_step(self, controls, Q, dt, zf, idf, zn, R, normals=None, strata=None, record_estimate=True, shard=False):
         """Marshal one filter step (k predicts + update [+ estimate_async]) once; the returned callable makes the single
         slamgpu_step call.  Lets a driver loop pay the numpy -> pointer conversions outside its timed region, the way a
         C++ host that already holds plain arrays would."""
@@ -208,8 +210,12 @@ class SlamGpu:
         st = None if strata is None else _f32(strata)
         keep = (ctl, Q, zf, zn, idf, R, nm, st)  # the pointers below borrow these buffers
         args = (self.h, _ptr(ctl), ctl.shape[0], _ptr(Q), C.c_float(dt), _ptr(zf), _ptr(idf), zf.shape[0], _ptr(zn), zn.shape[0],
-                _ptr(R), _ptr(nm), _ptr(st), 1 if record_estimate else 0)
-        fn = self.L.slamgpu_step
+                _ptr(R), _ptr(nm), _ptr(st))
+        if shard:
+            fn = self.L.slamgpu_shard_step
+        else:
+            fn = self.L.slamgpu_step
+            args = args + (1 if record_estimate else 0,)
 
         def call(_keep=keep):
             _chk(fn(*args))
@@ -217,6 +223,9 @@ class SlamGpu:
 
     def step(self, controls, Q, dt, zf, idf, zn, R, normals=None, strata=None, record_estimate=True):
         self.prepare_step(controls, Q, dt, zf, idf, zn, R, normals, strata, record_estimate)()
+
+    def shard_step(self, controls, Q, dt, zf, idf, zn, R, normals=None, strata=None):
+        self.prepare_step(controls, Q, dt, zf, idf, zn, R, normals, strata, shard=True)()
 
     def estimate(self):
         e = np.zeros(3, np.float64)
@@ -282,6 +291,9 @@ class SlamGpu:
         nm = None if normals is None else _f32(normals, (self.N, 3))
         st = None if strata is None else _f32(strata)
         _chk(self.L.slamgpu_shard_update(self.h, _ptr(zf), _ptr(idf), zf.shape[0], _ptr(zn), zn.shape[0], _ptr(R), _ptr(nm), _ptr(st)))
+
+    def shard_set_totals_buffer(self, ptr):
+        _chk(self.L.slamgpu_shard_set_totals_buffer(self.h, ptr))
 
     def shard_block_totals(self):
         """device pointer of this shard's [w(nb) | w2(nb)] block totals, nb"""

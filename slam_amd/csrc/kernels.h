@@ -188,7 +188,8 @@ struct KernelTable {
     void (*shard_plan)(hipStream_t, const ShardPlanArgs &, const RngArgs &, ShardPlan *out_dev);
     void (*shard_pack)(hipStream_t, const Buffers &, const WeightScratch &, const ShardPackArgs &, const RngArgs &);
     void (*shard_unpack)(hipStream_t, const Buffers &, const WeightScratch &, const ShardUnpackArgs &);
-    void (*shard_finish)(hipStream_t, const Buffers &, double W, double Q, float neff, int resampled);
+    // normalise or leave the lazy gather pending; this shard's pose-estimate partials; outcome into Ctrl
+    void (*shard_finish)(hipStream_t, const Buffers &, const WeightScratch &, double W, double Q, float neff, int resampled);
 };
 
 const KernelTable *kernels_strict();

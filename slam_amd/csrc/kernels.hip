@@ -276,6 +276,7 @@ SLAM_DEV void copy_unobserved(const Buffers &B, const UpdateArgs &U, const Weigh
     if (k >= B.n) return;
     const size_t S = (size_t) B.ncap;
     const int anc = ws.keep[B.slot][k];
+    if (anc < 0) return;  // sharded runs: this record arrived from another shard and is already in place
     const float4 *__restrict__ sA = cur ? B.lmkA[1] : B.lmkA[0];
     const float *__restrict__ sB = cur ? B.lmkB[1] : B.lmkB[0];
     float4 *__restrict__ dA = cur ? B.lmkA[0] : B.lmkA[1];
@@ -347,11 +348,6 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     // select (not index) the buffers: an indexed read of the pointer table in the kernel-argument segment
     // would be one more dependent scalar load at the head of every wave
-    const float4 *__restrict__ lmkA = cur ? B.lmkA[1] : B.lmkA[0];
-    const float *__restrict__ lmkB = cur ? B.lmkB[1] : B.lmkB[0];
-    const float4 *__restrict__ poseA = cur ? B.poseA[1] : B.poseA[0];
-    const float4 *__restrict__ poseB = cur ? B.poseB[1] : B.poseB[0];
-    const float2 *__restrict__ poseC = cur ? B.poseC[1] : B.poseC[0];
     float4 *__restrict__ lmkAo = out ? B.lmkA[1] : B.lmkA[0];
     float *__restrict__ lmkBo = out ? B.lmkB[1] : B.lmkB[0];
     float4 *__restrict__ poseAo = out ? B.poseA[1] : B.poseA[0];
@@ -362,7 +358,24 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     float w = 0.0f;
 
     if (active) {
-        const int si = pend ? ws.keep[B.slot][i] : i;  // where this particle's state is read from
+        // where this particle's state is read from: slot i of the live buffers; or, with a gather pending, slot
+        // keep[i] of the live buffers; or (sharded runs) slot i of the OUTPUT buffers when keep[i] < 0: the record
+        // came from another shard and shard_unpack_kernel has already put it in place
+        int si = i;
+        bool in_place = !pend;
+        if (pend) {
+            si = ws.keep[B.slot][i];
+            if (si < 0) {
+                si = i;
+                in_place = true;
+            }
+        }
+        const int sb = in_place ? out : cur;
+        const float4 *__restrict__ lmkA = sb ? B.lmkA[1] : B.lmkA[0];
+        const float *__restrict__ lmkB = sb ? B.lmkB[1] : B.lmkB[0];
+        const float4 *__restrict__ poseA = sb ? B.poseA[1] : B.poseA[0];
+        const float4 *__restrict__ poseB = sb ? B.poseB[1] : B.poseB[0];
+        const float2 *__restrict__ poseC = sb ? B.poseC[1] : B.poseC[0];
         const int32_t *__restrict__ idf;
         const float *__restrict__ zf, *__restrict__ zn;
         if (U.big) {
@@ -844,6 +857,7 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(Buffers B, WeightScratch
     const int k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= B.n) return;
     const int anc = ws.keep[B.slot][k];
+    if (anc < 0) return;  // sharded runs: arrived from another shard, already in place (pose, landmarks, w = 1/N)
     const size_t S = (size_t) B.ncap;
     if (blockIdx.y == 0) {
         float4 pa = B.poseA[cur][anc];
@@ -974,7 +988,7 @@ __global__ void __launch_bounds__(kBlock) shard_pack_kernel(Buffers B, WeightScr
     const int64_t j = (int64_t) blockIdx.x * kBlock + threadIdx.x;  // offspring slot of this shard
     const int64_t k = A.k_lo + j;
     if (k >= A.k_hi) return;
-    const int cur = B.ctrl->live[B.slot];
+    const int cur = B.ctrl->live[B.slot] ^ (B.ctrl->pend[B.slot] ? 1 : 0);  // the buffers this step's update wrote
     const size_t S = (size_t) B.ncap;
     const double target = (double) stratum(rng, k) * W;
     const int64_t ganc = find_ancestor(target, off, A.nb_global, ws.lcum, A.first_block, ws.nblocks, rng.n_global);
@@ -985,22 +999,10 @@ __global__ void __launch_bounds__(kBlock) shard_pack_kernel(Buffers B, WeightScr
     const int64_t blk_hi = min(A.k_hi, (int64_t) (d + 1) * A.n_per_shard);
     const int64_t cnt = blk_hi - blk_lo, slot = k - blk_lo;
     if (d == A.shard) {
-        // the output slot lives on this shard too: gather straight into the spare buffers (no exchange);
-        // with balanced weights this is almost every offspring
-        const int o = (int) (k - (int64_t) d * A.n_per_shard);
-        if (blockIdx.y == 0) {
-            float4 pa = B.poseA[cur][anc];
-            pa.w = B.ctrl->inv_n;
-            B.poseA[cur ^ 1][o] = pa;
-            B.poseB[cur ^ 1][o] = B.poseB[cur][anc];
-            B.poseC[cur ^ 1][o] = B.poseC[cur][anc];
-            ws.keep[B.slot ^ 1][o] = (int32_t) ganc;
-        }
-        const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(A.nf, j0 + kLmkPerBlockY);
-        for (int l = j0; l < j1; l++) {
-            B.lmkA[cur ^ 1][(size_t) l * S + o] = B.lmkA[cur][(size_t) l * S + anc];
-            B.lmkB[cur ^ 1][(size_t) l * S + o] = B.lmkB[cur][(size_t) l * S + anc];
-        }
+        // the output slot lives on this shard too: nothing moves now -- record the (local) ancestor; the next update
+        // launch gathers while it computes (lazy gather, as in the single-context pipeline).  With balanced weights
+        // this is almost every offspring.
+        if (blockIdx.y == 0) ws.keep[B.slot ^ 1][(int) (k - (int64_t) d * A.n_per_shard)] = anc;
         return;
     }
     // records before this block in the send buffer = offspring before it, minus the ones kept local
@@ -1028,12 +1030,12 @@ __global__ void __launch_bounds__(kBlock) shard_pack_kernel(Buffers B, WeightScr
 __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightScratch ws, ShardUnpackArgs A) {
     const int i = blockIdx.x * kBlock + threadIdx.x;  // local output particle
     if (i >= B.n) return;
-    const int cur = B.ctrl->live[B.slot];
+    const int cur = B.ctrl->live[B.slot] ^ (B.ctrl->pend[B.slot] ? 1 : 0);  // the buffers this step's update wrote
     const size_t S = (size_t) B.ncap;
     // source block: the s with src_lo[s] <= i < src_lo[s+1] (local output index boundaries, increasing)
     int s = 0;
     while (s + 1 < A.n_shards && i >= A.src_lo[s + 1]) s++;
-    if (s == A.shard) return;  // written directly by this shard's own pack kernel
+    if (s == A.shard) return;  // local ancestor: recorded in keep[] by this shard's own pack kernel, gathered lazily
     const int64_t cnt = A.src_lo[s + 1] - A.src_lo[s], slot = i - A.src_lo[s];
     // records before this block in the receive buffer = outputs before it, minus the locally produced ones
     const int64_t own = A.src_lo[A.shard + 1] - A.src_lo[A.shard];
@@ -1043,7 +1045,8 @@ __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightS
         B.poseA[cur ^ 1][i] = make_float4(src[0], src[cnt], src[2 * cnt], B.ctrl->inv_n);
         B.poseB[cur ^ 1][i] = make_float4(src[3 * cnt], src[4 * cnt], src[5 * cnt], src[6 * cnt]);
         B.poseC[cur ^ 1][i] = make_float2(src[7 * cnt], src[8 * cnt]);
-        ws.keep[B.slot ^ 1][i] = __float_as_int(src[9 * cnt]);
+        // negative = "already in place in the output buffers"; the global ancestor id is -(keep + 1)
+        ws.keep[B.slot ^ 1][i] = -(__float_as_int(src[9 * cnt]) + 1);
     }
     const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(A.nf, j0 + kLmkPerBlockY);
     for (int l = j0; l < j1; l++) {
@@ -1053,23 +1056,46 @@ __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightS
     }
 }
 
-__global__ void __launch_bounds__(kBlock) shard_normalize_kernel(Buffers B, double W) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= B.n) return;
-    float4 *pa = B.poseA[B.ctrl->live[B.slot]] + i;
-    pa->w = pa->w / (float) W;
-}
-
-// records the outcome of a sharded update in Ctrl (and commits the flip after an unpack)
-__global__ void shard_commit_kernel(Buffers B, double W, double Q, float neff, int resampled) {
+// Last stage of a sharded update: normalise (no resample), this shard's pose-estimate partials (through keep[] when
+// the resample left a lazy gather), and the outcome in Ctrl: the set stays in the buffers this step's update wrote;
+// after a resample it is defined through keep[] (local ancestors) / already in place in the other buffers (records
+// that arrived from other shards) until the next update launch, or gather_kernel, moves it.
+__global__ void __launch_bounds__(kBlock) shard_finalize_kernel(Buffers B, WeightScratch ws, double W, double Q, float neff,
+                                                                 int resampled) {
+    __shared__ EstItem sh_est[kBlock / kWave];
     Ctrl *c = B.ctrl;
-    c->wsum = W;
-    c->wsq = Q;
-    c->neff = neff;
-    c->resampled = resampled;
-    // published in the other slot; the host flips its slot after this launch (see Ctrl)
-    c->live[B.slot ^ 1] = c->live[B.slot] ^ (resampled ? 1 : 0);
-    c->pend[B.slot ^ 1] = 0;
+    const int cur = c->live[B.slot] ^ (c->pend[B.slot] ? 1 : 0);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        c->wsum = W;
+        c->wsq = Q;
+        c->neff = neff;
+        c->resampled = resampled;
+        // published in the other slot; the host flips its slot after this launch (see Ctrl)
+        c->live[B.slot ^ 1] = cur;
+        c->pend[B.slot ^ 1] = resampled ? 1 : 0;
+    }
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    EstItem ei{0.0, 0.0, -3.0e38f, 0.0f, 0x7fffffff};
+    if (i < B.n) {
+        if (!resampled) {
+            float4 pa = B.poseA[cur][i];
+            pa.w = pa.w / (float) W;
+            B.poseA[cur][i] = pa;
+            ei = EstItem{(double) pa.x, (double) pa.y, pa.w, pa.z, i};
+        } else {
+            const int k = ws.keep[B.slot ^ 1][i];
+            const float4 pa = k >= 0 ? B.poseA[cur][k] : B.poseA[cur ^ 1][i];
+            ei = EstItem{(double) pa.x, (double) pa.y, c->inv_n, pa.z, i};
+        }
+    }
+    ei = block_reduce_est(ei, sh_est);
+    if (threadIdx.x == 0) {
+        double *p = ws.est_part + (size_t) blockIdx.x * 4;
+        p[0] = ei.sx;
+        p[1] = ei.sy;
+        p[2] = (double) ei.th;
+        p[3] = (double) ei.w;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1094,9 +1120,9 @@ static void launch_shard_unpack(hipStream_t st, const Buffers &B, const WeightSc
     hipLaunchKernelGGL(shard_unpack_kernel, dim3(B.ncap / kBlock, gy), dim3(kBlock), 0, st, B, ws, A);
 }
 
-static void launch_shard_finish(hipStream_t st, const Buffers &B, double W, double Q, float neff, int resampled) {
-    if (!resampled) hipLaunchKernelGGL(shard_normalize_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B, W);
-    hipLaunchKernelGGL(shard_commit_kernel, dim3(1), dim3(1), 0, st, B, W, Q, neff, resampled);
+static void launch_shard_finish(hipStream_t st, const Buffers &B, const WeightScratch &ws, double W, double Q, float neff,
+                                int resampled) {
+    hipLaunchKernelGGL(shard_finalize_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B, ws, W, Q, neff, resampled);
 }
 
 static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &PA, const UpdateArgs &U,

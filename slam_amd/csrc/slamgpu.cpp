@@ -94,6 +94,9 @@ struct slamgpu_ctx {
     float copy_split = 0.3f;      // share of a pending lazy gather's copy roles carried by the update launch (measured
                                   // on MI355X at 100 000 particles: 0.0 26.4, 0.3 25.9, 0.5 26.2, 1.0 26.8 us/step)
     bool maybe_pending = false;   // the last update may have left a lazy gather (only the device knows)
+    bool shard_est_fresh = false; // sharded: est_part holds this shard's partials of the last update (shard_finalize_kernel)
+    bool own_totals = true;       // ws.blk_w is this context's allocation (not a caller-provided collective buffer)
+    float *own_blk_w = nullptr;
     bool est_deferred = false;    // est_part holds the partials of the last update, not reduced yet
     double *deferred_hist = nullptr;  // history slot that reduction has to fill (or null)
 };
@@ -390,6 +393,7 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     if (c->B.ctrl) (void) hipFree(c->B.ctrl);
     if (c->ctrl_host) (void) hipHostFree(c->ctrl_host);
     if (c->ws.lcum) (void) hipFree(c->ws.lcum);
+    if (!c->own_totals) c->ws.blk_w = c->own_blk_w;
     if (c->ws.blk_w) (void) hipFree(c->ws.blk_w);
     if (c->ws.est_part) (void) hipFree(c->ws.est_part);
     for (int b = 0; b < 2; b++)
@@ -438,6 +442,7 @@ int slamgpu_predict(slamgpu_ctx *c, float V, float G, const float Q[4], float dt
     s.sinGw = sinf(G / c->cfg.wheel_base);
     s.pad = 0;
     c->est_fresh = false;
+    c->shard_est_fresh = false;
     if (tape_noise) {
         HIP_TRY(hipSetDevice(c->cfg.device));
         HIP_TRY(hipStreamSynchronize(c->stream));  // tape_host is single-buffered (parity mode only)
@@ -468,11 +473,6 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     const bool need_normals = c->cfg.method == SLAMGPU_FASTSLAM2 && (m > 0 || n > 0);
     if (tape && ((need_normals && !normals) || !strata)) return fail(SLAMGPU_ERR_INVALID, "TAPE mode needs normals[3N] and strata[N]");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    if (sharded) {
-        // the sharded pipeline moves particles itself (pack / exchange / unpack): it starts from a plain set
-        if (int rc = materialize(c)) return rc;
-        if (int rc = finish_deferred(c)) return rc;
-    }
     c->obs_step++;
 
     UpdateArgs U{};
@@ -546,11 +546,13 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
 
     const RngArgs rng = rng_args(c, c->obs_step);
     c->B.slot = c->slot;
-    U.lazy = sharded ? 0 : 1;
+    U.lazy = 1;
     // copy roles of a pending lazy gather (one role = 256 particles x 8 landmarks known before this update), split
-    // between this launch and the resample launch so that neither waits for the other's share
-    const int roles = sharded ? 0 : c->ws.nblocks * ((U.nf + 7) / 8);
-    const int roles_k1 = (int) ((double) roles * c->copy_split + 0.5);
+    // between this launch and the resample launch so that neither waits for the other's share.  A sharded update
+    // carries all of them here: its resampling stage is other kernels, and other shards may overwrite nothing of
+    // ours, but this shard's spare buffers are the target of the next unpack
+    const int roles = c->ws.nblocks * ((U.nf + 7) / 8);
+    const int roles_k1 = sharded ? roles : (int) ((double) roles * c->copy_split + 0.5);
     U.copy_lo = 0;
     U.copy_hi = roles_k1;
     U.finalize = (!sharded && c->est_deferred) ? 1 : 0;
@@ -564,6 +566,7 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     if (sharded) {
         // the resampling stage is driven by the caller through slamgpu_shard_* (needs collectives)
         c->est_fresh = false;
+        c->shard_est_fresh = false;
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -618,6 +621,18 @@ int slamgpu_step(slamgpu_ctx *c, const float *controls, int32_t n_controls, cons
     return 0;
 }
 
+int slamgpu_shard_step(slamgpu_ctx *c, const float *controls, int32_t n_controls, const float Q[4], float dt, const float *zf,
+                       const int32_t *idf, int32_t m, const float *zn, int32_t n, const float R[4], const float *normals,
+                       const float *strata) {
+    if (int rc = check_ctx(c)) return rc;
+    if (n_controls < 0 || (n_controls > 0 && !controls)) return fail(SLAMGPU_ERR_INVALID, "bad control list");
+    if (n_controls > 0 && c->cfg.add_predict_noise && c->cfg.rng_mode == SLAMGPU_RNG_TAPE)
+        return fail(SLAMGPU_ERR_INVALID, "slamgpu_shard_step cannot carry TAPE-mode predict noise: call slamgpu_predict per control");
+    for (int k = 0; k < n_controls; k++)
+        if (int rc = slamgpu_predict(c, controls[3 * k], controls[3 * k + 1], Q, dt, controls[3 * k + 2], nullptr)) return rc;
+    return slamgpu_shard_update(c, zf, idf, m, zn, n, R, normals, strata);
+}
+
 // ---- sharded operation -------------------------------------------------------------------------------
 int slamgpu_shard_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n,
                          const float R[4], const float *normals, const float *strata) {
@@ -625,6 +640,18 @@ int slamgpu_shard_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, in
     if (c->cfg.n_particles % kBlock != 0 || c->cfg.first_particle % kBlock != 0)
         return fail(SLAMGPU_ERR_INVALID, "shards must hold a multiple of %d particles", kBlock);
     return do_update(c, zf, idf, m, zn, n, R, normals, strata, true);
+}
+
+int slamgpu_shard_set_totals_buffer(slamgpu_ctx *c, float *totals_dev) {
+    if (int rc = check_ctx(c)) return rc;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->own_totals) c->own_blk_w = c->ws.blk_w;
+    float *p = totals_dev ? totals_dev : c->own_blk_w;
+    c->own_totals = totals_dev == nullptr;
+    c->ws.blk_w = p;
+    c->ws.blk_w2 = p + c->ws.nblocks;
+    return 0;
 }
 
 int slamgpu_shard_block_totals(slamgpu_ctx *c, const float **totals_dev, int32_t *nblocks) {
@@ -736,12 +763,14 @@ int slamgpu_shard_finish(slamgpu_ctx *c, const slamgpu_shard_plan_t *plan) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     {
         Timed t(c, "shard_finish");
-        c->k->shard_finish(c->stream, c->B, plan->wsum, plan->wsq, plan->neff, plan->resampled);
+        c->k->shard_finish(c->stream, c->B, c->ws, plan->wsum, plan->wsq, plan->neff, plan->resampled);
     }
     c->keep_slot = c->slot ^ 1;  // pack / unpack wrote the ancestors there
-    c->slot ^= 1;  // shard_commit_kernel published the (possibly flipped) live buffer in the other slot
+    c->slot ^= 1;  // shard_finalize_kernel published the live / pending state in the other slot
     c->B.slot = c->slot;
+    c->maybe_pending = plan->resampled != 0;
     c->est_fresh = false;
+    c->shard_est_fresh = true;  // est_part holds this shard's partials of this update
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -786,9 +815,13 @@ int slamgpu_shard_estimate_async(slamgpu_ctx *c) {
     if (c->hist_n >= kHistCap) return fail(SLAMGPU_ERR_CAPACITY, "estimate history full (%d)", kHistCap);
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = flush_predict(c)) return rc;
-    if (int rc = materialize(c)) return rc;
-    if (int rc = finish_deferred(c)) return rc;
-    {
+    if (c->shard_est_fresh) {
+        // nothing moved since shard_finalize_kernel left this update's partials: only the one-block reduction
+        Timed t(c, "finish");
+        c->k->finish(c->stream, c->B, c->ws, c->hist_dev + kHistStride * (size_t) c->hist_n);
+    } else {
+        if (int rc = materialize(c)) return rc;
+        if (int rc = finish_deferred(c)) return rc;
         Timed t(c, "estimate");
         c->k->estimate(c->stream, c->B, c->ws, c->hist_dev + kHistStride * (size_t) c->hist_n);
     }
@@ -918,6 +951,10 @@ int slamgpu_ancestors(slamgpu_ctx *c, int32_t *keep) {
         return 0;
     }
     HIP_TRY(hipMemcpy(keep, c->ws.keep[c->keep_slot], sizeof(int32_t) * (size_t) c->B.n, hipMemcpyDeviceToHost));
+    if (c->cfg.n_particles_global != c->cfg.n_particles) {
+        // shard: device entries are local indices (>= 0) or -(global id + 1) for records that came from another shard
+        for (int i = 0; i < c->B.n; i++) keep[i] = keep[i] >= 0 ? (int32_t) (c->cfg.first_particle + keep[i]) : -(keep[i] + 1);
+    }
     return 0;
 }
 
@@ -1025,6 +1062,7 @@ int slamgpu_upload(slamgpu_ctx *c, int32_t nf, const float *xv, const float *Pv9
     }
     c->nf = nf;
     c->est_fresh = false;
+    c->shard_est_fresh = false;
     return 0;
 }
 

@@ -36,7 +36,20 @@ class GpuEngine:
     def local_update(self, zf, idf, zn, R, normals, strata):
         self.ctx.shard_update(zf, idf, zn, R, normals, strata)
 
+    def step_local(self, controls, Q, dt, zf, idf, zn, R, normals, strata):
+        """the queued predicts + the per-particle update in one C-ABI call (slamgpu_shard_step)"""
+        self.ctx.shard_step(controls, Q, dt, zf, idf, zn, R, normals, strata)
+
+    def use_totals_buffer(self, comm, buf):
+        """let the update kernel write the block totals straight into the collective's input buffer"""
+        self.ctx.shard_set_totals_buffer(comm.ptr(buf))
+        self._totals_direct = True
+
     def block_totals_into(self, comm, buf):
+        if getattr(self, "_totals_direct", False):
+            if not getattr(comm, "stream_ordered", False):
+                self.ctx.sync()
+            return
         t, nb = self.ctx.shard_block_totals()
         # a comm whose collectives are ordered on this context's stream needs no host wait here
         self.ctx.dev_copy(comm.ptr(buf), t, 8 * nb, not getattr(comm, "stream_ordered", False))
@@ -197,6 +210,9 @@ class ShardedFilter:
         self.send_cap = [0] * len(engines)
         self.last_plan = None
         self.exchanged_records = 0
+        for i, e in enumerate(engines):
+            if hasattr(e, "use_totals_buffer"):
+                e.use_totals_buffer(c, self.loc[i])
 
     def predict(self, V, G, Q, dt, phi_true=0.0, noise2=None):
         for i, e in enumerate(self.engines):
@@ -214,11 +230,30 @@ class ShardedFilter:
                 self.send[i] = self.comm.alloc(e, int(need * 1.25) + fields)
                 self.send_cap[i] = int(need * 1.25) + fields
 
+    def step(self, controls, Q, dt, zf, idf, zn, R, normals=None, strata=None, record_estimate=True):
+        """One whole filter step: the predicts of `controls` ([k,3]: V, G, phi_true), the update with its global
+        resampling stage and (optionally) the asynchronous pose estimate."""
+        for i, e in enumerate(self.engines):
+            nm = None if normals is None else normals[i]
+            if hasattr(e, "step_local"):
+                e.step_local(controls, Q, dt, zf, idf, zn, R, nm, strata)
+            else:
+                for (V, G, phi) in np.asarray(controls, np.float32).reshape(-1, 3):
+                    e.predict(float(V), float(G), Q, dt, float(phi))
+                e.local_update(zf, idf, zn, R, nm, strata)
+        plan = self._resample_stage()
+        if record_estimate:
+            self.estimate_async()
+        return plan
+
     def update(self, zf, idf, zn, R, normals=None, strata=None):
         """normals: per local shard [n,3] arrays (tape mode) or None; strata: global [N] (tape mode) or None."""
-        E, c = self.engines, self.comm
-        for i, e in enumerate(E):
+        for i, e in enumerate(self.engines):
             e.local_update(zf, idf, zn, R, None if normals is None else normals[i], strata)
+        return self._resample_stage()
+
+    def _resample_stage(self):
+        E, c = self.engines, self.comm
         for i, e in enumerate(E):
             e.block_totals_into(c, self.loc[i])
         c.all_gather(self.loc, 2 * self.nb_local, self.gtot)
