@@ -40,6 +40,10 @@ class GpuEngine:
         """the queued predicts + the per-particle update in one C-ABI call (slamgpu_shard_step)"""
         self.ctx.shard_step(controls, Q, dt, zf, idf, zn, R, normals, strata)
 
+    def prepare_step_local(self, controls, Q, dt, zf, idf, zn, R, normals, strata):
+        """step_local with the arguments marshalled once (SlamGpu.prepare_step): returns a callable"""
+        return self.ctx.prepare_step(controls, Q, dt, zf, idf, zn, R, normals, strata, shard=True)
+
     def use_totals_buffer(self, comm, buf):
         """let the update kernel write the block totals straight into the collective's input buffer"""
         self.ctx.shard_set_totals_buffer(comm.ptr(buf))
@@ -172,7 +176,11 @@ class TorchComm:
         return buf.data_ptr()
 
     def all_gather(self, local_bufs, nfloats_each, global_bufs):
-        self.dist.all_gather_into_tensor(global_bufs[0][: nfloats_each * self.world], local_bufs[0][:nfloats_each])
+        key = (local_bufs[0].data_ptr(), global_bufs[0].data_ptr(), nfloats_each)
+        if getattr(self, "_ag_key", None) != key:  # the step loop gathers the same two buffers every time: keep the views
+            self._ag_key = key
+            self._ag_views = (global_bufs[0][: nfloats_each * self.world], local_bufs[0][:nfloats_each])
+        self.dist.all_gather_into_tensor(*self._ag_views)
 
     def all_to_all(self, send_bufs, send_counts, recv_bufs, recv_counts):
         sc = [int(x) for x in send_counts[0]]
@@ -245,6 +253,31 @@ class ShardedFilter:
         if record_estimate:
             self.estimate_async()
         return plan
+
+    def prepare_step(self, controls, Q, dt, zf, idf, zn, R, normals=None, strata=None, record_estimate=True):
+        """step() with the per-shard arguments marshalled once, outside a driver's timed loop; returns a callable that
+        performs the step and returns its plan."""
+        locs = []
+        for i, e in enumerate(self.engines):
+            nm = None if normals is None else normals[i]
+            if hasattr(e, "prepare_step_local"):
+                locs.append(e.prepare_step_local(controls, Q, dt, zf, idf, zn, R, nm, strata))
+            else:
+                locs.append(lambda e=e, nm=nm: (self._predicts(e, controls, Q, dt), e.local_update(zf, idf, zn, R, nm, strata)))
+
+        def call():
+            for f in locs:
+                f()
+            plan = self._resample_stage()
+            if record_estimate:
+                self.estimate_async()
+            return plan
+        return call
+
+    @staticmethod
+    def _predicts(e, controls, Q, dt):
+        for (V, G, phi) in np.asarray(controls, np.float32).reshape(-1, 3):
+            e.predict(float(V), float(G), Q, dt, float(phi))
 
     def update(self, zf, idf, zn, R, normals=None, strata=None):
         """normals: per local shard [n,3] arrays (tape mode) or None; strata: global [N] (tape mode) or None."""
