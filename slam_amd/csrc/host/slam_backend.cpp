@@ -2,7 +2,7 @@
 //   slam-backend -m <map.mat> [-n name] -mode waypoints -method EKF1|FASTSLAM1|FASTSLAM2 [-KEY value ...]
 // (SLAMBackendApplication.cpp:40-89; anything but FASTSLAM1/FASTSLAM2 selects the EKF, :26-29), plus
 //   -rng parity|philox   parity = feed the libc rand() tape in the reference's draw order (default philox)
-//   -math strict|fast    kernel build (default strict)
+//   -math strict|fast    kernel build (default fast; strict replays the reference's float operations one by one)
 //   -log <file.csv>      per control step: iteration, true pose, estimated pose, loop time [us]
 //   -maxsteps <n>        stop after n control steps
 // It restates the wrapper loops (wrappers/fastslam2wrapper.cpp:31-122, fastslam1wrapper.cpp:32-113,
@@ -72,7 +72,7 @@ int main(int argc, char **argv) {
         g.wheel_base = c.WHEELBASE;
         g.sigma_phi = c.sigmaT;
         g.rng_mode = parity ? SLAMGPU_RNG_TAPE : SLAMGPU_RNG_PHILOX;
-        g.math_mode = math == "fast" ? SLAMGPU_MATH_FAST : SLAMGPU_MATH_STRICT;
+        g.math_mode = math == "strict" ? SLAMGPU_MATH_STRICT : SLAMGPU_MATH_FAST;
         g.seed = (uint64_t) c.SWITCH_SEED_RANDOM;
         if (slamgpu_create(&g, &ctx) != 0) {
             fprintf(stderr, "slamgpu_create: %s\n", slamgpu_last_error());
