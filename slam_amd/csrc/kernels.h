@@ -59,7 +59,9 @@ struct Buffers {
 struct ObsPacket {          // big packets live in device memory, uploaded once per update
     int32_t m, n, nf, pad;  // re-observed, new, landmarks before this update
     float R[4];
-    // followed by: int32 idf[m]; float zf[2m]; float zn[2n]   (offsets computed from m, n)
+    // followed by: int32 idf[m]; float zf[2m]; float zn[2n]; uint32 observed[(nf + 31) / 32]
+    // (offsets computed from m, n; `observed` = bitmap of idf over the nf landmarks known before this update, read by
+    //  the copy roles of a pending lazy gather, which must leave the re-observed landmarks to the compute blocks)
 };
 
 struct SmallObs {           // small packets travel in the kernel argument segment

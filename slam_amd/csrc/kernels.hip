@@ -264,9 +264,14 @@ constexpr int kLmkPerBlockY = 8;
 
 SLAM_DEV bool observed_now(const UpdateArgs &U, int j) {
     const int m = U.m;
-    const int32_t *idf = U.big ? reinterpret_cast<const int32_t *>(U.big + 1) : U.small.idf;
+    if (U.big) {
+        // big packets carry a bitmap of the re-observed landmarks behind idf / zf / zn (kernels.h: ObsPacket)
+        const int32_t *idf = reinterpret_cast<const int32_t *>(U.big + 1);
+        const uint32_t *bits = reinterpret_cast<const uint32_t *>(reinterpret_cast<const float *>(idf + m) + 2 * (m + U.n));
+        return (bits[j >> 5] >> (j & 31)) & 1u;
+    }
     bool hit = false;
-    for (int q = 0; q < m; q++) hit |= (idf[q] == j);
+    for (int q = 0; q < m; q++) hit |= (U.small.idf[q] == j);
     return hit;
 }
 

@@ -354,7 +354,7 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     }
     CTX_TRY(hipMalloc((void **) &c->hist_dev, sizeof(double) * kHistStride * (size_t) kHistCap));
     // big-packet ring: header + idf[cap] + zf[2cap] + zn[2cap]
-    c->pkt_bytes = ((sizeof(ObsPacket) + sizeof(int32_t) * cap_nf + sizeof(float) * 4 * cap_nf) + 255) / 256 * 256;
+    c->pkt_bytes = ((sizeof(ObsPacket) + sizeof(int32_t) * cap_nf + sizeof(float) * 4 * cap_nf + sizeof(uint32_t) * ((cap_nf + 31) / 32)) + 255) / 256 * 256;
     CTX_TRY(hipHostMalloc((void **) &c->pkt_host, c->pkt_bytes * kRing, hipHostMallocDefault));
     CTX_TRY(hipMalloc((void **) &c->pkt_dev, c->pkt_bytes * kRing));
     for (int i = 0; i < kRing; i++) CTX_TRY(hipEventCreateWithFlags(&c->pkt_ev[i], hipEventDisableTiming));
@@ -511,7 +511,11 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
             memcpy(hzf, zf, sizeof(float) * 2 * m);
         }
         if (n) memcpy(hzn, zn, sizeof(float) * 2 * n);
-        const size_t used = sizeof(ObsPacket) + sizeof(int32_t) * m + sizeof(float) * 2 * (m + n);
+        uint32_t *hbits = reinterpret_cast<uint32_t *>(hzn + 2 * n);
+        const int nwords = (c->nf + 31) / 32;
+        for (int k = 0; k < nwords; k++) hbits[k] = 0;
+        for (int k = 0; k < m; k++) hbits[idf[k] >> 5] |= 1u << (idf[k] & 31);
+        const size_t used = sizeof(ObsPacket) + sizeof(int32_t) * m + sizeof(float) * 2 * (m + n) + sizeof(uint32_t) * nwords;
         char *pd = c->pkt_dev + (size_t) slot * c->pkt_bytes;
         HIP_TRY(hipMemcpyAsync(pd, ph, used, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipEventRecord(c->pkt_ev[slot], c->stream));

@@ -450,3 +450,46 @@ def test_history_carries_the_resampling_record(sg):
         s.close()
     for a, b in zip(logs[0], logs[1]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+def test_lazy_gather_equals_eager_gather_with_big_packets(sg, tmp_path, math_mode):
+    """The lazy gather (update kernel reading through keep[], copy roles skipping the re-observed landmarks by list or,
+    for packets that live in device memory, by bitmap) must leave exactly the state the eager gather_kernel leaves:
+    run the same Philox-mode steps twice, once reading the state back after every step (forces gather_kernel), once
+    without.  Synthetic 1000-landmark map, MAX_RANGE 20: m and n above and below the 12-entry kernel-argument packet,
+    several hundred landmarks per particle, resampling on most steps."""
+    import os
+    from conftest import DATA
+    from slam_amd import host
+    lm = host.synthetic_landmarks(4321, 1000, -130, 100, -100, 90)
+    _, wp = host.HostSim(sim_args("example_webmap", "FASTSLAM2", 100, 7)).map()
+    mp = str(tmp_path / "syn1000.mat")
+    host.write_map(mp, lm, wp)
+    ini = open(os.path.join(DATA, "example_webmap.ini")).read().replace("MAX_RANGE           = 60.0", "MAX_RANGE           = 20.0")
+    open(str(tmp_path / "syn1000.ini"), "w").write(ini)
+    N = 1024
+    tape = host.make_tape(["-m", mp, "-method", "FASTSLAM2", "-NPARTICLES", N, "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", 3], max_obs=60)
+    ms = [st["zf"].shape[0] for st in tape["steps"]]
+    ns = [st["zn"].shape[0] for st in tape["steps"]]
+    assert max(ms) > 12 and min(ms) <= 12 and max(ns) > 8
+    out = []
+    for eager in (True, False):
+        s = sg.SlamGpu(N, tape["nlm"], method=2, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=5, math_mode=math_mode)
+        nres = 0
+        for st in tape["steps"]:
+            s.step(np.array(st["controls"], f32).reshape(-1, 3), tape["Q"], float(tape["dt"]), st["zf"], st["idf"], st["zn"], tape["R"])
+            if eager:
+                s.download(landmarks=False)
+                nres += int(s.stats()[1])
+        if eager:
+            assert nres >= 5
+        out.append((s.download(), s.estimate_fetch()))
+        s.close()
+    (a, ea), (b, eb) = out
+    assert a["nf"] == b["nf"] and a["nf"] > 40
+    finite = np.isfinite(a["w"])
+    assert np.array_equal(finite, np.isfinite(b["w"]))
+    for key in ("xv", "Pv", "w", "xf", "Pf"):
+        assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), key
+    assert np.array_equal(ea, eb, equal_nan=True)
