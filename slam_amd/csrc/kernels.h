@@ -34,8 +34,6 @@ struct Ctrl {
     int32_t live[2];      // live buffer (0/1), per slot
     int32_t pend[2];      // lazy gather pending, per slot
     int32_t resampled;    // 1 if the last update resampled
-    uint32_t done;        // block-arrival counter (last block flips cur / finishes the estimate)
-    uint32_t est_done;    // same, for the stand-alone estimate kernel
     float neff;           // Neff of the last update
     float inv_n;          // 1/N_global
     double wsum;          // sum of raw weights (global)

@@ -772,14 +772,15 @@ SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const f
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K3: resampleParticles (core.cpp:718-749) + the per-step pose estimate (ParticleSLAMWrapper.cpp:56-77).
-// Every block redundantly scans the block totals (LDS, double) => sum w, sum w^2, Neff and the decision
-// `doResample && Neff < nMin` without a separate launch or a host round trip.
+// K2: resampleParticles (core.cpp:718-749), planning only, + the per-step pose estimate
+// (ParticleSLAMWrapper.cpp:56-77).  Every planning block redundantly scans the block totals (LDS, double) => sum w,
+// sum w^2, Neff and the decision `doResample && Neff < nMin` without a separate launch or a host round trip.
 //   no resample: w_i /= sum(w) (core.cpp:726-729)
-//   resample   : ancestor of output k = min{ i : select_k < cumsum_i } (core.cpp:800-806) by a two-level
-//                binary search (block offsets in LDS, in-block prefix in HBM), gather-copy of the whole
-//                particle from the live buffers into the other set, w = 1/N (:744-747); blockIdx.y splits
-//                the landmarks.  The last block to finish reduces the estimate partials and flips Ctrl.cur.
+//   resample   : ancestor of output k = min{ i : select_k < cumsum_i } (core.cpp:800-806) by a two-level binary
+//                search (block offsets in LDS, in-block prefix in HBM) into keep[slot ^ 1]; NOTHING is moved here: the
+//                copy of core.cpp:738-747 is the lazy gather of the next update launch (w = 1/N is applied there).
+// Blocks beyond the planning blocks carry the second share of the copy roles of the gather that THIS step's update
+// launch started (copy_unobserved), so that HBM is busy while the planning blocks chase dependent loads.
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScratch ws, RngArgs rng, ResampleArgs ra,
                                                            UpdateArgs U) {
