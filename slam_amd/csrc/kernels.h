@@ -14,6 +14,15 @@ namespace slamgpu {
 //   poseC : float2[Ncap]          p21, p22                                      (40 B per particle)
 //   lmkA  : float4[cap_nf][Ncap]  xf.x, xf.y, Pf p00, p10
 //   lmkB  : float [cap_nf][Ncap]  Pf p11                                         (20 B per landmark)
+//   idxQ  : int4  [cap_nf/4][Ncap] landmark genealogy: WHICH SLOT of row j holds particle k's landmark j
+//                                  (4 landmarks per 16-B chunk)                   (4 B per landmark)
+// Landmark records are not moved when the particle set is resampled: only the slot indices are (idxQ, 4 B instead of
+// 20 B per landmark), so offspring share their ancestor's records until the landmark is observed again.  Every
+// particle re-observes the same landmarks in a step (the association is per step, not per particle), so that step
+// writes a fresh record for every particle into the row's OTHER buffer at the particle's own slot, sets the index to
+// "own slot" and flips the row's live flag (lmk_live[j], uniform for all particles) -- nothing a sibling still reads is
+// ever overwritten.  Composition of non-decreasing ancestor maps is non-decreasing, so reads through idxQ coalesce
+// like the plain gather did.
 // Two copies of everything (ping-pong for the resampling gather).  Which one is live, and whether the live set
 // still has to be read through the ancestor list of the last resample, is device-resident state (Ctrl.live /
 // Ctrl.pend), so no host round trip is needed to know whether a resample fired.
@@ -47,25 +56,35 @@ struct Buffers {
     float2 *poseC[2];
     float4 *lmkA[2];
     float *lmkB[2];
+    int4 *idxQ[2];        // genealogy chunks; the live one is the pose's (Ctrl.live): both are gathered together
+    int32_t *lmk_live[2]; // [cap_nf] live record buffer of every landmark row, double-buffered by `lslot`: the update
+                          // launch reads lmk_live[lslot] and writes the flags for the next launch into lmk_live[lslot^1]
     Ctrl *ctrl;
     int32_t n;        // local particles
     int32_t ncap;     // row stride (>= n, multiple of 256)
     int32_t cap_nf;
     int32_t slot;     // which Ctrl.live / Ctrl.pend entry this launch reads (host-tracked)
+    int32_t lslot;    // which lmk_live entry this launch reads (host-tracked; flipped after every update launch)
 };
 
 struct ObsPacket {          // big packets live in device memory, uploaded once per update
     int32_t m, n, nf, pad;  // re-observed, new, landmarks before this update
     float R[4];
-    // followed by: int32 idf[m]; float zf[2m]; float zn[2n]; uint32 observed[(nf + 31) / 32]
-    // (offsets computed from m, n; `observed` = bitmap of idf over the nf landmarks known before this update, read by
-    //  the copy roles of a pending lazy gather, which must leave the re-observed landmarks to the compute blocks)
+    // followed by: int32 idf[m]; float zf[2m]; float zn[2n]; uint32 touched[(nf + n + 31) / 32]
+    // (offsets computed from m, n; `touched` = bitmap over the nf + n landmarks after this update of the ones it
+    //  writes: the re-observed and the new.  A genealogy chunk (4 landmarks) with a non-zero nibble belongs to the
+    //  compute blocks; the copy roles of a pending lazy gather compose the others.)
 };
+
+constexpr int kSmallChunks = 2 * kSmallObs;  // distinct genealogy chunks a small packet can touch (m + n <= 24 landmarks)
 
 struct SmallObs {           // small packets travel in the kernel argument segment
     int32_t idf[kSmallObs];
     float zf[2 * kSmallObs];
     float zn[2 * kSmallObs];
+    int32_t nchunks;                 // genealogy chunks this update writes (re-observed or new landmarks), ascending
+    int32_t chunk_id[kSmallChunks];
+    int32_t chunk_mask[kSmallChunks];  // bit q set: landmark 4*chunk_id + q is re-observed or new
 };
 
 struct RngArgs {
@@ -115,7 +134,7 @@ struct UpdateArgs {
     const ObsPacket *big;    // null => use `small`
     SmallObs small;
     int32_t lazy;            // 1: single-context pipeline (honour Ctrl.pend, launch the copy + finalise blocks)
-    int32_t copy_lo, copy_hi;  // copy roles (particle tile x 8 landmarks) of a pending lazy gather this launch carries
+    int32_t copy_lo, copy_hi;  // copy roles (particle tile x 8 genealogy chunks) of a pending lazy gather this launch carries
     int32_t finalize;        // 1: the extra block reduces the previous update's pose-estimate partials
     double *finalize_hist;   // history slot of that estimate (kHistStride doubles) or null
 };
@@ -180,6 +199,10 @@ struct KernelTable {
                      const UpdateArgs &);
     // materialise a pending lazy gather (needed before anything but the next update touches the particle set)
     void (*gather)(hipStream_t, const Buffers &, const WeightScratch &, int nf);
+    // rewrite every landmark record into its particle's own slot (genealogy -> identity): download, sharded arrivals
+    void (*flatten)(hipStream_t, const Buffers &, int nf);
+    // identity genealogy ("every landmark in its particle's own slot") in idxQ[which]
+    void (*identity)(hipStream_t, const Buffers &, int which);
     // reduce the estimate partials of the last update now (-> Ctrl.est, history slot)
     void (*finish)(hipStream_t, const Buffers &, const WeightScratch &, double *hist);
     void (*predict)(hipStream_t, const Buffers &, const PredictArgs &, const RngArgs &);

@@ -254,63 +254,55 @@ SLAM_DEV void finish_estimate(const Buffers &B, const WeightScratch &ws, double 
 
 // ---------------------------------------------------------------------------------------------------
 // Lazy gather, copy role: after a resample nothing is moved until the next update kernel, whose compute blocks
-// read their particle through keep[] and write it (pose, re-observed and new landmarks) into the other buffer
-// set; these blocks move the landmarks that update does NOT touch, 8 landmarks x 256 particles per block, all
-// loads of a trip in flight before the first store.  They run beside the compute blocks, whose waves spend most
-// of their time waiting on dependent loads, so the copy (HBM-bound) hides the update (latency-bound) and
-// vice versa.
+// read their particle's pose and genealogy through keep[] and write them to the other buffer set; these blocks
+// compose the genealogy chunks that update does NOT write (idxQ_out[c][k] = idxQ[c][keep[k]]; 16 B per 4 landmarks
+// -- the 20-byte landmark records themselves stay where they are, kernels.h), 8 chunks x 256 particles per block,
+// all loads in flight before the first store.  They run beside the compute blocks / the planning blocks, whose waves
+// spend most of their time waiting on dependent loads.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kLmkPerBlockY = 8;
+constexpr int kLmkPerBlockY = 8;    // landmark rows per block in the kernels that move records (flatten, pack, unpack)
+constexpr int kChunksPerRole = 8;   // genealogy chunks (4 landmarks each) per copy role
 
-SLAM_DEV bool observed_now(const UpdateArgs &U, int j) {
-    const int m = U.m;
-    if (U.big) {
-        // big packets carry a bitmap of the re-observed landmarks behind idf / zf / zn (kernels.h: ObsPacket)
-        const int32_t *idf = reinterpret_cast<const int32_t *>(U.big + 1);
-        const uint32_t *bits = reinterpret_cast<const uint32_t *>(reinterpret_cast<const float *>(idf + m) + 2 * (m + U.n));
-        return (bits[j >> 5] >> (j & 31)) & 1u;
-    }
+// bitmap over the nf + n landmarks after this update of the ones it writes (big packets only, kernels.h: ObsPacket)
+SLAM_DEV const uint32_t *touched_bitmap(const UpdateArgs &U) {
+    const int32_t *idf = reinterpret_cast<const int32_t *>(U.big + 1);
+    return reinterpret_cast<const uint32_t *>(reinterpret_cast<const float *>(idf + U.m) + 2 * (U.m + U.n));
+}
+
+// does this update write a landmark of genealogy chunk c?  (uniform: scalar work)
+SLAM_DEV bool chunk_touched(const UpdateArgs &U, int c) {
+    if (U.big) return ((touched_bitmap(U)[c >> 3] >> ((c & 7) * 4)) & 0xFu) != 0;
     bool hit = false;
-    for (int q = 0; q < m; q++) hit |= (U.small.idf[q] == j);
+    for (int t = 0; t < U.small.nchunks; t++) hit |= (U.small.chunk_id[t] == c);
     return hit;
 }
 
-SLAM_DEV void copy_unobserved(const Buffers &B, const UpdateArgs &U, const WeightScratch &ws, int cur, int role) {
+SLAM_DEV void copy_genealogy(const Buffers &B, const UpdateArgs &U, const WeightScratch &ws, int cur, int role) {
     const int bx = role % ws.nblocks, by = role / ws.nblocks;
     const int k = bx * kBlock + threadIdx.x;
     if (k >= B.n) return;
     const size_t S = (size_t) B.ncap;
     const int anc = ws.keep[B.slot][k];
-    if (anc < 0) return;  // sharded runs: this record arrived from another shard and is already in place
-    const float4 *__restrict__ sA = cur ? B.lmkA[1] : B.lmkA[0];
-    const float *__restrict__ sB = cur ? B.lmkB[1] : B.lmkB[0];
-    float4 *__restrict__ dA = cur ? B.lmkA[0] : B.lmkA[1];
-    float *__restrict__ dB = cur ? B.lmkB[0] : B.lmkB[1];
-    const int j0 = by * kLmkPerBlockY, j1 = min(U.nf, j0 + kLmkPerBlockY);
-    for (int j = j0; j < j1; j += 4) {
-        const int c1 = min(j + 1, j1 - 1), c2 = min(j + 2, j1 - 1), c3 = min(j + 3, j1 - 1);
-        const float4 a0 = sA[(size_t) j * S + anc], a1 = sA[(size_t) c1 * S + anc];
-        const float4 a2 = sA[(size_t) c2 * S + anc], a3 = sA[(size_t) c3 * S + anc];
-        const float e0 = sB[(size_t) j * S + anc], e1 = sB[(size_t) c1 * S + anc];
-        const float e2 = sB[(size_t) c2 * S + anc], e3 = sB[(size_t) c3 * S + anc];
-        // the compute blocks own the re-observed landmarks (uniform test: scalar compares)
-        if (!observed_now(U, j)) {
-            dA[(size_t) j * S + k] = a0;
-            dB[(size_t) j * S + k] = e0;
-        }
-        if (c1 > j && !observed_now(U, c1)) {
-            dA[(size_t) c1 * S + k] = a1;
-            dB[(size_t) c1 * S + k] = e1;
-        }
-        if (c2 > c1 && !observed_now(U, c2)) {
-            dA[(size_t) c2 * S + k] = a2;
-            dB[(size_t) c2 * S + k] = e2;
-        }
-        if (c3 > c2 && !observed_now(U, c3)) {
-            dA[(size_t) c3 * S + k] = a3;
-            dB[(size_t) c3 * S + k] = e3;
-        }
-    }
+    const int4 *__restrict__ src = cur ? B.idxQ[1] : B.idxQ[0];
+    int4 *__restrict__ dst = cur ? B.idxQ[0] : B.idxQ[1];
+    const int c0 = by * kChunksPerRole, c1 = min((U.nf + 3) >> 2, c0 + kChunksPerRole);
+    int4 q[kChunksPerRole];
+#pragma unroll
+    for (int t = 0; t < kChunksPerRole; t++) q[t] = src[(size_t) min(c0 + t, max(c1 - 1, c0)) * S + anc];
+#pragma unroll
+    for (int t = 0; t < kChunksPerRole; t++)
+        if (c0 + t < c1 && !chunk_touched(U, c0 + t)) dst[(size_t) (c0 + t) * S + k] = q[t];  // the compute blocks own the rest
+}
+
+// Helper block of the update launch: the live flags of the landmark rows for the NEXT launch (lmk_live[lslot ^ 1]):
+// a re-observed row flips (every particle has just written its record into the row's other buffer), all others carry.
+SLAM_DEV void advance_live_flags(const Buffers &B, const UpdateArgs &U) {
+    const int32_t *__restrict__ cur = B.lslot ? B.lmk_live[1] : B.lmk_live[0];
+    int32_t *__restrict__ nxt = B.lslot ? B.lmk_live[0] : B.lmk_live[1];
+    const int32_t *idf = U.big ? reinterpret_cast<const int32_t *>(U.big + 1) : U.small.idf;
+    for (int j = threadIdx.x; j < B.cap_nf; j += kBlock) nxt[j] = cur[j];
+    __syncthreads();
+    for (int q = threadIdx.x; q < U.m; q += kBlock) nxt[idf[q]] = cur[idf[q]] ^ 1;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -343,18 +335,17 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             // pose estimate of the PREVIOUS update: its partials were left by resample_kernel, the kernel boundary
             // makes them visible, and this block runs beside the compute blocks instead of as a launch of its own
             __shared__ EstItem sh_est[kBlock / kWave];
+            advance_live_flags(B, U);
             if (U.finalize) finish_estimate(B, ws, U.finalize_hist, sh_est);
             return;
         }
-        if (pend) copy_unobserved(B, U, ws, cur, U.copy_lo + (int) blockIdx.x - ws.nblocks);
+        if (pend) copy_genealogy(B, U, ws, cur, U.copy_lo + (int) blockIdx.x - ws.nblocks);
         return;
     }
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     // select (not index) the buffers: an indexed read of the pointer table in the kernel-argument segment
     // would be one more dependent scalar load at the head of every wave
-    float4 *__restrict__ lmkAo = out ? B.lmkA[1] : B.lmkA[0];
-    float *__restrict__ lmkBo = out ? B.lmkB[1] : B.lmkB[0];
     float4 *__restrict__ poseAo = out ? B.poseA[1] : B.poseA[0];
     float4 *__restrict__ poseBo = out ? B.poseB[1] : B.poseB[0];
     float2 *__restrict__ poseCo = out ? B.poseC[1] : B.poseC[0];
@@ -363,24 +354,35 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     float w = 0.0f;
 
     if (active) {
-        // where this particle's state is read from: slot i of the live buffers; or, with a gather pending, slot
-        // keep[i] of the live buffers; or (sharded runs) slot i of the OUTPUT buffers when keep[i] < 0: the record
-        // came from another shard and shard_unpack_kernel has already put it in place
-        int si = i;
-        bool in_place = !pend;
-        if (pend) {
-            si = ws.keep[B.slot][i];
-            if (si < 0) {
-                si = i;
-                in_place = true;
-            }
-        }
-        const int sb = in_place ? out : cur;
-        const float4 *__restrict__ lmkA = sb ? B.lmkA[1] : B.lmkA[0];
-        const float *__restrict__ lmkB = sb ? B.lmkB[1] : B.lmkB[0];
-        const float4 *__restrict__ poseA = sb ? B.poseA[1] : B.poseA[0];
-        const float4 *__restrict__ poseB = sb ? B.poseB[1] : B.poseB[0];
-        const float2 *__restrict__ poseC = sb ? B.poseC[1] : B.poseC[0];
+        // where this particle's pose and genealogy are read from: slot i of the live buffers, or, with a gather
+        // pending, slot keep[i]
+        const int si = pend ? ws.keep[B.slot][i] : i;
+        const float4 *__restrict__ poseA = cur ? B.poseA[1] : B.poseA[0];
+        const float4 *__restrict__ poseB = cur ? B.poseB[1] : B.poseB[0];
+        const float2 *__restrict__ poseC = cur ? B.poseC[1] : B.poseC[0];
+        const int4 *__restrict__ idxS = cur ? B.idxQ[1] : B.idxQ[0];
+        int4 *__restrict__ idxO = out ? B.idxQ[1] : B.idxQ[0];
+        const int32_t *__restrict__ live = B.lslot ? B.lmk_live[1] : B.lmk_live[0];
+        // landmark j of this particle: the slot comes from the genealogy, the buffer from the row's live flag; a landmark
+        // this update writes goes to the particle's OWN slot of the row's other buffer (kernels.h: idxQ)
+        auto slot_of = [&](int j) -> int {
+            return reinterpret_cast<const int *>(idxS + (size_t) (j >> 2) * S + si)[j & 3];
+        };
+        auto load_lmk = [&](int j, int s, float4 &la, float &lb) {
+            const int b = live[j];
+            la = (b ? B.lmkA[1] : B.lmkA[0])[(size_t) j * S + s];
+            lb = (b ? B.lmkB[1] : B.lmkB[0])[(size_t) j * S + s];
+        };
+        auto store_lmk = [&](int j, const float4 &la, float lb) {
+            const int b = live[j];
+            (b ? B.lmkA[0] : B.lmkA[1])[(size_t) j * S + i] = la;
+            (b ? B.lmkB[0] : B.lmkB[1])[(size_t) j * S + i] = lb;
+        };
+        auto store_new = [&](int j, const float4 &la, float lb) {  // a new row keeps its flag: first record, live buffer
+            const int b = live[j];
+            (b ? B.lmkA[1] : B.lmkA[0])[(size_t) j * S + i] = la;
+            (b ? B.lmkB[1] : B.lmkB[0])[(size_t) j * S + i] = lb;
+        };
         const int32_t *__restrict__ idf;
         const float *__restrict__ zf, *__restrict__ zn;
         if (U.big) {
@@ -442,12 +444,11 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 {
                     float4 ta[kStage];
                     float tb[kStage];
+                    int ts[kStage];
 #pragma unroll
-                    for (int k = 0; k < kStage; k++) {
-                        const size_t li = (size_t) idf[min(k, m - 1)] * S + si;
-                        ta[k] = lmkA[li];
-                        tb[k] = lmkB[li];
-                    }
+                    for (int k = 0; k < kStage; k++) ts[k] = slot_of(idf[min(k, m - 1)]);
+#pragma unroll
+                    for (int k = 0; k < kStage; k++) load_lmk(idf[min(k, m - 1)], ts[k], ta[k], tb[k]);
 #pragma unroll
                     for (int k = 0; k < kStage; k++) {
                         shA[k][threadIdx.x] = ta[k];
@@ -461,8 +462,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                         la = shA[k][threadIdx.x];
                         lb = shB[k][threadIdx.x];
                     } else {
-                        la = lmkA[(size_t) idf[k] * S + si];
-                        lb = lmkB[(size_t) idf[k] * S + si];
+                        load_lmk(idf[k], slot_of(idf[k]), la, lb);
                     }
                     const Obs2 o = observe2(x, y, th, la.x, la.y, la.z, la.w, lb, r00, rl, r11);
                     proposal_update(x, y, th, P, o, zf[2 * k] - o.zp0, wrap_pi(zf[2 * k + 1] - o.zp1));
@@ -473,16 +473,18 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 const float ths = ffma(Lp.l22, g2, ffma(Lp.l21, g1, ffma(Lp.l20, g0, th)));
                 float lik = 1.0f;
                 auto second_pass = [&](int k, float4 la, float lb) {
-                    const size_t lo = (size_t) idf[k] * S + i;
                     const Obs2 o = observe2(xs, ys, ths, la.x, la.y, la.z, la.w, lb, r00, rl, r11);
                     lik *= feature_update2(la.x, la.y, la.z, la.w, lb, o, zf[2 * k] - o.zp0, wrap_pi(zf[2 * k + 1] - o.zp1));
-                    lmkAo[lo] = la;
-                    lmkBo[lo] = lb;
+                    store_lmk(idf[k], la, lb);
                 };
                 const int ms = min(m, kStage);
                 for (int k = 0; k < ms; k++) second_pass(k, shA[k][threadIdx.x], shB[k][threadIdx.x]);
-                for (int k = ms; k < m; k++)
-                    second_pass(k, lmkA[(size_t) idf[k] * S + si], lmkB[(size_t) idf[k] * S + si]);
+                for (int k = ms; k < m; k++) {
+                    float4 la;
+                    float lb;
+                    load_lmk(idf[k], slot_of(idf[k]), la, lb);
+                    second_pass(k, la, lb);
+                }
                 // w *= likelihood * prior / proposal (:360-367): one exponential for the ratio of the two Gaussians
                 const float E = gauss3_exponent(L0, x0 - xs, y0 - ys, wrap_pi(th0 - ths)) -
                                 gauss3_exponent(Lp, x - xs, y - ys, wrap_pi(th - ths));
@@ -505,9 +507,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 float4 la;
                 float lb;
                 add_feature_fast(x, y, th, zn[2 * k], zn[2 * k + 1], r00, r01, r10, r11, la.x, la.y, la.z, la.w, lb);
-                const size_t lo = (size_t) (nf + k) * S + i;
-                lmkAo[lo] = la;
-                lmkBo[lo] = lb;
+                store_new(nf + k, la, lb);
             }
         } else
 #endif
@@ -535,12 +535,11 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                     float tb[kStage];
                     // unconditional (index clamped to the last landmark): no branch between the loads, so the
                     // compiler issues all of them before the first s_waitcnt; duplicates are L1 hits
+                    int ts[kStage];
 #pragma unroll
-                    for (int k = 0; k < kStage; k++) {
-                        const size_t li = (size_t) idf[min(k, m - 1)] * S + si;
-                        ta[k] = lmkA[li];
-                        tb[k] = lmkB[li];
-                    }
+                    for (int k = 0; k < kStage; k++) ts[k] = slot_of(idf[min(k, m - 1)]);
+#pragma unroll
+                    for (int k = 0; k < kStage; k++) load_lmk(idf[min(k, m - 1)], ts[k], ta[k], tb[k]);
 #pragma unroll
                     for (int k = 0; k < kStage; k++) {
                         shA[k][threadIdx.x] = ta[k];
@@ -554,8 +553,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                         la = shA[k][threadIdx.x];
                         lb = shB[k][threadIdx.x];
                     } else {
-                        la = lmkA[(size_t) idf[k] * S + si];
-                        lb = lmkB[(size_t) idf[k] * S + si];
+                        load_lmk(idf[k], slot_of(idf[k]), la, lb);
                     }
                     // Jacobians at the running mean (fastslam2.cpp:320,:348)
                     Jac j = jacobian(x, y, th, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
@@ -601,21 +599,23 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 const float b0 = x - xs, b1 = y - ys, b2 = trig_offset(th - ths);
                 float lik = 1.0f;
                 auto second_pass = [&](int k, float4 la, float lb) {
-                    const size_t lo = (size_t) idf[k] * S + i;
                     Jac j = jacobian(xs, ys, ths, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
                     const float v0 = zf[2 * k] - j.zp0;
                     const float v1 = trig_offset(zf[2 * k + 1] - j.zp1);
                     lik = lik * gauss2(v0, v1, j.s00, j.s10, j.s11);
                     cholesky_update2(la.x, la.y, la.z, la.w, lb, v0, v1, r00, r01, r10, r11, j.hf00, j.hf01, j.hf10, j.hf11);
-                    lmkAo[lo] = la;
-                    lmkBo[lo] = lb;
+                    store_lmk(idf[k], la, lb);
                 };
                 // two loops on purpose: the LDS-fed one issues only stores to HBM, so nothing in it has to wait for a
                 // store to land (a global load after a global store costs an s_waitcnt vmcnt(0) per iteration)
                 const int ms = min(m, kStage);
                 for (int k = 0; k < ms; k++) second_pass(k, shA[k][threadIdx.x], shB[k][threadIdx.x]);
-                for (int k = ms; k < m; k++)
-                    second_pass(k, lmkA[(size_t) idf[k] * S + si], lmkB[(size_t) idf[k] * S + si]);
+                for (int k = ms; k < m; k++) {
+                    float4 la;
+                    float lb;
+                    load_lmk(idf[k], slot_of(idf[k]), la, lb);
+                    second_pass(k, la, lb);
+                }
                 const float prior = gauss3(a0, a1, a2, q00, q10, q11, q20, q21, q22);
                 const float prop = gauss3(b0, b1, b2, P[0], P[3], P[4], P[6], P[7], P[8]);
                 w = w * lik * prior / prop;
@@ -635,9 +635,9 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             if (m > 0) {
                 float wp = 1.0f;
                 for (int k = 0; k < m; k++) {
-                    const size_t lo = (size_t) idf[k] * S + i;
-                    float4 la = lmkA[(size_t) idf[k] * S + si];
-                    float lb = lmkB[(size_t) idf[k] * S + si];
+                    float4 la;
+                    float lb;
+                    load_lmk(idf[k], slot_of(idf[k]), la, lb);
                     Jac j = jacobian(x, y, th, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
                     const float v0 = zf[2 * k] - j.zp0;
                     const float v1 = trig_offset(zf[2 * k + 1] - j.zp1);
@@ -649,8 +649,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                     const float num = expf(t0 * v0 + t1 * v1);
                     wp = wp * num / den;
                     cholesky_update2(la.x, la.y, la.z, la.w, lb, v0, v1, r00, r01, r10, r11, j.hf00, j.hf01, j.hf10, j.hf11);
-                    lmkAo[lo] = la;
-                    lmkBo[lo] = lb;
+                    store_lmk(idf[k], la, lb);
                 }
                 w = w * wp;
             }
@@ -663,9 +662,27 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             float4 la;
             float lb;
             add_feature(x, y, th, zn[2 * k], zn[2 * k + 1], r00, r01, r10, r11, la.x, la.y, la.z, la.w, lb);
-            const size_t lo = (size_t) (nf + k) * S + i;
-            lmkAo[lo] = la;
-            lmkBo[lo] = lb;
+            store_new(nf + k, la, lb);
+        }
+        // genealogy chunks holding a landmark this update wrote: those entries now say "own slot"; the whole chunk
+        // moves to slot i of the output set here (the copy roles of a pending gather leave these chunks alone)
+        auto compose = [&](int c, int mask) {
+            int4 q = idxS[(size_t) c * S + si];
+            if (mask & 1) q.x = i;
+            if (mask & 2) q.y = i;
+            if (mask & 4) q.z = i;
+            if (mask & 8) q.w = i;
+            idxO[(size_t) c * S + i] = q;
+        };
+        if (U.big) {
+            const uint32_t *bits = touched_bitmap(U);
+            const int nch = (nf + n + 3) >> 2;
+            for (int c = 0; c < nch; c++) {
+                const int mask = (int) ((bits[c >> 3] >> ((c & 7) * 4)) & 0xFu);
+                if (mask) compose(c, mask);
+            }
+        } else {
+            for (int t = 0; t < U.small.nchunks; t++) compose(U.small.chunk_id[t], U.small.chunk_mask[t]);
         }
         poseAo[i] = make_float4(x, y, th, w);
         if (METHOD == 2 && pose_dirty) {
@@ -780,7 +797,7 @@ SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const f
 //                search (block offsets in LDS, in-block prefix in HBM) into keep[slot ^ 1]; NOTHING is moved here: the
 //                copy of core.cpp:738-747 is the lazy gather of the next update launch (w = 1/N is applied there).
 // Blocks beyond the planning blocks carry the second share of the copy roles of the gather that THIS step's update
-// launch started (copy_unobserved), so that HBM is busy while the planning blocks chase dependent loads.
+// launch started (copy_genealogy), so that HBM is busy while the planning blocks chase dependent loads.
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScratch ws, RngArgs rng, ResampleArgs ra,
                                                            UpdateArgs U) {
@@ -793,7 +810,7 @@ __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScrat
     if ((int) blockIdx.x >= nb) {
         // second share of the copy roles of the lazy gather this step's update kernel started: the planning blocks
         // below are a chain of dependent loads (scan, binary search), these keep HBM busy meanwhile
-        if (ctrl->pend[B.slot]) copy_unobserved(B, U, ws, ctrl->live[B.slot], U.copy_lo + (int) blockIdx.x - nb);
+        if (ctrl->pend[B.slot]) copy_genealogy(B, U, ws, ctrl->live[B.slot], U.copy_lo + (int) blockIdx.x - nb);
         return;
     }
     // the buffer the update kernel of this step wrote: the other one if it performed a lazy gather
@@ -847,10 +864,10 @@ __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScrat
     }
 }
 
-// Materialise a pending lazy gather: the whole particle (pose + every landmark) of keep[k] into slot k of the
-// other buffer set, w = 1/N (core.cpp:744-747).  Needed before anything but the next update reads the set
-// (download, stand-alone predict / estimate, sharded operation).  Every launch publishes the resulting state in
-// the other Ctrl slot; the host flips its slot afterwards.
+// Materialise a pending lazy gather: pose and genealogy chunks of keep[k] into slot k of the other buffer set,
+// w = 1/N (core.cpp:744-747); the landmark records stay where they are (kernels.h: idxQ).  Needed before anything
+// but the next update reads the set (download, stand-alone predict / estimate).  Every launch publishes the
+// resulting state in the other Ctrl slot; the host flips its slot afterwards.  blockIdx.y = group of 8 chunks.
 __global__ void __launch_bounds__(kBlock) gather_kernel(Buffers B, WeightScratch ws, int nf) {
     Ctrl *ctrl = B.ctrl;
     const int cur = ctrl->live[B.slot];
@@ -863,7 +880,6 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(Buffers B, WeightScratch
     const int k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= B.n) return;
     const int anc = ws.keep[B.slot][k];
-    if (anc < 0) return;  // sharded runs: arrived from another shard, already in place (pose, landmarks, w = 1/N)
     const size_t S = (size_t) B.ncap;
     if (blockIdx.y == 0) {
         float4 pa = B.poseA[cur][anc];
@@ -872,26 +888,40 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(Buffers B, WeightScratch
         B.poseB[cur ^ 1][k] = B.poseB[cur][anc];
         B.poseC[cur ^ 1][k] = B.poseC[cur][anc];
     }
-    const float4 *__restrict__ sA = B.lmkA[cur];
-    const float *__restrict__ sB = B.lmkB[cur];
-    float4 *__restrict__ dA = B.lmkA[cur ^ 1];
-    float *__restrict__ dB = B.lmkB[cur ^ 1];
+    const int4 *__restrict__ src = B.idxQ[cur];
+    int4 *__restrict__ dst = B.idxQ[cur ^ 1];
+    const int c0 = blockIdx.y * kChunksPerRole, c1 = min((nf + 3) >> 2, c0 + kChunksPerRole);
+    for (int c = c0; c < c1; c++) dst[(size_t) c * S + k] = src[(size_t) c * S + anc];
+}
+
+// Flatten the genealogy: every landmark record into its particle's own slot of the row's other buffer, indices back
+// to "own slot", every row's live flag flipped (published in lmk_live[lslot ^ 1]; the host flips lslot).  Requires a
+// plain set (no pending gather).  Used by download and before records from other shards are put in place.
+// blockIdx.y = group of 8 landmarks = 2 genealogy chunks, owned by this block alone.
+__global__ void __launch_bounds__(kBlock) flatten_kernel(Buffers B, int nf) {
+    const int cur = B.ctrl->live[B.slot];
+    const int32_t *__restrict__ live = B.lslot ? B.lmk_live[1] : B.lmk_live[0];
+    int32_t *__restrict__ nxt = B.lslot ? B.lmk_live[0] : B.lmk_live[1];
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int j = threadIdx.x; j < B.cap_nf; j += kBlock) nxt[j] = j < nf ? live[j] ^ 1 : live[j];
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= B.n) return;
+    const size_t S = (size_t) B.ncap;
+    int4 *__restrict__ idx = B.idxQ[cur];
     const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(nf, j0 + kLmkPerBlockY);
-    for (int j = j0; j < j1; j += 4) {
-        // four landmarks per trip: issue all the gathers before the first store
-        const int c1 = min(j + 1, j1 - 1), c2 = min(j + 2, j1 - 1), c3 = min(j + 3, j1 - 1);
-        const float4 a0 = sA[(size_t) j * S + anc], a1 = sA[(size_t) c1 * S + anc];
-        const float4 a2 = sA[(size_t) c2 * S + anc], a3 = sA[(size_t) c3 * S + anc];
-        const float e0 = sB[(size_t) j * S + anc], e1 = sB[(size_t) c1 * S + anc];
-        const float e2 = sB[(size_t) c2 * S + anc], e3 = sB[(size_t) c3 * S + anc];
-        dA[(size_t) j * S + k] = a0;
-        dB[(size_t) j * S + k] = e0;
-        dA[(size_t) c1 * S + k] = a1;
-        dB[(size_t) c1 * S + k] = e1;
-        dA[(size_t) c2 * S + k] = a2;
-        dB[(size_t) c2 * S + k] = e2;
-        dA[(size_t) c3 * S + k] = a3;
-        dB[(size_t) c3 * S + k] = e3;
+    for (int c = j0 >> 2; c < ((j1 + 3) >> 2); c++) {
+        const int4 q = idx[(size_t) c * S + k];
+        const int s4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int j = 4 * c + t;
+            if (j < j1) {
+                const int b = live[j];
+                B.lmkA[b ^ 1][(size_t) j * S + k] = B.lmkA[b][(size_t) j * S + s4[t]];
+                B.lmkB[b ^ 1][(size_t) j * S + k] = B.lmkB[b][(size_t) j * S + s4[t]];
+            }
+        }
+        idx[(size_t) c * S + k] = make_int4(k, k, k, k);
     }
 }
 
@@ -1024,16 +1054,30 @@ __global__ void __launch_bounds__(kBlock) shard_pack_kernel(Buffers B, WeightScr
         dst[7 * cnt] = pc.x; dst[8 * cnt] = pc.y;
         dst[9 * cnt] = __int_as_float((int) ganc);  // ancestor id (keep[]); the weight is reset to 1/N on arrival
     }
+    const int32_t *__restrict__ live = B.lslot ? B.lmk_live[1] : B.lmk_live[0];
     const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(A.nf, j0 + kLmkPerBlockY);
     for (int l = j0; l < j1; l++) {
-        const float4 la = B.lmkA[cur][(size_t) l * S + anc];
-        const float lb = B.lmkB[cur][(size_t) l * S + anc];
+        // the ancestor's record of landmark l: slot from its genealogy, buffer from the row's live flag
+        const int sl = reinterpret_cast<const int *>(B.idxQ[cur] + (size_t) (l >> 2) * S + anc)[l & 3];
+        const int b = live[l];
+        const float4 la = B.lmkA[b][(size_t) l * S + sl];
+        const float lb = B.lmkB[b][(size_t) l * S + sl];
         float *f = dst + (size_t) (10 + 5 * l) * cnt;
         f[0] = la.x; f[cnt] = la.y; f[2 * cnt] = la.z; f[3 * cnt] = la.w; f[4 * cnt] = lb;
     }
 }
 
+// Records from other shards need slots nobody shares, so a step in which any arrive settles the whole shard: every
+// output particle is written physically into the other pose / genealogy buffers and into the other buffer of every
+// landmark row -- local offspring from their ancestor (keep[], through the ancestor's genealogy), arrivals from the
+// receive buffer -- with identity genealogy, and every row's live flag flips (lmk_live[lslot ^ 1]; the host flips
+// lslot).  Steps without arrivals keep the lazy gather.  blockIdx.y = group of 8 landmarks.
 __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightScratch ws, ShardUnpackArgs A) {
+    const int32_t *__restrict__ live = B.lslot ? B.lmk_live[1] : B.lmk_live[0];
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        int32_t *__restrict__ nxt = B.lslot ? B.lmk_live[0] : B.lmk_live[1];
+        for (int j = threadIdx.x; j < B.cap_nf; j += kBlock) nxt[j] = j < A.nf ? live[j] ^ 1 : live[j];
+    }
     const int i = blockIdx.x * kBlock + threadIdx.x;  // local output particle
     if (i >= B.n) return;
     const int cur = B.ctrl->live[B.slot] ^ (B.ctrl->pend[B.slot] ? 1 : 0);  // the buffers this step's update wrote
@@ -1041,7 +1085,28 @@ __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightS
     // source block: the s with src_lo[s] <= i < src_lo[s+1] (local output index boundaries, increasing)
     int s = 0;
     while (s + 1 < A.n_shards && i >= A.src_lo[s + 1]) s++;
-    if (s == A.shard) return;  // local ancestor: recorded in keep[] by this shard's own pack kernel, gathered lazily
+    const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(A.nf, j0 + kLmkPerBlockY);
+    // identity genealogy for the two chunks of this landmark group
+    for (int c = 2 * (int) blockIdx.y; c < min((A.nf + 3) >> 2, 2 * (int) blockIdx.y + 2); c++)
+        B.idxQ[cur ^ 1][(size_t) c * S + i] = make_int4(i, i, i, i);
+    if (s == A.shard) {
+        // local ancestor (recorded in keep[] by this shard's own pack kernel)
+        const int anc = ws.keep[B.slot ^ 1][i];
+        if (blockIdx.y == 0) {
+            float4 pa = B.poseA[cur][anc];
+            pa.w = B.ctrl->inv_n;
+            B.poseA[cur ^ 1][i] = pa;
+            B.poseB[cur ^ 1][i] = B.poseB[cur][anc];
+            B.poseC[cur ^ 1][i] = B.poseC[cur][anc];
+        }
+        for (int l = j0; l < j1; l++) {
+            const int sl = reinterpret_cast<const int *>(B.idxQ[cur] + (size_t) (l >> 2) * S + anc)[l & 3];
+            const int b = live[l];
+            B.lmkA[b ^ 1][(size_t) l * S + i] = B.lmkA[b][(size_t) l * S + sl];
+            B.lmkB[b ^ 1][(size_t) l * S + i] = B.lmkB[b][(size_t) l * S + sl];
+        }
+        return;
+    }
     const int64_t cnt = A.src_lo[s + 1] - A.src_lo[s], slot = i - A.src_lo[s];
     // records before this block in the receive buffer = outputs before it, minus the locally produced ones
     const int64_t own = A.src_lo[A.shard + 1] - A.src_lo[A.shard];
@@ -1051,23 +1116,24 @@ __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightS
         B.poseA[cur ^ 1][i] = make_float4(src[0], src[cnt], src[2 * cnt], B.ctrl->inv_n);
         B.poseB[cur ^ 1][i] = make_float4(src[3 * cnt], src[4 * cnt], src[5 * cnt], src[6 * cnt]);
         B.poseC[cur ^ 1][i] = make_float2(src[7 * cnt], src[8 * cnt]);
-        // negative = "already in place in the output buffers"; the global ancestor id is -(keep + 1)
+        // negative = "came from another shard"; the global ancestor id is -(keep + 1)
         ws.keep[B.slot ^ 1][i] = -(__float_as_int(src[9 * cnt]) + 1);
     }
-    const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(A.nf, j0 + kLmkPerBlockY);
     for (int l = j0; l < j1; l++) {
         const float *f = src + (size_t) (10 + 5 * l) * cnt;
-        B.lmkA[cur ^ 1][(size_t) l * S + i] = make_float4(f[0], f[cnt], f[2 * cnt], f[3 * cnt]);
-        B.lmkB[cur ^ 1][(size_t) l * S + i] = f[4 * cnt];
+        const int b = live[l];
+        B.lmkA[b ^ 1][(size_t) l * S + i] = make_float4(f[0], f[cnt], f[2 * cnt], f[3 * cnt]);
+        B.lmkB[b ^ 1][(size_t) l * S + i] = f[4 * cnt];
     }
 }
 
-// Last stage of a sharded update: normalise (no resample), this shard's pose-estimate partials (through keep[] when
-// the resample left a lazy gather), and the outcome in Ctrl: the set stays in the buffers this step's update wrote;
-// after a resample it is defined through keep[] (local ancestors) / already in place in the other buffers (records
-// that arrived from other shards) until the next update launch, or gather_kernel, moves it.
+// Last stage of a sharded update: normalise (no resample), this shard's pose-estimate partials, and the outcome in
+// Ctrl.  mode 0: no resample, the set stays in the buffers this step's update wrote.  mode 1: resampled, nothing
+// arrived from other shards: the set is defined through keep[] until the next update launch (or gather_kernel) moves
+// it (lazy gather).  mode 2: resampled and settled by shard_unpack_kernel into the other buffers.
 __global__ void __launch_bounds__(kBlock) shard_finalize_kernel(Buffers B, WeightScratch ws, double W, double Q, float neff,
-                                                                 int resampled) {
+                                                                 int mode) {
+    const int resampled = mode != 0;
     __shared__ EstItem sh_est[kBlock / kWave];
     Ctrl *c = B.ctrl;
     const int cur = c->live[B.slot] ^ (c->pend[B.slot] ? 1 : 0);
@@ -1077,8 +1143,8 @@ __global__ void __launch_bounds__(kBlock) shard_finalize_kernel(Buffers B, Weigh
         c->neff = neff;
         c->resampled = resampled;
         // published in the other slot; the host flips its slot after this launch (see Ctrl)
-        c->live[B.slot ^ 1] = cur;
-        c->pend[B.slot ^ 1] = resampled ? 1 : 0;
+        c->live[B.slot ^ 1] = mode == 2 ? cur ^ 1 : cur;
+        c->pend[B.slot ^ 1] = mode == 1 ? 1 : 0;
     }
     const int i = blockIdx.x * kBlock + threadIdx.x;
     EstItem ei{0.0, 0.0, -3.0e38f, 0.0f, 0x7fffffff};
@@ -1089,8 +1155,7 @@ __global__ void __launch_bounds__(kBlock) shard_finalize_kernel(Buffers B, Weigh
             B.poseA[cur][i] = pa;
             ei = EstItem{(double) pa.x, (double) pa.y, pa.w, pa.z, i};
         } else {
-            const int k = ws.keep[B.slot ^ 1][i];
-            const float4 pa = k >= 0 ? B.poseA[cur][k] : B.poseA[cur ^ 1][i];
+            const float4 pa = mode == 2 ? B.poseA[cur ^ 1][i] : B.poseA[cur][ws.keep[B.slot ^ 1][i]];
             ei = EstItem{(double) pa.x, (double) pa.y, c->inv_n, pa.z, i};
         }
     }
@@ -1150,8 +1215,26 @@ static void launch_resample(hipStream_t st, const Buffers &B, const WeightScratc
 }
 
 static void launch_gather(hipStream_t st, const Buffers &B, const WeightScratch &ws, int nf) {
-    const int gy = nf > 0 ? (nf + kLmkPerBlockY - 1) / kLmkPerBlockY : 1;
+    const int nq = (nf + 3) / 4;
+    const int gy = nq > 0 ? (nq + kChunksPerRole - 1) / kChunksPerRole : 1;
     hipLaunchKernelGGL(gather_kernel, dim3(ws.nblocks, gy), dim3(kBlock), 0, st, B, ws, nf);
+}
+
+// identity genealogy in one idxQ buffer (context creation, upload)
+__global__ void __launch_bounds__(kBlock) identity_kernel(int4 *idx, int nq, int ncap) {
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= ncap) return;
+    for (int c = blockIdx.y; c < nq; c += gridDim.y) idx[(size_t) c * ncap + k] = make_int4(k, k, k, k);
+}
+
+static void launch_identity(hipStream_t st, const Buffers &B, int which) {
+    const int nq = (B.cap_nf + 3) / 4;
+    hipLaunchKernelGGL(identity_kernel, dim3(B.ncap / kBlock, nq < 64 ? nq : 64), dim3(kBlock), 0, st, B.idxQ[which], nq, B.ncap);
+}
+
+static void launch_flatten(hipStream_t st, const Buffers &B, int nf) {
+    const int gy = nf > 0 ? (nf + kLmkPerBlockY - 1) / kLmkPerBlockY : 1;
+    hipLaunchKernelGGL(flatten_kernel, dim3(B.ncap / kBlock, gy), dim3(kBlock), 0, st, B, nf);
 }
 
 static void launch_finish(hipStream_t st, const Buffers &B, const WeightScratch &ws, double *hist) {
@@ -1171,7 +1254,7 @@ static void launch_jacobians(hipStream_t st, const float *in, uint32_t n, float 
     hipLaunchKernelGGL(jacobians_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, in, n, out);
 }
 
-static const KernelTable kTable = {launch_update, launch_resample, launch_gather, launch_finish, launch_predict, launch_estimate, launch_jacobians,
+static const KernelTable kTable = {launch_update, launch_resample, launch_gather, launch_flatten, launch_identity, launch_finish, launch_predict, launch_estimate, launch_jacobians,
                                    launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish};
 
 }  // namespace SLAM_KNS

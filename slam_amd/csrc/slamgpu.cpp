@@ -89,6 +89,8 @@ struct slamgpu_ctx {
     ShardPlan *plan_dev = nullptr, *plan_host = nullptr;  // sharded resampling plan (device + pinned mirror)
     // Ctrl.live / Ctrl.pend slot the next launch reads (kernels.h: Ctrl); flipped after every launch that may
     // change the live buffer (resample_kernel, gather_kernel, shard_commit_kernel)
+    int lslot = 0;                // which lmk_live entry the next launch reads (flipped after every update launch, flatten, settle)
+    bool shard_settled = false;   // the sharded resampling stage of this step moved everything physically (records arrived)
     int slot = 0;
     int keep_slot = 0;            // which WeightScratch::keep buffer holds the ancestors of the last update
     float copy_split = 0.3f;      // share of a pending lazy gather's copy roles carried by the update launch (measured
@@ -220,6 +222,23 @@ int materialize(slamgpu_ctx *c) {
     return 0;
 }
 
+// Every landmark record into its particle's own slot (identity genealogy): what download hands out.
+int flatten(slamgpu_ctx *c) {
+    if (int rc = materialize(c)) return rc;
+    if (c->nf == 0) return 0;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    c->B.slot = c->slot;
+    c->B.lslot = c->lslot;
+    {
+        Timed t(c, "flatten");
+        c->k->flatten(c->stream, c->B, c->nf);
+    }
+    HIP_TRY(hipGetLastError());
+    c->lslot ^= 1;
+    c->B.lslot = c->lslot;
+    return 0;
+}
+
 // Reduce the pose-estimate partials of the last update now (normally the next update launch does it on the side).
 int finish_deferred(slamgpu_ctx *c) {
     if (!c->est_deferred) return 0;
@@ -336,7 +355,13 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
         CTX_TRY(hipMemsetAsync(c->B.poseC[b], 0, sizeof(float2) * S, c->stream));
         CTX_TRY(hipMemsetAsync(c->B.lmkA[b], 0, sizeof(float4) * S * cap_nf, c->stream));
         CTX_TRY(hipMemsetAsync(c->B.lmkB[b], 0, sizeof(float) * S * cap_nf, c->stream));
+        CTX_TRY(hipMalloc((void **) &c->B.idxQ[b], sizeof(int4) * S * ((cap_nf + 3) / 4)));
+        CTX_TRY(hipMalloc((void **) &c->B.lmk_live[b], sizeof(int32_t) * cap_nf));
+        CTX_TRY(hipMemsetAsync(c->B.lmk_live[b], 0, sizeof(int32_t) * cap_nf, c->stream));
     }
+    c->B.slot = 0;
+    c->B.lslot = 0;
+    for (int b = 0; b < 2; b++) c->k->identity(c->stream, c->B, b);
     CTX_TRY(hipMalloc((void **) &c->B.ctrl, sizeof(Ctrl)));
     CTX_TRY(hipHostMalloc((void **) &c->ctrl_host, sizeof(Ctrl), hipHostMallocDefault));
     memset(c->ctrl_host, 0, sizeof(Ctrl));
@@ -389,6 +414,8 @@ void slamgpu_destroy(slamgpu_ctx *c) {
         if (c->B.poseC[b]) (void) hipFree(c->B.poseC[b]);
         if (c->B.lmkA[b]) (void) hipFree(c->B.lmkA[b]);
         if (c->B.lmkB[b]) (void) hipFree(c->B.lmkB[b]);
+        if (c->B.idxQ[b]) (void) hipFree(c->B.idxQ[b]);
+        if (c->B.lmk_live[b]) (void) hipFree(c->B.lmk_live[b]);
     }
     if (c->B.ctrl) (void) hipFree(c->B.ctrl);
     if (c->ctrl_host) (void) hipHostFree(c->ctrl_host);
@@ -492,6 +519,16 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
             U.small.zn[2 * k] = zn[2 * k];
             U.small.zn[2 * k + 1] = zn[2 * k + 1];
         }
+        // genealogy chunks (4 landmarks each) this update writes: re-observed and new landmarks, ascending chunk id
+        std::map<int, int> chunks;
+        for (int k = 0; k < m; k++) chunks[idf[k] >> 2] |= 1 << (idf[k] & 3);
+        for (int k = 0; k < n; k++) chunks[(c->nf + k) >> 2] |= 1 << ((c->nf + k) & 3);
+        U.small.nchunks = 0;
+        for (auto &kv : chunks) {
+            U.small.chunk_id[U.small.nchunks] = kv.first;
+            U.small.chunk_mask[U.small.nchunks] = kv.second;
+            U.small.nchunks++;
+        }
         U.big = nullptr;
     } else {
         const int slot = (int) (c->pkt_seq++ % kRing);
@@ -512,9 +549,10 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
         }
         if (n) memcpy(hzn, zn, sizeof(float) * 2 * n);
         uint32_t *hbits = reinterpret_cast<uint32_t *>(hzn + 2 * n);
-        const int nwords = (c->nf + 31) / 32;
+        const int nwords = (c->nf + n + 31) / 32;  // landmarks this update writes: re-observed and new
         for (int k = 0; k < nwords; k++) hbits[k] = 0;
         for (int k = 0; k < m; k++) hbits[idf[k] >> 5] |= 1u << (idf[k] & 31);
+        for (int k = 0; k < n; k++) hbits[(c->nf + k) >> 5] |= 1u << ((c->nf + k) & 31);
         const size_t used = sizeof(ObsPacket) + sizeof(int32_t) * m + sizeof(float) * 2 * (m + n) + sizeof(uint32_t) * nwords;
         char *pd = c->pkt_dev + (size_t) slot * c->pkt_bytes;
         HIP_TRY(hipMemcpyAsync(pd, ph, used, hipMemcpyHostToDevice, c->stream));
@@ -550,12 +588,13 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
 
     const RngArgs rng = rng_args(c, c->obs_step);
     c->B.slot = c->slot;
+    c->B.lslot = c->lslot;
     U.lazy = 1;
     // copy roles of a pending lazy gather (one role = 256 particles x 8 landmarks known before this update), split
     // between this launch and the resample launch so that neither waits for the other's share.  A sharded update
     // carries all of them here: its resampling stage is other kernels, and other shards may overwrite nothing of
     // ours, but this shard's spare buffers are the target of the next unpack
-    const int roles = c->ws.nblocks * ((U.nf + 7) / 8);
+    const int roles = c->ws.nblocks * (((U.nf + 3) / 4 + 7) / 8);  // 8 genealogy chunks (32 landmarks) per role
     const int roles_k1 = sharded ? roles : (int) ((double) roles * c->copy_split + 0.5);
     U.copy_lo = 0;
     U.copy_hi = roles_k1;
@@ -565,6 +604,8 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
         Timed t(c, c->cfg.method == SLAMGPU_FASTSLAM2 ? "fs2_update" : "fs1_update");
         c->k->update(c->stream, c->B, PA, U, rng, c->ws);
     }
+    c->lslot ^= 1;  // the helper block of that launch wrote the landmark rows' live flags for the next launch
+    c->B.lslot = c->lslot;
     if (!sharded) c->est_deferred = false;  // reduced by the helper block of that launch
     c->nf += n;
     if (sharded) {
@@ -724,6 +765,9 @@ int slamgpu_shard_pack(slamgpu_ctx *c, const float *gtot, int32_t nb_global, int
     A.fields = 10 + 5 * c->nf;
     A.shard = shard;
     A.send = send_dev;
+    c->B.slot = c->slot;
+    c->B.lslot = c->lslot;
+    c->shard_settled = false;
     {
         Timed t(c, "shard_pack");
         c->k->shard_pack(c->stream, c->B, c->ws, A, rng_args(c, c->obs_step));
@@ -753,11 +797,17 @@ int slamgpu_shard_unpack(slamgpu_ctx *c, const float *recv_dev, int32_t n_shards
     A.fields = 10 + 5 * c->nf;
     A.shard = shard;
     for (int s = 0; s <= n_shards; s++) A.src_lo[s] = std::min(std::max(plan->K[s] - first, (int64_t) 0), n);
+    c->B.slot = c->slot;
+    c->B.lslot = c->lslot;
     {
         Timed t(c, "shard_unpack");
         c->k->shard_unpack(c->stream, c->B, c->ws, A);
     }
     HIP_TRY(hipGetLastError());
+    // records arrived: the kernel settled the whole shard physically and flipped every landmark row
+    c->shard_settled = true;
+    c->lslot ^= 1;
+    c->B.lslot = c->lslot;
     return 0;
 }
 
@@ -765,14 +815,18 @@ int slamgpu_shard_finish(slamgpu_ctx *c, const slamgpu_shard_plan_t *plan) {
     if (int rc = check_ctx(c)) return rc;
     if (!plan) return fail(SLAMGPU_ERR_INVALID, "null plan");
     HIP_TRY(hipSetDevice(c->cfg.device));
+    const int mode = !plan->resampled ? 0 : (c->shard_settled ? 2 : 1);
+    c->B.slot = c->slot;
+    c->B.lslot = c->lslot;
     {
         Timed t(c, "shard_finish");
-        c->k->shard_finish(c->stream, c->B, c->ws, plan->wsum, plan->wsq, plan->neff, plan->resampled);
+        c->k->shard_finish(c->stream, c->B, c->ws, plan->wsum, plan->wsq, plan->neff, mode);
     }
     c->keep_slot = c->slot ^ 1;  // pack / unpack wrote the ancestors there
     c->slot ^= 1;  // shard_finalize_kernel published the live / pending state in the other slot
     c->B.slot = c->slot;
-    c->maybe_pending = plan->resampled != 0;
+    c->maybe_pending = mode == 1;
+    c->shard_settled = false;
     c->est_fresh = false;
     c->shard_est_fresh = true;  // est_part holds this shard's partials of this update
     HIP_TRY(hipGetLastError());
@@ -975,6 +1029,10 @@ int slamgpu_sync(slamgpu_ctx *c) {
 
 int slamgpu_download(slamgpu_ctx *c, float *xv, float *Pv9, float *w, float *xf, float *Pf4) {
     if (int rc = check_ctx(c)) return rc;
+    if ((xf || Pf4) && c->nf > 0) {
+        if (int rc = flush_predict(c)) return rc;
+        if (int rc = flatten(c)) return rc;  // records into their particles' own slots
+    }
     if (int rc = read_ctrl(c, true)) return rc;
     const int cur = c->ctrl_host->live[c->slot], N = c->B.n, nf = c->nf;
     const size_t S = (size_t) c->B.ncap;
@@ -1001,8 +1059,13 @@ int slamgpu_download(slamgpu_ctx *c, float *xv, float *Pv9, float *w, float *xf,
     if ((xf || Pf4) && nf > 0) {
         std::vector<float4> la(S * nf);
         std::vector<float> lb(S * nf);
-        HIP_TRY(hipMemcpy(la.data(), c->B.lmkA[cur], sizeof(float4) * la.size(), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(lb.data(), c->B.lmkB[cur], sizeof(float) * lb.size(), hipMemcpyDeviceToHost));
+        // every landmark row has its own live buffer (kernels.h: lmk_live)
+        std::vector<int32_t> live(nf);
+        HIP_TRY(hipMemcpy(live.data(), c->B.lmk_live[c->lslot], sizeof(int32_t) * nf, hipMemcpyDeviceToHost));
+        for (int j = 0; j < nf; j++) {
+            HIP_TRY(hipMemcpy(la.data() + (size_t) j * S, c->B.lmkA[live[j]] + (size_t) j * S, sizeof(float4) * S, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(lb.data() + (size_t) j * S, c->B.lmkB[live[j]] + (size_t) j * S, sizeof(float) * S, hipMemcpyDeviceToHost));
+        }
         for (int i = 0; i < N; i++)
             for (int j = 0; j < nf; j++) {
                 const float4 a = la[(size_t) j * S + i];
@@ -1061,9 +1124,15 @@ int slamgpu_upload(slamgpu_ctx *c, int32_t nf, const float *xv, const float *Pv9
                 la[(size_t) j * S + i] = make_float4(xf[((size_t) i * nf + j) * 2], xf[((size_t) i * nf + j) * 2 + 1], P[0], P[2]);
                 lb[(size_t) j * S + i] = P[3];
             }
-        HIP_TRY(hipMemcpy(c->B.lmkA[cur], la.data(), sizeof(float4) * la.size(), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(c->B.lmkB[cur], lb.data(), sizeof(float) * lb.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->B.lmkA[0], la.data(), sizeof(float4) * la.size(), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->B.lmkB[0], lb.data(), sizeof(float) * lb.size(), hipMemcpyHostToDevice));
     }
+    // every landmark row live in buffer 0, every record in its particle's own slot
+    HIP_TRY(hipMemset(c->B.lmk_live[c->lslot], 0, sizeof(int32_t) * c->B.cap_nf));
+    c->B.slot = c->slot;
+    c->B.lslot = c->lslot;
+    c->k->identity(c->stream, c->B, cur);
+    HIP_TRY(hipStreamSynchronize(c->stream));
     c->nf = nf;
     c->est_fresh = false;
     c->shard_est_fresh = false;
