@@ -286,12 +286,17 @@ SLAM_DEV void copy_genealogy(const Buffers &B, const UpdateArgs &U, const Weight
     const int4 *__restrict__ src = cur ? B.idxQ[1] : B.idxQ[0];
     int4 *__restrict__ dst = cur ? B.idxQ[0] : B.idxQ[1];
     const int c0 = by * kChunksPerRole, c1 = min((U.nf + 3) >> 2, c0 + kChunksPerRole);
-    int4 q[kChunksPerRole];
-#pragma unroll
-    for (int t = 0; t < kChunksPerRole; t++) q[t] = src[(size_t) min(c0 + t, max(c1 - 1, c0)) * S + anc];
-#pragma unroll
-    for (int t = 0; t < kChunksPerRole; t++)
-        if (c0 + t < c1 && !chunk_touched(U, c0 + t)) dst[(size_t) (c0 + t) * S + k] = q[t];  // the compute blocks own the rest
+    for (int c = c0; c < c1; c += 4) {
+        // four chunks per trip, all loads in flight before the first store (named registers: an indexed array here
+        // ends up in scratch); the compute blocks own the chunks this update writes
+        const int d1 = min(c + 1, c1 - 1), d2 = min(c + 2, c1 - 1), d3 = min(c + 3, c1 - 1);
+        const int4 q0 = src[(size_t) c * S + anc], q1 = src[(size_t) d1 * S + anc];
+        const int4 q2 = src[(size_t) d2 * S + anc], q3 = src[(size_t) d3 * S + anc];
+        if (!chunk_touched(U, c)) dst[(size_t) c * S + k] = q0;
+        if (d1 > c && !chunk_touched(U, d1)) dst[(size_t) d1 * S + k] = q1;
+        if (d2 > d1 && !chunk_touched(U, d2)) dst[(size_t) d2 * S + k] = q2;
+        if (d3 > d2 && !chunk_touched(U, d3)) dst[(size_t) d3 * S + k] = q3;
+    }
 }
 
 // Helper block of the update launch: the live flags of the landmark rows for the NEXT launch (lmk_live[lslot ^ 1]):
@@ -397,6 +402,13 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         const float r00 = U.R[0], r01 = U.R[1], r10 = U.R[2], r11 = U.R[3];
 
         float4 pa = poseA[si];
+        // the genealogy chunks this update rewrites (small packets: at most a handful) are fetched now, with the pose,
+        // not at the end of the kernel behind one more memory round trip
+        constexpr int kEarly = 8;
+        const int nchs = U.big ? 0 : U.small.nchunks;
+        int4 cq[kEarly];
+#pragma unroll
+        for (int t = 0; t < kEarly; t++) cq[t] = idxS[(size_t) U.small.chunk_id[min(t, max(nchs - 1, 0))] * S + si];
         float x = pa.x, y = pa.y, th = pa.z;
         w = pend ? B.ctrl->inv_n : pa.w;  // resampled particles restart at 1/N (core.cpp:744-747)
         float q00 = 0.f, q10 = 0.f, q11 = 0.f, q20 = 0.f, q21 = 0.f, q22 = 0.f;
@@ -682,7 +694,19 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 if (mask) compose(c, mask);
             }
         } else {
-            for (int t = 0; t < U.small.nchunks; t++) compose(U.small.chunk_id[t], U.small.chunk_mask[t]);
+#pragma unroll
+            for (int t = 0; t < kEarly; t++) {
+                if (t < nchs) {
+                    const int mask = U.small.chunk_mask[t];
+                    int4 q = cq[t];
+                    if (mask & 1) q.x = i;
+                    if (mask & 2) q.y = i;
+                    if (mask & 4) q.z = i;
+                    if (mask & 8) q.w = i;
+                    idxO[(size_t) U.small.chunk_id[t] * S + i] = q;
+                }
+            }
+            for (int t = kEarly; t < nchs; t++) compose(U.small.chunk_id[t], U.small.chunk_mask[t]);
         }
         poseAo[i] = make_float4(x, y, th, w);
         if (METHOD == 2 && pose_dirty) {

@@ -93,8 +93,10 @@ struct slamgpu_ctx {
     bool shard_settled = false;   // the sharded resampling stage of this step moved everything physically (records arrived)
     int slot = 0;
     int keep_slot = 0;            // which WeightScratch::keep buffer holds the ancestors of the last update
-    float copy_split = 0.3f;      // share of a pending lazy gather's copy roles carried by the update launch (measured
-                                  // on MI355X at 100 000 particles: 0.0 26.4, 0.3 25.9, 0.5 26.2, 1.0 26.8 us/step)
+    float copy_split = -1.0f;     // share of a pending lazy gather's copy roles carried by the update launch; < 0: automatic
+                                  // (all of them for maps up to 256 landmarks: measured on MI355X at 100 000 particles,
+                                  // 30 landmarks: 0.0 23.4, 0.3 23.2, 0.6 23.2, 1.0 22.9 us/step; 30 % beyond, where the
+                                  // genealogy copy is long enough to be worth hiding behind the planning blocks too)
     bool maybe_pending = false;   // the last update may have left a lazy gather (only the device knows)
     bool shard_est_fresh = false; // sharded: est_part holds this shard's partials of the last update (shard_finalize_kernel)
     bool own_totals = true;       // ws.blk_w is this context's allocation (not a caller-provided collective buffer)
@@ -595,7 +597,8 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     // carries all of them here: its resampling stage is other kernels, and other shards may overwrite nothing of
     // ours, but this shard's spare buffers are the target of the next unpack
     const int roles = c->ws.nblocks * (((U.nf + 3) / 4 + 7) / 8);  // 8 genealogy chunks (32 landmarks) per role
-    const int roles_k1 = sharded ? roles : (int) ((double) roles * c->copy_split + 0.5);
+    const double split = c->copy_split >= 0.0f ? c->copy_split : (U.nf <= 256 ? 1.0 : 0.3);
+    const int roles_k1 = sharded ? roles : (int) ((double) roles * split + 0.5);
     U.copy_lo = 0;
     U.copy_hi = roles_k1;
     U.finalize = (!sharded && c->est_deferred) ? 1 : 0;
