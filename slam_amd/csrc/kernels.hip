@@ -804,11 +804,23 @@ SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const f
     const int lb = min(max(b0 - first_block, 0), nb_local - 1);
     const double o = off[b0];
     const float *lc = lcum_local + (size_t) lb * kBlock;
-    int l0 = 0, l1 = kBlock - 1;  // first slot with o + lc > target; the last slot if rounding hides it
-    while (l0 < l1) {
-        const int mid = (l0 + l1) >> 1;
-        if (o + (double) lc[mid] > target) l1 = mid; else l0 = mid + 1;
-    }
+    // first slot with o + lc > target; the last slot if rounding hides it.  The prefix is non-decreasing, so instead of
+    // 8 dependent probes: 16 pivots in flight together (every 16th entry), then the 16 entries of the pivot's segment
+    float pv[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) pv[q] = lc[16 * q + 15];
+    int seg = 15;
+#pragma unroll
+    for (int q = 14; q >= 0; q--)
+        if (o + (double) pv[q] > target) seg = q;
+    const float4 *l4 = reinterpret_cast<const float4 *>(lc + 16 * seg);
+    const float4 e0 = l4[0], e1 = l4[1], e2 = l4[2], e3 = l4[3];
+    const float ev[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
+    int r = 15;
+#pragma unroll
+    for (int q = 14; q >= 0; q--)
+        if (o + (double) ev[q] > target) r = q;
+    const int l0 = 16 * seg + r;
     return min((int64_t) b0 * kBlock + l0, n_global - 1);
 }
 
