@@ -95,6 +95,8 @@ struct RngArgs {
     int64_t n_global;
     const float *normals;    // tape: [3][ncap] device (update) or [2][ncap] (predict), component-major
     const float *strata;     // tape: [n_global] device
+    uint32_t prev_step;      // observation-step counter of the PREVIOUS update (its resampling may be planned inline)
+    const float *strata_prev;  // tape: the previous update's strata
 };
 
 struct PredictStep {
@@ -135,15 +137,25 @@ struct UpdateArgs {
     SmallObs small;
     int32_t lazy;            // 1: single-context pipeline (honour Ctrl.pend, launch the copy + finalise blocks)
     int32_t copy_lo, copy_hi;  // copy roles (particle tile x 8 genealogy chunks) of a pending lazy gather this launch carries
+    // Inline planning: the resampling stage of the PREVIOUS update (Neff, decision, ancestors, pose-estimate partials)
+    // has not run as a launch of its own; every block of this launch redoes its scan and every thread finds its own
+    // ancestor, so a step is ONE launch.  0: that stage already ran (resample_kernel), honour Ctrl.pend / keep[].
+    int32_t plan_inline;
+    int32_t do_resample, n_effective;  // SWITCH_RESAMPLE, NEFFECTIVE (for the inline plan)
+    int32_t finalize_par;    // parity of the estimate partials the helper block reduces
     int32_t finalize;        // 1: the extra block reduces the previous update's pose-estimate partials
     double *finalize_hist;   // history slot of that estimate (kHistStride doubles) or null
 };
 
+// The weight scratch is double-buffered by the parity of the observation step (wpar): the update launch of step t
+// writes lcum / blk_w [wpar] while -- when it also plans the resampling of step t-1 inline -- its blocks are still
+// searching lcum / blk_w [wpar ^ 1]; est_part[q] holds the pose-estimate partials of the last step of parity q.
 struct WeightScratch {
-    float *lcum;        // [ncap]    inclusive in-block (256 particles) prefix of the raw weights
-    float *blk_w;       // [nblocks] block totals of w        } one allocation: blk_w2 == blk_w + nblocks, so a
-    float *blk_w2;      // [nblocks] block totals of w^2      } shard's totals travel as one contiguous message
-    double *est_part;   // [nblocks][4] pose-estimate partials (sum x, sum y, heading, max w)
+    float *lcum[2];     // [ncap]    inclusive in-block (256 particles) prefix of the raw weights
+    float *blk_w[2];    // [2*nblocks] block totals of w, then of w^2: one allocation, so a shard's totals travel as one
+                        //           contiguous message ([w(nb) | w2(nb)])
+    double *est_part[2];  // [nblocks][4] pose-estimate partials (sum x, sum y, heading, max w)
+    int32_t wpar;       // parity of the step this launch belongs to
     int32_t *keep[2];   // [ncap] ancestors of the last resample, double-buffered by Buffers::slot: a launch reads the
                         // pending gather through keep[slot] and writes new ancestors into keep[slot ^ 1]
     int32_t nblocks;
@@ -203,8 +215,8 @@ struct KernelTable {
     void (*flatten)(hipStream_t, const Buffers &, int nf);
     // identity genealogy ("every landmark in its particle's own slot") in idxQ[which]
     void (*identity)(hipStream_t, const Buffers &, int which);
-    // reduce the estimate partials of the last update now (-> Ctrl.est, history slot)
-    void (*finish)(hipStream_t, const Buffers &, const WeightScratch &, double *hist);
+    // reduce the estimate partials est_part[par] now (-> Ctrl.est, history slot)
+    void (*finish)(hipStream_t, const Buffers &, const WeightScratch &, double *hist, int par);
     void (*predict)(hipStream_t, const Buffers &, const PredictArgs &, const RngArgs &);
     void (*estimate)(hipStream_t, const Buffers &, const WeightScratch &, double *hist);
     void (*jacobians)(hipStream_t, const float *in_dev, uint32_t n, float *out_dev);

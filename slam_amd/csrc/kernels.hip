@@ -224,10 +224,10 @@ SLAM_DEV EstItem block_reduce_est(EstItem v, EstItem *sh) {
 
 // One block: parallel reduction of the per-block pose-estimate partials (doubles, tree order fixed by the launch
 // geometry) into Ctrl.est and a history slot.
-SLAM_DEV void finish_estimate(const Buffers &B, const WeightScratch &ws, double *hist, EstItem *sh) {
+SLAM_DEV void finish_estimate(const Buffers &B, const WeightScratch &ws, int par, double *hist, EstItem *sh) {
     EstItem v{0.0, 0.0, -3.0e38f, 0.0f, 0x7fffffff};
     for (int b = threadIdx.x; b < ws.nblocks; b += kBlock) {
-        const double *p = ws.est_part + (size_t) b * 4;
+        const double *p = ws.est_part[par] + (size_t) b * 4;
         EstItem o{p[0], p[1], (float) p[3], (float) p[2], b};
         est_combine(v, o);
     }
@@ -244,12 +244,103 @@ SLAM_DEV void finish_estimate(const Buffers &B, const WeightScratch &ws, double 
             hist[1] = v.sy;
             hist[2] = (double) v.th;
             hist[3] = (double) v.w;
-            // the resampling record of the update these partials belong to (its resample_kernel wrote them; the
-            // resample_kernel of the launch this block may be riding in has not run yet)
-            hist[4] = (double) c->neff;
-            hist[5] = (double) c->resampled;
+            // the resampling record of the update these partials belong to: left behind the partials by whoever
+            // planned it (Ctrl.neff may already belong to a later update)
+            hist[4] = ws.est_part[par][4 * (size_t) ws.nblocks];
+            hist[5] = ws.est_part[par][4 * (size_t) ws.nblocks + 1];
         }
     }
+}
+
+// Exclusive prefix (double) of the block totals into LDS `off[0..nb]`, plus sum w and sum w^2.  Every block of
+// every kernel (and every rank of a sharded run, which sees the same all-gathered totals) executes exactly
+// this association, so W, Q, Neff, the resample decision and all ancestors are identical everywhere.
+// Layout of the totals: shard-major records [w(nbl) | w2(nbl)] (what one all-gather of each shard's contiguous
+// [w | w2] block produces): total k of shard k/nbl sits at (k/nbl)*2*nbl + k%nbl, its square sum nbl further.
+SLAM_DEV void scan_block_totals(const float *__restrict__ tot, int nb, int nbl, double *off, double *sh_a, double *sh_q,
+                                double &W, double &Q) {
+    const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
+    const int per = (nb + kBlock - 1) / kBlock;
+    const int lo = min(nb, t * per), hi = min(nb, lo + per);
+    double a = 0.0, q = 0.0;
+    for (int k = lo; k < hi; k++) {
+        const int at = (k / nbl) * 2 * nbl + (k % nbl);
+        a += (double) tot[at];
+        q += (double) tot[at + nbl];
+    }
+    double sa = a;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const double v = __shfl_up(sa, d, kWave);
+        if (lane >= d) sa += v;
+    }
+    double sq = q;
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) sq += __shfl_xor(sq, d, kWave);
+    if (lane == kWave - 1) sh_a[wv] = sa;
+    if (lane == 0) sh_q[wv] = sq;
+    __syncthreads();
+    double base = 0.0;
+#pragma unroll
+    for (int k = 0; k < kBlock / kWave; k++)
+        if (k < wv) base += sh_a[k];
+    double run = base + sa - a;  // exclusive prefix of this thread's segment
+    for (int k = lo; k < hi; k++) {
+        off[k] = run;
+        run += (double) tot[(k / nbl) * 2 * nbl + (k % nbl)];
+    }
+    W = ((sh_a[0] + sh_a[1]) + sh_a[2]) + sh_a[3];
+    Q = ((sh_q[0] + sh_q[1]) + sh_q[2]) + sh_q[3];
+    if (t == 0) off[nb] = W;
+}
+
+// stratum of global output particle gid: the caller's tape, or (gid + u)/N with u from Philox stream 1
+SLAM_DEV float stratum(const RngArgs &rng, int64_t gid) {
+    if (rng.mode == 0) return rng.strata[gid];
+    U4 r = philox4x32((uint32_t) gid, rng.step, 1u, 0u, rng.k0, rng.k1);
+    const double u = ((double) (r.x >> 8) + 0.5) * (1.0 / 16777216.0);
+    return (float) (((double) gid + u) / (double) rng.n_global);
+}
+
+// the same for the PREVIOUS update (inline planning inside the next update launch)
+SLAM_DEV float stratum_prev(const RngArgs &rng, int64_t gid) {
+    if (rng.mode == 0) return rng.strata_prev[gid];
+    U4 r = philox4x32((uint32_t) gid, rng.prev_step, 1u, 0u, rng.k0, rng.k1);
+    const double u = ((double) (r.x >> 8) + 0.5) * (1.0 / 16777216.0);
+    return (float) (((double) gid + u) / (double) rng.n_global);
+}
+
+// ancestor (global particle index) of a stratum: min{ i : target < cumsum_i }, two-level binary search
+SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const float *__restrict__ lcum_local,
+                               int first_block, int nb_local, int64_t n_global) {
+    int b0 = 0, b1 = nb;
+    while (b0 < b1) {
+        const int mid = (b0 + b1) >> 1;
+        if (off[mid + 1] > target) b1 = mid; else b0 = mid + 1;
+    }
+    if (b0 >= nb) return n_global - 1;  // select beyond the last cumulative weight: undefined upstream (keep = -1), clamp
+    // the in-block prefix is only resident for this shard's blocks; callers only ask for strata they own
+    const int lb = min(max(b0 - first_block, 0), nb_local - 1);
+    const double o = off[b0];
+    const float *lc = lcum_local + (size_t) lb * kBlock;
+    // first slot with o + lc > target; the last slot if rounding hides it.  The prefix is non-decreasing, so instead of
+    // 8 dependent probes: 16 pivots in flight together (every 16th entry), then the 16 entries of the pivot's segment
+    float pv[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) pv[q] = lc[16 * q + 15];
+    int seg = 15;
+#pragma unroll
+    for (int q = 14; q >= 0; q--)
+        if (o + (double) pv[q] > target) seg = q;
+    const float4 *l4 = reinterpret_cast<const float4 *>(lc + 16 * seg);
+    const float4 e0 = l4[0], e1 = l4[1], e2 = l4[2], e3 = l4[3];
+    const float ev[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
+    int r = 15;
+#pragma unroll
+    for (int q = 14; q >= 0; q--)
+        if (o + (double) ev[q] > target) r = q;
+    const int l0 = 16 * seg + r;
+    return min((int64_t) b0 * kBlock + l0, n_global - 1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -277,12 +368,13 @@ SLAM_DEV bool chunk_touched(const UpdateArgs &U, int c) {
     return hit;
 }
 
-SLAM_DEV void copy_genealogy(const Buffers &B, const UpdateArgs &U, const WeightScratch &ws, int cur, int role) {
+template <class AncOf>
+SLAM_DEV void copy_genealogy(const Buffers &B, const UpdateArgs &U, const WeightScratch &ws, int cur, int role, AncOf anc_of) {
     const int bx = role % ws.nblocks, by = role / ws.nblocks;
     const int k = bx * kBlock + threadIdx.x;
     if (k >= B.n) return;
     const size_t S = (size_t) B.ncap;
-    const int anc = ws.keep[B.slot][k];
+    const int anc = anc_of(k);
     const int4 *__restrict__ src = cur ? B.idxQ[1] : B.idxQ[0];
     int4 *__restrict__ dst = cur ? B.idxQ[0] : B.idxQ[1];
     const int c0 = by * kChunksPerRole, c1 = min((U.nf + 3) >> 2, c0 + kChunksPerRole);
@@ -328,23 +420,63 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     // (each thread only touches its own column: no barrier, no bank conflict: consecutive lanes, consecutive slots)
     __shared__ float4 shA[METHOD == 2 ? kStage : 1][kBlock];
     __shared__ float shB[METHOD == 2 ? kStage : 1][kBlock];
+    extern __shared__ double off[];  // inline plan: [nblocks + 1] exclusive prefix of the previous step's block totals
+    __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
+    __shared__ EstItem sh_est[kBlock / kWave];
     const size_t S = (size_t) B.ncap;
-    const int cur = B.ctrl->live[B.slot];
-    // lazy gather: the previous update resampled but moved nothing; this launch reads particle keep[i] of the live
-    // buffer and writes particle i of the other one (observed landmarks updated, the rest copied by the copy blocks)
-    const bool pend = U.lazy && B.ctrl->pend[B.slot] != 0;
+    Ctrl *ctrl = B.ctrl;
+    const int cur = ctrl->live[B.slot];
+    const int nb = ws.nblocks;
+    const bool helper = blockIdx.x == gridDim.x - 1 && (int) blockIdx.x >= nb;
+    // Where does particle i of the set this update works on come from?
+    //   plan_inline: the resampling stage of the previous update has not run: every block redoes its scan of the block
+    //                totals (=> sum w, Neff, decision, identical everywhere) and every thread finds its own ancestor
+    //                (core.cpp:718-749, :800-806); no resample: slot i, weight w / sum(w) (core.cpp:726-729);
+    //   otherwise  : resample_kernel ran: slot keep[i] of the live buffers if it left a gather pending, else slot i.
+    // Either way a gathered particle is written to slot i of the OTHER pose / genealogy buffers.
+    bool pend = U.lazy && ctrl->pend[B.slot] != 0;
+    double W = 1.0;
+    if (U.plan_inline && !helper) {
+        double Q;
+        scan_block_totals(ws.blk_w[ws.wpar ^ 1], nb, nb, off, sh_a, sh_q, W, Q);
+        const float neff = (float) ((W * W) / Q);  // Neff = 1 / sum((w/W)^2)  (core.cpp:784-788)
+        pend = U.do_resample && (neff < (float) U.n_effective);
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            ctrl->wsum = W;
+            ctrl->wsq = Q;
+            ctrl->neff = neff;
+            ctrl->resampled = pend ? 1 : 0;
+            ws.est_part[ws.wpar ^ 1][4 * (size_t) nb] = (double) neff;  // travels with the partials into the history
+            ws.est_part[ws.wpar ^ 1][4 * (size_t) nb + 1] = pend ? 1.0 : 0.0;
+        }
+        __syncthreads();
+    }
     const int out = pend ? cur ^ 1 : cur;
-    if ((int) blockIdx.x >= ws.nblocks) {
-        // ---- helper blocks of the single-context pipeline ------------------------------------------------
-        if (blockIdx.x == gridDim.x - 1) {
-            // pose estimate of the PREVIOUS update: its partials were left by resample_kernel, the kernel boundary
-            // makes them visible, and this block runs beside the compute blocks instead of as a launch of its own
-            __shared__ EstItem sh_est[kBlock / kWave];
+    auto ancestor = [&](int k) -> int {
+        if (!U.plan_inline) return ws.keep[B.slot][k];
+        const double target = (double) stratum_prev(rng, (int64_t) k) * W;
+        return (int) min(find_ancestor(target, off, nb, ws.lcum[ws.wpar ^ 1], 0, nb, (int64_t) B.n), (int64_t) B.n - 1);
+    };
+    if ((int) blockIdx.x >= nb) {
+        // ---- helper blocks ---------------------------------------------------------------------------------
+        if (helper) {
+            // the set this launch leaves lives in `out` (published in the other Ctrl slot; the host flips after the
+            // launch), the landmark rows' live flags for the next launch, and the pose estimate of an EARLIER update
+            // whose partials are complete: this block runs beside the compute blocks instead of as launches of its own
+            if (U.plan_inline) {  // the decision is needed for `out`: recompute it from the two totals, cheaply
+                double Q;
+                scan_block_totals(ws.blk_w[ws.wpar ^ 1], nb, nb, off, sh_a, sh_q, W, Q);
+                pend = U.do_resample && ((float) ((W * W) / Q) < (float) U.n_effective);
+            }
+            if (threadIdx.x == 0) {
+                ctrl->live[B.slot ^ 1] = pend ? cur ^ 1 : cur;
+                ctrl->pend[B.slot ^ 1] = 0;
+            }
             advance_live_flags(B, U);
-            if (U.finalize) finish_estimate(B, ws, U.finalize_hist, sh_est);
+            if (U.finalize) finish_estimate(B, ws, U.finalize_par, U.finalize_hist, sh_est);
             return;
         }
-        if (pend) copy_genealogy(B, U, ws, cur, U.copy_lo + (int) blockIdx.x - ws.nblocks);
+        if (pend) copy_genealogy(B, U, ws, cur, U.copy_lo + (int) blockIdx.x - nb, ancestor);
         return;
     }
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -358,10 +490,10 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     const int m = U.m, n = U.n, nf = U.nf;
     float w = 0.0f;
 
+    EstItem ei_prev{0.0, 0.0, -3.0e38f, 0.0f, 0x7fffffff};  // inline plan: this particle's term of the previous step's estimate
     if (active) {
-        // where this particle's pose and genealogy are read from: slot i of the live buffers, or, with a gather
-        // pending, slot keep[i]
-        const int si = pend ? ws.keep[B.slot][i] : i;
+        // where this particle's pose and genealogy are read from: slot i of the live buffers, or its ancestor's slot
+        const int si = pend ? ancestor(i) : i;
         const float4 *__restrict__ poseA = cur ? B.poseA[1] : B.poseA[0];
         const float4 *__restrict__ poseB = cur ? B.poseB[1] : B.poseB[0];
         const float2 *__restrict__ poseC = cur ? B.poseC[1] : B.poseC[0];
@@ -410,7 +542,11 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
 #pragma unroll
         for (int t = 0; t < kEarly; t++) cq[t] = idxS[(size_t) U.small.chunk_id[min(t, max(nchs - 1, 0))] * S + si];
         float x = pa.x, y = pa.y, th = pa.z;
-        w = pend ? B.ctrl->inv_n : pa.w;  // resampled particles restart at 1/N (core.cpp:744-747)
+        // resampled particles restart at 1/N (core.cpp:744-747); otherwise the weights are normalised (core.cpp:726-729;
+        // resample_kernel has already done it unless this launch plans inline)
+        w = pend ? ctrl->inv_n : (U.plan_inline ? pa.w / (float) W : pa.w);
+        // computeEstimatedPosition of the previous update (ParticleSLAMWrapper.cpp:56-77) sees exactly this set
+        ei_prev = EstItem{(double) pa.x, (double) pa.y, w, pa.z, i};
         float q00 = 0.f, q10 = 0.f, q11 = 0.f, q20 = 0.f, q21 = 0.f, q22 = 0.f;
         bool pose_dirty = pend;
         if (METHOD == 2) {
@@ -715,6 +851,16 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         }
     }
 
+    if (U.plan_inline) {
+        ei_prev = block_reduce_est(ei_prev, sh_est);
+        if (threadIdx.x == 0) {
+            double *p = ws.est_part[ws.wpar ^ 1] + (size_t) blockIdx.x * 4;
+            p[0] = ei_prev.sx;
+            p[1] = ei_prev.sy;
+            p[2] = (double) ei_prev.th;
+            p[3] = (double) ei_prev.w;
+        }
+    }
     // in-block inclusive prefix of w; block totals of w and w^2 (fixed association: deterministic)
     float s = w;
 #pragma unroll
@@ -734,94 +880,11 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
 #pragma unroll
     for (int k = 0; k < kBlock / kWave; k++)
         if (k < wv) base += sh_w[k];
-    ws.lcum[i] = base + s;
+    ws.lcum[ws.wpar][i] = base + s;
     if (threadIdx.x == kBlock - 1) {
-        ws.blk_w[blockIdx.x] = base + s;
-        ws.blk_w2[blockIdx.x] = ((sh_w2[0] + sh_w2[1]) + sh_w2[2]) + sh_w2[3];
+        ws.blk_w[ws.wpar][blockIdx.x] = base + s;
+        ws.blk_w[ws.wpar][ws.nblocks + blockIdx.x] = ((sh_w2[0] + sh_w2[1]) + sh_w2[2]) + sh_w2[3];
     }
-}
-
-// Exclusive prefix (double) of the block totals into LDS `off[0..nb]`, plus sum w and sum w^2.  Every block of
-// every kernel (and every rank of a sharded run, which sees the same all-gathered totals) executes exactly
-// this association, so W, Q, Neff, the resample decision and all ancestors are identical everywhere.
-// Layout of the totals: shard-major records [w(nbl) | w2(nbl)] (what one all-gather of each shard's contiguous
-// [w | w2] block produces): total k of shard k/nbl sits at (k/nbl)*2*nbl + k%nbl, its square sum nbl further.
-SLAM_DEV void scan_block_totals(const float *__restrict__ tot, int nb, int nbl, double *off, double *sh_a, double *sh_q,
-                                double &W, double &Q) {
-    const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
-    const int per = (nb + kBlock - 1) / kBlock;
-    const int lo = min(nb, t * per), hi = min(nb, lo + per);
-    double a = 0.0, q = 0.0;
-    for (int k = lo; k < hi; k++) {
-        const int at = (k / nbl) * 2 * nbl + (k % nbl);
-        a += (double) tot[at];
-        q += (double) tot[at + nbl];
-    }
-    double sa = a;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const double v = __shfl_up(sa, d, kWave);
-        if (lane >= d) sa += v;
-    }
-    double sq = q;
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) sq += __shfl_xor(sq, d, kWave);
-    if (lane == kWave - 1) sh_a[wv] = sa;
-    if (lane == 0) sh_q[wv] = sq;
-    __syncthreads();
-    double base = 0.0;
-#pragma unroll
-    for (int k = 0; k < kBlock / kWave; k++)
-        if (k < wv) base += sh_a[k];
-    double run = base + sa - a;  // exclusive prefix of this thread's segment
-    for (int k = lo; k < hi; k++) {
-        off[k] = run;
-        run += (double) tot[(k / nbl) * 2 * nbl + (k % nbl)];
-    }
-    W = ((sh_a[0] + sh_a[1]) + sh_a[2]) + sh_a[3];
-    Q = ((sh_q[0] + sh_q[1]) + sh_q[2]) + sh_q[3];
-    if (t == 0) off[nb] = W;
-}
-
-// stratum of global output particle gid: the caller's tape, or (gid + u)/N with u from Philox stream 1
-SLAM_DEV float stratum(const RngArgs &rng, int64_t gid) {
-    if (rng.mode == 0) return rng.strata[gid];
-    U4 r = philox4x32((uint32_t) gid, rng.step, 1u, 0u, rng.k0, rng.k1);
-    const double u = ((double) (r.x >> 8) + 0.5) * (1.0 / 16777216.0);
-    return (float) (((double) gid + u) / (double) rng.n_global);
-}
-
-// ancestor (global particle index) of a stratum: min{ i : target < cumsum_i }, two-level binary search
-SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const float *__restrict__ lcum_local,
-                               int first_block, int nb_local, int64_t n_global) {
-    int b0 = 0, b1 = nb;
-    while (b0 < b1) {
-        const int mid = (b0 + b1) >> 1;
-        if (off[mid + 1] > target) b1 = mid; else b0 = mid + 1;
-    }
-    if (b0 >= nb) return n_global - 1;  // select beyond the last cumulative weight: undefined upstream (keep = -1), clamp
-    // the in-block prefix is only resident for this shard's blocks; callers only ask for strata they own
-    const int lb = min(max(b0 - first_block, 0), nb_local - 1);
-    const double o = off[b0];
-    const float *lc = lcum_local + (size_t) lb * kBlock;
-    // first slot with o + lc > target; the last slot if rounding hides it.  The prefix is non-decreasing, so instead of
-    // 8 dependent probes: 16 pivots in flight together (every 16th entry), then the 16 entries of the pivot's segment
-    float pv[16];
-#pragma unroll
-    for (int q = 0; q < 16; q++) pv[q] = lc[16 * q + 15];
-    int seg = 15;
-#pragma unroll
-    for (int q = 14; q >= 0; q--)
-        if (o + (double) pv[q] > target) seg = q;
-    const float4 *l4 = reinterpret_cast<const float4 *>(lc + 16 * seg);
-    const float4 e0 = l4[0], e1 = l4[1], e2 = l4[2], e3 = l4[3];
-    const float ev[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
-    int r = 15;
-#pragma unroll
-    for (int q = 14; q >= 0; q--)
-        if (o + (double) ev[q] > target) r = q;
-    const int l0 = 16 * seg + r;
-    return min((int64_t) b0 * kBlock + l0, n_global - 1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -843,17 +906,11 @@ __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScrat
     Ctrl *ctrl = B.ctrl;
     const int t = threadIdx.x;
     const int nb = ws.nblocks;
-    if ((int) blockIdx.x >= nb) {
-        // second share of the copy roles of the lazy gather this step's update kernel started: the planning blocks
-        // below are a chain of dependent loads (scan, binary search), these keep HBM busy meanwhile
-        if (ctrl->pend[B.slot]) copy_genealogy(B, U, ws, ctrl->live[B.slot], U.copy_lo + (int) blockIdx.x - nb);
-        return;
-    }
-    // the buffer the update kernel of this step wrote: the other one if it performed a lazy gather
-    const int cur = ctrl->live[B.slot] ^ (ctrl->pend[B.slot] ? 1 : 0);
+    // every update launch publishes where it left the set (pend = 0) and the host flips its slot: plain read here
+    const int cur = ctrl->live[B.slot];
 
     double W, Q;
-    scan_block_totals(ws.blk_w, nb, nb, off, sh_a, sh_q, W, Q);  // one shard: [w(nb) | w2(nb)] contiguous
+    scan_block_totals(ws.blk_w[ws.wpar], nb, nb, off, sh_a, sh_q, W, Q);  // one shard: [w(nb) | w2(nb)] contiguous
     // Neff = 1 / sum((w/W)^2)  (core.cpp:784-788)
     const float neff = (float) ((W * W) / Q);
     const bool resample = ra.do_resample && (neff < (float) ra.n_effective);
@@ -862,6 +919,8 @@ __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScrat
         ctrl->wsq = Q;
         ctrl->neff = neff;
         ctrl->resampled = resample ? 1 : 0;
+        ws.est_part[ws.wpar][4 * (size_t) nb] = (double) neff;  // travels with the partials into the history
+        ws.est_part[ws.wpar][4 * (size_t) nb + 1] = resample ? 1.0 : 0.0;
         // state for the next launch goes to the OTHER slot (see Ctrl): the set now lives in `cur`, and after a
         // resample it is defined through keep[] until somebody gathers it
         ctrl->live[B.slot ^ 1] = cur;
@@ -881,7 +940,7 @@ __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScrat
         }
     } else if (active) {
         const double target = (double) stratum(rng, (int64_t) k) * W;
-        const int anc = (int) min(find_ancestor(target, off, nb, ws.lcum, 0, nb, (int64_t) B.n), (int64_t) B.n - 1);
+        const int anc = (int) min(find_ancestor(target, off, nb, ws.lcum[ws.wpar], 0, nb, (int64_t) B.n), (int64_t) B.n - 1);
         ws.keep[B.slot ^ 1][k] = anc;
         const float4 pa = B.poseA[cur][anc];
         ei = EstItem{(double) pa.x, (double) pa.y, ctrl->inv_n, pa.z, k};
@@ -892,7 +951,7 @@ __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScrat
     //  which costs far more than the kernel boundary it would save)
     ei = block_reduce_est(ei, sh_est);
     if (t == 0) {
-        double *p = ws.est_part + (size_t) blockIdx.x * 4;
+        double *p = ws.est_part[ws.wpar] + (size_t) blockIdx.x * 4;
         p[0] = ei.sx;
         p[1] = ei.sy;
         p[2] = (double) ei.th;
@@ -962,9 +1021,9 @@ __global__ void __launch_bounds__(kBlock) flatten_kernel(Buffers B, int nf) {
 }
 
 // One block: reduces the estimate partials (-> Ctrl.est, history slot) on demand.
-__global__ void __launch_bounds__(kBlock) finish_kernel(Buffers B, WeightScratch ws, double *hist) {
+__global__ void __launch_bounds__(kBlock) finish_kernel(Buffers B, WeightScratch ws, double *hist, int par) {
     __shared__ EstItem sh_est[kBlock / kWave];
-    finish_estimate(B, ws, hist, sh_est);
+    finish_estimate(B, ws, par, hist, sh_est);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -981,11 +1040,15 @@ __global__ void __launch_bounds__(kBlock) estimate_kernel(Buffers B, WeightScrat
     }
     ei = block_reduce_est(ei, sh_est);
     if (t == 0) {
-        double *p = ws.est_part + (size_t) blockIdx.x * 4;
+        double *p = ws.est_part[ws.wpar] + (size_t) blockIdx.x * 4;
         p[0] = ei.sx;
         p[1] = ei.sy;
         p[2] = (double) ei.th;
         p[3] = (double) ei.w;
+        if (blockIdx.x == 0) {  // the resampling record that goes with a history entry: the last update's
+            ws.est_part[ws.wpar][4 * (size_t) ws.nblocks] = (double) B.ctrl->neff;
+            ws.est_part[ws.wpar][4 * (size_t) ws.nblocks + 1] = (double) B.ctrl->resampled;
+        }
     }
 }
 
@@ -1063,7 +1126,7 @@ __global__ void __launch_bounds__(kBlock) shard_pack_kernel(Buffers B, WeightScr
     const int cur = B.ctrl->live[B.slot] ^ (B.ctrl->pend[B.slot] ? 1 : 0);  // the buffers this step's update wrote
     const size_t S = (size_t) B.ncap;
     const double target = (double) stratum(rng, k) * W;
-    const int64_t ganc = find_ancestor(target, off, A.nb_global, ws.lcum, A.first_block, ws.nblocks, rng.n_global);
+    const int64_t ganc = find_ancestor(target, off, A.nb_global, ws.lcum[ws.wpar], A.first_block, ws.nblocks, rng.n_global);
     const int anc = (int) min(max(ganc - rng.first_particle, (int64_t) 0), (int64_t) B.n - 1);
     // destination block: d = k / n_per_shard ; slot within it = k - max(K_lo, d*n_per_shard)
     const int d = (int) (k / A.n_per_shard);
@@ -1178,6 +1241,8 @@ __global__ void __launch_bounds__(kBlock) shard_finalize_kernel(Buffers B, Weigh
         c->wsq = Q;
         c->neff = neff;
         c->resampled = resampled;
+        ws.est_part[ws.wpar][4 * (size_t) ws.nblocks] = (double) neff;
+        ws.est_part[ws.wpar][4 * (size_t) ws.nblocks + 1] = (double) resampled;
         // published in the other slot; the host flips its slot after this launch (see Ctrl)
         c->live[B.slot ^ 1] = mode == 2 ? cur ^ 1 : cur;
         c->pend[B.slot ^ 1] = mode == 1 ? 1 : 0;
@@ -1197,7 +1262,7 @@ __global__ void __launch_bounds__(kBlock) shard_finalize_kernel(Buffers B, Weigh
     }
     ei = block_reduce_est(ei, sh_est);
     if (threadIdx.x == 0) {
-        double *p = ws.est_part + (size_t) blockIdx.x * 4;
+        double *p = ws.est_part[ws.wpar] + (size_t) blockIdx.x * 4;
         p[0] = ei.sx;
         p[1] = ei.sy;
         p[2] = (double) ei.th;
@@ -1238,16 +1303,17 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
     // pending lazy gather (they exit at once when nothing is pending: the host cannot know) and one helper block
     int grid = B.ncap / kBlock;
     if (U.lazy) grid += (U.copy_hi - U.copy_lo) + 1;
+    const size_t lds = sizeof(double) * ((size_t) ws.nblocks + 1);  // inline plan: prefix of the block totals
     if (U.method == 2)
-        hipLaunchKernelGGL(update_kernel<2>, dim3(grid), dim3(kBlock), 0, st, B, PA, U, rng, ws);
+        hipLaunchKernelGGL(update_kernel<2>, dim3(grid), dim3(kBlock), lds, st, B, PA, U, rng, ws);
     else
-        hipLaunchKernelGGL(update_kernel<1>, dim3(grid), dim3(kBlock), 0, st, B, PA, U, rng, ws);
+        hipLaunchKernelGGL(update_kernel<1>, dim3(grid), dim3(kBlock), lds, st, B, PA, U, rng, ws);
 }
 
 static void launch_resample(hipStream_t st, const Buffers &B, const WeightScratch &ws, const RngArgs &rng,
                             const ResampleArgs &ra, const UpdateArgs &U) {
     const size_t lds = sizeof(double) * ((size_t) ws.nblocks + 1);
-    hipLaunchKernelGGL(resample_kernel, dim3(ws.nblocks + (U.copy_hi - U.copy_lo)), dim3(kBlock), lds, st, B, ws, rng, ra, U);
+    hipLaunchKernelGGL(resample_kernel, dim3(ws.nblocks), dim3(kBlock), lds, st, B, ws, rng, ra, U);
 }
 
 static void launch_gather(hipStream_t st, const Buffers &B, const WeightScratch &ws, int nf) {
@@ -1273,8 +1339,8 @@ static void launch_flatten(hipStream_t st, const Buffers &B, int nf) {
     hipLaunchKernelGGL(flatten_kernel, dim3(B.ncap / kBlock, gy), dim3(kBlock), 0, st, B, nf);
 }
 
-static void launch_finish(hipStream_t st, const Buffers &B, const WeightScratch &ws, double *hist) {
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, B, ws, hist);
+static void launch_finish(hipStream_t st, const Buffers &B, const WeightScratch &ws, double *hist, int par) {
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, B, ws, hist, par);
 }
 
 static void launch_predict(hipStream_t st, const Buffers &B, const PredictArgs &A, const RngArgs &rng) {
@@ -1283,7 +1349,7 @@ static void launch_predict(hipStream_t st, const Buffers &B, const PredictArgs &
 
 static void launch_estimate(hipStream_t st, const Buffers &B, const WeightScratch &ws, double *hist) {
     hipLaunchKernelGGL(estimate_kernel, dim3(ws.nblocks), dim3(kBlock), 0, st, B, ws);
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, B, ws, hist);
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(kBlock), 0, st, B, ws, hist, ws.wpar);
 }
 
 static void launch_jacobians(hipStream_t st, const float *in, uint32_t n, float *out) {

@@ -71,7 +71,7 @@ struct slamgpu_ctx {
     // tape staging (TAPE mode)
     float *tape_host = nullptr;  // pinned: normals [3][ncap] (or predict [2][ncap]) + strata [n_global]
     float *normals_dev = nullptr;
-    float *strata_dev = nullptr;
+    float *strata_dev[2] = {nullptr, nullptr};  // by step parity: an update launch may still need the previous step's
     // lazy predict queue
     PredictArgs pending{};
     // host mirror of ctrl for readback
@@ -93,7 +93,7 @@ struct slamgpu_ctx {
     bool shard_settled = false;   // the sharded resampling stage of this step moved everything physically (records arrived)
     int slot = 0;
     int keep_slot = 0;            // which WeightScratch::keep buffer holds the ancestors of the last update
-    float copy_split = -1.0f;     // share of a pending lazy gather's copy roles carried by the update launch; < 0: automatic
+    float copy_split = -1.0f;  // (unused since the resampling stage rides inline: every copy role is in the update launch)     // share of a pending lazy gather's copy roles carried by the update launch; < 0: automatic
                                   // (all of them for maps up to 256 landmarks: measured on MI355X at 100 000 particles,
                                   // 30 landmarks: 0.0 23.4, 0.3 23.2, 0.6 23.2, 1.0 22.9 us/step; 30 % beyond, where the
                                   // genealogy copy is long enough to be worth hiding behind the planning blocks too)
@@ -101,8 +101,18 @@ struct slamgpu_ctx {
     bool shard_est_fresh = false; // sharded: est_part holds this shard's partials of the last update (shard_finalize_kernel)
     bool own_totals = true;       // ws.blk_w is this context's allocation (not a caller-provided collective buffer)
     float *own_blk_w = nullptr;
-    bool est_deferred = false;    // est_part holds the partials of the last update, not reduced yet
-    double *deferred_hist = nullptr;  // history slot that reduction has to fill (or null)
+    // Pose-estimate pipeline of the single-context path.  The resampling stage of update t (Neff, decision, ancestors,
+    // estimate partials) normally runs INSIDE the launch of update t+1 (UpdateArgs::plan_inline) and its partials are
+    // reduced by the helper block of launch t+2; anything that needs results earlier runs them as launches of their own.
+    struct EstStage {
+        bool has = false;
+        int par = 0;              // step parity: which est_part / lcum / blk_w buffers
+        uint32_t step = 0;        // observation-step counter of that update (Philox stream of its strata)
+        int nf = 0;               // landmarks after that update
+        double *hist = nullptr;   // history slot its estimate belongs to (or null)
+    };
+    EstStage unplanned;           // the last update: resampling stage not run yet
+    EstStage unreduced;           // an update whose partials exist (est_part[par]) but are not reduced yet
 };
 
 namespace {
@@ -161,7 +171,9 @@ RngArgs rng_args(const slamgpu_ctx *c, uint32_t step) {
     r.first_particle = c->cfg.first_particle;
     r.n_global = n_global(c);
     r.normals = c->normals_dev;
-    r.strata = c->strata_dev;
+    r.strata = c->strata_dev[step & 1];
+    r.prev_step = step - 1;
+    r.strata_prev = c->strata_dev[(step & 1) ^ 1];
     return r;
 }
 
@@ -209,7 +221,10 @@ void compose_predicts(PredictArgs &P) {
 
 // Make the particle set plain again (particle k in slot k of the live buffers) if the last update may have left a
 // lazy gather: everything except the next update launch needs that.
+int flush_stages(slamgpu_ctx *c);
+
 int materialize(slamgpu_ctx *c) {
+    if (int rc = flush_stages(c)) return rc;  // the plan of the last update decides whether anything is pending
     if (!c->maybe_pending) return 0;
     HIP_TRY(hipSetDevice(c->cfg.device));
     c->B.slot = c->slot;
@@ -241,16 +256,41 @@ int flatten(slamgpu_ctx *c) {
     return 0;
 }
 
-// Reduce the pose-estimate partials of the last update now (normally the next update launch does it on the side).
-int finish_deferred(slamgpu_ctx *c) {
-    if (!c->est_deferred) return 0;
+// Run, as launches of their own, whatever part of the last updates' resampling / estimate stages is still outstanding
+// (normally the next update launches do it on the side): first the reduction of complete partials, then the plan of
+// the last update (resample_kernel: Neff, decision, ancestors into keep[], partials) and its reduction.
+int flush_stages(slamgpu_ctx *c) {
+    if (!c->unreduced.has && !c->unplanned.has) return 0;
     HIP_TRY(hipSetDevice(c->cfg.device));
-    {
+    c->B.slot = c->slot;
+    c->B.lslot = c->lslot;
+    if (c->unreduced.has) {
         Timed t(c, "finish");
-        c->k->finish(c->stream, c->B, c->ws, c->deferred_hist);
+        c->k->finish(c->stream, c->B, c->ws, c->unreduced.hist, c->unreduced.par);
+        c->unreduced.has = false;
+    }
+    if (c->unplanned.has) {
+        ResampleArgs ra{};
+        ra.nf = c->unplanned.nf;
+        ra.do_resample = c->cfg.resample;
+        ra.n_effective = c->cfg.n_effective;
+        c->ws.wpar = c->unplanned.par;
+        {
+            Timed t(c, "resample");
+            c->k->resample(c->stream, c->B, c->ws, rng_args(c, c->unplanned.step), ra, UpdateArgs{});
+        }
+        // resample_kernel published the new live / pending state (and the ancestors) in the other slot
+        c->keep_slot = c->slot ^ 1;
+        c->slot ^= 1;
+        c->B.slot = c->slot;
+        c->maybe_pending = true;
+        {
+            Timed t(c, "finish");
+            c->k->finish(c->stream, c->B, c->ws, c->unplanned.hist, c->unplanned.par);
+        }
+        c->unplanned.has = false;
     }
     HIP_TRY(hipGetLastError());
-    c->est_deferred = false;
     return 0;
 }
 
@@ -282,7 +322,7 @@ int read_ctrl(slamgpu_ctx *c, bool need_set = false) {
     if (int rc = flush_predict(c)) return rc;
     if (need_set)
         if (int rc = materialize(c)) return rc;
-    if (int rc = finish_deferred(c)) return rc;
+    if (int rc = flush_stages(c)) return rc;
     HIP_TRY(hipMemcpyAsync(c->ctrl_host, c->B.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
@@ -371,10 +411,11 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     CTX_TRY(hipMemcpyAsync(c->B.ctrl, c->ctrl_host, sizeof(Ctrl), hipMemcpyHostToDevice, c->stream));
     // weight scratch
     c->ws.nblocks = ncap / kBlock;
-    CTX_TRY(hipMalloc((void **) &c->ws.lcum, sizeof(float) * S));
-    CTX_TRY(hipMalloc((void **) &c->ws.blk_w, sizeof(float) * 2 * (size_t) c->ws.nblocks));  // [w | w2] contiguous
-    c->ws.blk_w2 = c->ws.blk_w + c->ws.nblocks;
-    CTX_TRY(hipMalloc((void **) &c->ws.est_part, sizeof(double) * 4 * (size_t) c->ws.nblocks));
+    for (int b = 0; b < 2; b++) {
+        CTX_TRY(hipMalloc((void **) &c->ws.lcum[b], sizeof(float) * S));
+        CTX_TRY(hipMalloc((void **) &c->ws.blk_w[b], sizeof(float) * 2 * (size_t) c->ws.nblocks));  // [w | w2] contiguous
+        CTX_TRY(hipMalloc((void **) &c->ws.est_part[b], sizeof(double) * (4 * (size_t) c->ws.nblocks + 2)));  // + Neff, resampled
+    }
     for (int b = 0; b < 2; b++) {
         CTX_TRY(hipMalloc((void **) &c->ws.keep[b], sizeof(int32_t) * S));
         CTX_TRY(hipMemsetAsync(c->ws.keep[b], 0, sizeof(int32_t) * S, c->stream));
@@ -389,7 +430,7 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
         const size_t tape_floats = 3 * S + (size_t) n_global(c);
         CTX_TRY(hipHostMalloc((void **) &c->tape_host, sizeof(float) * tape_floats, hipHostMallocDefault));
         CTX_TRY(hipMalloc((void **) &c->normals_dev, sizeof(float) * 3 * S));
-        CTX_TRY(hipMalloc((void **) &c->strata_dev, sizeof(float) * (size_t) n_global(c)));
+        for (int b = 0; b < 2; b++) CTX_TRY(hipMalloc((void **) &c->strata_dev[b], sizeof(float) * (size_t) n_global(c)));
     }
     // initial particle set: Particle() then w = 1/N (ParticleSLAMWrapper.cpp:14-25)
     {
@@ -421,10 +462,12 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     }
     if (c->B.ctrl) (void) hipFree(c->B.ctrl);
     if (c->ctrl_host) (void) hipHostFree(c->ctrl_host);
-    if (c->ws.lcum) (void) hipFree(c->ws.lcum);
-    if (!c->own_totals) c->ws.blk_w = c->own_blk_w;
-    if (c->ws.blk_w) (void) hipFree(c->ws.blk_w);
-    if (c->ws.est_part) (void) hipFree(c->ws.est_part);
+    if (!c->own_totals) c->ws.blk_w[0] = c->own_blk_w;
+    for (int b = 0; b < 2; b++) {
+        if (c->ws.lcum[b]) (void) hipFree(c->ws.lcum[b]);
+        if (c->ws.blk_w[b]) (void) hipFree(c->ws.blk_w[b]);
+        if (c->ws.est_part[b]) (void) hipFree(c->ws.est_part[b]);
+    }
     for (int b = 0; b < 2; b++)
         if (c->ws.keep[b]) (void) hipFree(c->ws.keep[b]);
     if (c->hist_dev) (void) hipFree(c->hist_dev);
@@ -434,7 +477,8 @@ void slamgpu_destroy(slamgpu_ctx *c) {
         if (c->pkt_ev[i]) (void) hipEventDestroy(c->pkt_ev[i]);
     if (c->tape_host) (void) hipHostFree(c->tape_host);
     if (c->normals_dev) (void) hipFree(c->normals_dev);
-    if (c->strata_dev) (void) hipFree(c->strata_dev);
+    for (int b = 0; b < 2; b++)
+        if (c->strata_dev[b]) (void) hipFree(c->strata_dev[b]);
     if (c->plan_dev) (void) hipFree(c->plan_dev);
     if (c->plan_host) (void) hipHostFree(c->plan_host);
     if (c->stream && c->own_stream) (void) hipStreamDestroy(c->stream);
@@ -585,60 +629,54 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
         }
         float *sh = c->tape_host + 3 * (size_t) S;
         memcpy(sh, strata, sizeof(float) * (size_t) n_global(c));
-        HIP_TRY(hipMemcpyAsync(c->strata_dev, sh, sizeof(float) * (size_t) n_global(c), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->strata_dev[c->obs_step & 1], sh, sizeof(float) * (size_t) n_global(c), hipMemcpyHostToDevice, c->stream));
     }
 
     const RngArgs rng = rng_args(c, c->obs_step);
+    if (sharded)
+        if (int rc = flush_stages(c)) return rc;  // (a context is driven either way, not both; be safe)
     c->B.slot = c->slot;
     c->B.lslot = c->lslot;
+    c->ws.wpar = sharded ? 0 : (int) (c->obs_step & 1);
     U.lazy = 1;
-    // copy roles of a pending lazy gather (one role = 256 particles x 8 landmarks known before this update), split
-    // between this launch and the resample launch so that neither waits for the other's share.  A sharded update
-    // carries all of them here: its resampling stage is other kernels, and other shards may overwrite nothing of
-    // ours, but this shard's spare buffers are the target of the next unpack
-    const int roles = c->ws.nblocks * (((U.nf + 3) / 4 + 7) / 8);  // 8 genealogy chunks (32 landmarks) per role
-    const double split = c->copy_split >= 0.0f ? c->copy_split : (U.nf <= 256 ? 1.0 : 0.3);
-    const int roles_k1 = sharded ? roles : (int) ((double) roles * split + 0.5);
+    // copy roles of a pending gather (one role = 256 particles x 8 genealogy chunks known before this update)
+    const int roles = c->ws.nblocks * (((U.nf + 3) / 4 + 7) / 8);
     U.copy_lo = 0;
-    U.copy_hi = roles_k1;
-    U.finalize = (!sharded && c->est_deferred) ? 1 : 0;
-    U.finalize_hist = c->deferred_hist;
+    U.copy_hi = roles;
+    // the resampling stage of the previous update rides in this launch unless something already ran it
+    U.plan_inline = (!sharded && c->unplanned.has) ? 1 : 0;
+    U.do_resample = c->cfg.resample;
+    U.n_effective = c->cfg.n_effective;
+    U.finalize = (!sharded && c->unreduced.has) ? 1 : 0;
+    U.finalize_hist = c->unreduced.hist;
+    U.finalize_par = c->unreduced.par;
     {
         Timed t(c, c->cfg.method == SLAMGPU_FASTSLAM2 ? "fs2_update" : "fs1_update");
         c->k->update(c->stream, c->B, PA, U, rng, c->ws);
     }
+    HIP_TRY(hipGetLastError());
     c->lslot ^= 1;  // the helper block of that launch wrote the landmark rows' live flags for the next launch
     c->B.lslot = c->lslot;
-    if (!sharded) c->est_deferred = false;  // reduced by the helper block of that launch
+    c->slot ^= 1;   // ... and where it left the set (Ctrl.live / pend of the other slot)
+    c->B.slot = c->slot;
+    c->maybe_pending = false;  // whatever gather was pending, this launch performed it
     c->nf += n;
     if (sharded) {
         // the resampling stage is driven by the caller through slamgpu_shard_* (needs collectives)
         c->est_fresh = false;
         c->shard_est_fresh = false;
-        HIP_TRY(hipGetLastError());
         return 0;
     }
-    ResampleArgs ra{};
-    ra.nf = c->nf;
-    ra.do_resample = c->cfg.resample;
-    ra.n_effective = c->cfg.n_effective;
-    U.copy_lo = roles_k1;
-    U.copy_hi = roles;
-    {
-        Timed t(c, "resample");
-        c->k->resample(c->stream, c->B, c->ws, rng, ra, U);
-    }
-    HIP_TRY(hipGetLastError());
-    // resample_kernel published the new live / pending state (and the new ancestors) in the other slot
-    c->keep_slot = c->slot ^ 1;
-    c->slot ^= 1;
-    c->B.slot = c->slot;
-    c->maybe_pending = true;
-    // this step's pose estimate exists as per-block partials; the next update launch (or finish_deferred) reduces
-    // them into Ctrl.est and this history slot
-    c->deferred_hist = c->hist_n < kHistCap ? c->hist_dev + kHistStride * (size_t) c->hist_n : nullptr;
-    c->est_deferred = true;
-    c->est_fresh = c->deferred_hist != nullptr;
+    // stage bookkeeping: the helper block reduced `unreduced`; the inline plan left the partials of `unplanned`;
+    // this update's own resampling stage is now the outstanding one
+    c->unreduced.has = false;
+    if (U.plan_inline) c->unreduced = c->unplanned;
+    c->unplanned.has = true;
+    c->unplanned.par = c->ws.wpar;
+    c->unplanned.step = c->obs_step;
+    c->unplanned.nf = c->nf;
+    c->unplanned.hist = c->hist_n < kHistCap ? c->hist_dev + kHistStride * (size_t) c->hist_n : nullptr;
+    c->est_fresh = c->unplanned.hist != nullptr;
     return 0;
 }
 
@@ -694,17 +732,16 @@ int slamgpu_shard_set_totals_buffer(slamgpu_ctx *c, float *totals_dev) {
     if (int rc = check_ctx(c)) return rc;
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->own_totals) c->own_blk_w = c->ws.blk_w;
+    if (c->own_totals) c->own_blk_w = c->ws.blk_w[0];
     float *p = totals_dev ? totals_dev : c->own_blk_w;
     c->own_totals = totals_dev == nullptr;
-    c->ws.blk_w = p;
-    c->ws.blk_w2 = p + c->ws.nblocks;
+    c->ws.blk_w[0] = p;  // shard contexts only use parity 0 of the weight scratch
     return 0;
 }
 
 int slamgpu_shard_block_totals(slamgpu_ctx *c, const float **totals_dev, int32_t *nblocks) {
     if (int rc = check_ctx(c)) return rc;
-    if (totals_dev) *totals_dev = c->ws.blk_w;  // [w(nblocks) | w2(nblocks)]
+    if (totals_dev) *totals_dev = c->ws.blk_w[0];  // [w(nblocks) | w2(nblocks)]
     if (nblocks) *nblocks = c->ws.nblocks;
     return 0;
 }
@@ -879,10 +916,10 @@ int slamgpu_shard_estimate_async(slamgpu_ctx *c) {
     if (c->shard_est_fresh) {
         // nothing moved since shard_finalize_kernel left this update's partials: only the one-block reduction
         Timed t(c, "finish");
-        c->k->finish(c->stream, c->B, c->ws, c->hist_dev + kHistStride * (size_t) c->hist_n);
+        c->k->finish(c->stream, c->B, c->ws, c->hist_dev + kHistStride * (size_t) c->hist_n, 0);
     } else {
         if (int rc = materialize(c)) return rc;
-        if (int rc = finish_deferred(c)) return rc;
+        if (int rc = flush_stages(c)) return rc;
         Timed t(c, "estimate");
         c->k->estimate(c->stream, c->B, c->ws, c->hist_dev + kHistStride * (size_t) c->hist_n);
     }
@@ -895,7 +932,7 @@ int slamgpu_shard_estimate_fetch(slamgpu_ctx *c, double *raw4, int32_t max_count
     if (int rc = check_ctx(c)) return rc;
     if (!count) return fail(SLAMGPU_ERR_INVALID, "null count");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    if (int rc = finish_deferred(c)) return rc;
+    if (int rc = flush_stages(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     const int n = c->hist_n < max_count ? c->hist_n : max_count;
     if (n > 0 && raw4) {
@@ -916,7 +953,7 @@ int slamgpu_shard_estimate(slamgpu_ctx *c, double out[4]) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = flush_predict(c)) return rc;
     if (int rc = materialize(c)) return rc;
-    if (int rc = finish_deferred(c)) return rc;
+    if (int rc = flush_stages(c)) return rc;
     {
         Timed t(c, "estimate");
         c->k->estimate(c->stream, c->B, c->ws, nullptr);
@@ -934,7 +971,7 @@ int slamgpu_estimate(slamgpu_ctx *c, double xyt[3]) {
     if (int rc = flush_predict(c)) return rc;
     if (!c->est_fresh) {
         if (int rc = materialize(c)) return rc;
-        if (int rc = finish_deferred(c)) return rc;
+        if (int rc = flush_stages(c)) return rc;
         Timed t(c, "estimate");
         c->k->estimate(c->stream, c->B, c->ws, nullptr);
     }
@@ -954,7 +991,7 @@ int slamgpu_estimate_async(slamgpu_ctx *c) {
     if (!c->est_fresh) {
         // the particle set changed since the last update (predicts / upload): reduce it now
         if (int rc = materialize(c)) return rc;
-        if (int rc = finish_deferred(c)) return rc;
+        if (int rc = flush_stages(c)) return rc;
         Timed t(c, "estimate");
         c->k->estimate(c->stream, c->B, c->ws, c->hist_dev + kHistStride * (size_t) c->hist_n);
         HIP_TRY(hipGetLastError());
@@ -969,7 +1006,7 @@ int slamgpu_history_fetch(slamgpu_ctx *c, double *xyt, float *neff, int32_t *res
     if (int rc = check_ctx(c)) return rc;
     if (!count) return fail(SLAMGPU_ERR_INVALID, "null count");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    if (int rc = finish_deferred(c)) return rc;
+    if (int rc = flush_stages(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     const int n = c->hist_n < max_count ? c->hist_n : max_count;
     std::vector<double> h((size_t) kHistStride * (n > 0 ? n : 1));
@@ -1025,7 +1062,7 @@ int slamgpu_sync(slamgpu_ctx *c) {
     if (int rc = check_ctx(c)) return rc;
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = flush_predict(c)) return rc;
-    if (int rc = finish_deferred(c)) return rc;
+    if (int rc = flush_stages(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
