@@ -214,6 +214,12 @@ int slamgpu_dev_copy_async(slamgpu_ctx *ctx, void *dst, const void *src, uint64_
 /* ---- measurement / plumbing ------------------------------------------------------------------------ */
 /* HIP stream the context launches on (hipStream_t as void*), so a harness can record events on it. */
 void *slamgpu_stream(slamgpu_ctx *ctx);
+/* Device time of a region of the context's stream: two HIP events recorded on that stream (start now / stop now);
+ * stop synchronises on its event and returns the milliseconds between the two.  Unlike the per-launch event pairs of
+ * slamgpu_profile this perturbs nothing inside the region. */
+int slamgpu_timer_start(slamgpu_ctx *ctx);
+int slamgpu_timer_stop(slamgpu_ctx *ctx, double *ms);
+
 /* Device-time accounting: when enabled every kernel launch is bracketed by HIP events on the context
  * stream; slamgpu_kernel_time returns accumulated milliseconds and launch count for a kernel name
  * ("fs2_update", "weights_scan", "resample", "predict", "estimate", ...). */

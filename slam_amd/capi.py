@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DECLARED_SYMBOLS = [
     "slamgpu_last_error", "slamgpu_abi_version", "slamgpu_device_count", "slamgpu_jacobians", "slamgpu_create",
     "slamgpu_destroy", "slamgpu_predict", "slamgpu_update", "slamgpu_estimate", "slamgpu_estimate_async", "slamgpu_estimate_fetch", "slamgpu_stats", "slamgpu_ancestors",
-    "slamgpu_num_landmarks", "slamgpu_download", "slamgpu_upload", "slamgpu_sync", "slamgpu_step", "slamgpu_history_fetch", "slamgpu_shard_set_totals_buffer", "slamgpu_shard_step", "slamgpu_stream", "slamgpu_profile",
+    "slamgpu_num_landmarks", "slamgpu_download", "slamgpu_upload", "slamgpu_sync", "slamgpu_step", "slamgpu_history_fetch", "slamgpu_shard_set_totals_buffer", "slamgpu_shard_step", "slamgpu_timer_start", "slamgpu_timer_stop", "slamgpu_stream", "slamgpu_profile",
     "slamgpu_kernel_time", "slamgpu_algorithmic_bytes", "slamgpu_shard_update", "slamgpu_shard_block_totals", "slamgpu_shard_plan",
     "slamgpu_shard_record_floats", "slamgpu_shard_pack", "slamgpu_shard_unpack", "slamgpu_shard_finish", "slamgpu_shard_estimate",
     "slamgpu_dev_alloc", "slamgpu_dev_free", "slamgpu_dev_copy", "slamgpu_dev_copy_async", "slamgpu_shard_estimate_async",
@@ -82,6 +82,8 @@ def load_library():
     L.slamgpu_sync.argtypes = [C.c_void_p]
     L.slamgpu_stream.argtypes = [C.c_void_p]
     L.slamgpu_stream.restype = C.c_void_p
+    L.slamgpu_timer_start.argtypes = [C.c_void_p]
+    L.slamgpu_timer_stop.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     L.slamgpu_profile.argtypes = [C.c_void_p, C.c_int32]
     L.slamgpu_kernel_time.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.slamgpu_algorithmic_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -351,6 +353,14 @@ class SlamGpu:
 
     def stream(self):
         return self.L.slamgpu_stream(self.h)
+
+    def timer_start(self):
+        _chk(self.L.slamgpu_timer_start(self.h))
+
+    def timer_stop(self):
+        ms = C.c_double()
+        _chk(self.L.slamgpu_timer_stop(self.h, C.byref(ms)))
+        return ms.value
 
     def profile(self, enable=True):
         _chk(self.L.slamgpu_profile(self.h, int(enable)))

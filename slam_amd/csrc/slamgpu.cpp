@@ -84,6 +84,7 @@ struct slamgpu_ctx {
     bool profile = false;
     std::map<std::string, KernelStat> stats;
     std::vector<hipEvent_t> ev_pool;
+    hipEvent_t timer_a = nullptr, timer_b = nullptr;  // slamgpu_timer_start / _stop
     double predict_bytes = 0;
     bool own_stream = true;
     ShardPlan *plan_dev = nullptr, *plan_host = nullptr;  // sharded resampling plan (device + pinned mirror)
@@ -475,6 +476,8 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     if (c->pkt_dev) (void) hipFree(c->pkt_dev);
     for (int i = 0; i < kRing; i++)
         if (c->pkt_ev[i]) (void) hipEventDestroy(c->pkt_ev[i]);
+    if (c->timer_a) (void) hipEventDestroy(c->timer_a);
+    if (c->timer_b) (void) hipEventDestroy(c->timer_b);
     if (c->tape_host) (void) hipHostFree(c->tape_host);
     if (c->normals_dev) (void) hipFree(c->normals_dev);
     for (int b = 0; b < 2; b++)
@@ -1186,6 +1189,27 @@ int slamgpu_profile(slamgpu_ctx *c, int32_t enable) {
     if (int rc = slamgpu_sync(c)) return rc;
     drain_stats(c);
     c->profile = enable != 0;
+    return 0;
+}
+
+int slamgpu_timer_start(slamgpu_ctx *c) {
+    if (int rc = check_ctx(c)) return rc;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (!c->timer_a) HIP_TRY(hipEventCreate(&c->timer_a));
+    if (!c->timer_b) HIP_TRY(hipEventCreate(&c->timer_b));
+    HIP_TRY(hipEventRecord(c->timer_a, c->stream));
+    return 0;
+}
+
+int slamgpu_timer_stop(slamgpu_ctx *c, double *ms) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!ms || !c->timer_a || !c->timer_b) return fail(SLAMGPU_ERR_INVALID, "timer not started");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipEventRecord(c->timer_b, c->stream));
+    HIP_TRY(hipEventSynchronize(c->timer_b));
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, c->timer_a, c->timer_b));
+    *ms = t;
     return 0;
 }
 
