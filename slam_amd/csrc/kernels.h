@@ -201,12 +201,12 @@ struct ShardUnpackArgs {
 };
 
 struct KernelTable {
-    // K1: [lazy gather of the last resample] + [fused predicts] + per-particle observation update + in-block weight
-    //     prefix / totals  (+ the reduction of the previous update's pose-estimate partials)
+    // the step: [resampling stage of the previous update, inline] + [gather] + [fused predicts] + per-particle observation
+    // update + in-block weight prefix / totals  (+ helper blocks: genealogy copy, Ctrl words, estimate reduction)
     void (*update)(hipStream_t, const Buffers &, const PredictArgs &, const UpdateArgs &, const RngArgs &,
                    const WeightScratch &);
-    // K2: Neff + decision; normalise, or the ancestors of a stratified resample (nothing is moved); estimate partials
-    //     (+ the second share of the copy roles of a pending lazy gather: UpdateArgs::copy_lo..copy_hi)
+    // the resampling stage as a launch of its own (on demand): Neff + decision; normalise, or the ancestors of a
+    // stratified resample into keep[] (nothing is moved); estimate partials
     void (*resample)(hipStream_t, const Buffers &, const WeightScratch &, const RngArgs &, const ResampleArgs &,
                      const UpdateArgs &);
     // materialise a pending lazy gather (needed before anything but the next update touches the particle set)

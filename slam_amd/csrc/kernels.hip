@@ -888,15 +888,13 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
 }
 
 // ---------------------------------------------------------------------------------------------------
-// K2: resampleParticles (core.cpp:718-749), planning only, + the per-step pose estimate
-// (ParticleSLAMWrapper.cpp:56-77).  Every planning block redundantly scans the block totals (LDS, double) => sum w,
-// sum w^2, Neff and the decision `doResample && Neff < nMin` without a separate launch or a host round trip.
+// resampleParticles (core.cpp:718-749), planning only, + the per-step pose estimate (ParticleSLAMWrapper.cpp:56-77) as a
+// launch of its own: used when something needs the outcome of the last update before the next update launch (which
+// otherwise does the same work inline, update_kernel: plan_inline).  Every block redundantly scans the block totals
+// (LDS, double) => sum w, sum w^2, Neff and the decision `doResample && Neff < nMin`.
 //   no resample: w_i /= sum(w) (core.cpp:726-729)
-//   resample   : ancestor of output k = min{ i : select_k < cumsum_i } (core.cpp:800-806) by a two-level binary
-//                search (block offsets in LDS, in-block prefix in HBM) into keep[slot ^ 1]; NOTHING is moved here: the
-//                copy of core.cpp:738-747 is the lazy gather of the next update launch (w = 1/N is applied there).
-// Blocks beyond the planning blocks carry the second share of the copy roles of the gather that THIS step's update
-// launch started (copy_genealogy), so that HBM is busy while the planning blocks chase dependent loads.
+//   resample   : ancestor of output k = min{ i : select_k < cumsum_i } (core.cpp:800-806) into keep[slot ^ 1]; NOTHING
+//                is moved here: the next update launch (or gather_kernel) gathers through keep[].
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScratch ws, RngArgs rng, ResampleArgs ra,
                                                            UpdateArgs U) {

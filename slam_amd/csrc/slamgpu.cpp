@@ -94,10 +94,6 @@ struct slamgpu_ctx {
     bool shard_settled = false;   // the sharded resampling stage of this step moved everything physically (records arrived)
     int slot = 0;
     int keep_slot = 0;            // which WeightScratch::keep buffer holds the ancestors of the last update
-    float copy_split = -1.0f;  // (unused since the resampling stage rides inline: every copy role is in the update launch)     // share of a pending lazy gather's copy roles carried by the update launch; < 0: automatic
-                                  // (all of them for maps up to 256 landmarks: measured on MI355X at 100 000 particles,
-                                  // 30 landmarks: 0.0 23.4, 0.3 23.2, 0.6 23.2, 1.0 22.9 us/step; 30 % beyond, where the
-                                  // genealogy copy is long enough to be worth hiding behind the planning blocks too)
     bool maybe_pending = false;   // the last update may have left a lazy gather (only the device knows)
     bool shard_est_fresh = false; // sharded: est_part holds this shard's partials of the last update (shard_finalize_kernel)
     bool own_totals = true;       // ws.blk_w is this context's allocation (not a caller-provided collective buffer)
@@ -364,7 +360,6 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     c->cfg = *cfg;
     if (c->cfg.n_particles_global <= 0) c->cfg.n_particles_global = c->cfg.n_particles;
     c->k = cfg->math_mode == SLAMGPU_MATH_FAST ? kernels_fast() : kernels_strict();
-    if (const char *e = getenv("SLAMGPU_COPY_SPLIT")) c->copy_split = std::min(1.0f, std::max(0.0f, (float) atof(e)));
     const int cap_nf = cfg->max_landmarks > 0 ? cfg->max_landmarks : 1;
     c->B.n = n;
     c->B.ncap = ncap;
