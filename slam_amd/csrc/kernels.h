@@ -141,6 +141,7 @@ struct UpdateArgs {
     // has not run as a launch of its own; every block of this launch redoes its scan and every thread finds its own
     // ancestor, so a step is ONE launch.  0: that stage already ran (resample_kernel), honour Ctrl.pend / keep[].
     int32_t plan_inline;
+    int32_t scan_global;     // the prefix of the previous step's block totals is in WeightScratch::scan (scan_kernel ran)
     int32_t do_resample, n_effective;  // SWITCH_RESAMPLE, NEFFECTIVE (for the inline plan)
     int32_t finalize_par;    // parity of the estimate partials the helper block reduces
     int32_t finalize;        // 1: the extra block reduces the previous update's pose-estimate partials
@@ -155,6 +156,8 @@ struct WeightScratch {
     float *blk_w[2];    // [2*nblocks] block totals of w, then of w^2: one allocation, so a shard's totals travel as one
                         //           contiguous message ([w(nb) | w2(nb)])
     double *est_part[2];  // [nblocks][4] pose-estimate partials (sum x, sum y, heading, max w)
+    double *scan[2];      // [nblocks + 3] large contexts: exclusive prefix of the block totals, then sum w, sum w^2
+                          // (scan_kernel), so that the update launch need not rescan the totals in every block
     int32_t wpar;       // parity of the step this launch belongs to
     int32_t *keep[2];   // [ncap] ancestors of the last resample, double-buffered by Buffers::slot: a launch reads the
                         // pending gather through keep[slot] and writes new ancestors into keep[slot ^ 1]
@@ -209,6 +212,8 @@ struct KernelTable {
     // stratified resample into keep[] (nothing is moved); estimate partials
     void (*resample)(hipStream_t, const Buffers &, const WeightScratch &, const RngArgs &, const ResampleArgs &,
                      const UpdateArgs &);
+    // large contexts: prefix of this step's block totals into WeightScratch::scan[wpar] (one block)
+    void (*scan)(hipStream_t, const WeightScratch &);
     // materialise a pending lazy gather (needed before anything but the next update touches the particle set)
     void (*gather)(hipStream_t, const Buffers &, const WeightScratch &, int nf);
     // rewrite every landmark record into its particle's own slot (genealogy -> identity): download, sharded arrivals

@@ -436,9 +436,17 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     // Either way a gathered particle is written to slot i of the OTHER pose / genealogy buffers.
     bool pend = U.lazy && ctrl->pend[B.slot] != 0;
     double W = 1.0;
+    // large contexts: the prefix comes from scan_kernel (same function, same association, run once) instead of being
+    // redone by every block -- O(N^2 / 65 536) otherwise
+    const double *offp = U.scan_global ? ws.scan[ws.wpar ^ 1] : off;
     if (U.plan_inline && !helper) {
         double Q;
-        scan_block_totals(ws.blk_w[ws.wpar ^ 1], nb, nb, off, sh_a, sh_q, W, Q);
+        if (U.scan_global) {
+            W = offp[nb + 1];
+            Q = offp[nb + 2];
+        } else {
+            scan_block_totals(ws.blk_w[ws.wpar ^ 1], nb, nb, off, sh_a, sh_q, W, Q);
+        }
         const float neff = (float) ((W * W) / Q);  // Neff = 1 / sum((w/W)^2)  (core.cpp:784-788)
         pend = U.do_resample && (neff < (float) U.n_effective);
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -455,7 +463,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     auto ancestor = [&](int k) -> int {
         if (!U.plan_inline) return ws.keep[B.slot][k];
         const double target = (double) stratum_prev(rng, (int64_t) k) * W;
-        return (int) min(find_ancestor(target, off, nb, ws.lcum[ws.wpar ^ 1], 0, nb, (int64_t) B.n), (int64_t) B.n - 1);
+        return (int) min(find_ancestor(target, offp, nb, ws.lcum[ws.wpar ^ 1], 0, nb, (int64_t) B.n), (int64_t) B.n - 1);
     };
     if ((int) blockIdx.x >= nb) {
         // ---- helper blocks ---------------------------------------------------------------------------------
@@ -465,7 +473,12 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             // whose partials are complete: this block runs beside the compute blocks instead of as launches of its own
             if (U.plan_inline) {  // the decision is needed for `out`: recompute it from the two totals, cheaply
                 double Q;
-                scan_block_totals(ws.blk_w[ws.wpar ^ 1], nb, nb, off, sh_a, sh_q, W, Q);
+                if (U.scan_global) {
+                    W = offp[nb + 1];
+                    Q = offp[nb + 2];
+                } else {
+                    scan_block_totals(ws.blk_w[ws.wpar ^ 1], nb, nb, off, sh_a, sh_q, W, Q);
+                }
                 pend = U.do_resample && ((float) ((W * W) / Q) < (float) U.n_effective);
             }
             if (threadIdx.x == 0) {
@@ -1018,6 +1031,19 @@ __global__ void __launch_bounds__(kBlock) flatten_kernel(Buffers B, int nf) {
     }
 }
 
+// One block: the scan every block of a small context does for itself (scan_block_totals: same association, so the
+// results are bit-identical), once, into global memory: [0..nb] exclusive prefix, [nb+1] sum w, [nb+2] sum w^2.
+__global__ void __launch_bounds__(kBlock) scan_kernel(WeightScratch ws) {
+    __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
+    double W, Q;
+    double *out = ws.scan[ws.wpar];
+    scan_block_totals(ws.blk_w[ws.wpar], ws.nblocks, ws.nblocks, out, sh_a, sh_q, W, Q);
+    if (threadIdx.x == 0) {
+        out[ws.nblocks + 1] = W;
+        out[ws.nblocks + 2] = Q;
+    }
+}
+
 // One block: reduces the estimate partials (-> Ctrl.est, history slot) on demand.
 __global__ void __launch_bounds__(kBlock) finish_kernel(Buffers B, WeightScratch ws, double *hist, int par) {
     __shared__ EstItem sh_est[kBlock / kWave];
@@ -1301,7 +1327,7 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
     // pending lazy gather (they exit at once when nothing is pending: the host cannot know) and one helper block
     int grid = B.ncap / kBlock;
     if (U.lazy) grid += (U.copy_hi - U.copy_lo) + 1;
-    const size_t lds = sizeof(double) * ((size_t) ws.nblocks + 1);  // inline plan: prefix of the block totals
+    const size_t lds = U.scan_global ? 0 : sizeof(double) * ((size_t) ws.nblocks + 1);  // inline plan: prefix of the block totals
     if (U.method == 2)
         hipLaunchKernelGGL(update_kernel<2>, dim3(grid), dim3(kBlock), lds, st, B, PA, U, rng, ws);
     else
@@ -1312,6 +1338,10 @@ static void launch_resample(hipStream_t st, const Buffers &B, const WeightScratc
                             const ResampleArgs &ra, const UpdateArgs &U) {
     const size_t lds = sizeof(double) * ((size_t) ws.nblocks + 1);
     hipLaunchKernelGGL(resample_kernel, dim3(ws.nblocks), dim3(kBlock), lds, st, B, ws, rng, ra, U);
+}
+
+static void launch_scan(hipStream_t st, const WeightScratch &ws) {
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, st, ws);
 }
 
 static void launch_gather(hipStream_t st, const Buffers &B, const WeightScratch &ws, int nf) {
@@ -1354,7 +1384,7 @@ static void launch_jacobians(hipStream_t st, const float *in, uint32_t n, float 
     hipLaunchKernelGGL(jacobians_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, in, n, out);
 }
 
-static const KernelTable kTable = {launch_update, launch_resample, launch_gather, launch_flatten, launch_identity, launch_finish, launch_predict, launch_estimate, launch_jacobians,
+static const KernelTable kTable = {launch_update, launch_resample, launch_scan, launch_gather, launch_flatten, launch_identity, launch_finish, launch_predict, launch_estimate, launch_jacobians,
                                    launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish};
 
 }  // namespace SLAM_KNS

@@ -108,6 +108,8 @@ struct slamgpu_ctx {
         int nf = 0;               // landmarks after that update
         double *hist = nullptr;   // history slot its estimate belongs to (or null)
     };
+    bool scan_ready = false;      // scan_kernel ran on the last update's block totals (large contexts)
+    int scan_min_blocks = 1024;   // contexts with more blocks of 256 particles than this use scan_kernel (262 144 particles)
     EstStage unplanned;           // the last update: resampling stage not run yet
     EstStage unreduced;           // an update whose partials exist (est_part[par]) but are not reduced yet
 };
@@ -360,6 +362,7 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     c->cfg = *cfg;
     if (c->cfg.n_particles_global <= 0) c->cfg.n_particles_global = c->cfg.n_particles;
     c->k = cfg->math_mode == SLAMGPU_MATH_FAST ? kernels_fast() : kernels_strict();
+    if (const char *e = getenv("SLAMGPU_SCAN_MIN_BLOCKS")) c->scan_min_blocks = atoi(e);  // diagnostic
     const int cap_nf = cfg->max_landmarks > 0 ? cfg->max_landmarks : 1;
     c->B.n = n;
     c->B.ncap = ncap;
@@ -411,6 +414,7 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
         CTX_TRY(hipMalloc((void **) &c->ws.lcum[b], sizeof(float) * S));
         CTX_TRY(hipMalloc((void **) &c->ws.blk_w[b], sizeof(float) * 2 * (size_t) c->ws.nblocks));  // [w | w2] contiguous
         CTX_TRY(hipMalloc((void **) &c->ws.est_part[b], sizeof(double) * (4 * (size_t) c->ws.nblocks + 2)));  // + Neff, resampled
+        CTX_TRY(hipMalloc((void **) &c->ws.scan[b], sizeof(double) * ((size_t) c->ws.nblocks + 3)));
     }
     for (int b = 0; b < 2; b++) {
         CTX_TRY(hipMalloc((void **) &c->ws.keep[b], sizeof(int32_t) * S));
@@ -463,6 +467,7 @@ void slamgpu_destroy(slamgpu_ctx *c) {
         if (c->ws.lcum[b]) (void) hipFree(c->ws.lcum[b]);
         if (c->ws.blk_w[b]) (void) hipFree(c->ws.blk_w[b]);
         if (c->ws.est_part[b]) (void) hipFree(c->ws.est_part[b]);
+        if (c->ws.scan[b]) (void) hipFree(c->ws.scan[b]);
     }
     for (int b = 0; b < 2; b++)
         if (c->ws.keep[b]) (void) hipFree(c->ws.keep[b]);
@@ -643,6 +648,7 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     U.copy_hi = roles;
     // the resampling stage of the previous update rides in this launch unless something already ran it
     U.plan_inline = (!sharded && c->unplanned.has) ? 1 : 0;
+    U.scan_global = (U.plan_inline && c->scan_ready) ? 1 : 0;
     U.do_resample = c->cfg.resample;
     U.n_effective = c->cfg.n_effective;
     U.finalize = (!sharded && c->unreduced.has) ? 1 : 0;
@@ -675,6 +681,15 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     c->unplanned.nf = c->nf;
     c->unplanned.hist = c->hist_n < kHistCap ? c->hist_dev + kHistStride * (size_t) c->hist_n : nullptr;
     c->est_fresh = c->unplanned.hist != nullptr;
+    // large contexts: one block prepares the prefix of this step's block totals for the next launch, instead of every
+    // block of that launch redoing it (a second, tiny launch; negligible at these sizes)
+    c->scan_ready = false;
+    if (c->ws.nblocks > c->scan_min_blocks) {
+        Timed t(c, "scan");
+        c->k->scan(c->stream, c->ws);
+        c->scan_ready = true;
+    }
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

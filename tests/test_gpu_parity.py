@@ -493,3 +493,29 @@ def test_lazy_gather_equals_eager_gather_with_big_packets(sg, tmp_path, math_mod
     for key in ("xv", "Pv", "w", "xf", "Pf"):
         assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), key
     assert np.array_equal(ea, eb, equal_nan=True)
+
+
+def test_global_scan_path_equals_inline_scan(sg, monkeypatch):
+    """Large contexts take the prefix of the block totals from scan_kernel instead of rescanning in every block; same
+    function, same association: forcing that path on a small context must not change a single bit."""
+    import os
+    from slam_amd import host
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    N = 3000
+    tape = host.make_tape(["-m", os.path.join(root, "data", "example_webmap.mat"), "-method", "FASTSLAM2", "-NPARTICLES", N,
+                           "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", 4], max_obs=60)
+    out = []
+    for min_blocks in ("1024", "0"):
+        monkeypatch.setenv("SLAMGPU_SCAN_MIN_BLOCKS", min_blocks)
+        s = sg.SlamGpu(N, tape["nlm"], method=2, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=6, math_mode=1)
+        for st in tape["steps"]:
+            s.step(np.array(st["controls"], f32).reshape(-1, 3), tape["Q"], float(tape["dt"]), st["zf"], st["idf"], st["zn"], tape["R"])
+        h = s.history_fetch()
+        out.append((s.download(), h))
+        s.close()
+    (a, ha), (b, hb) = out
+    assert 5 < ha[2].sum() < 60
+    for x, y in zip(ha, hb):
+        assert np.array_equal(x, y)
+    for key in ("xv", "Pv", "w", "xf", "Pf"):
+        assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), key
