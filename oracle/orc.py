@@ -360,6 +360,13 @@ class Oracle(_FuncLib):
         L.orc_free.argtypes = [C.c_void_p]
 
     # --- rand() tape ---
+    def set_threads(self, n):
+        """OpenMP threads of the per-particle loops (bench.py cpu_baseline; results do not depend on it)"""
+        self.lib.orc_set_threads.argtypes = [C.c_int]
+        self.lib.orc_get_threads.restype = C.c_int
+        self.lib.orc_set_threads(int(n))
+        return int(self.lib.orc_get_threads())
+
     def srand(self, seed):
         self.lib.orc_srand(seed)
 

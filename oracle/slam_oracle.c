@@ -894,8 +894,24 @@ void orc_estimate(const orc_particles *p, double *xyt) {
     xyt[2] = t;
 }
 
+/* Host-core baseline only (bench.py cpu_baseline): the per-particle loops below are independent per particle, so they
+ * can be spread over threads without changing a single result bit.  Default 1 thread (the scalar port, and what every
+ * test uses); orc_set_threads(n) enables n OpenMP threads when the library was built with -fopenmp. */
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n > 0 ? n : 1; }
+int orc_get_threads(void) {
+#ifdef _OPENMP
+    return g_threads;
+#else
+    return 1;
+#endif
+}
+
 void orc_predict(orc_particles *p, const orc_algo *a, float V, float G, const float *Q4, float dt, float phi_true,
                  const float *noise2) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+#endif
     for (int i = 0; i < p->N; i++) {
         const float *nz = (a->add_predict_noise && noise2) ? noise2 + 2 * i : NULL;
         if (a->method == 2)
@@ -914,6 +930,9 @@ void orc_update_local(orc_particles *p, const orc_algo *a, const float *zf, cons
         fprintf(stderr, "orc_update: landmark capacity exceeded (%d + %d > %d)\n", p->nf, n, p->cap);
         abort();
     }
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+#endif
     for (int i = 0; i < N; i++) {
         float *xv = p->xv + 3 * i, *Pv = p->Pv + 9 * i, *xf = p->xf + (size_t) i * 2 * p->cap,
               *Pf = p->Pf + (size_t) i * 4 * p->cap;
@@ -971,6 +990,9 @@ void orc_update(orc_particles *p, const orc_algo *a, const float *zf, const int 
         memcpy(oPv, p->Pv, sizeof(float) * 9 * (size_t) N);
         memcpy(oxf, p->xf, sizeof(float) * 2 * (size_t) N * p->cap);
         memcpy(oPf, p->Pf, sizeof(float) * 4 * (size_t) N * p->cap);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
+#endif
         for (int i = 0; i < N; i++) {
             int k = keep[i];
             if (k < 0) k = N - 1; /* unfilled keep[] is UB upstream (core.cpp:793,741); clamp */

@@ -133,4 +133,8 @@ void orc_free(void *p);
 #ifdef __cplusplus
 }
 #endif
+/* bench.py cpu_baseline only: OpenMP threads for the per-particle loops (default 1; results are thread-count invariant) */
+void orc_set_threads(int n);
+int orc_get_threads(void);
+
 #endif
