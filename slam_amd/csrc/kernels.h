@@ -225,7 +225,8 @@ struct KernelTable {
     void (*predict)(hipStream_t, const Buffers &, const PredictArgs &, const RngArgs &);
     void (*estimate)(hipStream_t, const Buffers &, const WeightScratch &, double *hist);
     void (*jacobians)(hipStream_t, const float *in_dev, uint32_t n, float *out_dev);
-    void (*shard_plan)(hipStream_t, const ShardPlanArgs &, const RngArgs &, ShardPlan *out_dev);
+    // seq_out != null: `out` and `seq_out` are pinned host memory; the kernel stores `seq` there last (system-scope fence)
+    void (*shard_plan)(hipStream_t, const ShardPlanArgs &, const RngArgs &, ShardPlan *out, uint32_t *seq_out, uint32_t seq);
     void (*shard_pack)(hipStream_t, const Buffers &, const WeightScratch &, const ShardPackArgs &, const RngArgs &);
     void (*shard_unpack)(hipStream_t, const Buffers &, const WeightScratch &, const ShardUnpackArgs &);
     // normalise or leave the lazy gather pending; this shard's pose-estimate partials; outcome into Ctrl

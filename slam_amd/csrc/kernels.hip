@@ -1106,7 +1106,10 @@ __global__ void __launch_bounds__(kBlock) jacobians_kernel(const float *__restri
 //   shard_unpack : blocks received from each source shard scattered into the spare buffers, w = 1/N
 //   shard_normalize : no resample: w /= W
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kBlock) shard_plan_kernel(ShardPlanArgs A, RngArgs rng, ShardPlan *out) {
+// `out` may be pinned host memory (the host polls `seq_out` instead of synchronising the stream): everything is
+// written, fenced at system scope, and only then the sequence number.
+__global__ void __launch_bounds__(kBlock) shard_plan_kernel(ShardPlanArgs A, RngArgs rng, ShardPlan *out,
+                                                             volatile uint32_t *seq_out, uint32_t seq) {
     extern __shared__ double off[];
     __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
     double W, Q;
@@ -1135,6 +1138,14 @@ __global__ void __launch_bounds__(kBlock) shard_plan_kernel(ShardPlanArgs A, Rng
             }
         }
         out->K[r] = lo;
+    }
+    if (seq_out) {
+        __threadfence_system();
+        __syncthreads();
+        if (t == 0) {
+            __threadfence_system();
+            *seq_out = seq;
+        }
     }
 }
 
@@ -1297,9 +1308,10 @@ __global__ void __launch_bounds__(kBlock) shard_finalize_kernel(Buffers B, Weigh
 // ---------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------
-static void launch_shard_plan(hipStream_t st, const ShardPlanArgs &A, const RngArgs &rng, ShardPlan *out) {
+static void launch_shard_plan(hipStream_t st, const ShardPlanArgs &A, const RngArgs &rng, ShardPlan *out, uint32_t *seq_out,
+                              uint32_t seq) {
     const size_t lds = sizeof(double) * ((size_t) A.nb_global + 1);
-    hipLaunchKernelGGL(shard_plan_kernel, dim3(1), dim3(kBlock), lds, st, A, rng, out);
+    hipLaunchKernelGGL(shard_plan_kernel, dim3(1), dim3(kBlock), lds, st, A, rng, out, seq_out, seq);
 }
 
 static void launch_shard_pack(hipStream_t st, const Buffers &B, const WeightScratch &ws, const ShardPackArgs &A,

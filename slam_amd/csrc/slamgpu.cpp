@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -88,6 +90,8 @@ struct slamgpu_ctx {
     double predict_bytes = 0;
     bool own_stream = true;
     ShardPlan *plan_dev = nullptr, *plan_host = nullptr;  // sharded resampling plan (device + pinned mirror)
+    uint32_t *plan_seq_host = nullptr;  // pinned: sequence number the plan kernel stores after the plan
+    uint32_t plan_seq = 0;
     // Ctrl.live / Ctrl.pend slot the next launch reads (kernels.h: Ctrl); flipped after every launch that may
     // change the live buffer (resample_kernel, gather_kernel, shard_commit_kernel)
     int lslot = 0;                // which lmk_live entry the next launch reads (flipped after every update launch, flatten, settle)
@@ -384,6 +388,8 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     }
     CTX_TRY(hipMalloc((void **) &c->plan_dev, sizeof(ShardPlan)));
     CTX_TRY(hipHostMalloc((void **) &c->plan_host, sizeof(ShardPlan), hipHostMallocDefault));
+    CTX_TRY(hipHostMalloc((void **) &c->plan_seq_host, sizeof(uint32_t), hipHostMallocDefault));
+    *c->plan_seq_host = 0;
     const size_t S = (size_t) ncap;
     for (int b = 0; b < 2; b++) {
         CTX_TRY(hipMalloc((void **) &c->B.poseA[b], sizeof(float4) * S));
@@ -484,6 +490,7 @@ void slamgpu_destroy(slamgpu_ctx *c) {
         if (c->strata_dev[b]) (void) hipFree(c->strata_dev[b]);
     if (c->plan_dev) (void) hipFree(c->plan_dev);
     if (c->plan_host) (void) hipHostFree(c->plan_host);
+    if (c->plan_seq_host) (void) hipHostFree(c->plan_seq_host);
     if (c->stream && c->own_stream) (void) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -636,7 +643,7 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     }
 
     const RngArgs rng = rng_args(c, c->obs_step);
-    if (sharded)
+    if (sharded && c->unplanned.has)
         if (int rc = flush_stages(c)) return rc;  // (a context is driven either way, not both; be safe)
     c->B.slot = c->slot;
     c->B.lslot = c->lslot;
@@ -651,7 +658,7 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     U.scan_global = (U.plan_inline && c->scan_ready) ? 1 : 0;
     U.do_resample = c->cfg.resample;
     U.n_effective = c->cfg.n_effective;
-    U.finalize = (!sharded && c->unreduced.has) ? 1 : 0;
+    U.finalize = c->unreduced.has ? 1 : 0;  // (sharded: this shard's partials of the previous step, shard_finalize_kernel)
     U.finalize_hist = c->unreduced.hist;
     U.finalize_par = c->unreduced.par;
     {
@@ -667,6 +674,7 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     c->nf += n;
     if (sharded) {
         // the resampling stage is driven by the caller through slamgpu_shard_* (needs collectives)
+        c->unreduced.has = false;  // reduced by the helper block of this launch
         c->est_fresh = false;
         c->shard_est_fresh = false;
         return 0;
@@ -776,13 +784,27 @@ int slamgpu_shard_plan(slamgpu_ctx *c, const float *gtot, int32_t nb_global, int
     A.n_shards = n_shards;
     A.do_resample = c->cfg.resample;
     A.n_effective = c->cfg.n_effective;
+    // the plan goes straight into pinned host memory and the host polls a sequence word the kernel stores last: a
+    // stream synchronisation costs several microseconds more than the store takes to arrive.  Bounded: after 2 ms
+    // without the word (e.g. a profiler serialising the queue) fall back to synchronising the stream.
+    const uint32_t seq = ++c->plan_seq;
     {
         Timed t(c, "shard_plan");
-        c->k->shard_plan(c->stream, A, rng_args(c, c->obs_step), c->plan_dev);
+        c->k->shard_plan(c->stream, A, rng_args(c, c->obs_step), c->plan_host, c->plan_seq_host, seq);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(c->plan_host, c->plan_dev, sizeof(ShardPlan), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    volatile uint32_t *flag = c->plan_seq_host;
+    bool arrived = false;
+    for (uint64_t spin = 0;; spin++) {
+        if (*flag == seq) {
+            arrived = true;
+            break;
+        }
+        if ((spin & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
+    if (!arrived) HIP_TRY(hipStreamSynchronize(c->stream));
+    std::atomic_thread_fence(std::memory_order_acquire);
     memcpy(out, c->plan_host, sizeof(ShardPlan));
     return 0;
 }
@@ -927,9 +949,13 @@ int slamgpu_shard_estimate_async(slamgpu_ctx *c) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = flush_predict(c)) return rc;
     if (c->shard_est_fresh) {
-        // nothing moved since shard_finalize_kernel left this update's partials: only the one-block reduction
-        Timed t(c, "finish");
-        c->k->finish(c->stream, c->B, c->ws, c->hist_dev + kHistStride * (size_t) c->hist_n, 0);
+        // nothing moved since shard_finalize_kernel left this update's partials: their one-block reduction rides in the
+        // next update launch (or runs when the history is fetched)
+        if (int rc = flush_stages(c)) return rc;  // (an older reduction still outstanding)
+        c->unreduced.has = true;
+        c->unreduced.par = 0;
+        c->unreduced.hist = c->hist_dev + kHistStride * (size_t) c->hist_n;
+        c->shard_est_fresh = false;
     } else {
         if (int rc = materialize(c)) return rc;
         if (int rc = flush_stages(c)) return rc;
