@@ -30,6 +30,7 @@ constexpr int kWave = 64;
 constexpr int kBlock = 256;
 constexpr int kMaxFusedPredict = 16;
 constexpr int kSmallObs = 12;       // observation packets up to this many zf / zn travel as kernel arguments
+constexpr int kPoolBit = (int) 0x80000000;  // genealogy entry: the record lives in the arrival pool (Buffers::poolA/B)
 constexpr int kHistStride = 6;      // doubles per pose-estimate history entry: sum x, sum y, heading, max w, Neff, resampled
 constexpr int kMaxScanBlocks = 8192;  // block totals scanned inside every resample block (LDS)
 
@@ -57,6 +58,13 @@ struct Buffers {
     float4 *lmkA[2];
     float *lmkB[2];
     int4 *idxQ[2];        // genealogy chunks; the live one is the pose's (Ctrl.live): both are gathered together
+    // Sharded runs: landmark records of particles that ARRIVED from another shard.  Such a record needs a place no
+    // sibling shares; rather than settling the whole shard it goes into this side pool ([cap_nf][pool_cap]) and the
+    // genealogy entry says so (kPoolBit | pool slot).  Descendants share pool records like any other; the entry is
+    // replaced by "own slot" the next time the landmark is observed.  flatten / a settling unpack empty the pool.
+    float4 *poolA;
+    float *poolB;
+    int32_t pool_cap;
     int32_t *lmk_live[2]; // [cap_nf] live record buffer of every landmark row, double-buffered by `lslot`: the update
                           // launch reads lmk_live[lslot] and writes the flags for the next launch into lmk_live[lslot^1]
     Ctrl *ctrl;
@@ -198,6 +206,8 @@ struct ShardPackArgs {
 };
 
 struct ShardUnpackArgs {
+    int32_t pool_base;               // lazy arrivals: first free slot of the arrival pool; < 0: settle the whole shard
+    int32_t pad1;
     const float *recv;               // device buffer, n_local*fields floats, blocks in source-shard order
     int32_t n_shards, nf, fields, shard;
     int64_t src_lo[kMaxShards + 1];  // local output index boundaries per source shard (own block: written by pack)

@@ -375,6 +375,7 @@ SLAM_DEV void copy_genealogy(const Buffers &B, const UpdateArgs &U, const Weight
     if (k >= B.n) return;
     const size_t S = (size_t) B.ncap;
     const int anc = anc_of(k);
+    if (anc < 0) return;  // sharded runs: arrived from another shard, genealogy already in place
     const int4 *__restrict__ src = cur ? B.idxQ[1] : B.idxQ[0];
     int4 *__restrict__ dst = cur ? B.idxQ[0] : B.idxQ[1];
     const int c0 = by * kChunksPerRole, c1 = min((U.nf + 3) >> 2, c0 + kChunksPerRole);
@@ -505,12 +506,19 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
 
     EstItem ei_prev{0.0, 0.0, -3.0e38f, 0.0f, 0x7fffffff};  // inline plan: this particle's term of the previous step's estimate
     if (active) {
-        // where this particle's pose and genealogy are read from: slot i of the live buffers, or its ancestor's slot
-        const int si = pend ? ancestor(i) : i;
-        const float4 *__restrict__ poseA = cur ? B.poseA[1] : B.poseA[0];
-        const float4 *__restrict__ poseB = cur ? B.poseB[1] : B.poseB[0];
-        const float2 *__restrict__ poseC = cur ? B.poseC[1] : B.poseC[0];
-        const int4 *__restrict__ idxS = cur ? B.idxQ[1] : B.idxQ[0];
+        // where this particle's pose and genealogy are read from: slot i of the live buffers, or its ancestor's slot; or
+        // (sharded runs, keep[i] < 0) slot i of the OUTPUT buffers: the particle arrived from another shard and
+        // shard_unpack_kernel has already put its pose and genealogy in place
+        int si = pend ? ancestor(i) : i;
+        int sb = cur;
+        if (si < 0) {
+            si = i;
+            sb = out;
+        }
+        const float4 *__restrict__ poseA = sb ? B.poseA[1] : B.poseA[0];
+        const float4 *__restrict__ poseB = sb ? B.poseB[1] : B.poseB[0];
+        const float2 *__restrict__ poseC = sb ? B.poseC[1] : B.poseC[0];
+        const int4 *__restrict__ idxS = sb ? B.idxQ[1] : B.idxQ[0];
         int4 *__restrict__ idxO = out ? B.idxQ[1] : B.idxQ[0];
         const int32_t *__restrict__ live = B.lslot ? B.lmk_live[1] : B.lmk_live[0];
         // landmark j of this particle: the slot comes from the genealogy, the buffer from the row's live flag; a landmark
@@ -519,6 +527,12 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             return reinterpret_cast<const int *>(idxS + (size_t) (j >> 2) * S + si)[j & 3];
         };
         auto load_lmk = [&](int j, int s, float4 &la, float &lb) {
+            if (s < 0) {  // kPoolBit: a record that arrived from another shard (kernels.h: Buffers::poolA)
+                const size_t at = (size_t) j * B.pool_cap + (s & ~kPoolBit);
+                la = B.poolA[at];
+                lb = B.poolB[at];
+                return;
+            }
             const int b = live[j];
             la = (b ? B.lmkA[1] : B.lmkA[0])[(size_t) j * S + s];
             lb = (b ? B.lmkB[1] : B.lmkB[0])[(size_t) j * S + s];
@@ -986,6 +1000,7 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(Buffers B, WeightScratch
     const int k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= B.n) return;
     const int anc = ws.keep[B.slot][k];
+    if (anc < 0) return;  // sharded runs: arrived from another shard: pose and genealogy already in place, w = 1/N
     const size_t S = (size_t) B.ncap;
     if (blockIdx.y == 0) {
         float4 pa = B.poseA[cur][anc];
@@ -1023,8 +1038,14 @@ __global__ void __launch_bounds__(kBlock) flatten_kernel(Buffers B, int nf) {
             const int j = 4 * c + t;
             if (j < j1) {
                 const int b = live[j];
-                B.lmkA[b ^ 1][(size_t) j * S + k] = B.lmkA[b][(size_t) j * S + s4[t]];
-                B.lmkB[b ^ 1][(size_t) j * S + k] = B.lmkB[b][(size_t) j * S + s4[t]];
+                if (s4[t] < 0) {  // arrival pool
+                    const size_t at = (size_t) j * B.pool_cap + (s4[t] & ~kPoolBit);
+                    B.lmkA[b ^ 1][(size_t) j * S + k] = B.poolA[at];
+                    B.lmkB[b ^ 1][(size_t) j * S + k] = B.poolB[at];
+                } else {
+                    B.lmkA[b ^ 1][(size_t) j * S + k] = B.lmkA[b][(size_t) j * S + s4[t]];
+                    B.lmkB[b ^ 1][(size_t) j * S + k] = B.lmkB[b][(size_t) j * S + s4[t]];
+                }
             }
         }
         idx[(size_t) c * S + k] = make_int4(k, k, k, k);
@@ -1149,6 +1170,22 @@ __global__ void __launch_bounds__(kBlock) shard_plan_kernel(ShardPlanArgs A, Rng
     }
 }
 
+// landmark l of the particle in slot `anc` of genealogy buffer `cur`: through the genealogy, the row's live flag, or the
+// arrival pool
+SLAM_DEV void read_through_genealogy(const Buffers &B, const int32_t *__restrict__ live, int cur, size_t S, int l, int anc,
+                                     float4 &la, float &lb) {
+    const int sl = reinterpret_cast<const int *>(B.idxQ[cur] + (size_t) (l >> 2) * S + anc)[l & 3];
+    if (sl < 0) {
+        const size_t at = (size_t) l * B.pool_cap + (sl & ~kPoolBit);
+        la = B.poolA[at];
+        lb = B.poolB[at];
+    } else {
+        const int b = live[l];
+        la = B.lmkA[b][(size_t) l * S + sl];
+        lb = B.lmkB[b][(size_t) l * S + sl];
+    }
+}
+
 __global__ void __launch_bounds__(kBlock) shard_pack_kernel(Buffers B, WeightScratch ws, ShardPackArgs A, RngArgs rng) {
     extern __shared__ double off[];
     __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
@@ -1191,24 +1228,27 @@ __global__ void __launch_bounds__(kBlock) shard_pack_kernel(Buffers B, WeightScr
     const int32_t *__restrict__ live = B.lslot ? B.lmk_live[1] : B.lmk_live[0];
     const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(A.nf, j0 + kLmkPerBlockY);
     for (int l = j0; l < j1; l++) {
-        // the ancestor's record of landmark l: slot from its genealogy, buffer from the row's live flag
-        const int sl = reinterpret_cast<const int *>(B.idxQ[cur] + (size_t) (l >> 2) * S + anc)[l & 3];
-        const int b = live[l];
-        const float4 la = B.lmkA[b][(size_t) l * S + sl];
-        const float lb = B.lmkB[b][(size_t) l * S + sl];
+        float4 la;
+        float lb;
+        read_through_genealogy(B, live, cur, S, l, anc, la, lb);
         float *f = dst + (size_t) (10 + 5 * l) * cnt;
         f[0] = la.x; f[cnt] = la.y; f[2 * cnt] = la.z; f[3 * cnt] = la.w; f[4 * cnt] = lb;
     }
 }
 
-// Records from other shards need slots nobody shares, so a step in which any arrive settles the whole shard: every
-// output particle is written physically into the other pose / genealogy buffers and into the other buffer of every
-// landmark row -- local offspring from their ancestor (keep[], through the ancestor's genealogy), arrivals from the
-// receive buffer -- with identity genealogy, and every row's live flag flips (lmk_live[lslot ^ 1]; the host flips
-// lslot).  Steps without arrivals keep the lazy gather.  blockIdx.y = group of 8 landmarks.
+// Records that arrive from other shards need a place no sibling shares.
+//   A.pool_base >= 0 (normal): arrival number a of this step gets arrival-pool slot pool_base + a: its landmark records
+//     go there, its pose and a genealogy that points at the pool go to slot i of the buffers the NEXT update launch writes
+//     (which reads them in place: keep[i] < 0); local offspring stay a lazy gather.  Only arrivals do any work.
+//   A.pool_base < 0 (pool full): settle the whole shard: every output particle is written physically into the other pose /
+//     genealogy buffers and into the other buffer of every landmark row -- local offspring from their ancestor (keep[],
+//     through the ancestor's genealogy), arrivals from the receive buffer -- with identity genealogy, and every row's
+//     live flag flips (lmk_live[lslot ^ 1]; the host flips lslot).  Nothing references the pool afterwards.
+// blockIdx.y = group of 8 landmarks.
 __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightScratch ws, ShardUnpackArgs A) {
+    const bool settle = A.pool_base < 0;
     const int32_t *__restrict__ live = B.lslot ? B.lmk_live[1] : B.lmk_live[0];
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if (settle && blockIdx.x == 0 && blockIdx.y == 0) {
         int32_t *__restrict__ nxt = B.lslot ? B.lmk_live[0] : B.lmk_live[1];
         for (int j = threadIdx.x; j < B.cap_nf; j += kBlock) nxt[j] = j < A.nf ? live[j] ^ 1 : live[j];
     }
@@ -1220,12 +1260,11 @@ __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightS
     int s = 0;
     while (s + 1 < A.n_shards && i >= A.src_lo[s + 1]) s++;
     const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(A.nf, j0 + kLmkPerBlockY);
-    // identity genealogy for the two chunks of this landmark group
-    for (int c = 2 * (int) blockIdx.y; c < min((A.nf + 3) >> 2, 2 * (int) blockIdx.y + 2); c++)
-        B.idxQ[cur ^ 1][(size_t) c * S + i] = make_int4(i, i, i, i);
+    const int c_lo = 2 * (int) blockIdx.y, c_hi = min((A.nf + 3) >> 2, 2 * (int) blockIdx.y + 2);  // this group's chunks
     if (s == A.shard) {
-        // local ancestor (recorded in keep[] by this shard's own pack kernel)
+        if (!settle) return;  // lazy gather through keep[] (recorded by this shard's own pack kernel)
         const int anc = ws.keep[B.slot ^ 1][i];
+        for (int c = c_lo; c < c_hi; c++) B.idxQ[cur ^ 1][(size_t) c * S + i] = make_int4(i, i, i, i);
         if (blockIdx.y == 0) {
             float4 pa = B.poseA[cur][anc];
             pa.w = B.ctrl->inv_n;
@@ -1234,10 +1273,12 @@ __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightS
             B.poseC[cur ^ 1][i] = B.poseC[cur][anc];
         }
         for (int l = j0; l < j1; l++) {
-            const int sl = reinterpret_cast<const int *>(B.idxQ[cur] + (size_t) (l >> 2) * S + anc)[l & 3];
+            float4 la;
+            float lb;
+            read_through_genealogy(B, live, cur, S, l, anc, la, lb);
             const int b = live[l];
-            B.lmkA[b ^ 1][(size_t) l * S + i] = B.lmkA[b][(size_t) l * S + sl];
-            B.lmkB[b ^ 1][(size_t) l * S + i] = B.lmkB[b][(size_t) l * S + sl];
+            B.lmkA[b ^ 1][(size_t) l * S + i] = la;
+            B.lmkB[b ^ 1][(size_t) l * S + i] = lb;
         }
         return;
     }
@@ -1253,11 +1294,24 @@ __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightS
         // negative = "came from another shard"; the global ancestor id is -(keep + 1)
         ws.keep[B.slot ^ 1][i] = -(__float_as_int(src[9 * cnt]) + 1);
     }
-    for (int l = j0; l < j1; l++) {
-        const float *f = src + (size_t) (10 + 5 * l) * cnt;
-        const int b = live[l];
-        B.lmkA[b ^ 1][(size_t) l * S + i] = make_float4(f[0], f[cnt], f[2 * cnt], f[3 * cnt]);
-        B.lmkB[b ^ 1][(size_t) l * S + i] = f[4 * cnt];
+    if (settle) {
+        for (int c = c_lo; c < c_hi; c++) B.idxQ[cur ^ 1][(size_t) c * S + i] = make_int4(i, i, i, i);
+        for (int l = j0; l < j1; l++) {
+            const float *f = src + (size_t) (10 + 5 * l) * cnt;
+            const int b = live[l];
+            B.lmkA[b ^ 1][(size_t) l * S + i] = make_float4(f[0], f[cnt], f[2 * cnt], f[3 * cnt]);
+            B.lmkB[b ^ 1][(size_t) l * S + i] = f[4 * cnt];
+        }
+    } else {
+        const int p = A.pool_base + (int) (before + slot);  // arrival number within this step
+        const int ref = kPoolBit | p;
+        for (int c = c_lo; c < c_hi; c++) B.idxQ[cur ^ 1][(size_t) c * S + i] = make_int4(ref, ref, ref, ref);
+        for (int l = j0; l < j1; l++) {
+            const float *f = src + (size_t) (10 + 5 * l) * cnt;
+            const size_t at = (size_t) l * B.pool_cap + p;
+            B.poolA[at] = make_float4(f[0], f[cnt], f[2 * cnt], f[3 * cnt]);
+            B.poolB[at] = f[4 * cnt];
+        }
     }
 }
 
@@ -1291,7 +1345,8 @@ __global__ void __launch_bounds__(kBlock) shard_finalize_kernel(Buffers B, Weigh
             B.poseA[cur][i] = pa;
             ei = EstItem{(double) pa.x, (double) pa.y, pa.w, pa.z, i};
         } else {
-            const float4 pa = mode == 2 ? B.poseA[cur ^ 1][i] : B.poseA[cur][ws.keep[B.slot ^ 1][i]];
+            const int k = mode == 2 ? -1 : ws.keep[B.slot ^ 1][i];  // < 0: in place in the other buffers (settled / arrived)
+            const float4 pa = k < 0 ? B.poseA[cur ^ 1][i] : B.poseA[cur][k];
             ei = EstItem{(double) pa.x, (double) pa.y, c->inv_n, pa.z, i};
         }
     }

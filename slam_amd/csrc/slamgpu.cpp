@@ -94,6 +94,7 @@ struct slamgpu_ctx {
     uint32_t plan_seq = 0;
     // Ctrl.live / Ctrl.pend slot the next launch reads (kernels.h: Ctrl); flipped after every launch that may
     // change the live buffer (resample_kernel, gather_kernel, shard_commit_kernel)
+    int64_t pool_used = 0;        // arrival-pool slots handed out since the pool was last emptied (flatten / settle / upload)
     int lslot = 0;                // which lmk_live entry the next launch reads (flipped after every update launch, flatten, settle)
     bool shard_settled = false;   // the sharded resampling stage of this step moved everything physically (records arrived)
     int slot = 0;
@@ -256,6 +257,7 @@ int flatten(slamgpu_ctx *c) {
     HIP_TRY(hipGetLastError());
     c->lslot ^= 1;
     c->B.lslot = c->lslot;
+    c->pool_used = 0;  // every record is in its particle's own slot again
     return 0;
 }
 
@@ -465,6 +467,8 @@ void slamgpu_destroy(slamgpu_ctx *c) {
         if (c->B.lmkB[b]) (void) hipFree(c->B.lmkB[b]);
         if (c->B.idxQ[b]) (void) hipFree(c->B.idxQ[b]);
         if (c->B.lmk_live[b]) (void) hipFree(c->B.lmk_live[b]);
+        if (b == 0 && c->B.poolA) (void) hipFree(c->B.poolA);
+        if (b == 0 && c->B.poolB) (void) hipFree(c->B.poolB);
     }
     if (c->B.ctrl) (void) hipFree(c->B.ctrl);
     if (c->ctrl_host) (void) hipHostFree(c->ctrl_host);
@@ -872,6 +876,21 @@ int slamgpu_shard_unpack(slamgpu_ctx *c, const float *recv_dev, int32_t n_shards
     A.fields = 10 + 5 * c->nf;
     A.shard = shard;
     for (int s = 0; s <= n_shards; s++) A.src_lo[s] = std::min(std::max(plan->K[s] - first, (int64_t) 0), n);
+    // the arrivals' landmark records go into the arrival pool (allocated on first use); when it cannot take this step's,
+    // the kernel settles the whole shard instead, which also empties the pool
+    const int64_t arrivals = n - (A.src_lo[shard + 1] - A.src_lo[shard]);
+    if (!c->B.poolA) {
+        const int64_t budget = (int64_t) 256 << 20;  // bytes
+        int64_t cap = budget / (20 * (int64_t) c->B.cap_nf);
+        cap = std::max<int64_t>(256, std::min<int64_t>(cap, 32768));
+        if (const char *e = getenv("SLAMGPU_POOL_CAP")) cap = std::max(1, atoi(e));  // diagnostic / tests
+        HIP_TRY(hipMalloc((void **) &c->B.poolA, sizeof(float4) * (size_t) cap * c->B.cap_nf));
+        HIP_TRY(hipMalloc((void **) &c->B.poolB, sizeof(float) * (size_t) cap * c->B.cap_nf));
+        c->B.pool_cap = (int32_t) cap;
+        c->pool_used = 0;
+    }
+    const bool settle = c->pool_used + arrivals > c->B.pool_cap;
+    A.pool_base = settle ? -1 : (int32_t) c->pool_used;
     c->B.slot = c->slot;
     c->B.lslot = c->lslot;
     {
@@ -879,10 +898,15 @@ int slamgpu_shard_unpack(slamgpu_ctx *c, const float *recv_dev, int32_t n_shards
         c->k->shard_unpack(c->stream, c->B, c->ws, A);
     }
     HIP_TRY(hipGetLastError());
-    // records arrived: the kernel settled the whole shard physically and flipped every landmark row
-    c->shard_settled = true;
-    c->lslot ^= 1;
-    c->B.lslot = c->lslot;
+    if (settle) {
+        // the kernel rewrote the whole shard physically and flipped every landmark row; nothing references the pool now
+        c->shard_settled = true;
+        c->lslot ^= 1;
+        c->B.lslot = c->lslot;
+        c->pool_used = 0;
+    } else {
+        c->pool_used += arrivals;
+    }
     return 0;
 }
 
@@ -1207,6 +1231,7 @@ int slamgpu_upload(slamgpu_ctx *c, int32_t nf, const float *xv, const float *Pv9
         HIP_TRY(hipMemcpy(c->B.lmkB[0], lb.data(), sizeof(float) * lb.size(), hipMemcpyHostToDevice));
     }
     // every landmark row live in buffer 0, every record in its particle's own slot
+    c->pool_used = 0;
     HIP_TRY(hipMemset(c->B.lmk_live[c->lslot], 0, sizeof(int32_t) * c->B.cap_nf));
     c->B.slot = c->slot;
     c->B.lslot = c->lslot;

@@ -101,14 +101,17 @@ def test_torch_runtime_coexists():
     assert r.returncode == 0 and "COEXIST_OK" in r.stdout, r.stdout + r.stderr
 
 
-@pytest.mark.parametrize("G", [1, 2, 4])
-def test_sharded_steps_without_downloads_match_single_context(G):
+@pytest.mark.parametrize("G,pool_cap", [(1, None), (2, None), (4, None), (4, "24"), (8, "3")])
+def test_sharded_steps_without_downloads_match_single_context(G, pool_cap, monkeypatch):
     """The production loop: ShardedFilter.step() per observation step, nothing read back in between, so the local
     offspring of every resample stay a lazy gather until the next update launch and the boundary offspring travel
-    through pack / all-to-all / unpack.  Final state and the whole estimate history must equal the single-context run."""
+    through pack / all-to-all / unpack into the arrival pool (or, when the pool is full, a settling unpack).  Final state
+    and the whole estimate history must equal the single-context run."""
     import slam_amd as sg
     from slam_amd import host
     from slam_amd.sharded import GpuEngine, LocalComm, ShardedFilter
+    if pool_cap:  # a tiny arrival pool: most steps with arrivals must fall back to settling the whole shard
+        monkeypatch.setenv("SLAMGPU_POOL_CAP", pool_cap)
     Np, nobs = 4096, 70
     tp = host.make_tape(sim_args("example_webmap", "FASTSLAM2", Np, 3), max_obs=nobs)
     Q, R, dt = tp["Q"], tp["R"], float(tp["dt"])
