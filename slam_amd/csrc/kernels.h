@@ -207,7 +207,7 @@ struct ShardPackArgs {
 
 struct ShardUnpackArgs {
     int32_t pool_base;               // lazy arrivals: first free slot of the arrival pool; < 0: settle the whole shard
-    int32_t pad1;
+    int32_t own_lo, own_hi, pad1;    // local outputs [own_lo, own_hi) have local ancestors; the rest are arrivals
     const float *recv;               // device buffer, n_local*fields floats, blocks in source-shard order
     int32_t n_shards, nf, fields, shard;
     int64_t src_lo[kMaxShards + 1];  // local output index boundaries per source shard (own block: written by pack)

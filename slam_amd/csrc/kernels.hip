@@ -1252,7 +1252,9 @@ __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightS
         int32_t *__restrict__ nxt = B.lslot ? B.lmk_live[0] : B.lmk_live[1];
         for (int j = threadIdx.x; j < B.cap_nf; j += kBlock) nxt[j] = j < A.nf ? live[j] ^ 1 : live[j];
     }
-    const int i = blockIdx.x * kBlock + threadIdx.x;  // local output particle
+    // local output particle: every one when settling, only the arrivals ([0, own_lo) and [own_hi, n)) otherwise
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (!settle && i >= A.own_lo) i += A.own_hi - A.own_lo;
     if (i >= B.n) return;
     const int cur = B.ctrl->live[B.slot] ^ (B.ctrl->pend[B.slot] ? 1 : 0);  // the buffers this step's update wrote
     const size_t S = (size_t) B.ncap;
@@ -1380,7 +1382,9 @@ static void launch_shard_pack(hipStream_t st, const Buffers &B, const WeightScra
 
 static void launch_shard_unpack(hipStream_t st, const Buffers &B, const WeightScratch &ws, const ShardUnpackArgs &A) {
     const int gy = A.nf > 0 ? (A.nf + kLmkPerBlockY - 1) / kLmkPerBlockY : 1;
-    hipLaunchKernelGGL(shard_unpack_kernel, dim3(B.ncap / kBlock, gy), dim3(kBlock), 0, st, B, ws, A);
+    const int work = A.pool_base < 0 ? B.n : B.n - (A.own_hi - A.own_lo);  // everything when settling, else the arrivals
+    if (work <= 0) return;
+    hipLaunchKernelGGL(shard_unpack_kernel, dim3((work + kBlock - 1) / kBlock, gy), dim3(kBlock), 0, st, B, ws, A);
 }
 
 static void launch_shard_finish(hipStream_t st, const Buffers &B, const WeightScratch &ws, double W, double Q, float neff,

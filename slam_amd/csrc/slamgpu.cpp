@@ -891,6 +891,8 @@ int slamgpu_shard_unpack(slamgpu_ctx *c, const float *recv_dev, int32_t n_shards
     }
     const bool settle = c->pool_used + arrivals > c->B.pool_cap;
     A.pool_base = settle ? -1 : (int32_t) c->pool_used;
+    A.own_lo = (int32_t) A.src_lo[shard];
+    A.own_hi = (int32_t) A.src_lo[shard + 1];
     c->B.slot = c->slot;
     c->B.lslot = c->lslot;
     {
