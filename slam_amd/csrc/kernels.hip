@@ -1209,7 +1209,7 @@ __global__ void __launch_bounds__(kBlock) shard_pack_kernel(Buffers B, WeightScr
         // the output slot lives on this shard too: nothing moves now -- record the (local) ancestor; the next update
         // launch gathers while it computes (lazy gather, as in the single-context pipeline).  With balanced weights
         // this is almost every offspring.
-        if (blockIdx.y == 0) ws.keep[B.slot ^ 1][(int) (k - (int64_t) d * A.n_per_shard)] = anc;
+        ws.keep[B.slot ^ 1][(int) (k - (int64_t) d * A.n_per_shard)] = anc;
         return;
     }
     // records before this block in the send buffer = offspring before it, minus the ones kept local
@@ -1217,7 +1217,7 @@ __global__ void __launch_bounds__(kBlock) shard_pack_kernel(Buffers B, WeightScr
     const int64_t self_hi = min(A.k_hi, (int64_t) (A.shard + 1) * A.n_per_shard);
     const int64_t kept_before = (d > A.shard && self_hi > self_lo) ? (self_hi - self_lo) : 0;
     float *__restrict__ dst = A.send + (size_t) (blk_lo - A.k_lo - kept_before) * A.fields + slot;
-    if (blockIdx.y == 0) {
+    {
         const float4 pa = B.poseA[cur][anc], pb = B.poseB[cur][anc];
         const float2 pc = B.poseC[cur][anc];
         dst[0 * cnt] = pa.x; dst[1 * cnt] = pa.y; dst[2 * cnt] = pa.z;
@@ -1225,9 +1225,10 @@ __global__ void __launch_bounds__(kBlock) shard_pack_kernel(Buffers B, WeightScr
         dst[7 * cnt] = pc.x; dst[8 * cnt] = pc.y;
         dst[9 * cnt] = __int_as_float((int) ganc);  // ancestor id (keep[]); the weight is reset to 1/N on arrival
     }
+    // the few offspring that leave the shard carry all their landmarks (one thread each: they are a fraction of a
+    // percent of the particles; a second grid dimension would make every block redo the scan above for nothing)
     const int32_t *__restrict__ live = B.lslot ? B.lmk_live[1] : B.lmk_live[0];
-    const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(A.nf, j0 + kLmkPerBlockY);
-    for (int l = j0; l < j1; l++) {
+    for (int l = 0; l < A.nf; l++) {
         float4 la;
         float lb;
         read_through_genealogy(B, live, cur, S, l, anc, la, lb);
@@ -1375,9 +1376,8 @@ static void launch_shard_pack(hipStream_t st, const Buffers &B, const WeightScra
                               const RngArgs &rng) {
     const int64_t cnt = A.k_hi - A.k_lo;
     if (cnt <= 0) return;
-    const int gy = A.nf > 0 ? (A.nf + kLmkPerBlockY - 1) / kLmkPerBlockY : 1;
     const size_t lds = sizeof(double) * ((size_t) A.nb_global + 1);
-    hipLaunchKernelGGL(shard_pack_kernel, dim3((unsigned) ((cnt + kBlock - 1) / kBlock), gy), dim3(kBlock), lds, st, B, ws, A, rng);
+    hipLaunchKernelGGL(shard_pack_kernel, dim3((unsigned) ((cnt + kBlock - 1) / kBlock)), dim3(kBlock), lds, st, B, ws, A, rng);
 }
 
 static void launch_shard_unpack(hipStream_t st, const Buffers &B, const WeightScratch &ws, const ShardUnpackArgs &A) {
