@@ -148,6 +148,7 @@ struct UpdateArgs {
     // Inline planning: the resampling stage of the PREVIOUS update (Neff, decision, ancestors, pose-estimate partials)
     // has not run as a launch of its own; every block of this launch redoes its scan and every thread finds its own
     // ancestor, so a step is ONE launch.  0: that stage already ran (resample_kernel), honour Ctrl.pend / keep[].
+    int32_t arrivals;        // shard context: particles may have arrived from other shards (keep[i] < 0, pool records)
     int32_t plan_inline;
     int32_t scan_global;     // the prefix of the previous step's block totals is in WeightScratch::scan (scan_kernel ran)
     int32_t do_resample, n_effective;  // SWITCH_RESAMPLE, NEFFECTIVE (for the inline plan)

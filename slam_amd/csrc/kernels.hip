@@ -413,7 +413,9 @@ SLAM_DEV void advance_live_flags(const Buffers &B, const UpdateArgs &U) {
 // ---------------------------------------------------------------------------------------------------
 constexpr int kStage = 8;  // landmarks per particle kept in LDS between the two passes (40 KB per block)
 
-template <int METHOD>
+// ARR: the context is a shard whose particles may have ARRIVED from other shards (keep[i] < 0, arrival-pool records).
+// Single contexts instantiate ARR = false: per-lane buffer and pool selects cost them 6 % of the step for nothing.
+template <int METHOD, bool ARR>
 __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs PA, UpdateArgs U, RngArgs rng,
                                                          WeightScratch ws) {
     __shared__ float sh_w[kBlock / kWave], sh_w2[kBlock / kWave];
@@ -511,7 +513,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         // shard_unpack_kernel has already put its pose and genealogy in place
         int si = pend ? ancestor(i) : i;
         int sb = cur;
-        if (si < 0) {
+        if (ARR && si < 0) {
             si = i;
             sb = out;
         }
@@ -526,16 +528,24 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         auto slot_of = [&](int j) -> int {
             return reinterpret_cast<const int *>(idxS + (size_t) (j >> 2) * S + si)[j & 3];
         };
-        auto load_lmk = [&](int j, int s, float4 &la, float &lb) {
-            if (s < 0) {  // kPoolBit: a record that arrived from another shard (kernels.h: Buffers::poolA)
-                const size_t at = (size_t) j * B.pool_cap + (s & ~kPoolBit);
-                la = B.poolA[at];
-                lb = B.poolB[at];
-                return;
-            }
+        struct Rec {
+            float4 a;
+            float b;
+        };
+        auto load_rec = [&](int j, int s) -> Rec {
+            // kPoolBit set: a record that arrived from another shard lives in the arrival pool (kernels.h: Buffers::poolA).
+            // Address select, not a branch: the staging arrays these references point into must stay in registers.
             const int b = live[j];
-            la = (b ? B.lmkA[1] : B.lmkA[0])[(size_t) j * S + s];
-            lb = (b ? B.lmkB[1] : B.lmkB[0])[(size_t) j * S + s];
+            const bool pool = ARR && s < 0;
+            const size_t at = pool ? (size_t) j * B.pool_cap + (size_t) (s & ~kPoolBit) : (size_t) j * S + (size_t) s;
+            const float4 *pA = pool ? B.poolA : (b ? B.lmkA[1] : B.lmkA[0]);
+            const float *pB = pool ? B.poolB : (b ? B.lmkB[1] : B.lmkB[0]);
+            return Rec{pA[at], pB[at]};  // by value: a reference into the staging arrays would pin them to scratch
+        };
+        auto load_lmk = [&](int j, int s, float4 &la, float &lb) {
+            const Rec r = load_rec(j, s);
+            la = r.a;
+            lb = r.b;
         };
         auto store_lmk = [&](int j, const float4 &la, float lb) {
             const int b = live[j];
@@ -623,7 +633,11 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
 #pragma unroll
                     for (int k = 0; k < kStage; k++) ts[k] = slot_of(idf[min(k, m - 1)]);
 #pragma unroll
-                    for (int k = 0; k < kStage; k++) load_lmk(idf[min(k, m - 1)], ts[k], ta[k], tb[k]);
+                    for (int k = 0; k < kStage; k++) {
+                        const Rec r = load_rec(idf[min(k, m - 1)], ts[k]);
+                        ta[k] = r.a;
+                        tb[k] = r.b;
+                    }
 #pragma unroll
                     for (int k = 0; k < kStage; k++) {
                         shA[k][threadIdx.x] = ta[k];
@@ -714,7 +728,11 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
 #pragma unroll
                     for (int k = 0; k < kStage; k++) ts[k] = slot_of(idf[min(k, m - 1)]);
 #pragma unroll
-                    for (int k = 0; k < kStage; k++) load_lmk(idf[min(k, m - 1)], ts[k], ta[k], tb[k]);
+                    for (int k = 0; k < kStage; k++) {
+                        const Rec r = load_rec(idf[min(k, m - 1)], ts[k]);
+                        ta[k] = r.a;
+                        tb[k] = r.b;
+                    }
 #pragma unroll
                     for (int k = 0; k < kStage; k++) {
                         shA[k][threadIdx.x] = ta[k];
@@ -1399,10 +1417,17 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
     int grid = B.ncap / kBlock;
     if (U.lazy) grid += (U.copy_hi - U.copy_lo) + 1;
     const size_t lds = U.scan_global ? 0 : sizeof(double) * ((size_t) ws.nblocks + 1);  // inline plan: prefix of the block totals
-    if (U.method == 2)
-        hipLaunchKernelGGL(update_kernel<2>, dim3(grid), dim3(kBlock), lds, st, B, PA, U, rng, ws);
-    else
-        hipLaunchKernelGGL(update_kernel<1>, dim3(grid), dim3(kBlock), lds, st, B, PA, U, rng, ws);
+    if (U.method == 2) {
+        if (U.arrivals)
+            hipLaunchKernelGGL((update_kernel<2, true>), dim3(grid), dim3(kBlock), lds, st, B, PA, U, rng, ws);
+        else
+            hipLaunchKernelGGL((update_kernel<2, false>), dim3(grid), dim3(kBlock), lds, st, B, PA, U, rng, ws);
+    } else {
+        if (U.arrivals)
+            hipLaunchKernelGGL((update_kernel<1, true>), dim3(grid), dim3(kBlock), lds, st, B, PA, U, rng, ws);
+        else
+            hipLaunchKernelGGL((update_kernel<1, false>), dim3(grid), dim3(kBlock), lds, st, B, PA, U, rng, ws);
+    }
 }
 
 static void launch_resample(hipStream_t st, const Buffers &B, const WeightScratch &ws, const RngArgs &rng,

@@ -653,6 +653,7 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     c->B.lslot = c->lslot;
     c->ws.wpar = sharded ? 0 : (int) (c->obs_step & 1);
     U.lazy = 1;
+    U.arrivals = sharded ? 1 : 0;
     // copy roles of a pending gather (one role = 256 particles x 8 genealogy chunks known before this update)
     const int roles = c->ws.nblocks * (((U.nf + 3) / 4 + 7) / 8);
     U.copy_lo = 0;

@@ -161,3 +161,25 @@ def test_slam_backend_cli_ekf_and_loud_failure_without_gpu():
     if slam_amd.device_count() == 0:
         r = subprocess.run([exe, "-m", os.path.join(DATA, "example_webmap.mat"), "-method", "FASTSLAM2"], capture_output=True, text=True, timeout=60)
         assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
+def test_no_kernel_spills_to_scratch(tmp_path):
+    """Performance guard (no GPU needed: hipcc cross-compiles): an indexed register array that the compiler cannot keep
+    in registers lands in the private segment, which cost the update kernel ~5 us per launch twice during development.
+    Every kernel of both builds must report a private segment of 0 bytes."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(os.path.dirname(DATA), "slam_amd", "csrc")
+    inc = os.path.join(os.path.dirname(DATA), "include")
+    builds = {"strict": ["-ffp-contract=off", "-DSLAM_KNS=slam_strict", "-DSLAM_TABLE=strict"],
+              "fast": ["-ffp-contract=fast", "-DSLAM_FAST_MATH=1", "-DSLAM_KNS=slam_fast", "-DSLAM_TABLE=fast"]}
+    for name, flags in builds.items():
+        out = str(tmp_path / ("k_%s.s" % name))
+        subprocess.run([hipcc, "-std=c++17", "-O3", "--offload-arch=gfx950", "-I" + src, "-I" + inc, *flags, "-S", "--cuda-device-only",
+                        "-o", out, os.path.join(src, "kernels.hip")], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        sizes = re.findall(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", open(out).read())
+        assert len(sizes) >= 12 and all(int(x) == 0 for x in sizes), (name, sizes)

@@ -47,7 +47,7 @@ try:
 except Exception:
     pass
 kern = {}
-for short, pat in (("fs2_update", r"update_kernel<2>"), ("fs1_update", r"update_kernel<1>"), ("resample", r"resample_kernel"), ("finish", r"finish_kernel"), ("gather", r"gather_kernel")):
+for short, pat in (("fs2_update", r"update_kernel<2"), ("fs1_update", r"update_kernel<1"), ("resample", r"resample_kernel"), ("finish", r"finish_kernel"), ("gather", r"gather_kernel")):
     for k in means["FETCH_SIZE"]:
         if re.search(pat, k):
             fk, wk = means["FETCH_SIZE"].get(k, 0.0), means["WRITE_SIZE"].get(k, 0.0)
