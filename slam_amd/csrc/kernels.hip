@@ -2,6 +2,7 @@
 // HBM, wave64 shuffles for the weight prefix-sum / reductions, device-resident resample decision.
 // Compiled twice (see Makefile): -DSLAM_KNS=slam_strict -ffp-contract=off and -DSLAM_KNS=slam_fast.
 #include "kernels.h"
+#include <type_traits>
 #include "device_math.h"
 
 namespace SLAM_KNS {
@@ -557,6 +558,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             (b ? B.lmkA[1] : B.lmkA[0])[(size_t) j * S + i] = la;
             (b ? B.lmkB[1] : B.lmkB[0])[(size_t) j * S + i] = lb;
         };
+
         const int32_t *__restrict__ idf;
         const float *__restrict__ zf, *__restrict__ zn;
         if (U.big) {
@@ -569,6 +571,30 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             zn = U.small.zn;
         }
         const float r00 = U.R[0], r01 = U.R[1], r10 = U.R[2], r11 = U.R[3];
+        // Stage the first KS re-observed landmarks in LDS with all their loads in flight together (one HBM latency instead
+        // of one per landmark); both passes then read LDS.  Measured before this: 38 % of the wave's cycles were s_waitcnt
+        // stalls (profiles/rocprof_sq_counters_r01.txt).  Unconditional loads (index clamped to the last landmark): no
+        // branch between them, so the compiler issues all of them before the first s_waitcnt; duplicates are L1 hits.
+        // Two sizes: most steps re-observe at most kStage/2 landmarks and need not pay for eight address computations.
+        auto stage_landmarks = [&](auto KS) {
+            constexpr int ks = decltype(KS)::value;
+            float4 ta[ks];
+            float tb[ks];
+            int ts[ks];
+#pragma unroll
+            for (int k = 0; k < ks; k++) ts[k] = slot_of(idf[min(k, m - 1)]);
+#pragma unroll
+            for (int k = 0; k < ks; k++) {
+                const Rec r = load_rec(idf[min(k, m - 1)], ts[k]);
+                ta[k] = r.a;
+                tb[k] = r.b;
+            }
+#pragma unroll
+            for (int k = 0; k < ks; k++) {
+                shA[k][threadIdx.x] = ta[k];
+                shB[k][threadIdx.x] = tb[k];
+            }
+        };
 
         float4 pa = poseA[si];
         // the genealogy chunks this update rewrites (small packets: at most a handful) are fetched now, with the pose,
@@ -626,24 +652,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 const float x0 = x, y0 = y, th0 = th;
                 Sym3 P = {q00, q10, q11, q20, q21, q22};
                 const L3r L0 = llt3r(P);  // factor of Pv0 for the prior term (:366)
-                {
-                    float4 ta[kStage];
-                    float tb[kStage];
-                    int ts[kStage];
-#pragma unroll
-                    for (int k = 0; k < kStage; k++) ts[k] = slot_of(idf[min(k, m - 1)]);
-#pragma unroll
-                    for (int k = 0; k < kStage; k++) {
-                        const Rec r = load_rec(idf[min(k, m - 1)], ts[k]);
-                        ta[k] = r.a;
-                        tb[k] = r.b;
-                    }
-#pragma unroll
-                    for (int k = 0; k < kStage; k++) {
-                        shA[k][threadIdx.x] = ta[k];
-                        shB[k][threadIdx.x] = tb[k];
-                    }
-                }
+                if (m <= kStage / 2) stage_landmarks(std::integral_constant<int, kStage / 2>{});
+                else stage_landmarks(std::integral_constant<int, kStage>{});
                 for (int k = 0; k < m; k++) {
                     float4 la;
                     float lb;
@@ -716,29 +726,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 const float x0 = x, y0 = y, th0 = th;
                 // running proposal covariance, full 3x3 (the reference's Pv stays a full matrix inside the loop)
                 float P[9] = {q00, q10, q20, q10, q11, q21, q20, q21, q22};
-                // Stage the first kStage re-observed landmarks in LDS with all their loads in flight together
-                // (one HBM latency instead of one per landmark); both passes then read LDS.  Measured before this:
-                // 38 % of the wave's cycles were s_waitcnt stalls (profiles/rocprof_sq_counters_r01.txt).
-                {
-                    float4 ta[kStage];
-                    float tb[kStage];
-                    // unconditional (index clamped to the last landmark): no branch between the loads, so the
-                    // compiler issues all of them before the first s_waitcnt; duplicates are L1 hits
-                    int ts[kStage];
-#pragma unroll
-                    for (int k = 0; k < kStage; k++) ts[k] = slot_of(idf[min(k, m - 1)]);
-#pragma unroll
-                    for (int k = 0; k < kStage; k++) {
-                        const Rec r = load_rec(idf[min(k, m - 1)], ts[k]);
-                        ta[k] = r.a;
-                        tb[k] = r.b;
-                    }
-#pragma unroll
-                    for (int k = 0; k < kStage; k++) {
-                        shA[k][threadIdx.x] = ta[k];
-                        shB[k][threadIdx.x] = tb[k];
-                    }
-                }
+                if (m <= kStage / 2) stage_landmarks(std::integral_constant<int, kStage / 2>{});
+                else stage_landmarks(std::integral_constant<int, kStage>{});
                 for (int k = 0; k < m; k++) {
                     float4 la;
                     float lb;
