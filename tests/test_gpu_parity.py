@@ -519,3 +519,61 @@ def test_global_scan_path_equals_inline_scan(sg, monkeypatch):
         assert np.array_equal(x, y)
     for key in ("xv", "Pv", "w", "xf", "Pf"):
         assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), key
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_random_api_interleavings_do_not_change_results(sg, seed):
+    """The step loop defers work (resampling stage planned inside the next launch, estimate reduced two launches later,
+    gathers and genealogy kept lazy).  Any observer call between steps (stats, estimate, ancestors, download, sync,
+    stand-alone predicts + estimate_async) forces some of it to run early, as launches of its own.  Whatever the
+    interleaving, states and histories must equal the undisturbed run bit for bit."""
+    import os
+    from slam_amd import host
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    N = 1500
+    tape = host.make_tape(["-m", os.path.join(root, "data", "example_webmap.mat"), "-method", "FASTSLAM2", "-NPARTICLES", N,
+                           "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", 9], max_obs=90)
+    Q, R, dt = tape["Q"], tape["R"], float(tape["dt"])
+
+    def run(disturb):
+        rng = np.random.default_rng(seed)
+        s = sg.SlamGpu(N, tape["nlm"], method=2, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=3, math_mode=1)
+        est_sync = {}
+        for k, st in enumerate(tape["steps"]):
+            ctl = np.array(st["controls"], f32).reshape(-1, 3)
+            if disturb and rng.random() < 0.3:
+                # the same step through the separate calls
+                for (V, G, phi) in ctl:
+                    s.predict(float(V), float(G), Q, dt, float(phi))
+                s.update(st["zf"], st["idf"], st["zn"], R)
+                s.estimate_async()
+            else:
+                s.step(ctl, Q, dt, st["zf"], st["idf"], st["zn"], R)
+            if disturb:
+                for _ in range(rng.integers(0, 3)):
+                    what = rng.integers(0, 6)
+                    if what == 0:
+                        s.stats()
+                    elif what == 1:
+                        est_sync[k] = s.estimate()
+                    elif what == 2:
+                        s.ancestors()
+                    elif what == 3:
+                        s.download(landmarks=bool(rng.integers(0, 2)))
+                    elif what == 4:
+                        s.sync()
+                    else:
+                        s.stats()
+                        s.estimate()
+        h = s.history_fetch()
+        d = s.download()
+        s.close()
+        return d, h, est_sync
+
+    (a, ha, _), (b, hb, es) = run(False), run(True)
+    for x, y in zip(ha, hb):
+        assert np.array_equal(x, y)
+    for key in ("xv", "Pv", "w", "xf", "Pf"):
+        assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), key
+    for k, e in es.items():  # the synchronous estimate of step k is the history's entry k
+        assert np.array_equal(e, ha[0][k]), k
