@@ -577,3 +577,34 @@ def test_random_api_interleavings_do_not_change_results(sg, seed):
         assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), key
     for k, e in es.items():  # the synchronous estimate of step k is the history's entry k
         assert np.array_equal(e, ha[0][k]), k
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+def test_queued_predicts_vs_oracle_sequence(sg, oracle, math_mode):
+    """k queued predicts (applied by one launch; the fast build folds them into ONE composite step computed on the host
+    for a particle at the origin, kernels.h: PredictComposite) against the oracle applying FastSLAM2::predictState k
+    times, from random poses and random symmetric positive definite covariances."""
+    from oracle import orc
+    rng = np.random.default_rng(11)
+    N, k = 512, 8
+    xv = np.stack([rng.uniform(-100, 100, N), rng.uniform(-100, 100, N), rng.uniform(-3.1, 3.1, N)], 1).astype(f32)
+    A = rng.normal(size=(N, 3, 3)) * np.array([0.05, 0.05, 0.01])
+    Pv = (A @ A.transpose(0, 2, 1) + np.eye(3) * 1e-6).astype(f32)
+    Pv = 0.5 * (Pv + Pv.transpose(0, 2, 1))
+    Qm = np.array([[0.09, 0], [0, 0.0027415568]], f32)
+    ctl = [(3.0 + 0.1 * j, 0.02 * (j - 3)) for j in range(k)]
+    algo = orc.Algo(2, 0, 0, 1, int(0.75 * N), 4.0, 0.0)
+    P = oracle.particles(N, 1)
+    P.set(dict(nf=0, xv=xv, Pv=Pv, w=np.full(N, 1.0 / N, f32), xf=np.zeros((N, 0, 2), f32), Pf=np.zeros((N, 0, 2, 2), f32)))
+    for V, G in ctl:
+        P.predict(algo, V, G, Qm, 0.025, 0.0)
+    exp = P.get()
+    P.close()
+    s = sg.SlamGpu(N, 4, method=2, n_effective=int(0.75 * N), wheel_base=4.0, rng_mode=sg.RNG_PHILOX, math_mode=math_mode)
+    s.upload(dict(nf=0, xv=xv, Pv=Pv, w=np.full(N, 1.0 / N, f32), xf=None, Pf=None))
+    for V, G in ctl:
+        s.predict(V, G, Qm, 0.025, 0.0)
+    got = s.download(landmarks=False)
+    s.close()
+    assert np.abs(got["xv"] - exp["xv"]).max() <= 5e-5, np.abs(got["xv"] - exp["xv"]).max()
+    assert close_cov(got["Pv"], sym(exp["Pv"]), 2e-4)
