@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SLAMGPU_ABI_VERSION 1
+#define SLAMGPU_ABI_VERSION 2
 
 typedef enum {
     SLAMGPU_OK = 0,
@@ -50,6 +50,12 @@ enum {
 enum {
     SLAMGPU_MATH_STRICT = 0, /* no FMA contraction, IEEE divide/sqrt: closest to the reference's SSE2 float math */
     SLAMGPU_MATH_FAST = 1    /* FMA contraction allowed (results within the documented tolerance of STRICT) */
+};
+
+/* status bits of an update's resampling stage (slamgpu_step_status, slamgpu_history_fetch) */
+enum {
+    SLAMGPU_STATUS_DEGENERATE = 1 /* the sum of the weights was zero or not finite: the reference normalises to NaN here
+                                     (core.cpp:726-729) and so does the device; the step is flagged instead of hidden */
 };
 
 typedef struct slamgpu_ctx slamgpu_ctx;
@@ -91,6 +97,13 @@ int slamgpu_device_count(void);
  *                                                                              => 16n floats
  * Host pointers; synchronous (this is the start()/isDone() spin of core.cpp:619-622). */
 int slamgpu_jacobians(const float *in, uint32_t n, float *out);
+
+/* Known-answer entry point for the scalar device functions the update kernels are built from, in the arithmetic of the
+ * chosen build (SLAMGPU_MATH_*): op 0 = trigonometricOffset (core.cpp:460-477), in[n] -> out[n];
+ * op 1 = gaussEvaluate D=2 (fastslam2.cpp:127-163), in = n x (v0 v1 S00 S10 S11); op 2 = gaussEvaluate D=3,
+ * in = n x (v0 v1 v2 S00 S10 S11 S20 S21 S22); out[n].  Host pointers; synchronous.  Used by the parity tests to put
+ * the reference's edge-case vectors (angles at +-pi, +-2pi, |a| > 2pi; near-singular S) through the device code. */
+int slamgpu_kat(int32_t math_mode, int32_t op, const float *in, int32_t n, float *out);
 
 /* ---- Seam 2: the algorithm object ------------------------------------------------------------------ */
 int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out);
@@ -135,11 +148,16 @@ int slamgpu_estimate_fetch(slamgpu_ctx *ctx, double *xyt, int32_t max_count, int
  * resampled[i] = whether it resampled (core.cpp:781-788, :731).  Entries recorded after predicts only (no update
  * since the previous entry) repeat the last update's values.  Any output pointer may be NULL.  Reading the record
  * here, once per batch of steps, keeps the step loop free of host round trips (slamgpu_stats synchronises). */
-int slamgpu_history_fetch(slamgpu_ctx *ctx, double *xyt, float *neff, int32_t *resampled, int32_t max_count, int32_t *count);
+/* status[i] = SLAMGPU_STATUS_* bits of that update (0 = healthy).  A fetch that takes fewer entries than were recorded
+ * (max_count < recorded) keeps the rest for the next fetch. */
+int slamgpu_history_fetch(slamgpu_ctx *ctx, double *xyt, float *neff, int32_t *resampled, int32_t *status, int32_t max_count,
+                          int32_t *count);
 
 
 /* Outcome of the last update: Neff, whether the resample fired, sum of the raw weights. Synchronises. */
 int slamgpu_stats(slamgpu_ctx *ctx, float *neff, int32_t *resampled, double *weight_sum);
+/* SLAMGPU_STATUS_* bits of the last update's resampling stage. Synchronises. */
+int slamgpu_step_status(slamgpu_ctx *ctx, int32_t *status);
 /* Ancestor indices of the last resample (keep[], core.cpp:800-806), N_local int32. Synchronises. */
 int slamgpu_ancestors(slamgpu_ctx *ctx, int32_t *keep);
 
@@ -176,6 +194,7 @@ typedef struct {
     float neff;
     int32_t resampled;
     int64_t K[65]; /* K[r] = first global output particle whose ancestor lives on shard r; K[G] = N */
+    int32_t status, pad; /* SLAMGPU_STATUS_* */
 } slamgpu_shard_plan_t;
 
 int slamgpu_shard_update(slamgpu_ctx *ctx, const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n,

@@ -19,7 +19,7 @@ DECLARED_SYMBOLS = [
     "slamgpu_kernel_time", "slamgpu_algorithmic_bytes", "slamgpu_shard_update", "slamgpu_shard_block_totals", "slamgpu_shard_plan",
     "slamgpu_shard_record_floats", "slamgpu_shard_pack", "slamgpu_shard_unpack", "slamgpu_shard_finish", "slamgpu_shard_estimate",
     "slamgpu_dev_alloc", "slamgpu_dev_free", "slamgpu_dev_copy", "slamgpu_dev_copy_async", "slamgpu_shard_estimate_async",
-    "slamgpu_shard_estimate_fetch",
+    "slamgpu_shard_estimate_fetch", "slamgpu_step_status", "slamgpu_kat",
 ]
 
 
@@ -39,7 +39,8 @@ class Config(C.Structure):
 
 class ShardPlan(C.Structure):
     """slamgpu_shard_plan_t"""
-    _fields_ = [("wsum", C.c_double), ("wsq", C.c_double), ("neff", C.c_float), ("resampled", C.c_int32), ("K", C.c_int64 * 65)]
+    _fields_ = [("wsum", C.c_double), ("wsq", C.c_double), ("neff", C.c_float), ("resampled", C.c_int32), ("K", C.c_int64 * 65),
+                ("status", C.c_int32), ("pad", C.c_int32)]
 
 
 def lib_path():
@@ -73,7 +74,9 @@ def load_library():
     L.slamgpu_estimate.argtypes = [C.c_void_p, C.c_void_p]
     L.slamgpu_estimate_async.argtypes = [C.c_void_p]
     L.slamgpu_estimate_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
-    L.slamgpu_history_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.slamgpu_history_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.slamgpu_step_status.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    L.slamgpu_kat.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     L.slamgpu_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.slamgpu_ancestors.argtypes = [C.c_void_p, C.c_void_p]
     L.slamgpu_num_landmarks.argtypes = [C.c_void_p]
@@ -140,6 +143,16 @@ def jacobians(xv, R, xf, Pf):
     _chk(load_library().slamgpu_jacobians(_ptr(buf), n, _ptr(out)))
     o = out.reshape(n, 16)
     return o[:, 0:2].copy(), o[:, 6:12].reshape(n, 2, 3).copy(), o[:, 2:6].reshape(n, 2, 2).copy(), o[:, 12:16].reshape(n, 2, 2).copy()
+
+
+def kat(math_mode, op, data):
+    """slamgpu_kat: op 0 trig_offset [n], 1 gaussEvaluate D=2 [n,5], 2 gaussEvaluate D=3 [n,9] -> [n]"""
+    a = _f32(data)
+    per = {0: 1, 1: 5, 2: 9}[op]
+    n = a.size // per
+    out = np.zeros(n, np.float32)
+    _chk(load_library().slamgpu_kat(math_mode, op, _ptr(a), n, _ptr(out)))
+    return out
 
 
 class SlamGpu:
@@ -249,8 +262,16 @@ class SlamGpu:
         ne = np.zeros(max_count, np.float32)
         rs = np.zeros(max_count, np.int32)
         n = C.c_int32()
-        _chk(self.L.slamgpu_history_fetch(self.h, _ptr(out), _ptr(ne), _ptr(rs), max_count, C.byref(n)))
+        st = np.zeros(max_count, np.int32)
+        _chk(self.L.slamgpu_history_fetch(self.h, _ptr(out), _ptr(ne), _ptr(rs), _ptr(st), max_count, C.byref(n)))
+        self.last_history_status = st[:n.value].copy()
         return out[:n.value].copy(), ne[:n.value].copy(), rs[:n.value].astype(bool)
+
+    def status(self):
+        """SLAMGPU_STATUS_* bits of the last update's resampling stage"""
+        st = C.c_int32()
+        _chk(self.L.slamgpu_step_status(self.h, C.byref(st)))
+        return st.value
 
     def stats(self):
         ne, rs, ws = C.c_float(), C.c_int32(), C.c_double()

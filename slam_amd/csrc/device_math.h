@@ -472,13 +472,30 @@ SLAM_DEV void proposal_update(float &x, float &y, float &th, Sym3 &P, const Obs2
 
 // likelihoodGivenXv term (fastslam2.cpp:370-400) + featureUpdate (core.cpp:132-175, :275-291) of one feature at the
 // sampled pose; both use the same Sf.  Returns gaussEvaluate(v, Sf) = exp(-v^T Sf^-1 v / 2) / (2 pi sqrt(det Sf)).
-SLAM_DEV float feature_update2(float &fx, float &fy, float &f00, float &f10, float &f11, const Obs2 &o, float v0, float v1) {
-    const float det = ffma(o.s00, o.s11, -o.s10 * o.s10);
+// gaussEvaluate(v, S), D = 2 (fastslam2.cpp:127-163), closed form: exp(-v^T S^-1 v / 2) / (2 pi sqrt(det S)); also hands
+// back S^-1 and S^-1 v for the feature update that follows
+struct Gauss2 {
+    float i00, i10, i11, u0, u1, E, norm;  // lik = exp(E) * norm
+};
+
+SLAM_DEV Gauss2 gauss2_parts(float s00, float s10, float s11, float v0, float v1) {
+    Gauss2 g;
+    const float det = ffma(s00, s11, -s10 * s10);
     const float rdet = __builtin_amdgcn_rcpf(det);
-    const float i00 = o.s11 * rdet, i10 = -o.s10 * rdet, i11 = o.s00 * rdet;
-    const float u0 = ffma(i00, v0, i10 * v1), u1 = ffma(i10, v0, i11 * v1);  // Sf^-1 v
-    const float E = -0.5f * ffma(v0, u0, v1 * u1);
-    const float lik = __expf(E) * (0.15915494309189535f * __builtin_amdgcn_rsqf(det));
+    g.i00 = s11 * rdet;
+    g.i10 = -s10 * rdet;
+    g.i11 = s00 * rdet;
+    g.u0 = ffma(g.i00, v0, g.i10 * v1);
+    g.u1 = ffma(g.i10, v0, g.i11 * v1);  // S^-1 v
+    g.E = -0.5f * ffma(v0, g.u0, v1 * g.u1);
+    g.norm = 0.15915494309189535f * __builtin_amdgcn_rsqf(det);
+    return g;
+}
+
+SLAM_DEV float feature_update2(float &fx, float &fy, float &f00, float &f10, float &f11, const Obs2 &o, float v0, float v1) {
+    const Gauss2 g = gauss2_parts(o.s00, o.s10, o.s11, v0, v1);
+    const float i00 = g.i00, i10 = g.i10, i11 = g.i11, u0 = g.u0, u1 = g.u1;
+    const float lik = __expf(g.E) * g.norm;
     // C = Pf Hf^T ; W = C Sf^-1 ; xf += W v = C (Sf^-1 v) ; Pf -= W C^T
     const float c00 = ffma(f00, o.hf00, f10 * o.hf01), c01 = ffma(f00, o.hf10, f10 * o.hf11);
     const float c10 = ffma(f10, o.hf00, f11 * o.hf01), c11 = ffma(f10, o.hf10, f11 * o.hf11);

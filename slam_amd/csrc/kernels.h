@@ -32,7 +32,9 @@ constexpr int kMaxFusedPredict = 16;
 constexpr int kSmallObs = 12;       // observation packets up to this many zf / zn travel as kernel arguments
 constexpr int kPoolBit = (int) 0x80000000;  // genealogy entry: the record lives in the arrival pool (Buffers::poolA/B)
 constexpr int kHistStride = 6;      // doubles per pose-estimate history entry: sum x, sum y, heading, max w, Neff, resampled
-constexpr int kMaxScanBlocks = 8192;  // block totals scanned inside every resample block (LDS)
+constexpr int kMaxScanBlocks = 8192;
+// status bits of an update's resampling stage (slamgpu.h: SLAMGPU_STATUS_*)
+constexpr int kStatusDegenerate = 1;  // sum of the weights zero or not finite: the reference normalises to NaN (core.cpp:726-729)  // block totals scanned inside every resample block (LDS)
 
 // Ctrl.live / Ctrl.pend are double-buffered by a host-side slot number (Buffers::slot): a kernel that changes the
 // live buffer writes the NEW state into slot^1 while every block of that launch still reads slot, and the host
@@ -46,6 +48,7 @@ struct Ctrl {
     int32_t resampled;    // 1 if the last update resampled
     float neff;           // Neff of the last update
     float inv_n;          // 1/N_global
+    int32_t status;       // kStatus* bits of the last update's resampling stage
     double wsum;          // sum of raw weights (global)
     double wsq;           // sum of squared raw weights (global)
     double est[4];        // sum x, sum y, heading of max-w particle, max w
@@ -187,6 +190,7 @@ struct ShardPlan {           // written by shard_plan_kernel, read back by the h
     float neff;
     int32_t resampled;
     int64_t K[kMaxShards + 1];  // K[r] = first global output particle whose ancestor lives on shard r
+    int32_t status, pad;        // kStatus* bits
 };
 
 struct ShardPlanArgs {
@@ -236,6 +240,9 @@ struct KernelTable {
     void (*predict)(hipStream_t, const Buffers &, const PredictArgs &, const RngArgs &);
     void (*estimate)(hipStream_t, const Buffers &, const WeightScratch &, double *hist);
     void (*jacobians)(hipStream_t, const float *in_dev, uint32_t n, float *out_dev);
+    // known-answer entry point for the scalar device functions (slamgpu_kat): op 0 trigonometricOffset, 1 gaussEvaluate D=2,
+    // 2 gaussEvaluate D=3, in the arithmetic this build's update kernel uses
+    void (*kat)(hipStream_t, int op, const float *in_dev, int n, float *out_dev);
     // seq_out != null: `out` and `seq_out` are pinned host memory; the kernel stores `seq` there last (system-scope fence)
     void (*shard_plan)(hipStream_t, const ShardPlanArgs &, const RngArgs &, ShardPlan *out, uint32_t *seq_out, uint32_t seq);
     void (*shard_pack)(hipStream_t, const Buffers &, const WeightScratch &, const ShardPackArgs &, const RngArgs &);

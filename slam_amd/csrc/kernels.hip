@@ -295,6 +295,11 @@ SLAM_DEV void scan_block_totals(const float *__restrict__ tot, int nb, int nbl, 
     if (t == 0) off[nb] = W;
 }
 
+// kStatus* bits of a resampling stage from the two global sums (NaN-safe comparisons)
+SLAM_DEV int weight_status(double W, double Q) {
+    return (W > 0.0 && W < 1.0e300 && Q > 0.0 && Q < 1.0e300) ? 0 : kStatusDegenerate;
+}
+
 // stratum of global output particle gid: the caller's tape, or (gid + u)/N with u from Philox stream 1
 SLAM_DEV float stratum(const RngArgs &rng, int64_t gid) {
     if (rng.mode == 0) return rng.strata[gid];
@@ -458,8 +463,9 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             ctrl->wsq = Q;
             ctrl->neff = neff;
             ctrl->resampled = pend ? 1 : 0;
+            ctrl->status = weight_status(W, Q);
             ws.est_part[ws.wpar ^ 1][4 * (size_t) nb] = (double) neff;  // travels with the partials into the history
-            ws.est_part[ws.wpar ^ 1][4 * (size_t) nb + 1] = pend ? 1.0 : 0.0;
+            ws.est_part[ws.wpar ^ 1][4 * (size_t) nb + 1] = (double) ((pend ? 1 : 0) | (weight_status(W, Q) << 1));
         }
         __syncthreads();
     }
@@ -951,8 +957,9 @@ __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScrat
         ctrl->wsq = Q;
         ctrl->neff = neff;
         ctrl->resampled = resample ? 1 : 0;
+        ctrl->status = weight_status(W, Q);
         ws.est_part[ws.wpar][4 * (size_t) nb] = (double) neff;  // travels with the partials into the history
-        ws.est_part[ws.wpar][4 * (size_t) nb + 1] = resample ? 1.0 : 0.0;
+        ws.est_part[ws.wpar][4 * (size_t) nb + 1] = (double) ((resample ? 1 : 0) | (weight_status(W, Q) << 1));
         // state for the next launch goes to the OTHER slot (see Ctrl): the set now lives in `cur`, and after a
         // resample it is defined through keep[] until somebody gathers it
         ctrl->live[B.slot ^ 1] = cur;
@@ -1099,7 +1106,7 @@ __global__ void __launch_bounds__(kBlock) estimate_kernel(Buffers B, WeightScrat
         p[3] = (double) ei.w;
         if (blockIdx.x == 0) {  // the resampling record that goes with a history entry: the last update's
             ws.est_part[ws.wpar][4 * (size_t) ws.nblocks] = (double) B.ctrl->neff;
-            ws.est_part[ws.wpar][4 * (size_t) ws.nblocks + 1] = (double) B.ctrl->resampled;
+            ws.est_part[ws.wpar][4 * (size_t) ws.nblocks + 1] = (double) (B.ctrl->resampled | (B.ctrl->status << 1));
         }
     }
 }
@@ -1122,6 +1129,37 @@ __global__ void __launch_bounds__(kBlock) jacobians_kernel(const float *__restri
     o[2] = j.hf00; o[3] = j.hf01; o[4] = j.hf10; o[5] = j.hf11;
     o[6] = j.hv00; o[7] = j.hv01; o[8] = 0.0f; o[9] = j.hv10; o[10] = j.hv11; o[11] = -1.0f;
     o[12] = j.s00; o[13] = j.s01; o[14] = j.s10; o[15] = j.s11;
+}
+
+// Known-answer entry point (slamgpu_kat): the scalar device functions of THIS build against the reference's edge-case
+// vectors (tests/golden/kat_functions.npz): op 0 trigonometricOffset (core.cpp:460-477; the fast build's wrap_pi),
+// op 1 / 2 gaussEvaluate for D = 2 / 3 (fastslam2.cpp:127-163) in the form the update kernel evaluates it.
+__global__ void __launch_bounds__(kBlock) kat_kernel(int op, const float *__restrict__ in, int n, float *__restrict__ out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    if (op == 0) {
+#ifdef SLAM_FAST_MATH
+        out[i] = wrap_pi(in[i]);
+#else
+        out[i] = trig_offset(in[i]);
+#endif
+    } else if (op == 1) {
+        const float *p = in + 5 * (size_t) i;  // v0 v1 s00 s10 s11
+#ifdef SLAM_FAST_MATH
+        const Gauss2 g = gauss2_parts(p[2], p[3], p[4], p[0], p[1]);
+        out[i] = __expf(g.E) * g.norm;
+#else
+        out[i] = gauss2(p[0], p[1], p[2], p[3], p[4]);
+#endif
+    } else {
+        const float *p = in + 9 * (size_t) i;  // v0 v1 v2 a00 a10 a11 a20 a21 a22
+#ifdef SLAM_FAST_MATH
+        const L3r L = llt3r(Sym3{p[3], p[4], p[5], p[6], p[7], p[8]});
+        out[i] = __expf(gauss3_exponent(L, p[0], p[1], p[2])) * (0.15915494309189535f * ((L.r0 * L.r1) * L.r2));
+#else
+        out[i] = gauss3(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8]);
+#endif
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1150,6 +1188,8 @@ __global__ void __launch_bounds__(kBlock) shard_plan_kernel(ShardPlanArgs A, Rng
         out->wsq = Q;
         out->neff = neff;
         out->resampled = (A.do_resample && (neff < (float) A.n_effective)) ? 1 : 0;
+        out->status = weight_status(W, Q);
+        out->pad = 0;
     }
     // K[r] = #{ k : stratum_k * W < C_r },  C_r = off[r * nb_per_shard]; strata are increasing in k
     for (int r = t; r <= A.n_shards; r += kBlock) {
@@ -1340,8 +1380,9 @@ __global__ void __launch_bounds__(kBlock) shard_finalize_kernel(Buffers B, Weigh
         c->wsq = Q;
         c->neff = neff;
         c->resampled = resampled;
+        c->status = weight_status(W, Q);
         ws.est_part[ws.wpar][4 * (size_t) ws.nblocks] = (double) neff;
-        ws.est_part[ws.wpar][4 * (size_t) ws.nblocks + 1] = (double) resampled;
+        ws.est_part[ws.wpar][4 * (size_t) ws.nblocks + 1] = (double) (resampled | (weight_status(W, Q) << 1));
         // published in the other slot; the host flips its slot after this launch (see Ctrl)
         c->live[B.slot ^ 1] = mode == 2 ? cur ^ 1 : cur;
         c->pend[B.slot ^ 1] = mode == 1 ? 1 : 0;
@@ -1405,7 +1446,8 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
     // pending lazy gather (they exit at once when nothing is pending: the host cannot know) and one helper block
     int grid = B.ncap / kBlock;
     if (U.lazy) grid += (U.copy_hi - U.copy_lo) + 1;
-    const size_t lds = U.scan_global ? 0 : sizeof(double) * ((size_t) ws.nblocks + 1);  // inline plan: prefix of the block totals
+    // inline plan only: prefix of the previous step's block totals (launches that do not plan never touch off[])
+    const size_t lds = (U.plan_inline && !U.scan_global) ? sizeof(double) * ((size_t) ws.nblocks + 1) : 0;
     if (U.method == 2) {
         if (U.arrivals)
             hipLaunchKernelGGL((update_kernel<2, true>), dim3(grid), dim3(kBlock), lds, st, B, PA, U, rng, ws);
@@ -1469,7 +1511,11 @@ static void launch_jacobians(hipStream_t st, const float *in, uint32_t n, float 
     hipLaunchKernelGGL(jacobians_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, in, n, out);
 }
 
-static const KernelTable kTable = {launch_update, launch_resample, launch_scan, launch_gather, launch_flatten, launch_identity, launch_finish, launch_predict, launch_estimate, launch_jacobians,
+static void launch_kat(hipStream_t st, int op, const float *in, int n, float *out) {
+    hipLaunchKernelGGL(kat_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, op, in, n, out);
+}
+
+static const KernelTable kTable = {launch_update, launch_resample, launch_scan, launch_gather, launch_flatten, launch_identity, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat,
                                    launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish};
 
 }  // namespace SLAM_KNS

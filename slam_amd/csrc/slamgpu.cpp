@@ -316,6 +316,17 @@ int flush_predict(slamgpu_ctx *c) {
     return 0;
 }
 
+// A fetch that took fewer entries than were recorded (max_count < hist_n) keeps the rest: the unfetched tail moves to
+// the front of the device-side history (all stages have been flushed: nothing points into it).
+int keep_history_tail(slamgpu_ctx *c, const std::vector<double> &h, int taken) {
+    const int left = c->hist_n - taken;
+    if (left > 0 && taken > 0)
+        HIP_TRY(hipMemcpy(c->hist_dev, h.data() + (size_t) kHistStride * taken, sizeof(double) * kHistStride * (size_t) left,
+                          hipMemcpyHostToDevice));
+    c->hist_n = left > 0 ? left : 0;
+    return 0;
+}
+
 int check_ctx(slamgpu_ctx *c) {
     if (!c) return fail(SLAMGPU_ERR_INVALID, "null context");
     return 0;
@@ -1000,15 +1011,14 @@ int slamgpu_shard_estimate_fetch(slamgpu_ctx *c, double *raw4, int32_t max_count
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = flush_stages(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    const int n = c->hist_n < max_count ? c->hist_n : max_count;
-    if (n > 0 && raw4) {
-        std::vector<double> h((size_t) kHistStride * n);
-        HIP_TRY(hipMemcpy(h.data(), c->hist_dev, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    const int n = c->hist_n < std::max(max_count, 0) ? c->hist_n : std::max(max_count, 0);
+    std::vector<double> h((size_t) kHistStride * (c->hist_n > 0 ? c->hist_n : 1));
+    if (c->hist_n > 0) HIP_TRY(hipMemcpy(h.data(), c->hist_dev, sizeof(double) * kHistStride * (size_t) c->hist_n, hipMemcpyDeviceToHost));
+    if (raw4)
         for (int i = 0; i < n; i++)
             for (int k = 0; k < 4; k++) raw4[4 * (size_t) i + k] = h[(size_t) kHistStride * i + k];
-    }
     *count = n;
-    c->hist_n = 0;
+    if (int rc = keep_history_tail(c, h, n)) return rc;
     c->est_fresh = false;
     return 0;
 }
@@ -1068,15 +1078,16 @@ int slamgpu_estimate_async(slamgpu_ctx *c) {
     return 0;
 }
 
-int slamgpu_history_fetch(slamgpu_ctx *c, double *xyt, float *neff, int32_t *resampled, int32_t max_count, int32_t *count) {
+int slamgpu_history_fetch(slamgpu_ctx *c, double *xyt, float *neff, int32_t *resampled, int32_t *status, int32_t max_count,
+                          int32_t *count) {
     if (int rc = check_ctx(c)) return rc;
     if (!count) return fail(SLAMGPU_ERR_INVALID, "null count");
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = flush_stages(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    const int n = c->hist_n < max_count ? c->hist_n : max_count;
-    std::vector<double> h((size_t) kHistStride * (n > 0 ? n : 1));
-    if (n > 0) HIP_TRY(hipMemcpy(h.data(), c->hist_dev, sizeof(double) * kHistStride * (size_t) n, hipMemcpyDeviceToHost));
+    const int n = c->hist_n < std::max(max_count, 0) ? c->hist_n : std::max(max_count, 0);
+    std::vector<double> h((size_t) kHistStride * (c->hist_n > 0 ? c->hist_n : 1));
+    if (c->hist_n > 0) HIP_TRY(hipMemcpy(h.data(), c->hist_dev, sizeof(double) * kHistStride * (size_t) c->hist_n, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; i++) {
         const double *e = h.data() + (size_t) kHistStride * i;
         if (xyt) {
@@ -1085,16 +1096,17 @@ int slamgpu_history_fetch(slamgpu_ctx *c, double *xyt, float *neff, int32_t *res
             xyt[3 * i + 2] = e[2];
         }
         if (neff) neff[i] = (float) e[4];
-        if (resampled) resampled[i] = (int32_t) e[5];
+        if (resampled) resampled[i] = ((int32_t) e[5]) & 1;
+        if (status) status[i] = ((int32_t) e[5]) >> 1;
     }
     *count = n;
-    c->hist_n = 0;
+    if (int rc = keep_history_tail(c, h, n)) return rc;
     c->est_fresh = false;
     return 0;
 }
 
 int slamgpu_estimate_fetch(slamgpu_ctx *c, double *xyt, int32_t max_count, int32_t *count) {
-    return slamgpu_history_fetch(c, xyt, nullptr, nullptr, max_count, count);
+    return slamgpu_history_fetch(c, xyt, nullptr, nullptr, nullptr, max_count, count);
 }
 
 int slamgpu_stats(slamgpu_ctx *c, float *neff, int32_t *resampled, double *weight_sum) {
@@ -1103,6 +1115,14 @@ int slamgpu_stats(slamgpu_ctx *c, float *neff, int32_t *resampled, double *weigh
     if (neff) *neff = c->ctrl_host->neff;
     if (resampled) *resampled = c->ctrl_host->resampled;
     if (weight_sum) *weight_sum = c->ctrl_host->wsum;
+    return 0;
+}
+
+int slamgpu_step_status(slamgpu_ctx *c, int32_t *status) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!status) return fail(SLAMGPU_ERR_INVALID, "null output");
+    if (int rc = read_ctrl(c)) return rc;
+    *status = c->ctrl_host->status;
     return 0;
 }
 
@@ -1235,7 +1255,7 @@ int slamgpu_upload(slamgpu_ctx *c, int32_t nf, const float *xv, const float *Pv9
     }
     // every landmark row live in buffer 0, every record in its particle's own slot
     c->pool_used = 0;
-    HIP_TRY(hipMemset(c->B.lmk_live[c->lslot], 0, sizeof(int32_t) * c->B.cap_nf));
+    HIP_TRY(hipMemsetAsync(c->B.lmk_live[c->lslot], 0, sizeof(int32_t) * c->B.cap_nf, c->stream));
     c->B.slot = c->slot;
     c->B.lslot = c->lslot;
     c->k->identity(c->stream, c->B, cur);
@@ -1316,6 +1336,31 @@ int slamgpu_jacobians(const float *in, uint32_t n, float *out) {
         if ((e = hipGetLastError()) != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "launch: %s", hipGetErrorString(e));
     }
     if (!rc && (e = hipMemcpy(out, dout, sizeof(float) * nout, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "D2H: %s", hipGetErrorString(e));
+    (void) hipFree(din);
+    (void) hipFree(dout);
+    return rc;
+}
+
+int slamgpu_kat(int32_t math_mode, int32_t op, const float *in, int32_t n, float *out) {
+    if (op < 0 || op > 2 || n < 0 || (n > 0 && (!in || !out))) return fail(SLAMGPU_ERR_INVALID, "bad arguments");
+    if (n == 0) return 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SLAMGPU_ERR_NO_DEVICE, "no HIP device: libslamgpu has no CPU fallback");
+    const size_t per = op == 0 ? 1 : (op == 1 ? 5 : 9);
+    float *din = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc((void **) &din, sizeof(float) * per * n));
+    hipError_t e = hipMalloc((void **) &dout, sizeof(float) * n);
+    if (e != hipSuccess) {
+        (void) hipFree(din);
+        return fail(SLAMGPU_ERR_ALLOC, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    int rc = 0;
+    if ((e = hipMemcpy(din, in, sizeof(float) * per * n, hipMemcpyHostToDevice)) != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "H2D: %s", hipGetErrorString(e));
+    if (!rc) {
+        (math_mode == SLAMGPU_MATH_FAST ? kernels_fast() : kernels_strict())->kat(nullptr, op, din, n, dout);
+        if ((e = hipGetLastError()) != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "launch: %s", hipGetErrorString(e));
+    }
+    if (!rc && (e = hipMemcpy(out, dout, sizeof(float) * n, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "D2H: %s", hipGetErrorString(e));
     (void) hipFree(din);
     (void) hipFree(dout);
     return rc;

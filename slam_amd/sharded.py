@@ -165,6 +165,31 @@ class TorchComm:
         # True when the engines launch on torch's current stream (slamgpu_config.external_stream): RCCL collectives
         # enqueued through torch are then ordered with the kernels without host synchronisation
         self.stream_ordered = stream_ordered
+        self.engines = []  # registered by ShardedFilter
+
+    def _is_gpu(self):
+        return self.device.type == "cuda"
+
+    def _before(self):
+        # engines on streams of their own: what they enqueued (block totals, packed offspring) must have landed before
+        # the collective, which torch orders on ITS current stream, may read it
+        if self._is_gpu() and not self.stream_ordered:
+            for e in self.engines:
+                e.sync()
+
+    def _after(self):
+        # ... and the collective must have finished before the engines' kernels read what it produced
+        if self._is_gpu() and not self.stream_ordered:
+            self.torch.cuda.current_stream(self.device).synchronize()
+
+    def check_engine(self, e):
+        """stream_ordered promises that the engine launches on the stream torch orders the collectives on"""
+        if self._is_gpu() and self.stream_ordered and getattr(e, "is_gpu", False):
+            cur = self.torch.cuda.current_stream(self.device).cuda_stream
+            if (e.ctx.stream() or 0) != cur or cur == 0:
+                raise RuntimeError("TorchComm(stream_ordered=True): the engine's HIP stream (%#x) is not torch's current "
+                                   "stream (%#x): create the context with external_stream=torch.cuda.current_stream().cuda_stream "
+                                   "on an explicit non-default stream" % (e.ctx.stream() or 0, cur))
 
     def alloc(self, engine, nfloats):
         return self.torch.zeros(max(int(nfloats), 1), dtype=self.torch.float32, device=self.device)
@@ -180,12 +205,16 @@ class TorchComm:
         if getattr(self, "_ag_key", None) != key:  # the step loop gathers the same two buffers every time: keep the views
             self._ag_key = key
             self._ag_views = (global_bufs[0][: nfloats_each * self.world], local_bufs[0][:nfloats_each])
+        self._before()
         self.dist.all_gather_into_tensor(*self._ag_views)
+        self._after()
 
     def all_to_all(self, send_bufs, send_counts, recv_bufs, recv_counts):
         sc = [int(x) for x in send_counts[0]]
         rc = [int(x) for x in recv_counts[0]]
+        self._before()
         self.dist.all_to_all_single(recv_bufs[0][: sum(rc)], send_bufs[0][: sum(sc)], output_split_sizes=rc, input_split_sizes=sc)
+        self._after()
 
     def all_gather_small(self, local_vecs):
         t = self.torch.tensor(np.asarray(local_vecs[0], np.float64), dtype=self.torch.float64, device=self.device)
@@ -205,6 +234,10 @@ class ShardedFilter:
 
     def __init__(self, engines, comm, n_shards):
         self.engines, self.comm, self.G = engines, comm, n_shards
+        if hasattr(comm, "check_engine"):
+            comm.engines = list(engines)
+            for e in engines:
+                comm.check_engine(e)
         self.nb_local = engines[0].nblocks()
         self.nb_global = self.nb_local * n_shards
         self.n = engines[0].n

@@ -1,0 +1,66 @@
+"""The drop-in binary on the GPU: slam_amd/bin/slam-backend -method FASTSLAM{1,2} (the reference's command line,
+SLAMBackendApplication.cpp:40-89) restates FastSLAM{1,2}Wrapper::run (fastslam2wrapper.cpp:31-122,
+fastslam1wrapper.cpp:32-113) in C++ over the slamgpu C ABI.  With -rng parity it feeds the libc rand() tape in the
+reference's draw order, so its logged per-step estimates (ParticleSLAMWrapper::computeEstimatedPosition) must follow the
+reference's golden trajectory: to 1 mm until the first resample whose ancestors may differ at a cumulative-sum boundary,
+statistically (error against the true path no worse than the reference's) afterwards."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import DATA, load_golden
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(DATA)
+EXE = os.path.join(ROOT, "slam_amd", "bin", "slam-backend")
+
+
+def run_backend(tmp_path, method, math, extra=(), maxsteps=4000):
+    log = str(tmp_path / ("%s_%s.csv" % (method, math)))
+    cmd = [EXE, "-m", os.path.join(DATA, "example_webmap.mat"), "-method", method, "-rng", "parity", "-math", math,
+           "-NPARTICLES", "100", "-NEFFECTIVE", "75", "-SWITCH_SEED_RANDOM", "7", "-log", log, "-maxsteps", str(maxsteps), *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+    rows = np.loadtxt(log, delimiter=",", skiprows=1)
+    return r.stdout, rows
+
+
+@pytest.mark.parametrize("math", ["strict", "fast"])
+@pytest.mark.parametrize("method,golden", [("FASTSLAM2", "traj_fs2_webmap_N100_s7"), ("FASTSLAM1", "traj_fs1_webmap_N100_s7")])
+def test_slam_backend_follows_the_reference_trajectory(tmp_path, method, golden, math):
+    g = load_golden(golden)
+    maxsteps = 4000
+    out, rows = run_backend(tmp_path, method, math, maxsteps=maxsteps)
+    assert ("FastSLAM 2" if method == "FASTSLAM2" else "FastSLAM 1") in out and "control steps %d" % maxsteps in out
+    assert rows.shape == (maxsteps, 8)
+    # golden `ctl`[k] = control-step index (1-based iteration) at which observation step k happened
+    ctl = g["ctl"]
+    nobs = int((ctl <= maxsteps).sum())
+    assert nobs >= 400
+    est = rows[ctl[:nobs] - 1, 4:7]  # estimate logged at the control step of each observation
+    true = rows[ctl[:nobs] - 1, 1:4]
+    assert np.abs(true - g["true"][:nobs]).max() <= 1e-4  # the simulator front end reproduces the reference's true path
+    d = np.hypot(est[:, 0] - g["est"][:nobs, 0], est[:, 1] - g["est"][:nobs, 1])
+    first_res = int(np.argmax(g["resampled"][:nobs])) if g["resampled"][:nobs].any() else nobs
+    assert first_res >= 3
+    assert d[:first_res + 1].max() <= 1e-3, (first_res, d[:first_res + 1].max())
+    # FastSLAM1's weights are well conditioned: ancestors stay identical and so does the whole trajectory
+    if method == "FASTSLAM1":
+        assert d.max() <= 5e-3, d.max()
+    err_g = np.hypot(est[:, 0] - true[:, 0], est[:, 1] - true[:, 1])
+    err_r = np.hypot(g["est"][:nobs, 0] - g["true"][:nobs, 0], g["est"][:nobs, 1] - g["true"][:nobs, 1])
+    assert err_g.mean() <= 1.5 * err_r.mean() + 0.05, (err_g.mean(), err_r.mean())
+
+
+def test_slam_backend_philox_full_run_tracks_the_true_path(tmp_path):
+    """The throughput configuration of the binary (Philox noise, fast build) over the whole example_webmap run."""
+    log = str(tmp_path / "philox.csv")
+    r = subprocess.run([EXE, "-m", os.path.join(DATA, "example_webmap.mat"), "-method", "FASTSLAM2", "-NPARTICLES", "4096",
+                        "-NEFFECTIVE", "3072", "-SWITCH_SEED_RANDOM", "7", "-log", log], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+    rows = np.loadtxt(log, delimiter=",", skiprows=1)
+    assert rows.shape[0] > 17000 and "landmarks in map: 35" in r.stdout
+    err = np.hypot(rows[:, 4] - rows[:, 1], rows[:, 5] - rows[:, 2])
+    assert np.isfinite(err).all() and err.mean() < 1.0, err.mean()

@@ -69,8 +69,22 @@ def sym(P):
 #               the median can reach 6.5e-3 (a 6-landmark step), hence the per-step bound of 1e-2; a weight error eps
 #               moves about N * eps strata across a cumulative-sum boundary, so ONE step at N=100 can swap 9 % of the
 #               ancestors (bound 15 %) while the average over the run is 3-4 %.
-W_TOL = {0: dict(median=1e-3, p99=5e-2, max=0.3, tv=2e-2, ancestors=0.04),
-         1: dict(median=1e-2, p99=1e-1, max=0.5, tv=3e-2, ancestors=0.15)}
+W_TOL = {0: dict(median=1e-3, p99=5e-2, max=0.16, tv=1e-2, ancestors=0.04),
+         1: dict(median=1e-2, p99=1e-1, max=0.25, tv=2e-2, ancestors=0.15)}
+# The bounds above hold for EVERY step (a single 6-landmark step has been seen at median 6.5e-3 in the fast build).
+# Over a whole run the deviations pool much lower; these aggregate bounds are 2x what tools/parity_report.py measured on
+# MI355X (strict: median 1.1e-4, p99 1.05e-2, max 8.1e-2, ancestors 0.7 % at N=100 / 1.5 % at N=1000; fast: median
+# 1.7e-3, p99 3.6e-2, max 1.1e-1, ancestors 3.2-3.9 %), so a regression that doubles the error fails.
+W_AGG = {0: dict(median=2.5e-4, p99=2.2e-2, max=0.16, ancestors=0.03),
+         1: dict(median=4e-3, p99=7e-2, max=0.25, ancestors=0.08)}
+
+
+def weight_errors(got, exp, math_mode):
+    """|w_gpu / w_ref - 1| per particle; the fast build on normalised weights (see compare_weights)"""
+    g, e = got.astype(np.float64), exp.astype(np.float64)
+    if math_mode == 1:
+        g, e = g / g.sum(), e / e.sum()
+    return np.abs(g / e - 1.0)
 
 
 def compare_weights(got, exp, fs2, tag="", math_mode=0):
@@ -85,7 +99,7 @@ def compare_weights(got, exp, fs2, tag="", math_mode=0):
         # rotations of one matrix and the rounding error of its Cholesky shifts every weight by the same fraction
         # (seen: 0.7 % at a 6-landmark step), which normalisation removes.
         sg_, se_ = got.sum(dtype=np.float64), exp.sum(dtype=np.float64)
-        assert abs(sg_ / se_ - 1.0) <= 5e-2, (tag, "common factor", sg_ / se_)
+        assert abs(sg_ / se_ - 1.0) <= 2e-2, (tag, "common factor", sg_ / se_)
         rel = np.abs((got.astype(np.float64) / sg_) / (exp.astype(np.float64) / se_) - 1.0)
     assert np.median(rel) <= tol["median"] and np.quantile(rel, 0.99) <= tol["p99"] and rel.max() <= tol["max"], \
         (tag, np.median(rel), np.quantile(rel, 0.99), rel.max())
@@ -218,24 +232,39 @@ def drive_pair(sg, oracle, mapname, method, N, seed, nobs, math_mode=0, per_step
 
 @pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
 @pytest.mark.parametrize("method,N,seed,nobs", [("FASTSLAM2", 100, 7, 120), ("FASTSLAM2", 1000, 1, 40),
-                                                ("FASTSLAM1", 100, 7, 60), ("FASTSLAM2", 5000, 12345, 10)])
+                                                ("FASTSLAM1", 100, 7, 60), ("FASTSLAM1", 1000, 7, 40),
+                                                ("FASTSLAM2", 5000, 12345, 10)])
 def test_stepwise_vs_oracle(sg, oracle, method, N, seed, nobs, math_mode):
     """Both kernel builds (strict: no FMA contraction, IEEE divide/sqrt; fast: contraction + the 1-ulp hardware
     v_rcp_f32 / v_sqrt_f32 and the restructured arithmetic) meet the same pose / landmark / covariance tolerances; the
-    weight tolerances are per build (W_TOL)."""
+    weight tolerances are per build: W_TOL for every single step, W_AGG (2x the measured figures) over the run.
+    FASTSLAM1 N=1000 is BASELINE configs[1] at its real size (the reference resamples for N=1000, core.cpp:751-763)."""
+    fs2 = method == "FASTSLAM2"
+    rels, anc_bad, anc_tot = [], 0, 0
+
     def check(r):
+        nonlocal anc_bad, anc_tot
         tag = "%s N=%d obs %d (m=%d n=%d)" % (method, N, r["k"], r["m"], r["n"])
         assert r["did"][0] == r["did"][1], tag
-        fs2 = method == "FASTSLAM2"
         np.testing.assert_allclose(r["neff"][0], r["neff"][1], rtol=2e-2 if fs2 else 1e-4, err_msg=tag)
         if r["did"][0]:
             bad = np.abs(r["got"]["xv"] - r["exp"]["xv"]).max(axis=1) > POSE_ATOL
             assert bad.mean() <= (W_TOL[math_mode]["ancestors"] if fs2 else 0.0), (tag, bad.mean())
+            anc_bad += int(bad.sum())
+            anc_tot += bad.size
         else:
             compare_state(r["got"], r["exp"], fs2=fs2, tag=tag, math_mode=math_mode)
+            if fs2 and r["m"] > 0:
+                rels.append(weight_errors(r["got"]["w"], r["exp"]["w"], math_mode))
         # after a resample a few particles may descend from a neighbouring ancestor (see header): mean moves by <= frac * spread
         np.testing.assert_allclose(r["est"][0][:2], r["est"][1][:2], atol=1e-2 if r["did"][0] else 5e-4, err_msg=tag)
     drive_pair(sg, oracle, "example_webmap", method, N, seed, nobs, math_mode=math_mode, per_step=check)
+    if fs2 and rels:
+        rel, agg = np.concatenate(rels), W_AGG[math_mode]
+        assert np.median(rel) <= agg["median"] and np.quantile(rel, 0.99) <= agg["p99"] and rel.max() <= agg["max"], \
+            ("aggregate", np.median(rel), np.quantile(rel, 0.99), rel.max())
+        if anc_tot:
+            assert anc_bad / anc_tot <= agg["ancestors"], ("aggregate ancestors", anc_bad / anc_tot)
 
 
 def test_fast_build_vs_float64_yardstick(sg, oracle):
@@ -261,7 +290,8 @@ def test_fast_build_vs_float64_yardstick(sg, oracle):
     assert np.median(e_ref) >= 3e-4  # the yardstick really is this coarse: float32 FastSLAM2 weights carry ~1e-3 noise
 
 
-def test_free_running_statistics(sg, oracle):
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+def test_free_running_statistics(sg, oracle, math_mode):
     """Free-running (no teacher forcing) GPU run driven by the oracle front end's controls/observations and tape:
     trajectories decorrelate after the first differing ancestor, so this checks the filter's behaviour, not bits:
     the estimated path must track the true path as well as the reference's does."""
@@ -269,7 +299,8 @@ def test_free_running_statistics(sg, oracle):
     o = oracle.sim(sim_args("example_webmap", "FASTSLAM2", N, seed))
     algo = o.algo()
     Q, R, dt = o.noise()
-    s = sg.SlamGpu(N, o.nlm, method=2, n_effective=algo.n_effective, wheel_base=algo.wheel_base, rng_mode=sg.RNG_TAPE)
+    s = sg.SlamGpu(N, o.nlm, method=2, n_effective=algo.n_effective, wheel_base=algo.wheel_base, rng_mode=sg.RNG_TAPE,
+                   math_mode=math_mode)
     err_g, err_o, first_div = [], [], None
     k = 0
     while k < 400:
@@ -293,7 +324,8 @@ def test_free_running_statistics(sg, oracle):
     assert np.mean(err_g) < 1.5 * np.mean(err_o) + 0.05, (np.mean(err_g), np.mean(err_o))
 
 
-def test_many_landmarks_big_packet_path(sg, oracle, tmp_path):
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+def test_many_landmarks_big_packet_path(sg, oracle, tmp_path, math_mode):
     """BASELINE config 5 shape in miniature: a synthetic uniform map (400 landmarks on the webmap bounding box,
     MAX_RANGE 60 => dozens of re-observed landmarks per step) drives the device-resident packet path (m, n > 12),
     blockIdx.y > 1 in the resample gather, and landmark capacity growth; checked per step against the oracle."""
@@ -316,7 +348,8 @@ def test_many_landmarks_big_packet_path(sg, oracle, tmp_path):
     o = oracle.sim(args)
     algo = o.algo()
     Q, R, dt = o.noise()
-    s = sg.SlamGpu(N, o.nlm, method=2, n_effective=algo.n_effective, wheel_base=algo.wheel_base, rng_mode=sg.RNG_TAPE)
+    s = sg.SlamGpu(N, o.nlm, method=2, n_effective=algo.n_effective, wheel_base=algo.wheel_base, rng_mode=sg.RNG_TAPE,
+                   math_mode=math_mode)
     k, max_m = 0, 0
     while k < 10:
         a = o.control()
@@ -342,15 +375,16 @@ def test_many_landmarks_big_packet_path(sg, oracle, tmp_path):
                 fin = np.isfinite(exp["w"]) & (exp["w"] > 0)
                 assert np.array_equal(np.isfinite(got["w"]), np.isfinite(exp["w"])), k
                 if fin.any():
-                    rel = np.abs(got["w"][fin].astype(np.float64) / exp["w"][fin] - 1)
-                    assert np.median(rel) <= 5e-3, (k, np.median(rel))
+                    rel = weight_errors(got["w"][fin], exp["w"][fin], math_mode)
+                    assert np.median(rel) <= (5e-3 if math_mode == 0 else 2e-2), (k, np.median(rel))
             s.upload(exp)
     assert max_m > 12  # the big-packet path was exercised
     s.close()
     o.close()
 
 
-def test_full_size_philox_vs_oracle(sg, oracle):
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+def test_full_size_philox_vs_oracle(sg, oracle, math_mode):
     """BASELINE configs[2] size (100 000 particles, example_webmap) in the throughput RNG mode: the device's
     Philox4x32-10 + Box-Muller stream against the oracle's restatement of the same generator, teacher-forced for
     the first observation steps, plus the size-independent invariants of the update."""
@@ -359,7 +393,8 @@ def test_full_size_philox_vs_oracle(sg, oracle):
     o.set_rng(1, 7)  # particle noise from Philox(seed 7); control / sensor noise from libc rand() as always
     algo = o.algo()
     Q, R, dt = o.noise()
-    s = sg.SlamGpu(N, o.nlm, method=2, n_effective=algo.n_effective, wheel_base=algo.wheel_base, rng_mode=sg.RNG_PHILOX, seed=7)
+    s = sg.SlamGpu(N, o.nlm, method=2, n_effective=algo.n_effective, wheel_base=algo.wheel_base, rng_mode=sg.RNG_PHILOX, seed=7,
+                   math_mode=math_mode)
     k = 0
     while k < 5:
         a = o.control()
@@ -382,12 +417,14 @@ def test_full_size_philox_vs_oracle(sg, oracle):
                 assert np.all(np.diff(keep) >= 0) and keep.min() >= 0 and keep.max() < N   # monotone ancestors
                 assert np.all(got["w"] == np.float32(1.0) / np.float32(N))
                 bad = np.abs(got["xv"] - exp["xv"]).max(axis=1) > POSE_ATOL
-                assert bad.mean() <= 0.05, (k, bad.mean())
+                assert bad.mean() <= W_AGG[math_mode]["ancestors"] * 1.5, (k, bad.mean())
             else:
-                # same Philox bits; Box-Muller through device libm instead of glibc: poses agree to ~1e-5
+                # same Philox bits; Box-Muller through device libm (fast build: the hardware v_log / v_sin / v_cos) instead of
+                # glibc: poses agree to ~1e-5
                 assert np.abs(got["xv"] - exp["xv"]).max() <= 5e-4, (k, np.abs(got["xv"] - exp["xv"]).max())
-                rel = np.abs(got["w"].astype(np.float64) / exp["w"].astype(np.float64) - 1)
-                assert np.median(rel) <= 2e-3, (k, np.median(rel))
+                rel = weight_errors(got["w"], exp["w"], math_mode)
+                assert np.median(rel) <= W_AGG[math_mode]["median"] * 4 and np.quantile(rel, 0.99) <= W_TOL[math_mode]["p99"], \
+                    (k, np.median(rel), np.quantile(rel, 0.99))
             np.testing.assert_allclose(s.estimate()[:2], o.estimate()[:2], atol=2e-3)
             s.upload(exp)
     s.close()

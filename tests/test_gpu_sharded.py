@@ -143,3 +143,41 @@ def test_sharded_steps_without_downloads_match_single_context(G, pool_cap, monke
     for key in ("xv", "Pv", "w", "xf", "Pf"):
         got = np.concatenate([d[key] for d in ds])
         assert np.array_equal(got.view(np.uint32), ref[key].view(np.uint32)), key
+
+
+def test_config4_size_eight_shards_match_one_context():
+    """BASELINE configs[3] at its real size: FASTSLAM2, 8 shards x 125 184 particles (1 001 472 ~ 10^6; shards are
+    multiples of 256) as logical shards on one GPU (LocalComm: device-to-device copies stand in for the collectives)
+    against ONE context holding all of them (large-context path: scan_kernel): resample decisions, pose estimates
+    and the final particle state bit-identical, headline (fast) build, Philox noise."""
+    import os
+    import slam_amd as sg
+    from slam_amd import host
+    from slam_amd.sharded import GpuEngine, LocalComm, ShardedFilter
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    G, n, nobs = 8, 125184, 60
+    Ntot = n * G
+    tape = host.make_tape(["-m", os.path.join(root, "data", "example_webmap.mat"), "-method", "FASTSLAM2", "-NPARTICLES", Ntot,
+                           "-NEFFECTIVE", int(0.75 * Ntot), "-SWITCH_SEED_RANDOM", 7], max_obs=nobs)
+    Q, R, dt = tape["Q"], tape["R"], float(tape["dt"])
+    ctl = [np.array(st["controls"], np.float32).reshape(-1, 3) for st in tape["steps"]]
+    s = sg.SlamGpu(Ntot, tape["nlm"], method=2, n_effective=int(0.75 * Ntot), rng_mode=sg.RNG_PHILOX, seed=7, math_mode=1)
+    for k, st in enumerate(tape["steps"]):
+        s.step(ctl[k], Q, dt, st["zf"], st["idf"], st["zn"], R)
+    e1, _, r1 = s.history_fetch()
+    ref = s.download()
+    s.close()
+    eng = [GpuEngine(g, G, n, tape["nlm"], method=2, n_effective=int(0.75 * Ntot), rng_mode=sg.RNG_PHILOX, seed=7, math_mode=1)
+           for g in range(G)]
+    flt = ShardedFilter(eng, LocalComm(eng), G)
+    res = [bool(flt.step(ctl[k], Q, dt, st["zf"], st["idf"], st["zn"], R).resampled) for k, st in enumerate(tape["steps"])]
+    est = flt.estimate_fetch()
+    ds = [e.ctx.download() for e in eng]
+    moved = flt.exchanged_records
+    flt.close()
+    assert res == [bool(x) for x in r1] and 5 < sum(res) < nobs
+    assert moved > 0  # offspring really crossed shard boundaries
+    assert np.abs(est - e1).max() < 1e-9
+    for key in ("xv", "Pv", "w", "xf", "Pf"):
+        got = np.concatenate([d[key] for d in ds])
+        assert np.array_equal(got.view(np.uint32), ref[key].view(np.uint32)), key
