@@ -84,6 +84,16 @@ typedef struct {
     /* 0: the context creates its own HIP stream.  Otherwise a hipStream_t owned by the caller (e.g. the stream
      * the caller's RCCL collectives are ordered on); the context launches on it and never destroys it. */
     uint64_t external_stream;
+    /* 1: the context keeps LOG-weights: every weight factor of FastSLAM{1,2}::update enters as its logarithm -- the
+     * reference's own gaussEvaluate(v, S, logflag = 1) branch (fastslam2.cpp:154-160), which upstream never calls --
+     * and resampleParticles (core.cpp:718-749) works on exp(l - max l).  For maps where a step re-observes more than
+     * ~20 landmarks (BASELINE config 5: ~1.3 k): the reference's float32 weight is a product of ~90 per landmark and
+     * overflows to inf there.  w[] of slamgpu_download / _upload then holds log-weights (normalised so that
+     * sum exp(l) = 1 after an update without resampling, log(1/N) after a resample); slamgpu_stats reports
+     * log(sum of the raw weights) as weight_sum.  Single contexts only (not shards).  0 (default): the reference's
+     * linear float32 weights, bit-compatible with rounds before this flag existed. */
+    int32_t log_weights;
+    int32_t reserved0;
 } slamgpu_config;
 
 const char *slamgpu_last_error(void);
@@ -165,6 +175,10 @@ int slamgpu_num_landmarks(slamgpu_ctx *ctx);
 /* Particle-major host copies (any pointer may be NULL): xv[3N], Pv[9N] row-major, w[N],
  * xf[2*Nf*N], Pf[4*Nf*N] row-major — the layout of vector<Particle> flattened. Synchronises. */
 int slamgpu_download(slamgpu_ctx *ctx, float *xv, float *Pv9, float *w, float *xf, float *Pf4);
+/* The same for particles [first, first + count) only: what a plot sink with decimation, or a check of a context too
+ * large to copy whole (config 5: 24 GB of landmark records), needs. */
+int slamgpu_download_range(slamgpu_ctx *ctx, int32_t first, int32_t count, float *xv, float *Pv9, float *w, float *xf,
+                           float *Pf4);
 int slamgpu_upload(slamgpu_ctx *ctx, int32_t nf, const float *xv, const float *Pv9, const float *w, const float *xf,
                    const float *Pf4);
 int slamgpu_sync(slamgpu_ctx *ctx);

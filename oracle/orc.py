@@ -231,6 +231,11 @@ class Particles:
         self.L.orc_estimate(self.h, _p(e))
         return e
 
+    def set_log_weights(self, on=True):
+        """log-weight extension (slam_oracle.c: orc_particles_set_log_weights): w[] becomes log-weights"""
+        self.L.orc_particles_set_log_weights.argtypes = [C.c_void_p, C.c_int]
+        self.L.orc_particles_set_log_weights(self.h, int(on))
+
     def predict(self, algo, V, G, Q, dt, phi_true=0.0, noise2=None):
         self.L.orc_predict(self.h, C.byref(algo), C.c_float(V), C.c_float(G), _p(np.ascontiguousarray(Q, f32)),
                            C.c_float(dt), C.c_float(phi_true), _p(noise2))
@@ -285,6 +290,9 @@ class OrcSim(Sim):
 
     def set_rng(self, mode, seed):
         self.L.orc_sim_set_rng(self.h, mode, seed)
+
+    def set_log_weights(self, on=True):
+        self.P.set_log_weights(on)
 
     def nf(self):
         return self.P.nf()

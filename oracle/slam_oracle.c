@@ -553,10 +553,12 @@ void orc_fs1_predict_state(float *xv, float V, float G, const float *Q4, float w
     xv[2] = x2;
 }
 
-float orc_fs1_compute_weight(const float *xv, const float *xf, const float *Pf4, const float *zf, const int *idf,
-                             int m, const float *R4) {
+/* logw: the LOG of the same product, each factor entering as q - log(den) (log-weight extension, see orc_particles) */
+static double fs1_compute_weight(const float *xv, const float *xf, const float *Pf4, const float *zf, const int *idf,
+                                 int m, const float *R4, int logw) {
     /* fastslam1.cpp:91-118 */
     float w = 1.0f;
+    double dl = 0.0;
     for (int i = 0; i < m; i++) {
         float zp[2], Hv[6], Hf[4], S[4], Si[4], v[2];
         jac1(xv, R4, xf + 2 * idf[i], Pf4 + 4 * idf[i], zp, Hv, Hf, S);
@@ -568,10 +570,19 @@ float orc_fs1_compute_weight(const float *xv, const float *xf, const float *Pf4,
         float t0 = -0.5f * ((0.0f + v[0] * Si[0]) + v[1] * Si[2]);
         float t1 = -0.5f * ((0.0f + v[0] * Si[1]) + v[1] * Si[3]);
         float q = t0 * v[0] + t1 * v[1];
-        float num = expf(q);
-        w = w * num / den;
+        if (logw) {
+            dl += (double) (q - logf(den));
+        } else {
+            float num = expf(q);
+            w = w * num / den;
+        }
     }
-    return w;
+    return logw ? dl : (double) w;
+}
+
+float orc_fs1_compute_weight(const float *xv, const float *xf, const float *Pf4, const float *zf, const int *idf,
+                             int m, const float *R4) {
+    return (float) fs1_compute_weight(xv, xf, Pf4, zf, idf, m, R4, 0);
 }
 
 void orc_feature_update(const float *xv, float *xf, float *Pf4, const float *zf, const int *idf, int m,
@@ -587,8 +598,10 @@ void orc_feature_update(const float *xv, float *xf, float *Pf4, const float *zf,
     }
 }
 
-void orc_fs2_sample_proposal(float *pxv, float *pPv, float *pw, const float *xf, const float *Pf4, const float *zf,
-                             const int *idf, int m, const float *R4, const float *g3) {
+/* logw: *pw is a LOG-weight and every factor enters through gaussEvaluate's own logflag = 1 branch
+ * (fastslam2.cpp:154-160); the sum of the m log-likelihoods is kept in double */
+static void fs2_sample_proposal(float *pxv, float *pPv, float *pw, const float *xf, const float *Pf4, const float *zf,
+                                const int *idf, int m, const float *R4, const float *g3, int logw) {
     /* fastslam2.cpp:290-368 */
     float xv[3], Pv[9], xv0[3], Pv0[9];
     memcpy(xv, pxv, sizeof xv);
@@ -629,17 +642,30 @@ void orc_fs2_sample_proposal(float *pxv, float *pPv, float *pw, const float *xf,
     v2[2] = orc_trig_offset(v2[2]);
     /* likelihoodGivenXv (fastslam2.cpp:370-400) at the sampled pose */
     float lik = 1;
+    double dl = 0.0;
     for (int i = 0; i < m; i++) {
         float zp[2], Hv[6], Hf[4], Sf[4], v[2];
         jac1(pxv, R4, xf + 2 * idf[i], Pf4 + 4 * idf[i], zp, Hv, Hf, Sf);
         v[0] = zf[2 * i] - zp[0];
         v[1] = zf[2 * i + 1] - zp[1];
         v[1] = orc_trig_offset(v[1]);
-        lik = lik * orc_gauss_evaluate(v, Sf, 2, 0);
+        if (logw) dl += (double) orc_gauss_evaluate(v, Sf, 2, 1);
+        else lik = lik * orc_gauss_evaluate(v, Sf, 2, 0);
     }
-    float prior = orc_gauss_evaluate(v1, Pv0, 3, 0);
-    float proposal = orc_gauss_evaluate(v2, Pv, 3, 0);
-    *pw = *pw * lik * prior / proposal;
+    if (logw) {
+        float prior = orc_gauss_evaluate(v1, Pv0, 3, 1);
+        float proposal = orc_gauss_evaluate(v2, Pv, 3, 1);
+        *pw = (float) (((double) *pw + dl) + ((double) prior - (double) proposal));
+    } else {
+        float prior = orc_gauss_evaluate(v1, Pv0, 3, 0);
+        float proposal = orc_gauss_evaluate(v2, Pv, 3, 0);
+        *pw = *pw * lik * prior / proposal;
+    }
+}
+
+void orc_fs2_sample_proposal(float *pxv, float *pPv, float *pw, const float *xf, const float *Pf4, const float *zf,
+                             const int *idf, int m, const float *R4, const float *g3) {
+    fs2_sample_proposal(pxv, pPv, pw, xf, Pf4, zf, idf, m, R4, g3, 0);
 }
 
 /* ============================================================================================
@@ -820,6 +846,7 @@ void orc_philox_predict_tape(uint64_t seed, uint32_t step, int first, int count,
 
 struct orc_particles {
     int N, cap, nf;
+    int logw; /* log-weight extension (orc_particles_set_log_weights): w[] holds log-weights */
     float *w, *xv, *Pv, *xf, *Pf; /* particle-major; xf/Pf strided by cap */
 };
 
@@ -848,6 +875,21 @@ void orc_particles_destroy(orc_particles *p) {
     free(p->Pf);
     free(p);
 }
+
+/* LOG-WEIGHT EXTENSION (not in the reference; mirrors slamgpu_config.log_weights).  The reference's weight is a float32
+ * product of one gaussEvaluate(.., logflag = 0) per re-observed landmark, ~90 each at the bundled noise levels: it
+ * overflows to inf beyond ~20 landmarks per step.  With the flag on, w[] holds log-weights: every factor enters through
+ * the reference's own logflag = 1 branch of gaussEvaluate (fastslam2.cpp:154-160; FastSLAM1: q - log(den)), and
+ * resampleParticles works on exp(l - max l).  Pinned to the reference where the reference can go: gaussEvaluate(logflag=1)
+ * against the reference objects (tests/golden/kat_log.npz) and exp(log-weights) against the linear weights for small m
+ * (tests/test_oracle_golden.py). */
+void orc_particles_set_log_weights(orc_particles *p, int on) {
+    on = on ? 1 : 0;
+    if (on == p->logw) return;
+    for (int i = 0; i < p->N; i++) p->w[i] = on ? logf(p->w[i]) : expf(p->w[i]);
+    p->logw = on;
+}
+int orc_particles_log_weights(const orc_particles *p) { return p->logw; }
 
 int orc_particles_n(const orc_particles *p) { return p->N; }
 int orc_particles_nf(const orc_particles *p) { return p->nf; }
@@ -939,7 +981,7 @@ void orc_update_local(orc_particles *p, const orc_algo *a, const float *zf, cons
         if (a->method == 2) {
             /* fastslam2.cpp:26-45 */
             if (m > 0) {
-                orc_fs2_sample_proposal(xv, Pv, &p->w[i], xf, Pf, zf, idf, m, R4, normals + 3 * i);
+                fs2_sample_proposal(xv, Pv, &p->w[i], xf, Pf, zf, idf, m, R4, normals + 3 * i, p->logw);
                 orc_feature_update(xv, xf, Pf, zf, idf, m, R4);
             }
             if (n > 0) {
@@ -954,9 +996,8 @@ void orc_update_local(orc_particles *p, const orc_algo *a, const float *zf, cons
         } else {
             /* fastslam1.cpp:21-32 */
             if (m > 0) {
-                float w = orc_fs1_compute_weight(xv, xf, Pf, zf, idf, m, R4);
-                w = p->w[i] * w;
-                p->w[i] = w;
+                double w = fs1_compute_weight(xv, xf, Pf, zf, idf, m, R4, p->logw);
+                p->w[i] = p->logw ? (float) ((double) p->w[i] + w) : p->w[i] * (float) w;
                 orc_feature_update(xv, xf, Pf, zf, idf, m, R4);
             }
             if (n > 0) orc_add_feature(xv, zn, n, R4, xf + 2 * p->nf, Pf + 4 * p->nf);
@@ -975,8 +1016,19 @@ void orc_update(orc_particles *p, const orc_algo *a, const float *zf, const int 
     float *w = (float *) malloc(sizeof(float) * (size_t) N);
     int *keep = (int *) malloc(sizeof(int) * (size_t) N);
     memcpy(w, p->w, sizeof(float) * (size_t) N);
+    if (p->logw) {
+        /* log-weights: resampleParticles on exp(l - M), M = max l; normalised log-weight = l - (M + log sum exp(l - M)) */
+        double M = -INFINITY;
+        for (int i = 0; i < N; i++)
+            if ((double) p->w[i] > M) M = (double) p->w[i];
+        for (int i = 0; i < N; i++) w[i] = (p->w[i] == -INFINITY) ? 0.0f : (float) exp((double) p->w[i] - M);
+        double wsd = 0;
+        for (int i = 0; i < N; i++) wsd += (double) w[i];
+        for (int i = 0; i < N; i++) p->w[i] = p->w[i] - (float) (M + log(wsd));
+    } else {
     float ws = orc_eigen_sum(w, N);
     for (int i = 0; i < N; i++) p->w[i] = w[i] / ws;
+    }
     float nEff = 0;
     orc_stratified_resample(w, N, sel, keep, &nEff);
     int did = 0;
@@ -1002,6 +1054,7 @@ void orc_update(orc_particles *p, const orc_algo *a, const float *zf, const int 
             memcpy(p->Pf + (size_t) i * 4 * p->cap, oPf + (size_t) k * 4 * p->cap, sizeof(float) * 4 * (size_t) p->cap);
         }
         float nw = 1.0f / (float) N;
+        if (p->logw) nw = logf(nw);
         for (int i = 0; i < N; i++) p->w[i] = nw;
         free(oxv);
         free(oPv);

@@ -76,6 +76,9 @@ void orc_particles_get(const orc_particles *p, float *xv, float *Pv9, float *w, 
 void orc_particles_set(orc_particles *p, int nf, const float *xv, const float *Pv9, const float *w, const float *xf,
                        const float *Pf4);
 void orc_estimate(const orc_particles *p, double *xyt);             /* ParticleSLAMWrapper.cpp:56-77 */
+/* log-weight extension (mirrors slamgpu_config.log_weights; see slam_oracle.c): w[] becomes log-weights */
+void orc_particles_set_log_weights(orc_particles *p, int on);
+int orc_particles_log_weights(const orc_particles *p);
 
 typedef struct {
     int method;          /* 1 FASTSLAM1, 2 FASTSLAM2 */

@@ -19,7 +19,7 @@ DECLARED_SYMBOLS = [
     "slamgpu_kernel_time", "slamgpu_algorithmic_bytes", "slamgpu_shard_update", "slamgpu_shard_block_totals", "slamgpu_shard_plan",
     "slamgpu_shard_record_floats", "slamgpu_shard_pack", "slamgpu_shard_unpack", "slamgpu_shard_finish", "slamgpu_shard_estimate",
     "slamgpu_dev_alloc", "slamgpu_dev_free", "slamgpu_dev_copy", "slamgpu_dev_copy_async", "slamgpu_shard_estimate_async",
-    "slamgpu_shard_estimate_fetch", "slamgpu_step_status", "slamgpu_kat",
+    "slamgpu_shard_estimate_fetch", "slamgpu_step_status", "slamgpu_kat", "slamgpu_download_range",
 ]
 
 
@@ -34,7 +34,8 @@ class Config(C.Structure):
                 ("max_landmarks", C.c_int32), ("use_heading", C.c_int32), ("add_predict_noise", C.c_int32),
                 ("resample", C.c_int32), ("n_effective", C.c_int32), ("wheel_base", C.c_float), ("sigma_phi", C.c_float),
                 ("rng_mode", C.c_int32), ("math_mode", C.c_int32), ("seed", C.c_uint64), ("first_particle", C.c_int64),
-                ("n_particles_global", C.c_int64), ("external_stream", C.c_uint64)]
+                ("n_particles_global", C.c_int64), ("external_stream", C.c_uint64), ("log_weights", C.c_int32),
+                ("reserved0", C.c_int32)]
 
 
 class ShardPlan(C.Structure):
@@ -81,6 +82,7 @@ def load_library():
     L.slamgpu_ancestors.argtypes = [C.c_void_p, C.c_void_p]
     L.slamgpu_num_landmarks.argtypes = [C.c_void_p]
     L.slamgpu_download.argtypes = [C.c_void_p] * 6
+    L.slamgpu_download_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 5
     L.slamgpu_upload.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 5
     L.slamgpu_sync.argtypes = [C.c_void_p]
     L.slamgpu_stream.argtypes = [C.c_void_p]
@@ -148,7 +150,7 @@ def jacobians(xv, R, xf, Pf):
 def kat(math_mode, op, data):
     """slamgpu_kat: op 0 trig_offset [n], 1 gaussEvaluate D=2 [n,5], 2 gaussEvaluate D=3 [n,9] -> [n]"""
     a = _f32(data)
-    per = {0: 1, 1: 5, 2: 9}[op]
+    per = {0: 1, 1: 5, 2: 9}.get(op, 1)
     n = a.size // per
     out = np.zeros(n, np.float32)
     _chk(load_library().slamgpu_kat(math_mode, op, _ptr(a), n, _ptr(out)))
@@ -160,7 +162,7 @@ class SlamGpu:
 
     def __init__(self, n_particles, max_landmarks, method=FASTSLAM2, n_effective=None, resample=True, use_heading=False,
                  add_predict_noise=None, wheel_base=4.0, sigma_phi=0.017453292519943, rng_mode=RNG_TAPE, seed=0,
-                 math_mode=MATH_STRICT, device=0, first_particle=0, n_particles_global=0, external_stream=0):
+                 math_mode=MATH_STRICT, device=0, first_particle=0, n_particles_global=0, external_stream=0, log_weights=False):
         self.L = load_library()
         cfg = Config()
         cfg.struct_size = C.sizeof(Config)
@@ -181,6 +183,7 @@ class SlamGpu:
         cfg.first_particle = first_particle
         cfg.n_particles_global = ng
         cfg.external_stream = external_stream
+        cfg.log_weights = int(log_weights)
         self.cfg = cfg
         self.N = n_particles
         self.h = C.c_void_p()
@@ -286,14 +289,16 @@ class SlamGpu:
     def nf(self):
         return self.L.slamgpu_num_landmarks(self.h)
 
-    def download(self, landmarks=True):
-        N, nf = self.N, self.nf()
+    def download(self, landmarks=True, first=0, count=None):
+        """particles [first, first + count) (default: all); log-weight contexts: w holds log-weights"""
+        nf = self.nf()
+        N = self.N - first if count is None else count
         xv = np.zeros((N, 3), np.float32)
         Pv = np.zeros((N, 3, 3), np.float32)
         w = np.zeros(N, np.float32)
         xf = np.zeros((N, nf, 2), np.float32) if landmarks else None
         Pf = np.zeros((N, nf, 2, 2), np.float32) if landmarks else None
-        _chk(self.L.slamgpu_download(self.h, _ptr(xv), _ptr(Pv), _ptr(w), _ptr(xf), _ptr(Pf)))
+        _chk(self.L.slamgpu_download_range(self.h, first, N, _ptr(xv), _ptr(Pv), _ptr(w), _ptr(xf), _ptr(Pf)))
         return dict(xv=xv, Pv=Pv, w=w, xf=xf, Pf=Pf, nf=nf)
 
     def upload(self, st):

@@ -214,6 +214,37 @@ SLAM_DEV float gauss3(float v0, float v1, float v2, float a00, float a10, float 
     return fdiv(expf(E), C);
 }
 
+// gaussEvaluate with logflag = 1 (fastslam2.cpp:154-160): E - (0.5 * D * log(2 pi) + sum log diag(Sc)).  The reference
+// never calls it; log-weight contexts (slamgpu_config.log_weights) accumulate it instead of multiplying the
+// logflag = 0 value, whose float32 product overflows beyond ~20 re-observed landmarks per step.  (NB the log form uses
+// the true D/2, the linear form integer D/2: for D = 3 they differ by the constant factor sqrt(2 pi), which cancels in
+// prior / proposal.)
+SLAM_DEV float gauss2_log(float v0, float v1, float s00, float s10, float s11) {
+    L2 L = llt2(s00, s10, s11);
+    float n0 = fdiv(v0, L.l00);
+    float n1 = fdiv(v1 - L.l10 * n0, L.l11);
+    float E = n0 * n0;
+    E += n1 * n1;
+    E = -0.5f * E;
+    float sum = logf(L.l00) + logf(L.l11);
+    float C = (float) (0.5 * 2 * 1.8378770664093453 + (double) sum);
+    return E - C;
+}
+
+SLAM_DEV float gauss3_log(float v0, float v1, float v2, float a00, float a10, float a11, float a20, float a21, float a22) {
+    L3 L = llt3(a00, a10, a11, a20, a21, a22);
+    float n0 = fdiv(v0, L.l00);
+    float n1 = fdiv(v1 - L.l10 * n0, L.l11);
+    float n2 = fdiv(v2 - (L.l20 * n0 + L.l21 * n1), L.l22);
+    float E = n0 * n0;
+    E += n1 * n1;
+    E += n2 * n2;
+    E = -0.5f * E;
+    float sum = (logf(L.l00) + logf(L.l11)) + logf(L.l22);
+    float C = (float) (0.5 * 3 * 1.8378770664093453 + (double) sum);
+    return E - C;
+}
+
 // choleskyUpdate for a 2x2 landmark (core.cpp:275-291).  P symmetric-packed in/out (p00,p10,p11).
 SLAM_DEV void cholesky_update2(float &fx, float &fy, float &p00, float &p10, float &p11, float v0, float v1, float r00,
                                float r01, float r10, float r11, float h00, float h01, float h10, float h11) {
@@ -471,7 +502,7 @@ SLAM_DEV void proposal_update(float &x, float &y, float &th, Sym3 &P, const Obs2
 }
 
 // likelihoodGivenXv term (fastslam2.cpp:370-400) + featureUpdate (core.cpp:132-175, :275-291) of one feature at the
-// sampled pose; both use the same Sf.  Returns gaussEvaluate(v, Sf) = exp(-v^T Sf^-1 v / 2) / (2 pi sqrt(det Sf)).
+// sampled pose; both use the same Sf.  Returns the parts of gaussEvaluate(v, Sf) = exp(-v^T Sf^-1 v / 2) / (2 pi sqrt(det Sf)).
 // gaussEvaluate(v, S), D = 2 (fastslam2.cpp:127-163), closed form: exp(-v^T S^-1 v / 2) / (2 pi sqrt(det S)); also hands
 // back S^-1 and S^-1 v for the feature update that follows
 struct Gauss2 {
@@ -492,10 +523,9 @@ SLAM_DEV Gauss2 gauss2_parts(float s00, float s10, float s11, float v0, float v1
     return g;
 }
 
-SLAM_DEV float feature_update2(float &fx, float &fy, float &f00, float &f10, float &f11, const Obs2 &o, float v0, float v1) {
+SLAM_DEV Gauss2 feature_update2(float &fx, float &fy, float &f00, float &f10, float &f11, const Obs2 &o, float v0, float v1) {
     const Gauss2 g = gauss2_parts(o.s00, o.s10, o.s11, v0, v1);
     const float i00 = g.i00, i10 = g.i10, i11 = g.i11, u0 = g.u0, u1 = g.u1;
-    const float lik = __expf(g.E) * g.norm;
     // C = Pf Hf^T ; W = C Sf^-1 ; xf += W v = C (Sf^-1 v) ; Pf -= W C^T
     const float c00 = ffma(f00, o.hf00, f10 * o.hf01), c01 = ffma(f00, o.hf10, f10 * o.hf11);
     const float c10 = ffma(f10, o.hf00, f11 * o.hf01), c11 = ffma(f10, o.hf10, f11 * o.hf11);
@@ -506,7 +536,7 @@ SLAM_DEV float feature_update2(float &fx, float &fy, float &f00, float &f10, flo
     f00 = ffma(-w00, c00, ffma(-w01, c01, f00));
     f10 = ffma(-w10, c00, ffma(-w11, c01, f10));
     f11 = ffma(-w10, c10, ffma(-w11, c11, f11));
-    return lik;
+    return g;  // likelihood = exp(g.E) * g.norm
 }
 
 // addFeature (core.cpp:488-501) with the polynomial sincos

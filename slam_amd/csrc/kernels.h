@@ -47,10 +47,11 @@ struct Ctrl {
     int32_t pend[2];      // lazy gather pending, per slot
     int32_t resampled;    // 1 if the last update resampled
     float neff;           // Neff of the last update
-    float inv_n;          // 1/N_global
+    float inv_n;          // weight a resampled particle restarts with: 1/N_global (log-weight contexts: log(1/N_global))
     int32_t status;       // kStatus* bits of the last update's resampling stage
     double wsum;          // sum of raw weights (global)
     double wsq;           // sum of squared raw weights (global)
+    double wmax;          // log-weight contexts: the largest log-weight M; wsum / wsq are sums of exp(l - M) and its square
     double est[4];        // sum x, sum y, heading of max-w particle, max w
 };
 
@@ -155,6 +156,7 @@ struct UpdateArgs {
     int32_t plan_inline;
     int32_t scan_global;     // the prefix of the previous step's block totals is in WeightScratch::scan (scan_kernel ran)
     int32_t do_resample, n_effective;  // SWITCH_RESAMPLE, NEFFECTIVE (for the inline plan)
+    int32_t logw;            // the context keeps LOG-weights in poseA.w (slamgpu_config.log_weights)
     int32_t finalize_par;    // parity of the estimate partials the helper block reduces
     int32_t finalize;        // 1: the extra block reduces the previous update's pose-estimate partials
     double *finalize_hist;   // history slot of that estimate (kHistStride doubles) or null
@@ -165,10 +167,11 @@ struct UpdateArgs {
 // searching lcum / blk_w [wpar ^ 1]; est_part[q] holds the pose-estimate partials of the last step of parity q.
 struct WeightScratch {
     float *lcum[2];     // [ncap]    inclusive in-block (256 particles) prefix of the raw weights
-    float *blk_w[2];    // [2*nblocks] block totals of w, then of w^2: one allocation, so a shard's totals travel as one
-                        //           contiguous message ([w(nb) | w2(nb)])
+    float *blk_w[2];    // [3*nblocks] block totals of w, then of w^2: one allocation, so a shard's totals travel as one
+                        //           contiguous message ([w(nb) | w2(nb)]); log-weight contexts: third row = the block's
+                        //           largest log-weight M_b, and w / w^2 / lcum are those of exp(l - M_b)
     double *est_part[2];  // [nblocks][4] pose-estimate partials (sum x, sum y, heading, max w)
-    double *scan[2];      // [nblocks + 3] large contexts: exclusive prefix of the block totals, then sum w, sum w^2
+    double *scan[2];      // [nblocks + 4] large contexts: exclusive prefix of the block totals, then sum w, sum w^2, max log-weight
                           // (scan_kernel), so that the update launch need not rescan the totals in every block
     int32_t wpar;       // parity of the step this launch belongs to
     int32_t *keep[2];   // [ncap] ancestors of the last resample, double-buffered by Buffers::slot: a launch reads the
@@ -180,6 +183,7 @@ struct ResampleArgs {
     int32_t nf;             // landmarks after this update
     int32_t do_resample;    // SWITCH_RESAMPLE
     int32_t n_effective;    // NEFFECTIVE
+    int32_t logw;           // log-weight context
 };
 
 // ---- sharded resampling (see kernels.hip) ---------------------------------------------------------------
@@ -228,7 +232,7 @@ struct KernelTable {
     void (*resample)(hipStream_t, const Buffers &, const WeightScratch &, const RngArgs &, const ResampleArgs &,
                      const UpdateArgs &);
     // large contexts: prefix of this step's block totals into WeightScratch::scan[wpar] (one block)
-    void (*scan)(hipStream_t, const WeightScratch &);
+    void (*scan)(hipStream_t, const WeightScratch &, int logw);
     // materialise a pending lazy gather (needed before anything but the next update touches the particle set)
     void (*gather)(hipStream_t, const Buffers &, const WeightScratch &, int nf);
     // rewrite every landmark record into its particle's own slot (genealogy -> identity): download, sharded arrivals

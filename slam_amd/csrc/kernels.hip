@@ -258,16 +258,38 @@ SLAM_DEV void finish_estimate(const Buffers &B, const WeightScratch &ws, int par
 // this association, so W, Q, Neff, the resample decision and all ancestors are identical everywhere.
 // Layout of the totals: shard-major records [w(nbl) | w2(nbl)] (what one all-gather of each shard's contiguous
 // [w | w2] block produces): total k of shard k/nbl sits at (k/nbl)*2*nbl + k%nbl, its square sum nbl further.
-SLAM_DEV void scan_block_totals(const float *__restrict__ tot, int nb, int nbl, double *off, double *sh_a, double *sh_q,
-                                double &W, double &Q) {
+// Log-weight contexts (logw): row 3 of the totals holds each block's largest log-weight M_b and rows 1 / 2 are sums of
+// exp(l - M_b) and its square; a first pass finds M = max M_b and every total is rescaled by exp(M_b - M) (double), so W, Q
+// and the prefix are those of exp(l - M).  With linear weights the factor is exactly 1.0: same bits as without it.
+SLAM_DEV double block_scale(float mb, double M) {
+    return mb == -INFINITY ? 0.0 : exp((double) mb - M);
+}
+
+SLAM_DEV void scan_block_totals(const float *__restrict__ tot, int nb, int nbl, bool logw, double *off, double *sh_a,
+                                double *sh_q, double &W, double &Q, double &M) {
     const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
     const int per = (nb + kBlock - 1) / kBlock;
     const int lo = min(nb, t * per), hi = min(nb, lo + per);
+    const int rows = logw ? 3 : 2;
+    M = 0.0;
+    if (logw) {
+        float mx = -INFINITY;
+        for (int k = lo; k < hi; k++) mx = fmaxf(mx, tot[(k / nbl) * rows * nbl + 2 * nbl + (k % nbl)]);
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, kWave));
+        if (lane == 0) sh_a[wv] = (double) mx;
+        __syncthreads();
+        M = fmax(fmax(sh_a[0], sh_a[1]), fmax(sh_a[2], sh_a[3]));
+        __syncthreads();
+    }
     double a = 0.0, q = 0.0;
     for (int k = lo; k < hi; k++) {
-        const int at = (k / nbl) * 2 * nbl + (k % nbl);
-        a += (double) tot[at];
-        q += (double) tot[at + nbl];
+        const int at = (k / nbl) * rows * nbl + (k % nbl);
+        const double sc = logw ? block_scale(tot[at + 2 * nbl], M) : 1.0;
+        const double tk = (double) tot[at] * sc;
+        off[k] = tk;  // this thread's own segment: read back below
+        a += tk;
+        q += (double) tot[at + nbl] * (sc * sc);
     }
     double sa = a;
 #pragma unroll
@@ -287,8 +309,9 @@ SLAM_DEV void scan_block_totals(const float *__restrict__ tot, int nb, int nbl, 
         if (k < wv) base += sh_a[k];
     double run = base + sa - a;  // exclusive prefix of this thread's segment
     for (int k = lo; k < hi; k++) {
+        const double tk = off[k];
         off[k] = run;
-        run += (double) tot[(k / nbl) * 2 * nbl + (k % nbl)];
+        run += tk;
     }
     W = ((sh_a[0] + sh_a[1]) + sh_a[2]) + sh_a[3];
     Q = ((sh_q[0] + sh_q[1]) + sh_q[2]) + sh_q[3];
@@ -317,8 +340,11 @@ SLAM_DEV float stratum_prev(const RngArgs &rng, int64_t gid) {
 }
 
 // ancestor (global particle index) of a stratum: min{ i : target < cumsum_i }, two-level binary search
+// blk_m != null (log-weight contexts): the in-block prefix of block b is that of exp(l - M_b); it is rescaled by
+// exp(M_b - M) like the block totals (scan_block_totals).  Linear weights: factor 1.0, same bits as without it.
 SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const float *__restrict__ lcum_local,
-                               int first_block, int nb_local, int64_t n_global) {
+                               int first_block, int nb_local, int64_t n_global, const float *__restrict__ blk_m = nullptr,
+                               double M = 0.0) {
     int b0 = 0, b1 = nb;
     while (b0 < b1) {
         const int mid = (b0 + b1) >> 1;
@@ -328,6 +354,7 @@ SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const f
     // the in-block prefix is only resident for this shard's blocks; callers only ask for strata they own
     const int lb = min(max(b0 - first_block, 0), nb_local - 1);
     const double o = off[b0];
+    const double sc = blk_m ? block_scale(blk_m[b0], M) : 1.0;
     const float *lc = lcum_local + (size_t) lb * kBlock;
     // first slot with o + lc > target; the last slot if rounding hides it.  The prefix is non-decreasing, so instead of
     // 8 dependent probes: 16 pivots in flight together (every 16th entry), then the 16 entries of the pivot's segment
@@ -337,14 +364,14 @@ SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const f
     int seg = 15;
 #pragma unroll
     for (int q = 14; q >= 0; q--)
-        if (o + (double) pv[q] > target) seg = q;
+        if (o + (double) pv[q] * sc > target) seg = q;
     const float4 *l4 = reinterpret_cast<const float4 *>(lc + 16 * seg);
     const float4 e0 = l4[0], e1 = l4[1], e2 = l4[2], e3 = l4[3];
     const float ev[16] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w, e3.x, e3.y, e3.z, e3.w};
     int r = 15;
 #pragma unroll
     for (int q = 14; q >= 0; q--)
-        if (o + (double) ev[q] > target) r = q;
+        if (o + (double) ev[q] * sc > target) r = q;
     const int l0 = 16 * seg + r;
     return min((int64_t) b0 * kBlock + l0, n_global - 1);
 }
@@ -421,14 +448,22 @@ constexpr int kStage = 8;  // landmarks per particle kept in LDS between the two
 
 // ARR: the context is a shard whose particles may have ARRIVED from other shards (keep[i] < 0, arrival-pool records).
 // Single contexts instantiate ARR = false: per-lane buffer and pool selects cost them 6 % of the step for nothing.
-template <int METHOD, bool ARR>
+// BIG: the observation packet lives in device memory (more than kSmallObs re-observed or new landmarks: synthetic maps,
+// BASELINE config 5 re-observes ~1.3 k per step).  Every landmark loop then runs as a software pipeline over chunks of
+// kBigChunk landmarks: while a chunk is computed out of LDS the next chunk's records are in flight into registers and
+// the genealogy slots of the chunk after that behind them, so a wave has ~2 x kBigChunk x 20 B per lane outstanding
+// instead of one dependent slot -> record round trip per landmark.
+constexpr int kBigChunk = 8;
+
+template <int METHOD, bool ARR, bool BIG>
 __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs PA, UpdateArgs U, RngArgs rng,
                                                          WeightScratch ws) {
     __shared__ float sh_w[kBlock / kWave], sh_w2[kBlock / kWave];
     // landmarks re-observed this step, staged between the proposal pass and the likelihood/feature-update pass
     // (each thread only touches its own column: no barrier, no bank conflict: consecutive lanes, consecutive slots)
-    __shared__ float4 shA[METHOD == 2 ? kStage : 1][kBlock];
-    __shared__ float shB[METHOD == 2 ? kStage : 1][kBlock];
+    constexpr int kLds = BIG ? kBigChunk : (METHOD == 2 ? kStage : 1);
+    __shared__ float4 shA[kLds][kBlock];
+    __shared__ float shB[kLds][kBlock];
     extern __shared__ double off[];  // inline plan: [nblocks + 1] exclusive prefix of the previous step's block totals
     __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
     __shared__ EstItem sh_est[kBlock / kWave];
@@ -444,7 +479,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     //   otherwise  : resample_kernel ran: slot keep[i] of the live buffers if it left a gather pending, else slot i.
     // Either way a gathered particle is written to slot i of the OTHER pose / genealogy buffers.
     bool pend = U.lazy && ctrl->pend[B.slot] != 0;
-    double W = 1.0;
+    double W = 1.0, Mx = 0.0;
+    const bool logw = U.logw != 0;
     // large contexts: the prefix comes from scan_kernel (same function, same association, run once) instead of being
     // redone by every block -- O(N^2 / 65 536) otherwise
     const double *offp = U.scan_global ? ws.scan[ws.wpar ^ 1] : off;
@@ -453,14 +489,16 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         if (U.scan_global) {
             W = offp[nb + 1];
             Q = offp[nb + 2];
+            Mx = offp[nb + 3];
         } else {
-            scan_block_totals(ws.blk_w[ws.wpar ^ 1], nb, nb, off, sh_a, sh_q, W, Q);
+            scan_block_totals(ws.blk_w[ws.wpar ^ 1], nb, nb, logw, off, sh_a, sh_q, W, Q, Mx);
         }
         const float neff = (float) ((W * W) / Q);  // Neff = 1 / sum((w/W)^2)  (core.cpp:784-788)
         pend = U.do_resample && (neff < (float) U.n_effective);
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             ctrl->wsum = W;
             ctrl->wsq = Q;
+            ctrl->wmax = Mx;
             ctrl->neff = neff;
             ctrl->resampled = pend ? 1 : 0;
             ctrl->status = weight_status(W, Q);
@@ -473,7 +511,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     auto ancestor = [&](int k) -> int {
         if (!U.plan_inline) return ws.keep[B.slot][k];
         const double target = (double) stratum_prev(rng, (int64_t) k) * W;
-        return (int) min(find_ancestor(target, offp, nb, ws.lcum[ws.wpar ^ 1], 0, nb, (int64_t) B.n), (int64_t) B.n - 1);
+        return (int) min(find_ancestor(target, offp, nb, ws.lcum[ws.wpar ^ 1], 0, nb, (int64_t) B.n,
+                                       logw ? ws.blk_w[ws.wpar ^ 1] + 2 * nb : nullptr, Mx), (int64_t) B.n - 1);
     };
     if ((int) blockIdx.x >= nb) {
         // ---- helper blocks ---------------------------------------------------------------------------------
@@ -487,7 +526,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                     W = offp[nb + 1];
                     Q = offp[nb + 2];
                 } else {
-                    scan_block_totals(ws.blk_w[ws.wpar ^ 1], nb, nb, off, sh_a, sh_q, W, Q);
+                    scan_block_totals(ws.blk_w[ws.wpar ^ 1], nb, nb, logw, off, sh_a, sh_q, W, Q, Mx);
                 }
                 pend = U.do_resample && ((float) ((W * W) / Q) < (float) U.n_effective);
             }
@@ -511,7 +550,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     float2 *__restrict__ poseCo = out ? B.poseC[1] : B.poseC[0];
     const bool active = i < B.n;
     const int m = U.m, n = U.n, nf = U.nf;
-    float w = 0.0f;
+    float w = logw ? -INFINITY : 0.0f;  // lanes beyond the particle count carry no weight
 
     EstItem ei_prev{0.0, 0.0, -3.0e38f, 0.0f, 0x7fffffff};  // inline plan: this particle's term of the previous step's estimate
     if (active) {
@@ -567,7 +606,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
 
         const int32_t *__restrict__ idf;
         const float *__restrict__ zf, *__restrict__ zn;
-        if (U.big) {
+        if (BIG) {
             idf = reinterpret_cast<const int32_t *>(U.big + 1);
             zf = reinterpret_cast<const float *>(idf + m);
             zn = zf + 2 * m;
@@ -602,18 +641,56 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             }
         };
 
+        // BIG: body(k, la, lb) for k = 0..m-1, in order, over the re-observed landmarks, as a three-stage software pipeline
+        // (see kBigChunk).  Out-of-range tail entries re-read the last landmark (never consumed).
+        auto pipeline = [&](auto body) {
+            constexpr int CH = kBigChunk;
+            int sl[CH];
+            float4 ta[CH];
+            float tb[CH];
+            auto load_slots = [&](int k0) {
+#pragma unroll
+                for (int k = 0; k < CH; k++) sl[k] = slot_of(idf[min(k0 + k, m - 1)]);
+            };
+            auto load_recs = [&](int k0) {
+#pragma unroll
+                for (int k = 0; k < CH; k++) {
+                    const Rec r = load_rec(idf[min(k0 + k, m - 1)], sl[k]);
+                    ta[k] = r.a;
+                    tb[k] = r.b;
+                }
+            };
+            load_slots(0);
+            load_recs(0);
+            load_slots(CH);
+            for (int k0 = 0; k0 < m; k0 += CH) {
+#pragma unroll
+                for (int k = 0; k < CH; k++) {
+                    shA[k][threadIdx.x] = ta[k];
+                    shB[k][threadIdx.x] = tb[k];
+                }
+                if (k0 + CH < m) {
+                    load_recs(k0 + CH);       // slots of this chunk were requested one chunk of compute ago
+                    load_slots(k0 + 2 * CH);  // (clamped: harmless re-reads past the end)
+                }
+                const int kn = min(CH, m - k0);
+                for (int k = 0; k < kn; k++) body(k0 + k, shA[k][threadIdx.x], shB[k][threadIdx.x]);
+            }
+        };
+
         float4 pa = poseA[si];
         // the genealogy chunks this update rewrites (small packets: at most a handful) are fetched now, with the pose,
         // not at the end of the kernel behind one more memory round trip
         constexpr int kEarly = 8;
-        const int nchs = U.big ? 0 : U.small.nchunks;
+        const int nchs = BIG ? 0 : U.small.nchunks;
         int4 cq[kEarly];
 #pragma unroll
         for (int t = 0; t < kEarly; t++) cq[t] = idxS[(size_t) U.small.chunk_id[min(t, max(nchs - 1, 0))] * S + si];
         float x = pa.x, y = pa.y, th = pa.z;
         // resampled particles restart at 1/N (core.cpp:744-747); otherwise the weights are normalised (core.cpp:726-729;
         // resample_kernel has already done it unless this launch plans inline)
-        w = pend ? ctrl->inv_n : (U.plan_inline ? pa.w / (float) W : pa.w);
+        // (log-weight contexts: l - (M + log sum exp(l - M)); Ctrl.inv_n holds log(1/N))
+        w = pend ? ctrl->inv_n : (U.plan_inline ? (logw ? pa.w - (float) (Mx + log(W)) : pa.w / (float) W) : pa.w);
         // computeEstimatedPosition of the previous update (ParticleSLAMWrapper.cpp:56-77) sees exactly this set
         ei_prev = EstItem{(double) pa.x, (double) pa.y, w, pa.z, i};
         float q00 = 0.f, q10 = 0.f, q11 = 0.f, q20 = 0.f, q21 = 0.f, q22 = 0.f;
@@ -658,43 +735,58 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 const float x0 = x, y0 = y, th0 = th;
                 Sym3 P = {q00, q10, q11, q20, q21, q22};
                 const L3r L0 = llt3r(P);  // factor of Pv0 for the prior term (:366)
-                if (m <= kStage / 2) stage_landmarks(std::integral_constant<int, kStage / 2>{});
-                else stage_landmarks(std::integral_constant<int, kStage>{});
-                for (int k = 0; k < m; k++) {
-                    float4 la;
-                    float lb;
-                    if (k < kStage) {
-                        la = shA[k][threadIdx.x];
-                        lb = shB[k][threadIdx.x];
-                    } else {
-                        load_lmk(idf[k], slot_of(idf[k]), la, lb);
-                    }
+                auto first_pass = [&](int k, float4 la, float lb) {
                     const Obs2 o = observe2(x, y, th, la.x, la.y, la.z, la.w, lb, r00, rl, r11);
                     proposal_update(x, y, th, P, o, zf[2 * k] - o.zp0, wrap_pi(zf[2 * k + 1] - o.zp1));
+                };
+                if constexpr (BIG) {
+                    pipeline(first_pass);
+                } else {
+                    if (m <= kStage / 2) stage_landmarks(std::integral_constant<int, kStage / 2>{});
+                    else stage_landmarks(std::integral_constant<int, kStage>{});
+                    for (int k = 0; k < m; k++) {
+                        float4 la;
+                        float lb;
+                        if (k < kStage) {
+                            la = shA[k][threadIdx.x];
+                            lb = shB[k][threadIdx.x];
+                        } else {
+                            load_lmk(idf[k], slot_of(idf[k]), la, lb);
+                        }
+                        first_pass(k, la, lb);
+                    }
                 }
                 const L3r Lp = llt3r(P);
                 const float xs = ffma(Lp.l00, g0, x);
                 const float ys = ffma(Lp.l11, g1, ffma(Lp.l10, g0, y));
                 const float ths = ffma(Lp.l22, g2, ffma(Lp.l21, g1, ffma(Lp.l20, g0, th)));
                 float lik = 1.0f;
+                double dl = 0.0;  // log-weight contexts: sum of the log-likelihoods (double: ~1.3 k terms of ~4.5 at config 5)
                 auto second_pass = [&](int k, float4 la, float lb) {
                     const Obs2 o = observe2(xs, ys, ths, la.x, la.y, la.z, la.w, lb, r00, rl, r11);
-                    lik *= feature_update2(la.x, la.y, la.z, la.w, lb, o, zf[2 * k] - o.zp0, wrap_pi(zf[2 * k + 1] - o.zp1));
+                    const Gauss2 g = feature_update2(la.x, la.y, la.z, la.w, lb, o, zf[2 * k] - o.zp0, wrap_pi(zf[2 * k + 1] - o.zp1));
+                    if (logw) dl += (double) (g.E + __logf(g.norm));
+                    else lik *= __expf(g.E) * g.norm;
                     store_lmk(idf[k], la, lb);
                 };
-                const int ms = min(m, kStage);
-                for (int k = 0; k < ms; k++) second_pass(k, shA[k][threadIdx.x], shB[k][threadIdx.x]);
-                for (int k = ms; k < m; k++) {
-                    float4 la;
-                    float lb;
-                    load_lmk(idf[k], slot_of(idf[k]), la, lb);
-                    second_pass(k, la, lb);
+                if constexpr (BIG) {
+                    pipeline(second_pass);
+                } else {
+                    const int ms = min(m, kStage);
+                    for (int k = 0; k < ms; k++) second_pass(k, shA[k][threadIdx.x], shB[k][threadIdx.x]);
+                    for (int k = ms; k < m; k++) {
+                        float4 la;
+                        float lb;
+                        load_lmk(idf[k], slot_of(idf[k]), la, lb);
+                        second_pass(k, la, lb);
+                    }
                 }
                 // w *= likelihood * prior / proposal (:360-367): one exponential for the ratio of the two Gaussians
                 const float E = gauss3_exponent(L0, x0 - xs, y0 - ys, wrap_pi(th0 - ths)) -
                                 gauss3_exponent(Lp, x - xs, y - ys, wrap_pi(th - ths));
                 const float ratio = ((Lp.l00 * Lp.l11) * Lp.l22) * ((L0.r0 * L0.r1) * L0.r2);
-                w = w * lik * (__expf(E) * ratio);
+                if (logw) w = (float) ((double) w + dl + (double) (E + __logf(ratio)));
+                else w = w * lik * (__expf(E) * ratio);
                 x = xs;
                 y = ys;
                 th = ths;
@@ -732,17 +824,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 const float x0 = x, y0 = y, th0 = th;
                 // running proposal covariance, full 3x3 (the reference's Pv stays a full matrix inside the loop)
                 float P[9] = {q00, q10, q20, q10, q11, q21, q20, q21, q22};
-                if (m <= kStage / 2) stage_landmarks(std::integral_constant<int, kStage / 2>{});
-                else stage_landmarks(std::integral_constant<int, kStage>{});
-                for (int k = 0; k < m; k++) {
-                    float4 la;
-                    float lb;
-                    if (k < kStage) {
-                        la = shA[k][threadIdx.x];
-                        lb = shB[k][threadIdx.x];
-                    } else {
-                        load_lmk(idf[k], slot_of(idf[k]), la, lb);
-                    }
+                auto first_pass = [&](int k, float4 la, float lb) {
                     // Jacobians at the running mean (fastslam2.cpp:320,:348)
                     Jac j = jacobian(x, y, th, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
                     float s00, s01, s10, s11;
@@ -778,6 +860,23 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                     x = x + c[0];
                     y = y + c[1];
                     th = th + c[2];
+                };
+                if constexpr (BIG) {
+                    pipeline(first_pass);
+                } else {
+                    if (m <= kStage / 2) stage_landmarks(std::integral_constant<int, kStage / 2>{});
+                    else stage_landmarks(std::integral_constant<int, kStage>{});
+                    for (int k = 0; k < m; k++) {
+                        float4 la;
+                        float lb;
+                        if (k < kStage) {
+                            la = shA[k][threadIdx.x];
+                            lb = shB[k][threadIdx.x];
+                        } else {
+                            load_lmk(idf[k], slot_of(idf[k]), la, lb);
+                        }
+                        first_pass(k, la, lb);
+                    }
                 }
                 // sample from the proposal (:353) ; weight terms (:360-367)
                 const L3 Lp = llt3(P[0], P[3], P[4], P[6], P[7], P[8]);
@@ -786,27 +885,39 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 const float a0 = x0 - xs, a1 = y0 - ys, a2 = trig_offset(th0 - ths);
                 const float b0 = x - xs, b1 = y - ys, b2 = trig_offset(th - ths);
                 float lik = 1.0f;
+                double dl = 0.0;  // log-weight contexts: sum of gaussEvaluate(.., logflag = 1)
                 auto second_pass = [&](int k, float4 la, float lb) {
                     Jac j = jacobian(xs, ys, ths, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
                     const float v0 = zf[2 * k] - j.zp0;
                     const float v1 = trig_offset(zf[2 * k + 1] - j.zp1);
-                    lik = lik * gauss2(v0, v1, j.s00, j.s10, j.s11);
+                    if (logw) dl += (double) gauss2_log(v0, v1, j.s00, j.s10, j.s11);
+                    else lik = lik * gauss2(v0, v1, j.s00, j.s10, j.s11);
                     cholesky_update2(la.x, la.y, la.z, la.w, lb, v0, v1, r00, r01, r10, r11, j.hf00, j.hf01, j.hf10, j.hf11);
                     store_lmk(idf[k], la, lb);
                 };
                 // two loops on purpose: the LDS-fed one issues only stores to HBM, so nothing in it has to wait for a
                 // store to land (a global load after a global store costs an s_waitcnt vmcnt(0) per iteration)
-                const int ms = min(m, kStage);
-                for (int k = 0; k < ms; k++) second_pass(k, shA[k][threadIdx.x], shB[k][threadIdx.x]);
-                for (int k = ms; k < m; k++) {
-                    float4 la;
-                    float lb;
-                    load_lmk(idf[k], slot_of(idf[k]), la, lb);
-                    second_pass(k, la, lb);
+                if constexpr (BIG) {
+                    pipeline(second_pass);
+                } else {
+                    const int ms = min(m, kStage);
+                    for (int k = 0; k < ms; k++) second_pass(k, shA[k][threadIdx.x], shB[k][threadIdx.x]);
+                    for (int k = ms; k < m; k++) {
+                        float4 la;
+                        float lb;
+                        load_lmk(idf[k], slot_of(idf[k]), la, lb);
+                        second_pass(k, la, lb);
+                    }
                 }
-                const float prior = gauss3(a0, a1, a2, q00, q10, q11, q20, q21, q22);
-                const float prop = gauss3(b0, b1, b2, P[0], P[3], P[4], P[6], P[7], P[8]);
-                w = w * lik * prior / prop;
+                if (logw) {
+                    const float prior = gauss3_log(a0, a1, a2, q00, q10, q11, q20, q21, q22);
+                    const float prop = gauss3_log(b0, b1, b2, P[0], P[3], P[4], P[6], P[7], P[8]);
+                    w = (float) (((double) w + dl) + ((double) prior - (double) prop));
+                } else {
+                    const float prior = gauss3(a0, a1, a2, q00, q10, q11, q20, q21, q22);
+                    const float prop = gauss3(b0, b1, b2, P[0], P[3], P[4], P[6], P[7], P[8]);
+                    w = w * lik * prior / prop;
+                }
                 x = xs;
                 y = ys;
                 th = ths;
@@ -822,10 +933,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             // FastSLAM 1: computeWeight (fastslam1.cpp:91-118) + featureUpdate at the particle pose
             if (m > 0) {
                 float wp = 1.0f;
-                for (int k = 0; k < m; k++) {
-                    float4 la;
-                    float lb;
-                    load_lmk(idf[k], slot_of(idf[k]), la, lb);
+                double dl = 0.0;
+                auto one_pass = [&](int k, float4 la, float lb) {
                     Jac j = jacobian(x, y, th, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
                     const float v0 = zf[2 * k] - j.zp0;
                     const float v1 = trig_offset(zf[2 * k + 1] - j.zp1);
@@ -834,12 +943,26 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                     inverse2(j.s00, j.s01, j.s10, j.s11, i00, i01, i10, i11);
                     const float t0 = -0.5f * (v0 * i00 + v1 * i10);
                     const float t1 = -0.5f * (v0 * i01 + v1 * i11);
-                    const float num = expf(t0 * v0 + t1 * v1);
-                    wp = wp * num / den;
+                    if (logw) {
+                        dl += (double) ((t0 * v0 + t1 * v1) - logf(den));
+                    } else {
+                        const float num = expf(t0 * v0 + t1 * v1);
+                        wp = wp * num / den;
+                    }
                     cholesky_update2(la.x, la.y, la.z, la.w, lb, v0, v1, r00, r01, r10, r11, j.hf00, j.hf01, j.hf10, j.hf11);
                     store_lmk(idf[k], la, lb);
+                };
+                if constexpr (BIG) {
+                    pipeline(one_pass);
+                } else {
+                    for (int k = 0; k < m; k++) {
+                        float4 la;
+                        float lb;
+                        load_lmk(idf[k], slot_of(idf[k]), la, lb);
+                        one_pass(k, la, lb);
+                    }
                 }
-                w = w * wp;
+                w = logw ? (float) ((double) w + dl) : w * wp;
             }
         }
         // addFeature (core.cpp:479-509): new landmarks appended at nf, nf+1, ...
@@ -862,7 +985,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             if (mask & 8) q.w = i;
             idxO[(size_t) c * S + i] = q;
         };
-        if (U.big) {
+        if (BIG) {
             const uint32_t *bits = touched_bitmap(U);
             const int nch = (nf + n + 3) >> 2;
             for (int c = 0; c < nch; c++) {
@@ -900,6 +1023,19 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             p[2] = (double) ei_prev.th;
             p[3] = (double) ei_prev.w;
         }
+    }
+    // log-weight contexts: the prefix / totals below are those of exp(l - M_b), M_b = the block's largest log-weight,
+    // which travels as a third row of the totals (scan_block_totals rescales by exp(M_b - M))
+    if (logw) {
+        float mb = w;
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) mb = fmaxf(mb, __shfl_xor(mb, d, kWave));
+        if (lane == 0) sh_w[wv] = mb;
+        __syncthreads();
+        mb = fmaxf(fmaxf(sh_w[0], sh_w[1]), fmaxf(sh_w[2], sh_w[3]));
+        __syncthreads();
+        if (threadIdx.x == 0) ws.blk_w[ws.wpar][2 * ws.nblocks + blockIdx.x] = mb;
+        w = (w == -INFINITY) ? 0.0f : expf(w - mb);  // NaN log-weights stay NaN and are flagged by the plan (status)
     }
     // in-block inclusive prefix of w; block totals of w and w^2 (fixed association: deterministic)
     float s = w;
@@ -947,14 +1083,16 @@ __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScrat
     // every update launch publishes where it left the set (pend = 0) and the host flips its slot: plain read here
     const int cur = ctrl->live[B.slot];
 
-    double W, Q;
-    scan_block_totals(ws.blk_w[ws.wpar], nb, nb, off, sh_a, sh_q, W, Q);  // one shard: [w(nb) | w2(nb)] contiguous
+    double W, Q, Mx;
+    const bool logw = ra.logw != 0;
+    scan_block_totals(ws.blk_w[ws.wpar], nb, nb, logw, off, sh_a, sh_q, W, Q, Mx);  // one shard: [w(nb) | w2(nb)] contiguous
     // Neff = 1 / sum((w/W)^2)  (core.cpp:784-788)
     const float neff = (float) ((W * W) / Q);
     const bool resample = ra.do_resample && (neff < (float) ra.n_effective);
     if (blockIdx.x == 0 && t == 0) {
         ctrl->wsum = W;
         ctrl->wsq = Q;
+        ctrl->wmax = Mx;
         ctrl->neff = neff;
         ctrl->resampled = resample ? 1 : 0;
         ctrl->status = weight_status(W, Q);
@@ -973,13 +1111,14 @@ __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScrat
     if (!resample) {
         if (active) {
             float4 pa = B.poseA[cur][k];
-            pa.w = pa.w / (float) W;
+            pa.w = logw ? pa.w - (float) (Mx + log(W)) : pa.w / (float) W;
             B.poseA[cur][k] = pa;
             ei = EstItem{(double) pa.x, (double) pa.y, pa.w, pa.z, k};
         }
     } else if (active) {
         const double target = (double) stratum(rng, (int64_t) k) * W;
-        const int anc = (int) min(find_ancestor(target, off, nb, ws.lcum[ws.wpar], 0, nb, (int64_t) B.n), (int64_t) B.n - 1);
+        const int anc = (int) min(find_ancestor(target, off, nb, ws.lcum[ws.wpar], 0, nb, (int64_t) B.n,
+                                                logw ? ws.blk_w[ws.wpar] + 2 * nb : nullptr, Mx), (int64_t) B.n - 1);
         ws.keep[B.slot ^ 1][k] = anc;
         const float4 pa = B.poseA[cur][anc];
         ei = EstItem{(double) pa.x, (double) pa.y, ctrl->inv_n, pa.z, k};
@@ -1068,14 +1207,15 @@ __global__ void __launch_bounds__(kBlock) flatten_kernel(Buffers B, int nf) {
 
 // One block: the scan every block of a small context does for itself (scan_block_totals: same association, so the
 // results are bit-identical), once, into global memory: [0..nb] exclusive prefix, [nb+1] sum w, [nb+2] sum w^2.
-__global__ void __launch_bounds__(kBlock) scan_kernel(WeightScratch ws) {
+__global__ void __launch_bounds__(kBlock) scan_kernel(WeightScratch ws, int logw) {
     __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
-    double W, Q;
+    double W, Q, Mx;
     double *out = ws.scan[ws.wpar];
-    scan_block_totals(ws.blk_w[ws.wpar], ws.nblocks, ws.nblocks, out, sh_a, sh_q, W, Q);
+    scan_block_totals(ws.blk_w[ws.wpar], ws.nblocks, ws.nblocks, logw != 0, out, sh_a, sh_q, W, Q, Mx);
     if (threadIdx.x == 0) {
         out[ws.nblocks + 1] = W;
         out[ws.nblocks + 2] = Q;
+        out[ws.nblocks + 3] = Mx;
     }
 }
 
@@ -1179,7 +1319,8 @@ __global__ void __launch_bounds__(kBlock) shard_plan_kernel(ShardPlanArgs A, Rng
     extern __shared__ double off[];
     __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
     double W, Q;
-    scan_block_totals(A.gblk, A.nb_global, A.nb_per_shard, off, sh_a, sh_q, W, Q);
+    double Mx;
+    scan_block_totals(A.gblk, A.nb_global, A.nb_per_shard, false, off, sh_a, sh_q, W, Q, Mx);  // shards: linear weights only
     __syncthreads();
     const int t = threadIdx.x;
     if (t == 0) {
@@ -1237,7 +1378,8 @@ __global__ void __launch_bounds__(kBlock) shard_pack_kernel(Buffers B, WeightScr
     extern __shared__ double off[];
     __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
     double W, Q;
-    scan_block_totals(A.gblk, A.nb_global, A.nb_per_shard, off, sh_a, sh_q, W, Q);
+    double Mx;
+    scan_block_totals(A.gblk, A.nb_global, A.nb_per_shard, false, off, sh_a, sh_q, W, Q, Mx);  // shards: linear weights only
     __syncthreads();
     const int64_t j = (int64_t) blockIdx.x * kBlock + threadIdx.x;  // offspring slot of this shard
     const int64_t k = A.k_lo + j;
@@ -1448,17 +1590,19 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
     if (U.lazy) grid += (U.copy_hi - U.copy_lo) + 1;
     // inline plan only: prefix of the previous step's block totals (launches that do not plan never touch off[])
     const size_t lds = (U.plan_inline && !U.scan_global) ? sizeof(double) * ((size_t) ws.nblocks + 1) : 0;
-    if (U.method == 2) {
-        if (U.arrivals)
-            hipLaunchKernelGGL((update_kernel<2, true>), dim3(grid), dim3(kBlock), lds, st, B, PA, U, rng, ws);
-        else
-            hipLaunchKernelGGL((update_kernel<2, false>), dim3(grid), dim3(kBlock), lds, st, B, PA, U, rng, ws);
-    } else {
-        if (U.arrivals)
-            hipLaunchKernelGGL((update_kernel<1, true>), dim3(grid), dim3(kBlock), lds, st, B, PA, U, rng, ws);
-        else
-            hipLaunchKernelGGL((update_kernel<1, false>), dim3(grid), dim3(kBlock), lds, st, B, PA, U, rng, ws);
+    const int sel = (U.method == 2 ? 4 : 0) | (U.arrivals ? 2 : 0) | (U.big ? 1 : 0);
+#define SLAM_LAUNCH_UPDATE(M, A, G) hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, B, PA, U, rng, ws)
+    switch (sel) {
+        case 7: SLAM_LAUNCH_UPDATE(2, true, true); break;
+        case 6: SLAM_LAUNCH_UPDATE(2, true, false); break;
+        case 5: SLAM_LAUNCH_UPDATE(2, false, true); break;
+        case 4: SLAM_LAUNCH_UPDATE(2, false, false); break;
+        case 3: SLAM_LAUNCH_UPDATE(1, true, true); break;
+        case 2: SLAM_LAUNCH_UPDATE(1, true, false); break;
+        case 1: SLAM_LAUNCH_UPDATE(1, false, true); break;
+        default: SLAM_LAUNCH_UPDATE(1, false, false); break;
     }
+#undef SLAM_LAUNCH_UPDATE
 }
 
 static void launch_resample(hipStream_t st, const Buffers &B, const WeightScratch &ws, const RngArgs &rng,
@@ -1467,8 +1611,8 @@ static void launch_resample(hipStream_t st, const Buffers &B, const WeightScratc
     hipLaunchKernelGGL(resample_kernel, dim3(ws.nblocks), dim3(kBlock), lds, st, B, ws, rng, ra, U);
 }
 
-static void launch_scan(hipStream_t st, const WeightScratch &ws) {
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, st, ws);
+static void launch_scan(hipStream_t st, const WeightScratch &ws, int logw) {
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, st, ws, logw);
 }
 
 static void launch_gather(hipStream_t st, const Buffers &B, const WeightScratch &ws, int nf) {

@@ -279,6 +279,7 @@ int flush_stages(slamgpu_ctx *c) {
         ra.nf = c->unplanned.nf;
         ra.do_resample = c->cfg.resample;
         ra.n_effective = c->cfg.n_effective;
+        ra.logw = c->cfg.log_weights;
         c->ws.wpar = c->unplanned.par;
         {
             Timed t(c, "resample");
@@ -365,6 +366,8 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     if (cfg->n_particles <= 0 || cfg->max_landmarks < 0) return fail(SLAMGPU_ERR_INVALID, "bad sizes");
     if (cfg->method != SLAMGPU_FASTSLAM1 && cfg->method != SLAMGPU_FASTSLAM2)
         return fail(SLAMGPU_ERR_INVALID, "method must be SLAMGPU_FASTSLAM1 or SLAMGPU_FASTSLAM2 (EKF1 runs on the host)");
+    if (cfg->log_weights && cfg->n_particles_global > 0 && cfg->n_particles_global != cfg->n_particles)
+        return fail(SLAMGPU_ERR_INVALID, "log_weights is not available for shards (n_particles_global != n_particles)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(SLAMGPU_ERR_NO_DEVICE, "no HIP device: libslamgpu has no CPU fallback");
@@ -426,14 +429,15 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     CTX_TRY(hipHostMalloc((void **) &c->ctrl_host, sizeof(Ctrl), hipHostMallocDefault));
     memset(c->ctrl_host, 0, sizeof(Ctrl));
     c->ctrl_host->inv_n = 1.0f / (float) n_global(c);  // core.cpp:745
+    if (cfg->log_weights) c->ctrl_host->inv_n = logf(c->ctrl_host->inv_n);
     CTX_TRY(hipMemcpyAsync(c->B.ctrl, c->ctrl_host, sizeof(Ctrl), hipMemcpyHostToDevice, c->stream));
     // weight scratch
     c->ws.nblocks = ncap / kBlock;
     for (int b = 0; b < 2; b++) {
         CTX_TRY(hipMalloc((void **) &c->ws.lcum[b], sizeof(float) * S));
-        CTX_TRY(hipMalloc((void **) &c->ws.blk_w[b], sizeof(float) * 2 * (size_t) c->ws.nblocks));  // [w | w2] contiguous
+        CTX_TRY(hipMalloc((void **) &c->ws.blk_w[b], sizeof(float) * 3 * (size_t) c->ws.nblocks));  // [w | w2 (| max log-weight)] contiguous
         CTX_TRY(hipMalloc((void **) &c->ws.est_part[b], sizeof(double) * (4 * (size_t) c->ws.nblocks + 2)));  // + Neff, resampled
-        CTX_TRY(hipMalloc((void **) &c->ws.scan[b], sizeof(double) * ((size_t) c->ws.nblocks + 3)));
+        CTX_TRY(hipMalloc((void **) &c->ws.scan[b], sizeof(double) * ((size_t) c->ws.nblocks + 4)));
     }
     for (int b = 0; b < 2; b++) {
         CTX_TRY(hipMalloc((void **) &c->ws.keep[b], sizeof(int32_t) * S));
@@ -454,7 +458,7 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     // initial particle set: Particle() then w = 1/N (ParticleSLAMWrapper.cpp:14-25)
     {
         std::vector<float4> a(S, make_float4(0.f, 0.f, 0.f, 0.f));
-        const float uw = (float) (1.0 / (float) n_global(c));
+        const float uw = cfg->log_weights ? c->ctrl_host->inv_n : (float) (1.0 / (float) n_global(c));
         for (int i = 0; i < n; i++) a[i].w = uw;
         CTX_TRY(hipMemcpyAsync(c->B.poseA[0], a.data(), sizeof(float4) * S, hipMemcpyHostToDevice, c->stream));
         CTX_TRY(hipStreamSynchronize(c->stream));
@@ -674,6 +678,7 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     U.scan_global = (U.plan_inline && c->scan_ready) ? 1 : 0;
     U.do_resample = c->cfg.resample;
     U.n_effective = c->cfg.n_effective;
+    U.logw = c->cfg.log_weights;
     U.finalize = c->unreduced.has ? 1 : 0;  // (sharded: this shard's partials of the previous step, shard_finalize_kernel)
     U.finalize_hist = c->unreduced.hist;
     U.finalize_par = c->unreduced.par;
@@ -710,7 +715,7 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     c->scan_ready = false;
     if (c->ws.nblocks > c->scan_min_blocks) {
         Timed t(c, "scan");
-        c->k->scan(c->stream, c->ws);
+        c->k->scan(c->stream, c->ws, c->cfg.log_weights);
         c->scan_ready = true;
     }
     HIP_TRY(hipGetLastError());
@@ -762,6 +767,7 @@ int slamgpu_shard_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, in
     if (int rc = check_ctx(c)) return rc;
     if (c->cfg.n_particles % kBlock != 0 || c->cfg.first_particle % kBlock != 0)
         return fail(SLAMGPU_ERR_INVALID, "shards must hold a multiple of %d particles", kBlock);
+    if (c->cfg.log_weights) return fail(SLAMGPU_ERR_INVALID, "the sharded resampling stage works on linear weights (log_weights contexts: slamgpu_update)");
     return do_update(c, zf, idf, m, zn, n, R, normals, strata, true);
 }
 
@@ -1114,7 +1120,7 @@ int slamgpu_stats(slamgpu_ctx *c, float *neff, int32_t *resampled, double *weigh
     if (int rc = read_ctrl(c)) return rc;
     if (neff) *neff = c->ctrl_host->neff;
     if (resampled) *resampled = c->ctrl_host->resampled;
-    if (weight_sum) *weight_sum = c->ctrl_host->wsum;
+    if (weight_sum) *weight_sum = c->cfg.log_weights ? c->ctrl_host->wmax + log(c->ctrl_host->wsum) : c->ctrl_host->wsum;
     return 0;
 }
 
@@ -1153,21 +1159,24 @@ int slamgpu_sync(slamgpu_ctx *c) {
     return 0;
 }
 
-int slamgpu_download(slamgpu_ctx *c, float *xv, float *Pv9, float *w, float *xf, float *Pf4) {
+int slamgpu_download_range(slamgpu_ctx *c, int32_t first, int32_t count, float *xv, float *Pv9, float *w, float *xf, float *Pf4) {
     if (int rc = check_ctx(c)) return rc;
+    if (first < 0 || count < 0 || (int64_t) first + count > c->B.n)
+        return fail(SLAMGPU_ERR_INVALID, "particle range [%d, %d) outside [0, %d)", first, first + count, c->B.n);
     if ((xf || Pf4) && c->nf > 0) {
         if (int rc = flush_predict(c)) return rc;
         if (int rc = flatten(c)) return rc;  // records into their particles' own slots
     }
     if (int rc = read_ctrl(c, true)) return rc;
-    const int cur = c->ctrl_host->live[c->slot], N = c->B.n, nf = c->nf;
-    const size_t S = (size_t) c->B.ncap;
-    std::vector<float4> pa(S), pb(S);
-    std::vector<float2> pc(S);
-    HIP_TRY(hipMemcpy(pa.data(), c->B.poseA[cur], sizeof(float4) * S, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(pb.data(), c->B.poseB[cur], sizeof(float4) * S, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(pc.data(), c->B.poseC[cur], sizeof(float2) * S, hipMemcpyDeviceToHost));
-    for (int i = 0; i < N; i++) {
+    const int cur = c->ctrl_host->live[c->slot], nf = c->nf;
+    const size_t S = (size_t) c->B.ncap, M = (size_t) count;
+    if (count == 0) return 0;
+    std::vector<float4> pa(M), pb(M);
+    std::vector<float2> pc(M);
+    HIP_TRY(hipMemcpy(pa.data(), c->B.poseA[cur] + first, sizeof(float4) * M, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pb.data(), c->B.poseB[cur] + first, sizeof(float4) * M, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pc.data(), c->B.poseC[cur] + first, sizeof(float2) * M, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < M; i++) {
         if (xv) {
             xv[3 * i] = pa[i].x;
             xv[3 * i + 1] = pa[i].y;
@@ -1175,7 +1184,7 @@ int slamgpu_download(slamgpu_ctx *c, float *xv, float *Pv9, float *w, float *xf,
         }
         if (Pv9) {
             const float p00 = pb[i].x, p10 = pb[i].y, p11 = pb[i].z, p20 = pb[i].w, p21 = pc[i].x, p22 = pc[i].y;
-            float *P = Pv9 + 9 * (size_t) i;
+            float *P = Pv9 + 9 * i;
             P[0] = p00; P[1] = p10; P[2] = p20;
             P[3] = p10; P[4] = p11; P[5] = p21;
             P[6] = p20; P[7] = p21; P[8] = p22;
@@ -1183,33 +1192,46 @@ int slamgpu_download(slamgpu_ctx *c, float *xv, float *Pv9, float *w, float *xf,
         if (w) w[i] = pa[i].w;
     }
     if ((xf || Pf4) && nf > 0) {
-        std::vector<float4> la(S * nf);
-        std::vector<float> lb(S * nf);
-        // every landmark row has its own live buffer (kernels.h: lmk_live)
+        // every landmark row has its own live buffer (kernels.h: lmk_live); rows are fetched a bounded batch at a time so
+        // that a 10 000-landmark context does not need the whole slice on the host twice
         std::vector<int32_t> live(nf);
         HIP_TRY(hipMemcpy(live.data(), c->B.lmk_live[c->lslot], sizeof(int32_t) * nf, hipMemcpyDeviceToHost));
-        for (int j = 0; j < nf; j++) {
-            HIP_TRY(hipMemcpy(la.data() + (size_t) j * S, c->B.lmkA[live[j]] + (size_t) j * S, sizeof(float4) * S, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(lb.data() + (size_t) j * S, c->B.lmkB[live[j]] + (size_t) j * S, sizeof(float) * S, hipMemcpyDeviceToHost));
-        }
-        for (int i = 0; i < N; i++)
-            for (int j = 0; j < nf; j++) {
-                const float4 a = la[(size_t) j * S + i];
-                const float b = lb[(size_t) j * S + i];
-                if (xf) {
-                    xf[((size_t) i * nf + j) * 2] = a.x;
-                    xf[((size_t) i * nf + j) * 2 + 1] = a.y;
-                }
-                if (Pf4) {
-                    float *P = Pf4 + ((size_t) i * nf + j) * 4;
-                    P[0] = a.z;
-                    P[1] = a.w;
-                    P[2] = a.w;
-                    P[3] = b;
-                }
+        const int batch = (int) std::max<size_t>(1, std::min<size_t>((size_t) nf, ((size_t) 64 << 20) / (20 * M)));
+        std::vector<float4> la(M * batch);
+        std::vector<float> lb(M * batch);
+        for (int j0 = 0; j0 < nf; j0 += batch) {
+            const int jn = std::min(batch, nf - j0);
+            for (int j = 0; j < jn; j++) {
+                const size_t row = (size_t) (j0 + j) * S + first;
+                HIP_TRY(hipMemcpyAsync(la.data() + (size_t) j * M, c->B.lmkA[live[j0 + j]] + row, sizeof(float4) * M, hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipMemcpyAsync(lb.data() + (size_t) j * M, c->B.lmkB[live[j0 + j]] + row, sizeof(float) * M, hipMemcpyDeviceToHost, c->stream));
             }
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            for (size_t i = 0; i < M; i++)
+                for (int j = 0; j < jn; j++) {
+                    const float4 a = la[(size_t) j * M + i];
+                    const float b = lb[(size_t) j * M + i];
+                    const size_t at = i * nf + (size_t) (j0 + j);
+                    if (xf) {
+                        xf[at * 2] = a.x;
+                        xf[at * 2 + 1] = a.y;
+                    }
+                    if (Pf4) {
+                        float *P = Pf4 + at * 4;
+                        P[0] = a.z;
+                        P[1] = a.w;
+                        P[2] = a.w;
+                        P[3] = b;
+                    }
+                }
+        }
     }
     return 0;
+}
+
+int slamgpu_download(slamgpu_ctx *c, float *xv, float *Pv9, float *w, float *xf, float *Pf4) {
+    if (int rc = check_ctx(c)) return rc;
+    return slamgpu_download_range(c, 0, c->B.n, xv, Pv9, w, xf, Pf4);
 }
 
 int slamgpu_upload(slamgpu_ctx *c, int32_t nf, const float *xv, const float *Pv9, const float *w, const float *xf,

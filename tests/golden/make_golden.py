@@ -324,5 +324,19 @@ def make_ekf(R, name, mapname, seed, extra=()):
     print(name, "control steps", len(xs), "final dim", dims[-1], "%.0f KB" % (os.path.getsize(path) / 1024))
 
 
+def make_log_kats(R):
+    """gaussEvaluate(v, S, logflag = 1) of the reference objects (fastslam2.cpp:154-160) on the same S, v as the
+    logflag = 0 KATs: pins the log-weight extension of the oracle where the reference itself can go."""
+    k = np.load(os.path.join(OUT, "kat_functions.npz"))
+    d = {}
+    for D in (2, 3):
+        S, v = k["gauss%d_S" % D], k["gauss%d_v" % D]
+        d["gauss%d_log" % D] = np.array([R.gauss_evaluate(v[i].copy(), S[i].copy(), 1) for i in range(S.shape[0])], f32)
+    np.savez_compressed(os.path.join(OUT, "kat_log.npz"), **d)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "log":
+        make_log_kats(orc.Reference())  # only the logflag = 1 vectors (added in round 2)
+    else:
+        main()

@@ -1,0 +1,129 @@
+"""BASELINE configs[4] ("config 5"): FASTSLAM2, 100 000 particles, synthetic 10 000-landmark map (i.i.d. uniform over the
+webmap bounding box, SplitMix64(12345)), webmap waypoints and .ini.
+
+  * representable range (MAX_RANGE 6 => ~13 landmarks per step): the reference's linear float32 weights, teacher-forced
+    against the oracle, both builds;
+  * MAX_RANGE 60 (~1.3 k re-observed landmarks per step, the config's real shape): log-weights (the linear product
+    overflows beyond ~20 landmarks), teacher-forced against the log-weight oracle at a particle count the oracle finishes
+    in seconds, both builds;
+  * full size (100 000 particles x 10 000-landmark capacity, 48 GB of device state): size-independent properties --
+    per-particle independence (with resampling off, particle i of the 100 000-particle run is bit-identical to particle i
+    of a 512-particle run: same Philox streams, the update never looks at another particle), finite normalised
+    log-weights, no degenerate step, Neff in (0, N], monotone ancestors, and the estimate follows the true path."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DATA, sim_args
+from test_gpu_logweights import check_step
+from test_gpu_parity import drive_pair
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def sg():
+    import slam_amd
+    assert slam_amd.device_count() >= 1
+    return slam_amd
+
+
+@pytest.fixture(scope="module")
+def synmap(tmp_path_factory):
+    from slam_amd import host
+    d = tmp_path_factory.mktemp("cfg5")
+    lm = host.synthetic_landmarks(12345, 10000, -130, 100, -100, 90)
+    h = host.HostSim(sim_args("example_webmap", "FASTSLAM2", 100, 7))
+    _, wp = h.map()
+    h.close()
+    mp = str(d / "synthetic10k.mat")
+    host.write_map(mp, lm, wp)
+    open(str(d / "synthetic10k.ini"), "w").write(open(os.path.join(DATA, "example_webmap.ini")).read())
+    return mp
+
+
+def args_for(mp, N, max_range, seed=7):
+    return ["-m", mp, "-method", "FASTSLAM2", "-NPARTICLES", N, "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", seed,
+            "-MAX_RANGE", max_range]
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+def test_config5_representable_range_linear_weights_vs_oracle(sg, oracle, synmap, math_mode):
+    from test_gpu_parity import compare_state, POSE_ATOL, W_TOL
+    ms = []
+
+    def check(r):
+        ms.append(r["m"])
+        tag = "obs %d (m=%d n=%d)" % (r["k"], r["m"], r["n"])
+        assert r["did"][0] == r["did"][1], tag
+        np.testing.assert_allclose(r["neff"][0], r["neff"][1], rtol=2e-2, err_msg=tag)
+        if r["did"][0]:
+            bad = np.abs(r["got"]["xv"] - r["exp"]["xv"]).max(axis=1) > POSE_ATOL
+            assert bad.mean() <= W_TOL[math_mode]["ancestors"], (tag, bad.mean())
+        else:
+            compare_state(r["got"], r["exp"], fs2=True, tag=tag, math_mode=math_mode)
+    drive_pair(sg, oracle, None, "FASTSLAM2", 500, 7, 12, math_mode=math_mode, args=args_for(synmap, 500, 6), per_step=check)
+    assert 8 <= max(ms) <= 24  # big-packet path, still representable in float32
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+def test_config5_full_range_log_weights_vs_oracle(sg, oracle, synmap, math_mode):
+    ms, ns = [], []
+
+    def check(r):
+        ms.append(r["m"])
+        ns.append(r["n"])
+        check_step(r, math_mode)
+    drive_pair(sg, oracle, None, "FASTSLAM2", 256, 7, 4, math_mode=math_mode, log_weights=True, args=args_for(synmap, 256, 60),
+               per_step=check)
+    assert max(ms) > 1000 and max(ns) > 1000  # ~1.3 k new landmarks on the first step, ~1.3 k re-observed afterwards
+
+
+def test_config5_full_size_properties(sg, synmap):
+    from slam_amd import host
+    N, n_small, steps = 100000, 512, 4
+    tape = host.make_tape(args_for(synmap, N, 60), max_obs=steps + 4)
+    Q, R, dt = tape["Q"], tape["R"], float(tape["dt"])
+    assert tape["nlm"] == 10000
+
+    def run(n, resample, nsteps):
+        s = sg.SlamGpu(n, tape["nlm"], method=2, n_effective=int(0.75 * n), resample=resample, rng_mode=sg.RNG_PHILOX, seed=7,
+                       math_mode=1, log_weights=True)
+        for st in tape["steps"][:nsteps]:
+            s.step(np.array(st["controls"], f32).reshape(-1, 3), Q, dt, st["zf"], st["idf"], st["zn"], R)
+        return s
+
+    # (1) per-particle independence, resampling off: first 512 particles of the full-size run == the 512-particle run
+    big, small = run(N, False, steps), run(n_small, False, steps)
+    hb, hs = big.history_fetch(), small.history_fetch()
+    assert not big.last_history_status.any() and not small.last_history_status.any()
+    a, b = big.download(first=0, count=n_small), small.download()
+    assert a["nf"] == b["nf"] and a["nf"] > 1500
+    for key in ("xv", "Pv", "xf", "Pf"):
+        assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), key
+    # log-weights differ by the normalisation constant only (each run normalises over its own particles)
+    d = a["w"].astype(np.float64) - b["w"].astype(np.float64)
+    assert np.isfinite(d).all() and np.ptp(d) <= 2e-3 * max(1.0, np.abs(b["w"]).max()), np.ptp(d)
+    full = big.download(landmarks=False)
+    np.testing.assert_allclose(np.exp(full["w"].astype(np.float64)).sum(), 1.0, rtol=2e-3)
+    big.close()
+    small.close()
+
+    # (2) the filter proper at full size, resampling on
+    s = run(N, True, steps + 4)
+    est, neff, res = s.history_fetch()
+    assert not s.last_history_status.any()
+    assert np.isfinite(est).all() and np.all(neff > 0) and np.all(neff <= N * 1.001)
+    assert res.any()  # ~1.3 k observations per step collapse Neff: it must have resampled
+    err = np.array([np.hypot(e[0] - st["true"][0], e[1] - st["true"][1]) for e, st in zip(est, tape["steps"])])
+    assert err.mean() < 0.5, err
+    if res[-1]:
+        keep = s.ancestors()
+        assert np.all(np.diff(keep) >= 0) and keep.min() >= 0 and keep.max() < N
+    d = s.download(landmarks=False)
+    assert np.isfinite(d["w"]).all() and np.isfinite(d["xv"]).all()
+    if res[-1]:
+        assert np.all(d["w"] == d["w"][0]) and abs(float(d["w"][0]) - np.log(1.0 / N)) < 1e-4
+    s.close()

@@ -1,0 +1,108 @@
+"""Log-weight contexts (slamgpu_config.log_weights) on the GPU, through the C ABI, against the oracle's log-weight
+extension (oracle/slam_oracle.c: orc_particles_set_log_weights), which is itself pinned to the reference's
+gaussEvaluate(logflag = 1) and to the linear-weight run where that one is representable (tests/test_oracle_golden.py).
+
+Tolerances: poses / landmarks / covariances as everywhere (tests/test_gpu_parity.py).  Log-weights are compared after
+normalisation, as weights: |exp(l_gpu) / exp(l_oracle) - 1| within the same per-build bounds as the linear weights
+(W_TOL), because the same float32 evaluation noise of the prior / proposal Gaussians is in them; with ~80 landmarks per
+step the sum of log-likelihoods adds ~1e-4 per term of rounding, well inside those bounds."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import DATA, sim_args
+from test_gpu_parity import POSE_ATOL, W_TOL, close_cov, drive_pair, sym
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+@pytest.fixture(scope="module")
+def sg():
+    import slam_amd
+    assert slam_amd.device_count() >= 1
+    return slam_amd
+
+
+def check_step(r, math_mode, fs2=True, anc_tol=None):
+    tag = "obs %d (m=%d n=%d)" % (r["k"], r["m"], r["n"])
+    assert r["did"][0] == r["did"][1], tag
+    np.testing.assert_allclose(r["neff"][0], r["neff"][1], rtol=2e-2 if fs2 else 1e-3, err_msg=tag)
+    got, exp = r["got"], r["exp"]
+    assert got["nf"] == exp["xf"].shape[1]
+    if r["did"][0]:
+        bad = np.abs(got["xv"] - exp["xv"]).max(axis=1) > POSE_ATOL
+        assert bad.mean() <= (anc_tol if anc_tol is not None else W_TOL[math_mode]["ancestors"]), (tag, bad.mean())
+        assert np.all(got["w"] == got["w"][0]) and abs(got["w"][0] - np.log(1.0 / got["w"].shape[0])) < 1e-5
+        return
+    assert np.abs(got["xv"] - exp["xv"]).max() <= POSE_ATOL, (tag, np.abs(got["xv"] - exp["xv"]).max())
+    assert close_cov(got["Pv"], sym(exp["Pv"])), tag
+    if got["nf"]:
+        assert np.abs(got["xf"] - exp["xf"]).max() <= POSE_ATOL * 5, tag
+        assert close_cov(got["Pf"], sym(exp["Pf"])), tag
+    lg, le = got["w"].astype(np.float64), exp["w"].astype(np.float64)
+    assert np.isfinite(lg).all() and np.isfinite(le).all(), tag
+    np.testing.assert_allclose(np.exp(lg).sum(), 1.0, rtol=2e-3, err_msg=tag)  # normalised
+    if r["m"] > 0:
+        rel = np.abs(np.exp(lg - le) - 1.0)
+        tol = W_TOL[math_mode] if fs2 else dict(median=1e-3, p99=1e-3, max=1e-3)
+        assert np.median(rel) <= tol["median"] and np.quantile(rel, 0.99) <= tol["p99"] and rel.max() <= tol["max"], \
+            (tag, np.median(rel), np.quantile(rel, 0.99), rel.max())
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+@pytest.mark.parametrize("method,N,nobs", [("FASTSLAM2", 100, 100), ("FASTSLAM1", 100, 60), ("FASTSLAM2", 1000, 30)])
+def test_log_weights_webmap_vs_oracle(sg, oracle, method, N, nobs, math_mode):
+    """example_webmap, teacher-forced per step, both builds, small packets (kernel-argument path)."""
+    fs2 = method == "FASTSLAM2"
+    drive_pair(sg, oracle, "example_webmap", method, N, 7, nobs, math_mode=math_mode, log_weights=True,
+               per_step=lambda r: check_step(r, math_mode, fs2, anc_tol=None if fs2 else 0.0))
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+def test_log_weights_many_landmarks_vs_oracle(sg, oracle, tmp_path, math_mode):
+    """BASELINE config 5 in miniature: synthetic uniform map (2 000 landmarks on the webmap bounding box), MAX_RANGE 30
+    => ~80 re-observed landmarks per step (the reference's linear float32 weights overflow there,
+    tests/test_oracle_golden.py::test_log_weight_mode_survives_many_landmarks), device-resident observation packets,
+    the chunked landmark pipeline, hundreds of landmarks per particle; teacher-forced against the log-weight oracle."""
+    from slam_amd import host
+    lm = host.synthetic_landmarks(12345, 2000, -130, 100, -100, 90)
+    _, wp = host.HostSim(sim_args("example_webmap", "FASTSLAM2", 100, 7)).map()
+    mp = str(tmp_path / "syn2000.mat")
+    host.write_map(mp, lm, wp)
+    open(str(tmp_path / "syn2000.ini"), "w").write(open(os.path.join(DATA, "example_webmap.ini")).read())
+    N = 512
+    args = ["-m", mp, "-method", "FASTSLAM2", "-NPARTICLES", N, "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", 3, "-MAX_RANGE", 30]
+    ms = []
+
+    def check(r):
+        ms.append(r["m"])
+        check_step(r, math_mode)
+    drive_pair(sg, oracle, None, "FASTSLAM2", N, 3, 12, math_mode=math_mode, log_weights=True, args=args, per_step=check)
+    assert max(ms) > 40
+
+
+def test_log_weights_free_running_tracks_truth(sg, tmp_path):
+    """Free-running Philox run on the synthetic 2 000-landmark map at MAX_RANGE 30 with log-weights: finite normalised
+    log-weights at every step, no degenerate-step flag, the estimate follows the true path."""
+    from slam_amd import host
+    lm = host.synthetic_landmarks(12345, 2000, -130, 100, -100, 90)
+    _, wp = host.HostSim(sim_args("example_webmap", "FASTSLAM2", 100, 7)).map()
+    mp = str(tmp_path / "syn2000.mat")
+    host.write_map(mp, lm, wp)
+    open(str(tmp_path / "syn2000.ini"), "w").write(open(os.path.join(DATA, "example_webmap.ini")).read())
+    N = 4096
+    tape = host.make_tape(["-m", mp, "-method", "FASTSLAM2", "-NPARTICLES", N, "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", 3,
+                           "-MAX_RANGE", 30], max_obs=120)
+    s = sg.SlamGpu(N, tape["nlm"], method=2, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=5, math_mode=1, log_weights=True)
+    for st in tape["steps"]:
+        s.step(np.array(st["controls"], f32).reshape(-1, 3), tape["Q"], float(tape["dt"]), st["zf"], st["idf"], st["zn"], tape["R"])
+    est, neff, res = s.history_fetch()
+    assert not s.last_history_status.any()
+    assert np.isfinite(est).all() and np.all(neff > 0) and np.all(neff <= N * 1.001)
+    err = np.array([np.hypot(e[0] - st["true"][0], e[1] - st["true"][1]) for e, st in zip(est, tape["steps"])])
+    assert err.mean() < 0.5, err.mean()
+    d = s.download(landmarks=False)
+    assert np.isfinite(d["w"]).all()
+    s.close()

@@ -187,17 +187,21 @@ def test_teacher_forced_predict_vs_golden(sg):
             s.close()
 
 
-def drive_pair(sg, oracle, mapname, method, N, seed, nobs, math_mode=0, per_step=None, want_pre=False):
+def drive_pair(sg, oracle, mapname, method, N, seed, nobs, math_mode=0, per_step=None, want_pre=False, log_weights=False,
+               args=None):
     """Run the oracle simulation; feed the GPU context the same controls, observations and RNG tape; at each
-    observation step re-synchronise the GPU state to the oracle's (teacher forcing) after comparing."""
+    observation step re-synchronise the GPU state to the oracle's (teacher forcing) after comparing.
+    log_weights: both sides keep log-weights (slamgpu_config.log_weights / orc_particles_set_log_weights)."""
     from oracle import orc  # noqa: F401  (checker only)
-    o = oracle.sim(sim_args(mapname, method, N, seed))
+    o = oracle.sim(args if args is not None else sim_args(mapname, method, N, seed))
+    if log_weights:
+        o.set_log_weights(True)
     algo = o.algo()
     Q, R, dt = o.noise()
     m_id = 2 if method == "FASTSLAM2" else 1
     s = sg.SlamGpu(N, o.nlm, method=m_id, n_effective=algo.n_effective, use_heading=bool(algo.use_heading),
                    add_predict_noise=bool(algo.add_predict_noise), wheel_base=algo.wheel_base, sigma_phi=algo.sigma_phi,
-                   rng_mode=sg.RNG_TAPE, math_mode=math_mode)
+                   rng_mode=sg.RNG_TAPE, math_mode=math_mode, log_weights=log_weights)
     k = 0
     out = []
     while k < nobs:
@@ -249,7 +253,8 @@ def test_stepwise_vs_oracle(sg, oracle, method, N, seed, nobs, math_mode):
         np.testing.assert_allclose(r["neff"][0], r["neff"][1], rtol=2e-2 if fs2 else 1e-4, err_msg=tag)
         if r["did"][0]:
             bad = np.abs(r["got"]["xv"] - r["exp"]["xv"]).max(axis=1) > POSE_ATOL
-            assert bad.mean() <= (W_TOL[math_mode]["ancestors"] if fs2 else 0.0), (tag, bad.mean())
+            # FastSLAM1's weights agree to ~1e-4: identical ancestors at N=100, a boundary stratum or two at N=1000
+            assert bad.mean() <= (W_TOL[math_mode]["ancestors"] if fs2 else (0.0 if N <= 100 else 0.005)), (tag, bad.mean())
             anc_bad += int(bad.sum())
             anc_tot += bad.size
         else:

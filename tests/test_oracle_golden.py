@@ -210,3 +210,95 @@ def test_map_reader(oracle):
     lm, wp = oracle.read_map(os.path.join(DATA, "example_webmap.mat"))
     assert lm.shape == (2, 35) and wp.shape == (2, 17)
     assert abs(lm[0, 0] - 2.9922) < 1e-6 and abs(lm[1, 0] + 25.7009) < 1e-6
+
+
+# ---- log-weight extension of the oracle (mirrors slamgpu_config.log_weights) --------------------------------------
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_gauss_evaluate_logflag1(oracle, kat, D):
+    """The reference's own log branch of gaussEvaluate (fastslam2.cpp:154-160), bit-exact against the reference objects
+    (tests/golden/kat_log.npz, generated by make_golden.py log): the building block of the log-weight mode."""
+    import os
+    from conftest import GOLDEN
+    exp = np.load(os.path.join(GOLDEN, "kat_log.npz"))["gauss%d_log" % D]
+    S, v = kat["gauss%d_S" % D], kat["gauss%d_v" % D]
+    got = np.array([oracle.gauss_evaluate(v[i].copy(), S[i].copy(), 1) for i in range(S.shape[0])], f32)
+    fin = np.isfinite(exp)
+    assert fin.sum() >= 56 and bits_equal(got[fin], exp[fin])
+    # and it IS the log of the linear branch where that one is representable: D = 2 exactly the same normaliser, D = 3
+    # differs by the constant sqrt(2 pi) (integer D/2 in the linear branch, fastslam2.cpp:152)
+    lin = kat["gauss%d_out" % D]
+    ok = fin & np.isfinite(lin) & (lin > 1e-30)
+    off = 0.0 if D == 2 else 0.5 * np.log(2 * np.pi)
+    assert np.abs(exp[ok] - (np.log(lin[ok].astype(np.float64)) - off)).max() <= 2e-4
+
+
+@pytest.mark.parametrize("method", ["FASTSLAM2", "FASTSLAM1"])
+def test_log_weight_mode_equals_linear_mode_where_representable(oracle, method):
+    """example_webmap (at most 7 landmarks per step: the linear float32 weights are representable): the log-weight
+    oracle run, fed the same tape, makes the same resampling decisions and exp(log-weight) reproduces the linear
+    weights; the poses and maps are identical until ancestors can differ at a cumulative-sum boundary."""
+    N, seed, nobs = 100, 7, 150
+    runs = []
+    for logw in (False, True):
+        o = oracle.sim(sim_args("example_webmap", method, N, seed))
+        if logw:
+            o.set_log_weights(True)
+        rec, k = [], 0
+        while k < nobs:
+            if o.step() == 1:
+                k += 1
+                rec.append((o.particles(), o.last_resample(), o.estimate()))
+        o.close()
+        runs.append(rec)
+    same_state = True
+    nres = 0
+    for k, ((pa, (nea, dida), ea), (pb, (neb, didb), eb)) in enumerate(zip(*runs)):
+        assert dida == didb, k
+        nres += int(dida)
+        np.testing.assert_allclose(neb, nea, rtol=2e-3)
+        if same_state:
+            same_state = np.array_equal(pa["xv"], pb["xv"])
+        if same_state:  # identical ancestors so far: everything but the weights' representation is bit-identical
+            assert bits_equal(pa["xf"], pb["xf"]) and bits_equal(pa["Pv"], pb["Pv"])
+            wl, wb = pa["w"].astype(np.float64), np.exp(pb["w"].astype(np.float64))
+            np.testing.assert_allclose(wb / wb.sum(), wl / wl.sum(), rtol=2e-3 if method == "FASTSLAM2" else 1e-4)
+            np.testing.assert_allclose(wb.sum(), 1.0, rtol=1e-4)  # normalised log-weights
+    assert nres >= 20 and k >= 100
+
+
+def test_log_weight_mode_survives_many_landmarks(oracle, tmp_path):
+    """BASELINE config 5 in miniature: synthetic uniform map, MAX_RANGE 30 => ~80 re-observed landmarks per step: the
+    linear float32 weights overflow (inf -> NaN after normalisation), the log-weights stay finite, normalised, and the
+    filter keeps tracking the true path."""
+    import os
+    from conftest import DATA
+    from slam_amd import host
+    lm = host.synthetic_landmarks(12345, 2000, -130, 100, -100, 90)
+    _, wp = host.HostSim(sim_args("example_webmap", "FASTSLAM2", 100, 7)).map()
+    mp = str(tmp_path / "syn2000.mat")
+    host.write_map(mp, lm, wp)
+    open(str(tmp_path / "syn2000.ini"), "w").write(open(os.path.join(DATA, "example_webmap.ini")).read())
+    args = ["-m", mp, "-method", "FASTSLAM2", "-NPARTICLES", 64, "-NEFFECTIVE", 48, "-SWITCH_SEED_RANDOM", 3, "-MAX_RANGE", 30]
+    out = {}
+    for logw in (False, True):
+        o = oracle.sim(args)
+        if logw:
+            o.set_log_weights(True)
+        k, ms, errs, finite = 0, [], [], True
+        while k < 25:
+            if o.step() == 1:
+                k += 1
+                ms.append(o.last_obs()["zf"].shape[0])
+                p = o.particles()
+                finite = finite and bool(np.isfinite(p["w"]).all())
+                x, _ = o.true_pose()
+                e = o.estimate()
+                errs.append(np.hypot(e[0] - x[0], e[1] - x[1]))
+                if logw and not o.last_resample()[1]:
+                    np.testing.assert_allclose(np.exp(p["w"].astype(np.float64)).sum(), 1.0, rtol=1e-3)
+        o.close()
+        out[logw] = (finite, max(ms), float(np.mean(errs)))
+    assert out[True][1] > 40                      # far beyond the ~20 landmarks float32 products survive
+    assert not out[False][0]                      # the reference arithmetic really does overflow here
+    assert out[True][0] and out[True][2] < 0.5    # log-weights: finite and tracking
