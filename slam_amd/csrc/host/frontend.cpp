@@ -302,11 +302,18 @@ bool Simulator::init(int argc, char **argv, std::string *err) {
     dt = conf.DT_CONTROLS;
     iwp = 0;
     table.assign((size_t) map.nlm, -1.0f);
+    seed();
+    return true;
+}
+
+// slamwrapper.cpp:48-52.  NB the reference constructs its accelerator object BEFORE the wrapper seeds libc rand()
+// (SLAMBackendApplication.cpp:22-24); a drop-in must keep that order, or seed again after creating the GPU context:
+// the first HIP call of a process initialises the runtime, which draws from libc rand() itself and would shift the tape.
+void Simulator::seed() {
     if (conf.SWITCH_SEED_RANDOM != 0)
         srand((unsigned) conf.SWITCH_SEED_RANDOM);
     else
         srand((unsigned) time(nullptr));
-    return true;
 }
 
 void Simulator::update_steering() {

@@ -48,6 +48,7 @@ class Simulator {
     int64_t control_steps = 0;
 
     bool init(int argc, char **argv, std::string *err);  // SLAMBackendApplication.cpp:59-89 + slamwrapper.cpp:8-53
+    void seed();                                         // slamwrapper.cpp:48-52 (call again after the GPU context exists)
     int control();                                       // slamwrapper.cpp:174-238 (+ dtSum bookkeeping)
     void observe();                                      // core.cpp:185-273, 438-449
     void associate_known(int nf, std::vector<float> &zf, std::vector<int32_t> &idf, std::vector<float> &zn);  // core.cpp:91-120

@@ -78,6 +78,9 @@ int main(int argc, char **argv) {
             fprintf(stderr, "slamgpu_create: %s\n", slamgpu_last_error());
             return EXIT_FAILURE;
         }
+        // the reference creates its accelerator object before the wrapper seeds rand() (SLAMBackendApplication.cpp:22-24,
+        // slamwrapper.cpp:48-52); HIP runtime initialisation draws from libc rand(), so seed (again) only now
+        sim.seed();
     } else {
         printf("EKFSLAM\n\n");
         ekf.enableBatchUpdate = c.SWITCH_BATCH_UPDATE == 1;

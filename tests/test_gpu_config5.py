@@ -75,7 +75,7 @@ def test_config5_full_range_log_weights_vs_oracle(sg, oracle, synmap, math_mode)
     def check(r):
         ms.append(r["m"])
         ns.append(r["n"])
-        check_step(r, math_mode)
+        check_step(r, math_mode, anc_tol=0.10)
     drive_pair(sg, oracle, None, "FASTSLAM2", 256, 7, 4, math_mode=math_mode, log_weights=True, args=args_for(synmap, 256, 60),
                per_step=check)
     assert max(ms) > 1000 and max(ns) > 1000  # ~1.3 k new landmarks on the first step, ~1.3 k re-observed afterwards
@@ -100,7 +100,7 @@ def test_config5_full_size_properties(sg, synmap):
     hb, hs = big.history_fetch(), small.history_fetch()
     assert not big.last_history_status.any() and not small.last_history_status.any()
     a, b = big.download(first=0, count=n_small), small.download()
-    assert a["nf"] == b["nf"] and a["nf"] > 1500
+    assert a["nf"] == b["nf"] and a["nf"] > 1300
     for key in ("xv", "Pv", "xf", "Pf"):
         assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), key
     # log-weights differ by the normalisation constant only (each run normalises over its own particles)

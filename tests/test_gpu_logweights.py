@@ -78,7 +78,9 @@ def test_log_weights_many_landmarks_vs_oracle(sg, oracle, tmp_path, math_mode):
 
     def check(r):
         ms.append(r["m"])
-        check_step(r, math_mode)
+        # dozens of likelihood terms per weight: a few more strata land on the other side of a cumulative-sum boundary
+        # than with the webmap's 3-7 (measured 6 % at a 64-landmark step, strict build)
+        check_step(r, math_mode, anc_tol=0.10)
     drive_pair(sg, oracle, None, "FASTSLAM2", N, 3, 12, math_mode=math_mode, log_weights=True, args=args, per_step=check)
     assert max(ms) > 40
 
