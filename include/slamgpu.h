@@ -260,6 +260,11 @@ int slamgpu_profile(slamgpu_ctx *ctx, int32_t enable);
 int slamgpu_kernel_time(slamgpu_ctx *ctx, const char *kernel, double *ms, int64_t *launches);
 /* Algorithmic bytes moved by the update path so far (SURVEY.md §8(d) formula, accumulated per step). */
 int slamgpu_algorithmic_bytes(slamgpu_ctx *ctx, double *update_bytes, double *predict_bytes);
+/* Diagnostic: wall-clock stamps (100 MHz) of the LAST update launch at the levels of its dependent-load chain, 16 per
+ * compute block (slot meaning: tools/stamps.py).  Only the instrumented build (slam_amd/libslamgpu_stamps.so, `make
+ * stamps`) writes them, and only for contexts created with SLAMGPU_STAMPS=1 in the environment; otherwise an error
+ * (or zeros).  Synchronises. */
+int slamgpu_debug_stamps(slamgpu_ctx *ctx, uint64_t *out, int32_t max_blocks, int32_t *nblocks);
 
 #ifdef __cplusplus
 }

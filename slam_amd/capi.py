@@ -19,7 +19,7 @@ DECLARED_SYMBOLS = [
     "slamgpu_kernel_time", "slamgpu_algorithmic_bytes", "slamgpu_shard_update", "slamgpu_shard_block_totals", "slamgpu_shard_plan",
     "slamgpu_shard_record_floats", "slamgpu_shard_pack", "slamgpu_shard_unpack", "slamgpu_shard_finish", "slamgpu_shard_estimate",
     "slamgpu_dev_alloc", "slamgpu_dev_free", "slamgpu_dev_copy", "slamgpu_dev_copy_async", "slamgpu_shard_estimate_async",
-    "slamgpu_shard_estimate_fetch", "slamgpu_step_status", "slamgpu_kat", "slamgpu_download_range",
+    "slamgpu_shard_estimate_fetch", "slamgpu_step_status", "slamgpu_kat", "slamgpu_download_range", "slamgpu_debug_stamps",
 ]
 
 
@@ -45,7 +45,8 @@ class ShardPlan(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_HERE, "libslamgpu.so")
+    # SLAMGPU_LIB: diagnostic override (tools/stamps.py loads the instrumented libslamgpu_stamps.so)
+    return os.environ.get("SLAMGPU_LIB") or os.path.join(_HERE, "libslamgpu.so")
 
 
 _lib = None
@@ -78,6 +79,7 @@ def load_library():
     L.slamgpu_history_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.slamgpu_step_status.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.slamgpu_kat.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+    L.slamgpu_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.slamgpu_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.slamgpu_ancestors.argtypes = [C.c_void_p, C.c_void_p]
     L.slamgpu_num_landmarks.argtypes = [C.c_void_p]
@@ -375,6 +377,12 @@ class SlamGpu:
         out = np.zeros((max_count, 4), np.float64)
         n = C.c_int32()
         _chk(self.L.slamgpu_shard_estimate_fetch(self.h, _ptr(out), max_count, C.byref(n)))
+        return out[:n.value].copy()
+
+    def debug_stamps(self, max_blocks=8192):
+        out = np.zeros((max_blocks, 16), np.uint64)
+        n = C.c_int32()
+        _chk(self.L.slamgpu_debug_stamps(self.h, _ptr(out), max_blocks, C.byref(n)))
         return out[:n.value].copy()
 
     def stream(self):

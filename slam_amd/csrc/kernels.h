@@ -160,7 +160,9 @@ struct UpdateArgs {
     int32_t finalize_par;    // parity of the estimate partials the helper block reduces
     int32_t finalize;        // 1: the extra block reduces the previous update's pose-estimate partials
     double *finalize_hist;   // history slot of that estimate (kHistStride doubles) or null
+    unsigned long long *stamps;  // diagnostic build (-DSLAM_STAMPS, libslamgpu_stamps.so): [compute blocks][kStampSlots] wall-clock stamps
 };
+constexpr int kStampSlots = 16;
 
 // The weight scratch is double-buffered by the parity of the observation step (wpar): the update launch of step t
 // writes lcum / blk_w [wpar] while -- when it also plans the resampling of step t-1 inline -- its blocks are still

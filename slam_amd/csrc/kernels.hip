@@ -8,6 +8,22 @@
 namespace SLAM_KNS {
 using namespace slamgpu;
 
+// Diagnostic build only (make stamps -> libslamgpu_stamps.so, tools/stamps.py): thread 0 of every compute block drains its
+// wave's outstanding memory operations and records the 100 MHz wall clock at the levels of the update kernel's
+// dependent-load chain.  The drain is the point (the stamp is the time the level's data has ARRIVED); it perturbs the
+// overlap a little, so the instrumented kernel is slower than the product's.  Compiled out of the product libraries.
+#ifdef SLAM_STAMPS
+#define SLAM_STAMP(k)                                                                                      \
+    do {                                                                                                   \
+        if (U.stamps && threadIdx.x == 0 && (int) blockIdx.x < ws.nblocks) {                               \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                    \
+            U.stamps[(size_t) blockIdx.x * kStampSlots + (k)] = wall_clock64();                            \
+        }                                                                                                  \
+    } while (0)
+#else
+#define SLAM_STAMP(k)
+#endif
+
 // ---------------------------------------------------------------------------------------------------
 // predictState x nsteps with the pose in registers: FastSLAM2::predictState (fastslam2.cpp:70-105)
 // [+ observeHeading -> josephUpdate (fastslam2.cpp:113-125, core.cpp:294-317)] or
@@ -467,11 +483,13 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     extern __shared__ double off[];  // inline plan: [nblocks + 1] exclusive prefix of the previous step's block totals
     __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
     __shared__ EstItem sh_est[kBlock / kWave];
+    SLAM_STAMP(0);  // kernel entry
     const size_t S = (size_t) B.ncap;
     Ctrl *ctrl = B.ctrl;
     const int cur = ctrl->live[B.slot];
     const int nb = ws.nblocks;
     const bool helper = blockIdx.x == gridDim.x - 1 && (int) blockIdx.x >= nb;
+    SLAM_STAMP(1);  // Ctrl words arrived
     // Where does particle i of the set this update works on come from?
     //   plan_inline: the resampling stage of the previous update has not run: every block redoes its scan of the block
     //                totals (=> sum w, Neff, decision, identical everywhere) and every thread finds its own ancestor
@@ -507,6 +525,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         }
         __syncthreads();
     }
+    SLAM_STAMP(2);  // block totals scanned: W, Neff, decision known
     const int out = pend ? cur ^ 1 : cur;
     auto ancestor = [&](int k) -> int {
         if (!U.plan_inline) return ws.keep[B.slot][k];
@@ -558,6 +577,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         // (sharded runs, keep[i] < 0) slot i of the OUTPUT buffers: the particle arrived from another shard and
         // shard_unpack_kernel has already put its pose and genealogy in place
         int si = pend ? ancestor(i) : i;
+        SLAM_STAMP(3);  // ancestor found (two dependent rounds of the in-block search)
         int sb = cur;
         if (ARR && si < 0) {
             si = i;
@@ -686,6 +706,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         int4 cq[kEarly];
 #pragma unroll
         for (int t = 0; t < kEarly; t++) cq[t] = idxS[(size_t) U.small.chunk_id[min(t, max(nchs - 1, 0))] * S + si];
+        SLAM_STAMP(4);  // pose + genealogy chunks of the ancestor arrived
         float x = pa.x, y = pa.y, th = pa.z;
         // resampled particles restart at 1/N (core.cpp:744-747); otherwise the weights are normalised (core.cpp:726-729;
         // resample_kernel has already done it unless this launch plans inline)
@@ -753,9 +774,11 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                         } else {
                             load_lmk(idf[k], slot_of(idf[k]), la, lb);
                         }
+                        if (k == 0) SLAM_STAMP(5);  // records staged (slot -> record round trips done)
                         first_pass(k, la, lb);
                     }
                 }
+                SLAM_STAMP(6);  // proposal pass done
                 const L3r Lp = llt3r(P);
                 const float xs = ffma(Lp.l00, g0, x);
                 const float ys = ffma(Lp.l11, g1, ffma(Lp.l10, g0, y));
@@ -781,6 +804,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                         second_pass(k, la, lb);
                     }
                 }
+                SLAM_STAMP(7);  // likelihood / feature-update pass done, record stores landed
                 // w *= likelihood * prior / proposal (:360-367): one exponential for the ratio of the two Gaussians
                 const float E = gauss3_exponent(L0, x0 - xs, y0 - ys, wrap_pi(th0 - ths)) -
                                 gauss3_exponent(Lp, x - xs, y - ys, wrap_pi(th - ths));
@@ -1014,6 +1038,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         }
     }
 
+    SLAM_STAMP(8);  // pose / genealogy stores landed
     if (U.plan_inline) {
         ei_prev = block_reduce_est(ei_prev, sh_est);
         if (threadIdx.x == 0) {
@@ -1061,6 +1086,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         ws.blk_w[ws.wpar][blockIdx.x] = base + s;
         ws.blk_w[ws.wpar][ws.nblocks + blockIdx.x] = ((sh_w2[0] + sh_w2[1]) + sh_w2[2]) + sh_w2[3];
     }
+    SLAM_STAMP(9);  // weight prefix + totals written: end of the block
 }
 
 // ---------------------------------------------------------------------------------------------------

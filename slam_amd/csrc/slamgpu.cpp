@@ -115,6 +115,7 @@ struct slamgpu_ctx {
     };
     bool scan_ready = false;      // scan_kernel ran on the last update's block totals (large contexts)
     int scan_min_blocks = 1024;   // contexts with more blocks of 256 particles than this use scan_kernel (262 144 particles)
+    unsigned long long *stamps_dev = nullptr;  // diagnostic (SLAMGPU_STAMPS=1 + libslamgpu_stamps.so): UpdateArgs::stamps
     EstStage unplanned;           // the last update: resampling stage not run yet
     EstStage unreduced;           // an update whose partials exist (est_part[par]) but are not reduced yet
 };
@@ -383,6 +384,7 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     if (c->cfg.n_particles_global <= 0) c->cfg.n_particles_global = c->cfg.n_particles;
     c->k = cfg->math_mode == SLAMGPU_MATH_FAST ? kernels_fast() : kernels_strict();
     if (const char *e = getenv("SLAMGPU_SCAN_MIN_BLOCKS")) c->scan_min_blocks = atoi(e);  // diagnostic
+    const bool want_stamps = getenv("SLAMGPU_STAMPS") != nullptr;                         // diagnostic
     const int cap_nf = cfg->max_landmarks > 0 ? cfg->max_landmarks : 1;
     c->B.n = n;
     c->B.ncap = ncap;
@@ -444,6 +446,10 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
         CTX_TRY(hipMemsetAsync(c->ws.keep[b], 0, sizeof(int32_t) * S, c->stream));
     }
     CTX_TRY(hipMalloc((void **) &c->hist_dev, sizeof(double) * kHistStride * (size_t) kHistCap));
+    if (want_stamps) {
+        CTX_TRY(hipMalloc((void **) &c->stamps_dev, sizeof(unsigned long long) * kStampSlots * (size_t) c->ws.nblocks));
+        CTX_TRY(hipMemsetAsync(c->stamps_dev, 0, sizeof(unsigned long long) * kStampSlots * (size_t) c->ws.nblocks, c->stream));
+    }
     // big-packet ring: header + idf[cap] + zf[2cap] + zn[2cap]
     c->pkt_bytes = ((sizeof(ObsPacket) + sizeof(int32_t) * cap_nf + sizeof(float) * 4 * cap_nf + sizeof(uint32_t) * ((cap_nf + 31) / 32)) + 255) / 256 * 256;
     CTX_TRY(hipHostMalloc((void **) &c->pkt_host, c->pkt_bytes * kRing, hipHostMallocDefault));
@@ -497,6 +503,7 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     for (int b = 0; b < 2; b++)
         if (c->ws.keep[b]) (void) hipFree(c->ws.keep[b]);
     if (c->hist_dev) (void) hipFree(c->hist_dev);
+    if (c->stamps_dev) (void) hipFree(c->stamps_dev);
     if (c->pkt_host) (void) hipHostFree(c->pkt_host);
     if (c->pkt_dev) (void) hipFree(c->pkt_dev);
     for (int i = 0; i < kRing; i++)
@@ -679,6 +686,7 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     U.do_resample = c->cfg.resample;
     U.n_effective = c->cfg.n_effective;
     U.logw = c->cfg.log_weights;
+    U.stamps = c->stamps_dev;
     U.finalize = c->unreduced.has ? 1 : 0;  // (sharded: this shard's partials of the previous step, shard_finalize_kernel)
     U.finalize_hist = c->unreduced.hist;
     U.finalize_par = c->unreduced.par;
@@ -1361,6 +1369,19 @@ int slamgpu_jacobians(const float *in, uint32_t n, float *out) {
     (void) hipFree(din);
     (void) hipFree(dout);
     return rc;
+}
+
+int slamgpu_debug_stamps(slamgpu_ctx *c, uint64_t *out, int32_t max_blocks, int32_t *nblocks) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!nblocks) return fail(SLAMGPU_ERR_INVALID, "null output");
+    *nblocks = 0;
+    if (!c->stamps_dev) return fail(SLAMGPU_ERR_INVALID, "no stamps: create the context with SLAMGPU_STAMPS=1 in the environment");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int n = std::min(max_blocks, c->ws.nblocks);
+    if (n > 0 && out) HIP_TRY(hipMemcpy(out, c->stamps_dev, sizeof(uint64_t) * kStampSlots * (size_t) n, hipMemcpyDeviceToHost));
+    *nblocks = n;
+    return 0;
 }
 
 int slamgpu_kat(int32_t math_mode, int32_t op, const float *in, int32_t n, float *out) {
