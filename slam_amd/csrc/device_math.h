@@ -298,6 +298,54 @@ SLAM_DEV void mvgauss3(float &x0, float &x1, float &x2, const L3 &L, float g0, f
     x2 = s2 + x2;
 }
 
+// ---- wave64 prefix sums / reductions on the DPP data path ---------------------------------------------------------
+// `__shfl_up` / `__shfl_xor` compile to ds_bpermute_b32 (an LDS-crossbar round trip, ~100 cycles of dependent latency
+// each, two per double): the six-step scans and reductions of the update kernel spent ~1.5 us per launch in them
+// (profiles/update_kernel_levels_r02_before_*.txt: levels 2 and 9).  DPP moves are VALU operands (~8 cycles).  gfx9
+// wave64 scan: row_shr 1, 2, 4, 8 inside each row of 16 lanes, then row_bcast:15 into rows 1 and 3 and row_bcast:31
+// into rows 2 and 3; lanes without a source read 0 (old = 0, bound_ctrl off), which is the identity of the sum.
+// The association is fixed by the lane layout, so every block, kernel and shard computes bit-identical sums.
+template <int CTRL, int ROW_MASK>
+SLAM_DEV int dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false); }
+template <int CTRL, int ROW_MASK>
+SLAM_DEV float dpp_f(float v) { return __int_as_float(dpp_i<CTRL, ROW_MASK>(__float_as_int(v))); }
+template <int CTRL, int ROW_MASK>
+SLAM_DEV double dpp_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = dpp_i<CTRL, ROW_MASK>((int) (b & 0xffffffffll)), hi = dpp_i<CTRL, ROW_MASK>((int) (b >> 32));
+    return __longlong_as_double(((long long) hi << 32) | (unsigned int) lo);
+}
+
+SLAM_DEV float wave_scan_f(float v) {  // inclusive prefix sum over the 64 lanes
+    v += dpp_f<0x111, 0xf>(v);
+    v += dpp_f<0x112, 0xf>(v);
+    v += dpp_f<0x114, 0xf>(v);
+    v += dpp_f<0x118, 0xf>(v);
+    v += dpp_f<0x142, 0xa>(v);
+    v += dpp_f<0x143, 0xc>(v);
+    return v;
+}
+
+SLAM_DEV double wave_scan_d(double v) {
+    v += dpp_d<0x111, 0xf>(v);
+    v += dpp_d<0x112, 0xf>(v);
+    v += dpp_d<0x114, 0xf>(v);
+    v += dpp_d<0x118, 0xf>(v);
+    v += dpp_d<0x142, 0xa>(v);
+    v += dpp_d<0x143, 0xc>(v);
+    return v;
+}
+
+// lane 63's value in every lane (uniform)
+SLAM_DEV float wave_last_f(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63)); }
+SLAM_DEV double wave_last_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int) (b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int) (b >> 32), 63);
+    return __longlong_as_double(((long long) hi << 32) | (unsigned int) lo);
+}
+SLAM_DEV float wave_sum_f(float v) { return wave_last_f(wave_scan_f(v)); }
+SLAM_DEV double wave_sum_d(double v) { return wave_last_d(wave_scan_d(v)); }
+
 // ---- Philox4x32-10, identical to oracle/slam_oracle.c:orc_philox4x32 --------------------------------
 struct U4 {
     uint32_t x, y, z, w;

@@ -14,15 +14,21 @@ namespace slamgpu {
 //   poseC : float2[Ncap]          p21, p22                                      (40 B per particle)
 //   lmkA  : float4[cap_nf][Ncap]  xf.x, xf.y, Pf p00, p10
 //   lmkB  : float [cap_nf][Ncap]  Pf p11                                         (20 B per landmark)
-//   idxQ  : int4  [cap_nf/4][Ncap] landmark genealogy: WHICH SLOT of row j holds particle k's landmark j
-//                                  (4 landmarks per 16-B chunk)                   (4 B per landmark)
-// Landmark records are not moved when the particle set is resampled: only the slot indices are (idxQ, 4 B instead of
-// 20 B per landmark), so offspring share their ancestor's records until the landmark is observed again.  Every
-// particle re-observes the same landmarks in a step (the association is per step, not per particle), so that step
-// writes a fresh record for every particle into the row's OTHER buffer at the particle's own slot, sets the index to
-// "own slot" and flips the row's live flag (lmk_live[j], uniform for all particles) -- nothing a sibling still reads is
-// ever overwritten.  Composition of non-decreasing ancestor maps is non-decreasing, so reads through idxQ coalesce
-// like the plain gather did.
+//   gen   : int32 [cap_nf+1][Ncap] landmark GENEALOGY rows: which slot of its row holds particle k's record (4 B per row)
+// Landmark records are not moved when the particle set is resampled: only slot indices are.  Every particle re-observes
+// the same landmarks in a step (the association is per step, not per particle), so that step writes a fresh record for
+// every particle into the landmark row's OTHER buffer at the particle's own slot and flips the row's live flag
+// (lmk_live[j], uniform for all particles) -- nothing a sibling still reads is ever overwritten -- and offspring share
+// their ancestor's records until the landmark is observed again.
+// The slot of particle k's record of landmark j is the composition of the ancestor maps of every resample since j was
+// last written -- the same for ALL landmarks last written in the same step.  So the genealogy is kept per EPOCH (= the
+// step that last wrote a set of landmarks), not per landmark: row e of `gen` serves every landmark whose last write was
+// epoch e; the host knows which row each landmark uses (the association is global) and hands the rows of the
+// re-observed landmarks to the kernel with the observation packet.  A step that writes landmarks opens a new row
+// (identity: own slot); a resample composes the live rows with the ancestor map (4 B per particle and LIVE ROW, not per
+// landmark: ~25 rows on example_webmap, ~1 k rows after 1 000 steps of the 10 000-landmark map); a row is recycled when
+// no landmark uses it any more.  Composition of non-decreasing ancestor maps is non-decreasing, so reads through a row
+// coalesce like the plain gather did.
 // Two copies of everything (ping-pong for the resampling gather).  Which one is live, and whether the live set
 // still has to be read through the ancestor list of the last resample, is device-resident state (Ctrl.live /
 // Ctrl.pend), so no host round trip is needed to know whether a resample fired.
@@ -30,9 +36,13 @@ constexpr int kWave = 64;
 constexpr int kBlock = 256;
 constexpr int kMaxFusedPredict = 16;
 constexpr int kSmallObs = 12;       // observation packets up to this many zf / zn travel as kernel arguments
+constexpr int kSmallRows = 40;      // ... together with up to this many live genealogy rows (else: device-resident packet)
+constexpr int kRowsPerRole = 16;    // genealogy rows composed by one copy role (x 256 particles)
+constexpr int kRowLiveBit = 1 << 30;  // packet row[k]: the landmark's live record buffer rides in bit 30 of its genealogy row
 constexpr int kPoolBit = (int) 0x80000000;  // genealogy entry: the record lives in the arrival pool (Buffers::poolA/B)
 constexpr int kHistStride = 6;      // doubles per pose-estimate history entry: sum x, sum y, heading, max w, Neff, resampled
 constexpr int kMaxScanBlocks = 8192;
+constexpr int kPivLdsBlocks = 512;   // contexts up to this many blocks (131 072 particles) keep the pivot table in LDS (32 KB)
 // status bits of an update's resampling stage (slamgpu.h: SLAMGPU_STATUS_*)
 constexpr int kStatusDegenerate = 1;  // sum of the weights zero or not finite: the reference normalises to NaN (core.cpp:726-729)  // block totals scanned inside every resample block (LDS)
 
@@ -61,7 +71,13 @@ struct Buffers {
     float2 *poseC[2];
     float4 *lmkA[2];
     float *lmkB[2];
-    int4 *idxQ[2];        // genealogy chunks; the live one is the pose's (Ctrl.live): both are gathered together
+    int32_t *gen[2];      // genealogy rows [cap_rows][Ncap]; the live one is the pose's (Ctrl.live): both are gathered together
+    // device copies of the host's genealogy bookkeeping, refreshed before the kernels that need them (gather, flatten,
+    // shard pack / unpack; the update kernel gets what it needs with the observation packet)
+    const int32_t *erow;  // [cap_nf] row of every landmark
+    const int32_t *rows;  // [n_rows] live rows
+    int32_t n_rows;
+    int32_t cap_rows;
     // Sharded runs: landmark records of particles that ARRIVED from another shard.  Such a record needs a place no
     // sibling shares; rather than settling the whole shard it goes into this side pool ([cap_nf][pool_cap]) and the
     // genealogy entry says so (kPoolBit | pool slot).  Descendants share pool records like any other; the entry is
@@ -69,34 +85,32 @@ struct Buffers {
     float4 *poolA;
     float *poolB;
     int32_t pool_cap;
-    int32_t *lmk_live[2]; // [cap_nf] live record buffer of every landmark row, double-buffered by `lslot`: the update
-                          // launch reads lmk_live[lslot] and writes the flags for the next launch into lmk_live[lslot^1]
+    const int32_t *lmk_live;  // [cap_nf] which record buffer of every landmark row is live: device copy of the host's table
+                              // (the association is global, so the host knows: a re-observed row flips, a flatten /
+                              // settle flips all), refreshed for flatten / shard pack + unpack; the update kernel gets
+                              // the flags of the landmarks it touches with the observation packet (bit 30 of row[k])
     Ctrl *ctrl;
     int32_t n;        // local particles
     int32_t ncap;     // row stride (>= n, multiple of 256)
     int32_t cap_nf;
     int32_t slot;     // which Ctrl.live / Ctrl.pend entry this launch reads (host-tracked)
-    int32_t lslot;    // which lmk_live entry this launch reads (host-tracked; flipped after every update launch)
 };
 
 struct ObsPacket {          // big packets live in device memory, uploaded once per update
     int32_t m, n, nf, pad;  // re-observed, new, landmarks before this update
     float R[4];
-    // followed by: int32 idf[m]; float zf[2m]; float zn[2n]; uint32 touched[(nf + n + 31) / 32]
-    // (offsets computed from m, n; `touched` = bitmap over the nf + n landmarks after this update of the ones it
-    //  writes: the re-observed and the new.  A genealogy chunk (4 landmarks) with a non-zero nibble belongs to the
-    //  compute blocks; the copy roles of a pending lazy gather compose the others.)
+    // followed by: int32 idf[m]; float zf[2m]; float zn[2n]; int32 row[m]; int32 rows[n_rows]
+    // (offsets computed from m, n; row[k] = genealogy row of re-observed landmark k BEFORE this update; rows = the rows
+    //  still in use after it, without the one this update opens: what the copy roles of a pending lazy gather compose;
+    //  n_rows travels in UpdateArgs)
 };
-
-constexpr int kSmallChunks = 2 * kSmallObs;  // distinct genealogy chunks a small packet can touch (m + n <= 24 landmarks)
 
 struct SmallObs {           // small packets travel in the kernel argument segment
     int32_t idf[kSmallObs];
+    int32_t row[kSmallObs];          // genealogy row of each re-observed landmark before this update
     float zf[2 * kSmallObs];
     float zn[2 * kSmallObs];
-    int32_t nchunks;                 // genealogy chunks this update writes (re-observed or new landmarks), ascending
-    int32_t chunk_id[kSmallChunks];
-    int32_t chunk_mask[kSmallChunks];  // bit q set: landmark 4*chunk_id + q is re-observed or new
+    int32_t rows[kSmallRows];        // live rows after this update, without e_new (copy roles)
 };
 
 struct RngArgs {
@@ -148,7 +162,11 @@ struct UpdateArgs {
     const ObsPacket *big;    // null => use `small`
     SmallObs small;
     int32_t lazy;            // 1: single-context pipeline (honour Ctrl.pend, launch the copy + finalise blocks)
-    int32_t copy_lo, copy_hi;  // copy roles (particle tile x 8 genealogy chunks) of a pending lazy gather this launch carries
+    int32_t copy_lo, copy_hi;  // copy roles (particle tile x kRowsPerRole genealogy rows) of a pending lazy gather this launch carries
+    int32_t e_new;           // genealogy row this update opens for the landmarks it writes (-1: it writes none)
+    int32_t n_rows;          // live rows a pending gather composes (small.rows / the packet's rows): small packets: by the
+                             // compute threads themselves (at most kSmallRows rows); device packets: by copy roles
+    int32_t rows_per_role;   // ... of this many rows each
     // Inline planning: the resampling stage of the PREVIOUS update (Neff, decision, ancestors, pose-estimate partials)
     // has not run as a launch of its own; every block of this launch redoes its scan and every thread finds its own
     // ancestor, so a step is ONE launch.  0: that stage already ran (resample_kernel), honour Ctrl.pend / keep[].
@@ -169,9 +187,12 @@ constexpr int kStampSlots = 16;
 // searching lcum / blk_w [wpar ^ 1]; est_part[q] holds the pose-estimate partials of the last step of parity q.
 struct WeightScratch {
     float *lcum[2];     // [ncap]    inclusive in-block (256 particles) prefix of the raw weights
-    float *blk_w[2];    // [3*nblocks] block totals of w, then of w^2: one allocation, so a shard's totals travel as one
-                        //           contiguous message ([w(nb) | w2(nb)]); log-weight contexts: third row = the block's
-                        //           largest log-weight M_b, and w / w^2 / lcum are those of exp(l - M_b)
+    float *piv[2];      // [16*nblocks] every 16th entry of lcum (lcum[16 q + 15]), compact: the first level of the in-block
+                        //           ancestor search, small enough (64 B per block) to be prefetched into LDS by every block
+    float *blk_w[2];    // [3*nblocks] block totals T of w, then q = sum (w/T)^2 (scale-free: w^2 may overflow float32): one
+                        //           allocation, so a shard's totals travel as one contiguous message ([w(nb) | q(nb)]);
+                        //           log-weight contexts: third row = the block's largest log-weight M_b, and w / q / lcum
+                        //           are those of exp(l - M_b)
     double *est_part[2];  // [nblocks][4] pose-estimate partials (sum x, sum y, heading, max w)
     double *scan[2];      // [nblocks + 4] large contexts: exclusive prefix of the block totals, then sum w, sum w^2, max log-weight
                           // (scan_kernel), so that the update launch need not rescan the totals in every block
@@ -236,11 +257,11 @@ struct KernelTable {
     // large contexts: prefix of this step's block totals into WeightScratch::scan[wpar] (one block)
     void (*scan)(hipStream_t, const WeightScratch &, int logw);
     // materialise a pending lazy gather (needed before anything but the next update touches the particle set)
-    void (*gather)(hipStream_t, const Buffers &, const WeightScratch &, int nf);
-    // rewrite every landmark record into its particle's own slot (genealogy -> identity): download, sharded arrivals
+    void (*gather)(hipStream_t, const Buffers &, const WeightScratch &);
+    // rewrite every landmark record into its particle's own slot, genealogy row 0 = identity (download, sharded arrivals)
     void (*flatten)(hipStream_t, const Buffers &, int nf);
-    // identity genealogy ("every landmark in its particle's own slot") in idxQ[which]
-    void (*identity)(hipStream_t, const Buffers &, int which);
+    // identity ("own slot") in genealogy row `row` of gen[which]
+    void (*identity)(hipStream_t, const Buffers &, int which, int row);
     // reduce the estimate partials est_part[par] now (-> Ctrl.est, history slot)
     void (*finish)(hipStream_t, const Buffers &, const WeightScratch &, double *hist, int par);
     void (*predict)(hipStream_t, const Buffers &, const PredictArgs &, const RngArgs &);

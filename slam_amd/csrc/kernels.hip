@@ -217,17 +217,20 @@ SLAM_DEV void est_combine(EstItem &a, const EstItem &b) {
     }
 }
 
-// reduce over the 256 threads of a block; result valid in thread 0
+// reduce over the 256 threads of a block; result valid in thread 0.  Sums on the DPP path (device_math.h); the first
+// strictly greatest weight of a wave = the lowest lane holding the wave's maximum (indices ascend with the lane).
 SLAM_DEV EstItem block_reduce_est(EstItem v, EstItem *sh) {
+    v.sx = wave_sum_d(v.sx);
+    v.sy = wave_sum_d(v.sy);
+    float wm = v.w;
 #pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) {
-        EstItem o;
-        o.sx = __shfl_down(v.sx, d, kWave);
-        o.sy = __shfl_down(v.sy, d, kWave);
-        o.w = __shfl_down(v.w, d, kWave);
-        o.th = __shfl_down(v.th, d, kWave);
-        o.idx = __shfl_down(v.idx, d, kWave);
-        est_combine(v, o);
+    for (int d = kWave / 2; d > 0; d >>= 1) wm = fmaxf(wm, __shfl_xor(wm, d, kWave));
+    const unsigned long long holders = __ballot(v.w == wm);
+    if (holders) {
+        const int src = __ffsll((long long) holders) - 1;
+        v.w = wm;
+        v.th = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v.th), src));
+        v.idx = __builtin_amdgcn_readlane(v.idx, src);
     }
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     if (lane == 0) sh[wv] = v;
@@ -305,17 +308,10 @@ SLAM_DEV void scan_block_totals(const float *__restrict__ tot, int nb, int nbl, 
         const double tk = (double) tot[at] * sc;
         off[k] = tk;  // this thread's own segment: read back below
         a += tk;
-        q += (double) tot[at + nbl] * (sc * sc);
+        q += (double) tot[at + nbl] * (tk * tk);  // second row: sum (w_i / T)^2 of the block (update_kernel's tail)
     }
-    double sa = a;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const double v = __shfl_up(sa, d, kWave);
-        if (lane >= d) sa += v;
-    }
-    double sq = q;
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) sq += __shfl_xor(sq, d, kWave);
+    const double sa = wave_scan_d(a);
+    const double sq = wave_sum_d(q);
     if (lane == kWave - 1) sh_a[wv] = sa;
     if (lane == 0) sh_q[wv] = sq;
     __syncthreads();
@@ -360,7 +356,7 @@ SLAM_DEV float stratum_prev(const RngArgs &rng, int64_t gid) {
 // exp(M_b - M) like the block totals (scan_block_totals).  Linear weights: factor 1.0, same bits as without it.
 SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const float *__restrict__ lcum_local,
                                int first_block, int nb_local, int64_t n_global, const float *__restrict__ blk_m = nullptr,
-                               double M = 0.0) {
+                               double M = 0.0, const float *piv_lds = nullptr) {
     int b0 = 0, b1 = nb;
     while (b0 < b1) {
         const int mid = (b0 + b1) >> 1;
@@ -374,9 +370,17 @@ SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const f
     const float *lc = lcum_local + (size_t) lb * kBlock;
     // first slot with o + lc > target; the last slot if rounding hides it.  The prefix is non-decreasing, so instead of
     // 8 dependent probes: 16 pivots in flight together (every 16th entry), then the 16 entries of the pivot's segment
+    // (piv_lds: the pivots of every block were prefetched into LDS at kernel entry: one global round trip less)
     float pv[16];
+    if (piv_lds) {
+        const float4 *p4 = reinterpret_cast<const float4 *>(piv_lds + 16 * lb);
+        const float4 a0 = p4[0], a1 = p4[1], a2 = p4[2], a3 = p4[3];
+        pv[0] = a0.x; pv[1] = a0.y; pv[2] = a0.z; pv[3] = a0.w; pv[4] = a1.x; pv[5] = a1.y; pv[6] = a1.z; pv[7] = a1.w;
+        pv[8] = a2.x; pv[9] = a2.y; pv[10] = a2.z; pv[11] = a2.w; pv[12] = a3.x; pv[13] = a3.y; pv[14] = a3.z; pv[15] = a3.w;
+    } else {
 #pragma unroll
-    for (int q = 0; q < 16; q++) pv[q] = lc[16 * q + 15];
+        for (int q = 0; q < 16; q++) pv[q] = lc[16 * q + 15];
+    }
     int seg = 15;
 #pragma unroll
     for (int q = 14; q >= 0; q--)
@@ -395,62 +399,46 @@ SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const f
 // ---------------------------------------------------------------------------------------------------
 // Lazy gather, copy role: after a resample nothing is moved until the next update kernel, whose compute blocks
 // read their particle's pose and genealogy through keep[] and write them to the other buffer set; these blocks
-// compose the genealogy chunks that update does NOT write (idxQ_out[c][k] = idxQ[c][keep[k]]; 16 B per 4 landmarks
-// -- the 20-byte landmark records themselves stay where they are, kernels.h), 8 chunks x 256 particles per block,
-// all loads in flight before the first store.  They run beside the compute blocks / the planning blocks, whose waves
-// spend most of their time waiting on dependent loads.
+// compose the genealogy rows still in use (gen_out[e][k] = gen[e][anc(k)]; 4 B per particle and LIVE ROW -- the
+// 20-byte landmark records themselves stay where they are, kernels.h), kRowsPerRole rows x 256 particles per block,
+// all loads in flight before the first store.  The row this update opens is written by the compute blocks (own slot).
+// They run beside the compute blocks / the planning blocks, whose waves spend most of their time waiting on
+// dependent loads.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kLmkPerBlockY = 8;    // landmark rows per block in the kernels that move records (flatten, pack, unpack)
-constexpr int kChunksPerRole = 8;   // genealogy chunks (4 landmarks each) per copy role
-
-// bitmap over the nf + n landmarks after this update of the ones it writes (big packets only, kernels.h: ObsPacket)
-SLAM_DEV const uint32_t *touched_bitmap(const UpdateArgs &U) {
-    const int32_t *idf = reinterpret_cast<const int32_t *>(U.big + 1);
-    return reinterpret_cast<const uint32_t *>(reinterpret_cast<const float *>(idf + U.m) + 2 * (U.m + U.n));
-}
-
-// does this update write a landmark of genealogy chunk c?  (uniform: scalar work)
-SLAM_DEV bool chunk_touched(const UpdateArgs &U, int c) {
-    if (U.big) return ((touched_bitmap(U)[c >> 3] >> ((c & 7) * 4)) & 0xFu) != 0;
-    bool hit = false;
-    for (int t = 0; t < U.small.nchunks; t++) hit |= (U.small.chunk_id[t] == c);
-    return hit;
-}
 
 template <class AncOf>
-SLAM_DEV void copy_genealogy(const Buffers &B, const UpdateArgs &U, const WeightScratch &ws, int cur, int role, AncOf anc_of) {
+SLAM_DEV void copy_genealogy(const Buffers &B, const int32_t *__restrict__ rows, int n_rows, int per_role, const WeightScratch &ws,
+                             int cur, int role, AncOf anc_of) {
     const int bx = role % ws.nblocks, by = role / ws.nblocks;
     const int k = bx * kBlock + threadIdx.x;
     if (k >= B.n) return;
     const size_t S = (size_t) B.ncap;
     const int anc = anc_of(k);
     if (anc < 0) return;  // sharded runs: arrived from another shard, genealogy already in place
-    const int4 *__restrict__ src = cur ? B.idxQ[1] : B.idxQ[0];
-    int4 *__restrict__ dst = cur ? B.idxQ[0] : B.idxQ[1];
-    const int c0 = by * kChunksPerRole, c1 = min((U.nf + 3) >> 2, c0 + kChunksPerRole);
-    for (int c = c0; c < c1; c += 4) {
-        // four chunks per trip, all loads in flight before the first store (named registers: an indexed array here
-        // ends up in scratch); the compute blocks own the chunks this update writes
-        const int d1 = min(c + 1, c1 - 1), d2 = min(c + 2, c1 - 1), d3 = min(c + 3, c1 - 1);
-        const int4 q0 = src[(size_t) c * S + anc], q1 = src[(size_t) d1 * S + anc];
-        const int4 q2 = src[(size_t) d2 * S + anc], q3 = src[(size_t) d3 * S + anc];
-        if (!chunk_touched(U, c)) dst[(size_t) c * S + k] = q0;
-        if (d1 > c && !chunk_touched(U, d1)) dst[(size_t) d1 * S + k] = q1;
-        if (d2 > d1 && !chunk_touched(U, d2)) dst[(size_t) d2 * S + k] = q2;
-        if (d3 > d2 && !chunk_touched(U, d3)) dst[(size_t) d3 * S + k] = q3;
+    const int32_t *__restrict__ src = cur ? B.gen[1] : B.gen[0];
+    int32_t *__restrict__ dst = cur ? B.gen[0] : B.gen[1];
+    const int r0 = by * per_role, r1 = min(n_rows, r0 + per_role);
+    for (int r = r0; r < r1; r += 4) {
+        // four rows per trip, all loads in flight before the first store (named registers: an indexed array here
+        // ends up in scratch)
+        const int d1 = min(r + 1, r1 - 1), d2 = min(r + 2, r1 - 1), d3 = min(r + 3, r1 - 1);
+        const int e0 = rows[r], e1 = rows[d1], e2 = rows[d2], e3 = rows[d3];
+        const int q0 = src[(size_t) e0 * S + anc], q1 = src[(size_t) e1 * S + anc];
+        const int q2 = src[(size_t) e2 * S + anc], q3 = src[(size_t) e3 * S + anc];
+        dst[(size_t) e0 * S + k] = q0;
+        if (d1 > r) dst[(size_t) e1 * S + k] = q1;
+        if (d2 > d1) dst[(size_t) e2 * S + k] = q2;
+        if (d3 > d2) dst[(size_t) e3 * S + k] = q3;
     }
 }
 
-// Helper block of the update launch: the live flags of the landmark rows for the NEXT launch (lmk_live[lslot ^ 1]):
-// a re-observed row flips (every particle has just written its record into the row's other buffer), all others carry.
-SLAM_DEV void advance_live_flags(const Buffers &B, const UpdateArgs &U) {
-    const int32_t *__restrict__ cur = B.lslot ? B.lmk_live[1] : B.lmk_live[0];
-    int32_t *__restrict__ nxt = B.lslot ? B.lmk_live[0] : B.lmk_live[1];
-    const int32_t *idf = U.big ? reinterpret_cast<const int32_t *>(U.big + 1) : U.small.idf;
-    for (int j = threadIdx.x; j < B.cap_nf; j += kBlock) nxt[j] = cur[j];
-    __syncthreads();
-    for (int q = threadIdx.x; q < U.m; q += kBlock) nxt[idf[q]] = cur[idf[q]] ^ 1;
+// device-resident observation packet (kernels.h: ObsPacket): idf[m] zf[2m] zn[2n] row[m] rows[n_rows]
+SLAM_DEV const int32_t *packet_row(const UpdateArgs &U) {
+    const int32_t *idf = reinterpret_cast<const int32_t *>(U.big + 1);
+    return reinterpret_cast<const int32_t *>(reinterpret_cast<const float *>(idf + U.m) + 2 * (U.m + U.n));
 }
+SLAM_DEV const int32_t *packet_rows(const UpdateArgs &U) { return packet_row(U) + U.m; }
 
 // ---------------------------------------------------------------------------------------------------
 // K1: [pending predicts] + per-particle observation update.  FastSLAM2::update body
@@ -460,7 +448,6 @@ SLAM_DEV void advance_live_flags(const Buffers &B, const UpdateArgs &U) {
 // prefix of the raw weights and the block totals of w and w^2 (inputs of resampleParticles'
 // normalisation / Neff / cumulative sum, core.cpp:726-729,781-788,813-824).
 // ---------------------------------------------------------------------------------------------------
-constexpr int kStage = 8;  // landmarks per particle kept in LDS between the two passes (40 KB per block)
 
 // ARR: the context is a shard whose particles may have ARRIVED from other shards (keep[i] < 0, arrival-pool records).
 // Single contexts instantiate ARR = false: per-lane buffer and pool selects cost them 6 % of the step for nothing.
@@ -470,6 +457,14 @@ constexpr int kStage = 8;  // landmarks per particle kept in LDS between the two
 // the genealogy slots of the chunk after that behind them, so a wave has ~2 x kBigChunk x 20 B per lane outstanding
 // instead of one dependent slot -> record round trip per landmark.
 constexpr int kBigChunk = 8;
+constexpr int kStage = 8;  // landmarks per particle kept in LDS between the two passes of a small packet
+
+// staged landmark slots per thread of an update launch (host and device agree on the dynamic LDS layout)
+__host__ __device__ inline int staging_slots(int method, bool big, int m) {
+    if (big) return kBigChunk;
+    if (method != 2 || m <= 0) return 0;
+    return m <= kStage / 2 ? kStage / 2 : kStage;
+}
 
 template <int METHOD, bool ARR, bool BIG>
 __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs PA, UpdateArgs U, RngArgs rng,
@@ -477,10 +472,29 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     __shared__ float sh_w[kBlock / kWave], sh_w2[kBlock / kWave];
     // landmarks re-observed this step, staged between the proposal pass and the likelihood/feature-update pass
     // (each thread only touches its own column: no barrier, no bank conflict: consecutive lanes, consecutive slots)
-    constexpr int kLds = BIG ? kBigChunk : (METHOD == 2 ? kStage : 1);
-    __shared__ float4 shA[kLds][kBlock];
-    __shared__ float shB[kLds][kBlock];
-    extern __shared__ double off[];  // inline plan: [nblocks + 1] exclusive prefix of the previous step's block totals
+    // dynamic LDS (sized by the launcher, staging_slots()): [slots][256] float4 + [slots][256] float of staged records,
+    // then -- inline plan only -- [nblocks + 1] doubles: exclusive prefix of the previous step's block totals.  Sizing the
+    // staging by the packet (0 / 4 / 8 landmarks) instead of a static 40 KB keeps 5-8 blocks per CU resident at the
+    // webmap's 3.5 landmarks per step instead of 3.
+    extern __shared__ __align__(16) unsigned char dyn_lds[];
+    const int nslots = staging_slots(METHOD, BIG, U.m);
+    float4 *const shA = reinterpret_cast<float4 *>(dyn_lds);
+    float *const shB = reinterpret_cast<float *>(dyn_lds + (size_t) nslots * kBlock * sizeof(float4));
+    double *const off = reinterpret_cast<double *>(dyn_lds + (size_t) nslots * kBlock * (sizeof(float4) + sizeof(float)));
+    // ... then, inline plan of a context of at most kPivLdsBlocks blocks: [16 * nblocks] floats, the pivot table of the
+    // previous step's in-block prefixes (WeightScratch::piv), requested at kernel entry together with the block totals
+    const bool piv_in_lds = U.plan_inline && !U.scan_global && ws.nblocks <= kPivLdsBlocks;
+    float *const pivs = reinterpret_cast<float *>(off + (((size_t) ws.nblocks + 3) & ~(size_t) 1));  // 16-byte aligned
+    constexpr int kPivPerThread = kPivLdsBlocks * 16 / 4 / kBlock;  // float4 per thread at the largest table
+    float4 pvreg[kPivPerThread];
+    if (piv_in_lds) {
+        const float4 *src = reinterpret_cast<const float4 *>(ws.piv[ws.wpar ^ 1]);
+#pragma unroll
+        for (int t = 0; t < kPivPerThread; t++) {
+            const int at = t * kBlock + (int) threadIdx.x;
+            pvreg[t] = at < ws.nblocks * 4 ? src[at] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
     __shared__ EstItem sh_est[kBlock / kWave];
     SLAM_STAMP(0);  // kernel entry
@@ -523,6 +537,13 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             ws.est_part[ws.wpar ^ 1][4 * (size_t) nb] = (double) neff;  // travels with the partials into the history
             ws.est_part[ws.wpar ^ 1][4 * (size_t) nb + 1] = (double) ((pend ? 1 : 0) | (weight_status(W, Q) << 1));
         }
+        if (piv_in_lds && pend) {
+#pragma unroll
+            for (int t = 0; t < kPivPerThread; t++) {
+                const int at = t * kBlock + (int) threadIdx.x;
+                if (at < nb * 4) reinterpret_cast<float4 *>(pivs)[at] = pvreg[t];
+            }
+        }
         __syncthreads();
     }
     SLAM_STAMP(2);  // block totals scanned: W, Neff, decision known
@@ -531,7 +552,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         if (!U.plan_inline) return ws.keep[B.slot][k];
         const double target = (double) stratum_prev(rng, (int64_t) k) * W;
         return (int) min(find_ancestor(target, offp, nb, ws.lcum[ws.wpar ^ 1], 0, nb, (int64_t) B.n,
-                                       logw ? ws.blk_w[ws.wpar ^ 1] + 2 * nb : nullptr, Mx), (int64_t) B.n - 1);
+                                       logw ? ws.blk_w[ws.wpar ^ 1] + 2 * nb : nullptr, Mx, piv_in_lds ? pivs : nullptr),
+                         (int64_t) B.n - 1);
     };
     if ((int) blockIdx.x >= nb) {
         // ---- helper blocks ---------------------------------------------------------------------------------
@@ -553,11 +575,13 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 ctrl->live[B.slot ^ 1] = pend ? cur ^ 1 : cur;
                 ctrl->pend[B.slot ^ 1] = 0;
             }
-            advance_live_flags(B, U);
             if (U.finalize) finish_estimate(B, ws, U.finalize_par, U.finalize_hist, sh_est);
             return;
         }
-        if (pend) copy_genealogy(B, U, ws, cur, U.copy_lo + (int) blockIdx.x - nb, ancestor);
+        if (pend) {
+            const int32_t *rows = BIG ? packet_rows(U) : U.small.rows;
+            copy_genealogy(B, rows, U.n_rows, U.rows_per_role, ws, cur, U.copy_lo + (int) blockIdx.x - nb, ancestor);
+        }
         return;
     }
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -586,78 +610,75 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         const float4 *__restrict__ poseA = sb ? B.poseA[1] : B.poseA[0];
         const float4 *__restrict__ poseB = sb ? B.poseB[1] : B.poseB[0];
         const float2 *__restrict__ poseC = sb ? B.poseC[1] : B.poseC[0];
-        const int4 *__restrict__ idxS = sb ? B.idxQ[1] : B.idxQ[0];
-        int4 *__restrict__ idxO = out ? B.idxQ[1] : B.idxQ[0];
-        const int32_t *__restrict__ live = B.lslot ? B.lmk_live[1] : B.lmk_live[0];
-        // landmark j of this particle: the slot comes from the genealogy, the buffer from the row's live flag; a landmark
-        // this update writes goes to the particle's OWN slot of the row's other buffer (kernels.h: idxQ)
-        auto slot_of = [&](int j) -> int {
-            return reinterpret_cast<const int *>(idxS + (size_t) (j >> 2) * S + si)[j & 3];
-        };
+        const int32_t *__restrict__ genS = sb ? B.gen[1] : B.gen[0];
+        int32_t *__restrict__ genO = out ? B.gen[1] : B.gen[0];
         struct Rec {
             float4 a;
             float b;
         };
-        auto load_rec = [&](int j, int s) -> Rec {
+        // record of landmark j in slot s of record buffer b (b: bit 30 of the packet's row word, see slot_of / buf_of)
+        auto load_rec = [&](int j, int s, int b) -> Rec {
             // kPoolBit set: a record that arrived from another shard lives in the arrival pool (kernels.h: Buffers::poolA).
             // Address select, not a branch: the staging arrays these references point into must stay in registers.
-            const int b = live[j];
             const bool pool = ARR && s < 0;
             const size_t at = pool ? (size_t) j * B.pool_cap + (size_t) (s & ~kPoolBit) : (size_t) j * S + (size_t) s;
             const float4 *pA = pool ? B.poolA : (b ? B.lmkA[1] : B.lmkA[0]);
             const float *pB = pool ? B.poolB : (b ? B.lmkB[1] : B.lmkB[0]);
             return Rec{pA[at], pB[at]};  // by value: a reference into the staging arrays would pin them to scratch
         };
-        auto load_lmk = [&](int j, int s, float4 &la, float &lb) {
-            const Rec r = load_rec(j, s);
+        auto load_lmk = [&](int j, int s, int b, float4 &la, float &lb) {
+            const Rec r = load_rec(j, s, b);
             la = r.a;
             lb = r.b;
         };
-        auto store_lmk = [&](int j, const float4 &la, float lb) {
-            const int b = live[j];
+        // a re-observed landmark's fresh record goes to the particle's own slot of the row's OTHER buffer
+        auto store_lmk = [&](int j, int b, const float4 &la, float lb) {
             (b ? B.lmkA[0] : B.lmkA[1])[(size_t) j * S + i] = la;
             (b ? B.lmkB[0] : B.lmkB[1])[(size_t) j * S + i] = lb;
         };
-        auto store_new = [&](int j, const float4 &la, float lb) {  // a new row keeps its flag: first record, live buffer
-            const int b = live[j];
-            (b ? B.lmkA[1] : B.lmkA[0])[(size_t) j * S + i] = la;
-            (b ? B.lmkB[1] : B.lmkB[0])[(size_t) j * S + i] = lb;
+        auto store_new = [&](int j, const float4 &la, float lb) {  // a new row starts in record buffer 0 (host: live flag 0)
+            B.lmkA[0][(size_t) j * S + i] = la;
+            B.lmkB[0][(size_t) j * S + i] = lb;
         };
 
-        const int32_t *__restrict__ idf;
+        const int32_t *__restrict__ idf, *__restrict__ lrow;
         const float *__restrict__ zf, *__restrict__ zn;
         if (BIG) {
             idf = reinterpret_cast<const int32_t *>(U.big + 1);
             zf = reinterpret_cast<const float *>(idf + m);
             zn = zf + 2 * m;
+            lrow = packet_row(U);
         } else {
             idf = U.small.idf;
             zf = U.small.zf;
             zn = U.small.zn;
+            lrow = U.small.row;
         }
+        // re-observed landmark k of this particle: the slot comes from the genealogy row the landmark uses (kernels.h:
+        // gen), the buffer from the row's live flag; a landmark this update writes goes to the particle's OWN slot of the
+        // row's other buffer and into the genealogy row this update opens (U.e_new: identity)
+        auto slot_of = [&](int k) -> int { return genS[(size_t) (lrow[k] & (kRowLiveBit - 1)) * S + si]; };
+        auto buf_of = [&](int k) -> int { return (lrow[k] >> 30) & 1; };
         const float r00 = U.R[0], r01 = U.R[1], r10 = U.R[2], r11 = U.R[3];
         // Stage the first KS re-observed landmarks in LDS with all their loads in flight together (one HBM latency instead
         // of one per landmark); both passes then read LDS.  Measured before this: 38 % of the wave's cycles were s_waitcnt
         // stalls (profiles/rocprof_sq_counters_r01.txt).  Unconditional loads (index clamped to the last landmark): no
         // branch between them, so the compiler issues all of them before the first s_waitcnt; duplicates are L1 hits.
         // Two sizes: most steps re-observe at most kStage/2 landmarks and need not pay for eight address computations.
-        auto stage_landmarks = [&](auto KS) {
+        auto stage_landmarks = [&](auto KS, const int *ts) {
             constexpr int ks = decltype(KS)::value;
             float4 ta[ks];
             float tb[ks];
-            int ts[ks];
-#pragma unroll
-            for (int k = 0; k < ks; k++) ts[k] = slot_of(idf[min(k, m - 1)]);
 #pragma unroll
             for (int k = 0; k < ks; k++) {
-                const Rec r = load_rec(idf[min(k, m - 1)], ts[k]);
+                const Rec r = load_rec(idf[min(k, m - 1)], ts[k], buf_of(min(k, m - 1)));
                 ta[k] = r.a;
                 tb[k] = r.b;
             }
 #pragma unroll
             for (int k = 0; k < ks; k++) {
-                shA[k][threadIdx.x] = ta[k];
-                shB[k][threadIdx.x] = tb[k];
+                shA[(k) * kBlock + threadIdx.x] = ta[k];
+                shB[(k) * kBlock + threadIdx.x] = tb[k];
             }
         };
 
@@ -670,12 +691,12 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             float tb[CH];
             auto load_slots = [&](int k0) {
 #pragma unroll
-                for (int k = 0; k < CH; k++) sl[k] = slot_of(idf[min(k0 + k, m - 1)]);
+                for (int k = 0; k < CH; k++) sl[k] = slot_of(min(k0 + k, m - 1));
             };
             auto load_recs = [&](int k0) {
 #pragma unroll
                 for (int k = 0; k < CH; k++) {
-                    const Rec r = load_rec(idf[min(k0 + k, m - 1)], sl[k]);
+                    const Rec r = load_rec(idf[min(k0 + k, m - 1)], sl[k], buf_of(min(k0 + k, m - 1)));
                     ta[k] = r.a;
                     tb[k] = r.b;
                 }
@@ -686,28 +707,48 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             for (int k0 = 0; k0 < m; k0 += CH) {
 #pragma unroll
                 for (int k = 0; k < CH; k++) {
-                    shA[k][threadIdx.x] = ta[k];
-                    shB[k][threadIdx.x] = tb[k];
+                    shA[(k) * kBlock + threadIdx.x] = ta[k];
+                    shB[(k) * kBlock + threadIdx.x] = tb[k];
                 }
                 if (k0 + CH < m) {
                     load_recs(k0 + CH);       // slots of this chunk were requested one chunk of compute ago
                     load_slots(k0 + 2 * CH);  // (clamped: harmless re-reads past the end)
                 }
                 const int kn = min(CH, m - k0);
-                for (int k = 0; k < kn; k++) body(k0 + k, shA[k][threadIdx.x], shB[k][threadIdx.x]);
+                for (int k = 0; k < kn; k++) body(k0 + k, shA[(k) * kBlock + threadIdx.x], shB[(k) * kBlock + threadIdx.x]);
             }
         };
 
-        float4 pa = poseA[si];
-        // the genealogy chunks this update rewrites (small packets: at most a handful) are fetched now, with the pose,
-        // not at the end of the kernel behind one more memory round trip
-        constexpr int kEarly = 8;
-        const int nchs = BIG ? 0 : U.small.nchunks;
-        int4 cq[kEarly];
+        // Small packets: a pending gather's genealogy composition (gen_out[e][i] = gen[e][ancestor], the live rows still in
+        // use) is done right here by the particle's own thread -- it knows its ancestor already -- instead of by helper
+        // blocks that would each redo the scan and the search: first kRowsA rows requested with the pose and stored when
+        // it arrives, the rest requested then and stored with the pose at the end (at most kSmallRows live rows).
+        constexpr int kRowsA = 24, kRowsB = kSmallRows - kRowsA;
+        const bool copy_inline = !BIG && pend && sb == cur;  // (an arrival's genealogy is already in place)
+        int ga[kRowsA], gb[kRowsB];
+        if (!BIG && copy_inline) {
 #pragma unroll
-        for (int t = 0; t < kEarly; t++) cq[t] = idxS[(size_t) U.small.chunk_id[min(t, max(nchs - 1, 0))] * S + si];
-        SLAM_STAMP(4);  // pose + genealogy chunks of the ancestor arrived
+            for (int r = 0; r < kRowsA; r++)
+                if (r < U.n_rows) ga[r] = genS[(size_t) U.small.rows[r] * S + si];
+        }
+        float4 pa = poseA[si];
+        // the slots of the (first kStage) re-observed landmarks are fetched now, with the pose: they depend on nothing but
+        // the source slot, so the records are one round trip behind the pose, not two
+        int ts[kStage];
+        if (!BIG) {
+#pragma unroll
+            for (int k = 0; k < kStage; k++) ts[k] = slot_of(min(k, max(m - 1, 0)));
+        }
+        SLAM_STAMP(4);  // pose + genealogy of the ancestor arrived
         float x = pa.x, y = pa.y, th = pa.z;
+        if (!BIG && copy_inline) {
+#pragma unroll
+            for (int r = 0; r < kRowsA; r++)
+                if (r < U.n_rows) genO[(size_t) U.small.rows[r] * S + i] = ga[r];
+#pragma unroll
+            for (int r = 0; r < kRowsB; r++)
+                if (kRowsA + r < U.n_rows) gb[r] = genS[(size_t) U.small.rows[kRowsA + r] * S + si];
+        }
         // resampled particles restart at 1/N (core.cpp:744-747); otherwise the weights are normalised (core.cpp:726-729;
         // resample_kernel has already done it unless this launch plans inline)
         // (log-weight contexts: l - (M + log sum exp(l - M)); Ctrl.inv_n holds log(1/N))
@@ -763,16 +804,16 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 if constexpr (BIG) {
                     pipeline(first_pass);
                 } else {
-                    if (m <= kStage / 2) stage_landmarks(std::integral_constant<int, kStage / 2>{});
-                    else stage_landmarks(std::integral_constant<int, kStage>{});
+                    if (m <= kStage / 2) stage_landmarks(std::integral_constant<int, kStage / 2>{}, ts);
+                    else stage_landmarks(std::integral_constant<int, kStage>{}, ts);
                     for (int k = 0; k < m; k++) {
                         float4 la;
                         float lb;
                         if (k < kStage) {
-                            la = shA[k][threadIdx.x];
-                            lb = shB[k][threadIdx.x];
+                            la = shA[(k) * kBlock + threadIdx.x];
+                            lb = shB[(k) * kBlock + threadIdx.x];
                         } else {
-                            load_lmk(idf[k], slot_of(idf[k]), la, lb);
+                            load_lmk(idf[k], slot_of(k), buf_of(k), la, lb);
                         }
                         if (k == 0) SLAM_STAMP(5);  // records staged (slot -> record round trips done)
                         first_pass(k, la, lb);
@@ -790,17 +831,17 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                     const Gauss2 g = feature_update2(la.x, la.y, la.z, la.w, lb, o, zf[2 * k] - o.zp0, wrap_pi(zf[2 * k + 1] - o.zp1));
                     if (logw) dl += (double) (g.E + __logf(g.norm));
                     else lik *= __expf(g.E) * g.norm;
-                    store_lmk(idf[k], la, lb);
+                    store_lmk(idf[k], buf_of(k), la, lb);
                 };
                 if constexpr (BIG) {
                     pipeline(second_pass);
                 } else {
                     const int ms = min(m, kStage);
-                    for (int k = 0; k < ms; k++) second_pass(k, shA[k][threadIdx.x], shB[k][threadIdx.x]);
+                    for (int k = 0; k < ms; k++) second_pass(k, shA[(k) * kBlock + threadIdx.x], shB[(k) * kBlock + threadIdx.x]);
                     for (int k = ms; k < m; k++) {
                         float4 la;
                         float lb;
-                        load_lmk(idf[k], slot_of(idf[k]), la, lb);
+                        load_lmk(idf[k], slot_of(k), buf_of(k), la, lb);
                         second_pass(k, la, lb);
                     }
                 }
@@ -888,16 +929,16 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 if constexpr (BIG) {
                     pipeline(first_pass);
                 } else {
-                    if (m <= kStage / 2) stage_landmarks(std::integral_constant<int, kStage / 2>{});
-                    else stage_landmarks(std::integral_constant<int, kStage>{});
+                    if (m <= kStage / 2) stage_landmarks(std::integral_constant<int, kStage / 2>{}, ts);
+                    else stage_landmarks(std::integral_constant<int, kStage>{}, ts);
                     for (int k = 0; k < m; k++) {
                         float4 la;
                         float lb;
                         if (k < kStage) {
-                            la = shA[k][threadIdx.x];
-                            lb = shB[k][threadIdx.x];
+                            la = shA[(k) * kBlock + threadIdx.x];
+                            lb = shB[(k) * kBlock + threadIdx.x];
                         } else {
-                            load_lmk(idf[k], slot_of(idf[k]), la, lb);
+                            load_lmk(idf[k], slot_of(k), buf_of(k), la, lb);
                         }
                         first_pass(k, la, lb);
                     }
@@ -917,7 +958,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                     if (logw) dl += (double) gauss2_log(v0, v1, j.s00, j.s10, j.s11);
                     else lik = lik * gauss2(v0, v1, j.s00, j.s10, j.s11);
                     cholesky_update2(la.x, la.y, la.z, la.w, lb, v0, v1, r00, r01, r10, r11, j.hf00, j.hf01, j.hf10, j.hf11);
-                    store_lmk(idf[k], la, lb);
+                    store_lmk(idf[k], buf_of(k), la, lb);
                 };
                 // two loops on purpose: the LDS-fed one issues only stores to HBM, so nothing in it has to wait for a
                 // store to land (a global load after a global store costs an s_waitcnt vmcnt(0) per iteration)
@@ -925,11 +966,11 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                     pipeline(second_pass);
                 } else {
                     const int ms = min(m, kStage);
-                    for (int k = 0; k < ms; k++) second_pass(k, shA[k][threadIdx.x], shB[k][threadIdx.x]);
+                    for (int k = 0; k < ms; k++) second_pass(k, shA[(k) * kBlock + threadIdx.x], shB[(k) * kBlock + threadIdx.x]);
                     for (int k = ms; k < m; k++) {
                         float4 la;
                         float lb;
-                        load_lmk(idf[k], slot_of(idf[k]), la, lb);
+                        load_lmk(idf[k], slot_of(k), buf_of(k), la, lb);
                         second_pass(k, la, lb);
                     }
                 }
@@ -974,7 +1015,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                         wp = wp * num / den;
                     }
                     cholesky_update2(la.x, la.y, la.z, la.w, lb, v0, v1, r00, r01, r10, r11, j.hf00, j.hf01, j.hf10, j.hf11);
-                    store_lmk(idf[k], la, lb);
+                    store_lmk(idf[k], buf_of(k), la, lb);
                 };
                 if constexpr (BIG) {
                     pipeline(one_pass);
@@ -982,7 +1023,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                     for (int k = 0; k < m; k++) {
                         float4 la;
                         float lb;
-                        load_lmk(idf[k], slot_of(idf[k]), la, lb);
+                        load_lmk(idf[k], slot_of(k), buf_of(k), la, lb);
                         one_pass(k, la, lb);
                     }
                 }
@@ -999,37 +1040,13 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             add_feature(x, y, th, zn[2 * k], zn[2 * k + 1], r00, r01, r10, r11, la.x, la.y, la.z, la.w, lb);
             store_new(nf + k, la, lb);
         }
-        // genealogy chunks holding a landmark this update wrote: those entries now say "own slot"; the whole chunk
-        // moves to slot i of the output set here (the copy roles of a pending gather leave these chunks alone)
-        auto compose = [&](int c, int mask) {
-            int4 q = idxS[(size_t) c * S + si];
-            if (mask & 1) q.x = i;
-            if (mask & 2) q.y = i;
-            if (mask & 4) q.z = i;
-            if (mask & 8) q.w = i;
-            idxO[(size_t) c * S + i] = q;
-        };
-        if (BIG) {
-            const uint32_t *bits = touched_bitmap(U);
-            const int nch = (nf + n + 3) >> 2;
-            for (int c = 0; c < nch; c++) {
-                const int mask = (int) ((bits[c >> 3] >> ((c & 7) * 4)) & 0xFu);
-                if (mask) compose(c, mask);
-            }
-        } else {
+        // the landmarks this update wrote are in this particle's own slot now: that is what the genealogy row this update
+        // opens says for all of them (the copy roles of a pending gather compose the other rows)
+        if (U.e_new >= 0) genO[(size_t) U.e_new * S + i] = i;
+        if (!BIG && copy_inline) {
 #pragma unroll
-            for (int t = 0; t < kEarly; t++) {
-                if (t < nchs) {
-                    const int mask = U.small.chunk_mask[t];
-                    int4 q = cq[t];
-                    if (mask & 1) q.x = i;
-                    if (mask & 2) q.y = i;
-                    if (mask & 4) q.z = i;
-                    if (mask & 8) q.w = i;
-                    idxO[(size_t) U.small.chunk_id[t] * S + i] = q;
-                }
-            }
-            for (int t = kEarly; t < nchs; t++) compose(U.small.chunk_id[t], U.small.chunk_mask[t]);
+            for (int r = 0; r < kRowsB; r++)
+                if (kRowsA + r < U.n_rows) genO[(size_t) U.small.rows[kRowsA + r] * S + i] = gb[r];
         }
         poseAo[i] = make_float4(x, y, th, w);
         if (METHOD == 2 && pose_dirty) {
@@ -1062,16 +1079,14 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         if (threadIdx.x == 0) ws.blk_w[ws.wpar][2 * ws.nblocks + blockIdx.x] = mb;
         w = (w == -INFINITY) ? 0.0f : expf(w - mb);  // NaN log-weights stay NaN and are flagged by the plan (status)
     }
-    // in-block inclusive prefix of w; block totals of w and w^2 (fixed association: deterministic)
-    float s = w;
-#pragma unroll
-    for (int d = 1; d < kWave; d <<= 1) {
-        const float t = __shfl_up(s, d, kWave);
-        if (lane >= d) s += t;
-    }
-    float s2 = w * w;
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) s2 += __shfl_xor(s2, d, kWave);
+    // in-block inclusive prefix of w; block totals of w and of w^2 (fixed association: deterministic).  The sum of squares
+    // is kept SCALE-FREE, as q = sum (w_i / T)^2 with T the block total (every partial a ratio <= 1): the reference computes
+    // Neff from the normalised weights (core.cpp:784-788) and survives weights whose square overflows float32 (w > 1.8e19:
+    // a dozen landmarks in one update); scan_block_totals rebuilds sum w^2 = q T^2 in double.
+    const float s = wave_scan_f(w);
+    const float tw = wave_last_f(s);  // this wave's total
+    const float rw = tw > 0.0f ? w / tw : 0.0f;
+    const float s2 = wave_sum_f(rw * rw);
     if (lane == kWave - 1) {
         sh_w[wv] = s;
         sh_w2[wv] = s2;
@@ -1082,9 +1097,19 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     for (int k = 0; k < kBlock / kWave; k++)
         if (k < wv) base += sh_w[k];
     ws.lcum[ws.wpar][i] = base + s;
+    if ((threadIdx.x & 15) == 15) ws.piv[ws.wpar][(size_t) blockIdx.x * 16 + (threadIdx.x >> 4)] = base + s;
     if (threadIdx.x == kBlock - 1) {
-        ws.blk_w[ws.wpar][blockIdx.x] = base + s;
-        ws.blk_w[ws.wpar][ws.nblocks + blockIdx.x] = ((sh_w2[0] + sh_w2[1]) + sh_w2[2]) + sh_w2[3];
+        const float T = base + s;
+        float q = 0.0f;
+        if (T > 0.0f) {
+#pragma unroll
+            for (int k = 0; k < kBlock / kWave; k++) {
+                const float f = sh_w[k] / T;
+                q += sh_w2[k] * (f * f);
+            }
+        }
+        ws.blk_w[ws.wpar][blockIdx.x] = T;
+        ws.blk_w[ws.wpar][ws.nblocks + blockIdx.x] = q;
     }
     SLAM_STAMP(9);  // weight prefix + totals written: end of the block
 }
@@ -1163,11 +1188,11 @@ __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScrat
     }
 }
 
-// Materialise a pending lazy gather: pose and genealogy chunks of keep[k] into slot k of the other buffer set,
-// w = 1/N (core.cpp:744-747); the landmark records stay where they are (kernels.h: idxQ).  Needed before anything
+// Materialise a pending lazy gather: pose and the live genealogy rows (B.rows) of keep[k] into slot k of the other buffer
+// set, w = 1/N (core.cpp:744-747); the landmark records stay where they are (kernels.h: gen).  Needed before anything
 // but the next update reads the set (download, stand-alone predict / estimate).  Every launch publishes the
-// resulting state in the other Ctrl slot; the host flips its slot afterwards.  blockIdx.y = group of 8 chunks.
-__global__ void __launch_bounds__(kBlock) gather_kernel(Buffers B, WeightScratch ws, int nf) {
+// resulting state in the other Ctrl slot; the host flips its slot afterwards.  blockIdx.y = group of kRowsPerRole rows.
+__global__ void __launch_bounds__(kBlock) gather_kernel(Buffers B, WeightScratch ws) {
     Ctrl *ctrl = B.ctrl;
     const int cur = ctrl->live[B.slot];
     const bool pend = ctrl->pend[B.slot] != 0;
@@ -1188,46 +1213,39 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(Buffers B, WeightScratch
         B.poseB[cur ^ 1][k] = B.poseB[cur][anc];
         B.poseC[cur ^ 1][k] = B.poseC[cur][anc];
     }
-    const int4 *__restrict__ src = B.idxQ[cur];
-    int4 *__restrict__ dst = B.idxQ[cur ^ 1];
-    const int c0 = blockIdx.y * kChunksPerRole, c1 = min((nf + 3) >> 2, c0 + kChunksPerRole);
-    for (int c = c0; c < c1; c++) dst[(size_t) c * S + k] = src[(size_t) c * S + anc];
+    const int32_t *__restrict__ src = B.gen[cur];
+    int32_t *__restrict__ dst = B.gen[cur ^ 1];
+    const int r0 = blockIdx.y * kRowsPerRole, r1 = min(B.n_rows, r0 + kRowsPerRole);
+    for (int r = r0; r < r1; r++) {
+        const size_t e = (size_t) B.rows[r];
+        dst[e * S + k] = src[e * S + anc];
+    }
 }
 
-// Flatten the genealogy: every landmark record into its particle's own slot of the row's other buffer, indices back
-// to "own slot", every row's live flag flipped (published in lmk_live[lslot ^ 1]; the host flips lslot).  Requires a
-// plain set (no pending gather).  Used by download and before records from other shards are put in place.
-// blockIdx.y = group of 8 landmarks = 2 genealogy chunks, owned by this block alone.
+// Flatten the genealogy: every landmark record into its particle's own slot of the row's other buffer, genealogy row 0
+// = identity (the host points every landmark at row 0 afterwards and flips every landmark row's live flag in its
+// table).  Requires a plain set (no pending gather), B.erow and B.lmk_live.  Used by download
+// and before records from other shards are put in place.  blockIdx.y = group of 8 landmarks.  Row 0 may be in use as a
+// source row: it is rewritten by a second launch (identity_kernel), after every block of this one has read it.
 __global__ void __launch_bounds__(kBlock) flatten_kernel(Buffers B, int nf) {
     const int cur = B.ctrl->live[B.slot];
-    const int32_t *__restrict__ live = B.lslot ? B.lmk_live[1] : B.lmk_live[0];
-    int32_t *__restrict__ nxt = B.lslot ? B.lmk_live[0] : B.lmk_live[1];
-    if (blockIdx.x == 0 && blockIdx.y == 0)
-        for (int j = threadIdx.x; j < B.cap_nf; j += kBlock) nxt[j] = j < nf ? live[j] ^ 1 : live[j];
+    const int32_t *__restrict__ live = B.lmk_live;
     const int k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= B.n) return;
     const size_t S = (size_t) B.ncap;
-    int4 *__restrict__ idx = B.idxQ[cur];
+    const int32_t *__restrict__ gen = B.gen[cur];
     const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(nf, j0 + kLmkPerBlockY);
-    for (int c = j0 >> 2; c < ((j1 + 3) >> 2); c++) {
-        const int4 q = idx[(size_t) c * S + k];
-        const int s4[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const int j = 4 * c + t;
-            if (j < j1) {
-                const int b = live[j];
-                if (s4[t] < 0) {  // arrival pool
-                    const size_t at = (size_t) j * B.pool_cap + (s4[t] & ~kPoolBit);
-                    B.lmkA[b ^ 1][(size_t) j * S + k] = B.poolA[at];
-                    B.lmkB[b ^ 1][(size_t) j * S + k] = B.poolB[at];
-                } else {
-                    B.lmkA[b ^ 1][(size_t) j * S + k] = B.lmkA[b][(size_t) j * S + s4[t]];
-                    B.lmkB[b ^ 1][(size_t) j * S + k] = B.lmkB[b][(size_t) j * S + s4[t]];
-                }
-            }
+    for (int j = j0; j < j1; j++) {
+        const int sl = gen[(size_t) B.erow[j] * S + k];
+        const int b = live[j];
+        if (sl < 0) {  // arrival pool
+            const size_t at = (size_t) j * B.pool_cap + (sl & ~kPoolBit);
+            B.lmkA[b ^ 1][(size_t) j * S + k] = B.poolA[at];
+            B.lmkB[b ^ 1][(size_t) j * S + k] = B.poolB[at];
+        } else {
+            B.lmkA[b ^ 1][(size_t) j * S + k] = B.lmkA[b][(size_t) j * S + sl];
+            B.lmkB[b ^ 1][(size_t) j * S + k] = B.lmkB[b][(size_t) j * S + sl];
         }
-        idx[(size_t) c * S + k] = make_int4(k, k, k, k);
     }
 }
 
@@ -1388,7 +1406,7 @@ __global__ void __launch_bounds__(kBlock) shard_plan_kernel(ShardPlanArgs A, Rng
 // arrival pool
 SLAM_DEV void read_through_genealogy(const Buffers &B, const int32_t *__restrict__ live, int cur, size_t S, int l, int anc,
                                      float4 &la, float &lb) {
-    const int sl = reinterpret_cast<const int *>(B.idxQ[cur] + (size_t) (l >> 2) * S + anc)[l & 3];
+    const int sl = B.gen[cur][(size_t) B.erow[l] * S + anc];
     if (sl < 0) {
         const size_t at = (size_t) l * B.pool_cap + (sl & ~kPoolBit);
         la = B.poolA[at];
@@ -1442,7 +1460,7 @@ __global__ void __launch_bounds__(kBlock) shard_pack_kernel(Buffers B, WeightScr
     }
     // the few offspring that leave the shard carry all their landmarks (one thread each: they are a fraction of a
     // percent of the particles; a second grid dimension would make every block redo the scan above for nothing)
-    const int32_t *__restrict__ live = B.lslot ? B.lmk_live[1] : B.lmk_live[0];
+    const int32_t *__restrict__ live = B.lmk_live;
     for (int l = 0; l < A.nf; l++) {
         float4 la;
         float lb;
@@ -1459,15 +1477,11 @@ __global__ void __launch_bounds__(kBlock) shard_pack_kernel(Buffers B, WeightScr
 //   A.pool_base < 0 (pool full): settle the whole shard: every output particle is written physically into the other pose /
 //     genealogy buffers and into the other buffer of every landmark row -- local offspring from their ancestor (keep[],
 //     through the ancestor's genealogy), arrivals from the receive buffer -- with identity genealogy, and every row's
-//     live flag flips (lmk_live[lslot ^ 1]; the host flips lslot).  Nothing references the pool afterwards.
+//     live flag flips (in the host's table).  Nothing references the pool afterwards.
 // blockIdx.y = group of 8 landmarks.
 __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightScratch ws, ShardUnpackArgs A) {
     const bool settle = A.pool_base < 0;
-    const int32_t *__restrict__ live = B.lslot ? B.lmk_live[1] : B.lmk_live[0];
-    if (settle && blockIdx.x == 0 && blockIdx.y == 0) {
-        int32_t *__restrict__ nxt = B.lslot ? B.lmk_live[0] : B.lmk_live[1];
-        for (int j = threadIdx.x; j < B.cap_nf; j += kBlock) nxt[j] = j < A.nf ? live[j] ^ 1 : live[j];
-    }
+    const int32_t *__restrict__ live = B.lmk_live;
     // local output particle: every one when settling, only the arrivals ([0, own_lo) and [own_hi, n)) otherwise
     int i = blockIdx.x * kBlock + threadIdx.x;
     if (!settle && i >= A.own_lo) i += A.own_hi - A.own_lo;
@@ -1478,12 +1492,11 @@ __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightS
     int s = 0;
     while (s + 1 < A.n_shards && i >= A.src_lo[s + 1]) s++;
     const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(A.nf, j0 + kLmkPerBlockY);
-    const int c_lo = 2 * (int) blockIdx.y, c_hi = min((A.nf + 3) >> 2, 2 * (int) blockIdx.y + 2);  // this group's chunks
     if (s == A.shard) {
         if (!settle) return;  // lazy gather through keep[] (recorded by this shard's own pack kernel)
         const int anc = ws.keep[B.slot ^ 1][i];
-        for (int c = c_lo; c < c_hi; c++) B.idxQ[cur ^ 1][(size_t) c * S + i] = make_int4(i, i, i, i);
         if (blockIdx.y == 0) {
+            B.gen[cur ^ 1][i] = i;  // settled: every landmark in genealogy row 0, own slot
             float4 pa = B.poseA[cur][anc];
             pa.w = B.ctrl->inv_n;
             B.poseA[cur ^ 1][i] = pa;
@@ -1513,7 +1526,7 @@ __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightS
         ws.keep[B.slot ^ 1][i] = -(__float_as_int(src[9 * cnt]) + 1);
     }
     if (settle) {
-        for (int c = c_lo; c < c_hi; c++) B.idxQ[cur ^ 1][(size_t) c * S + i] = make_int4(i, i, i, i);
+        if (blockIdx.y == 0) B.gen[cur ^ 1][i] = i;  // row 0, own slot
         for (int l = j0; l < j1; l++) {
             const float *f = src + (size_t) (10 + 5 * l) * cnt;
             const int b = live[l];
@@ -1523,7 +1536,8 @@ __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightS
     } else {
         const int p = A.pool_base + (int) (before + slot);  // arrival number within this step
         const int ref = kPoolBit | p;
-        for (int c = c_lo; c < c_hi; c++) B.idxQ[cur ^ 1][(size_t) c * S + i] = make_int4(ref, ref, ref, ref);
+        // every live genealogy row of this particle points at its pool slot (rows spread over the blockIdx.y groups)
+        for (int r = blockIdx.y; r < B.n_rows; r += gridDim.y) B.gen[cur ^ 1][(size_t) B.rows[r] * S + i] = ref;
         for (int l = j0; l < j1; l++) {
             const float *f = src + (size_t) (10 + 5 * l) * cnt;
             const size_t at = (size_t) l * B.pool_cap + p;
@@ -1615,7 +1629,9 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
     int grid = B.ncap / kBlock;
     if (U.lazy) grid += (U.copy_hi - U.copy_lo) + 1;
     // inline plan only: prefix of the previous step's block totals (launches that do not plan never touch off[])
-    const size_t lds = (U.plan_inline && !U.scan_global) ? sizeof(double) * ((size_t) ws.nblocks + 1) : 0;
+    const size_t lds = (size_t) staging_slots(U.method, U.big != nullptr, U.m) * kBlock * (sizeof(float4) + sizeof(float)) +
+                       ((U.plan_inline && !U.scan_global) ? sizeof(double) * (((size_t) ws.nblocks + 3) & ~(size_t) 1) : 0) +
+                       ((U.plan_inline && !U.scan_global && ws.nblocks <= kPivLdsBlocks) ? sizeof(float) * 16 * (size_t) ws.nblocks : 0);
     const int sel = (U.method == 2 ? 4 : 0) | (U.arrivals ? 2 : 0) | (U.big ? 1 : 0);
 #define SLAM_LAUNCH_UPDATE(M, A, G) hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, B, PA, U, rng, ws)
     switch (sel) {
@@ -1641,27 +1657,27 @@ static void launch_scan(hipStream_t st, const WeightScratch &ws, int logw) {
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, st, ws, logw);
 }
 
-static void launch_gather(hipStream_t st, const Buffers &B, const WeightScratch &ws, int nf) {
-    const int nq = (nf + 3) / 4;
-    const int gy = nq > 0 ? (nq + kChunksPerRole - 1) / kChunksPerRole : 1;
-    hipLaunchKernelGGL(gather_kernel, dim3(ws.nblocks, gy), dim3(kBlock), 0, st, B, ws, nf);
+static void launch_gather(hipStream_t st, const Buffers &B, const WeightScratch &ws) {
+    const int gy = B.n_rows > 0 ? (B.n_rows + kRowsPerRole - 1) / kRowsPerRole : 1;
+    hipLaunchKernelGGL(gather_kernel, dim3(ws.nblocks, gy), dim3(kBlock), 0, st, B, ws);
 }
 
-// identity genealogy in one idxQ buffer (context creation, upload)
-__global__ void __launch_bounds__(kBlock) identity_kernel(int4 *idx, int nq, int ncap) {
+// identity ("own slot") in one genealogy row (context creation, upload, flatten)
+__global__ void __launch_bounds__(kBlock) identity_kernel(int32_t *gen_row, int ncap) {
     const int k = blockIdx.x * kBlock + threadIdx.x;
-    if (k >= ncap) return;
-    for (int c = blockIdx.y; c < nq; c += gridDim.y) idx[(size_t) c * ncap + k] = make_int4(k, k, k, k);
+    if (k < ncap) gen_row[k] = k;
 }
 
-static void launch_identity(hipStream_t st, const Buffers &B, int which) {
-    const int nq = (B.cap_nf + 3) / 4;
-    hipLaunchKernelGGL(identity_kernel, dim3(B.ncap / kBlock, nq < 64 ? nq : 64), dim3(kBlock), 0, st, B.idxQ[which], nq, B.ncap);
+static void launch_identity(hipStream_t st, const Buffers &B, int which, int row) {
+    hipLaunchKernelGGL(identity_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B.gen[which] + (size_t) row * B.ncap, B.ncap);
 }
 
 static void launch_flatten(hipStream_t st, const Buffers &B, int nf) {
     const int gy = nf > 0 ? (nf + kLmkPerBlockY - 1) / kLmkPerBlockY : 1;
     hipLaunchKernelGGL(flatten_kernel, dim3(B.ncap / kBlock, gy), dim3(kBlock), 0, st, B, nf);
+    // row 0 may have been a source row of that launch: it becomes the identity only now
+    hipLaunchKernelGGL(identity_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B.gen[0], B.ncap);
+    hipLaunchKernelGGL(identity_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B.gen[1], B.ncap);
 }
 
 static void launch_finish(hipStream_t st, const Buffers &B, const WeightScratch &ws, double *hist, int par) {

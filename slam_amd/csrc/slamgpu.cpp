@@ -95,7 +95,6 @@ struct slamgpu_ctx {
     // Ctrl.live / Ctrl.pend slot the next launch reads (kernels.h: Ctrl); flipped after every launch that may
     // change the live buffer (resample_kernel, gather_kernel, shard_commit_kernel)
     int64_t pool_used = 0;        // arrival-pool slots handed out since the pool was last emptied (flatten / settle / upload)
-    int lslot = 0;                // which lmk_live entry the next launch reads (flipped after every update launch, flatten, settle)
     bool shard_settled = false;   // the sharded resampling stage of this step moved everything physically (records arrived)
     int slot = 0;
     int keep_slot = 0;            // which WeightScratch::keep buffer holds the ancestors of the last update
@@ -115,6 +114,18 @@ struct slamgpu_ctx {
     };
     bool scan_ready = false;      // scan_kernel ran on the last update's block totals (large contexts)
     int scan_min_blocks = 1024;   // contexts with more blocks of 256 particles than this use scan_kernel (262 144 particles)
+    // Genealogy bookkeeping (kernels.h: gen).  The association is global, so the host knows which genealogy row every
+    // landmark uses: a step that writes landmarks opens a new row for them; a row whose last landmark moved on is recycled.
+    std::vector<uint32_t> seen_step; // [cap_nf] observation step that last re-observed each landmark (duplicate check)
+    std::vector<int32_t> live_flag;  // [cap_nf] which record buffer of every landmark row is live (flips when re-observed)
+    int32_t *live_dev = nullptr;     // device copy for flatten / shard pack + unpack
+    std::vector<int32_t> erow;       // [cap_nf] row of every landmark
+    std::vector<int32_t> refcnt;     // [cap_rows] landmarks using each row
+    std::vector<int32_t> free_rows;  // stack of unused rows
+    std::vector<int32_t> live_rows;  // rows with refcnt > 0
+    std::vector<int32_t> live_pos;   // [cap_rows] position in live_rows, -1 if not live
+    int32_t *erow_dev = nullptr, *rows_dev = nullptr;  // device copies for gather / flatten / shard pack + unpack
+    bool tables_dirty = true;
     unsigned long long *stamps_dev = nullptr;  // diagnostic (SLAMGPU_STAMPS=1 + libslamgpu_stamps.so): UpdateArgs::stamps
     EstStage unplanned;           // the last update: resampling stage not run yet
     EstStage unreduced;           // an update whose partials exist (est_part[par]) but are not reduced yet
@@ -224,6 +235,54 @@ void compose_predicts(PredictArgs &P) {
     C.m22 = (float) M[2][2];
 }
 
+// ---- genealogy rows (host bookkeeping) ----
+void rows_add_live(slamgpu_ctx *c, int r) {
+    c->live_pos[r] = (int32_t) c->live_rows.size();
+    c->live_rows.push_back(r);
+}
+
+void rows_remove_live(slamgpu_ctx *c, int r) {
+    const int p = c->live_pos[r], last = c->live_rows.back();
+    c->live_rows[p] = last;
+    c->live_pos[last] = p;
+    c->live_rows.pop_back();
+    c->live_pos[r] = -1;
+}
+
+// every landmark [0, nf) in row 0 (own slot): after upload, flatten, a settling unpack
+void rows_reset(slamgpu_ctx *c, int nf) {
+    const int cap_rows = c->B.cap_rows;
+    std::fill(c->refcnt.begin(), c->refcnt.end(), 0);
+    std::fill(c->live_pos.begin(), c->live_pos.end(), -1);
+    std::fill(c->erow.begin(), c->erow.end(), 0);
+    c->live_rows.clear();
+    c->free_rows.clear();
+    for (int r = cap_rows - 1; r >= (nf > 0 ? 1 : 0); r--) c->free_rows.push_back(r);  // back() = lowest free row
+    if (nf > 0) {
+        c->refcnt[0] = nf;
+        rows_add_live(c, 0);
+    }
+    c->tables_dirty = true;
+}
+
+// device copies of the row tables for the kernels that run outside the update launch
+int sync_tables(slamgpu_ctx *c) {
+    c->B.erow = c->erow_dev;
+    c->B.rows = c->rows_dev;
+    c->B.lmk_live = c->live_dev;
+    c->B.n_rows = (int32_t) c->live_rows.size();
+    if (!c->tables_dirty) return 0;
+    if (c->nf > 0) {
+        HIP_TRY(hipMemcpyAsync(c->erow_dev, c->erow.data(), sizeof(int32_t) * (size_t) c->nf, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->live_dev, c->live_flag.data(), sizeof(int32_t) * (size_t) c->nf, hipMemcpyHostToDevice, c->stream));
+    }
+    if (!c->live_rows.empty())
+        HIP_TRY(hipMemcpyAsync(c->rows_dev, c->live_rows.data(), sizeof(int32_t) * c->live_rows.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // pageable sources: the vectors may change right after
+    c->tables_dirty = false;
+    return 0;
+}
+
 // Make the particle set plain again (particle k in slot k of the live buffers) if the last update may have left a
 // lazy gather: everything except the next update launch needs that.
 int flush_stages(slamgpu_ctx *c);
@@ -232,10 +291,11 @@ int materialize(slamgpu_ctx *c) {
     if (int rc = flush_stages(c)) return rc;  // the plan of the last update decides whether anything is pending
     if (!c->maybe_pending) return 0;
     HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = sync_tables(c)) return rc;
     c->B.slot = c->slot;
     {
         Timed t(c, "gather");
-        c->k->gather(c->stream, c->B, c->ws, c->nf);
+        c->k->gather(c->stream, c->B, c->ws);
     }
     HIP_TRY(hipGetLastError());
     c->slot ^= 1;
@@ -249,16 +309,16 @@ int flatten(slamgpu_ctx *c) {
     if (int rc = materialize(c)) return rc;
     if (c->nf == 0) return 0;
     HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = sync_tables(c)) return rc;
     c->B.slot = c->slot;
-    c->B.lslot = c->lslot;
     {
         Timed t(c, "flatten");
         c->k->flatten(c->stream, c->B, c->nf);
     }
     HIP_TRY(hipGetLastError());
-    c->lslot ^= 1;
-    c->B.lslot = c->lslot;
+    for (int j = 0; j < c->nf; j++) c->live_flag[j] ^= 1;  // every row's records now live in its other buffer
     c->pool_used = 0;  // every record is in its particle's own slot again
+    rows_reset(c, c->nf);  // ... which is what genealogy row 0 says now, for every landmark
     return 0;
 }
 
@@ -269,7 +329,6 @@ int flush_stages(slamgpu_ctx *c) {
     if (!c->unreduced.has && !c->unplanned.has) return 0;
     HIP_TRY(hipSetDevice(c->cfg.device));
     c->B.slot = c->slot;
-    c->B.lslot = c->lslot;
     if (c->unreduced.has) {
         Timed t(c, "finish");
         c->k->finish(c->stream, c->B, c->ws, c->unreduced.hist, c->unreduced.par);
@@ -420,13 +479,19 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
         CTX_TRY(hipMemsetAsync(c->B.poseC[b], 0, sizeof(float2) * S, c->stream));
         CTX_TRY(hipMemsetAsync(c->B.lmkA[b], 0, sizeof(float4) * S * cap_nf, c->stream));
         CTX_TRY(hipMemsetAsync(c->B.lmkB[b], 0, sizeof(float) * S * cap_nf, c->stream));
-        CTX_TRY(hipMalloc((void **) &c->B.idxQ[b], sizeof(int4) * S * ((cap_nf + 3) / 4)));
-        CTX_TRY(hipMalloc((void **) &c->B.lmk_live[b], sizeof(int32_t) * cap_nf));
-        CTX_TRY(hipMemsetAsync(c->B.lmk_live[b], 0, sizeof(int32_t) * cap_nf, c->stream));
+        CTX_TRY(hipMalloc((void **) &c->B.gen[b], sizeof(int32_t) * S * (size_t) (cap_nf + 1)));
     }
     c->B.slot = 0;
-    c->B.lslot = 0;
-    for (int b = 0; b < 2; b++) c->k->identity(c->stream, c->B, b);
+    c->B.cap_rows = cap_nf + 1;  // at most one row per landmark, plus the one a step opens while the old ones are still read
+    c->erow.assign((size_t) cap_nf, 0);
+    c->live_flag.assign((size_t) cap_nf, 0);
+    c->seen_step.assign((size_t) cap_nf, 0);
+    CTX_TRY(hipMalloc((void **) &c->live_dev, sizeof(int32_t) * (size_t) cap_nf));
+    c->refcnt.assign((size_t) c->B.cap_rows, 0);
+    c->live_pos.assign((size_t) c->B.cap_rows, -1);
+    rows_reset(c, 0);
+    CTX_TRY(hipMalloc((void **) &c->erow_dev, sizeof(int32_t) * (size_t) cap_nf));
+    CTX_TRY(hipMalloc((void **) &c->rows_dev, sizeof(int32_t) * (size_t) c->B.cap_rows));
     CTX_TRY(hipMalloc((void **) &c->B.ctrl, sizeof(Ctrl)));
     CTX_TRY(hipHostMalloc((void **) &c->ctrl_host, sizeof(Ctrl), hipHostMallocDefault));
     memset(c->ctrl_host, 0, sizeof(Ctrl));
@@ -437,6 +502,7 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     c->ws.nblocks = ncap / kBlock;
     for (int b = 0; b < 2; b++) {
         CTX_TRY(hipMalloc((void **) &c->ws.lcum[b], sizeof(float) * S));
+        CTX_TRY(hipMalloc((void **) &c->ws.piv[b], sizeof(float) * 16 * (size_t) c->ws.nblocks));
         CTX_TRY(hipMalloc((void **) &c->ws.blk_w[b], sizeof(float) * 3 * (size_t) c->ws.nblocks));  // [w | w2 (| max log-weight)] contiguous
         CTX_TRY(hipMalloc((void **) &c->ws.est_part[b], sizeof(double) * (4 * (size_t) c->ws.nblocks + 2)));  // + Neff, resampled
         CTX_TRY(hipMalloc((void **) &c->ws.scan[b], sizeof(double) * ((size_t) c->ws.nblocks + 4)));
@@ -451,7 +517,7 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
         CTX_TRY(hipMemsetAsync(c->stamps_dev, 0, sizeof(unsigned long long) * kStampSlots * (size_t) c->ws.nblocks, c->stream));
     }
     // big-packet ring: header + idf[cap] + zf[2cap] + zn[2cap]
-    c->pkt_bytes = ((sizeof(ObsPacket) + sizeof(int32_t) * cap_nf + sizeof(float) * 4 * cap_nf + sizeof(uint32_t) * ((cap_nf + 31) / 32)) + 255) / 256 * 256;
+    c->pkt_bytes = ((sizeof(ObsPacket) + sizeof(int32_t) * cap_nf + sizeof(float) * 4 * cap_nf + sizeof(int32_t) * (2 * (size_t) cap_nf + 1)) + 255) / 256 * 256;
     CTX_TRY(hipHostMalloc((void **) &c->pkt_host, c->pkt_bytes * kRing, hipHostMallocDefault));
     CTX_TRY(hipMalloc((void **) &c->pkt_dev, c->pkt_bytes * kRing));
     for (int i = 0; i < kRing; i++) CTX_TRY(hipEventCreateWithFlags(&c->pkt_ev[i], hipEventDisableTiming));
@@ -486,8 +552,7 @@ void slamgpu_destroy(slamgpu_ctx *c) {
         if (c->B.poseC[b]) (void) hipFree(c->B.poseC[b]);
         if (c->B.lmkA[b]) (void) hipFree(c->B.lmkA[b]);
         if (c->B.lmkB[b]) (void) hipFree(c->B.lmkB[b]);
-        if (c->B.idxQ[b]) (void) hipFree(c->B.idxQ[b]);
-        if (c->B.lmk_live[b]) (void) hipFree(c->B.lmk_live[b]);
+        if (c->B.gen[b]) (void) hipFree(c->B.gen[b]);
         if (b == 0 && c->B.poolA) (void) hipFree(c->B.poolA);
         if (b == 0 && c->B.poolB) (void) hipFree(c->B.poolB);
     }
@@ -496,6 +561,7 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     if (!c->own_totals) c->ws.blk_w[0] = c->own_blk_w;
     for (int b = 0; b < 2; b++) {
         if (c->ws.lcum[b]) (void) hipFree(c->ws.lcum[b]);
+        if (c->ws.piv[b]) (void) hipFree(c->ws.piv[b]);
         if (c->ws.blk_w[b]) (void) hipFree(c->ws.blk_w[b]);
         if (c->ws.est_part[b]) (void) hipFree(c->ws.est_part[b]);
         if (c->ws.scan[b]) (void) hipFree(c->ws.scan[b]);
@@ -504,6 +570,9 @@ void slamgpu_destroy(slamgpu_ctx *c) {
         if (c->ws.keep[b]) (void) hipFree(c->ws.keep[b]);
     if (c->hist_dev) (void) hipFree(c->hist_dev);
     if (c->stamps_dev) (void) hipFree(c->stamps_dev);
+    if (c->erow_dev) (void) hipFree(c->erow_dev);
+    if (c->live_dev) (void) hipFree(c->live_dev);
+    if (c->rows_dev) (void) hipFree(c->rows_dev);
     if (c->pkt_host) (void) hipHostFree(c->pkt_host);
     if (c->pkt_dev) (void) hipFree(c->pkt_dev);
     for (int i = 0; i < kRing; i++)
@@ -584,16 +653,49 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     HIP_TRY(hipSetDevice(c->cfg.device));
     c->obs_step++;
 
+    // genealogy rows: the landmarks this update writes move to a row it opens; the rows they leave may become unused
+    for (int k = 0; k < m; k++) {
+        if (c->seen_step[idf[k]] == c->obs_step) return fail(SLAMGPU_ERR_INVALID, "landmark %d re-observed twice in one update", idf[k]);
+        c->seen_step[idf[k]] = c->obs_step;
+    }
+    int e_new = -1;
+    std::vector<int32_t> rows_of((size_t) m), dropped;
+    if (m + n > 0) {
+        e_new = c->free_rows.back();
+        c->free_rows.pop_back();
+    }
+    for (int k = 0; k < m; k++) {
+        const int r = c->erow[idf[k]];
+        rows_of[k] = r | (c->live_flag[idf[k]] ? kRowLiveBit : 0);  // the landmark's live record buffer rides in bit 30
+        c->live_flag[idf[k]] ^= 1;                                   // this update writes its records into the other one
+        if (--c->refcnt[r] == 0) {
+            rows_remove_live(c, r);
+            dropped.push_back(r);
+        }
+        c->erow[idf[k]] = e_new;
+        c->refcnt[e_new]++;
+    }
+    for (int k = 0; k < n; k++) {
+        c->erow[c->nf + k] = e_new;
+        c->refcnt[e_new]++;
+        c->live_flag[c->nf + k] = 0;  // a new row's first records go to buffer 0
+    }
+    const int n_rows = (int) c->live_rows.size();  // still in use, without e_new: what a pending gather has to compose
+    c->tables_dirty = true;
+
     UpdateArgs U{};
     U.method = c->cfg.method;
     U.m = m;
     U.n = n;
     U.nf = c->nf;
+    U.e_new = e_new;
+    U.n_rows = n_rows;
     memcpy(U.R, R, sizeof U.R);
-    if (m <= kSmallObs && n <= kSmallObs) {
+    if (m <= kSmallObs && n <= kSmallObs && n_rows <= kSmallRows) {
         // small packet: rides in the kernel-argument segment, no staging copy on the stream
         for (int k = 0; k < m; k++) {
             U.small.idf[k] = idf[k];
+            U.small.row[k] = rows_of[k];
             U.small.zf[2 * k] = zf[2 * k];
             U.small.zf[2 * k + 1] = zf[2 * k + 1];
         }
@@ -601,16 +703,7 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
             U.small.zn[2 * k] = zn[2 * k];
             U.small.zn[2 * k + 1] = zn[2 * k + 1];
         }
-        // genealogy chunks (4 landmarks each) this update writes: re-observed and new landmarks, ascending chunk id
-        std::map<int, int> chunks;
-        for (int k = 0; k < m; k++) chunks[idf[k] >> 2] |= 1 << (idf[k] & 3);
-        for (int k = 0; k < n; k++) chunks[(c->nf + k) >> 2] |= 1 << ((c->nf + k) & 3);
-        U.small.nchunks = 0;
-        for (auto &kv : chunks) {
-            U.small.chunk_id[U.small.nchunks] = kv.first;
-            U.small.chunk_mask[U.small.nchunks] = kv.second;
-            U.small.nchunks++;
-        }
+        for (int r = 0; r < n_rows; r++) U.small.rows[r] = c->live_rows[r];
         U.big = nullptr;
     } else {
         const int slot = (int) (c->pkt_seq++ % kRing);
@@ -620,7 +713,7 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
         hp->m = m;
         hp->n = n;
         hp->nf = c->nf;
-        hp->pad = 0;
+        hp->pad = n_rows;
         memcpy(hp->R, R, sizeof hp->R);
         int32_t *hidf = reinterpret_cast<int32_t *>(hp + 1);
         float *hzf = reinterpret_cast<float *>(hidf + m);
@@ -630,18 +723,22 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
             memcpy(hzf, zf, sizeof(float) * 2 * m);
         }
         if (n) memcpy(hzn, zn, sizeof(float) * 2 * n);
-        uint32_t *hbits = reinterpret_cast<uint32_t *>(hzn + 2 * n);
-        const int nwords = (c->nf + n + 31) / 32;  // landmarks this update writes: re-observed and new
-        for (int k = 0; k < nwords; k++) hbits[k] = 0;
-        for (int k = 0; k < m; k++) hbits[idf[k] >> 5] |= 1u << (idf[k] & 31);
-        for (int k = 0; k < n; k++) hbits[(c->nf + k) >> 5] |= 1u << ((c->nf + k) & 31);
-        const size_t used = sizeof(ObsPacket) + sizeof(int32_t) * m + sizeof(float) * 2 * (m + n) + sizeof(uint32_t) * nwords;
+        int32_t *hrow = reinterpret_cast<int32_t *>(hzn + 2 * n);
+        if (m) memcpy(hrow, rows_of.data(), sizeof(int32_t) * m);
+        if (n_rows) memcpy(hrow + m, c->live_rows.data(), sizeof(int32_t) * n_rows);
+        const size_t used = sizeof(ObsPacket) + sizeof(int32_t) * m + sizeof(float) * 2 * (m + n) + sizeof(int32_t) * ((size_t) m + n_rows);
         char *pd = c->pkt_dev + (size_t) slot * c->pkt_bytes;
         HIP_TRY(hipMemcpyAsync(pd, ph, used, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipEventRecord(c->pkt_ev[slot], c->stream));
         c->pkt_ev_used[slot] = true;
         U.big = reinterpret_cast<const ObsPacket *>(pd);
     }
+    // the row this update opens is in use from now on; the rows it emptied can be opened again by a later update
+    if (e_new >= 0) {
+        if (c->refcnt[e_new] > 0) rows_add_live(c, e_new);
+        else c->free_rows.push_back(e_new);
+    }
+    for (int r : dropped) c->free_rows.push_back(r);
 
     // pending predicts ride inside the update launch (state stays in registers) unless their noise is a host tape
     PredictArgs PA{};
@@ -672,12 +769,14 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     if (sharded && c->unplanned.has)
         if (int rc = flush_stages(c)) return rc;  // (a context is driven either way, not both; be safe)
     c->B.slot = c->slot;
-    c->B.lslot = c->lslot;
     c->ws.wpar = sharded ? 0 : (int) (c->obs_step & 1);
     U.lazy = 1;
     U.arrivals = sharded ? 1 : 0;
-    // copy roles of a pending gather (one role = 256 particles x 8 genealogy chunks known before this update)
-    const int roles = c->ws.nblocks * (((U.nf + 3) / 4 + 7) / 8);
+    // a pending gather's genealogy composition: small packets: by the compute threads themselves; device packets: by copy
+    // roles (one role = 256 particles x rows_per_role live rows; at most ~4 roles per particle tile: every role block
+    // redoes the plan's scan and search)
+    U.rows_per_role = std::max(16, ((n_rows + 3) / 4 + 3) / 4 * 4);
+    const int roles = U.big ? c->ws.nblocks * ((n_rows + U.rows_per_role - 1) / U.rows_per_role) : 0;
     U.copy_lo = 0;
     U.copy_hi = roles;
     // the resampling stage of the previous update rides in this launch unless something already ran it
@@ -695,8 +794,6 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
         c->k->update(c->stream, c->B, PA, U, rng, c->ws);
     }
     HIP_TRY(hipGetLastError());
-    c->lslot ^= 1;  // the helper block of that launch wrote the landmark rows' live flags for the next launch
-    c->B.lslot = c->lslot;
     c->slot ^= 1;   // ... and where it left the set (Ctrl.live / pend of the other slot)
     c->B.slot = c->slot;
     c->maybe_pending = false;  // whatever gather was pending, this launch performed it
@@ -870,8 +967,8 @@ int slamgpu_shard_pack(slamgpu_ctx *c, const float *gtot, int32_t nb_global, int
     A.fields = 10 + 5 * c->nf;
     A.shard = shard;
     A.send = send_dev;
+    if (int rc = sync_tables(c)) return rc;  // the pack kernel reads records through the genealogy (B.erow)
     c->B.slot = c->slot;
-    c->B.lslot = c->lslot;
     c->shard_settled = false;
     {
         Timed t(c, "shard_pack");
@@ -919,8 +1016,8 @@ int slamgpu_shard_unpack(slamgpu_ctx *c, const float *recv_dev, int32_t n_shards
     A.pool_base = settle ? -1 : (int32_t) c->pool_used;
     A.own_lo = (int32_t) A.src_lo[shard];
     A.own_hi = (int32_t) A.src_lo[shard + 1];
+    if (int rc = sync_tables(c)) return rc;  // arrivals: every live row points at the pool; settling reads through B.erow
     c->B.slot = c->slot;
-    c->B.lslot = c->lslot;
     {
         Timed t(c, "shard_unpack");
         c->k->shard_unpack(c->stream, c->B, c->ws, A);
@@ -929,9 +1026,9 @@ int slamgpu_shard_unpack(slamgpu_ctx *c, const float *recv_dev, int32_t n_shards
     if (settle) {
         // the kernel rewrote the whole shard physically and flipped every landmark row; nothing references the pool now
         c->shard_settled = true;
-        c->lslot ^= 1;
-        c->B.lslot = c->lslot;
+        for (int j = 0; j < c->nf; j++) c->live_flag[j] ^= 1;
         c->pool_used = 0;
+        rows_reset(c, c->nf);  // every landmark of every output particle in its own slot: genealogy row 0
     } else {
         c->pool_used += arrivals;
     }
@@ -944,7 +1041,6 @@ int slamgpu_shard_finish(slamgpu_ctx *c, const slamgpu_shard_plan_t *plan) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     const int mode = !plan->resampled ? 0 : (c->shard_settled ? 2 : 1);
     c->B.slot = c->slot;
-    c->B.lslot = c->lslot;
     {
         Timed t(c, "shard_finish");
         c->k->shard_finish(c->stream, c->B, c->ws, plan->wsum, plan->wsq, plan->neff, mode);
@@ -1202,8 +1298,7 @@ int slamgpu_download_range(slamgpu_ctx *c, int32_t first, int32_t count, float *
     if ((xf || Pf4) && nf > 0) {
         // every landmark row has its own live buffer (kernels.h: lmk_live); rows are fetched a bounded batch at a time so
         // that a 10 000-landmark context does not need the whole slice on the host twice
-        std::vector<int32_t> live(nf);
-        HIP_TRY(hipMemcpy(live.data(), c->B.lmk_live[c->lslot], sizeof(int32_t) * nf, hipMemcpyDeviceToHost));
+        const std::vector<int32_t> &live = c->live_flag;
         const int batch = (int) std::max<size_t>(1, std::min<size_t>((size_t) nf, ((size_t) 64 << 20) / (20 * M)));
         std::vector<float4> la(M * batch);
         std::vector<float> lb(M * batch);
@@ -1285,12 +1380,12 @@ int slamgpu_upload(slamgpu_ctx *c, int32_t nf, const float *xv, const float *Pv9
     }
     // every landmark row live in buffer 0, every record in its particle's own slot
     c->pool_used = 0;
-    HIP_TRY(hipMemsetAsync(c->B.lmk_live[c->lslot], 0, sizeof(int32_t) * c->B.cap_nf, c->stream));
+    std::fill(c->live_flag.begin(), c->live_flag.end(), 0);
     c->B.slot = c->slot;
-    c->B.lslot = c->lslot;
-    c->k->identity(c->stream, c->B, cur);
+    c->k->identity(c->stream, c->B, cur, 0);  // every landmark in genealogy row 0: own slot
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->nf = nf;
+    rows_reset(c, nf);
     c->est_fresh = false;
     c->shard_est_fresh = false;
     return 0;
