@@ -35,10 +35,17 @@ namespace slamgpu {
 constexpr int kWave = 64;
 constexpr int kBlock = 256;
 constexpr int kMaxFusedPredict = 16;
-constexpr int kSmallObs = 12;       // observation packets up to this many zf / zn travel as kernel arguments
-constexpr int kSmallRows = 40;      // ... together with up to this many live genealogy rows (else: device-resident packet)
+constexpr int kSmallRows = 40;      // contexts with at most this many genealogy rows (landmark capacity <= 39: the bundled maps)
+                                    // are COMPACT: their rows are interleaved four to a 16-byte chunk per particle, so that a
+                                    // resample composes ceil(rows / 4) chunks per particle with one wide load + store each,
+                                    // and their observation packets always travel as kernel arguments
+constexpr int kSmallObs = kSmallRows;  // ... so a packet holds up to this many zf / zn
 constexpr int kRowsPerRole = 16;    // genealogy rows composed by one copy role (x 256 particles)
 constexpr int kRowLiveBit = 1 << 30;  // packet row[k]: the landmark's live record buffer rides in bit 30 of its genealogy row
+constexpr int kRowFreshBit = 1 << 29; // packet row[k]: the landmark was written by the PREVIOUS update and nothing has composed its
+                                      // row since (the resample this launch applies excepted): its record sits in the source
+                                      // slot itself, no genealogy lookup needed -- the usual case for a landmark in view
+constexpr int kRowMask = kRowFreshBit - 1;
 constexpr int kPoolBit = (int) 0x80000000;  // genealogy entry: the record lives in the arrival pool (Buffers::poolA/B)
 constexpr int kHistStride = 6;      // doubles per pose-estimate history entry: sum x, sum y, heading, max w, Neff, resampled
 constexpr int kMaxScanBlocks = 8192;
@@ -71,7 +78,10 @@ struct Buffers {
     float2 *poseC[2];
     float4 *lmkA[2];
     float *lmkB[2];
-    int32_t *gen[2];      // genealogy rows [cap_rows][Ncap]; the live one is the pose's (Ctrl.live): both are gathered together
+    int32_t *gen[2];      // genealogy rows; the live one is the pose's (Ctrl.live): both are gathered together.
+                          // plain  : [cap_rows][Ncap]              element (row, k) at row * Ncap + k
+                          // compact: [ceil(cap_rows/4)][Ncap][4]   element (row, k) at ((row / 4) * Ncap + k) * 4 + row % 4
+    int32_t compact;      // which (fixed at context creation: cap_rows <= kSmallRows)
     // device copies of the host's genealogy bookkeeping, refreshed before the kernels that need them (gather, flatten,
     // shard pack / unpack; the update kernel gets what it needs with the observation packet)
     const int32_t *erow;  // [cap_nf] row of every landmark
@@ -96,6 +106,11 @@ struct Buffers {
     int32_t slot;     // which Ctrl.live / Ctrl.pend entry this launch reads (host-tracked)
 };
 
+// index of genealogy element (row, particle k) in Buffers::gen[b]
+__host__ __device__ inline size_t gen_index(int compact, size_t ncap, int row, size_t k) {
+    return compact ? (((size_t) (row >> 2) * ncap + k) << 2) + (size_t) (row & 3) : (size_t) row * ncap + k;
+}
+
 struct ObsPacket {          // big packets live in device memory, uploaded once per update
     int32_t m, n, nf, pad;  // re-observed, new, landmarks before this update
     float R[4];
@@ -105,12 +120,11 @@ struct ObsPacket {          // big packets live in device memory, uploaded once 
     //  n_rows travels in UpdateArgs)
 };
 
-struct SmallObs {           // small packets travel in the kernel argument segment
+struct SmallObs {           // compact contexts: the packet travels in the kernel argument segment
     int32_t idf[kSmallObs];
-    int32_t row[kSmallObs];          // genealogy row of each re-observed landmark before this update
+    int32_t row[kSmallObs];          // genealogy row (| live record buffer << 30) of each re-observed landmark before this update
     float zf[2 * kSmallObs];
     float zn[2 * kSmallObs];
-    int32_t rows[kSmallRows];        // live rows after this update, without e_new (copy roles)
 };
 
 struct RngArgs {
@@ -164,9 +178,11 @@ struct UpdateArgs {
     int32_t lazy;            // 1: single-context pipeline (honour Ctrl.pend, launch the copy + finalise blocks)
     int32_t copy_lo, copy_hi;  // copy roles (particle tile x kRowsPerRole genealogy rows) of a pending lazy gather this launch carries
     int32_t e_new;           // genealogy row this update opens for the landmarks it writes (-1: it writes none)
-    int32_t n_rows;          // live rows a pending gather composes (small.rows / the packet's rows): small packets: by the
-                             // compute threads themselves (at most kSmallRows rows); device packets: by copy roles
-    int32_t rows_per_role;   // ... of this many rows each
+    int32_t n_rows;          // device packets: live rows a pending gather composes (the packet's rows), by copy roles
+    int32_t rows_per_role;   // ... of this many rows each.  (Compact contexts: the compute threads copy all their chunks.)
+    int32_t live_chunks;     // compact contexts: chunks [0, live_chunks) hold every row in use (rows are opened lowest-first)
+    int32_t all_fresh;       // compact contexts: every staged re-observed landmark carries kRowFreshBit: their records are
+                             // requested together with the pose, one dependent round trip earlier
     // Inline planning: the resampling stage of the PREVIOUS update (Neff, decision, ancestors, pose-estimate partials)
     // has not run as a launch of its own; every block of this launch redoes its scan and every thread finds its own
     // ancestor, so a step is ONE launch.  0: that stage already ran (resample_kernel), honour Ctrl.pend / keep[].

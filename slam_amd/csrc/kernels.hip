@@ -284,16 +284,47 @@ SLAM_DEV double block_scale(float mb, double M) {
     return mb == -INFINITY ? 0.0 : exp((double) mb - M);
 }
 
+struct NoOp {
+    SLAM_DEV void operator()() const {}
+};
+
+// after_loads(): called once this function's own global loads have been requested (contexts of at most 512 blocks: at
+// most two totals per thread) -- the place for a caller to request data it needs AFTER the scan (the update kernel's
+// pivot table), so that it queues behind the totals on the in-order return path instead of in front of them.
+template <class After = NoOp>
 SLAM_DEV void scan_block_totals(const float *__restrict__ tot, int nb, int nbl, bool logw, double *off, double *sh_a,
-                                double *sh_q, double &W, double &Q, double &M) {
+                                double *sh_q, double &W, double &Q, double &M, After after_loads = After()) {
     const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
     const int per = (nb + kBlock - 1) / kBlock;
     const int lo = min(nb, t * per), hi = min(nb, lo + per);
     const int rows = logw ? 3 : 2;
+    const bool two = per <= 2;
+    // (named scalars, not arrays: a register array indexed by k - lo would be demoted to scratch)
+    float tv0 = 0.0f, tv1 = 0.0f, qv0 = 0.0f, qv1 = 0.0f, mv0 = -INFINITY, mv1 = -INFINITY;
+    // (one shard: nbl == nb and the index is k itself; the general form costs two integer divisions per entry)
+    const bool one = nbl == nb;
+    auto at_of = [&](int k) { return one ? k : (k / nbl) * rows * nbl + (k % nbl); };
+    if (two) {
+        if (lo < hi) {
+            const int at = at_of(lo);
+            tv0 = tot[at];
+            qv0 = tot[at + nbl];
+            if (logw) mv0 = tot[at + 2 * nbl];
+        }
+        if (lo + 1 < hi) {
+            const int at = at_of(lo + 1);
+            tv1 = tot[at];
+            qv1 = tot[at + nbl];
+            if (logw) mv1 = tot[at + 2 * nbl];
+        }
+    }
+    after_loads();
     M = 0.0;
     if (logw) {
         float mx = -INFINITY;
-        for (int k = lo; k < hi; k++) mx = fmaxf(mx, tot[(k / nbl) * rows * nbl + 2 * nbl + (k % nbl)]);
+        if (two) mx = fmaxf(mv0, mv1);
+        else
+            for (int k = lo; k < hi; k++) mx = fmaxf(mx, tot[at_of(k) + 2 * nbl]);
 #pragma unroll
         for (int d = kWave / 2; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, kWave));
         if (lane == 0) sh_a[wv] = (double) mx;
@@ -302,13 +333,21 @@ SLAM_DEV void scan_block_totals(const float *__restrict__ tot, int nb, int nbl, 
         __syncthreads();
     }
     double a = 0.0, q = 0.0;
-    for (int k = lo; k < hi; k++) {
-        const int at = (k / nbl) * rows * nbl + (k % nbl);
-        const double sc = logw ? block_scale(tot[at + 2 * nbl], M) : 1.0;
-        const double tk = (double) tot[at] * sc;
+    auto acc = [&](int k, float tk_f, float qk_f, float mk_f) {
+        const double sc = logw ? block_scale(mk_f, M) : 1.0;
+        const double tk = (double) tk_f * sc;
         off[k] = tk;  // this thread's own segment: read back below
         a += tk;
-        q += (double) tot[at + nbl] * (tk * tk);  // second row: sum (w_i / T)^2 of the block (update_kernel's tail)
+        q += (double) qk_f * (tk * tk);  // second row: sum (w_i / T)^2 of the block (update_kernel's tail)
+    };
+    if (two) {
+        if (lo < hi) acc(lo, tv0, qv0, mv0);
+        if (lo + 1 < hi) acc(lo + 1, tv1, qv1, mv1);
+    } else {
+        for (int k = lo; k < hi; k++) {
+            const int at = at_of(k);
+            acc(k, tot[at], tot[at + nbl], logw ? tot[at + 2 * nbl] : 0.0f);
+        }
     }
     const double sa = wave_scan_d(a);
     const double sq = wave_sum_d(q);
@@ -328,6 +367,14 @@ SLAM_DEV void scan_block_totals(const float *__restrict__ tot, int nb, int nbl, 
     W = ((sh_a[0] + sh_a[1]) + sh_a[2]) + sh_a[3];
     Q = ((sh_q[0] + sh_q[1]) + sh_q[2]) + sh_q[3];
     if (t == 0) off[nb] = W;
+}
+
+// Neff = W^2 / Q, the same expression in every kernel, block and shard (the decision must be identical everywhere): one
+// v_rcp_f64 + a Newton step instead of the ~40-instruction IEEE double division on the step's critical path
+SLAM_DEV float neff_of(double W, double Q) {
+    double r = __builtin_amdgcn_rcp(Q);
+    r = fma(fma(-Q, r, 1.0), r, r);
+    return (float) ((W * W) * r);
 }
 
 // kStatus* bits of a resampling stage from the two global sums (NaN-safe comparisons)
@@ -487,14 +534,16 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     float *const pivs = reinterpret_cast<float *>(off + (((size_t) ws.nblocks + 3) & ~(size_t) 1));  // 16-byte aligned
     constexpr int kPivPerThread = kPivLdsBlocks * 16 / 4 / kBlock;  // float4 per thread at the largest table
     float4 pvreg[kPivPerThread];
-    if (piv_in_lds) {
-        const float4 *src = reinterpret_cast<const float4 *>(ws.piv[ws.wpar ^ 1]);
+    auto request_pivots = [&]() {
+        if (piv_in_lds) {
+            const float4 *src = reinterpret_cast<const float4 *>(ws.piv[ws.wpar ^ 1]);
 #pragma unroll
-        for (int t = 0; t < kPivPerThread; t++) {
-            const int at = t * kBlock + (int) threadIdx.x;
-            pvreg[t] = at < ws.nblocks * 4 ? src[at] : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = 0; t < kPivPerThread; t++) {
+                const int at = t * kBlock + (int) threadIdx.x;
+                pvreg[t] = at < ws.nblocks * 4 ? src[at] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
-    }
+    };
     __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
     __shared__ EstItem sh_est[kBlock / kWave];
     SLAM_STAMP(0);  // kernel entry
@@ -523,9 +572,9 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             Q = offp[nb + 2];
             Mx = offp[nb + 3];
         } else {
-            scan_block_totals(ws.blk_w[ws.wpar ^ 1], nb, nb, logw, off, sh_a, sh_q, W, Q, Mx);
+            scan_block_totals(ws.blk_w[ws.wpar ^ 1], nb, nb, logw, off, sh_a, sh_q, W, Q, Mx, request_pivots);
         }
-        const float neff = (float) ((W * W) / Q);  // Neff = 1 / sum((w/W)^2)  (core.cpp:784-788)
+        const float neff = neff_of(W, Q);  // Neff = 1 / sum((w/W)^2)  (core.cpp:784-788)
         pend = U.do_resample && (neff < (float) U.n_effective);
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             ctrl->wsum = W;
@@ -569,7 +618,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 } else {
                     scan_block_totals(ws.blk_w[ws.wpar ^ 1], nb, nb, logw, off, sh_a, sh_q, W, Q, Mx);
                 }
-                pend = U.do_resample && ((float) ((W * W) / Q) < (float) U.n_effective);
+                pend = U.do_resample && (neff_of(W, Q) < (float) U.n_effective);
             }
             if (threadIdx.x == 0) {
                 ctrl->live[B.slot ^ 1] = pend ? cur ^ 1 : cur;
@@ -578,10 +627,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             if (U.finalize) finish_estimate(B, ws, U.finalize_par, U.finalize_hist, sh_est);
             return;
         }
-        if (pend) {
-            const int32_t *rows = BIG ? packet_rows(U) : U.small.rows;
-            copy_genealogy(B, rows, U.n_rows, U.rows_per_role, ws, cur, U.copy_lo + (int) blockIdx.x - nb, ancestor);
-        }
+        if (BIG && pend) copy_genealogy(B, packet_rows(U), U.n_rows, U.rows_per_role, ws, cur, U.copy_lo + (int) blockIdx.x - nb, ancestor);
         return;
     }
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -657,7 +703,10 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         // re-observed landmark k of this particle: the slot comes from the genealogy row the landmark uses (kernels.h:
         // gen), the buffer from the row's live flag; a landmark this update writes goes to the particle's OWN slot of the
         // row's other buffer and into the genealogy row this update opens (U.e_new: identity)
-        auto slot_of = [&](int k) -> int { return genS[(size_t) (lrow[k] & (kRowLiveBit - 1)) * S + si]; };
+        // (compact contexts = small packets: rows interleaved four to a chunk, kernels.h: Buffers::gen)
+        auto slot_of = [&](int k) -> int {
+            return (lrow[k] & kRowFreshBit) ? si : genS[gen_index(!BIG, S, lrow[k] & kRowMask, (size_t) si)];
+        };
         auto buf_of = [&](int k) -> int { return (lrow[k] >> 30) & 1; };
         const float r00 = U.R[0], r01 = U.R[1], r10 = U.R[2], r11 = U.R[3];
         // Stage the first KS re-observed landmarks in LDS with all their loads in flight together (one HBM latency instead
@@ -665,20 +714,34 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         // stalls (profiles/rocprof_sq_counters_r01.txt).  Unconditional loads (index clamped to the last landmark): no
         // branch between them, so the compiler issues all of them before the first s_waitcnt; duplicates are L1 hits.
         // Two sizes: most steps re-observe at most kStage/2 landmarks and need not pay for eight address computations.
-        auto stage_landmarks = [&](auto KS, const int *ts) {
+        // Split in two so that the loads can be requested as early as their addresses are known (with the pose when every
+        // staged landmark is fresh: kRowFreshBit) and the wave only waits for them when it needs them.
+        float4 sta[kStage];
+        float stb[kStage];
+        auto issue_records = [&](auto KS, const int *ts) {
             constexpr int ks = decltype(KS)::value;
-            float4 ta[ks];
-            float tb[ks];
 #pragma unroll
             for (int k = 0; k < ks; k++) {
                 const Rec r = load_rec(idf[min(k, m - 1)], ts[k], buf_of(min(k, m - 1)));
-                ta[k] = r.a;
-                tb[k] = r.b;
+                sta[k] = r.a;
+                stb[k] = r.b;
             }
+        };
+        auto commit_records = [&](auto KS) {
+            constexpr int ks = decltype(KS)::value;
 #pragma unroll
             for (int k = 0; k < ks; k++) {
-                shA[(k) * kBlock + threadIdx.x] = ta[k];
-                shB[(k) * kBlock + threadIdx.x] = tb[k];
+                shA[(k) * kBlock + threadIdx.x] = sta[k];
+                shB[(k) * kBlock + threadIdx.x] = stb[k];
+            }
+        };
+        auto stage_landmarks = [&](const int *ts, bool issued) {
+            if (m <= kStage / 2) {
+                if (!issued) issue_records(std::integral_constant<int, kStage / 2>{}, ts);
+                commit_records(std::integral_constant<int, kStage / 2>{});
+            } else {
+                if (!issued) issue_records(std::integral_constant<int, kStage>{}, ts);
+                commit_records(std::integral_constant<int, kStage>{});
             }
         };
 
@@ -719,35 +782,36 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             }
         };
 
-        // Small packets: a pending gather's genealogy composition (gen_out[e][i] = gen[e][ancestor], the live rows still in
-        // use) is done right here by the particle's own thread -- it knows its ancestor already -- instead of by helper
-        // blocks that would each redo the scan and the search: first kRowsA rows requested with the pose and stored when
-        // it arrives, the rest requested then and stored with the pose at the end (at most kSmallRows live rows).
-        constexpr int kRowsA = 24, kRowsB = kSmallRows - kRowsA;
+        // Compact contexts: a pending gather's genealogy composition (gen_out[e][i] = gen[e][ancestor]) is done right here
+        // by the particle's own thread -- it knows its ancestor already -- instead of by helper blocks that would each redo
+        // the scan and the search: all of the particle's chunks (four rows each, at most kSmallRows / 4) requested with the
+        // pose, stored when it arrives, with the row this update opens already set to "own slot".
+        constexpr int kChunks = (kSmallRows + 3) / 4;
         const bool copy_inline = !BIG && pend && sb == cur;  // (an arrival's genealogy is already in place)
-        int ga[kRowsA], gb[kRowsB];
-        if (!BIG && copy_inline) {
-#pragma unroll
-            for (int r = 0; r < kRowsA; r++)
-                if (r < U.n_rows) ga[r] = genS[(size_t) U.small.rows[r] * S + si];
-        }
+        const int nchunks = U.live_chunks;  // chunks holding a row in use after this update (incl. the one it opens)
+        int4 gq[kChunks];
         float4 pa = poseA[si];
         // the slots of the (first kStage) re-observed landmarks are fetched now, with the pose: they depend on nothing but
         // the source slot, so the records are one round trip behind the pose, not two
         int ts[kStage];
+        const bool early_records = !BIG && METHOD == 2 && m > 0 && U.all_fresh;
         if (!BIG) {
 #pragma unroll
-            for (int k = 0; k < kStage; k++) ts[k] = slot_of(min(k, max(m - 1, 0)));
+            for (int k = 0; k < kStage; k++) ts[k] = U.all_fresh ? si : slot_of(min(k, max(m - 1, 0)));
+            if (early_records) {  // fresh landmarks: the record sits in the source slot: requested with the pose
+                if (m <= kStage / 2) issue_records(std::integral_constant<int, kStage / 2>{}, ts);
+                else issue_records(std::integral_constant<int, kStage>{}, ts);
+            }
         }
         SLAM_STAMP(4);  // pose + genealogy of the ancestor arrived
         float x = pa.x, y = pa.y, th = pa.z;
         if (!BIG && copy_inline) {
+            // requested only now, behind the pose and the records on the in-order return path (the step's critical chain);
+            // they arrive during the compute below and are stored with the pose at the end
+            const int4 *__restrict__ g4 = reinterpret_cast<const int4 *>(genS);
 #pragma unroll
-            for (int r = 0; r < kRowsA; r++)
-                if (r < U.n_rows) genO[(size_t) U.small.rows[r] * S + i] = ga[r];
-#pragma unroll
-            for (int r = 0; r < kRowsB; r++)
-                if (kRowsA + r < U.n_rows) gb[r] = genS[(size_t) U.small.rows[kRowsA + r] * S + si];
+            for (int c = 0; c < kChunks; c++)
+                if (c < nchunks) gq[c] = g4[(size_t) c * S + si];
         }
         // resampled particles restart at 1/N (core.cpp:744-747); otherwise the weights are normalised (core.cpp:726-729;
         // resample_kernel has already done it unless this launch plans inline)
@@ -804,8 +868,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 if constexpr (BIG) {
                     pipeline(first_pass);
                 } else {
-                    if (m <= kStage / 2) stage_landmarks(std::integral_constant<int, kStage / 2>{}, ts);
-                    else stage_landmarks(std::integral_constant<int, kStage>{}, ts);
+                    stage_landmarks(ts, early_records);
                     for (int k = 0; k < m; k++) {
                         float4 la;
                         float lb;
@@ -929,8 +992,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 if constexpr (BIG) {
                     pipeline(first_pass);
                 } else {
-                    if (m <= kStage / 2) stage_landmarks(std::integral_constant<int, kStage / 2>{}, ts);
-                    else stage_landmarks(std::integral_constant<int, kStage>{}, ts);
+                    stage_landmarks(ts, early_records);
                     for (int k = 0; k < m; k++) {
                         float4 la;
                         float lb;
@@ -1042,11 +1104,23 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         }
         // the landmarks this update wrote are in this particle's own slot now: that is what the genealogy row this update
         // opens says for all of them (the copy roles of a pending gather compose the other rows)
-        if (U.e_new >= 0) genO[(size_t) U.e_new * S + i] = i;
         if (!BIG && copy_inline) {
+            int4 *__restrict__ o4 = reinterpret_cast<int4 *>(genO);
 #pragma unroll
-            for (int r = 0; r < kRowsB; r++)
-                if (kRowsA + r < U.n_rows) genO[(size_t) U.small.rows[kRowsA + r] * S + i] = gb[r];
+            for (int c = 0; c < kChunks; c++)
+                if (c < nchunks) {
+                    int4 q = gq[c];
+                    if (c == (U.e_new >> 2)) {  // (e_new = -1: never)
+                        const int comp = U.e_new & 3;
+                        if (comp == 0) q.x = i;
+                        else if (comp == 1) q.y = i;
+                        else if (comp == 2) q.z = i;
+                        else q.w = i;
+                    }
+                    o4[(size_t) c * S + i] = q;
+                }
+        } else if (U.e_new >= 0) {
+            genO[gen_index(!BIG, S, U.e_new, (size_t) i)] = i;
         }
         poseAo[i] = make_float4(x, y, th, w);
         if (METHOD == 2 && pose_dirty) {
@@ -1138,7 +1212,7 @@ __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScrat
     const bool logw = ra.logw != 0;
     scan_block_totals(ws.blk_w[ws.wpar], nb, nb, logw, off, sh_a, sh_q, W, Q, Mx);  // one shard: [w(nb) | w2(nb)] contiguous
     // Neff = 1 / sum((w/W)^2)  (core.cpp:784-788)
-    const float neff = (float) ((W * W) / Q);
+    const float neff = neff_of(W, Q);
     const bool resample = ra.do_resample && (neff < (float) ra.n_effective);
     if (blockIdx.x == 0 && t == 0) {
         ctrl->wsum = W;
@@ -1215,6 +1289,12 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(Buffers B, WeightScratch
     }
     const int32_t *__restrict__ src = B.gen[cur];
     int32_t *__restrict__ dst = B.gen[cur ^ 1];
+    if (B.compact) {  // every chunk of the particle (grid.y == 1)
+        const int4 *__restrict__ s4 = reinterpret_cast<const int4 *>(src);
+        int4 *__restrict__ d4 = reinterpret_cast<int4 *>(dst);
+        for (int c = 0; c < ((B.cap_rows + 3) >> 2); c++) d4[(size_t) c * S + k] = s4[(size_t) c * S + anc];
+        return;
+    }
     const int r0 = blockIdx.y * kRowsPerRole, r1 = min(B.n_rows, r0 + kRowsPerRole);
     for (int r = r0; r < r1; r++) {
         const size_t e = (size_t) B.rows[r];
@@ -1236,7 +1316,7 @@ __global__ void __launch_bounds__(kBlock) flatten_kernel(Buffers B, int nf) {
     const int32_t *__restrict__ gen = B.gen[cur];
     const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(nf, j0 + kLmkPerBlockY);
     for (int j = j0; j < j1; j++) {
-        const int sl = gen[(size_t) B.erow[j] * S + k];
+        const int sl = gen[gen_index(B.compact, S, B.erow[j], (size_t) k)];
         const int b = live[j];
         if (sl < 0) {  // arrival pool
             const size_t at = (size_t) j * B.pool_cap + (sl & ~kPoolBit);
@@ -1368,7 +1448,7 @@ __global__ void __launch_bounds__(kBlock) shard_plan_kernel(ShardPlanArgs A, Rng
     __syncthreads();
     const int t = threadIdx.x;
     if (t == 0) {
-        const float neff = (float) ((W * W) / Q);
+        const float neff = neff_of(W, Q);
         out->wsum = W;
         out->wsq = Q;
         out->neff = neff;
@@ -1406,7 +1486,7 @@ __global__ void __launch_bounds__(kBlock) shard_plan_kernel(ShardPlanArgs A, Rng
 // arrival pool
 SLAM_DEV void read_through_genealogy(const Buffers &B, const int32_t *__restrict__ live, int cur, size_t S, int l, int anc,
                                      float4 &la, float &lb) {
-    const int sl = B.gen[cur][(size_t) B.erow[l] * S + anc];
+    const int sl = B.gen[cur][gen_index(B.compact, S, B.erow[l], (size_t) anc)];
     if (sl < 0) {
         const size_t at = (size_t) l * B.pool_cap + (sl & ~kPoolBit);
         la = B.poolA[at];
@@ -1496,7 +1576,7 @@ __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightS
         if (!settle) return;  // lazy gather through keep[] (recorded by this shard's own pack kernel)
         const int anc = ws.keep[B.slot ^ 1][i];
         if (blockIdx.y == 0) {
-            B.gen[cur ^ 1][i] = i;  // settled: every landmark in genealogy row 0, own slot
+            B.gen[cur ^ 1][gen_index(B.compact, S, 0, (size_t) i)] = i;  // settled: every landmark in genealogy row 0, own slot
             float4 pa = B.poseA[cur][anc];
             pa.w = B.ctrl->inv_n;
             B.poseA[cur ^ 1][i] = pa;
@@ -1526,7 +1606,7 @@ __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightS
         ws.keep[B.slot ^ 1][i] = -(__float_as_int(src[9 * cnt]) + 1);
     }
     if (settle) {
-        if (blockIdx.y == 0) B.gen[cur ^ 1][i] = i;  // row 0, own slot
+        if (blockIdx.y == 0) B.gen[cur ^ 1][gen_index(B.compact, S, 0, (size_t) i)] = i;  // row 0, own slot
         for (int l = j0; l < j1; l++) {
             const float *f = src + (size_t) (10 + 5 * l) * cnt;
             const int b = live[l];
@@ -1537,7 +1617,7 @@ __global__ void __launch_bounds__(kBlock) shard_unpack_kernel(Buffers B, WeightS
         const int p = A.pool_base + (int) (before + slot);  // arrival number within this step
         const int ref = kPoolBit | p;
         // every live genealogy row of this particle points at its pool slot (rows spread over the blockIdx.y groups)
-        for (int r = blockIdx.y; r < B.n_rows; r += gridDim.y) B.gen[cur ^ 1][(size_t) B.rows[r] * S + i] = ref;
+        for (int r = blockIdx.y; r < B.n_rows; r += gridDim.y) B.gen[cur ^ 1][gen_index(B.compact, S, B.rows[r], (size_t) i)] = ref;
         for (int l = j0; l < j1; l++) {
             const float *f = src + (size_t) (10 + 5 * l) * cnt;
             const size_t at = (size_t) l * B.pool_cap + p;
@@ -1658,26 +1738,26 @@ static void launch_scan(hipStream_t st, const WeightScratch &ws, int logw) {
 }
 
 static void launch_gather(hipStream_t st, const Buffers &B, const WeightScratch &ws) {
-    const int gy = B.n_rows > 0 ? (B.n_rows + kRowsPerRole - 1) / kRowsPerRole : 1;
+    const int gy = (!B.compact && B.n_rows > 0) ? (B.n_rows + kRowsPerRole - 1) / kRowsPerRole : 1;
     hipLaunchKernelGGL(gather_kernel, dim3(ws.nblocks, gy), dim3(kBlock), 0, st, B, ws);
 }
 
-// identity ("own slot") in one genealogy row (context creation, upload, flatten)
-__global__ void __launch_bounds__(kBlock) identity_kernel(int32_t *gen_row, int ncap) {
+// identity ("own slot") in one genealogy row (upload, flatten)
+__global__ void __launch_bounds__(kBlock) identity_kernel(int32_t *gen, int compact, int row, int ncap) {
     const int k = blockIdx.x * kBlock + threadIdx.x;
-    if (k < ncap) gen_row[k] = k;
+    if (k < ncap) gen[gen_index(compact, (size_t) ncap, row, (size_t) k)] = k;
 }
 
 static void launch_identity(hipStream_t st, const Buffers &B, int which, int row) {
-    hipLaunchKernelGGL(identity_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B.gen[which] + (size_t) row * B.ncap, B.ncap);
+    hipLaunchKernelGGL(identity_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B.gen[which], B.compact, row, B.ncap);
 }
 
 static void launch_flatten(hipStream_t st, const Buffers &B, int nf) {
     const int gy = nf > 0 ? (nf + kLmkPerBlockY - 1) / kLmkPerBlockY : 1;
     hipLaunchKernelGGL(flatten_kernel, dim3(B.ncap / kBlock, gy), dim3(kBlock), 0, st, B, nf);
     // row 0 may have been a source row of that launch: it becomes the identity only now
-    hipLaunchKernelGGL(identity_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B.gen[0], B.ncap);
-    hipLaunchKernelGGL(identity_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B.gen[1], B.ncap);
+    launch_identity(st, B, 0, 0);
+    launch_identity(st, B, 1, 0);
 }
 
 static void launch_finish(hipStream_t st, const Buffers &B, const WeightScratch &ws, double *hist, int par) {

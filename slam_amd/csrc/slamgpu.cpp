@@ -125,6 +125,8 @@ struct slamgpu_ctx {
     std::vector<int32_t> live_rows;  // rows with refcnt > 0
     std::vector<int32_t> live_pos;   // [cap_rows] position in live_rows, -1 if not live
     int32_t *erow_dev = nullptr, *rows_dev = nullptr;  // device copies for gather / flatten / shard pack + unpack
+    int fresh_row = -1;              // row the last update opened, while nothing but the resample the next update launch
+                                     // applies has touched it: records of its landmarks sit in the source slot itself
     bool tables_dirty = true;
     unsigned long long *stamps_dev = nullptr;  // diagnostic (SLAMGPU_STAMPS=1 + libslamgpu_stamps.so): UpdateArgs::stamps
     EstStage unplanned;           // the last update: resampling stage not run yet
@@ -252,6 +254,7 @@ void rows_remove_live(slamgpu_ctx *c, int r) {
 // every landmark [0, nf) in row 0 (own slot): after upload, flatten, a settling unpack
 void rows_reset(slamgpu_ctx *c, int nf) {
     const int cap_rows = c->B.cap_rows;
+    c->fresh_row = -1;
     std::fill(c->refcnt.begin(), c->refcnt.end(), 0);
     std::fill(c->live_pos.begin(), c->live_pos.end(), -1);
     std::fill(c->erow.begin(), c->erow.end(), 0);
@@ -297,6 +300,7 @@ int materialize(slamgpu_ctx *c) {
         Timed t(c, "gather");
         c->k->gather(c->stream, c->B, c->ws);
     }
+    c->fresh_row = -1;  // rows may have been composed: no shortcut past the genealogy for the next update
     HIP_TRY(hipGetLastError());
     c->slot ^= 1;
     c->B.slot = c->slot;
@@ -479,10 +483,12 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
         CTX_TRY(hipMemsetAsync(c->B.poseC[b], 0, sizeof(float2) * S, c->stream));
         CTX_TRY(hipMemsetAsync(c->B.lmkA[b], 0, sizeof(float4) * S * cap_nf, c->stream));
         CTX_TRY(hipMemsetAsync(c->B.lmkB[b], 0, sizeof(float) * S * cap_nf, c->stream));
-        CTX_TRY(hipMalloc((void **) &c->B.gen[b], sizeof(int32_t) * S * (size_t) (cap_nf + 1)));
+        // genealogy rows: plain [cap_rows][S], or compact [ceil(cap_rows / 4)][S][4] (kernels.h: Buffers::gen)
+        CTX_TRY(hipMalloc((void **) &c->B.gen[b], sizeof(int32_t) * S * (size_t) ((cap_nf + 1 + 3) / 4 * 4)));
     }
     c->B.slot = 0;
     c->B.cap_rows = cap_nf + 1;  // at most one row per landmark, plus the one a step opens while the old ones are still read
+    c->B.compact = c->B.cap_rows <= kSmallRows ? 1 : 0;
     c->erow.assign((size_t) cap_nf, 0);
     c->live_flag.assign((size_t) cap_nf, 0);
     c->seen_step.assign((size_t) cap_nf, 0);
@@ -667,6 +673,7 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     for (int k = 0; k < m; k++) {
         const int r = c->erow[idf[k]];
         rows_of[k] = r | (c->live_flag[idf[k]] ? kRowLiveBit : 0);  // the landmark's live record buffer rides in bit 30
+        if (r == c->fresh_row && !sharded) rows_of[k] |= kRowFreshBit;
         c->live_flag[idf[k]] ^= 1;                                   // this update writes its records into the other one
         if (--c->refcnt[r] == 0) {
             rows_remove_live(c, r);
@@ -690,9 +697,18 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     U.nf = c->nf;
     U.e_new = e_new;
     U.n_rows = n_rows;
+    {
+        int top = e_new;
+        for (int r : c->live_rows) top = std::max(top, r);
+        U.live_chunks = (top >> 2) + 1;  // (top = -1: 0 chunks)
+    }
+    U.all_fresh = 1;
+    for (int k = 0; k < std::min(m, 8); k++) U.all_fresh &= (rows_of[k] & kRowFreshBit) ? 1 : 0;
+    c->fresh_row = sharded ? -1 : e_new;
     memcpy(U.R, R, sizeof U.R);
-    if (m <= kSmallObs && n <= kSmallObs && n_rows <= kSmallRows) {
-        // small packet: rides in the kernel-argument segment, no staging copy on the stream
+    if (c->B.compact) {
+        // compact context (at most kSmallRows - 1 landmarks): the packet rides in the kernel-argument segment, no staging
+        // copy on the stream
         for (int k = 0; k < m; k++) {
             U.small.idf[k] = idf[k];
             U.small.row[k] = rows_of[k];
@@ -703,7 +719,6 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
             U.small.zn[2 * k] = zn[2 * k];
             U.small.zn[2 * k + 1] = zn[2 * k + 1];
         }
-        for (int r = 0; r < n_rows; r++) U.small.rows[r] = c->live_rows[r];
         U.big = nullptr;
     } else {
         const int slot = (int) (c->pkt_seq++ % kRing);
@@ -739,6 +754,10 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
         else c->free_rows.push_back(e_new);
     }
     for (int r : dropped) c->free_rows.push_back(r);
+    // rows are opened lowest-first, so that the rows in use stay dense at the bottom (compact contexts copy chunks
+    // [0, live_chunks) on a resample)
+    if (c->B.compact && (!dropped.empty() || (e_new >= 0 && c->refcnt[e_new] == 0)))
+        std::sort(c->free_rows.begin(), c->free_rows.end(), std::greater<int32_t>());
 
     // pending predicts ride inside the update launch (state stays in registers) unless their noise is a host tape
     PredictArgs PA{};
