@@ -1,0 +1,7 @@
+#!/bin/bash
+D=gpurun_out/s8; mkdir -p $D
+python -c "import __graft_entry__ as g; g.build()" > $D/build.log 2>&1 || { echo BUILD FAILED; exit 1; }
+timeout -k 10 600 python -m pytest tests -m gpu -q --timeout 900 -x -k "config5 or logweights or many_landmarks or lazy_gather" > $D/tests.log 2>&1; echo "tests rc=$?"; tail -3 $D/tests.log
+timeout -k 10 600 python bench.py --config 5 --no-strict --no-cpu-baseline --single-pass > $D/bench_c5.json 2> $D/bench_c5.err; echo "c5 rc=$?"
+python -c "
+import json; j=json.loads(open('$D/bench_c5.json').read().strip().splitlines()[-1]); print('  c5 value %.4g ms/step %.4f' % (j['value'], j['ms_per_step']))"
