@@ -68,6 +68,32 @@ double slamhost_unif_rand(void);                                    /* unifRand 
 void slamhost_synthetic_landmarks(uint64_t seed, int32_t n, float x0, float x1, float y0, float y1, float *lm /*2 x n*/);
 int slamhost_write_map(const char *path, const float *lm, int32_t nlm, const float *wp, int32_t nwp);
 
+/* ---- plot wire format + headless sink --------------------------------------------------
+ * The backend -> GUI link of the reference: NetworkPlot (src/backend/plotting/NetworkPlot.cpp:22-218) sends one ZeroMQ
+ * multipart message per command -- command name, then one frame per value in network byte order as the vendored zmqpp
+ * serialises it (libs/zmqpp/message.cpp:225-328) -- over a PAIR socket to tcp://127.0.0.1:4242.  These entry points
+ * produce exactly those frames and carry them to any of
+ *     tcp://host:port   a ZMTP 3.0 PAIR client: the reference's slam-gui (libzmq) on the other side
+ *     file:<path>       a frame file: u32 n_messages, per message u32 n_frames, per frame u32 length + bytes (LE)
+ *     gather:<dir>      the GUI's DataGatherer (src/gui/plotting/DataGatherer.cpp:50-138), headless: results.txt,
+ *                       errors.txt, times.txt, positions.txt, observedCounts.txt, averageLengthLandmark.txt under
+ *                       <dir>/<simulation name>/
+ * (several sinks separated by ','; "none" = no sink).  Every call returns 0 on success, -1 on failure
+ * (slamhost_last_error). */
+typedef struct slamhost_plot slamhost_plot;
+slamhost_plot *slamhost_plot_open(const char *spec);
+void slamhost_plot_close(slamhost_plot *p);
+/* cmd = setLandmarks | setWaypoints | setParticles | setFeatureParticles (NetworkPlot.cpp:22-69) */
+int slamhost_plot_xy(slamhost_plot *p, const char *cmd, const double *xs, int32_t nx, const double *ys, int32_t ny);
+/* cmd = setLaserLines (idx ignored) | setCovEllipse; the matrix row-major (:71-101) */
+int slamhost_plot_matrix(slamhost_plot *p, const char *cmd, uint32_t rows, uint32_t cols, const float *row_major, int32_t idx);
+/* cmd = addTruePosition | addEstimatedPosition (2) | setCarTruePosition | setCarEstimatedPosition (3) | setPlotRange (4) */
+int slamhost_plot_doubles(slamhost_plot *p, const char *cmd, const double *v, int32_t n);
+int slamhost_plot_car_size(slamhost_plot *p, double s, uint32_t id);          /* setCarSize (:123-131) */
+int slamhost_plot_u32(slamhost_plot *p, const char *cmd, uint32_t v);         /* loopTime | covEllipseAdd | setCurrentIteration (sends nothing, :176-186) */
+int slamhost_plot_cmd(slamhost_plot *p, const char *cmd);                     /* clear | plot | endPlot */
+int slamhost_plot_name(slamhost_plot *p, const char *name);                   /* setSimulationName (:168-174) */
+
 #ifdef __cplusplus
 }
 #endif

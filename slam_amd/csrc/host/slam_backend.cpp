@@ -5,9 +5,16 @@
 //   -math strict|fast    kernel build (default fast; strict replays the reference's float operations one by one)
 //   -log <file.csv>      per control step: iteration, true pose, estimated pose, loop time [us]
 //   -maxsteps <n>        stop after n control steps
+//   -plot <sinks>        the per-step output the reference sends to slam-gui (plotting/NetworkPlot.cpp), byte for byte:
+//                        tcp://127.0.0.1:4242 (the existing slam-gui) | file:<frames> | gather:<dir> (the GUI's DataGatherer
+//                        files, headless) | none (default); several separated by ','
+//   -plotstride <k>      particles / feature particles sent per step are decimated to every k-th particle (default: as
+//                        many as keep a frame below ~2 000 particles; the reference sends all of them: N = 10^5 would be
+//                        1.6 MB of poses and 56 MB of feature points per control step)
 // It restates the wrapper loops (wrappers/fastslam2wrapper.cpp:31-122, fastslam1wrapper.cpp:32-113,
 // ekfslamwrapper.cpp:33-109) minus the ZeroMQ plotting: the FastSLAM hot path runs on the GPU through the
 // slamgpu C ABI (the seam AcceleratorHandler occupied), EKF-SLAM runs on the host CPU.
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -19,6 +26,7 @@
 #include "../../../include/slamgpu.h"
 #include "ekfslam.h"
 #include "frontend.h"
+#include "plotwire.h"
 
 using namespace slamhost;
 
@@ -29,6 +37,7 @@ static void usage(const char *a0) {
     printf("    -mode               [s] running mode (waypoints)\n");
     printf("    -method             [s] SLAM method: EKF1 | FASTSLAM1 | FASTSLAM2\n");
     printf("    -rng parity|philox  -math strict|fast  -log file.csv  -maxsteps n\n");
+    printf("    -plot tcp://127.0.0.1:4242|file:<path>|gather:<dir>|none   -plotstride k\n");
     printf("    -KEY value          any ini key, e.g. -NPARTICLES 100000 -NEFFECTIVE 75000 -SWITCH_SEED_RANDOM 7\n");
     printf("    -h  (print usage)\n\n");
 }
@@ -53,6 +62,16 @@ int main(int argc, char **argv) {
     FILE *log = logf.empty() ? nullptr : fopen(logf.c_str(), "wt");
     if (log) fprintf(log, "iteration,true_x,true_y,true_t,est_x,est_y,est_t,loop_us\n");
 
+    // per-step output (SLAMBackendApplication.cpp:18-20: NetworkPlot created first, then named)
+    Plot plot;
+    {
+        std::string perr;
+        if (!plot.open(c.s("plot").empty() ? "none" : c.s("plot"), &perr)) {
+            fprintf(stderr, "%s\n", perr.c_str());
+            return EXIT_FAILURE;
+        }
+        if (plot.active()) plot.setSimulationName(c.simulation_name);
+    }
     slamgpu_ctx *ctx = nullptr;
     EkfSlam ekf;
     std::vector<float> ekf_table((size_t) sim.map.nlm, -1.0f);
@@ -92,6 +111,58 @@ int main(int argc, char **argv) {
         ekf.sigmaPhi = c.sigmaT;
     }
 
+    int stride = c.s("plotstride").empty() ? std::max(1, N / 2000) : std::max(1, atoi(c.s("plotstride").c_str()));
+    if (plot.active()) {
+        // SLAMWrapper::configurePlot (slamwrapper.cpp:94-110) + addWaypointsAndLandmarks (:112-139) + setPlotRange (:141-172)
+        plot.setCarSize(c.WHEELBASE, 0);
+        plot.setCarSize(c.WHEELBASE, 1);
+        std::vector<double> wx, wy, lx, ly;
+        double xMin = 1e30, xMax = -1e30, yMin = 1e30, yMax = -1e30;
+        auto grow = [&](double x, double y) {
+            if (x > xMax) xMax = x;
+            if (x < xMin) xMin = x;
+            if (y > yMax) yMax = y;
+            if (y < yMin) yMin = y;
+        };
+        for (int i = 0; i < sim.map.nwp; i++) {
+            wx.push_back(sim.map.wp[i]);
+            wy.push_back(sim.map.wp[(size_t) sim.map.nwp + i]);
+            grow(wx.back(), wy.back());
+        }
+        plot.setWaypoints(wx, wy);
+        for (int i = 0; i < sim.map.nlm; i++) {
+            lx.push_back(sim.map.lm[i]);
+            ly.push_back(sim.map.lm[(size_t) sim.map.nlm + i]);
+            grow(lx.back(), ly.back());
+        }
+        plot.setLandmarks(lx, ly);
+        plot.setPlotRange(xMin - (xMax - xMin) * 0.05, xMax + (xMax - xMin) * 0.05, yMin - (yMax - yMin) * 0.05, yMax + (yMax - yMin) * 0.05);
+        plot.addTruePosition(sim.xTrue[0], sim.xTrue[1]);
+        plot.setCarTruePosition(sim.xTrue[0], sim.xTrue[1], sim.xTrue[2]);
+        plot.addEstimatedPosition(sim.xTrue[0], sim.xTrue[1]);
+        plot.setCarEstimatedPosition(sim.xTrue[0], sim.xTrue[1], sim.xTrue[2]);
+        plot.plot();
+    }
+    std::vector<float> plines;  // 4 x len, row-major: makeLaserLines (core.cpp:330-355)
+    uint32_t plines_cols = 0;
+    auto mark = std::chrono::steady_clock::now();
+    std::vector<float> dxv, dxf;
+    std::vector<double> px, py, fx, fy;
+
+    auto laser_lines = [&]() {  // makeLaserLines(landmarksRangeBearing, xTrue) + transform_to_global (core.cpp:330-355, 827-843)
+        if (!plot.active()) return;
+        plines_cols = (uint32_t) (sim.z.size() / 2);
+        plines.assign(4 * (size_t) plines_cols, 0.0f);
+        const float cs = std::cos(sim.xTrue[2]), sn = std::sin(sim.xTrue[2]);
+        for (uint32_t q = 0; q < plines_cols; q++) {
+            const float gx = sim.z[2 * q] * std::cos(sim.z[2 * q + 1]), gy = sim.z[2 * q] * std::sin(sim.z[2 * q + 1]);
+            plines[0 * plines_cols + q] = sim.xTrue[0];
+            plines[1 * plines_cols + q] = sim.xTrue[1];
+            plines[2 * plines_cols + q] = (cs * gx + -sn * gy) + sim.xTrue[0];
+            plines[3 * plines_cols + q] = (sn * gx + cs * gy) + sim.xTrue[1];
+        }
+    };
+
     std::vector<float> zf, zn, normals, strata, noise2;
     std::vector<int32_t> idf;
     long iter = 0, nobs = 0;
@@ -112,6 +183,7 @@ int main(int argc, char **argv) {
             rc = slamgpu_predict(ctx, sim.Vnoisy, sim.Gnoisy, sim.Qe, sim.dt, sim.xTrue[2], n2);
             if (!rc && r == 1) {
                 sim.observe();
+                laser_lines();
                 sim.associate_known(slamgpu_num_landmarks(ctx), zf, idf, zn);
                 const float *nm = nullptr, *st = nullptr;
                 if (parity) {
@@ -135,6 +207,7 @@ int main(int argc, char **argv) {
         } else {
             if (r == 1) {
                 sim.observe();
+                laser_lines();
                 nobs++;
             }
             const float phi = (float) (sim.xTrue[2] + c.sigmaT * unif_rand());  // ekfslamwrapper.cpp:82
@@ -144,6 +217,40 @@ int main(int argc, char **argv) {
             est[2] = ekf.x[2];
         }
         iter++;
+        if (plot.active()) {
+            // the tail of the wrappers' loop body (fastslam2wrapper.cpp:92-117, ekfslamwrapper.cpp:86-105)
+            const auto now = std::chrono::steady_clock::now();
+            plot.loopTime((uint32_t) std::chrono::duration_cast<std::chrono::microseconds>(now - mark).count());
+            mark = now;
+            plot.setCurrentIteration((uint32_t) iter);
+            if (ctx) {  // drawParticles / drawFeatureParticles (ParticleSLAMWrapper.cpp:34-54), decimated
+                const int nfl = slamgpu_num_landmarks(ctx);
+                px.clear(); py.clear(); fx.clear(); fy.clear();
+                dxv.resize(3);
+                dxf.resize(2 * (size_t) std::max(nfl, 1));
+                for (int i = 0; i < N && !rc; i += stride) {
+                    rc = slamgpu_download_range(ctx, i, 1, dxv.data(), nullptr, nullptr, nfl ? dxf.data() : nullptr, nullptr);
+                    px.push_back(dxv[0]);
+                    py.push_back(dxv[1]);
+                    for (int j = 0; j < nfl; j++) {
+                        fx.push_back(dxf[2 * j]);
+                        fy.push_back(dxf[2 * j + 1]);
+                    }
+                }
+                plot.setParticles(px, py);
+                plot.setFeatureParticles(fx, fy);
+            }
+            plot.addTruePosition(sim.xTrue[0], sim.xTrue[1]);
+            plot.addEstimatedPosition(est[0], est[1]);
+            plot.setCarTruePosition(sim.xTrue[0], sim.xTrue[1], sim.xTrue[2]);
+            plot.setCarEstimatedPosition(est[0], est[1], est[2]);
+            plot.setLaserLines(plines_cols ? 4 : 0, plines_cols, plines.data());
+            plot.plot();
+            if (rc) {
+                fprintf(stderr, "slamgpu: %s\n", slamgpu_last_error());
+                break;
+            }
+        }
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
         sum_us += us;
         sq_err += (est[0] - sim.xTrue[0]) * (est[0] - sim.xTrue[0]) + (est[1] - sim.xTrue[1]) * (est[1] - sim.xTrue[1]);
@@ -153,6 +260,10 @@ int main(int argc, char **argv) {
            iter, nobs, iter ? sum_us / iter : 0.0, iter ? std::sqrt(sq_err / iter) : 0.0, est[0], est[1], est[2]);
     if (ctx) printf("landmarks in map: %d\n", slamgpu_num_landmarks(ctx));
     else printf("landmarks in map: %d\n", ekf.num_features());
+    if (plot.active()) {
+        plot.endPlot();
+        plot.close();
+    }
     if (log) fclose(log);
     if (ctx) slamgpu_destroy(ctx);
     return rc ? EXIT_FAILURE : 0;

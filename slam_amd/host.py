@@ -12,7 +12,8 @@ DECLARED_SYMBOLS = [
     "slamhost_sim_control", "slamhost_sim_observe", "slamhost_sim_last_z", "slamhost_sim_true",
     "slamhost_sim_control_steps", "slamhost_draw_normals", "slamhost_draw_strata", "slamhost_unif_rand",
     "slamhost_synthetic_landmarks", "slamhost_write_map", "slamhost_ekf_create", "slamhost_ekf_destroy", "slamhost_ekf_step",
-    "slamhost_ekf_state",
+    "slamhost_ekf_state", "slamhost_plot_open", "slamhost_plot_close", "slamhost_plot_xy", "slamhost_plot_matrix",
+    "slamhost_plot_doubles", "slamhost_plot_car_size", "slamhost_plot_u32", "slamhost_plot_cmd", "slamhost_plot_name",
 ]
 
 
@@ -67,6 +68,17 @@ def load_library():
         L.slamhost_ekf_destroy.restype = None
         L.slamhost_ekf_step.argtypes = [C.c_void_p, C.c_void_p]
         L.slamhost_ekf_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        L.slamhost_plot_open.restype = C.c_void_p
+        L.slamhost_plot_open.argtypes = [C.c_char_p]
+        L.slamhost_plot_close.argtypes = [C.c_void_p]
+        L.slamhost_plot_close.restype = None
+        L.slamhost_plot_xy.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.slamhost_plot_matrix.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int32]
+        L.slamhost_plot_doubles.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32]
+        L.slamhost_plot_car_size.argtypes = [C.c_void_p, C.c_double, C.c_uint32]
+        L.slamhost_plot_u32.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
+        L.slamhost_plot_cmd.argtypes = [C.c_void_p, C.c_char_p]
+        L.slamhost_plot_name.argtypes = [C.c_void_p, C.c_char_p]
         _lib = L
     return _lib
 
@@ -194,3 +206,49 @@ def make_tape(args, max_obs=None):
     conf = sim.conf
     sim.close()
     return dict(steps=steps, Q=Q, R=R, dt=dt, conf=conf, nlm=conf.n_landmarks, tail_controls=ctl)
+
+
+class Plot:
+    """NetworkPlot's method surface (src/backend/plotting/NetworkPlot.cpp) over the product's wire encoder and sinks
+    (include/slamhost.h: slamhost_plot_*).  spec: tcp://host:port | file:<path> | gather:<dir> | none, comma-separated."""
+
+    def __init__(self, spec):
+        self.L = load_library()
+        h = self.L.slamhost_plot_open(spec.encode())
+        if not h:
+            raise RuntimeError("slamhost_plot_open: %s" % self.L.slamhost_last_error().decode())
+        self.h = C.c_void_p(h)
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError("plot: %s" % self.L.slamhost_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.L.slamhost_plot_close(self.h)
+            self.h = None
+
+    def xy(self, cmd, xs, ys):
+        xs, ys = np.ascontiguousarray(xs, np.float64), np.ascontiguousarray(ys, np.float64)
+        self._chk(self.L.slamhost_plot_xy(self.h, cmd.encode(), _p(xs), xs.size, _p(ys), ys.size))
+
+    def matrix(self, cmd, a, idx=0):
+        a = np.ascontiguousarray(a, np.float32)
+        rows, cols = (a.shape if a.ndim == 2 else (0, 0))
+        self._chk(self.L.slamhost_plot_matrix(self.h, cmd.encode(), rows, cols, _p(a), idx))
+
+    def doubles(self, cmd, *v):
+        a = np.array(v, np.float64)
+        self._chk(self.L.slamhost_plot_doubles(self.h, cmd.encode(), _p(a), a.size))
+
+    def car_size(self, s, ident):
+        self._chk(self.L.slamhost_plot_car_size(self.h, s, ident))
+
+    def u32(self, cmd, v):
+        self._chk(self.L.slamhost_plot_u32(self.h, cmd.encode(), v))
+
+    def cmd(self, cmd):
+        self._chk(self.L.slamhost_plot_cmd(self.h, cmd.encode()))
+
+    def name(self, n):
+        self._chk(self.L.slamhost_plot_name(self.h, n.encode()))

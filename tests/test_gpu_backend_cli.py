@@ -64,3 +64,37 @@ def test_slam_backend_philox_full_run_tracks_the_true_path(tmp_path):
     assert rows.shape[0] > 17000 and "landmarks in map: 35" in r.stdout
     err = np.hypot(rows[:, 4] - rows[:, 1], rows[:, 5] - rows[:, 2])
     assert np.isfinite(err).all() and err.mean() < 1.0, err.mean()
+
+
+def test_slam_backend_plot_stream_with_particles(tmp_path):
+    """FASTSLAM2 on the GPU with -plot file:<frames>: per control step the wrapper's tail (fastslam2wrapper.cpp:92-117):
+    loopTime, setParticles, setFeatureParticles (decimated by -plotstride), positions, laser lines, plot."""
+    import struct
+    frames = str(tmp_path / "fs2_frames.bin")
+    r = subprocess.run([EXE, "-m", os.path.join(DATA, "example_webmap.mat"), "-method", "FASTSLAM2", "-NPARTICLES", "1000", "-NEFFECTIVE", "750",
+                        "-SWITCH_SEED_RANDOM", "7", "-maxsteps", "60", "-plot", "file:" + frames, "-plotstride", "100"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+    b = open(frames, "rb").read()
+    off, msgs = 4, []
+    for _ in range(struct.unpack_from("<I", b, 0)[0]):
+        (nf,) = struct.unpack_from("<I", b, off)
+        off += 4
+        fr = []
+        for _ in range(nf):
+            (ln,) = struct.unpack_from("<I", b, off)
+            off += 4
+            fr.append(b[off:off + ln])
+            off += ln
+        msgs.append(fr)
+    names = [m[0].decode() for m in msgs]
+    per_step = ["loopTime", "setParticles", "setFeatureParticles", "addTruePosition", "addEstimatedPosition", "setCarTruePosition",
+                "setCarEstimatedPosition", "setLaserLines", "plot"]
+    body = names[11:-1]
+    assert names[-1] == "endPlot" and len(body) == 60 * len(per_step) and body[-len(per_step):] == per_step
+    last_particles = [m for m in msgs if m[0] == b"setParticles"][-1]
+    assert struct.unpack(">i", last_particles[1])[0] == 10  # 1000 particles, every 100th
+    last_features = [m for m in msgs if m[0] == b"setFeatureParticles"][-1]
+    assert struct.unpack(">i", last_features[1])[0] == 10 * 6  # 6 landmarks in the map after 60 control steps
+    xs = [struct.unpack(">d", f)[0] for f in last_particles[2:12]]
+    assert all(np.isfinite(xs)) and 0.5 < np.mean(xs) < 10.0
