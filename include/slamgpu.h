@@ -171,6 +171,18 @@ int slamgpu_step_status(slamgpu_ctx *ctx, int32_t *status);
 /* Ancestor indices of the last resample (keep[], core.cpp:800-806), N_local int32. Synchronises. */
 int slamgpu_ancestors(slamgpu_ctx *ctx, int32_t *keep);
 
+/* Per-particle gated nearest-neighbour data association (the reference has it for EKF-SLAM only:
+ * EKFSLAM::dataAssociate, algorithms/ekfslam.cpp:151-189; applied here to every particle with its own landmark
+ * estimates: P = blockdiag(0, Pf_j), so S = Hf Pf Hf^T + R).  z[2*nz] = (range, bearing) of the nz observations.
+ * labels[N*nz] (host, particle-major; may be NULL): landmark index >= 0, SLAMGPU_ASSOC_NEW or SLAMGPU_ASSOC_DISCARD.
+ * consensus[nz] / support[nz] (may be NULL): the label carrying the largest total particle weight per observation and
+ * that weight share -- what a caller feeds to slamgpu_update, whose association is per step, not per particle (two
+ * observations claiming one landmark: the weaker one is discarded).  gate_reject / gate_augment = GATE_REJECT /
+ * GATE_AUGMENT of the .ini.  Cost is O(N * nz * Nf): for maps with tens of landmarks.  Synchronises. */
+enum { SLAMGPU_ASSOC_NEW = -1, SLAMGPU_ASSOC_DISCARD = -2 };
+int slamgpu_associate(slamgpu_ctx *ctx, const float *z, int32_t nz, const float R[4], float gate_reject, float gate_augment,
+                      int32_t *labels, int32_t *consensus, float *support);
+
 int slamgpu_num_landmarks(slamgpu_ctx *ctx);
 /* Particle-major host copies (any pointer may be NULL): xv[3N], Pv[9N] row-major, w[N],
  * xf[2*Nf*N], Pf[4*Nf*N] row-major — the layout of vector<Particle> flattened. Synchronises. */

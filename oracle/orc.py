@@ -505,6 +505,16 @@ class Reference(_FuncLib):
         L.ref_fs1_compute_weight.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.ref_fs2_observe_particle.argtypes = [C.c_uint] + [C.c_void_p] * 5 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.ref_feature_update.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        if hasattr(L, "ref_data_associate"):
+            L.ref_data_associate.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+
+    def data_associate(self, xv, xf, Pf, z, R, gate1, gate2):
+        """EKFSLAM::dataAssociate for one particle (pose known): labels [nz]"""
+        c = lambda a: np.ascontiguousarray(a, f32)
+        xv, xf, Pf, z, R = c(xv), c(xf).reshape(-1, 2), c(Pf).reshape(-1, 2, 2), c(z).reshape(-1, 2), c(R)
+        lab = np.zeros(z.shape[0], np.int32)
+        self.lib.ref_data_associate(_p(xv), _p(xf), _p(Pf), xf.shape[0], _p(z), z.shape[0], _p(R), gate1, gate2, _p(lab))
+        return lab
 
     def rand_stream(self, seed, count):
         out = np.zeros(count, np.int32)

@@ -171,6 +171,33 @@ void ref_compute_jacobians(const float *xv, const float *R4, const float *xf, co
 }
 
 // fastslam2.cpp:127 — D = 2 or 3, S row-major DxD.
+// EKFSLAM::dataAssociate (algorithms/ekfslam.cpp:151-189) for ONE FastSLAM particle: pose known (zero pose covariance),
+// landmarks with their own 2x2 covariances: x = [xv; xf_1; ..], P = blockdiag(0, Pf_1, ..).  One observation per call of
+// the reference function (its decisions are independent per observation): labels[q] = landmark index, -1 new, -2 dropped.
+void ref_data_associate(const float *xv, const float *xf, const float *Pf4, int nf, const float *z, int nz, const float *R4,
+                        float gate1, float gate2, int *labels) {
+    OpenEKF a;
+    const int D = 3 + 2 * nf;
+    VectorXf x(D);
+    MatrixXf P = MatrixXf::Zero(D, D);
+    for (int k = 0; k < 3; k++) x(k) = xv[k];
+    for (int j = 0; j < nf; j++) {
+        x(3 + 2 * j) = xf[2 * j];
+        x(3 + 2 * j + 1) = xf[2 * j + 1];
+        for (int r = 0; r < 2; r++)
+            for (int c = 0; c < 2; c++) P(3 + 2 * j + r, 3 + 2 * j + c) = Pf4[4 * j + 2 * r + c];
+    }
+    MatrixXf R = mat2(R4);
+    for (int q = 0; q < nz; q++) {
+        vector<VectorXf> zz(1, VectorXf(2)), zf, zn;
+        vector<int> idf;
+        zz[0](0) = z[2 * q];
+        zz[0](1) = z[2 * q + 1];
+        a.dataAssociate(x, P, zz, R, gate1, gate2, zf, idf, zn);
+        labels[q] = !idf.empty() ? idf[0] : (!zn.empty() ? -1 : -2);
+    }
+}
+
 float ref_gauss_evaluate(const float *v, const float *S, int D, int logflag) {
     OpenFS2 a;
     VectorXf vv(D);

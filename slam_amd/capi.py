@@ -8,6 +8,7 @@ import numpy as np
 FASTSLAM1, FASTSLAM2 = 1, 2
 RNG_TAPE, RNG_PHILOX = 0, 1
 MATH_STRICT, MATH_FAST = 0, 1
+ASSOC_NEW, ASSOC_DISCARD = -1, -2
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -19,7 +20,7 @@ DECLARED_SYMBOLS = [
     "slamgpu_kernel_time", "slamgpu_algorithmic_bytes", "slamgpu_shard_update", "slamgpu_shard_block_totals", "slamgpu_shard_plan",
     "slamgpu_shard_record_floats", "slamgpu_shard_pack", "slamgpu_shard_unpack", "slamgpu_shard_finish", "slamgpu_shard_estimate",
     "slamgpu_dev_alloc", "slamgpu_dev_free", "slamgpu_dev_copy", "slamgpu_dev_copy_async", "slamgpu_shard_estimate_async",
-    "slamgpu_shard_estimate_fetch", "slamgpu_step_status", "slamgpu_kat", "slamgpu_download_range", "slamgpu_debug_stamps",
+    "slamgpu_shard_estimate_fetch", "slamgpu_step_status", "slamgpu_kat", "slamgpu_download_range", "slamgpu_debug_stamps", "slamgpu_associate",
 ]
 
 
@@ -79,6 +80,7 @@ def load_library():
     L.slamgpu_history_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.slamgpu_step_status.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.slamgpu_kat.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
+    L.slamgpu_associate.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     L.slamgpu_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.slamgpu_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.slamgpu_ancestors.argtypes = [C.c_void_p, C.c_void_p]
@@ -378,6 +380,16 @@ class SlamGpu:
         n = C.c_int32()
         _chk(self.L.slamgpu_shard_estimate_fetch(self.h, _ptr(out), max_count, C.byref(n)))
         return out[:n.value].copy()
+
+    def associate(self, z, R, gate_reject=4.0, gate_augment=25.0, want_labels=True):
+        """per-particle gated nearest-neighbour association (slamgpu_associate): labels [N, nz], consensus [nz], support [nz]"""
+        z = _f32(z).reshape(-1, 2)
+        nz = z.shape[0]
+        lab = np.zeros((self.N, nz), np.int32) if want_labels else None
+        cons = np.zeros(nz, np.int32)
+        sup = np.zeros(nz, np.float32)
+        _chk(self.L.slamgpu_associate(self.h, _ptr(z), nz, _ptr(_f32(R, 4)), gate_reject, gate_augment, _ptr(lab), _ptr(cons), _ptr(sup)))
+        return lab, cons, sup
 
     def debug_stamps(self, max_blocks=8192):
         out = np.zeros((max_blocks, 16), np.uint64)

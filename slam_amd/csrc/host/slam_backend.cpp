@@ -5,6 +5,10 @@
 //   -math strict|fast    kernel build (default fast; strict replays the reference's float operations one by one)
 //   -log <file.csv>      per control step: iteration, true pose, estimated pose, loop time [us]
 //   -maxsteps <n>        stop after n control steps
+//   -assoc known|gated   FastSLAM data association: known = dataAssociationKnown (core.cpp:91-120), what the reference's
+//                        FastSLAM wrappers always use (default); gated = per-particle gated nearest neighbour
+//                        (EKFSLAM::dataAssociate, ekfslam.cpp:151-189, applied to every particle with GATE_REJECT /
+//                        GATE_AUGMENT) reduced to one association per step by weighted vote (slamgpu_associate)
 //   -plot <sinks>        the per-step output the reference sends to slam-gui (plotting/NetworkPlot.cpp), byte for byte:
 //                        tcp://127.0.0.1:4242 (the existing slam-gui) | file:<frames> | gather:<dir> (the GUI's DataGatherer
 //                        files, headless) | none (default); several separated by ','
@@ -77,13 +81,14 @@ int main(int argc, char **argv) {
     std::vector<float> ekf_table((size_t) sim.map.nlm, -1.0f);
     const int N = c.NPARTICLES;
     const bool parity = rng == "parity";
+    const bool gated = c.s("assoc") == "gated";
     if (c.method != 0) {
         printf("%s\n\n", c.method == 2 ? "FastSLAM 2" : "FastSLAM 1");
         slamgpu_config g{};
         g.struct_size = sizeof g;
         g.method = c.method;
         g.n_particles = N;
-        g.max_landmarks = sim.map.nlm;
+        g.max_landmarks = gated ? 2 * sim.map.nlm : sim.map.nlm;  // unknown association may open spurious landmarks
         g.use_heading = c.SWITCH_HEADING_KNOWN == 1;
         g.add_predict_noise = c.method == 1 ? 1 : (c.SWITCH_PREDICT_NOISE == 1);
         g.resample = c.SWITCH_RESAMPLE == 1;
@@ -184,7 +189,32 @@ int main(int argc, char **argv) {
             if (!rc && r == 1) {
                 sim.observe();
                 laser_lines();
-                sim.associate_known(slamgpu_num_landmarks(ctx), zf, idf, zn);
+                if (gated) {
+                    // unknown association: every particle gates the observations against its own map; the weighted vote
+                    // becomes this step's association (slamgpu_update's association is per step)
+                    const int nz = (int) (sim.z.size() / 2);
+                    std::vector<int32_t> cons((size_t) std::max(nz, 1));
+                    zf.clear();
+                    idf.clear();
+                    zn.clear();
+                    if (nz > 0) rc = slamgpu_associate(ctx, sim.z.data(), nz, sim.Re, c.GATE_REJECT, c.GATE_AUGMENT, nullptr, cons.data(), nullptr);
+                    for (int q = 0; q < nz && !rc; q++) {
+                        if (cons[q] >= 0) {
+                            zf.push_back(sim.z[2 * q]);
+                            zf.push_back(sim.z[2 * q + 1]);
+                            idf.push_back(cons[q]);
+                        } else if (cons[q] == SLAMGPU_ASSOC_NEW && slamgpu_num_landmarks(ctx) + (int) (zn.size() / 2) < sim.map.nlm * 2) {
+                            zn.push_back(sim.z[2 * q]);
+                            zn.push_back(sim.z[2 * q + 1]);
+                        }
+                    }
+                    if (rc) {
+                        fprintf(stderr, "slamgpu: %s\n", slamgpu_last_error());
+                        break;
+                    }
+                } else {
+                    sim.associate_known(slamgpu_num_landmarks(ctx), zf, idf, zn);
+                }
                 const float *nm = nullptr, *st = nullptr;
                 if (parity) {
                     if (c.method == 2 && (!idf.empty() || !zn.empty())) {

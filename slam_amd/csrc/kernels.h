@@ -197,6 +197,8 @@ struct UpdateArgs {
     unsigned long long *stamps;  // diagnostic build (-DSLAM_STAMPS, libslamgpu_stamps.so): [compute blocks][kStampSlots] wall-clock stamps
 };
 constexpr int kStampSlots = 16;
+constexpr int kAssocNew = -1, kAssocDiscard = -2;
+constexpr int kAssocBatch = 8;  // observations associated per pass over a particle's landmarks (registers)
 
 // The weight scratch is double-buffered by the parity of the observation step (wpar): the update launch of step t
 // writes lcum / blk_w [wpar] while -- when it also plans the resampling of step t-1 inline -- its blocks are still
@@ -286,6 +288,10 @@ struct KernelTable {
     // known-answer entry point for the scalar device functions (slamgpu_kat): op 0 trigonometricOffset, 1 gaussEvaluate D=2,
     // 2 gaussEvaluate D=3, in the arithmetic this build's update kernel uses
     void (*kat)(hipStream_t, int op, const float *in_dev, int n, float *out_dev);
+    // per-particle gated nearest-neighbour association of nz observations against every landmark of every particle
+    // (slamgpu_associate): labels [n][nz] = landmark index, kAssocNew or kAssocDiscard.  Plain set required (no pending gather).
+    void (*associate)(hipStream_t, const Buffers &, int nf, const float *z_dev, int nz, const float *R4, float gate_reject,
+                      float gate_augment, int32_t *labels_dev);
     // seq_out != null: `out` and `seq_out` are pinned host memory; the kernel stores `seq` there last (system-scope fence)
     void (*shard_plan)(hipStream_t, const ShardPlanArgs &, const RngArgs &, ShardPlan *out, uint32_t *seq_out, uint32_t seq);
     void (*shard_pack)(hipStream_t, const Buffers &, const WeightScratch &, const ShardPackArgs &, const RngArgs &);

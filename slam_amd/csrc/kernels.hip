@@ -1428,6 +1428,67 @@ __global__ void __launch_bounds__(kBlock) kat_kernel(int op, const float *__rest
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Per-particle gated nearest-neighbour data association.  The reference only has it for EKF-SLAM:
+// EKFSLAM::dataAssociate (algorithms/ekfslam.cpp:151-189) over ekfComputeAssociation (:131-149): for every observation z,
+// over the Nf landmarks j: v = wrap(z - h_j), S = H P H^T + R, nis = v^T S^-1 v, nd = nis + log det S;
+//     if (nis < gate1 && nd < nbest) { nbest = nd; jbest = j; } else if (nis < outer) outer = nis;
+// then: jbest found -> associate; else outer > gate2 -> new feature; else the observation is dropped.
+// For a FastSLAM particle the pose is given, so P = blockdiag(0, Pf_1, .., Pf_Nf) and H P H^T = Hf Pf Hf^T: exactly the Sf
+// of computeJacobians (core.cpp:682-704).  One particle per work-item; the particle's landmarks are read once per batch of
+// kAssocBatch observations, through the genealogy (needs Buffers::erow / lmk_live; plain set).
+// ---------------------------------------------------------------------------------------------------
+SLAM_DEV void read_through_genealogy(const Buffers &B, const int32_t *__restrict__ live, int cur, size_t S, int l, int anc,
+                                     float4 &la, float &lb);
+
+__global__ void __launch_bounds__(kBlock) associate_kernel(Buffers B, int nf, const float *__restrict__ z, int nz, float r00, float r01,
+                                                            float r10, float r11, float gate1, float gate2,
+                                                            int32_t *__restrict__ labels) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= B.n) return;
+    const int cur = B.ctrl->live[B.slot];
+    const size_t S = (size_t) B.ncap;
+    const float4 pa = B.poseA[cur][i];
+    for (int q0 = 0; q0 < nz; q0 += kAssocBatch) {
+        float nbest[kAssocBatch], outer[kAssocBatch];
+        int jbest[kAssocBatch];
+#pragma unroll
+        for (int q = 0; q < kAssocBatch; q++) {
+            nbest[q] = INFINITY;  // the reference's `float nbest = 1e60` is +inf in float32
+            outer[q] = INFINITY;
+            jbest[q] = -1;
+        }
+        for (int j = 0; j < nf; j++) {
+            float4 la;
+            float lb;
+            read_through_genealogy(B, B.lmk_live, cur, S, j, i, la, lb);
+            const Jac jc = jacobian(pa.x, pa.y, pa.z, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
+            float i00, i01, i10, i11;
+            inverse2(jc.s00, jc.s01, jc.s10, jc.s11, i00, i01, i10, i11);
+            const float ldet = logf(determinant2(jc.s00, jc.s01, jc.s10, jc.s11));
+#pragma unroll
+            for (int q = 0; q < kAssocBatch; q++) {
+                if (q0 + q < nz) {
+                    const float v0 = z[2 * (q0 + q)] - jc.zp0;
+                    const float v1 = trig_offset(z[2 * (q0 + q) + 1] - jc.zp1);
+                    const float t0 = v0 * i00 + v1 * i10, t1 = v0 * i01 + v1 * i11;  // v^T S^-1
+                    const float nis = t0 * v0 + t1 * v1;
+                    const float nd = nis + ldet;
+                    if (nis < gate1 && nd < nbest[q]) {
+                        nbest[q] = nd;
+                        jbest[q] = j;
+                    } else if (nis < outer[q]) {
+                        outer[q] = nis;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kAssocBatch; q++)
+            if (q0 + q < nz) labels[(size_t) i * nz + q0 + q] = jbest[q] > -1 ? jbest[q] : (outer[q] > gate2 ? kAssocNew : kAssocDiscard);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Sharded resampling (particles partitioned over contexts / GPUs in contiguous blocks of 256).  The host
 // layer all-gathers the per-block totals (4 B + 4 B per 256 particles); every shard then runs the same
 // scan, so the decision and every ancestor are independent of the number of shards.
@@ -1778,11 +1839,17 @@ static void launch_jacobians(hipStream_t st, const float *in, uint32_t n, float 
     hipLaunchKernelGGL(jacobians_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, in, n, out);
 }
 
+static void launch_associate(hipStream_t st, const Buffers &B, int nf, const float *z, int nz, const float *R4, float g1, float g2,
+                             int32_t *labels) {
+    hipLaunchKernelGGL(associate_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B, nf, z, nz, R4[0], R4[1], R4[2], R4[3], g1, g2,
+                       labels);
+}
+
 static void launch_kat(hipStream_t st, int op, const float *in, int n, float *out) {
     hipLaunchKernelGGL(kat_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, op, in, n, out);
 }
 
-static const KernelTable kTable = {launch_update, launch_resample, launch_scan, launch_gather, launch_flatten, launch_identity, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat,
+static const KernelTable kTable = {launch_update, launch_resample, launch_scan, launch_gather, launch_flatten, launch_identity, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat, launch_associate,
                                    launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish};
 
 }  // namespace SLAM_KNS

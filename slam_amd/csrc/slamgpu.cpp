@@ -1271,6 +1271,90 @@ int slamgpu_ancestors(slamgpu_ctx *c, int32_t *keep) {
     return 0;
 }
 
+int slamgpu_associate(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4], float gate_reject, float gate_augment,
+                      int32_t *labels, int32_t *consensus, float *support) {
+    if (int rc = check_ctx(c)) return rc;
+    if (nz < 0 || (nz > 0 && !z) || !R) return fail(SLAMGPU_ERR_INVALID, "bad observation list");
+    if (nz == 0) return 0;
+    static_assert(SLAMGPU_ASSOC_NEW == kAssocNew && SLAMGPU_ASSOC_DISCARD == kAssocDiscard, "public / device labels");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = flush_predict(c)) return rc;
+    if (int rc = materialize(c)) return rc;  // plain set: particle k in slot k
+    if (int rc = sync_tables(c)) return rc;
+    const int N = c->B.n;
+    float *z_dev = nullptr;
+    int32_t *lab_dev = nullptr;
+    HIP_TRY(hipMalloc((void **) &z_dev, sizeof(float) * 2 * (size_t) nz));
+    hipError_t e = hipMalloc((void **) &lab_dev, sizeof(int32_t) * (size_t) N * nz);
+    if (e != hipSuccess) {
+        (void) hipFree(z_dev);
+        return fail(SLAMGPU_ERR_ALLOC, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    int rc = 0;
+    std::vector<int32_t> lab((size_t) N * nz);
+    std::vector<float4> pa;
+    auto step = [&](hipError_t er, const char *what) {
+        if (!rc && er != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "%s: %s", what, hipGetErrorString(er));
+    };
+    step(hipMemcpyAsync(z_dev, z, sizeof(float) * 2 * (size_t) nz, hipMemcpyHostToDevice, c->stream), "H2D");
+    step(hipStreamSynchronize(c->stream), "sync");
+    if (!rc) {
+        c->B.slot = c->slot;
+        {
+            Timed t(c, "associate");
+            c->k->associate(c->stream, c->B, c->nf, z_dev, nz, R, gate_reject, gate_augment, lab_dev);
+        }
+        step(hipGetLastError(), "launch");
+        step(hipMemcpyAsync(lab.data(), lab_dev, sizeof(int32_t) * lab.size(), hipMemcpyDeviceToHost, c->stream), "D2H");
+        step(hipStreamSynchronize(c->stream), "sync");
+    }
+    (void) hipFree(z_dev);
+    (void) hipFree(lab_dev);
+    if (rc) return rc;
+    if (labels) memcpy(labels, lab.data(), sizeof(int32_t) * lab.size());
+    if (consensus || support) {
+        if (int rc2 = read_ctrl(c, true)) return rc2;
+        const int cur = c->ctrl_host->live[c->slot];
+        pa.resize((size_t) N);
+        HIP_TRY(hipMemcpy(pa.data(), c->B.poseA[cur], sizeof(float4) * (size_t) N, hipMemcpyDeviceToHost));
+        // weights (log-weight contexts: exp(l - max l)), normalised
+        std::vector<double> w((size_t) N);
+        double wmax = -1e300, wsum = 0;
+        for (int i = 0; i < N; i++) wmax = std::max(wmax, (double) pa[i].w);
+        for (int i = 0; i < N; i++) {
+            w[i] = c->cfg.log_weights ? exp((double) pa[i].w - wmax) : (double) pa[i].w;
+            wsum += w[i];
+        }
+        std::vector<int32_t> best((size_t) nz);
+        std::vector<double> share((size_t) nz);
+        for (int q = 0; q < nz; q++) {
+            std::map<int32_t, double> votes;
+            for (int i = 0; i < N; i++) votes[lab[(size_t) i * nz + q]] += w[i];
+            int32_t b = SLAMGPU_ASSOC_DISCARD;
+            double bw = -1;
+            for (auto &kv : votes)
+                if (kv.second > bw) {
+                    bw = kv.second;
+                    b = kv.first;
+                }
+            best[q] = b;
+            share[q] = wsum > 0 ? bw / wsum : 0.0;
+        }
+        // the update's association is per step: one observation per landmark (the better-supported one wins)
+        for (int q = 0; q < nz; q++)
+            for (int p = 0; p < q; p++)
+                if (best[q] >= 0 && best[q] == best[p]) {
+                    if (share[q] > share[p]) best[p] = SLAMGPU_ASSOC_DISCARD;
+                    else best[q] = SLAMGPU_ASSOC_DISCARD;
+                }
+        for (int q = 0; q < nz; q++) {
+            if (consensus) consensus[q] = best[q];
+            if (support) support[q] = (float) share[q];
+        }
+    }
+    return 0;
+}
+
 int slamgpu_num_landmarks(slamgpu_ctx *c) { return c ? c->nf : SLAMGPU_ERR_INVALID; }
 
 int slamgpu_sync(slamgpu_ctx *c) {

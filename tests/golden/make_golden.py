@@ -335,8 +335,43 @@ def make_log_kats(R):
     np.savez_compressed(os.path.join(OUT, "kat_log.npz"), **d)
 
 
+def make_assoc_kats(R):
+    """EKFSLAM::dataAssociate (algorithms/ekfslam.cpp:151-189) of the reference objects applied to single FastSLAM
+    particles (pose known: P = blockdiag(0, Pf_j)): groups of 16 particles sharing the landmark count and the observation
+    list (as the particles of one filter do), labels per particle and observation: landmark index, -1 new, -2 dropped."""
+    rng = np.random.default_rng(20261004)
+    d = {}
+    groups = 10
+    for g in range(groups):
+        nf = int(rng.integers(1, 30))
+        N = 16
+        xv0 = (rng.normal(size=3) * [20, 20, 1.0])
+        xf0 = xv0[:2] + rng.normal(size=(nf, 2)) * 25
+        xv = (xv0 + rng.normal(size=(N, 3)) * [0.3, 0.3, 0.03]).astype(f32)
+        xf = (xf0 + rng.normal(size=(N, nf, 2)) * 0.3).astype(f32)
+        B = rng.normal(size=(N, nf, 2, 2)) * rng.uniform(0.02, 0.6, size=(N, nf, 1, 1))
+        Pf = (B @ B.transpose(0, 1, 3, 2) + 1e-4 * np.eye(2)).astype(f32)
+        zs = []
+        for k in range(9):
+            j = int(rng.integers(0, nf))
+            dx, dy = xf0[j] - xv0[:2]
+            scale = rng.choice([0.5, 2.0, 6.0, 30.0])
+            zs.append([np.hypot(dx, dy) + rng.normal() * 0.1 * scale, np.arctan2(dy, dx) - xv0[2] + rng.normal() * 0.0175 * scale])
+        for k in range(2):
+            zs.append([rng.uniform(1, 60), rng.uniform(-3, 3)])
+        z = np.array(zs, f32)
+        lab = np.stack([R.data_associate(xv[i], xf[i], Pf[i], z, RM, 4.0, 25.0) for i in range(N)])
+        d.update({"g%d_xv" % g: xv, "g%d_xf" % g: xf, "g%d_Pf" % g: Pf, "g%d_z" % g: z, "g%d_lab" % g: lab})
+    d["n_groups"] = np.array(groups)
+    d["gates"] = np.array([4.0, 25.0], f32)
+    np.savez_compressed(os.path.join(OUT, "kat_assoc.npz"), **d)
+    print("kat_assoc:", {k: int(sum((d["g%d_lab" % g] == k).sum() if k < 0 else (d["g%d_lab" % g] >= 0).sum() for g in range(groups))) for k in (0, -1, -2)})
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "log":
+    if len(sys.argv) > 1 and sys.argv[1] == "assoc":
+        make_assoc_kats(orc.Reference())  # per-particle association decisions (added in round 2)
+    elif len(sys.argv) > 1 and sys.argv[1] == "log":
         make_log_kats(orc.Reference())  # only the logflag = 1 vectors (added in round 2)
     else:
         main()
