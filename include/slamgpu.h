@@ -171,6 +171,21 @@ int slamgpu_step_status(slamgpu_ctx *ctx, int32_t *status);
 /* Ancestor indices of the last resample (keep[], core.cpp:800-806), N_local int32. Synchronises. */
 int slamgpu_ancestors(slamgpu_ctx *ctx, int32_t *keep);
 
+/* ---- observation front end on the device ------------------------------------------------
+ * getObservations (core.cpp:185-273: visibility scan + range / bearing), addObservationNoise (:438-449) and
+ * dataAssociationKnown (:91-120) as one kernel over a device-resident landmark map and association table.
+ * slamgpu_set_map uploads the map (2 x nlm, row-major: xs then ys) and resets the table.  slamgpu_observe: xtrue = the
+ * true vehicle pose; noise: 0 none, 1 tape (r1 / r2 = host arrays of at least nlm normals, consumed one per VISIBLE
+ * landmark in visibility order, as the reference's two randn(1, len) calls are), 2 Philox(seed, observation step, landmark
+ * id).  Outputs (host, any may be NULL): z[2 nz] + vis[nz] = the raw observation, and its split zf[2 m], idf[m], zn[2 n]
+ * against the landmarks the context already holds (new ones are numbered Nf, Nf + 1, ... in visibility order).  The
+ * caller hands zf / idf / zn to slamgpu_update (the genealogy bookkeeping of the update is host-side, so the ids have to
+ * come back anyway); the kernel exists for maps where the visibility scan is the host's bottleneck (10^4 landmarks).
+ * Synchronises. */
+int slamgpu_set_map(slamgpu_ctx *ctx, const float *lm, int32_t nlm);
+int slamgpu_observe(slamgpu_ctx *ctx, const float xtrue[3], float max_range, const float R[4], int32_t noise, const float *r1,
+                    const float *r2, float *z, int32_t *vis, int32_t *nz, float *zf, int32_t *idf, int32_t *m, float *zn, int32_t *n);
+
 /* Per-particle gated nearest-neighbour data association (the reference has it for EKF-SLAM only:
  * EKFSLAM::dataAssociate, algorithms/ekfslam.cpp:151-189; applied here to every particle with its own landmark
  * estimates: P = blockdiag(0, Pf_j), so S = Hf Pf Hf^T + R).  z[2*nz] = (range, bearing) of the nz observations.

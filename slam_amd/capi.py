@@ -20,7 +20,7 @@ DECLARED_SYMBOLS = [
     "slamgpu_kernel_time", "slamgpu_algorithmic_bytes", "slamgpu_shard_update", "slamgpu_shard_block_totals", "slamgpu_shard_plan",
     "slamgpu_shard_record_floats", "slamgpu_shard_pack", "slamgpu_shard_unpack", "slamgpu_shard_finish", "slamgpu_shard_estimate",
     "slamgpu_dev_alloc", "slamgpu_dev_free", "slamgpu_dev_copy", "slamgpu_dev_copy_async", "slamgpu_shard_estimate_async",
-    "slamgpu_shard_estimate_fetch", "slamgpu_step_status", "slamgpu_kat", "slamgpu_download_range", "slamgpu_debug_stamps", "slamgpu_associate",
+    "slamgpu_shard_estimate_fetch", "slamgpu_step_status", "slamgpu_kat", "slamgpu_download_range", "slamgpu_debug_stamps", "slamgpu_associate", "slamgpu_set_map", "slamgpu_observe",
 ]
 
 
@@ -81,6 +81,8 @@ def load_library():
     L.slamgpu_step_status.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.slamgpu_kat.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     L.slamgpu_associate.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.slamgpu_set_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    L.slamgpu_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32] + [C.c_void_p] * 2 + [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32)]
     L.slamgpu_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.slamgpu_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.slamgpu_ancestors.argtypes = [C.c_void_p, C.c_void_p]
@@ -380,6 +382,24 @@ class SlamGpu:
         n = C.c_int32()
         _chk(self.L.slamgpu_shard_estimate_fetch(self.h, _ptr(out), max_count, C.byref(n)))
         return out[:n.value].copy()
+
+    def set_map(self, lm):
+        """landmark map for the device observation front end: lm [2, nlm] (xs, ys)"""
+        lm = _f32(lm)
+        self._nlm = lm.shape[1]
+        _chk(self.L.slamgpu_set_map(self.h, _ptr(lm), self._nlm))
+
+    def observe(self, xtrue, max_range, R, noise=0, r1=None, r2=None):
+        """slamgpu_observe: dict(z, vis, zf, idf, zn)"""
+        nl = self._nlm
+        z, vis = np.zeros((nl, 2), np.float32), np.zeros(nl, np.int32)
+        zf, idf, zn = np.zeros((nl, 2), np.float32), np.zeros(nl, np.int32), np.zeros((nl, 2), np.float32)
+        nz, m, n = C.c_int32(), C.c_int32(), C.c_int32()
+        a1 = None if r1 is None else _f32(np.pad(np.asarray(r1, np.float32), (0, max(0, nl - len(r1)))))
+        a2 = None if r2 is None else _f32(np.pad(np.asarray(r2, np.float32), (0, max(0, nl - len(r2)))))
+        _chk(self.L.slamgpu_observe(self.h, _ptr(_f32(xtrue, 3)), max_range, _ptr(_f32(R, 4)), noise, _ptr(a1), _ptr(a2), _ptr(z), _ptr(vis),
+                                    C.byref(nz), _ptr(zf), _ptr(idf), C.byref(m), _ptr(zn), C.byref(n)))
+        return dict(z=z[:nz.value].copy(), vis=vis[:nz.value].copy(), zf=zf[:m.value].copy(), idf=idf[:m.value].copy(), zn=zn[:n.value].copy())
 
     def associate(self, z, R, gate_reject=4.0, gate_augment=25.0, want_labels=True):
         """per-particle gated nearest-neighbour association (slamgpu_associate): labels [N, nz], consensus [nz], support [nz]"""

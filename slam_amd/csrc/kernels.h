@@ -263,6 +263,24 @@ struct ShardUnpackArgs {
     int64_t src_lo[kMaxShards + 1];  // local output index boundaries per source shard (own block: written by pack)
 };
 
+// ---- observation front end -------------------------------------------------------------
+struct ObserveOut {
+    int32_t nz, m, n, nf_after;
+};
+
+struct ObserveArgs {
+    const float *lm;       // [2][nlm] landmark map, device
+    int32_t *table;        // [nlm] dataAssociationTable: landmark -> feature index, -1 = never seen (device-resident)
+    int32_t nlm, nf;       // map size; features known before this observation
+    float x, y, phi;       // true vehicle pose
+    float max_range;
+    float sr, sb;          // sqrt(R(0,0)), sqrt(R(1,1))
+    int32_t noise;         // 0 none; 1 tape (r1 / r2: one normal per visible landmark, in visibility order); 2 Philox
+    const float *r1, *r2;  // device, tape mode
+    uint32_t k0, k1, step; // Philox key / observation step
+    ObserveOut *out;       // device: header, then z[2 nlm], vis[nlm], zf[2 nlm], idf[nlm], zn[2 nlm] (4-byte units, in this order)
+};
+
 struct KernelTable {
     // the step: [resampling stage of the previous update, inline] + [gather] + [fused predicts] + per-particle observation
     // update + in-block weight prefix / totals  (+ helper blocks: genealogy copy, Ctrl words, estimate reduction)
@@ -288,6 +306,9 @@ struct KernelTable {
     // known-answer entry point for the scalar device functions (slamgpu_kat): op 0 trigonometricOffset, 1 gaussEvaluate D=2,
     // 2 gaussEvaluate D=3, in the arithmetic this build's update kernel uses
     void (*kat)(hipStream_t, int op, const float *in_dev, int n, float *out_dev);
+    // observation front end on the device (slamgpu_observe): visibility scan + range / bearing + sensor noise + known data
+    // association, one block; results into `out` (ObserveOut header, then z[2 cap], vis[cap], zf[2 cap], idf[cap], zn[2 cap])
+    void (*observe)(hipStream_t, const ObserveArgs &);
     // per-particle gated nearest-neighbour association of nz observations against every landmark of every particle
     // (slamgpu_associate): labels [n][nz] = landmark index, kAssocNew or kAssocDiscard.  Plain set required (no pending gather).
     void (*associate)(hipStream_t, const Buffers &, int nf, const float *z_dev, int nz, const float *R4, float gate_reject,

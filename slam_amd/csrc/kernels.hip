@@ -1428,6 +1428,111 @@ __global__ void __launch_bounds__(kBlock) kat_kernel(int op, const float *__rest
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Observation front end on the device: getObservations = findVisibleLandmarks +
+// computeRangeBearing (core.cpp:185-273), addObservationNoise (:438-449), dataAssociationKnown (:91-120), restated
+// operation by operation from the reference's float / double mix (the product's host front end, host/frontend.cpp, is
+// the CPU twin and reproduces the reference's tape bit for bit).  One block: the landmark list is scanned in chunks of 256
+// with an ordered block-wide compaction (visibility order = landmark order, as upstream), then the visible ones are split
+// into re-observed (zf, idf) and new (zn) by the device-resident association table, again in order, and the new ones get
+// feature indices nf, nf + 1, ...  The bearing is atan2 evaluated in double and rounded once (glibc's atan2f, which the
+// reference calls, is within 1 ulp of that).
+// ---------------------------------------------------------------------------------------------------
+SLAM_DEV int block_exclusive_count(int flag, int *sh, int &total) {
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const unsigned long long mask = __ballot(flag);
+    const int before = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) sh[wv] = __popcll(mask);
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < kBlock / kWave; k++)
+        if (k < wv) base += sh[k];
+    total = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    __syncthreads();
+    return base + before;
+}
+
+__global__ void __launch_bounds__(kBlock) observe_kernel(ObserveArgs A) {
+    __shared__ int sh[kBlock / kWave];
+    float *z = reinterpret_cast<float *>(A.out + 1);
+    int32_t *vis = reinterpret_cast<int32_t *>(z + 2 * (size_t) A.nlm);
+    float *zf = reinterpret_cast<float *>(vis + A.nlm);
+    int32_t *idf = reinterpret_cast<int32_t *>(zf + 2 * (size_t) A.nlm);
+    float *zn = reinterpret_cast<float *>(idf + A.nlm);
+    const float cph = cosf(A.phi), sph = sinf(A.phi);
+    // pass 1: visibility + range / bearing, compacted in landmark order
+    int nz = 0;
+    for (int j0 = 0; j0 < A.nlm; j0 += kBlock) {
+        const int j = j0 + (int) threadIdx.x;
+        bool v = false;
+        float dx = 0.f, dy = 0.f;
+        if (j < A.nlm) {
+            dx = A.lm[j] - A.x;
+            dy = A.lm[(size_t) A.nlm + j] - A.y;
+            const double d2 = (double) dx * (double) dx + (double) dy * (double) dy;
+            v = (fabsf(dx) < A.max_range) && (fabsf(dy) < A.max_range) && ((dx * cph + dy * sph) > 0.0f) &&
+                (d2 < (double) A.max_range * (double) A.max_range);
+        }
+        int tot;
+        const int at = nz + block_exclusive_count(v ? 1 : 0, sh, tot);
+        if (v) {
+            const double d2 = (double) dx * (double) dx + (double) dy * (double) dy;
+            vis[at] = j;
+            z[2 * at] = (float) sqrt(d2);
+            z[2 * at + 1] = (float) atan2((double) dy, (double) dx) - A.phi;
+        }
+        nz += tot;
+    }
+    __syncthreads();
+    // sensor noise: z(0,c) += randn * sqrt(R00); z(1,c) += randn * sqrt(R11)   (core.cpp:438-449)
+    if (A.noise) {
+        for (int c = threadIdx.x; c < nz; c += kBlock) {
+            float g0, g1;
+            if (A.noise == 1) {
+                g0 = A.r1[c];
+                g1 = A.r2[c];
+            } else {
+                U4 r = philox4x32((uint32_t) vis[c], A.step, 3u, 0u, A.k0, A.k1);
+                float g2;
+                box_muller3(r, g0, g1, g2);
+            }
+            z[2 * c] = z[2 * c] + g0 * A.sr;
+            z[2 * c + 1] = z[2 * c + 1] + g1 * A.sb;
+        }
+        __syncthreads();
+    }
+    // pass 2: dataAssociationKnown: split by the table, in order; new landmarks get indices nf, nf + 1, ...
+    int m = 0, n = 0;
+    for (int c0 = 0; c0 < nz; c0 += kBlock) {
+        const int c = c0 + (int) threadIdx.x;
+        const bool in = c < nz;
+        const int lmk = in ? vis[c] : 0;
+        const int t = in ? A.table[lmk] : 0;
+        const bool is_new = in && t < 0;
+        int tot_new, tot_old;
+        const int an = n + block_exclusive_count(is_new ? 1 : 0, sh, tot_new);
+        const int ao = m + block_exclusive_count((in && !is_new) ? 1 : 0, sh, tot_old);
+        if (is_new) {
+            zn[2 * an] = z[2 * c];
+            zn[2 * an + 1] = z[2 * c + 1];
+            A.table[lmk] = A.nf + an;
+        } else if (in) {
+            zf[2 * ao] = z[2 * c];
+            zf[2 * ao + 1] = z[2 * c + 1];
+            idf[ao] = t;
+        }
+        n += tot_new;
+        m += tot_old;
+    }
+    if (threadIdx.x == 0) {
+        A.out->nz = nz;
+        A.out->m = m;
+        A.out->n = n;
+        A.out->nf_after = A.nf + n;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Per-particle gated nearest-neighbour data association.  The reference only has it for EKF-SLAM:
 // EKFSLAM::dataAssociate (algorithms/ekfslam.cpp:151-189) over ekfComputeAssociation (:131-149): for every observation z,
 // over the Nf landmarks j: v = wrap(z - h_j), S = H P H^T + R, nis = v^T S^-1 v, nd = nis + log det S;
@@ -1839,6 +1944,8 @@ static void launch_jacobians(hipStream_t st, const float *in, uint32_t n, float 
     hipLaunchKernelGGL(jacobians_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, in, n, out);
 }
 
+static void launch_observe(hipStream_t st, const ObserveArgs &A) { hipLaunchKernelGGL(observe_kernel, dim3(1), dim3(kBlock), 0, st, A); }
+
 static void launch_associate(hipStream_t st, const Buffers &B, int nf, const float *z, int nz, const float *R4, float g1, float g2,
                              int32_t *labels) {
     hipLaunchKernelGGL(associate_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B, nf, z, nz, R4[0], R4[1], R4[2], R4[3], g1, g2,
@@ -1849,7 +1956,7 @@ static void launch_kat(hipStream_t st, int op, const float *in, int n, float *ou
     hipLaunchKernelGGL(kat_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, op, in, n, out);
 }
 
-static const KernelTable kTable = {launch_update, launch_resample, launch_scan, launch_gather, launch_flatten, launch_identity, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat, launch_associate,
+static const KernelTable kTable = {launch_update, launch_resample, launch_scan, launch_gather, launch_flatten, launch_identity, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat, launch_observe, launch_associate,
                                    launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish};
 
 }  // namespace SLAM_KNS

@@ -125,6 +125,12 @@ struct slamgpu_ctx {
     std::vector<int32_t> live_rows;  // rows with refcnt > 0
     std::vector<int32_t> live_pos;   // [cap_rows] position in live_rows, -1 if not live
     int32_t *erow_dev = nullptr, *rows_dev = nullptr;  // device copies for gather / flatten / shard pack + unpack
+    // observation front end (slamgpu_set_map / slamgpu_observe)
+    float *map_dev = nullptr, *obs_r_dev = nullptr;
+    int32_t *table_dev = nullptr;
+    ObserveOut *obs_out_dev = nullptr;
+    int32_t map_n = 0, obs_nf = 0;
+    uint32_t observe_step = 0;
     int fresh_row = -1;              // row the last update opened, while nothing but the resample the next update launch
                                      // applies has touched it: records of its landmarks sit in the source slot itself
     bool tables_dirty = true;
@@ -576,6 +582,10 @@ void slamgpu_destroy(slamgpu_ctx *c) {
         if (c->ws.keep[b]) (void) hipFree(c->ws.keep[b]);
     if (c->hist_dev) (void) hipFree(c->hist_dev);
     if (c->stamps_dev) (void) hipFree(c->stamps_dev);
+    if (c->map_dev) (void) hipFree(c->map_dev);
+    if (c->obs_r_dev) (void) hipFree(c->obs_r_dev);
+    if (c->table_dev) (void) hipFree(c->table_dev);
+    if (c->obs_out_dev) (void) hipFree(c->obs_out_dev);
     if (c->erow_dev) (void) hipFree(c->erow_dev);
     if (c->live_dev) (void) hipFree(c->live_dev);
     if (c->rows_dev) (void) hipFree(c->rows_dev);
@@ -1268,6 +1278,85 @@ int slamgpu_ancestors(slamgpu_ctx *c, int32_t *keep) {
         // shard: device entries are local indices (>= 0) or -(global id + 1) for records that came from another shard
         for (int i = 0; i < c->B.n; i++) keep[i] = keep[i] >= 0 ? (int32_t) (c->cfg.first_particle + keep[i]) : -(keep[i] + 1);
     }
+    return 0;
+}
+
+int slamgpu_set_map(slamgpu_ctx *c, const float *lm, int32_t nlm) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!lm || nlm <= 0) return fail(SLAMGPU_ERR_INVALID, "empty map");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (void *p : {(void *) c->map_dev, (void *) c->obs_r_dev, (void *) c->table_dev, (void *) c->obs_out_dev})
+        if (p) (void) hipFree(p);
+    c->map_dev = c->obs_r_dev = nullptr;
+    c->table_dev = nullptr;
+    c->obs_out_dev = nullptr;
+    const size_t n = (size_t) nlm;
+    HIP_TRY(hipMalloc((void **) &c->map_dev, sizeof(float) * 2 * n));
+    HIP_TRY(hipMalloc((void **) &c->obs_r_dev, sizeof(float) * 2 * n));
+    HIP_TRY(hipMalloc((void **) &c->table_dev, sizeof(int32_t) * n));
+    HIP_TRY(hipMalloc((void **) &c->obs_out_dev, sizeof(ObserveOut) + 4 * 8 * n));  // z 2n, vis n, zf 2n, idf n, zn 2n
+    HIP_TRY(hipMemcpy(c->map_dev, lm, sizeof(float) * 2 * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemsetAsync(c->table_dev, 0xff, sizeof(int32_t) * n, c->stream));  // -1: never seen
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->map_n = nlm;
+    c->obs_nf = 0;
+    return 0;
+}
+
+int slamgpu_observe(slamgpu_ctx *c, const float xtrue[3], float max_range, const float R[4], int32_t noise, const float *r1,
+                    const float *r2, float *z, int32_t *vis, int32_t *nz, float *zf, int32_t *idf, int32_t *m, float *zn, int32_t *n) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!c->map_dev) return fail(SLAMGPU_ERR_INVALID, "no map: call slamgpu_set_map first");
+    if (!xtrue || !R || noise < 0 || noise > 2 || (noise == 1 && (!r1 || !r2))) return fail(SLAMGPU_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const size_t nl = (size_t) c->map_n;
+    if (noise == 1) {
+        HIP_TRY(hipMemcpyAsync(c->obs_r_dev, r1, sizeof(float) * nl, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->obs_r_dev + nl, r2, sizeof(float) * nl, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // pageable sources
+    }
+    ObserveArgs A{};
+    A.lm = c->map_dev;
+    A.table = c->table_dev;
+    A.nlm = c->map_n;
+    A.nf = c->obs_nf;
+    A.x = xtrue[0];
+    A.y = xtrue[1];
+    A.phi = xtrue[2];
+    A.max_range = max_range;
+    A.sr = sqrtf(R[0]);
+    A.sb = sqrtf(R[3]);
+    A.noise = noise;
+    A.r1 = c->obs_r_dev;
+    A.r2 = c->obs_r_dev + nl;
+    A.k0 = (uint32_t) c->cfg.seed;
+    A.k1 = (uint32_t) (c->cfg.seed >> 32);
+    A.step = ++c->observe_step;
+    A.out = c->obs_out_dev;
+    {
+        Timed t(c, "observe");
+        c->k->observe(c->stream, A);
+    }
+    HIP_TRY(hipGetLastError());
+    std::vector<char> host(sizeof(ObserveOut) + 4 * 8 * nl);
+    HIP_TRY(hipMemcpyAsync(host.data(), c->obs_out_dev, host.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const ObserveOut *o = reinterpret_cast<const ObserveOut *>(host.data());
+    const float *hz = reinterpret_cast<const float *>(o + 1);
+    const int32_t *hvis = reinterpret_cast<const int32_t *>(hz + 2 * nl);
+    const float *hzf = reinterpret_cast<const float *>(hvis + nl);
+    const int32_t *hidf = reinterpret_cast<const int32_t *>(hzf + 2 * nl);
+    const float *hzn = reinterpret_cast<const float *>(hidf + nl);
+    if (z) memcpy(z, hz, sizeof(float) * 2 * (size_t) o->nz);
+    if (vis) memcpy(vis, hvis, sizeof(int32_t) * (size_t) o->nz);
+    if (zf) memcpy(zf, hzf, sizeof(float) * 2 * (size_t) o->m);
+    if (idf) memcpy(idf, hidf, sizeof(int32_t) * (size_t) o->m);
+    if (zn) memcpy(zn, hzn, sizeof(float) * 2 * (size_t) o->n);
+    if (nz) *nz = o->nz;
+    if (m) *m = o->m;
+    if (n) *n = o->n;
+    c->obs_nf = o->nf_after;
     return 0;
 }
 

@@ -152,6 +152,14 @@ class HostSim:
         self.L.slamhost_sim_observe(self.h, nf_known, _p(self._zf), _p(self._idf), C.byref(m), _p(self._zn), C.byref(n))
         return self._zf[:m.value].copy(), self._idf[:m.value].copy(), self._zn[:n.value].copy()
 
+    def last_z(self):
+        """raw observation of the last observe(): z [nz, 2] (range, bearing), visible landmark ids [nz]"""
+        z = np.zeros((self.nlm, 2), np.float32)
+        vis = np.zeros(self.nlm, np.int32)
+        nz = C.c_int32()
+        self.L.slamhost_sim_last_z(self.h, _p(z), _p(vis), C.byref(nz))
+        return z[:nz.value].copy(), vis[:nz.value].copy()
+
     def true_pose(self):
         x = np.zeros(3, np.float32)
         self.L.slamhost_sim_true(self.h, _p(x))
