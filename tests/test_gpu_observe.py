@@ -54,8 +54,9 @@ def test_device_front_end_matches_the_host_front_end(sg, tmp_path, mapname, extr
             got = s.observe(h.true_pose(), float(h.conf.MAX_RANGE), R, noise=0)
             assert np.array_equal(got["vis"], vis), k
             assert np.array_equal(got["z"][:, 0].view(np.uint32), z[:, 0].view(np.uint32)), k      # ranges: same bits
-            ulp = np.abs(got["z"][:, 1].astype(np.float64) - z[:, 1]) / np.maximum(np.spacing(np.abs(z[:, 1]).astype(f32)), 1e-45)
-            worst_ulp = max(worst_ulp, float(ulp.max()) if ulp.size else 0.0)
+            # bearing = atan2 - phi: one ulp of the atan2 (|atan2| <= pi: 2.4e-7) survives the subtraction unchanged
+            dif = np.abs(got["z"][:, 1].astype(np.float64) - z[:, 1]) / 2.384185791015625e-07
+            worst_ulp = max(worst_ulp, float(dif.max()) if dif.size else 0.0)
             assert np.array_equal(got["idf"], idf), k
             assert got["zf"].shape == zf.shape and got["zn"].shape == zn.shape, k
             np.testing.assert_allclose(got["zf"], zf, rtol=0, atol=1e-6)
@@ -64,7 +65,7 @@ def test_device_front_end_matches_the_host_front_end(sg, tmp_path, mapname, extr
             seen_new += zn.shape[0]
             seen_old += zf.shape[0]
             k += 1
-    assert worst_ulp <= 1.0, worst_ulp
+    assert worst_ulp <= 1.0 + 1e-9, worst_ulp
     assert seen_new >= 3 and seen_old >= 50
     s.close()
     h.close()
