@@ -263,6 +263,40 @@ int slamgpu_shard_estimate(slamgpu_ctx *ctx, double out[4]);
  * history and fetched together (one synchronisation + one all-gather for many steps) */
 int slamgpu_shard_estimate_async(slamgpu_ctx *ctx);
 int slamgpu_shard_estimate_fetch(slamgpu_ctx *ctx, double *raw4, int32_t max_count, int32_t *count);
+/* ---- distributed operation (the multi-GPU path: nothing migrates) ---------------------------------------------------
+ * One context per GPU; shard g holds the contiguous global particles [g*n, (g+1)*n), n a multiple of 256; contexts may
+ * live in one process (peer access) or one process per GPU (hipIpc).  Every context maps every other shard's state arrays
+ * (slamgpu_dist_export / slamgpu_dist_connect); from then on a filter step is
+ *
+ *     slamgpu_dist_step   ONE kernel launch per shard: the queued predicts, the resampling stage of the PREVIOUS step
+ *                         (every shard scans the same all-gathered block totals: identical Neff, decision and ancestors
+ *                         everywhere, independent of the number of shards) and the per-particle update.  A particle
+ *                         whose ancestor lives on another GPU reads that ancestor's pose and genealogy in place over xGMI;
+ *                         genealogy entries are global slot ids, so landmark records stay on the GPU that wrote them until
+ *                         the landmark is observed again.  No pack / send / unpack, no host synchronisation.
+ *     ALL-GATHER          of this step's block totals (slamgpu_dist_totals: 8 or 12 B per 256 particles per shard), by the
+ *                         caller, stream-ordered on the context's stream (RCCL through torch.distributed or ncclAllGather;
+ *                         device copies for contexts of one process).  It is also the only barrier the scheme needs: a
+ *                         shard's next launch starts after every shard's current launch has finished.
+ *
+ * The pose estimate of a step is this shard's raw partial (slamgpu_shard_estimate_fetch: sum x, sum y, heading and weight
+ * of the local maximum); combine across shards in shard order.  slamgpu_dist_settle (collective: every shard, followed by
+ * the all-gather) applies the pending resampling stage so that slamgpu_download* can read the set. */
+int slamgpu_dist_export_size(void);
+int slamgpu_dist_export(slamgpu_ctx *ctx, void *blob);
+int slamgpu_dist_connect(slamgpu_ctx *ctx, int32_t n_shards, int32_t shard, const void *blobs);
+int slamgpu_dist_step(slamgpu_ctx *ctx, const float *controls, int32_t n_controls, const float Q[4], float dt, const float *zf,
+                      const int32_t *idf, int32_t m, const float *zn, int32_t n, const float R[4], int32_t record_estimate);
+/* buffers of the all-gather that follows the last slamgpu_dist_step / _settle: this shard's totals (floats_per_shard
+ * floats) go to slot `shard` of every context's `gathered` (n_shards * floats_per_shard floats) */
+int slamgpu_dist_totals(slamgpu_ctx *ctx, const float **local_dev, float **gathered_dev, int32_t *floats_per_shard);
+int slamgpu_dist_settle(slamgpu_ctx *ctx);
+/* the recorded steps of this shard (settled): raw partial of the estimate (sum x, sum y, heading and weight of the local
+ * maximum-weight particle; combine in shard order, strict > on the weight) and the stage's Neff / resampled / status,
+ * which are identical on every shard */
+int slamgpu_dist_history_fetch(slamgpu_ctx *ctx, double *raw4, float *neff, int32_t *resampled, int32_t *status, int32_t max_count,
+                               int32_t *count);
+
 /* Plain device-memory helpers for callers that have no allocator of their own (tests, the C++ host): buffers
  * for the gathered block totals and the send / receive records.  copy is device-to-device, ordered on the
  * context's stream and synchronised before returning. */

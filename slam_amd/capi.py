@@ -21,6 +21,8 @@ DECLARED_SYMBOLS = [
     "slamgpu_shard_record_floats", "slamgpu_shard_pack", "slamgpu_shard_unpack", "slamgpu_shard_finish", "slamgpu_shard_estimate",
     "slamgpu_dev_alloc", "slamgpu_dev_free", "slamgpu_dev_copy", "slamgpu_dev_copy_async", "slamgpu_shard_estimate_async",
     "slamgpu_shard_estimate_fetch", "slamgpu_step_status", "slamgpu_kat", "slamgpu_download_range", "slamgpu_debug_stamps", "slamgpu_associate", "slamgpu_set_map", "slamgpu_observe",
+    "slamgpu_dist_export_size", "slamgpu_dist_export", "slamgpu_dist_connect", "slamgpu_dist_step", "slamgpu_dist_totals", "slamgpu_dist_settle",
+    "slamgpu_dist_history_fetch",
 ]
 
 
@@ -114,6 +116,14 @@ def load_library():
     L.slamgpu_dev_copy_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
     L.slamgpu_shard_estimate_async.argtypes = [C.c_void_p]
     L.slamgpu_shard_estimate_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.slamgpu_dist_export_size.argtypes = []
+    L.slamgpu_dist_export.argtypes = [C.c_void_p, C.c_void_p]
+    L.slamgpu_dist_connect.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    L.slamgpu_dist_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int32,
+                                    C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+    L.slamgpu_dist_totals.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
+    L.slamgpu_dist_settle.argtypes = [C.c_void_p]
+    L.slamgpu_dist_history_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     _lib = L
     return L
 
@@ -373,6 +383,54 @@ class SlamGpu:
             _chk(self.L.slamgpu_dev_copy(self.h, dst, src, nbytes))
         else:
             _chk(self.L.slamgpu_dev_copy_async(self.h, dst, src, nbytes))
+
+    # ---- distributed operation (include/slamgpu.h: slamgpu_dist_*) ----
+    def dist_export(self):
+        blob = C.create_string_buffer(self.L.slamgpu_dist_export_size())
+        _chk(self.L.slamgpu_dist_export(self.h, blob))
+        return blob.raw
+
+    def dist_connect(self, n_shards, shard, blobs):
+        raw = b"".join(blobs)
+        assert len(raw) == n_shards * self.L.slamgpu_dist_export_size()
+        _chk(self.L.slamgpu_dist_connect(self.h, n_shards, shard, raw))
+
+    def prepare_dist_step(self, controls, Q, dt, zf, idf, zn, R, record_estimate=True):
+        ctl = _f32(controls).reshape(-1, 3)
+        Q = _f32(Q, 4)
+        zf = _f32(zf).reshape(-1, 2)
+        zn = _f32(zn).reshape(-1, 2)
+        idf = np.ascontiguousarray(idf, np.int32)
+        R = _f32(R, 4)
+        keep = (ctl, Q, zf, zn, idf, R)
+        args = (self.h, _ptr(ctl), ctl.shape[0], _ptr(Q), C.c_float(dt), _ptr(zf), _ptr(idf), zf.shape[0], _ptr(zn), zn.shape[0],
+                _ptr(R), 1 if record_estimate else 0)
+        fn = self.L.slamgpu_dist_step
+
+        def call(_keep=keep):
+            _chk(fn(*args))
+        return call
+
+    def dist_step(self, controls, Q, dt, zf, idf, zn, R, record_estimate=True):
+        self.prepare_dist_step(controls, Q, dt, zf, idf, zn, R, record_estimate)()
+
+    def dist_totals(self):
+        """(this shard's totals, the gathered table, floats per shard) for the all-gather after the last dist step"""
+        a, b, n = C.c_void_p(), C.c_void_p(), C.c_int32()
+        _chk(self.L.slamgpu_dist_totals(self.h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
+    def dist_settle(self):
+        _chk(self.L.slamgpu_dist_settle(self.h))
+
+    def shard_estimate_fetch_full(self, max_count=4096):
+        raw = np.zeros((max_count, 4), np.float64)
+        neff = np.zeros(max_count, np.float32)
+        res = np.zeros(max_count, np.int32)
+        st = np.zeros(max_count, np.int32)
+        n = C.c_int32()
+        _chk(self.L.slamgpu_dist_history_fetch(self.h, _ptr(raw), _ptr(neff), _ptr(res), _ptr(st), max_count, C.byref(n)))
+        return raw[:n.value].copy(), neff[:n.value].copy(), res[:n.value].copy(), st[:n.value].copy()
 
     def shard_estimate_async(self):
         _chk(self.L.slamgpu_shard_estimate_async(self.h))

@@ -72,6 +72,21 @@ struct Ctrl {
     double est[4];        // sum x, sum y, heading of max-w particle, max w
 };
 
+// Distributed operation (one context per GPU, particles sharded in contiguous blocks): the state arrays of every shard as
+// mapped into THIS process (own allocations, peer-enabled pointers of contexts in the same process, or hipIpc mappings of
+// other processes' contexts).  Nothing is ever migrated: a resampled particle reads its ancestor's pose and genealogy
+// straight out of the owning GPU's memory over xGMI, genealogy entries are GLOBAL slot ids (shard * n + local slot), and
+// landmark records stay where they were written until the landmark is observed again.
+struct PeerPtrs {
+    float4 *poseA[2];
+    float4 *poseB[2];
+    float2 *poseC[2];
+    float4 *lmkA[2];
+    float *lmkB[2];
+    int32_t *gen[2];
+    float *lcum[2];
+};
+
 struct Buffers {
     float4 *poseA[2];
     float4 *poseB[2];
@@ -99,6 +114,14 @@ struct Buffers {
                               // (the association is global, so the host knows: a re-observed row flips, a flatten /
                               // settle flips all), refreshed for flatten / shard pack + unpack; the update kernel gets
                               // the flags of the landmarks it touches with the observation packet (bit 30 of row[k])
+    // distributed contexts (slamgpu_dist_*): n_shards > 1 shards of n = ncap particles each; this one is `shard`, its slot 0
+    // is global particle `first`.  Single contexts: n_shards = 1, first = 0 (global ids == local slots).
+    const PeerPtrs *peers;    // [n_shards] device table (entry `shard` = this context's own arrays)
+    const float *gtot[2];     // all-gathered block totals by step parity, shard-major [n_shards][rows][nblocks]
+    int32_t n_shards, shard;
+    int32_t first;
+    uint32_t pad_dist;
+    unsigned long long div_n; // floor(2^64 / ncap) + 1: global slot -> shard by one 64-bit multiply-high
     Ctrl *ctrl;
     int32_t n;        // local particles
     int32_t ncap;     // row stride (>= n, multiple of 256)
@@ -186,7 +209,8 @@ struct UpdateArgs {
     // Inline planning: the resampling stage of the PREVIOUS update (Neff, decision, ancestors, pose-estimate partials)
     // has not run as a launch of its own; every block of this launch redoes its scan and every thread finds its own
     // ancestor, so a step is ONE launch.  0: that stage already ran (resample_kernel), honour Ctrl.pend / keep[].
-    int32_t arrivals;        // shard context: particles may have arrived from other shards (keep[i] < 0, pool records)
+    int32_t arrivals;        // 1: legacy shard context: particles may have arrived from other shards (keep[i] < 0, pool records)
+                             // 2: distributed context (Buffers::peers): ancestors, genealogy and records may live on another GPU
     int32_t plan_inline;
     int32_t scan_global;     // the prefix of the previous step's block totals is in WeightScratch::scan (scan_kernel ran)
     int32_t do_resample, n_effective;  // SWITCH_RESAMPLE, NEFFECTIVE (for the inline plan)

@@ -403,7 +403,7 @@ SLAM_DEV float stratum_prev(const RngArgs &rng, int64_t gid) {
 // exp(M_b - M) like the block totals (scan_block_totals).  Linear weights: factor 1.0, same bits as without it.
 SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const float *__restrict__ lcum_local,
                                int first_block, int nb_local, int64_t n_global, const float *__restrict__ blk_m = nullptr,
-                               double M = 0.0, const float *piv_lds = nullptr) {
+                               double M = 0.0, const float *piv_lds = nullptr, const PeerPtrs *peers = nullptr, int par = 0) {
     int b0 = 0, b1 = nb;
     while (b0 < b1) {
         const int mid = (b0 + b1) >> 1;
@@ -414,7 +414,8 @@ SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const f
     const int lb = min(max(b0 - first_block, 0), nb_local - 1);
     const double o = off[b0];
     const double sc = blk_m ? block_scale(blk_m[b0], M) : 1.0;
-    const float *lc = lcum_local + (size_t) lb * kBlock;
+    // (distributed contexts: the in-block prefix of a block of another shard is read out of that GPU's memory)
+    const float *lc = peers ? peers[b0 / nb_local].lcum[par] + (size_t) (b0 % nb_local) * kBlock : lcum_local + (size_t) lb * kBlock;
     // first slot with o + lc > target; the last slot if rounding hides it.  The prefix is non-decreasing, so instead of
     // 8 dependent probes: 16 pivots in flight together (every 16th entry), then the 16 entries of the pivot's segment
     // (piv_lds: the pivots of every block were prefetched into LDS at kernel entry: one global round trip less)
@@ -461,10 +462,15 @@ SLAM_DEV void copy_genealogy(const Buffers &B, const int32_t *__restrict__ rows,
     const int k = bx * kBlock + threadIdx.x;
     if (k >= B.n) return;
     const size_t S = (size_t) B.ncap;
-    const int anc = anc_of(k);
-    if (anc < 0) return;  // sharded runs: arrived from another shard, genealogy already in place
+    int anc = anc_of(k);
+    if (anc < 0) return;  // legacy shards: arrived from another shard, genealogy already in place
     const int32_t *__restrict__ src = cur ? B.gen[1] : B.gen[0];
     int32_t *__restrict__ dst = cur ? B.gen[0] : B.gen[1];
+    if (B.n_shards > 1) {  // distributed context: anc is a global index; the ancestor's rows may live on another GPU
+        const int h = (int) __umul64hi((unsigned long long) (unsigned) anc, B.div_n);
+        anc -= h * B.ncap;
+        if (h != B.shard) src = B.peers[h].gen[cur];
+    }
     const int r0 = by * per_role, r1 = min(n_rows, r0 + per_role);
     // sixteen rows per trip, all loads in flight before the first store: a role is a chain of dependent round trips, and
     // with ~1 000 live rows (config 5) the copy roles are a quarter of the launch's work
@@ -514,9 +520,13 @@ __host__ __device__ inline int staging_slots(int method, bool big, int m) {
     return m <= kStage / 2 ? kStage / 2 : kStage;
 }
 
-template <int METHOD, bool ARR, bool BIG>
+// MODE 0: single context.  MODE 1 (ARR): legacy shard context (arrival pool).  MODE 2 (DIST): distributed context: the
+// particle set spans several GPUs whose state arrays are all mapped here (Buffers::peers); the plan runs over the
+// all-gathered block totals of every shard, and whatever an ancestor owns on another GPU is read in place.
+template <int METHOD, int MODE, bool BIG>
 __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs PA, UpdateArgs U, RngArgs rng,
                                                          WeightScratch ws) {
+    constexpr bool ARR = MODE == 1, DIST = MODE == 2;
     __shared__ float sh_w[kBlock / kWave], sh_w2[kBlock / kWave];
     // landmarks re-observed this step, staged between the proposal pass and the likelihood/feature-update pass
     // (each thread only touches its own column: no barrier, no bank conflict: consecutive lanes, consecutive slots)
@@ -531,8 +541,9 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     double *const off = reinterpret_cast<double *>(dyn_lds + (size_t) nslots * kBlock * (sizeof(float4) + sizeof(float)));
     // ... then, inline plan of a context of at most kPivLdsBlocks blocks: [16 * nblocks] floats, the pivot table of the
     // previous step's in-block prefixes (WeightScratch::piv), requested at kernel entry together with the block totals
-    const bool piv_in_lds = U.plan_inline && !U.scan_global && ws.nblocks <= kPivLdsBlocks;
-    float *const pivs = reinterpret_cast<float *>(off + (((size_t) ws.nblocks + 3) & ~(size_t) 1));  // 16-byte aligned
+    const int nbg = DIST ? ws.nblocks * B.n_shards : ws.nblocks;  // blocks of the whole particle set
+    const bool piv_in_lds = !DIST && U.plan_inline && !U.scan_global && ws.nblocks <= kPivLdsBlocks;
+    float *const pivs = reinterpret_cast<float *>(off + (((size_t) nbg + 3) & ~(size_t) 1));  // 16-byte aligned
     constexpr int kPivPerThread = kPivLdsBlocks * 16 / 4 / kBlock;  // float4 per thread at the largest table
     float4 pvreg[kPivPerThread];
     auto request_pivots = [&]() {
@@ -573,7 +584,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             Q = offp[nb + 2];
             Mx = offp[nb + 3];
         } else {
-            scan_block_totals(ws.blk_w[ws.wpar ^ 1], nb, nb, logw, off, sh_a, sh_q, W, Q, Mx, request_pivots);
+            scan_block_totals(DIST ? B.gtot[ws.wpar ^ 1] : ws.blk_w[ws.wpar ^ 1], nbg, nb, logw, off, sh_a, sh_q, W, Q, Mx, request_pivots);
         }
         const float neff = neff_of(W, Q);  // Neff = 1 / sum((w/W)^2)  (core.cpp:784-788)
         pend = U.do_resample && (neff < (float) U.n_effective);
@@ -598,8 +609,13 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     }
     SLAM_STAMP(2);  // block totals scanned: W, Neff, decision known
     const int out = pend ? cur ^ 1 : cur;
+    // (DIST: the GLOBAL index of the ancestor of local particle k; global particle ids key the strata)
     auto ancestor = [&](int k) -> int {
         if (!U.plan_inline) return ws.keep[B.slot][k];
+        if (DIST) {
+            const double target = (double) stratum_prev(rng, (int64_t) B.first + k) * W;
+            return (int) find_ancestor(target, offp, nbg, nullptr, 0, nb, rng.n_global, nullptr, 0.0, nullptr, B.peers, ws.wpar ^ 1);
+        }
         const double target = (double) stratum_prev(rng, (int64_t) k) * W;
         return (int) min(find_ancestor(target, offp, nb, ws.lcum[ws.wpar ^ 1], 0, nb, (int64_t) B.n,
                                        logw ? ws.blk_w[ws.wpar ^ 1] + 2 * nb : nullptr, Mx, piv_in_lds ? pivs : nullptr),
@@ -617,7 +633,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                     W = offp[nb + 1];
                     Q = offp[nb + 2];
                 } else {
-                    scan_block_totals(ws.blk_w[ws.wpar ^ 1], nb, nb, logw, off, sh_a, sh_q, W, Q, Mx);
+                    scan_block_totals(DIST ? B.gtot[ws.wpar ^ 1] : ws.blk_w[ws.wpar ^ 1], nbg, nb, logw, off, sh_a, sh_q, W, Q, Mx);
                 }
                 pend = U.do_resample && (neff_of(W, Q) < (float) U.n_effective);
             }
@@ -654,10 +670,22 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             si = i;
             sb = out;
         }
-        const float4 *__restrict__ poseA = sb ? B.poseA[1] : B.poseA[0];
-        const float4 *__restrict__ poseB = sb ? B.poseB[1] : B.poseB[0];
-        const float2 *__restrict__ poseC = sb ? B.poseC[1] : B.poseC[0];
-        const int32_t *__restrict__ genS = sb ? B.gen[1] : B.gen[0];
+        // DIST: `si` is a global index when a resample is applied: which shard owns it, and where
+        int gsrc = B.first + i;          // global id of the source slot
+        bool src_local = true;
+        const PeerPtrs *rp = B.peers;    // the owning shard's arrays (only read when the source is remote; read from the
+                                         // table in place: a private copy indexed by `sb` would live in scratch)
+        if (DIST && pend) {
+            gsrc = si;
+            const int h = (int) __umul64hi((unsigned long long) (unsigned) si, B.div_n);
+            si -= h * B.ncap;
+            src_local = h == B.shard;
+            rp = B.peers + h;
+        }
+        const float4 *__restrict__ poseA = (DIST && !src_local) ? rp->poseA[sb] : (sb ? B.poseA[1] : B.poseA[0]);
+        const float4 *__restrict__ poseB = (DIST && !src_local) ? rp->poseB[sb] : (sb ? B.poseB[1] : B.poseB[0]);
+        const float2 *__restrict__ poseC = (DIST && !src_local) ? rp->poseC[sb] : (sb ? B.poseC[1] : B.poseC[0]);
+        const int32_t *__restrict__ genS = (DIST && !src_local) ? rp->gen[sb] : (sb ? B.gen[1] : B.gen[0]);
         int32_t *__restrict__ genO = out ? B.gen[1] : B.gen[0];
         struct Rec {
             float4 a;
@@ -668,9 +696,20 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             // kPoolBit set: a record that arrived from another shard lives in the arrival pool (kernels.h: Buffers::poolA).
             // Address select, not a branch: the staging arrays these references point into must stay in registers.
             const bool pool = ARR && s < 0;
-            const size_t at = pool ? (size_t) j * B.pool_cap + (size_t) (s & ~kPoolBit) : (size_t) j * S + (size_t) s;
+            size_t at = pool ? (size_t) j * B.pool_cap + (size_t) (s & ~kPoolBit) : (size_t) j * S + (size_t) s;
             const float4 *pA = pool ? B.poolA : (b ? B.lmkA[1] : B.lmkA[0]);
             const float *pB = pool ? B.poolB : (b ? B.lmkB[1] : B.lmkB[0]);
+            if (DIST) {  // s is a global slot id: almost always one of this shard's
+                const int ls = s - B.first;
+                if (ls >= 0 && ls < B.ncap) {
+                    at = (size_t) j * S + (size_t) ls;
+                } else {
+                    const int h = (int) __umul64hi((unsigned long long) (unsigned) s, B.div_n);
+                    at = (size_t) j * S + (size_t) (s - h * B.ncap);
+                    pA = B.peers[h].lmkA[b];
+                    pB = B.peers[h].lmkB[b];
+                }
+            }
             return Rec{pA[at], pB[at]};  // by value: a reference into the staging arrays would pin them to scratch
         };
         auto load_lmk = [&](int j, int s, int b, float4 &la, float &lb) {
@@ -705,8 +744,9 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         // gen), the buffer from the row's live flag; a landmark this update writes goes to the particle's OWN slot of the
         // row's other buffer and into the genealogy row this update opens (U.e_new: identity)
         // (compact contexts = small packets: rows interleaved four to a chunk, kernels.h: Buffers::gen)
+        // (DIST: genealogy entries and the values returned here are GLOBAL slot ids)
         auto slot_of = [&](int k) -> int {
-            return (lrow[k] & kRowFreshBit) ? si : genS[gen_index(!BIG, S, lrow[k] & kRowMask, (size_t) si)];
+            return (lrow[k] & kRowFreshBit) ? (DIST ? gsrc : si) : genS[gen_index(!BIG, S, lrow[k] & kRowMask, (size_t) si)];
         };
         auto buf_of = [&](int k) -> int { return (lrow[k] >> 30) & 1; };
         const float r00 = U.R[0], r01 = U.R[1], r10 = U.R[2], r11 = U.R[3];
@@ -798,7 +838,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         const bool early_records = !BIG && METHOD == 2 && m > 0 && U.all_fresh;
         if (!BIG) {
 #pragma unroll
-            for (int k = 0; k < kStage; k++) ts[k] = U.all_fresh ? si : slot_of(min(k, max(m - 1, 0)));
+            for (int k = 0; k < kStage; k++) ts[k] = U.all_fresh ? (DIST ? gsrc : si) : slot_of(min(k, max(m - 1, 0)));
             if (early_records) {  // fresh landmarks: the record sits in the source slot: requested with the pose
                 if (m <= kStage / 2) issue_records(std::integral_constant<int, kStage / 2>{}, ts);
                 else issue_records(std::integral_constant<int, kStage>{}, ts);
@@ -1112,16 +1152,16 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 if (c < nchunks) {
                     int4 q = gq[c];
                     if (c == (U.e_new >> 2)) {  // (e_new = -1: never)
-                        const int comp = U.e_new & 3;
-                        if (comp == 0) q.x = i;
-                        else if (comp == 1) q.y = i;
-                        else if (comp == 2) q.z = i;
-                        else q.w = i;
+                        const int comp = U.e_new & 3, own = B.first + i;
+                        if (comp == 0) q.x = own;
+                        else if (comp == 1) q.y = own;
+                        else if (comp == 2) q.z = own;
+                        else q.w = own;
                     }
                     o4[(size_t) c * S + i] = q;
                 }
         } else if (U.e_new >= 0) {
-            genO[gen_index(!BIG, S, U.e_new, (size_t) i)] = i;
+            genO[gen_index(!BIG, S, U.e_new, (size_t) i)] = B.first + i;
         }
         poseAo[i] = make_float4(x, y, th, w);
         if (METHOD == 2 && pose_dirty) {
@@ -1303,6 +1343,9 @@ __global__ void __launch_bounds__(kBlock) gather_kernel(Buffers B, WeightScratch
     }
 }
 
+SLAM_DEV void read_through_genealogy(const Buffers &B, const int32_t *__restrict__ live, int cur, size_t S, int l, int anc,
+                                     float4 &la, float &lb);
+
 // Flatten the genealogy: every landmark record into its particle's own slot of the row's other buffer, genealogy row 0
 // = identity (the host points every landmark at row 0 afterwards and flips every landmark row's live flag in its
 // table).  Requires a plain set (no pending gather), B.erow and B.lmk_live.  Used by download
@@ -1319,7 +1362,13 @@ __global__ void __launch_bounds__(kBlock) flatten_kernel(Buffers B, int nf) {
     for (int j = j0; j < j1; j++) {
         const int sl = gen[gen_index(B.compact, S, B.erow[j], (size_t) k)];
         const int b = live[j];
-        if (sl < 0) {  // arrival pool
+        if (B.n_shards > 1) {  // distributed context: global slot ids
+            float4 la;
+            float lb;
+            read_through_genealogy(B, live, cur, S, j, k, la, lb);
+            B.lmkA[b ^ 1][(size_t) j * S + k] = la;
+            B.lmkB[b ^ 1][(size_t) j * S + k] = lb;
+        } else if (sl < 0) {  // arrival pool
             const size_t at = (size_t) j * B.pool_cap + (sl & ~kPoolBit);
             B.lmkA[b ^ 1][(size_t) j * S + k] = B.poolA[at];
             B.lmkB[b ^ 1][(size_t) j * S + k] = B.poolB[at];
@@ -1653,7 +1702,15 @@ __global__ void __launch_bounds__(kBlock) shard_plan_kernel(ShardPlanArgs A, Rng
 // arrival pool
 SLAM_DEV void read_through_genealogy(const Buffers &B, const int32_t *__restrict__ live, int cur, size_t S, int l, int anc,
                                      float4 &la, float &lb) {
-    const int sl = B.gen[cur][gen_index(B.compact, S, B.erow[l], (size_t) anc)];
+    int sl = B.gen[cur][gen_index(B.compact, S, B.erow[l], (size_t) anc)];
+    if (B.n_shards > 1) {  // distributed context: global slot id, possibly another GPU's record
+        const int h = (int) __umul64hi((unsigned long long) (unsigned) sl, B.div_n);
+        const int b = live[l];
+        const size_t at = (size_t) l * S + (size_t) (sl - h * B.ncap);
+        la = (h == B.shard ? B.lmkA[b] : B.peers[h].lmkA[b])[at];
+        lb = (h == B.shard ? B.lmkB[b] : B.peers[h].lmkB[b])[at];
+        return;
+    }
     if (sl < 0) {
         const size_t at = (size_t) l * B.pool_cap + (sl & ~kPoolBit);
         la = B.poolA[at];
@@ -1876,20 +1933,25 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
     int grid = B.ncap / kBlock;
     if (U.lazy) grid += (U.copy_hi - U.copy_lo) + 1;
     // inline plan only: prefix of the previous step's block totals (launches that do not plan never touch off[])
+    const size_t nbg = (size_t) ws.nblocks * (U.arrivals == 2 ? (size_t) B.n_shards : 1);  // distributed: blocks of all shards
     const size_t lds = (size_t) staging_slots(U.method, U.big != nullptr, U.m) * kBlock * (sizeof(float4) + sizeof(float)) +
-                       ((U.plan_inline && !U.scan_global) ? sizeof(double) * (((size_t) ws.nblocks + 3) & ~(size_t) 1) : 0) +
-                       ((U.plan_inline && !U.scan_global && ws.nblocks <= kPivLdsBlocks) ? sizeof(float) * 16 * (size_t) ws.nblocks : 0);
-    const int sel = (U.method == 2 ? 4 : 0) | (U.arrivals ? 2 : 0) | (U.big ? 1 : 0);
+                       ((U.plan_inline && !U.scan_global) ? sizeof(double) * ((nbg + 3) & ~(size_t) 1) : 0) +
+                       ((U.arrivals != 2 && U.plan_inline && !U.scan_global && ws.nblocks <= kPivLdsBlocks) ? sizeof(float) * 16 * (size_t) ws.nblocks : 0);
+    const int sel = (U.method == 2 ? 6 : 0) + 2 * U.arrivals + (U.big ? 1 : 0);
 #define SLAM_LAUNCH_UPDATE(M, A, G) hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, B, PA, U, rng, ws)
     switch (sel) {
-        case 7: SLAM_LAUNCH_UPDATE(2, true, true); break;
-        case 6: SLAM_LAUNCH_UPDATE(2, true, false); break;
-        case 5: SLAM_LAUNCH_UPDATE(2, false, true); break;
-        case 4: SLAM_LAUNCH_UPDATE(2, false, false); break;
-        case 3: SLAM_LAUNCH_UPDATE(1, true, true); break;
-        case 2: SLAM_LAUNCH_UPDATE(1, true, false); break;
-        case 1: SLAM_LAUNCH_UPDATE(1, false, true); break;
-        default: SLAM_LAUNCH_UPDATE(1, false, false); break;
+        case 11: SLAM_LAUNCH_UPDATE(2, 2, true); break;
+        case 10: SLAM_LAUNCH_UPDATE(2, 2, false); break;
+        case 9: SLAM_LAUNCH_UPDATE(2, 1, true); break;
+        case 8: SLAM_LAUNCH_UPDATE(2, 1, false); break;
+        case 7: SLAM_LAUNCH_UPDATE(2, 0, true); break;
+        case 6: SLAM_LAUNCH_UPDATE(2, 0, false); break;
+        case 5: SLAM_LAUNCH_UPDATE(1, 2, true); break;
+        case 4: SLAM_LAUNCH_UPDATE(1, 2, false); break;
+        case 3: SLAM_LAUNCH_UPDATE(1, 1, true); break;
+        case 2: SLAM_LAUNCH_UPDATE(1, 1, false); break;
+        case 1: SLAM_LAUNCH_UPDATE(1, 0, true); break;
+        default: SLAM_LAUNCH_UPDATE(1, 0, false); break;
     }
 #undef SLAM_LAUNCH_UPDATE
 }
@@ -1910,13 +1972,13 @@ static void launch_gather(hipStream_t st, const Buffers &B, const WeightScratch 
 }
 
 // identity ("own slot") in one genealogy row (upload, flatten)
-__global__ void __launch_bounds__(kBlock) identity_kernel(int32_t *gen, int compact, int row, int ncap) {
+__global__ void __launch_bounds__(kBlock) identity_kernel(int32_t *gen, int compact, int row, int ncap, int first) {
     const int k = blockIdx.x * kBlock + threadIdx.x;
-    if (k < ncap) gen[gen_index(compact, (size_t) ncap, row, (size_t) k)] = k;
+    if (k < ncap) gen[gen_index(compact, (size_t) ncap, row, (size_t) k)] = first + k;  // (distributed: global slot ids)
 }
 
 static void launch_identity(hipStream_t st, const Buffers &B, int which, int row) {
-    hipLaunchKernelGGL(identity_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B.gen[which], B.compact, row, B.ncap);
+    hipLaunchKernelGGL(identity_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B.gen[which], B.compact, row, B.ncap, B.first);
 }
 
 static void launch_flatten(hipStream_t st, const Buffers &B, int nf) {

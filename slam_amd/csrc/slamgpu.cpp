@@ -4,6 +4,7 @@
 #include "../../include/slamgpu.h"
 
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -63,6 +64,7 @@ struct slamgpu_ctx {
     WeightScratch ws{};
     int nf = 0;
     uint32_t obs_step = 0, ctl_step = 0;
+    uint32_t rng_skew = 0;  // update launches that were not filter steps (slamgpu_dist_settle): they draw nothing
     // big-packet ring (observation packets that do not fit the kernel-argument form)
     size_t pkt_bytes = 0;
     char *pkt_host = nullptr;  // pinned [kRing][pkt_bytes]
@@ -125,6 +127,11 @@ struct slamgpu_ctx {
     std::vector<int32_t> live_rows;  // rows with refcnt > 0
     std::vector<int32_t> live_pos;   // [cap_rows] position in live_rows, -1 if not live
     int32_t *erow_dev = nullptr, *rows_dev = nullptr;  // device copies for gather / flatten / shard pack + unpack
+    // distributed operation (slamgpu_dist_*)
+    bool dist = false, dist_clean = false;
+    PeerPtrs *peers_dev = nullptr;
+    float *gtot_dev[2] = {nullptr, nullptr};
+    std::vector<void *> ipc_opened;
     // observation front end (slamgpu_set_map / slamgpu_observe)
     float *map_dev = nullptr, *obs_r_dev = nullptr;
     int32_t *table_dev = nullptr;
@@ -344,6 +351,10 @@ int flush_stages(slamgpu_ctx *c) {
         c->k->finish(c->stream, c->B, c->ws, c->unreduced.hist, c->unreduced.par);
         c->unreduced.has = false;
     }
+    if (c->unplanned.has && c->dist)
+        // the resampling stage of a distributed context needs every shard's totals: it only ever runs inside the next
+        // update launch (slamgpu_dist_step / slamgpu_dist_settle)
+        return fail(SLAMGPU_ERR_INVALID, "distributed context: call slamgpu_dist_settle on every shard (and all-gather) before reading results");
     if (c->unplanned.has) {
         ResampleArgs ra{};
         ra.nf = c->unplanned.nf;
@@ -582,6 +593,10 @@ void slamgpu_destroy(slamgpu_ctx *c) {
         if (c->ws.keep[b]) (void) hipFree(c->ws.keep[b]);
     if (c->hist_dev) (void) hipFree(c->hist_dev);
     if (c->stamps_dev) (void) hipFree(c->stamps_dev);
+    for (void *p : c->ipc_opened) (void) hipIpcCloseMemHandle(p);
+    if (c->peers_dev) (void) hipFree(c->peers_dev);
+    for (int b = 0; b < 2; b++)
+        if (c->gtot_dev[b]) (void) hipFree(c->gtot_dev[b]);
     if (c->map_dev) (void) hipFree(c->map_dev);
     if (c->obs_r_dev) (void) hipFree(c->obs_r_dev);
     if (c->table_dev) (void) hipFree(c->table_dev);
@@ -794,13 +809,22 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
         HIP_TRY(hipMemcpyAsync(c->strata_dev[c->obs_step & 1], sh, sizeof(float) * (size_t) n_global(c), hipMemcpyHostToDevice, c->stream));
     }
 
-    const RngArgs rng = rng_args(c, c->obs_step);
+    RngArgs rng = rng_args(c, c->obs_step);
+    if (c->dist) {
+        rng.step = c->obs_step - c->rng_skew;  // (device noise only: the tape buffers above do not apply)
+        rng.prev_step = c->unplanned.step;
+    }
     if (sharded && c->unplanned.has)
         if (int rc = flush_stages(c)) return rc;  // (a context is driven either way, not both; be safe)
     c->B.slot = c->slot;
     c->ws.wpar = sharded ? 0 : (int) (c->obs_step & 1);
     U.lazy = 1;
-    U.arrivals = sharded ? 1 : 0;
+    U.arrivals = c->dist ? 2 : (sharded ? 1 : 0);
+    if (c->dist) {
+        c->B.gtot[0] = c->gtot_dev[0];
+        c->B.gtot[1] = c->gtot_dev[1];
+        c->dist_clean = false;
+    }
     // a pending gather's genealogy composition: small packets: by the compute threads themselves; device packets: by copy
     // roles (one role = 256 particles x rows_per_role live rows; at most ~4 roles per particle tile: every role block
     // redoes the plan's scan and search)
@@ -840,14 +864,14 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     if (U.plan_inline) c->unreduced = c->unplanned;
     c->unplanned.has = true;
     c->unplanned.par = c->ws.wpar;
-    c->unplanned.step = c->obs_step;
+    c->unplanned.step = c->obs_step - c->rng_skew;
     c->unplanned.nf = c->nf;
     c->unplanned.hist = c->hist_n < kHistCap ? c->hist_dev + kHistStride * (size_t) c->hist_n : nullptr;
     c->est_fresh = c->unplanned.hist != nullptr;
     // large contexts: one block prepares the prefix of this step's block totals for the next launch, instead of every
     // block of that launch redoing it (a second, tiny launch; negligible at these sizes)
     c->scan_ready = false;
-    if (c->ws.nblocks > c->scan_min_blocks) {
+    if (c->ws.nblocks > c->scan_min_blocks && !c->dist) {
         Timed t(c, "scan");
         c->k->scan(c->stream, c->ws, c->cfg.log_weights);
         c->scan_ready = true;
@@ -1085,6 +1109,149 @@ int slamgpu_shard_finish(slamgpu_ctx *c, const slamgpu_shard_plan_t *plan) {
     return 0;
 }
 
+// ---- distributed operation ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int kDistArrays = 14;
+struct DistBlob {
+    int64_t pid;
+    int32_t device, ncap, cap_nf, compact;
+    void *ptr[kDistArrays];
+    hipIpcMemHandle_t handle[kDistArrays];
+};
+void dist_arrays(slamgpu_ctx *c, void **a) {
+    int k = 0;
+    for (int b = 0; b < 2; b++) a[k++] = c->B.poseA[b];
+    for (int b = 0; b < 2; b++) a[k++] = c->B.poseB[b];
+    for (int b = 0; b < 2; b++) a[k++] = c->B.poseC[b];
+    for (int b = 0; b < 2; b++) a[k++] = c->B.lmkA[b];
+    for (int b = 0; b < 2; b++) a[k++] = c->B.lmkB[b];
+    for (int b = 0; b < 2; b++) a[k++] = c->B.gen[b];
+    for (int b = 0; b < 2; b++) a[k++] = c->ws.lcum[b];
+}
+}  // namespace
+
+int slamgpu_dist_export_size(void) { return (int) sizeof(DistBlob); }
+
+int slamgpu_dist_export(slamgpu_ctx *c, void *blob) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!blob) return fail(SLAMGPU_ERR_INVALID, "null blob");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    DistBlob b{};
+    b.pid = (int64_t) getpid();
+    b.device = c->cfg.device;
+    b.ncap = c->B.ncap;
+    b.cap_nf = c->B.cap_nf;
+    b.compact = c->B.compact;
+    dist_arrays(c, b.ptr);
+    for (int k = 0; k < kDistArrays; k++) HIP_TRY(hipIpcGetMemHandle(&b.handle[k], b.ptr[k]));
+    memcpy(blob, &b, sizeof b);
+    return 0;
+}
+
+int slamgpu_dist_connect(slamgpu_ctx *c, int32_t n_shards, int32_t shard, const void *blobs) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!blobs || n_shards < 1 || n_shards > kMaxShards || shard < 0 || shard >= n_shards) return fail(SLAMGPU_ERR_INVALID, "bad shard geometry");
+    if (c->cfg.log_weights && n_shards > 1) return fail(SLAMGPU_ERR_INVALID, "log_weights is not available for distributed contexts");
+    const int64_t n = c->cfg.n_particles;
+    if (n_shards > 1 && (n % kBlock != 0 || c->cfg.first_particle != (int64_t) shard * n || n_global(c) != n * n_shards))
+        return fail(SLAMGPU_ERR_INVALID, "shard %d of %d must hold global particles [%lld, %lld) of %lld, a multiple of %d each", shard, n_shards,
+                    (long long) (shard * n), (long long) ((shard + 1) * n), (long long) (n * n_shards), kBlock);
+    if ((int64_t) c->ws.nblocks * n_shards > kMaxScanBlocks)
+        return fail(SLAMGPU_ERR_INVALID, "%lld particles exceed %d blocks of 256", (long long) (n * n_shards), kMaxScanBlocks);
+    if (c->obs_step != 0 || c->nf != 0) return fail(SLAMGPU_ERR_INVALID, "connect a distributed context before its first update");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const DistBlob *all = static_cast<const DistBlob *>(blobs);
+    std::vector<PeerPtrs> table((size_t) n_shards);
+    for (int h = 0; h < n_shards; h++) {
+        const DistBlob &b = all[h];
+        if (b.ncap != c->B.ncap || b.cap_nf != c->B.cap_nf || b.compact != c->B.compact)
+            return fail(SLAMGPU_ERR_INVALID, "shard %d was created with different sizes", h);
+        void *p[kDistArrays];
+        if (h == shard) {
+            dist_arrays(c, p);
+        } else if (b.pid == (int64_t) getpid()) {
+            for (int k = 0; k < kDistArrays; k++) p[k] = b.ptr[k];
+            if (b.device != c->cfg.device) {
+                hipError_t e = hipDeviceEnablePeerAccess(b.device, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+                    return fail(SLAMGPU_ERR_HIP, "no peer access from device %d to device %d: %s", c->cfg.device, b.device, hipGetErrorString(e));
+                (void) hipGetLastError();
+            }
+        } else {
+            for (int k = 0; k < kDistArrays; k++) {
+                hipError_t e = hipIpcOpenMemHandle(&p[k], b.handle[k], hipIpcMemLazyEnablePeerAccess);
+                if (e != hipSuccess) return fail(SLAMGPU_ERR_HIP, "hipIpcOpenMemHandle (shard %d, array %d): %s", h, k, hipGetErrorString(e));
+                c->ipc_opened.push_back(p[k]);
+            }
+        }
+        PeerPtrs &t = table[(size_t) h];
+        int k = 0;
+        for (int q = 0; q < 2; q++) t.poseA[q] = (float4 *) p[k++];
+        for (int q = 0; q < 2; q++) t.poseB[q] = (float4 *) p[k++];
+        for (int q = 0; q < 2; q++) t.poseC[q] = (float2 *) p[k++];
+        for (int q = 0; q < 2; q++) t.lmkA[q] = (float4 *) p[k++];
+        for (int q = 0; q < 2; q++) t.lmkB[q] = (float *) p[k++];
+        for (int q = 0; q < 2; q++) t.gen[q] = (int32_t *) p[k++];
+        for (int q = 0; q < 2; q++) t.lcum[q] = (float *) p[k++];
+    }
+    HIP_TRY(hipMalloc((void **) &c->peers_dev, sizeof(PeerPtrs) * (size_t) n_shards));
+    HIP_TRY(hipMemcpy(c->peers_dev, table.data(), sizeof(PeerPtrs) * (size_t) n_shards, hipMemcpyHostToDevice));
+    for (int b = 0; b < 2; b++) {
+        HIP_TRY(hipMalloc((void **) &c->gtot_dev[b], sizeof(float) * 3 * (size_t) c->ws.nblocks * n_shards));
+        HIP_TRY(hipMemset(c->gtot_dev[b], 0, sizeof(float) * 3 * (size_t) c->ws.nblocks * n_shards));
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    c->B.peers = c->peers_dev;
+    c->B.n_shards = n_shards;
+    c->B.shard = shard;
+    c->B.first = (int32_t) c->cfg.first_particle;
+    c->B.div_n = (unsigned long long) (~0ull / (unsigned long long) c->B.ncap) + 1ull;
+    c->dist = true;
+    return 0;
+}
+
+int slamgpu_dist_step(slamgpu_ctx *c, const float *controls, int32_t n_controls, const float Q[4], float dt, const float *zf,
+                      const int32_t *idf, int32_t m, const float *zn, int32_t n, const float R[4], int32_t record_estimate) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!c->dist) return fail(SLAMGPU_ERR_INVALID, "not a distributed context: call slamgpu_dist_connect first");
+    if (c->cfg.rng_mode != SLAMGPU_RNG_PHILOX) return fail(SLAMGPU_ERR_INVALID, "distributed contexts draw their noise on the device (SLAMGPU_RNG_PHILOX)");
+    if (n_controls < 0 || (n_controls > 0 && !controls)) return fail(SLAMGPU_ERR_INVALID, "bad control list");
+    for (int k = 0; k < n_controls; k++)
+        if (int rc = slamgpu_predict(c, controls[3 * k], controls[3 * k + 1], Q, dt, controls[3 * k + 2], nullptr)) return rc;
+    if (int rc = do_update(c, zf, idf, m, zn, n, R, nullptr, nullptr, false)) return rc;
+    if (record_estimate) {
+        if (c->hist_n >= kHistCap) return fail(SLAMGPU_ERR_CAPACITY, "estimate history full (%d): fetch it", kHistCap);
+        c->hist_n++;  // slot filled when the partials of this update are reduced (next launch / fetch)
+        c->est_fresh = false;
+    }
+    return 0;
+}
+
+int slamgpu_dist_totals(slamgpu_ctx *c, const float **local_dev, float **gathered_dev, int32_t *floats_per_shard) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!c->dist) return fail(SLAMGPU_ERR_INVALID, "not a distributed context");
+    const int par = (int) (c->obs_step & 1);
+    if (local_dev) *local_dev = c->ws.blk_w[par];
+    if (gathered_dev) *gathered_dev = c->gtot_dev[par];
+    if (floats_per_shard) *floats_per_shard = 2 * c->ws.nblocks;  // [w | q] (linear weights)
+    return 0;
+}
+
+int slamgpu_dist_settle(slamgpu_ctx *c) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!c->dist) return fail(SLAMGPU_ERR_INVALID, "not a distributed context");
+    if (c->dist_clean || !c->unplanned.has) return 0;
+    // an update without observations and without predicts: applies the pending resampling stage (inline plan) and leaves
+    // a stage that is a no-op.  It must not consume an observation-step number: the Philox streams of later steps would shift.
+    const float R[4] = {1.0f, 0.0f, 0.0f, 1.0f};
+    if (int rc = flush_predict(c)) return rc;
+    if (int rc = do_update(c, nullptr, nullptr, 0, nullptr, 0, R, nullptr, nullptr, false)) return rc;
+    c->rng_skew++;
+    c->unplanned.has = false;  // the stage this launch leaves is a no-op: weights normalised, nothing to resample
+    c->dist_clean = true;
+    return 0;
+}
+
 int slamgpu_dev_alloc(slamgpu_ctx *c, uint64_t bytes, void **ptr) {
     if (int rc = check_ctx(c)) return rc;
     if (!ptr) return fail(SLAMGPU_ERR_INVALID, "null pointer");
@@ -1234,6 +1401,30 @@ int slamgpu_history_fetch(slamgpu_ctx *c, double *xyt, float *neff, int32_t *res
             xyt[3 * i + 1] = e[1] / (double) c->B.n;
             xyt[3 * i + 2] = e[2];
         }
+        if (neff) neff[i] = (float) e[4];
+        if (resampled) resampled[i] = ((int32_t) e[5]) & 1;
+        if (status) status[i] = ((int32_t) e[5]) >> 1;
+    }
+    *count = n;
+    if (int rc = keep_history_tail(c, h, n)) return rc;
+    c->est_fresh = false;
+    return 0;
+}
+
+int slamgpu_dist_history_fetch(slamgpu_ctx *c, double *raw4, float *neff, int32_t *resampled, int32_t *status, int32_t max_count,
+                               int32_t *count) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!count) return fail(SLAMGPU_ERR_INVALID, "null count");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = flush_stages(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int n = c->hist_n < std::max(max_count, 0) ? c->hist_n : std::max(max_count, 0);
+    std::vector<double> h((size_t) kHistStride * (c->hist_n > 0 ? c->hist_n : 1));
+    if (c->hist_n > 0) HIP_TRY(hipMemcpy(h.data(), c->hist_dev, sizeof(double) * kHistStride * (size_t) c->hist_n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+        const double *e = h.data() + (size_t) kHistStride * i;
+        if (raw4)
+            for (int k = 0; k < 4; k++) raw4[4 * (size_t) i + k] = e[k];
         if (neff) neff[i] = (float) e[4];
         if (resampled) resampled[i] = ((int32_t) e[5]) & 1;
         if (status) status[i] = ((int32_t) e[5]) >> 1;
@@ -1449,8 +1640,10 @@ int slamgpu_num_landmarks(slamgpu_ctx *c) { return c ? c->nf : SLAMGPU_ERR_INVAL
 int slamgpu_sync(slamgpu_ctx *c) {
     if (int rc = check_ctx(c)) return rc;
     HIP_TRY(hipSetDevice(c->cfg.device));
-    if (int rc = flush_predict(c)) return rc;
-    if (int rc = flush_stages(c)) return rc;
+    if (!c->dist) {  // (a distributed context's outstanding stage needs the other shards: it stays queued)
+        if (int rc = flush_predict(c)) return rc;
+        if (int rc = flush_stages(c)) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
