@@ -297,6 +297,30 @@ int slamgpu_dist_settle(slamgpu_ctx *ctx);
 int slamgpu_dist_history_fetch(slamgpu_ctx *ctx, double *raw4, float *neff, int32_t *resampled, int32_t *status, int32_t max_count,
                                int32_t *count);
 
+/* RCCL inside the library (bound at run time: dlopen librccl.so.1): one process per GPU.  Rank 0 makes an id
+ * (SLAMGPU_DIST_COMM_ID_BYTES bytes) and hands it to every rank by whatever means the launcher has; after
+ * slamgpu_dist_comm_init (collective), slamgpu_dist_step and slamgpu_dist_settle enqueue the all-gather themselves on
+ * the context's stream: a filter step is one C call, one launch and one collective, and never waits on the host. */
+#define SLAMGPU_DIST_COMM_ID_BYTES 128
+int slamgpu_dist_comm_id(void *id, int32_t bytes);
+int slamgpu_dist_comm_init(slamgpu_ctx *ctx, const void *id, int32_t n_ranks, int32_t rank);
+
+/* All shards in ONE process (the reference's single backend process driving k GPUs; or k logical shards on one GPU, which
+ * must then share one stream): export + connect + communicators (ncclCommInitAll; a copy kernel on a shared device) in
+ * one call, then steps for every shard at once.  Contexts are created by the caller as for slamgpu_dist_connect and
+ * destroyed by the caller after the group.  _history combines the shards' partial estimates (xyt[3] per recorded step);
+ * _download concatenates the shards in shard order (buffers sized for all k * n particles). */
+typedef struct slamgpu_dist_group slamgpu_dist_group;
+int slamgpu_dist_group_create(slamgpu_ctx **ctxs, int32_t k, slamgpu_dist_group **out);
+void slamgpu_dist_group_destroy(slamgpu_dist_group *g);
+int slamgpu_dist_group_step(slamgpu_dist_group *g, const float *controls, int32_t n_controls, const float Q[4], float dt,
+                            const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n, const float R[4],
+                            int32_t record_estimate);
+int slamgpu_dist_group_settle(slamgpu_dist_group *g);
+int slamgpu_dist_group_history(slamgpu_dist_group *g, double *xyt, float *neff, int32_t *resampled, int32_t *status,
+                               int32_t max_count, int32_t *count);
+int slamgpu_dist_group_download(slamgpu_dist_group *g, float *xv, float *Pv9, float *w, float *xf, float *Pf4);
+
 /* Plain device-memory helpers for callers that have no allocator of their own (tests, the C++ host): buffers
  * for the gathered block totals and the send / receive records.  copy is device-to-device, ordered on the
  * context's stream and synchronised before returning. */

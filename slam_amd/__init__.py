@@ -4,7 +4,7 @@ is slam_amd/libslamgpu.so (+ the C++ host driver slam_amd/bin/slam-backend).  Th
 PyTorch fallback: importing works anywhere, but every compute call needs the built library and a GPU.
 """
 from .capi import (Config, ShardPlan, SlamGpu, SlamGpuError, FASTSLAM1, FASTSLAM2, RNG_TAPE, RNG_PHILOX, MATH_STRICT, MATH_FAST,
-                   lib_path, load_library, jacobians, kat, device_count, DECLARED_SYMBOLS)
+                   lib_path, load_library, jacobians, kat, device_count, DECLARED_SYMBOLS, DistGroup, dist_comm_id)
 
 __all__ = ["Config", "ShardPlan", "SlamGpu", "SlamGpuError", "FASTSLAM1", "FASTSLAM2", "RNG_TAPE", "RNG_PHILOX", "MATH_STRICT",
-           "MATH_FAST", "lib_path", "load_library", "jacobians", "kat", "device_count", "DECLARED_SYMBOLS"]
+           "MATH_FAST", "lib_path", "load_library", "jacobians", "kat", "device_count", "DECLARED_SYMBOLS", "DistGroup", "dist_comm_id"]

@@ -22,7 +22,8 @@ DECLARED_SYMBOLS = [
     "slamgpu_dev_alloc", "slamgpu_dev_free", "slamgpu_dev_copy", "slamgpu_dev_copy_async", "slamgpu_shard_estimate_async",
     "slamgpu_shard_estimate_fetch", "slamgpu_step_status", "slamgpu_kat", "slamgpu_download_range", "slamgpu_debug_stamps", "slamgpu_associate", "slamgpu_set_map", "slamgpu_observe",
     "slamgpu_dist_export_size", "slamgpu_dist_export", "slamgpu_dist_connect", "slamgpu_dist_step", "slamgpu_dist_totals", "slamgpu_dist_settle",
-    "slamgpu_dist_history_fetch",
+    "slamgpu_dist_history_fetch", "slamgpu_dist_comm_id", "slamgpu_dist_comm_init", "slamgpu_dist_group_create", "slamgpu_dist_group_destroy",
+    "slamgpu_dist_group_step", "slamgpu_dist_group_settle", "slamgpu_dist_group_history", "slamgpu_dist_group_download",
 ]
 
 
@@ -124,6 +125,15 @@ def load_library():
     L.slamgpu_dist_totals.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
     L.slamgpu_dist_settle.argtypes = [C.c_void_p]
     L.slamgpu_dist_history_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.slamgpu_dist_comm_id.argtypes = [C.c_void_p, C.c_int32]
+    L.slamgpu_dist_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+    L.slamgpu_dist_group_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]
+    L.slamgpu_dist_group_destroy.argtypes = [C.c_void_p]
+    L.slamgpu_dist_group_destroy.restype = None
+    L.slamgpu_dist_group_step.argtypes = [C.c_void_p] + L.slamgpu_dist_step.argtypes[1:]
+    L.slamgpu_dist_group_settle.argtypes = [C.c_void_p]
+    L.slamgpu_dist_group_history.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.slamgpu_dist_group_download.argtypes = [C.c_void_p] * 6
     _lib = L
     return L
 
@@ -171,6 +181,93 @@ def kat(math_mode, op, data):
     out = np.zeros(n, np.float32)
     _chk(load_library().slamgpu_kat(math_mode, op, _ptr(a), n, _ptr(out)))
     return out
+
+
+def dist_comm_id():
+    """a fresh RCCL unique id (rank 0 makes it, every rank passes it to SlamGpu.dist_comm_init)"""
+    buf = C.create_string_buffer(128)
+    _chk(load_library().slamgpu_dist_comm_id(buf, 128))
+    return buf.raw
+
+
+class DistGroup:
+    """All shards of a distributed run in this process (slamgpu_dist_group_*): k contexts on k GPUs (RCCL inside the
+    library) or k logical shards on one GPU sharing `stream`."""
+
+    def __init__(self, n_shards, n_per_shard, max_landmarks, devices=None, stream=0, **kw):
+        self.L = load_library()
+        kw.setdefault("rng_mode", RNG_PHILOX)
+        self.G, self.n = n_shards, n_per_shard
+        self.ctx = []
+        for g in range(n_shards):
+            dev = devices[g] if devices else 0
+            ext = stream
+            if not devices and n_shards > 1 and not stream and self.ctx:
+                ext = self.ctx[0].stream()  # logical shards: everybody on the first context's stream
+            self.ctx.append(SlamGpu(n_per_shard, max_landmarks, first_particle=g * n_per_shard, n_particles_global=n_shards * n_per_shard,
+                                    device=dev, external_stream=ext or 0, **kw))
+        arr = (C.c_void_p * n_shards)(*[c.h for c in self.ctx])
+        self.h = C.c_void_p()
+        _chk(self.L.slamgpu_dist_group_create(arr, n_shards, C.byref(self.h)))
+
+    def prepare_step(self, controls, Q, dt, zf, idf, zn, R, record_estimate=True):
+        ctl = _f32(controls).reshape(-1, 3)
+        Q = _f32(Q, 4)
+        zf = _f32(zf).reshape(-1, 2)
+        zn = _f32(zn).reshape(-1, 2)
+        idf = np.ascontiguousarray(idf, np.int32)
+        R = _f32(R, 4)
+        keep = (ctl, Q, zf, zn, idf, R)
+        args = (self.h, _ptr(ctl), ctl.shape[0], _ptr(Q), C.c_float(dt), _ptr(zf), _ptr(idf), zf.shape[0], _ptr(zn), zn.shape[0],
+                _ptr(R), 1 if record_estimate else 0)
+        fn = self.L.slamgpu_dist_group_step
+
+        def call(_keep=keep):
+            _chk(fn(*args))
+        return call
+
+    def step(self, controls, Q, dt, zf, idf, zn, R, record_estimate=True):
+        self.prepare_step(controls, Q, dt, zf, idf, zn, R, record_estimate)()
+
+    def settle(self):
+        _chk(self.L.slamgpu_dist_group_settle(self.h))
+
+    def history_fetch(self, max_count=4096):
+        out = np.zeros((max_count, 3), np.float64)
+        ne = np.zeros(max_count, np.float32)
+        rs = np.zeros(max_count, np.int32)
+        st = np.zeros(max_count, np.int32)
+        n = C.c_int32()
+        _chk(self.L.slamgpu_dist_group_history(self.h, _ptr(out), _ptr(ne), _ptr(rs), _ptr(st), max_count, C.byref(n)))
+        self.last_history_status = st[:n.value].copy()
+        return out[:n.value].copy(), ne[:n.value].copy(), rs[:n.value].astype(bool)
+
+    def download(self, landmarks=True):
+        N, nf = self.G * self.n, self.ctx[0].nf()
+        xv = np.zeros((N, 3), np.float32)
+        Pv = np.zeros((N, 3, 3), np.float32)
+        w = np.zeros(N, np.float32)
+        xf = np.zeros((N, nf, 2), np.float32) if landmarks else None
+        Pf = np.zeros((N, nf, 2, 2), np.float32) if landmarks else None
+        _chk(self.L.slamgpu_dist_group_download(self.h, _ptr(xv), _ptr(Pv), _ptr(w), _ptr(xf), _ptr(Pf)))
+        return dict(nf=nf, xv=xv, Pv=Pv, w=w, xf=xf, Pf=Pf)
+
+    def sync(self):
+        for c in self.ctx:
+            _chk(self.L.slamgpu_sync(c.h))
+
+    def close(self):
+        if self.h:
+            self.L.slamgpu_dist_group_destroy(self.h)
+            self.h = C.c_void_p()
+        for c in self.ctx:
+            c.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class SlamGpu:
@@ -419,6 +516,9 @@ class SlamGpu:
         a, b, n = C.c_void_p(), C.c_void_p(), C.c_int32()
         _chk(self.L.slamgpu_dist_totals(self.h, C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
+
+    def dist_comm_init(self, comm_id, n_ranks, rank):
+        _chk(self.L.slamgpu_dist_comm_init(self.h, comm_id, n_ranks, rank))
 
     def dist_settle(self):
         _chk(self.L.slamgpu_dist_settle(self.h))

@@ -15,6 +15,10 @@
 //   -plotstride <k>      particles / feature particles sent per step are decimated to every k-th particle (default: as
 //                        many as keep a frame below ~2 000 particles; the reference sends all of them: N = 10^5 would be
 //                        1.6 MB of poses and 56 MB of feature points per control step)
+//   -gpus <k>            FastSLAM over k GPUs from this one process (slamgpu_dist_group_*): shard g = particles
+//                        [g N/k, (g+1) N/k) on device g, one launch + one RCCL all-gather per observation step, the set is
+//                        never moved; results do not depend on k.  k above the number of devices: logical shards on device 0
+//                        (rehearsal).  Needs -rng philox, -assoc known, NPARTICLES a multiple of 256 k.
 // It restates the wrapper loops (wrappers/fastslam2wrapper.cpp:31-122, fastslam1wrapper.cpp:32-113,
 // ekfslamwrapper.cpp:33-109) minus the ZeroMQ plotting: the FastSLAM hot path runs on the GPU through the
 // slamgpu C ABI (the seam AcceleratorHandler occupied), EKF-SLAM runs on the host CPU.
@@ -42,8 +46,126 @@ static void usage(const char *a0) {
     printf("    -method             [s] SLAM method: EKF1 | FASTSLAM1 | FASTSLAM2\n");
     printf("    -rng parity|philox  -math strict|fast  -log file.csv  -maxsteps n\n");
     printf("    -plot tcp://127.0.0.1:4242|file:<path>|gather:<dir>|none   -plotstride k\n");
+    printf("    -gpus k             FastSLAM particle set distributed over k GPUs (k > devices: logical shards on device 0)\n");
     printf("    -KEY value          any ini key, e.g. -NPARTICLES 100000 -NEFFECTIVE 75000 -SWITCH_SEED_RANDOM 7\n");
     printf("    -h  (print usage)\n\n");
+}
+
+// -gpus k: the wrapper loop with the particle set distributed over k contexts.  The queued controls ride inside the next
+// observation step's launch; estimates are recorded on the device per observation step and fetched in batches.
+static int run_distributed(Simulator &sim, int k, long maxsteps, FILE *log, Plot &plot) {
+    const Conf &c = sim.conf;
+    const int N = c.NPARTICLES;
+    if (c.s("rng") == "parity" || c.s("assoc") == "gated") {
+        fprintf(stderr, "-gpus %d needs -rng philox and -assoc known\n", k);
+        return EXIT_FAILURE;
+    }
+    if (k < 1 || N % (256 * k) != 0) {
+        fprintf(stderr, "-gpus %d: NPARTICLES must be a multiple of %d (e.g. %d)\n", k, 256 * k, (N + 256 * k - 1) / (256 * k) * (256 * k));
+        return EXIT_FAILURE;
+    }
+    const int ndev = slamgpu_device_count();
+    if (ndev < 1) {
+        fprintf(stderr, "slamgpu: no GPU (libslamgpu has no CPU fallback)\n");
+        return EXIT_FAILURE;
+    }
+    const bool logical = k > ndev;
+    printf("%s, %d particles over %d %s\n\n", c.method == 2 ? "FastSLAM 2" : "FastSLAM 1", N, k,
+           logical ? "logical shards on device 0" : "GPUs");
+    std::vector<slamgpu_ctx *> ctx((size_t) k, nullptr);
+    slamgpu_dist_group *grp = nullptr;
+    int rc = 0;
+    for (int g = 0; g < k && !rc; g++) {
+        slamgpu_config q{};
+        q.struct_size = sizeof q;
+        q.device = logical ? 0 : g;
+        q.method = c.method;
+        q.n_particles = N / k;
+        q.n_particles_global = N;
+        q.first_particle = (int64_t) g * (N / k);
+        q.max_landmarks = sim.map.nlm;
+        q.use_heading = c.SWITCH_HEADING_KNOWN == 1;
+        q.add_predict_noise = c.method == 1 ? 1 : (c.SWITCH_PREDICT_NOISE == 1);
+        q.resample = c.SWITCH_RESAMPLE == 1;
+        q.n_effective = c.NEFFECTIVE;
+        q.wheel_base = c.WHEELBASE;
+        q.sigma_phi = c.sigmaT;
+        q.rng_mode = SLAMGPU_RNG_PHILOX;
+        q.math_mode = c.s("math") == "strict" ? SLAMGPU_MATH_STRICT : SLAMGPU_MATH_FAST;
+        q.seed = (uint64_t) c.SWITCH_SEED_RANDOM;
+        q.external_stream = (logical && g > 0) ? (uint64_t) (uintptr_t) slamgpu_stream(ctx[0]) : 0;  // logical shards share one stream
+        rc = slamgpu_create(&q, &ctx[(size_t) g]);
+    }
+    if (!rc) rc = slamgpu_dist_group_create(ctx.data(), k, &grp);
+    if (rc) {
+        fprintf(stderr, "slamgpu: %s\n", slamgpu_last_error());
+        for (slamgpu_ctx *x : ctx)
+            if (x) slamgpu_destroy(x);
+        return EXIT_FAILURE;
+    }
+    sim.seed();  // (after the HIP runtime has initialised: see main)
+
+    struct ObsRow {
+        long iter;
+        float xt[3];
+        double us;
+    };
+    std::vector<ObsRow> rows;       // observation steps whose estimate has not been fetched yet
+    std::vector<float> controls, zf, zn;
+    std::vector<int32_t> idf;
+    std::vector<double> xyt(3 * 4096);
+    long iter = 0, nobs = 0;
+    double sum_us = 0, sq_err = 0, est[3] = {0, 0, 0};
+    auto fetch = [&]() -> int {
+        int32_t got = 0;
+        if (int r = slamgpu_dist_group_history(grp, xyt.data(), nullptr, nullptr, nullptr, 4096, &got)) return r;
+        for (int t = 0; t < got && t < (int) rows.size(); t++) {
+            const ObsRow &o = rows[(size_t) t];
+            for (int q = 0; q < 3; q++) est[q] = xyt[3 * (size_t) t + q];
+            sq_err += (est[0] - o.xt[0]) * (est[0] - o.xt[0]) + (est[1] - o.xt[1]) * (est[1] - o.xt[1]);
+            if (log) fprintf(log, "%ld,%.6f,%.6f,%.6f,%.6f,%.6f,%.6f,%.1f\n", o.iter, o.xt[0], o.xt[1], o.xt[2], est[0], est[1], est[2], o.us);
+            if (plot.active()) {
+                plot.setCurrentIteration((uint32_t) o.iter);
+                plot.addTruePosition(o.xt[0], o.xt[1]);
+                plot.addEstimatedPosition(est[0], est[1]);
+                plot.setCarTruePosition(o.xt[0], o.xt[1], o.xt[2]);
+                plot.setCarEstimatedPosition(est[0], est[1], est[2]);
+                plot.plot();
+            }
+        }
+        rows.clear();
+        return 0;
+    };
+    auto t_obs = std::chrono::steady_clock::now();
+    while ((maxsteps < 0 || iter < maxsteps) && !rc) {
+        const int r = sim.control();
+        if (r < 0) break;
+        controls.push_back(sim.Vnoisy);
+        controls.push_back(sim.Gnoisy);
+        controls.push_back(sim.xTrue[2]);
+        iter++;
+        if (r != 1) continue;
+        sim.observe();
+        sim.associate_known(slamgpu_num_landmarks(ctx[0]), zf, idf, zn);
+        rc = slamgpu_dist_group_step(grp, controls.data(), (int) (controls.size() / 3), sim.Qe, sim.dt, zf.data(), idf.data(), (int) idf.size(),
+                                     zn.data(), (int) (zn.size() / 2), sim.Re, 1);
+        controls.clear();
+        nobs++;
+        const auto now = std::chrono::steady_clock::now();
+        const double us = std::chrono::duration<double, std::micro>(now - t_obs).count();
+        t_obs = now;
+        sum_us += us;
+        rows.push_back(ObsRow{iter, {sim.xTrue[0], sim.xTrue[1], sim.xTrue[2]}, us});
+        if (!rc && rows.size() == 4096) rc = fetch();
+    }
+    if (!rc) rc = fetch();
+    if (rc) fprintf(stderr, "slamgpu: %s\n", slamgpu_last_error());
+    printf("control steps %ld, observation steps %ld, mean observation-step time %.1f us, rms position error %.4f m, final estimate (%.4f, %.4f, %.4f)\n",
+           iter, nobs, nobs ? sum_us / nobs : 0.0, nobs ? std::sqrt(sq_err / nobs) : 0.0, est[0], est[1], est[2]);
+    printf("landmarks in map: %d\n", slamgpu_num_landmarks(ctx[0]));
+    slamgpu_dist_group_destroy(grp);
+    for (slamgpu_ctx *x : ctx) slamgpu_destroy(x);
+    return rc ? EXIT_FAILURE : 0;
 }
 
 int main(int argc, char **argv) {
@@ -75,6 +197,19 @@ int main(int argc, char **argv) {
             return EXIT_FAILURE;
         }
         if (plot.active()) plot.setSimulationName(c.simulation_name);
+    }
+    if (c.method != 0 && !c.s("gpus").empty() && atoi(c.s("gpus").c_str()) != 1) {
+        if (plot.active()) {
+            plot.setCarSize(c.WHEELBASE, 0);
+            plot.setCarSize(c.WHEELBASE, 1);
+        }
+        const int rcd = run_distributed(sim, atoi(c.s("gpus").c_str()), maxsteps, log, plot);
+        if (plot.active()) {
+            plot.endPlot();
+            plot.close();
+        }
+        if (log) fclose(log);
+        return rcd;
     }
     slamgpu_ctx *ctx = nullptr;
     EkfSlam ekf;

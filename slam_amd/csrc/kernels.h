@@ -305,6 +305,14 @@ struct ObserveArgs {
     ObserveOut *out;       // device: header, then z[2 nlm], vis[nlm], zf[2 nlm], idf[nlm], zn[2 nlm] (4-byte units, in this order)
 };
 
+// all-gather of the block totals between distributed contexts that share one device and one stream (rehearsal of the
+// multi-GPU path on a single GPU): block (h, g) copies shard g's totals into slot g of shard h's table
+struct DistGatherArgs {
+    const float *local[kMaxShards];
+    float *gathered[kMaxShards];
+    int32_t n_shards, floats_per_shard;
+};
+
 struct KernelTable {
     // the step: [resampling stage of the previous update, inline] + [gather] + [fused predicts] + per-particle observation
     // update + in-block weight prefix / totals  (+ helper blocks: genealogy copy, Ctrl words, estimate reduction)
@@ -343,6 +351,7 @@ struct KernelTable {
     void (*shard_unpack)(hipStream_t, const Buffers &, const WeightScratch &, const ShardUnpackArgs &);
     // normalise or leave the lazy gather pending; this shard's pose-estimate partials; outcome into Ctrl
     void (*shard_finish)(hipStream_t, const Buffers &, const WeightScratch &, double W, double Q, float neff, int resampled);
+    void (*dist_gather)(hipStream_t, const DistGatherArgs &);
 };
 
 const KernelTable *kernels_strict();

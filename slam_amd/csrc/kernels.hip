@@ -2018,8 +2018,19 @@ static void launch_kat(hipStream_t st, int op, const float *in, int n, float *ou
     hipLaunchKernelGGL(kat_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, op, in, n, out);
 }
 
+__global__ void __launch_bounds__(kBlock) dist_gather_kernel(DistGatherArgs A) {
+    const int h = blockIdx.x / A.n_shards, g = blockIdx.x % A.n_shards;
+    const float *src = A.local[g];
+    float *dst = A.gathered[h] + (size_t) g * A.floats_per_shard;
+    for (int i = threadIdx.x; i < A.floats_per_shard; i += kBlock) dst[i] = src[i];
+}
+
+static void launch_dist_gather(hipStream_t st, const DistGatherArgs &A) {
+    hipLaunchKernelGGL(dist_gather_kernel, dim3(A.n_shards * A.n_shards), dim3(kBlock), 0, st, A);
+}
+
 static const KernelTable kTable = {launch_update, launch_resample, launch_scan, launch_gather, launch_flatten, launch_identity, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat, launch_observe, launch_associate,
-                                   launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish};
+                                   launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish, launch_dist_gather};
 
 }  // namespace SLAM_KNS
 

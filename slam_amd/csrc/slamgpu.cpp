@@ -4,6 +4,8 @@
 #include "../../include/slamgpu.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -33,6 +35,48 @@ int fail(int code, const char *fmt, ...) {
     va_end(ap);
     return code;
 }
+
+// RCCL is bound at run time (dlopen): the library of the process (torch's when torch is loaded, /opt/rocm's otherwise), and no
+// link-time dependency for single-GPU users.
+struct Rccl {
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+const Rccl *rccl() {
+    static Rccl R;
+    static bool tried = false;
+    if (tried) return R.ok ? &R : nullptr;
+    tried = true;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+        if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return nullptr;
+#define SLAM_SYM(f) R.f = reinterpret_cast<decltype(R.f)>(dlsym(h, "nccl" #f))
+    SLAM_SYM(GetUniqueId);
+    SLAM_SYM(CommInitRank);
+    SLAM_SYM(CommInitAll);
+    SLAM_SYM(CommDestroy);
+    SLAM_SYM(AllGather);
+    SLAM_SYM(GroupStart);
+    SLAM_SYM(GroupEnd);
+    SLAM_SYM(GetErrorString);
+#undef SLAM_SYM
+    R.ok = R.GetUniqueId && R.CommInitRank && R.CommInitAll && R.CommDestroy && R.AllGather && R.GroupStart && R.GroupEnd && R.GetErrorString;
+    return R.ok ? &R : nullptr;
+}
+#define RCCL_TRY(expr)                                                                                  \
+    do {                                                                                                \
+        ncclResult_t r_ = (expr);                                                                       \
+        if (r_ != ncclSuccess) return fail(SLAMGPU_ERR_HIP, "%s: %s", #expr, rccl()->GetErrorString(r_)); \
+    } while (0)
+
 
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
@@ -132,6 +176,7 @@ struct slamgpu_ctx {
     PeerPtrs *peers_dev = nullptr;
     float *gtot_dev[2] = {nullptr, nullptr};
     std::vector<void *> ipc_opened;
+    void *comm = nullptr;  // ncclComm_t: when set, slamgpu_dist_step / _settle run the all-gather themselves
     // observation front end (slamgpu_set_map / slamgpu_observe)
     float *map_dev = nullptr, *obs_r_dev = nullptr;
     int32_t *table_dev = nullptr;
@@ -593,6 +638,7 @@ void slamgpu_destroy(slamgpu_ctx *c) {
         if (c->ws.keep[b]) (void) hipFree(c->ws.keep[b]);
     if (c->hist_dev) (void) hipFree(c->hist_dev);
     if (c->stamps_dev) (void) hipFree(c->stamps_dev);
+    if (c->comm && rccl()) (void) rccl()->CommDestroy((ncclComm_t) c->comm);
     for (void *p : c->ipc_opened) (void) hipIpcCloseMemHandle(p);
     if (c->peers_dev) (void) hipFree(c->peers_dev);
     for (int b = 0; b < 2; b++)
@@ -1111,6 +1157,14 @@ int slamgpu_shard_finish(slamgpu_ctx *c, const slamgpu_shard_plan_t *plan) {
 
 // ---- distributed operation ---------------------------------------------------------------------------------------------
 namespace {
+// the all-gather that follows an update launch of a distributed context, on the context's stream
+int gather_totals(slamgpu_ctx *c) {
+    if (!c->comm) return 0;
+    const int par = (int) (c->obs_step & 1);
+    RCCL_TRY(rccl()->AllGather(c->ws.blk_w[par], c->gtot_dev[par], (size_t) 2 * c->ws.nblocks, ncclFloat, (ncclComm_t) c->comm, c->stream));
+    return 0;
+}
+
 constexpr int kDistArrays = 14;
 struct DistBlob {
     int64_t pid;
@@ -1218,12 +1272,36 @@ int slamgpu_dist_step(slamgpu_ctx *c, const float *controls, int32_t n_controls,
     if (n_controls < 0 || (n_controls > 0 && !controls)) return fail(SLAMGPU_ERR_INVALID, "bad control list");
     for (int k = 0; k < n_controls; k++)
         if (int rc = slamgpu_predict(c, controls[3 * k], controls[3 * k + 1], Q, dt, controls[3 * k + 2], nullptr)) return rc;
+    if (record_estimate && c->hist_n >= kHistCap) return fail(SLAMGPU_ERR_CAPACITY, "estimate history full (%d): fetch it", kHistCap);
     if (int rc = do_update(c, zf, idf, m, zn, n, R, nullptr, nullptr, false)) return rc;
     if (record_estimate) {
-        if (c->hist_n >= kHistCap) return fail(SLAMGPU_ERR_CAPACITY, "estimate history full (%d): fetch it", kHistCap);
         c->hist_n++;  // slot filled when the partials of this update are reduced (next launch / fetch)
         c->est_fresh = false;
     }
+    return gather_totals(c);
+}
+
+int slamgpu_dist_comm_id(void *id, int32_t bytes) {
+    if (!id || bytes < (int32_t) sizeof(ncclUniqueId)) return fail(SLAMGPU_ERR_INVALID, "id buffer must hold %d bytes", (int) sizeof(ncclUniqueId));
+    if (!rccl()) return fail(SLAMGPU_ERR_HIP, "librccl.so.1 not found: %s", dlerror());
+    ncclUniqueId u;
+    RCCL_TRY(rccl()->GetUniqueId(&u));
+    memcpy(id, &u, sizeof u);
+    return (int) sizeof u > 0 ? 0 : 0;
+}
+
+int slamgpu_dist_comm_init(slamgpu_ctx *c, const void *id, int32_t n_ranks, int32_t rank) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!c->dist) return fail(SLAMGPU_ERR_INVALID, "not a distributed context: call slamgpu_dist_connect first");
+    if (!id || n_ranks != c->B.n_shards || rank != c->B.shard) return fail(SLAMGPU_ERR_INVALID, "communicator geometry differs from the shard geometry");
+    if (c->comm) return fail(SLAMGPU_ERR_INVALID, "communicator already initialised");
+    if (!rccl()) return fail(SLAMGPU_ERR_HIP, "librccl.so.1 not found: %s", dlerror());
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    ncclComm_t comm = nullptr;
+    RCCL_TRY(rccl()->CommInitRank(&comm, n_ranks, u, rank));
+    c->comm = comm;
     return 0;
 }
 
@@ -1249,6 +1327,162 @@ int slamgpu_dist_settle(slamgpu_ctx *c) {
     c->rng_skew++;
     c->unplanned.has = false;  // the stage this launch leaves is a no-op: weights normalised, nothing to resample
     c->dist_clean = true;
+    return gather_totals(c);
+}
+
+// ---- all shards of a distributed run in ONE process (slam-backend -gpus k, rehearsals on one GPU) ------------------------
+struct slamgpu_dist_group {
+    std::vector<slamgpu_ctx *> ctx;
+    std::vector<ncclComm_t> comms;  // one per context when every context has a device of its own
+    bool shared = false;            // all contexts on one device and one stream: dist_gather_kernel instead of RCCL
+};
+
+namespace {
+int group_gather(slamgpu_dist_group *g) {
+    const int k = (int) g->ctx.size();
+    if (g->shared) {
+        DistGatherArgs A{};
+        A.n_shards = k;
+        A.floats_per_shard = 2 * g->ctx[0]->ws.nblocks;
+        for (int i = 0; i < k; i++) {
+            const int par = (int) (g->ctx[i]->obs_step & 1);
+            A.local[i] = g->ctx[i]->ws.blk_w[par];
+            A.gathered[i] = g->ctx[i]->gtot_dev[par];
+        }
+        HIP_TRY(hipSetDevice(g->ctx[0]->cfg.device));
+        g->ctx[0]->k->dist_gather(g->ctx[0]->stream, A);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    RCCL_TRY(rccl()->GroupStart());
+    for (int i = 0; i < k; i++) {
+        slamgpu_ctx *c = g->ctx[i];
+        const int par = (int) (c->obs_step & 1);
+        RCCL_TRY(rccl()->AllGather(c->ws.blk_w[par], c->gtot_dev[par], (size_t) 2 * c->ws.nblocks, ncclFloat, g->comms[i], c->stream));
+    }
+    RCCL_TRY(rccl()->GroupEnd());
+    return 0;
+}
+}  // namespace
+
+int slamgpu_dist_group_create(slamgpu_ctx **ctxs, int32_t k, slamgpu_dist_group **out) {
+    if (!ctxs || !out || k < 1 || k > kMaxShards) return fail(SLAMGPU_ERR_INVALID, "bad context list");
+    for (int i = 0; i < k; i++)
+        if (!ctxs[i]) return fail(SLAMGPU_ERR_INVALID, "null context %d", i);
+    bool same = true, distinct = true;
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j < i; j++) {
+            if (ctxs[i]->cfg.device == ctxs[j]->cfg.device) distinct = false;
+            else same = false;
+        }
+    if (k > 1 && !same && !distinct) return fail(SLAMGPU_ERR_INVALID, "contexts must all share one device or each have a device of its own");
+    const bool shared = k > 1 ? same : true;
+    if (shared)
+        for (int i = 1; i < k; i++)
+            if (ctxs[i]->stream != ctxs[0]->stream)
+                return fail(SLAMGPU_ERR_INVALID, "contexts sharing a device must share a stream (slamgpu_config.external_stream)");
+    std::vector<DistBlob> blobs((size_t) k);
+    for (int i = 0; i < k; i++)
+        if (int rc = slamgpu_dist_export(ctxs[i], &blobs[(size_t) i])) return rc;
+    for (int i = 0; i < k; i++)
+        if (int rc = slamgpu_dist_connect(ctxs[i], k, i, blobs.data())) return rc;
+    auto *g = new slamgpu_dist_group();
+    g->ctx.assign(ctxs, ctxs + k);
+    g->shared = shared;
+    if (!shared) {
+        if (!rccl()) {
+            delete g;
+            return fail(SLAMGPU_ERR_HIP, "librccl.so.1 not found: %s", dlerror());
+        }
+        std::vector<int> devs((size_t) k);
+        for (int i = 0; i < k; i++) devs[(size_t) i] = ctxs[i]->cfg.device;
+        g->comms.resize((size_t) k);
+        ncclResult_t r = rccl()->CommInitAll(g->comms.data(), k, devs.data());
+        if (r != ncclSuccess) {
+            delete g;
+            return fail(SLAMGPU_ERR_HIP, "ncclCommInitAll: %s", rccl()->GetErrorString(r));
+        }
+    }
+    *out = g;
+    return 0;
+}
+
+void slamgpu_dist_group_destroy(slamgpu_dist_group *g) {
+    if (!g) return;
+    for (slamgpu_ctx *c : g->ctx) {
+        (void) hipSetDevice(c->cfg.device);
+        (void) hipStreamSynchronize(c->stream);
+    }
+    for (ncclComm_t c : g->comms) (void) rccl()->CommDestroy(c);
+    delete g;
+}
+
+int slamgpu_dist_group_step(slamgpu_dist_group *g, const float *controls, int32_t n_controls, const float Q[4], float dt, const float *zf,
+                            const int32_t *idf, int32_t m, const float *zn, int32_t n, const float R[4], int32_t record_estimate) {
+    if (!g) return fail(SLAMGPU_ERR_INVALID, "null group");
+    for (slamgpu_ctx *c : g->ctx)
+        if (int rc = slamgpu_dist_step(c, controls, n_controls, Q, dt, zf, idf, m, zn, n, R, record_estimate)) return rc;
+    return group_gather(g);
+}
+
+int slamgpu_dist_group_settle(slamgpu_dist_group *g) {
+    if (!g) return fail(SLAMGPU_ERR_INVALID, "null group");
+    for (slamgpu_ctx *c : g->ctx)
+        if (int rc = slamgpu_dist_settle(c)) return rc;
+    if (int rc = group_gather(g)) return rc;
+    for (slamgpu_ctx *c : g->ctx) {  // reads of one shard (flatten) follow: every shard's launch must have finished
+        HIP_TRY(hipSetDevice(c->cfg.device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+int slamgpu_dist_group_history(slamgpu_dist_group *g, double *xyt, float *neff, int32_t *resampled, int32_t *status, int32_t max_count,
+                               int32_t *count) {
+    if (!g || !count) return fail(SLAMGPU_ERR_INVALID, "null group / count");
+    if (int rc = slamgpu_dist_group_settle(g)) return rc;
+    const int k = (int) g->ctx.size();
+    int nmin = std::max(max_count, 0);
+    for (slamgpu_ctx *c : g->ctx) nmin = std::min(nmin, c->hist_n);
+    std::vector<double> raw((size_t) 4 * std::max(nmin, 1)), best((size_t) std::max(nmin, 1), -1.0e300);
+    if (xyt) std::fill(xyt, xyt + 3 * (size_t) nmin, 0.0);
+    const double n_all = (double) g->ctx[0]->B.n * k;
+    for (int i = 0; i < k; i++) {
+        int32_t got = 0;
+        // (Neff / decision / status of a stage are the same on every shard: the last shard's copy stays)
+        if (int rc = slamgpu_dist_history_fetch(g->ctx[i], raw.data(), neff, resampled, status, nmin, &got)) return rc;
+        if (got != nmin) return fail(SLAMGPU_ERR_INVALID, "shard %d recorded %d steps, expected %d", i, got, nmin);
+        if (xyt)
+            for (int t = 0; t < nmin; t++) {
+                xyt[3 * t] += raw[4 * (size_t) t];
+                xyt[3 * t + 1] += raw[4 * (size_t) t + 1];
+                if (raw[4 * (size_t) t + 3] > best[(size_t) t]) {  // strict: ties keep the lowest global index
+                    best[(size_t) t] = raw[4 * (size_t) t + 3];
+                    xyt[3 * t + 2] = raw[4 * (size_t) t + 2];
+                }
+            }
+    }
+    if (xyt)
+        for (int t = 0; t < nmin; t++) {
+            xyt[3 * t] /= n_all;
+            xyt[3 * t + 1] /= n_all;
+        }
+    *count = nmin;
+    return 0;
+}
+
+int slamgpu_dist_group_download(slamgpu_dist_group *g, float *xv, float *Pv9, float *w, float *xf, float *Pf4) {
+    if (!g) return fail(SLAMGPU_ERR_INVALID, "null group");
+    if (int rc = slamgpu_dist_group_settle(g)) return rc;
+    const size_t n = (size_t) g->ctx[0]->B.n, nf = (size_t) g->ctx[0]->nf;
+    for (size_t i = 0; i < g->ctx.size(); i++)
+        if (int rc = slamgpu_download(g->ctx[i], xv ? xv + 3 * n * i : nullptr, Pv9 ? Pv9 + 9 * n * i : nullptr, w ? w + n * i : nullptr,
+                                      xf ? xf + 2 * nf * n * i : nullptr, Pf4 ? Pf4 + 4 * nf * n * i : nullptr))
+            return rc;
+    for (slamgpu_ctx *c : g->ctx) {  // a shard's flatten reads its peers: nobody may step before everybody has read
+        HIP_TRY(hipSetDevice(c->cfg.device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     return 0;
 }
 

@@ -95,6 +95,22 @@ class TorchGather:
         self.dist.barrier()
 
 
+class NativeGather(TorchGather):
+    """One shard per rank; the all-gather runs INSIDE slamgpu_dist_step (RCCL bound by libslamgpu itself:
+    slamgpu_dist_comm_init), so a filter step is a single C call.  torch.distributed only carries the set-up (mapping
+    blobs, the RCCL unique id) and the final combination of the estimate partials."""
+
+    native = True
+
+    def connect_comm(self):
+        ids = [capi.dist_comm_id() if self.rank == 0 else None]
+        self.dist.broadcast_object_list(ids, src=0)
+        self.ctx[0].dist_comm_init(ids[0], self.world, self.rank)
+
+    def all_gather(self):
+        pass
+
+
 class DistFilter:
     """FastSLAM{1,2}::predict / ::update / computeEstimatedPosition over a particle set distributed across contexts.
 
@@ -108,6 +124,8 @@ class DistFilter:
         blobs = gather.exchange_blobs([c.dist_export() for c in self.ctx])
         for c, s in zip(self.ctx, gather.shards):
             c.dist_connect(self.G, s, blobs)
+        if hasattr(gather, "connect_comm"):
+            gather.connect_comm()
         gather.barrier()
 
     @classmethod
@@ -119,6 +137,8 @@ class DistFilter:
 
     def prepare_step(self, controls, Q, dt, zf, idf, zn, R, record_estimate=True):
         calls = [c.prepare_dist_step(controls, Q, dt, zf, idf, zn, R, record_estimate) for c in self.ctx]
+        if getattr(self.g, "native", False):
+            return calls[0]
         gather = self.g.all_gather
 
         def call():

@@ -116,3 +116,38 @@ def test_slam_backend_gated_association_builds_the_same_map(tmp_path):
     rows = np.loadtxt(log, delimiter=",", skiprows=1)
     err = np.hypot(rows[:, 4] - rows[:, 1], rows[:, 5] - rows[:, 2])
     assert np.isfinite(err).all() and err.mean() < 1.0, err.mean()
+
+
+def test_slam_backend_gpus_k_is_independent_of_k(tmp_path):
+    """slam-backend -gpus k (slamgpu_dist_group_*: one process, k shards; k above the device count = logical shards on
+    device 0): the logged estimates of the whole run must not depend on k (Philox noise: same streams whatever the
+    sharding) and must track the single-context loop."""
+    def run(k, n=4096, maxsteps=6000):
+        log = str(tmp_path / ("gpus%d.csv" % k))
+        cmd = [EXE, "-m", os.path.join(DATA, "example_webmap.mat"), "-method", "FASTSLAM2", "-NPARTICLES", str(n), "-NEFFECTIVE", str(3 * n // 4),
+               "-SWITCH_SEED_RANDOM", "7", "-log", log, "-maxsteps", str(maxsteps)] + (["-gpus", str(k)] if k else [])
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+        return r.stdout, np.loadtxt(log, delimiter=",", skiprows=1)
+    out1, single = run(0)
+    by_iter = {int(r[0]): r for r in single}
+    prev = None
+    for k in (2, 4, 8):
+        out, rows = run(k)
+        assert "over %d logical shards" % k in out or "over %d GPUs" % k in out
+        assert len(rows) >= 500
+        # against the single-context loop: that one runs every predict as a launch of its own (it reports an estimate per
+        # control step), this one folds the queued predicts into the update launch: same filter, float rounding differs, so
+        # the runs agree closely until a resample picks a different ancestor, and statistically afterwards
+        ref = np.array([by_iter[int(r[0])][4:7] for r in rows])
+        assert np.abs(rows[:8, 4:7] - ref[:8]).max() <= 1e-3, k
+        err_k = np.hypot(rows[:, 4] - rows[:, 1], rows[:, 5] - rows[:, 2]).mean()
+        err_1 = np.hypot(ref[:, 0] - rows[:, 1], ref[:, 1] - rows[:, 2]).mean()
+        assert err_k <= 1.5 * err_1 + 0.05, (k, err_k, err_1)
+        if prev is not None:
+            assert np.array_equal(prev[:, :7], rows[:, :7]), k
+        prev = rows
+    # not a multiple of 256 k: refused with the nearest valid size, nothing run
+    r = subprocess.run([EXE, "-m", os.path.join(DATA, "example_webmap.mat"), "-method", "FASTSLAM2", "-NPARTICLES", "1000", "-gpus", "2"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "multiple of 512" in r.stderr

@@ -132,3 +132,44 @@ def test_two_processes_share_one_gpu_over_hip_ipc():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dist_ipc_check.py")], cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "DIST_IPC_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("G", [1, 2, 4])
+def test_group_api_logical_shards_match_single_context(G):
+    """slamgpu_dist_group_* (what slam-backend -gpus k drives): k logical shards on this GPU, one stream, the copy-kernel
+    all-gather; no host wait anywhere in the step loop"""
+    import slam_amd as sg
+    from slam_amd import host
+    Np, nobs = 4096, 70
+    tp = host.make_tape(sim_args("example_webmap", "FASTSLAM2", Np, 3), max_obs=nobs)
+    ref, href, _ = run_single(sg, tp, Np, sg.FASTSLAM2, 1, 9)
+    g = sg.DistGroup(G, Np // G, tp["nlm"], method=sg.FASTSLAM2, n_effective=int(0.75 * Np), seed=9, math_mode=1)
+    for st in tp["steps"]:
+        g.step(np.array(st["controls"], np.float32).reshape(-1, 3), tp["Q"], float(tp["dt"]), st["zf"], st["idf"], st["zn"], tp["R"])
+    hgot = g.history_fetch()
+    got = g.download()
+    g.close()
+    same_history(href, hgot)
+    same_state(ref, got, "final")
+
+
+def test_rccl_communicator_inside_the_library_one_rank():
+    """slamgpu_dist_comm_init + the all-gather enqueued by slamgpu_dist_step itself (RCCL bound with dlopen), world size 1
+    (one GPU here); the 8-rank run is the driver's scaling bench"""
+    import slam_amd as sg
+    from slam_amd import host
+    Np, nobs = 2048, 40
+    tp = host.make_tape(sim_args("example_webmap", "FASTSLAM2", Np, 3), max_obs=nobs)
+    ref, href, _ = run_single(sg, tp, Np, sg.FASTSLAM2, 1, 9)
+    c = sg.SlamGpu(Np, tp["nlm"], method=sg.FASTSLAM2, n_effective=int(0.75 * Np), seed=9, math_mode=1, rng_mode=sg.RNG_PHILOX)
+    c.dist_connect(1, 0, [c.dist_export()])
+    c.dist_comm_init(sg.dist_comm_id(), 1, 0)
+    for st in tp["steps"]:
+        c.dist_step(np.array(st["controls"], np.float32).reshape(-1, 3), tp["Q"], float(tp["dt"]), st["zf"], st["idf"], st["zn"], tp["R"])
+    c.dist_settle()
+    raw, neff, res, _ = c.shard_estimate_fetch_full()
+    got = c.download()
+    c.close()
+    assert np.array_equal(neff, href[1]) and np.array_equal(res.astype(bool), href[2])
+    assert np.allclose(raw[:, :2] / Np, href[0][:, :2], rtol=0, atol=1e-12)
+    same_state(ref, got, "final")
