@@ -120,7 +120,7 @@ class DistFilter:
     def __init__(self, contexts, gather):
         self.ctx, self.g = list(contexts), gather
         self.G = gather.world
-        self.n = self.ctx[0].N
+        self.n = getattr(self.ctx[0], "n_local", None) or self.ctx[0].N  # particles per shard
         blobs = gather.exchange_blobs([c.dist_export() for c in self.ctx])
         for c, s in zip(self.ctx, gather.shards):
             c.dist_connect(self.G, s, blobs)
