@@ -727,13 +727,21 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             B.lmkB[0][(size_t) j * S + i] = lb;
         };
 
-        const int32_t *__restrict__ idf, *__restrict__ lrow;
-        const float *__restrict__ zf, *__restrict__ zn;
-        if (BIG) {
-            idf = reinterpret_cast<const int32_t *>(U.big + 1);
-            zf = reinterpret_cast<const float *>(idf + m);
+        // BIG: the packet sits in device memory, written before the launch and never during it: read it through the
+        // constant address space, so that the (uniform) per-landmark reads become scalar loads.  As plain global pointers
+        // they were VECTOR loads, and the s_waitcnt vmcnt(0) in front of their first use also waited for every record
+        // prefetch and record store in flight: the software pipeline below never overlapped anything
+        // (profiles/update_kernel_levels_r02_c5_*.txt: 0.78 + 1.18 us per landmark before, both passes).
+        using IdxP = std::conditional_t<BIG, const __attribute__((address_space(4))) int32_t *, const int32_t *>;
+        using FltP = std::conditional_t<BIG, const __attribute__((address_space(4))) float *, const float *>;
+        IdxP idf, lrow;
+        FltP zf, zn;
+        if constexpr (BIG) {
+            const int32_t *gi = reinterpret_cast<const int32_t *>(U.big + 1);
+            idf = (IdxP) reinterpret_cast<uintptr_t>(gi);
+            zf = (FltP) reinterpret_cast<uintptr_t>(gi + m);
             zn = zf + 2 * m;
-            lrow = packet_row(U);
+            lrow = (IdxP) reinterpret_cast<uintptr_t>(packet_row(U));
         } else {
             idf = U.small.idf;
             zf = U.small.zf;
