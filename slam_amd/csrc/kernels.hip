@@ -510,7 +510,10 @@ SLAM_DEV const int32_t *packet_rows(const UpdateArgs &U) { return packet_row(U) 
 // kBigChunk landmarks: while a chunk is computed out of LDS the next chunk's records are in flight into registers and
 // the genealogy slots of the chunk after that behind them, so a wave has ~2 x kBigChunk x 20 B per lane outstanding
 // instead of one dependent slot -> record round trip per landmark.
-constexpr int kBigChunk = 8;
+#ifndef SLAM_BIG_CHUNK
+#define SLAM_BIG_CHUNK 8
+#endif
+constexpr int kBigChunk = SLAM_BIG_CHUNK;
 constexpr int kStage = 8;  // landmarks per particle kept in LDS between the two passes of a small packet
 
 // staged landmark slots per thread of an update launch (host and device agree on the dynamic LDS layout)
@@ -564,6 +567,19 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     const int cur = ctrl->live[B.slot];
     const int nb = ws.nblocks;
     const bool helper = blockIdx.x == gridDim.x - 1 && (int) blockIdx.x >= nb;
+    // XCD-aware tile mapping.  Workgroups go round-robin to the 8 XCDs (workgroup b -> XCD b % 8) and every XCD has an L2
+    // of its own, so with tile = workgroup the 256 particles next to a tile always belong to another XCD: after a resample
+    // the ancestor's pose, genealogy and records -- written one launch ago by a neighbouring tile -- missed this XCD's L2
+    // and came over the fabric (pose level +2.2 us against +0.6 us for the particle's own slot,
+    // profiles/update_kernel_levels_r02_mid_N100000.txt).  Tile bt = the j-th tile of XCD x's contiguous range of the
+    // particle set instead: stratified ancestors are near i, so they were written by this XCD.
+    int bt = (int) blockIdx.x;
+#ifndef SLAM_NO_XCD_TILES
+    if (bt < nb) {
+        const int x = bt & 7, j = bt >> 3, q = nb >> 3, r = nb & 7;
+        bt = x < r ? x * (q + 1) + j : r * (q + 1) + (x - r) * q + j;
+    }
+#endif
     SLAM_STAMP(1);  // Ctrl words arrived
     // Where does particle i of the set this update works on come from?
     //   plan_inline: the resampling stage of the previous update has not run: every block redoes its scan of the block
@@ -647,7 +663,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         if (BIG && pend) copy_genealogy(B, packet_rows(U), U.n_rows, U.rows_per_role, ws, cur, U.copy_lo + (int) blockIdx.x - nb, ancestor);
         return;
     }
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int i = bt * kBlock + threadIdx.x;
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     // select (not index) the buffers: an indexed read of the pointer table in the kernel-argument segment
     // would be one more dependent scalar load at the head of every wave
@@ -827,7 +843,13 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                     load_slots(k0 + 2 * CH);  // (clamped: harmless re-reads past the end)
                 }
                 const int kn = min(CH, m - k0);
+#ifdef SLAM_BIG_UNROLL
+#pragma unroll
+                for (int k = 0; k < CH; k++)
+                    if (k < kn) body(k0 + k, shA[(k) * kBlock + threadIdx.x], shB[(k) * kBlock + threadIdx.x]);
+#else
                 for (int k = 0; k < kn; k++) body(k0 + k, shA[(k) * kBlock + threadIdx.x], shB[(k) * kBlock + threadIdx.x]);
+#endif
             }
         };
 
@@ -1182,7 +1204,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     if (U.plan_inline) {
         ei_prev = block_reduce_est(ei_prev, sh_est);
         if (threadIdx.x == 0) {
-            double *p = ws.est_part[ws.wpar ^ 1] + (size_t) blockIdx.x * 4;
+            double *p = ws.est_part[ws.wpar ^ 1] + (size_t) bt * 4;
             p[0] = ei_prev.sx;
             p[1] = ei_prev.sy;
             p[2] = (double) ei_prev.th;
@@ -1199,7 +1221,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         __syncthreads();
         mb = fmaxf(fmaxf(sh_w[0], sh_w[1]), fmaxf(sh_w[2], sh_w[3]));
         __syncthreads();
-        if (threadIdx.x == 0) ws.blk_w[ws.wpar][2 * ws.nblocks + blockIdx.x] = mb;
+        if (threadIdx.x == 0) ws.blk_w[ws.wpar][2 * ws.nblocks + bt] = mb;
         w = (w == -INFINITY) ? 0.0f : expf(w - mb);  // NaN log-weights stay NaN and are flagged by the plan (status)
     }
     // in-block inclusive prefix of w; block totals of w and of w^2 (fixed association: deterministic).  The sum of squares
@@ -1220,7 +1242,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     for (int k = 0; k < kBlock / kWave; k++)
         if (k < wv) base += sh_w[k];
     ws.lcum[ws.wpar][i] = base + s;
-    if ((threadIdx.x & 15) == 15) ws.piv[ws.wpar][(size_t) blockIdx.x * 16 + (threadIdx.x >> 4)] = base + s;
+    if ((threadIdx.x & 15) == 15) ws.piv[ws.wpar][(size_t) bt * 16 + (threadIdx.x >> 4)] = base + s;
     if (threadIdx.x == kBlock - 1) {
         const float T = base + s;
         float q = 0.0f;
@@ -1231,8 +1253,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                 q += sh_w2[k] * (f * f);
             }
         }
-        ws.blk_w[ws.wpar][blockIdx.x] = T;
-        ws.blk_w[ws.wpar][ws.nblocks + blockIdx.x] = q;
+        ws.blk_w[ws.wpar][bt] = T;
+        ws.blk_w[ws.wpar][ws.nblocks + bt] = q;
     }
     SLAM_STAMP(9);  // weight prefix + totals written: end of the block
 }
