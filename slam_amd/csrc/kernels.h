@@ -51,6 +51,7 @@ constexpr int kHistStride = 6;      // doubles per pose-estimate history entry: 
 constexpr int kMaxScanBlocks = 8192;
 constexpr int kPivLdsBlocks = 512;   // contexts up to this many blocks (131 072 particles) keep the pivot table in LDS (32 KB)
 // status bits of an update's resampling stage (slamgpu.h: SLAMGPU_STATUS_*)
+constexpr int kStatusBadPacket = 2;   // the kernel did not find its packet where the kernel-argument layout says (never seen)
 constexpr int kStatusDegenerate = 1;  // sum of the weights zero or not finite: the reference normalises to NaN (core.cpp:726-729)  // block totals scanned inside every resample block (LDS)
 
 // Ctrl.live / Ctrl.pend are double-buffered by a host-side slot number (Buffers::slot): a kernel that changes the
@@ -148,7 +149,11 @@ struct SmallObs {           // compact contexts: the packet travels in the kerne
     int32_t row[kSmallObs];          // genealogy row (| live record buffer << 30) of each re-observed landmark before this update
     float zf[2 * kSmallObs];
     float zn[2 * kSmallObs];
+    uint32_t magic, pad;             // kSmallMagic: the update kernel copies this struct out of its kernel-argument segment
+                                     // with vector loads at a computed offset and refuses to run on anything else
 };
+constexpr uint32_t kSmallMagic = 0x534c414du;
+constexpr int kSmallWords = (int) (sizeof(SmallObs) / 4);
 
 struct RngArgs {
     int32_t mode;            // 0 tape, 1 philox

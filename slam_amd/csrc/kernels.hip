@@ -291,38 +291,49 @@ struct NoOp {
 // after_loads(): called once this function's own global loads have been requested (contexts of at most 512 blocks: at
 // most two totals per thread) -- the place for a caller to request data it needs AFTER the scan (the update kernel's
 // pivot table), so that it queues behind the totals on the in-order return path instead of in front of them.
-template <class After = NoOp>
-SLAM_DEV void scan_block_totals(const float *__restrict__ tot, int nb, int nbl, bool logw, double *off, double *sh_a,
-                                double *sh_q, double &W, double &Q, double &M, After after_loads = After()) {
+// The loads of the scan (contexts of at most 512 blocks: at most two totals per thread), separated from the arithmetic so
+// that a caller can request them before anything else (update_kernel: at kernel entry, from preloaded arguments).
+struct ScanLoads {
+    float tv0, tv1, qv0, qv1, mv0, mv1;
+};
+SLAM_DEV int scan_at(int k, int nb, int nbl, bool logw) {
+    // (one shard: nbl == nb and the index is k itself; the general form costs two integer divisions per entry)
+    return nbl == nb ? k : (k / nbl) * (logw ? 3 : 2) * nbl + (k % nbl);
+}
+SLAM_DEV ScanLoads scan_issue(const float *__restrict__ tot, int nb, int nbl, bool logw) {
+    const int t = threadIdx.x;
+    const int per = (nb + kBlock - 1) / kBlock;
+    const int lo = min(nb, t * per), hi = min(nb, lo + per);
+    // (named scalars, not arrays: a register array indexed by k - lo would be demoted to scratch)
+    ScanLoads L{0.0f, 0.0f, 0.0f, 0.0f, -INFINITY, -INFINITY};
+    if (per <= 2) {
+        if (lo < hi) {
+            const int at = scan_at(lo, nb, nbl, logw);
+            L.tv0 = tot[at];
+            L.qv0 = tot[at + nbl];
+            if (logw) L.mv0 = tot[at + 2 * nbl];
+        }
+        if (lo + 1 < hi) {
+            const int at = scan_at(lo + 1, nb, nbl, logw);
+            L.tv1 = tot[at];
+            L.qv1 = tot[at + nbl];
+            if (logw) L.mv1 = tot[at + 2 * nbl];
+        }
+    }
+    return L;
+}
+
+SLAM_DEV void scan_finish(const ScanLoads L, const float *__restrict__ tot, int nb, int nbl, bool logw, double *off, double *sh_a,
+                          double *sh_q, double &W, double &Q, double &M) {
     const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
     const int per = (nb + kBlock - 1) / kBlock;
     const int lo = min(nb, t * per), hi = min(nb, lo + per);
-    const int rows = logw ? 3 : 2;
     const bool two = per <= 2;
-    // (named scalars, not arrays: a register array indexed by k - lo would be demoted to scratch)
-    float tv0 = 0.0f, tv1 = 0.0f, qv0 = 0.0f, qv1 = 0.0f, mv0 = -INFINITY, mv1 = -INFINITY;
-    // (one shard: nbl == nb and the index is k itself; the general form costs two integer divisions per entry)
-    const bool one = nbl == nb;
-    auto at_of = [&](int k) { return one ? k : (k / nbl) * rows * nbl + (k % nbl); };
-    if (two) {
-        if (lo < hi) {
-            const int at = at_of(lo);
-            tv0 = tot[at];
-            qv0 = tot[at + nbl];
-            if (logw) mv0 = tot[at + 2 * nbl];
-        }
-        if (lo + 1 < hi) {
-            const int at = at_of(lo + 1);
-            tv1 = tot[at];
-            qv1 = tot[at + nbl];
-            if (logw) mv1 = tot[at + 2 * nbl];
-        }
-    }
-    after_loads();
+    auto at_of = [&](int k) { return scan_at(k, nb, nbl, logw); };
     M = 0.0;
     if (logw) {
         float mx = -INFINITY;
-        if (two) mx = fmaxf(mv0, mv1);
+        if (two) mx = fmaxf(L.mv0, L.mv1);
         else
             for (int k = lo; k < hi; k++) mx = fmaxf(mx, tot[at_of(k) + 2 * nbl]);
 #pragma unroll
@@ -341,8 +352,8 @@ SLAM_DEV void scan_block_totals(const float *__restrict__ tot, int nb, int nbl, 
         q += (double) qk_f * (tk * tk);  // second row: sum (w_i / T)^2 of the block (update_kernel's tail)
     };
     if (two) {
-        if (lo < hi) acc(lo, tv0, qv0, mv0);
-        if (lo + 1 < hi) acc(lo + 1, tv1, qv1, mv1);
+        if (lo < hi) acc(lo, L.tv0, L.qv0, L.mv0);
+        if (lo + 1 < hi) acc(lo + 1, L.tv1, L.qv1, L.mv1);
     } else {
         for (int k = lo; k < hi; k++) {
             const int at = at_of(k);
@@ -367,6 +378,14 @@ SLAM_DEV void scan_block_totals(const float *__restrict__ tot, int nb, int nbl, 
     W = ((sh_a[0] + sh_a[1]) + sh_a[2]) + sh_a[3];
     Q = ((sh_q[0] + sh_q[1]) + sh_q[2]) + sh_q[3];
     if (t == 0) off[nb] = W;
+}
+
+template <class After = NoOp>
+SLAM_DEV void scan_block_totals(const float *__restrict__ tot, int nb, int nbl, bool logw, double *off, double *sh_a,
+                                double *sh_q, double &W, double &Q, double &M, After after_loads = After()) {
+    const ScanLoads L = scan_issue(tot, nb, nbl, logw);
+    after_loads();
+    scan_finish(L, tot, nb, nbl, logw, off, sh_a, sh_q, W, Q, M);
 }
 
 // Neff = W^2 / Q, the same expression in every kernel, block and shard (the decision must be identical everywhere): one
@@ -526,9 +545,18 @@ __host__ __device__ inline int staging_slots(int method, bool big, int m) {
 // MODE 0: single context.  MODE 1 (ARR): legacy shard context (arrival pool).  MODE 2 (DIST): distributed context: the
 // particle set spans several GPUs whose state arrays are all mapped here (Buffers::peers); the plan runs over the
 // all-gathered block totals of every shard, and whatever an ancestor owns on another GPU is read in place.
+// The leading scalar parameters repeat what the HEAD of the kernel's dependent chain needs (the previous step's block
+// totals and pivots, the Ctrl words, the launch shape) as plain pointers / ints, fetched with the first scalar load of the
+// kernel: the loads of the scan, the pivot table and the packet are requested at once, before any field of the argument
+// structs is looked at (the compiler fetches those where they are first used: five to six dependent scalar round trips
+// stood between kernel entry and the first vector load before; 16.7 -> 16.05 us per step at 10^5 particles).
+// Tried on top and measured as no better (gpurun_out/ab, 16.28 / 16.10 / 16.04 us): preloading these arguments into SGPRs
+// (-mllvm -amdgpu-kernarg-preload-count=16) and touching every 64-byte line of the argument segment at entry.
+//   h_flags: bit 0 plan_inline, bit 1 scan_global, bit 2 logw, bit 3 lazy
 template <int METHOD, int MODE, bool BIG>
-__global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs PA, UpdateArgs U, RngArgs rng,
-                                                         WeightScratch ws) {
+__global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict__ h_tot, const float *__restrict__ h_piv, Ctrl *h_ctrl,
+                                                         int h_nb, int h_slot, int h_grid, int h_flags, Buffers B, PredictArgs PA,
+                                                         UpdateArgs U, RngArgs rng, WeightScratch ws) {
     constexpr bool ARR = MODE == 1, DIST = MODE == 2;
     __shared__ float sh_w[kBlock / kWave], sh_w2[kBlock / kWave];
     // landmarks re-observed this step, staged between the proposal pass and the likelihood/feature-update pass
@@ -537,25 +565,30 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     // then -- inline plan only -- [nblocks + 1] doubles: exclusive prefix of the previous step's block totals.  Sizing the
     // staging by the packet (0 / 4 / 8 landmarks) instead of a static 40 KB keeps 5-8 blocks per CU resident at the
     // webmap's 3.5 landmarks per step instead of 3.
+    // Layout (every offset a function of the preloaded head arguments only, so that the scan can start before the argument
+    // structs have arrived): [prefix of the block totals][pivot table][staged records A][staged records B]
     extern __shared__ __align__(16) unsigned char dyn_lds[];
-    const int nslots = staging_slots(METHOD, BIG, U.m);
-    float4 *const shA = reinterpret_cast<float4 *>(dyn_lds);
-    float *const shB = reinterpret_cast<float *>(dyn_lds + (size_t) nslots * kBlock * sizeof(float4));
-    double *const off = reinterpret_cast<double *>(dyn_lds + (size_t) nslots * kBlock * (sizeof(float4) + sizeof(float)));
+    const int nbg = DIST ? h_nb * B.n_shards : h_nb;  // blocks of the whole particle set
+    const bool h_plan = (h_flags & 1) != 0, h_scan_global = (h_flags & 2) != 0;
+    const bool piv_in_lds = !DIST && h_plan && !h_scan_global && h_nb <= kPivLdsBlocks;
+    double *const off = reinterpret_cast<double *>(dyn_lds);
+    const size_t off_bytes = (h_plan && !h_scan_global) ? sizeof(double) * (((size_t) nbg + 3) & ~(size_t) 1) : 0;
     // ... then, inline plan of a context of at most kPivLdsBlocks blocks: [16 * nblocks] floats, the pivot table of the
     // previous step's in-block prefixes (WeightScratch::piv), requested at kernel entry together with the block totals
-    const int nbg = DIST ? ws.nblocks * B.n_shards : ws.nblocks;  // blocks of the whole particle set
-    const bool piv_in_lds = !DIST && U.plan_inline && !U.scan_global && ws.nblocks <= kPivLdsBlocks;
-    float *const pivs = reinterpret_cast<float *>(off + (((size_t) nbg + 3) & ~(size_t) 1));  // 16-byte aligned
+    float *const pivs = reinterpret_cast<float *>(dyn_lds + off_bytes);  // 16-byte aligned
+    const size_t piv_bytes = piv_in_lds ? sizeof(float) * 16 * (size_t) h_nb : 0;
+    float4 *const shA = reinterpret_cast<float4 *>(dyn_lds + off_bytes + piv_bytes);
+    const int nslots = staging_slots(METHOD, BIG, U.m);
+    float *const shB = reinterpret_cast<float *>(dyn_lds + off_bytes + piv_bytes + (size_t) nslots * kBlock * sizeof(float4));
     constexpr int kPivPerThread = kPivLdsBlocks * 16 / 4 / kBlock;  // float4 per thread at the largest table
     float4 pvreg[kPivPerThread];
     auto request_pivots = [&]() {
         if (piv_in_lds) {
-            const float4 *src = reinterpret_cast<const float4 *>(ws.piv[ws.wpar ^ 1]);
+            const float4 *src = reinterpret_cast<const float4 *>(h_piv);
 #pragma unroll
             for (int t = 0; t < kPivPerThread; t++) {
                 const int at = t * kBlock + (int) threadIdx.x;
-                pvreg[t] = at < ws.nblocks * 4 ? src[at] : make_float4(0.f, 0.f, 0.f, 0.f);
+                pvreg[t] = at < h_nb * 4 ? src[at] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
@@ -563,16 +596,42 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     __shared__ EstItem sh_est[kBlock / kWave];
     SLAM_STAMP(0);  // kernel entry
     const size_t S = (size_t) B.ncap;
-    Ctrl *ctrl = B.ctrl;
-    const int cur = ctrl->live[B.slot];
-    const int nb = ws.nblocks;
-    const bool helper = blockIdx.x == gridDim.x - 1 && (int) blockIdx.x >= nb;
+    Ctrl *ctrl = h_ctrl;
+    const int nb = h_nb;
+    const bool helper = (int) blockIdx.x == h_grid - 1 && (int) blockIdx.x >= nb;
     // XCD-aware tile mapping.  Workgroups go round-robin to the 8 XCDs (workgroup b -> XCD b % 8) and every XCD has an L2
     // of its own, so with tile = workgroup the 256 particles next to a tile always belong to another XCD: after a resample
     // the ancestor's pose, genealogy and records -- written one launch ago by a neighbouring tile -- missed this XCD's L2
     // and came over the fabric (pose level +2.2 us against +0.6 us for the particle's own slot,
     // profiles/update_kernel_levels_r02_mid_N100000.txt).  Tile bt = the j-th tile of XCD x's contiguous range of the
     // particle set instead: stratified ancestors are near i, so they were written by this XCD.
+    // Compact contexts: the packet rides in the kernel-argument segment (no staging copy on the stream).  Reading it there
+    // element by element (U.small.idf[k] ...) means a scalar load per access into a scalar cache that is cold at every
+    // launch: 18 % of the kernel's scalar requests waited on a miss (SQC_DCACHE_MISSES + _DUPLICATE,
+    // profiles/rocprof_sq_counters_r02_c3_*.txt), ~14 per wave, each a trip to L2 / memory in the middle of the dependent
+    // chain.  Instead: ONE coalesced vector load of the whole struct at kernel entry, in flight together with the block
+    // totals, parked in LDS; the per-landmark reads below are LDS broadcasts.
+    // HEAD: everything whose address follows from the preloaded arguments is requested now, in one burst
+    const bool logw = (h_flags & 4) != 0;
+    const bool do_scan = h_plan && !h_scan_global;
+    ScanLoads scl{0.0f, 0.0f, 0.0f, 0.0f, -INFINITY, -INFINITY};
+    if (do_scan) {
+        scl = scan_issue(h_tot, nbg, h_nb, logw);
+        request_pivots();
+    }
+    __shared__ int32_t pk[kSmallWords];
+    int32_t pkv = 0;
+#ifndef SLAM_NO_PK_LDS
+    if constexpr (!BIG) {
+        constexpr size_t a0 = (40 + sizeof(Buffers) + alignof(PredictArgs) - 1) / alignof(PredictArgs) * alignof(PredictArgs);  // (40: the head)
+        constexpr size_t a1 = (a0 + sizeof(PredictArgs) + alignof(UpdateArgs) - 1) / alignof(UpdateArgs) * alignof(UpdateArgs);
+        constexpr size_t at = (a1 + offsetof(UpdateArgs, small)) / 4;  // dword offset of U.small in the kernel arguments
+        const auto *ka = (const __attribute__((address_space(4))) int32_t *) __builtin_amdgcn_kernarg_segment_ptr();
+        if (threadIdx.x < kSmallWords) pkv = ka[at + threadIdx.x];  // (parked in LDS below, once the scan's loads are out too)
+    }
+#endif
+    const int cur = h_ctrl->live[h_slot];  // ... and the Ctrl words
+    const bool pend_word = h_ctrl->pend[h_slot] != 0;
     int bt = (int) blockIdx.x;
 #ifndef SLAM_NO_XCD_TILES
     if (bt < nb) {
@@ -587,20 +646,19 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
     //                (core.cpp:718-749, :800-806); no resample: slot i, weight w / sum(w) (core.cpp:726-729);
     //   otherwise  : resample_kernel ran: slot keep[i] of the live buffers if it left a gather pending, else slot i.
     // Either way a gathered particle is written to slot i of the OTHER pose / genealogy buffers.
-    bool pend = U.lazy && ctrl->pend[B.slot] != 0;
+    bool pend = (h_flags & 8) && pend_word;
     double W = 1.0, Mx = 0.0;
-    const bool logw = U.logw != 0;
     // large contexts: the prefix comes from scan_kernel (same function, same association, run once) instead of being
     // redone by every block -- O(N^2 / 65 536) otherwise
-    const double *offp = U.scan_global ? ws.scan[ws.wpar ^ 1] : off;
-    if (U.plan_inline && !helper) {
+    const double *offp = h_scan_global ? ws.scan[ws.wpar ^ 1] : off;
+    if (h_plan && !helper) {
         double Q;
-        if (U.scan_global) {
+        if (h_scan_global) {
             W = offp[nb + 1];
             Q = offp[nb + 2];
             Mx = offp[nb + 3];
         } else {
-            scan_block_totals(DIST ? B.gtot[ws.wpar ^ 1] : ws.blk_w[ws.wpar ^ 1], nbg, nb, logw, off, sh_a, sh_q, W, Q, Mx, request_pivots);
+            scan_finish(scl, h_tot, nbg, nb, logw, off, sh_a, sh_q, W, Q, Mx);
         }
         const float neff = neff_of(W, Q);  // Neff = 1 / sum((w/W)^2)  (core.cpp:784-788)
         pend = U.do_resample && (neff < (float) U.n_effective);
@@ -649,7 +707,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
                     W = offp[nb + 1];
                     Q = offp[nb + 2];
                 } else {
-                    scan_block_totals(DIST ? B.gtot[ws.wpar ^ 1] : ws.blk_w[ws.wpar ^ 1], nbg, nb, logw, off, sh_a, sh_q, W, Q, Mx);
+                    scan_finish(scl, h_tot, nbg, nb, logw, off, sh_a, sh_q, W, Q, Mx);
                 }
                 pend = U.do_resample && (neff_of(W, Q) < (float) U.n_effective);
             }
@@ -663,6 +721,16 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
         if (BIG && pend) copy_genealogy(B, packet_rows(U), U.n_rows, U.rows_per_role, ws, cur, U.copy_lo + (int) blockIdx.x - nb, ancestor);
         return;
     }
+#ifndef SLAM_NO_PK_LDS
+    if constexpr (!BIG) {
+        if (threadIdx.x < kSmallWords) pk[threadIdx.x] = pkv;
+        __syncthreads();
+        if ((uint32_t) pk[offsetof(SmallObs, magic) / 4] != kSmallMagic) {  // (layout guard: never seen)
+            if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->status = kStatusBadPacket;
+            return;
+        }
+    }
+#endif
     const int i = bt * kBlock + threadIdx.x;
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     // select (not index) the buffers: an indexed read of the pointer table in the kernel-argument segment
@@ -759,10 +827,17 @@ __global__ void __launch_bounds__(kBlock) update_kernel(Buffers B, PredictArgs P
             zn = zf + 2 * m;
             lrow = (IdxP) reinterpret_cast<uintptr_t>(packet_row(U));
         } else {
+#ifndef SLAM_NO_PK_LDS
+            idf = pk + offsetof(SmallObs, idf) / 4;
+            lrow = pk + offsetof(SmallObs, row) / 4;
+            zf = reinterpret_cast<const float *>(pk + offsetof(SmallObs, zf) / 4);
+            zn = reinterpret_cast<const float *>(pk + offsetof(SmallObs, zn) / 4);
+#else
             idf = U.small.idf;
             zf = U.small.zf;
             zn = U.small.zn;
             lrow = U.small.row;
+#endif
         }
         // re-observed landmark k of this particle: the slot comes from the genealogy row the landmark uses (kernels.h:
         // gen), the buffer from the row's live flag; a landmark this update writes goes to the particle's OWN slot of the
@@ -1968,7 +2043,12 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
                        ((U.plan_inline && !U.scan_global) ? sizeof(double) * ((nbg + 3) & ~(size_t) 1) : 0) +
                        ((U.arrivals != 2 && U.plan_inline && !U.scan_global && ws.nblocks <= kPivLdsBlocks) ? sizeof(float) * 16 * (size_t) ws.nblocks : 0);
     const int sel = (U.method == 2 ? 6 : 0) + 2 * U.arrivals + (U.big ? 1 : 0);
-#define SLAM_LAUNCH_UPDATE(M, A, G) hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, B, PA, U, rng, ws)
+    const float *h_tot = U.arrivals == 2 ? B.gtot[ws.wpar ^ 1] : ws.blk_w[ws.wpar ^ 1];
+    const float *h_piv = ws.piv[ws.wpar ^ 1];
+    const int h_flags = (U.plan_inline ? 1 : 0) | (U.scan_global ? 2 : 0) | (U.logw ? 4 : 0) | (U.lazy ? 8 : 0);
+#define SLAM_LAUNCH_UPDATE(M, A, G)                                                                                              \
+    hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, h_tot, h_piv, B.ctrl, ws.nblocks, B.slot, grid, \
+                       h_flags, B, PA, U, rng, ws)
     switch (sel) {
         case 11: SLAM_LAUNCH_UPDATE(2, 2, true); break;
         case 10: SLAM_LAUNCH_UPDATE(2, 2, false); break;

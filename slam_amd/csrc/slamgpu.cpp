@@ -790,6 +790,7 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
             U.small.zn[2 * k] = zn[2 * k];
             U.small.zn[2 * k + 1] = zn[2 * k + 1];
         }
+        U.small.magic = kSmallMagic;
         U.big = nullptr;
     } else {
         const int slot = (int) (c->pkt_seq++ % kRing);
