@@ -355,9 +355,30 @@ SLAM_DEV void scan_finish(const ScanLoads L, const float *__restrict__ tot, int 
         if (lo < hi) acc(lo, L.tv0, L.qv0, L.mv0);
         if (lo + 1 < hi) acc(lo + 1, L.tv1, L.qv1, L.mv1);
     } else {
-        for (int k = lo; k < hi; k++) {
-            const int at = at_of(k);
-            acc(k, tot[at], tot[at + nbl], logw ? tot[at + 2 * nbl] : 0.0f);
+        // (gathered tables of several shards: [shard][w(nbl) | q(nbl) (| m(nbl))]: walk the index instead of dividing per
+        // entry, and request a thread's whole segment before using any of it)
+        const int rows = logw ? 3 : 2;
+        int sh = lo < hi ? lo / nbl : 0, r = lo < hi ? lo - sh * nbl : 0;
+        for (int k0 = lo; k0 < hi; k0 += 4) {
+            float tk[4], qk[4], mk[4];
+            int shq = sh, rq = r;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool on = k0 + u < hi;
+                const int at = on ? shq * rows * nbl + rq : 0;
+                tk[u] = on ? tot[at] : 0.0f;
+                qk[u] = on ? tot[at + nbl] : 0.0f;
+                mk[u] = (on && logw) ? tot[at + 2 * nbl] : 0.0f;
+                if (++rq == nbl) {
+                    rq = 0;
+                    shq++;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (k0 + u < hi) acc(k0 + u, tk[u], qk[u], mk[u]);
+            sh = shq;
+            r = rq;
         }
     }
     const double sa = wave_scan_d(a);

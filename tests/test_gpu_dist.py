@@ -173,3 +173,16 @@ def test_rccl_communicator_inside_the_library_one_rank():
     assert np.array_equal(neff, href[1]) and np.array_equal(res.astype(bool), href[2])
     assert np.allclose(raw[:, :2] / Np, href[0][:, :2], rtol=0, atol=1e-12)
     same_state(ref, got, "final")
+
+
+def test_logical_shards_beyond_two_totals_per_thread():
+    """more than 512 blocks in the gathered table: the scan walks several totals per thread across shard boundaries"""
+    import slam_amd as sg
+    from slam_amd import host
+    Np, nobs = 536 * 256, 40
+    tp = host.make_tape(sim_args("example_webmap", "FASTSLAM2", Np, 3), max_obs=nobs)
+    ref, href, _ = run_single(sg, tp, Np, sg.FASTSLAM2, 1, 9)
+    got, hgot, _ = run_dist(sg, tp, Np, 4, sg.FASTSLAM2, 1, 9)
+    assert href[2].sum() >= 3
+    same_history(href, hgot)
+    same_state(ref, got, "final")
