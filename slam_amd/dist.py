@@ -103,8 +103,15 @@ class NativeGather(TorchGather):
     native = True
 
     def connect_comm(self):
-        ids = [capi.dist_comm_id() if self.rank == 0 else None]
+        ids = [None]
+        if self.rank == 0:
+            try:
+                ids = [capi.dist_comm_id()]
+            except Exception as e:  # noqa: BLE001 (every rank learns about it below)
+                ids = ["error: %s" % e]
         self.dist.broadcast_object_list(ids, src=0)
+        if not isinstance(ids[0], bytes):
+            raise RuntimeError("distributed set-up: no RCCL unique id (%s)" % ids[0])
         self.ctx[0].dist_comm_init(ids[0], self.world, self.rank)
 
     def all_gather(self):
@@ -121,12 +128,32 @@ class DistFilter:
         self.ctx, self.g = list(contexts), gather
         self.G = gather.world
         self.n = getattr(self.ctx[0], "n_local", None) or self.ctx[0].N  # particles per shard
-        blobs = gather.exchange_blobs([c.dist_export() for c in self.ctx])
+        # every step of the set-up is collective: a rank that fails must still take part in the exchange, and all ranks
+        # leave together (an exception on one rank alone would leave the others waiting in a collective forever)
+        mine, err = [], None
+        for c in self.ctx:
+            try:
+                mine.append(c.dist_export())
+            except Exception as e:  # noqa: BLE001
+                mine.append(None)
+                err = err or e
+        blobs = gather.exchange_blobs(mine)
+        if any(b is None for b in blobs):
+            raise RuntimeError("distributed set-up: a shard could not export its state arrays (%s)" % (err or "on another rank"))
         for c, s in zip(self.ctx, gather.shards):
-            c.dist_connect(self.G, s, blobs)
+            try:
+                c.dist_connect(self.G, s, blobs)
+            except Exception as e:  # noqa: BLE001
+                err = err or e
+        if not self._agree(err is None):
+            raise RuntimeError("distributed set-up: a shard could not map its peers (%s)" % (err or "on another rank"))
         if hasattr(gather, "connect_comm"):
             gather.connect_comm()
         gather.barrier()
+
+    def _agree(self, ok):
+        flags = self.g.exchange_blobs([bytes([1 if ok else 0])] * len(self.ctx))
+        return all(f == bytes([1]) for f in flags)
 
     @classmethod
     def local(cls, n_shards, n_per_shard, max_landmarks, devices=None, **kw):
