@@ -550,8 +550,10 @@ SLAM_DEV const int32_t *packet_rows(const UpdateArgs &U) { return packet_row(U) 
 // kBigChunk landmarks: while a chunk is computed out of LDS the next chunk's records are in flight into registers and
 // the genealogy slots of the chunk after that behind them, so a wave has ~2 x kBigChunk x 20 B per lane outstanding
 // instead of one dependent slot -> record round trip per landmark.
+// (measured at config 5, gpurun_out/var: 4 and 8 landmarks per chunk run the same 1.61 ms per step, 12 and 16 are slower;
+// 4 keeps the kernel at 103 / 110 VGPRs (fast / strict build: 4 waves per SIMD) and 20 KB of LDS per block, 8 needs 134 / 143)
 #ifndef SLAM_BIG_CHUNK
-#define SLAM_BIG_CHUNK 8
+#define SLAM_BIG_CHUNK 4
 #endif
 constexpr int kBigChunk = SLAM_BIG_CHUNK;
 constexpr int kStage = 8;  // landmarks per particle kept in LDS between the two passes of a small packet
