@@ -186,3 +186,23 @@ def test_logical_shards_beyond_two_totals_per_thread():
     assert href[2].sum() >= 3
     same_history(href, hgot)
     same_state(ref, got, "final")
+
+
+def test_logical_shards_at_the_scaling_bench_size():
+    """the driver's N=8 scaling run in miniature time but at full width: 8 shards x 100 096 particles (3 128 gathered block
+    totals scanned in LDS by every block, the 25 KB prefix beside the staged records) against one context of 800 768"""
+    import slam_amd as sg
+    from slam_amd import host
+    G, n, nobs = 8, 100096, 45
+    Np = G * n
+    tp = host.make_tape(sim_args("example_webmap", "FASTSLAM2", Np, 7), max_obs=nobs)
+    ref, href, _ = run_single(sg, tp, Np, sg.FASTSLAM2, 1, 7)
+    g = sg.DistGroup(G, n, tp["nlm"], method=sg.FASTSLAM2, n_effective=int(0.75 * Np), seed=7, math_mode=1)
+    for st in tp["steps"]:
+        g.step(np.array(st["controls"], np.float32).reshape(-1, 3), tp["Q"], float(tp["dt"]), st["zf"], st["idf"], st["zn"], tp["R"])
+    hgot = g.history_fetch()
+    got = g.download()
+    g.close()
+    assert href[2].sum() >= 3
+    same_history(href, hgot)
+    same_state(ref, got, "final")
