@@ -60,9 +60,9 @@ def sym(P):
 #   fast   (1): the same step algebraically restructured (device_math.h, fast section).  It cannot replay the
 #               reference's roundings, and FastSLAM2's weights amplify rounding: nudging every stored float of the
 #               predicted Pv by ONE ulp moves the reference's own weights by median 3e-4, p99 4e-3..9e-3, max 1.6e-2
-#               (tools/weight_conditioning.py, CPU, oracle only).  Measured for the fast build over 300 teacher-forced
+#               (tests/weight_conditioning.py, CPU, oracle only).  Measured for the fast build over 300 teacher-forced
 #               steps: median 1.7e-3 (N=100) / 6.7e-4 (N=1000), p99 3.6e-2, max 1.1e-1, ancestors 3-4 %
-#               (tools/parity_report.py); poses and landmarks meet the same absolute tolerances as strict.
+#               (tests/parity_report.py); poses and landmarks meet the same absolute tolerances as strict.
 #               Against a float64 evaluation of the same update (tests/fs2_float64.py) the float32 REFERENCE is off by
 #               median 1.4e-3, p99 2.1e-2, max 6e-2 and the fast build by median 1.9e-3, p99 2.9e-2, max 8.5e-2: the two
 #               are equally good float32 evaluations of one formula (test_fast_build_vs_float64_yardstick).  Per step
@@ -72,7 +72,7 @@ def sym(P):
 W_TOL = {0: dict(median=1e-3, p99=5e-2, max=0.16, tv=1e-2, ancestors=0.04),
          1: dict(median=1e-2, p99=1e-1, max=0.25, tv=2e-2, ancestors=0.15)}
 # The bounds above hold for EVERY step (a single 6-landmark step has been seen at median 6.5e-3 in the fast build).
-# Over a whole run the deviations pool much lower; these aggregate bounds are 2x what tools/parity_report.py measured on
+# Over a whole run the deviations pool much lower; these aggregate bounds are 2x what tests/parity_report.py measured on
 # MI355X (strict: median 1.1e-4, p99 1.05e-2, max 8.1e-2, ancestors 0.7 % at N=100 / 1.5 % at N=1000; fast: median
 # 1.7e-3, p99 3.6e-2, max 1.1e-1, ancestors 3.2-3.9 %), so a regression that doubles the error fails.
 W_AGG = {0: dict(median=2.5e-4, p99=2.2e-2, max=0.16, ancestors=0.03),
