@@ -137,6 +137,36 @@ SLAM_DEV void predict_steps(float &x, float &y, float &th, float P[9], const Pre
 }
 
 #ifdef SLAM_FAST_MATH
+#ifdef SLAM_FAST_MATH
+// FastSLAM1::predictState x nsteps (fastslam1.cpp:37-54) in the fast build's arithmetic: every step samples its own
+// (V, G) ~ N((V, G), Q) per particle, so the steps cannot be composed -- but they need not cost ~500 instructions each:
+// chol(Q) is step- and particle-independent, the first sincos of predict_steps is dead when the controls are resampled,
+// Box-Muller and the trigonometry use the bounded-angle polynomials / hardware transcendentals of this build
+// (1.5 ulp, tools/check_fast_math.py).  BASELINE config 2 (1 000 particles): 19.8 -> see DESIGN.md section 5.
+SLAM_DEV void predict_steps_fs1_fast(float &x, float &y, float &th, const PredictArgs &A, const RngArgs &rng, int i, size_t S) {
+    const float dt = A.dt, iwb = 1.0f / A.wheel_base;
+    const L2 L = llt2(A.Q[0], A.Q[2], A.Q[3]);  // multivariateGauss((V,G), Q, 1) (core.cpp:452)
+    for (int s = 0; s < A.nsteps; s++) {
+        float g0, g1, g2;
+        if (rng.mode == 0) {
+            g0 = rng.normals[((size_t) s * 2 + 0) * S + i];
+            g1 = rng.normals[((size_t) s * 2 + 1) * S + i];
+        } else {
+            U4 r = philox4x32((uint32_t) (rng.first_particle + i), A.steps[s].step, 2u, 0u, rng.k0, rng.k1);
+            box_muller3_fast(r, g0, g1, g2);
+        }
+        const float V = ffma(L.l00, g0, A.steps[s].V);
+        const float G = ffma(L.l11, g1, ffma(L.l10, g0, A.steps[s].G));
+        float sn, cs, sgw, cgw;
+        sincos_cw(G + th, sn, cs);
+        sincos_cw(G * iwb, sgw, cgw);  // sin(G / wheelBase): upstream quirk (fastslam1.cpp:52)
+        x = ffma(V * dt, cs, x);
+        y = ffma(V * dt, sn, y);
+        th = wrap_pi(ffma(V * dt, sgw, th));
+    }
+}
+#endif
+
 // All queued predicts as one step (PredictComposite, kernels.h): one sincos and ~60 FMAs per particle instead of
 // ~190 instructions per queued predict.
 SLAM_DEV void predict_composite(float &x, float &y, float &th, Sym3 &P, const PredictComposite &C) {
@@ -178,6 +208,11 @@ __global__ void __launch_bounds__(kBlock) predict_kernel(Buffers B, PredictArgs 
         B.poseA[cur][i] = a;
         B.poseB[cur][i] = make_float4(P.p00, P.p10, P.p11, P.p20);
         B.poseC[cur][i] = make_float2(P.p21, P.p22);
+        return;
+    }
+    if (A.method == 1 && A.add_noise && !A.use_heading) {  // (the same arithmetic as inside the update launch)
+        predict_steps_fs1_fast(a.x, a.y, a.z, A, rng, i, (size_t) B.ncap);
+        B.poseA[cur][i] = a;
         return;
     }
 #endif
@@ -1001,6 +1036,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                 Sym3 P = {q00, q10, q11, q20, q21, q22};
                 predict_composite(x, y, th, P, PA.comp);
                 q00 = P.p00; q10 = P.p10; q11 = P.p11; q20 = P.p20; q21 = P.p21; q22 = P.p22;
+            } else if (METHOD == 1 && PA.add_noise && !PA.use_heading) {
+                predict_steps_fs1_fast(x, y, th, PA, rng, i, S);
             } else
 #endif
             {

@@ -47,7 +47,9 @@ def test_slam_backend_follows_the_reference_trajectory(tmp_path, method, golden,
     assert d[:first_res + 1].max() <= 1e-3, (first_res, d[:first_res + 1].max())
     # FastSLAM1's weights are well conditioned (GPU vs reference ~1e-4): ancestors stay identical for dozens of
     # resamples before one stratum lands on the other side of a cumulative-sum boundary
-    if method == "FASTSLAM1":
+    # (strict build; the fast build's predict uses the bounded-angle polynomials, ~1e-6 per step on the pose, and a first
+    # stratum changes sides within a dozen resamples: it is held to the first resample above and to the statistics below)
+    if method == "FASTSLAM1" and math == "strict":
         assert d[:25].max() <= 1e-3, d[:25].max()
     err_g = np.hypot(est[:, 0] - true[:, 0], est[:, 1] - true[:, 1])
     err_r = np.hypot(g["est"][:nobs, 0] - g["true"][:nobs, 0], g["est"][:nobs, 1] - g["true"][:nobs, 1])
