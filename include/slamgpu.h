@@ -274,14 +274,18 @@ int slamgpu_shard_estimate_fetch(slamgpu_ctx *ctx, double *raw4, int32_t max_cou
  *                         whose ancestor lives on another GPU reads that ancestor's pose and genealogy in place over xGMI;
  *                         genealogy entries are global slot ids, so landmark records stay on the GPU that wrote them until
  *                         the landmark is observed again.  No pack / send / unpack, no host synchronisation.
- *     ALL-GATHER          of this step's block totals (slamgpu_dist_totals: 8 or 12 B per 256 particles per shard), by the
- *                         caller, stream-ordered on the context's stream (RCCL through torch.distributed or ncclAllGather;
- *                         device copies for contexts of one process).  It is also the only barrier the scheme needs: a
- *                         shard's next launch starts after every shard's current launch has finished.
+ *     ALL-GATHER          of this step's block totals (slamgpu_dist_totals: 8 B per 256 particles per shard), stream-ordered
+ *                         on the context's stream: by the library itself once slamgpu_dist_comm_init has run (RCCL), else
+ *                         by the caller (torch.distributed, MPI, device copies for contexts of one process).  It is also
+ *                         the only barrier the scheme needs: a shard's next launch starts after every shard's current
+ *                         launch has finished.
  *
- * The pose estimate of a step is this shard's raw partial (slamgpu_shard_estimate_fetch: sum x, sum y, heading and weight
- * of the local maximum); combine across shards in shard order.  slamgpu_dist_settle (collective: every shard, followed by
- * the all-gather) applies the pending resampling stage so that slamgpu_download* can read the set. */
+ * Together the two are resampleParticles (core.cpp:718-824) and the predict / update calls of the wrapper loop
+ * (fastslam2wrapper.cpp:64,88) for a particle set that spans GPUs; results do not depend on the number of shards.
+ * The pose estimate of a step (ParticleSLAMWrapper.cpp:56-77) is this shard's raw partial (slamgpu_dist_history_fetch: sum x,
+ * sum y, heading and weight of the local maximum); combine across shards in shard order.  slamgpu_dist_settle (collective:
+ * every shard, followed by the all-gather) applies the pending resampling stage so that slamgpu_download* can read the set.
+ * Linear weights and SLAMGPU_RNG_PHILOX only. */
 int slamgpu_dist_export_size(void);
 int slamgpu_dist_export(slamgpu_ctx *ctx, void *blob);
 int slamgpu_dist_connect(slamgpu_ctx *ctx, int32_t n_shards, int32_t shard, const void *blobs);

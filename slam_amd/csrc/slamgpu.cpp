@@ -934,6 +934,7 @@ extern "C" {
 int slamgpu_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n,
                    const float R[4], const float *normals, const float *strata) {
     if (int rc = check_ctx(c)) return rc;
+    if (c->dist) return fail(SLAMGPU_ERR_INVALID, "distributed context: use slamgpu_dist_step (an update here would skip the all-gather)");
     if (c->cfg.n_particles_global != c->cfg.n_particles)
         return fail(SLAMGPU_ERR_INVALID, "this context is a shard (%d of %lld particles): use slamgpu_shard_update + slamgpu_shard_*",
                     c->cfg.n_particles, (long long) c->cfg.n_particles_global);
@@ -973,6 +974,7 @@ int slamgpu_shard_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, in
     if (c->cfg.n_particles % kBlock != 0 || c->cfg.first_particle % kBlock != 0)
         return fail(SLAMGPU_ERR_INVALID, "shards must hold a multiple of %d particles", kBlock);
     if (c->cfg.log_weights) return fail(SLAMGPU_ERR_INVALID, "the sharded resampling stage works on linear weights (log_weights contexts: slamgpu_update)");
+    if (c->dist) return fail(SLAMGPU_ERR_INVALID, "distributed context: use slamgpu_dist_step");
     return do_update(c, zf, idf, m, zn, n, R, normals, strata, true);
 }
 

@@ -122,6 +122,11 @@ def test_reading_an_unsettled_distributed_context_fails_loudly():
     f.step(np.array(st["controls"], np.float32).reshape(-1, 3), tp["Q"], float(tp["dt"]), st["zf"], st["idf"], st["zn"], tp["R"])
     with pytest.raises(sg.SlamGpuError, match="slamgpu_dist_settle"):
         f.ctx[0].download()
+    # ... and the single-context entry points refuse a distributed context (they would skip the all-gather)
+    with pytest.raises(sg.SlamGpuError, match="slamgpu_dist_step"):
+        f.ctx[0].update(st["zf"], st["idf"], st["zn"], tp["R"])
+    with pytest.raises(sg.SlamGpuError, match="slamgpu_dist_step"):
+        f.ctx[0].shard_update(st["zf"], st["idf"], st["zn"], tp["R"])
     f.close()
 
 
