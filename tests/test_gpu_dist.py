@@ -193,12 +193,14 @@ def test_logical_shards_beyond_two_totals_per_thread():
     same_state(ref, got, "final")
 
 
-def test_logical_shards_at_the_scaling_bench_size():
+@pytest.mark.parametrize("n", [100096, 125184])
+def test_logical_shards_at_the_scaling_bench_size(n):
     """the driver's N=8 scaling run in miniature time but at full width: 8 shards x 100 096 particles (3 128 gathered block
-    totals scanned in LDS by every block, the 25 KB prefix beside the staged records) against one context of 800 768"""
+    totals scanned in LDS by every block, the 25 KB prefix beside the staged records) against one context of 800 768; and
+    BASELINE config 4's shape, 8 x 125 184 = 1 001 472 particles"""
     import slam_amd as sg
     from slam_amd import host
-    G, n, nobs = 8, 100096, 45
+    G, nobs = 8, 45
     Np = G * n
     tp = host.make_tape(sim_args("example_webmap", "FASTSLAM2", Np, 7), max_obs=nobs)
     ref, href, _ = run_single(sg, tp, Np, sg.FASTSLAM2, 1, 7)
