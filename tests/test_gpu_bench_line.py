@@ -61,3 +61,16 @@ def test_multi_gpu_path_with_one_rank():
     chk = j["config"]["check_vs_single_context"]
     assert chk["max_abs_diff"] <= 1e-9, chk  # the distributed run reproduces the single-context estimates
     assert "cpu_baseline" not in j
+
+
+def test_multi_gpu_path_falls_back_to_the_exchange_path_when_the_peer_mappings_fail():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29743", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", SLAM_BENCH_FAIL_DIST_SETUP="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded", "--steps", "60", "--warmup", "5"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "falling back to --mgpu exchange" in r.stderr
+    j = one_line(r.stdout)
+    check_common(j, 60, 5)
+    assert "multi_gpu_path" not in j["config"] and "all-to-all" in j["config"]["workload"]
+    assert j["config"]["check_vs_single_context"]["max_abs_diff"] <= 1e-9
