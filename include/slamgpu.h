@@ -308,6 +308,8 @@ int slamgpu_dist_history_fetch(slamgpu_ctx *ctx, double *raw4, float *neff, int3
 #define SLAMGPU_DIST_COMM_ID_BYTES 128
 int slamgpu_dist_comm_id(void *id, int32_t bytes);
 int slamgpu_dist_comm_init(slamgpu_ctx *ctx, const void *id, int32_t n_ranks, int32_t rank);
+/* the all-gather of the last step's totals once more (collective, idempotent): lets a harness time the collective alone */
+int slamgpu_dist_gather(slamgpu_ctx *ctx);
 
 /* All shards in ONE process (the reference's single backend process driving k GPUs; or k logical shards on one GPU, which
  * must then share one stream): export + connect + communicators (ncclCommInitAll; a copy kernel on a shared device) in

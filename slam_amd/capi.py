@@ -22,7 +22,7 @@ DECLARED_SYMBOLS = [
     "slamgpu_dev_alloc", "slamgpu_dev_free", "slamgpu_dev_copy", "slamgpu_dev_copy_async", "slamgpu_shard_estimate_async",
     "slamgpu_shard_estimate_fetch", "slamgpu_step_status", "slamgpu_kat", "slamgpu_download_range", "slamgpu_debug_stamps", "slamgpu_associate", "slamgpu_set_map", "slamgpu_observe",
     "slamgpu_dist_export_size", "slamgpu_dist_export", "slamgpu_dist_connect", "slamgpu_dist_step", "slamgpu_dist_totals", "slamgpu_dist_settle",
-    "slamgpu_dist_history_fetch", "slamgpu_dist_comm_id", "slamgpu_dist_comm_init", "slamgpu_dist_group_create", "slamgpu_dist_group_destroy",
+    "slamgpu_dist_history_fetch", "slamgpu_dist_gather", "slamgpu_dist_comm_id", "slamgpu_dist_comm_init", "slamgpu_dist_group_create", "slamgpu_dist_group_destroy",
     "slamgpu_dist_group_step", "slamgpu_dist_group_settle", "slamgpu_dist_group_history", "slamgpu_dist_group_download",
 ]
 
@@ -125,6 +125,7 @@ def load_library():
     L.slamgpu_dist_totals.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
     L.slamgpu_dist_settle.argtypes = [C.c_void_p]
     L.slamgpu_dist_history_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+    L.slamgpu_dist_gather.argtypes = [C.c_void_p]
     L.slamgpu_dist_comm_id.argtypes = [C.c_void_p, C.c_int32]
     L.slamgpu_dist_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     L.slamgpu_dist_group_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]
@@ -519,6 +520,9 @@ class SlamGpu:
 
     def dist_comm_init(self, comm_id, n_ranks, rank):
         _chk(self.L.slamgpu_dist_comm_init(self.h, comm_id, n_ranks, rank))
+
+    def dist_gather(self):
+        _chk(self.L.slamgpu_dist_gather(self.h))
 
     def dist_settle(self):
         _chk(self.L.slamgpu_dist_settle(self.h))

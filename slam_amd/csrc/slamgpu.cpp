@@ -1318,6 +1318,13 @@ int slamgpu_dist_totals(slamgpu_ctx *c, const float **local_dev, float **gathere
     return 0;
 }
 
+int slamgpu_dist_gather(slamgpu_ctx *c) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!c->dist || !c->comm) return fail(SLAMGPU_ERR_INVALID, "no communicator: slamgpu_dist_comm_init first");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    return gather_totals(c);
+}
+
 int slamgpu_dist_settle(slamgpu_ctx *c) {
     if (int rc = check_ctx(c)) return rc;
     if (!c->dist) return fail(SLAMGPU_ERR_INVALID, "not a distributed context");

@@ -58,6 +58,7 @@ def test_multi_gpu_path_with_one_rank():
     j = one_line(r.stdout)
     check_common(j, 60, 5)
     assert j["config"]["multi_gpu_path"] == "dist" and j["config"]["collective"] == "native"
+    assert 0.5 < j["config"]["allgather_us"] < 1e3  # the collective alone, timed after the run
     chk = j["config"]["check_vs_single_context"]
     assert chk["max_abs_diff"] <= 1e-9, chk  # the distributed run reproduces the single-context estimates
     assert "cpu_baseline" not in j
