@@ -311,6 +311,23 @@ int slamgpu_dist_comm_init(slamgpu_ctx *ctx, const void *id, int32_t n_ranks, in
 /* the all-gather of the last step's totals once more (collective, idempotent): lets a harness time the collective alone */
 int slamgpu_dist_gather(slamgpu_ctx *ctx);
 
+/* The collective between two launches, two ways:
+ *   SLAMGPU_DIST_GATHER (default)  an all-gather of the block totals after every launch (RCCL inside the library after
+ *                                  slamgpu_dist_comm_init, else the caller's);
+ *   SLAMGPU_DIST_PUSH              the update launch stores its block totals straight into every shard's table (peer
+ *                                  mappings), and a one-wave kernel is the barrier: it stores this step's sequence number
+ *                                  into every peer's flag word (system-scope release) and polls its own flag words
+ *                                  (fine-grained memory, bounded spin).  No collective library on the step's path.
+ * Contexts driven from one thread need a stream of their own each for PUSH (a shared stream would queue a shard's flag
+ * store behind the wave that waits for it).  slamgpu_dist_handshake_test (collective) runs `iters` barriers alone and
+ * reports their device time and whether every peer arrived; slamgpu_dist_collective_status (synchronises) tells
+ * afterwards whether any barrier of the run timed out.  Switch modes only between settled steps, on every shard alike. */
+#define SLAMGPU_DIST_GATHER 0
+#define SLAMGPU_DIST_PUSH 1
+int slamgpu_dist_set_collective(slamgpu_ctx *ctx, int32_t mode);
+int slamgpu_dist_handshake_test(slamgpu_ctx *ctx, int32_t iters, double *usec, int32_t *ok);
+int slamgpu_dist_collective_status(slamgpu_ctx *ctx, int32_t *ok);
+
 /* All shards in ONE process (the reference's single backend process driving k GPUs; or k logical shards on one GPU, which
  * must then share one stream): export + connect + communicators (ncclCommInitAll; a copy kernel on a shared device) in
  * one call, then steps for every shard at once.  Contexts are created by the caller as for slamgpu_dist_connect and

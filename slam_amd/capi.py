@@ -22,7 +22,8 @@ DECLARED_SYMBOLS = [
     "slamgpu_dev_alloc", "slamgpu_dev_free", "slamgpu_dev_copy", "slamgpu_dev_copy_async", "slamgpu_shard_estimate_async",
     "slamgpu_shard_estimate_fetch", "slamgpu_step_status", "slamgpu_kat", "slamgpu_download_range", "slamgpu_debug_stamps", "slamgpu_associate", "slamgpu_set_map", "slamgpu_observe",
     "slamgpu_dist_export_size", "slamgpu_dist_export", "slamgpu_dist_connect", "slamgpu_dist_step", "slamgpu_dist_totals", "slamgpu_dist_settle",
-    "slamgpu_dist_history_fetch", "slamgpu_dist_gather", "slamgpu_dist_comm_id", "slamgpu_dist_comm_init", "slamgpu_dist_group_create", "slamgpu_dist_group_destroy",
+    "slamgpu_dist_history_fetch", "slamgpu_dist_gather", "slamgpu_dist_set_collective", "slamgpu_dist_handshake_test",
+    "slamgpu_dist_collective_status", "slamgpu_dist_comm_id", "slamgpu_dist_comm_init", "slamgpu_dist_group_create", "slamgpu_dist_group_destroy",
     "slamgpu_dist_group_step", "slamgpu_dist_group_settle", "slamgpu_dist_group_history", "slamgpu_dist_group_download",
 ]
 
@@ -126,6 +127,9 @@ def load_library():
     L.slamgpu_dist_settle.argtypes = [C.c_void_p]
     L.slamgpu_dist_history_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.slamgpu_dist_gather.argtypes = [C.c_void_p]
+    L.slamgpu_dist_set_collective.argtypes = [C.c_void_p, C.c_int32]
+    L.slamgpu_dist_handshake_test.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.slamgpu_dist_collective_status.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.slamgpu_dist_comm_id.argtypes = [C.c_void_p, C.c_int32]
     L.slamgpu_dist_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     L.slamgpu_dist_group_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]
@@ -520,6 +524,24 @@ class SlamGpu:
 
     def dist_comm_init(self, comm_id, n_ranks, rank):
         _chk(self.L.slamgpu_dist_comm_init(self.h, comm_id, n_ranks, rank))
+
+    def dist_set_collective(self, push):
+        _chk(self.L.slamgpu_dist_set_collective(self.h, 1 if push else 0))
+
+    def dist_handshake_test(self, iters=50):
+        """(microseconds per barrier, every peer arrived) -- collective"""
+        us, ok = C.c_double(), C.c_int32()
+        _chk(self.L.slamgpu_dist_handshake_test(self.h, iters, C.byref(us), C.byref(ok)))
+        return us.value, bool(ok.value)
+
+    def dist_handshake_enqueue(self, iters=50):
+        """the same barriers, enqueued only (contexts driven by one thread: queue everybody's before anybody waits)"""
+        _chk(self.L.slamgpu_dist_handshake_test(self.h, iters, None, None))
+
+    def dist_collective_ok(self):
+        ok = C.c_int32()
+        _chk(self.L.slamgpu_dist_collective_status(self.h, C.byref(ok)))
+        return bool(ok.value)
 
     def dist_gather(self):
         _chk(self.L.slamgpu_dist_gather(self.h))

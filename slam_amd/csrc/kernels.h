@@ -86,6 +86,7 @@ struct PeerPtrs {
     float *lmkB[2];
     int32_t *gen[2];
     float *lcum[2];
+    float *gtot[2];       // the shard's table of everybody's block totals: peers push their totals into it (push collective)
 };
 
 struct Buffers {
@@ -220,6 +221,8 @@ struct UpdateArgs {
     int32_t scan_global;     // the prefix of the previous step's block totals is in WeightScratch::scan (scan_kernel ran)
     int32_t do_resample, n_effective;  // SWITCH_RESAMPLE, NEFFECTIVE (for the inline plan)
     int32_t logw;            // the context keeps LOG-weights in poseA.w (slamgpu_config.log_weights)
+    int32_t push_totals;     // distributed contexts, push collective: every block stores its totals into EVERY shard's table
+                             // (Buffers::peers[h].gtot) instead of leaving them to an all-gather
     int32_t finalize_par;    // parity of the estimate partials the helper block reduces
     int32_t finalize;        // 1: the extra block reduces the previous update's pose-estimate partials
     double *finalize_hist;   // history slot of that estimate (kHistStride doubles) or null
@@ -318,6 +321,17 @@ struct DistGatherArgs {
     int32_t n_shards, floats_per_shard;
 };
 
+// Barrier of the push collective: one wave per shard.  Lane t stores `seq` into shard t's flag word for this shard (a
+// release at system scope: this shard's update launch has completed, its totals are in every table), then polls this
+// shard's own flag word for shard t until it says `seq` too.  Flags are fine-grained device memory; the spin is bounded.
+struct DistFlagArgs {
+    uint32_t *peer_flags[kMaxShards];  // [h] = shard h's flag array (n_shards words), as mapped here
+    uint32_t *my_flags;
+    uint32_t *err;                     // set to seq if a peer did not arrive within max_spins polls
+    int32_t n_shards, shard;
+    uint32_t seq, max_spins;
+};
+
 struct KernelTable {
     // the step: [resampling stage of the previous update, inline] + [gather] + [fused predicts] + per-particle observation
     // update + in-block weight prefix / totals  (+ helper blocks: genealogy copy, Ctrl words, estimate reduction)
@@ -357,6 +371,7 @@ struct KernelTable {
     // normalise or leave the lazy gather pending; this shard's pose-estimate partials; outcome into Ctrl
     void (*shard_finish)(hipStream_t, const Buffers &, const WeightScratch &, double W, double Q, float neff, int resampled);
     void (*dist_gather)(hipStream_t, const DistGatherArgs &);
+    void (*dist_flags)(hipStream_t, const DistFlagArgs &);
 };
 
 const KernelTable *kernels_strict();

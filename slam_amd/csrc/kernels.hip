@@ -1390,6 +1390,16 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         }
         ws.blk_w[ws.wpar][bt] = T;
         ws.blk_w[ws.wpar][ws.nblocks + bt] = q;
+        if (DIST && U.push_totals) {
+            // push collective: this block's totals straight into every shard's table, shard-major [shard][w(nb) | q(nb)]
+            // (visible to the peers' next launch: the flag handshake that follows this launch orders them)
+            const size_t at = (size_t) B.shard * 2 * ws.nblocks + bt;
+            for (int h = 0; h < B.n_shards; h++) {
+                float *g = B.peers[h].gtot[ws.wpar];
+                g[at] = T;
+                g[at + ws.nblocks] = q;
+            }
+        }
     }
     SLAM_STAMP(9);  // weight prefix + totals written: end of the block
 }
@@ -2199,8 +2209,27 @@ static void launch_dist_gather(hipStream_t st, const DistGatherArgs &A) {
     hipLaunchKernelGGL(dist_gather_kernel, dim3(A.n_shards * A.n_shards), dim3(kBlock), 0, st, A);
 }
 
+__global__ void __launch_bounds__(kWave) dist_flag_kernel(DistFlagArgs A) {
+    const int t = threadIdx.x;
+    if (t >= A.n_shards || t == A.shard) return;
+    __hip_atomic_store(A.peer_flags[t] + A.shard, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint32_t spins = 0;
+    // (sequence numbers only grow: signed distance copes with the wrap)
+    while ((int32_t) (__hip_atomic_load(A.my_flags + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - A.seq) < 0) {
+        if (++spins > A.max_spins) {
+            __hip_atomic_store(A.err, A.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+static void launch_dist_flags(hipStream_t st, const DistFlagArgs &A) {
+    hipLaunchKernelGGL(dist_flag_kernel, dim3(1), dim3(kWave), 0, st, A);
+}
+
 static const KernelTable kTable = {launch_update, launch_resample, launch_scan, launch_gather, launch_flatten, launch_identity, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat, launch_observe, launch_associate,
-                                   launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish, launch_dist_gather};
+                                   launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish, launch_dist_gather, launch_dist_flags};
 
 }  // namespace SLAM_KNS
 

@@ -177,6 +177,12 @@ struct slamgpu_ctx {
     float *gtot_dev[2] = {nullptr, nullptr};
     std::vector<void *> ipc_opened;
     void *comm = nullptr;  // ncclComm_t: when set, slamgpu_dist_step / _settle run the all-gather themselves
+    // push collective (slamgpu_dist_set_collective): the update launch stores its totals into every shard's table and a
+    // one-wave flag kernel is the barrier; flags_dev = [kMaxShards] flag words + the error word, fine-grained memory
+    bool dist_push = false;
+    uint32_t *flags_dev = nullptr;
+    uint32_t *peer_flags[kMaxShards] = {};
+    uint32_t flag_seq = 0;
     // observation front end (slamgpu_set_map / slamgpu_observe)
     float *map_dev = nullptr, *obs_r_dev = nullptr;
     int32_t *table_dev = nullptr;
@@ -643,6 +649,7 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     if (c->peers_dev) (void) hipFree(c->peers_dev);
     for (int b = 0; b < 2; b++)
         if (c->gtot_dev[b]) (void) hipFree(c->gtot_dev[b]);
+    if (c->flags_dev) (void) hipFree(c->flags_dev);
     if (c->map_dev) (void) hipFree(c->map_dev);
     if (c->obs_r_dev) (void) hipFree(c->obs_r_dev);
     if (c->table_dev) (void) hipFree(c->table_dev);
@@ -871,6 +878,7 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
         c->B.gtot[0] = c->gtot_dev[0];
         c->B.gtot[1] = c->gtot_dev[1];
         c->dist_clean = false;
+        U.push_totals = c->dist_push ? 1 : 0;
     }
     // a pending gather's genealogy composition: small packets: by the compute threads themselves; device packets: by copy
     // roles (one role = 256 particles x rows_per_role live rows; at most ~4 roles per particle tile: every role block
@@ -1161,14 +1169,17 @@ int slamgpu_shard_finish(slamgpu_ctx *c, const slamgpu_shard_plan_t *plan) {
 // ---- distributed operation ---------------------------------------------------------------------------------------------
 namespace {
 // the all-gather that follows an update launch of a distributed context, on the context's stream
+int launch_flags(slamgpu_ctx *c);
 int gather_totals(slamgpu_ctx *c) {
+    if (c->dist_push) return launch_flags(c);  // the totals are in every table already: only the barrier is left
     if (!c->comm) return 0;
     const int par = (int) (c->obs_step & 1);
     RCCL_TRY(rccl()->AllGather(c->ws.blk_w[par], c->gtot_dev[par], (size_t) 2 * c->ws.nblocks, ncclFloat, (ncclComm_t) c->comm, c->stream));
     return 0;
 }
 
-constexpr int kDistArrays = 14;
+constexpr int kDistArrays = 17;
+constexpr int kFlagWords = 2 * kMaxShards;  // flags [0, kMaxShards), error word at kMaxShards
 struct DistBlob {
     int64_t pid;
     int32_t device, ncap, cap_nf, compact;
@@ -1184,6 +1195,37 @@ void dist_arrays(slamgpu_ctx *c, void **a) {
     for (int b = 0; b < 2; b++) a[k++] = c->B.lmkB[b];
     for (int b = 0; b < 2; b++) a[k++] = c->B.gen[b];
     for (int b = 0; b < 2; b++) a[k++] = c->ws.lcum[b];
+    for (int b = 0; b < 2; b++) a[k++] = c->gtot_dev[b];
+    a[k++] = c->flags_dev;
+}
+
+// the table of everybody's block totals (by step parity) and the flag words: allocated before the export, because the
+// peers map them too (push collective)
+int dist_alloc_shared(slamgpu_ctx *c) {
+    if (c->gtot_dev[0]) return 0;
+    const int64_t n_shards = std::max<int64_t>(1, n_global(c) / std::max(1, c->cfg.n_particles));
+    for (int b = 0; b < 2; b++) {
+        HIP_TRY(hipMalloc((void **) &c->gtot_dev[b], sizeof(float) * 3 * (size_t) c->ws.nblocks * (size_t) n_shards));
+        HIP_TRY(hipMemset(c->gtot_dev[b], 0, sizeof(float) * 3 * (size_t) c->ws.nblocks * (size_t) n_shards));
+    }
+    HIP_TRY(hipExtMallocWithFlags((void **) &c->flags_dev, sizeof(uint32_t) * kFlagWords, hipDeviceMallocFinegrained));
+    HIP_TRY(hipMemset(c->flags_dev, 0, sizeof(uint32_t) * kFlagWords));
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+int launch_flags(slamgpu_ctx *c) {
+    DistFlagArgs A{};
+    for (int h = 0; h < c->B.n_shards; h++) A.peer_flags[h] = c->peer_flags[h];
+    A.my_flags = c->flags_dev;
+    A.err = c->flags_dev + kMaxShards;
+    A.n_shards = c->B.n_shards;
+    A.shard = c->B.shard;
+    A.seq = ++c->flag_seq;
+    A.max_spins = 1u << 22;  // (~seconds: a peer that never arrives is reported, not waited for)
+    c->k->dist_flags(c->stream, A);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 }  // namespace
 
@@ -1199,6 +1241,7 @@ int slamgpu_dist_export(slamgpu_ctx *c, void *blob) {
     b.ncap = c->B.ncap;
     b.cap_nf = c->B.cap_nf;
     b.compact = c->B.compact;
+    if (int rc = dist_alloc_shared(c)) return rc;
     dist_arrays(c, b.ptr);
     for (int k = 0; k < kDistArrays; k++) HIP_TRY(hipIpcGetMemHandle(&b.handle[k], b.ptr[k]));
     memcpy(blob, &b, sizeof b);
@@ -1225,6 +1268,7 @@ int slamgpu_dist_connect(slamgpu_ctx *c, int32_t n_shards, int32_t shard, const 
             return fail(SLAMGPU_ERR_INVALID, "shard %d was created with different sizes", h);
         void *p[kDistArrays];
         if (h == shard) {
+            if (int rc = dist_alloc_shared(c)) return rc;
             dist_arrays(c, p);
         } else if (b.pid == (int64_t) getpid()) {
             for (int k = 0; k < kDistArrays; k++) p[k] = b.ptr[k];
@@ -1250,13 +1294,11 @@ int slamgpu_dist_connect(slamgpu_ctx *c, int32_t n_shards, int32_t shard, const 
         for (int q = 0; q < 2; q++) t.lmkB[q] = (float *) p[k++];
         for (int q = 0; q < 2; q++) t.gen[q] = (int32_t *) p[k++];
         for (int q = 0; q < 2; q++) t.lcum[q] = (float *) p[k++];
+        for (int q = 0; q < 2; q++) t.gtot[q] = (float *) p[k++];
+        c->peer_flags[h] = (uint32_t *) p[k++];
     }
     HIP_TRY(hipMalloc((void **) &c->peers_dev, sizeof(PeerPtrs) * (size_t) n_shards));
     HIP_TRY(hipMemcpy(c->peers_dev, table.data(), sizeof(PeerPtrs) * (size_t) n_shards, hipMemcpyHostToDevice));
-    for (int b = 0; b < 2; b++) {
-        HIP_TRY(hipMalloc((void **) &c->gtot_dev[b], sizeof(float) * 3 * (size_t) c->ws.nblocks * n_shards));
-        HIP_TRY(hipMemset(c->gtot_dev[b], 0, sizeof(float) * 3 * (size_t) c->ws.nblocks * n_shards));
-    }
     HIP_TRY(hipDeviceSynchronize());
     c->B.peers = c->peers_dev;
     c->B.n_shards = n_shards;
@@ -1318,11 +1360,62 @@ int slamgpu_dist_totals(slamgpu_ctx *c, const float **local_dev, float **gathere
     return 0;
 }
 
+int slamgpu_dist_set_collective(slamgpu_ctx *c, int32_t mode) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!c->dist) return fail(SLAMGPU_ERR_INVALID, "not a distributed context");
+    if (mode != SLAMGPU_DIST_GATHER && mode != SLAMGPU_DIST_PUSH) return fail(SLAMGPU_ERR_INVALID, "unknown collective %d", mode);
+    if (c->unplanned.has && !c->dist_clean) return fail(SLAMGPU_ERR_INVALID, "switch the collective between settled steps (slamgpu_dist_settle)");
+    c->dist_push = mode == SLAMGPU_DIST_PUSH;
+    return 0;
+}
+
+int slamgpu_dist_handshake_test(slamgpu_ctx *c, int32_t iters, double *usec, int32_t *ok) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!c->dist || !c->flags_dev) return fail(SLAMGPU_ERR_INVALID, "not a distributed context");
+    if (iters < 1 || iters > 100000) return fail(SLAMGPU_ERR_INVALID, "iters out of range");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (!usec && !ok) {  // enqueue only: several contexts driven by one thread must all have theirs queued before anybody waits
+        for (int i = 0; i < iters; i++)
+            if (int rc = launch_flags(c)) return rc;
+        return 0;
+    }
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < iters; i++)
+        if (int rc = launch_flags(c)) return rc;
+    HIP_TRY(hipEventRecord(e1, c->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void) hipEventDestroy(e0);
+    (void) hipEventDestroy(e1);
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpy(&err, c->flags_dev + kMaxShards, sizeof err, hipMemcpyDeviceToHost));
+    if (usec) *usec = 1e3 * (double) ms / iters;
+    if (ok) *ok = err == 0 ? 1 : 0;
+    return 0;
+}
+
+int slamgpu_dist_collective_status(slamgpu_ctx *c, int32_t *ok) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!c->dist || !c->flags_dev || !ok) return fail(SLAMGPU_ERR_INVALID, "not a distributed context / null output");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpy(&err, c->flags_dev + kMaxShards, sizeof err, hipMemcpyDeviceToHost));
+    *ok = err == 0 ? 1 : 0;
+    return 0;
+}
+
 int slamgpu_dist_gather(slamgpu_ctx *c) {
     if (int rc = check_ctx(c)) return rc;
     if (!c->dist || !c->comm) return fail(SLAMGPU_ERR_INVALID, "no communicator: slamgpu_dist_comm_init first");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    return gather_totals(c);
+    const int par = (int) (c->obs_step & 1);
+    RCCL_TRY(rccl()->AllGather(c->ws.blk_w[par], c->gtot_dev[par], (size_t) 2 * c->ws.nblocks, ncclFloat, (ncclComm_t) c->comm, c->stream));
+    return 0;
 }
 
 int slamgpu_dist_settle(slamgpu_ctx *c) {

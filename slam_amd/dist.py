@@ -126,6 +126,7 @@ class DistFilter:
 
     def __init__(self, contexts, gather):
         self.ctx, self.g = list(contexts), gather
+        self.push = False
         self.G = gather.world
         self.n = getattr(self.ctx[0], "n_local", None) or self.ctx[0].N  # particles per shard
         # every step of the set-up is collective: a rank that fails must still take part in the exchange, and all ranks
@@ -151,6 +152,25 @@ class DistFilter:
             gather.connect_comm()
         gather.barrier()
 
+    def use_push(self, iters=20):
+        """switch to the push collective (slamgpu.h: SLAMGPU_DIST_PUSH) after trying `iters` barriers; returns False (and stays
+        with the gather) if a peer did not arrive.  Collective; call between settled steps."""
+        if len(self.ctx) == 1:
+            _, ok = self.ctx[0].dist_handshake_test(iters)
+        else:
+            for c in self.ctx:
+                c.dist_handshake_enqueue(iters)
+            ok = all(c.dist_collective_ok() for c in self.ctx)
+        if not self._agree(ok):
+            return False
+        for c in self.ctx:
+            c.dist_set_collective(True)
+        self.push = True
+        return True
+
+    def collective_ok(self):
+        return self._agree(all(c.dist_collective_ok() for c in self.ctx))
+
     def _agree(self, ok):
         flags = self.g.exchange_blobs([bytes([1 if ok else 0])] * len(self.ctx))
         return all(f == bytes([1]) for f in flags)
@@ -164,9 +184,9 @@ class DistFilter:
 
     def prepare_step(self, controls, Q, dt, zf, idf, zn, R, record_estimate=True):
         calls = [c.prepare_dist_step(controls, Q, dt, zf, idf, zn, R, record_estimate) for c in self.ctx]
-        if getattr(self.g, "native", False):
+        if getattr(self.g, "native", False) and len(calls) == 1:
             return calls[0]
-        gather = self.g.all_gather
+        gather = (lambda: None) if self.push else self.g.all_gather
 
         def call():
             for f in calls:
@@ -181,7 +201,8 @@ class DistFilter:
         """apply the pending resampling stage everywhere (collective); afterwards the contexts can be read"""
         for c in self.ctx:
             c.dist_settle()
-        self.g.all_gather()
+        if not self.push:
+            self.g.all_gather()
         self.g.barrier()
 
     def history_fetch(self):

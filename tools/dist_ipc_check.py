@@ -65,10 +65,14 @@ def worker(rank, world, Np, nobs, q):
     c = sg.SlamGpu(n, tp["nlm"], method=sg.FASTSLAM2, n_effective=int(0.75 * Np), rng_mode=sg.RNG_PHILOX, seed=9, math_mode=1,
                    first_particle=rank * n, n_particles_global=Np)
     f = DistFilter([c], GlooGather(c, rank, world))
+    if os.environ.get("SLAM_DIST_PUSH"):
+        assert f.use_push(), "a peer did not arrive at the flag handshake"
     for st in tp["steps"]:
         f.step(np.array(st["controls"], np.float32).reshape(-1, 3), tp["Q"], float(tp["dt"]), st["zf"], st["idf"], st["zn"], tp["R"])
     hist = f.history_fetch()
     d = f.download()[0]
+    if os.environ.get("SLAM_DIST_PUSH"):
+        assert f.collective_ok()
     f.close()
     q.put((rank, d, hist))
     dist.barrier()
@@ -107,7 +111,7 @@ def main():
     for r in range(world):
         assert np.allclose(got[r][1][0], href[0], rtol=0, atol=1e-12)
         assert np.array_equal(got[r][1][2], href[2])
-    print("DIST_IPC_OK")
+    print("DIST_IPC_OK" + (" push" if os.environ.get("SLAM_DIST_PUSH") else ""))
 
 
 if __name__ == "__main__":
