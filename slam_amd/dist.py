@@ -168,6 +168,12 @@ class DistFilter:
         self.push = True
         return True
 
+    def use_gather(self):
+        """back to the all-gather collective (between settled steps, every shard alike)"""
+        for c in self.ctx:
+            c.dist_set_collective(False)
+        self.push = False
+
     def collective_ok(self):
         return self._agree(all(c.dist_collective_ok() for c in self.ctx))
 

@@ -57,8 +57,10 @@ def test_multi_gpu_path_with_one_rank():
     assert r.returncode == 0, r.stderr[-2000:]
     j = one_line(r.stdout)
     check_common(j, 60, 5)
-    assert j["config"]["multi_gpu_path"] == "dist" and j["config"]["collective"] == "native"
-    assert 0.5 < j["config"]["allgather_us"] < 1e3  # the collective alone, timed after the run
+    assert j["config"]["multi_gpu_path"] == "dist" and j["config"]["collective"] in ("push", "rccl")
+    # both collectives were tried alone before the run, and the line says which one it took and why
+    assert 0.5 < j["config"]["allgather_us"] < 1e3 and 0.5 < j["config"]["flag_barrier_us"] < 1e3
+    assert j["config"]["collective_choice"].startswith(j["config"]["collective"])
     chk = j["config"]["check_vs_single_context"]
     assert chk["max_abs_diff"] <= 1e-9, chk  # the distributed run reproduces the single-context estimates
     assert "cpu_baseline" not in j
@@ -74,4 +76,17 @@ def test_multi_gpu_path_falls_back_to_the_exchange_path_when_the_peer_mappings_f
     j = one_line(r.stdout)
     check_common(j, 60, 5)
     assert "multi_gpu_path" not in j["config"] and "all-to-all" in j["config"]["workload"]
+    assert j["config"]["check_vs_single_context"]["max_abs_diff"] <= 1e-9
+
+
+@pytest.mark.parametrize("collective", ["push", "native", "torch"])
+def test_multi_gpu_path_every_collective(collective):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29745", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded", "--steps", "60", "--warmup", "5",
+                        "--collective", collective], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = one_line(r.stdout)
+    check_common(j, 60, 5)
+    assert j["config"]["collective"] == {"push": "push", "native": "rccl", "torch": "torch"}[collective]
     assert j["config"]["check_vs_single_context"]["max_abs_diff"] <= 1e-9
