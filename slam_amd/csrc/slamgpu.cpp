@@ -1208,8 +1208,14 @@ int dist_alloc_shared(slamgpu_ctx *c) {
         HIP_TRY(hipMalloc((void **) &c->gtot_dev[b], sizeof(float) * 3 * (size_t) c->ws.nblocks * (size_t) n_shards));
         HIP_TRY(hipMemset(c->gtot_dev[b], 0, sizeof(float) * 3 * (size_t) c->ws.nblocks * (size_t) n_shards));
     }
-    HIP_TRY(hipExtMallocWithFlags((void **) &c->flags_dev, sizeof(uint32_t) * kFlagWords, hipDeviceMallocFinegrained));
-    HIP_TRY(hipMemset(c->flags_dev, 0, sizeof(uint32_t) * kFlagWords));
+    // (fine-grained device memory: polled by a running kernel while another GPU stores into it.  A stack that cannot
+    // provide it loses the push collective, nothing else.)
+    if (hipExtMallocWithFlags((void **) &c->flags_dev, sizeof(uint32_t) * kFlagWords, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void) hipGetLastError();
+        c->flags_dev = nullptr;
+    } else {
+        HIP_TRY(hipMemset(c->flags_dev, 0, sizeof(uint32_t) * kFlagWords));
+    }
     HIP_TRY(hipDeviceSynchronize());
     return 0;
 }
@@ -1243,7 +1249,8 @@ int slamgpu_dist_export(slamgpu_ctx *c, void *blob) {
     b.compact = c->B.compact;
     if (int rc = dist_alloc_shared(c)) return rc;
     dist_arrays(c, b.ptr);
-    for (int k = 0; k < kDistArrays; k++) HIP_TRY(hipIpcGetMemHandle(&b.handle[k], b.ptr[k]));
+    for (int k = 0; k < kDistArrays; k++)
+        if (b.ptr[k]) HIP_TRY(hipIpcGetMemHandle(&b.handle[k], b.ptr[k]));  // (null: no flag words on that shard)
     memcpy(blob, &b, sizeof b);
     return 0;
 }
@@ -1280,6 +1287,10 @@ int slamgpu_dist_connect(slamgpu_ctx *c, int32_t n_shards, int32_t shard, const 
             }
         } else {
             for (int k = 0; k < kDistArrays; k++) {
+                if (!b.ptr[k]) {
+                    p[k] = nullptr;
+                    continue;
+                }
                 hipError_t e = hipIpcOpenMemHandle(&p[k], b.handle[k], hipIpcMemLazyEnablePeerAccess);
                 if (e != hipSuccess) return fail(SLAMGPU_ERR_HIP, "hipIpcOpenMemHandle (shard %d, array %d): %s", h, k, hipGetErrorString(e));
                 c->ipc_opened.push_back(p[k]);
@@ -1364,6 +1375,9 @@ int slamgpu_dist_set_collective(slamgpu_ctx *c, int32_t mode) {
     if (int rc = check_ctx(c)) return rc;
     if (!c->dist) return fail(SLAMGPU_ERR_INVALID, "not a distributed context");
     if (mode != SLAMGPU_DIST_GATHER && mode != SLAMGPU_DIST_PUSH) return fail(SLAMGPU_ERR_INVALID, "unknown collective %d", mode);
+    if (mode == SLAMGPU_DIST_PUSH)
+        for (int h = 0; h < c->B.n_shards; h++)
+            if (!c->peer_flags[h]) return fail(SLAMGPU_ERR_INVALID, "push collective unavailable: shard %d has no flag words (fine-grained memory)", h);
     if (c->unplanned.has && !c->dist_clean) return fail(SLAMGPU_ERR_INVALID, "switch the collective between settled steps (slamgpu_dist_settle)");
     c->dist_push = mode == SLAMGPU_DIST_PUSH;
     return 0;
@@ -1371,7 +1385,9 @@ int slamgpu_dist_set_collective(slamgpu_ctx *c, int32_t mode) {
 
 int slamgpu_dist_handshake_test(slamgpu_ctx *c, int32_t iters, double *usec, int32_t *ok) {
     if (int rc = check_ctx(c)) return rc;
-    if (!c->dist || !c->flags_dev) return fail(SLAMGPU_ERR_INVALID, "not a distributed context");
+    if (!c->dist) return fail(SLAMGPU_ERR_INVALID, "not a distributed context");
+    for (int h = 0; h < c->B.n_shards; h++)
+        if (!c->peer_flags[h]) return fail(SLAMGPU_ERR_INVALID, "push collective unavailable: shard %d has no flag words (fine-grained memory)", h);
     if (iters < 1 || iters > 100000) return fail(SLAMGPU_ERR_INVALID, "iters out of range");
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (!usec && !ok) {  // enqueue only: several contexts driven by one thread must all have theirs queued before anybody waits
@@ -1400,7 +1416,11 @@ int slamgpu_dist_handshake_test(slamgpu_ctx *c, int32_t iters, double *usec, int
 
 int slamgpu_dist_collective_status(slamgpu_ctx *c, int32_t *ok) {
     if (int rc = check_ctx(c)) return rc;
-    if (!c->dist || !c->flags_dev || !ok) return fail(SLAMGPU_ERR_INVALID, "not a distributed context / null output");
+    if (!c->dist || !ok) return fail(SLAMGPU_ERR_INVALID, "not a distributed context / null output");
+    if (!c->flags_dev) {
+        *ok = 1;  // (no flag words: the push collective was never in use)
+        return 0;
+    }
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     uint32_t err = 0;

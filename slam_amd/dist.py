@@ -155,12 +155,15 @@ class DistFilter:
     def use_push(self, iters=20):
         """switch to the push collective (slamgpu.h: SLAMGPU_DIST_PUSH) after trying `iters` barriers; returns False (and stays
         with the gather) if a peer did not arrive.  Collective; call between settled steps."""
-        if len(self.ctx) == 1:
-            _, ok = self.ctx[0].dist_handshake_test(iters)
-        else:
-            for c in self.ctx:
-                c.dist_handshake_enqueue(iters)
-            ok = all(c.dist_collective_ok() for c in self.ctx)
+        try:
+            if len(self.ctx) == 1:
+                _, ok = self.ctx[0].dist_handshake_test(iters)
+            else:
+                for c in self.ctx:
+                    c.dist_handshake_enqueue(iters)
+                ok = all(c.dist_collective_ok() for c in self.ctx)
+        except capi.SlamGpuError:  # (no fine-grained flag words on this stack)
+            ok = False
         if not self._agree(ok):
             return False
         for c in self.ctx:
