@@ -2213,6 +2213,8 @@ __global__ void __launch_bounds__(kWave) dist_flag_kernel(DistFlagArgs A) {
     const int t = threadIdx.x;
     if (t >= A.n_shards || t == A.shard) return;
     __hip_atomic_store(A.peer_flags[t] + A.shard, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (an earlier barrier already gave up on a peer: the run is void and will be repeated: do not wait again)
+    if (__hip_atomic_load(A.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0) return;
     uint32_t spins = 0;
     // (sequence numbers only grow: signed distance copes with the wrap)
     while ((int32_t) (__hip_atomic_load(A.my_flags + t, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - A.seq) < 0) {

@@ -1228,7 +1228,7 @@ int launch_flags(slamgpu_ctx *c) {
     A.n_shards = c->B.n_shards;
     A.shard = c->B.shard;
     A.seq = ++c->flag_seq;
-    A.max_spins = 1u << 22;  // (~seconds: a peer that never arrives is reported, not waited for)
+    A.max_spins = 1u << 20;  // (~a second: a peer that never arrives is reported, not waited for)
     c->k->dist_flags(c->stream, A);
     HIP_TRY(hipGetLastError());
     return 0;

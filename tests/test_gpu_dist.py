@@ -243,3 +243,20 @@ def test_push_collective_two_processes_over_hip_ipc():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dist_ipc_check.py")], cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "DIST_IPC_OK push" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_flag_barrier_reports_a_peer_that_never_arrives():
+    """the barrier's spin is bounded: a shard whose peer never stores its flag gets an error word, not a hang, and later
+    barriers of that context do not wait again"""
+    import time
+    import slam_amd as sg
+    from slam_amd import host
+    from slam_amd.dist import DistFilter
+    Np = 1024
+    tp = host.make_tape(sim_args("example_webmap", "FASTSLAM2", Np, 3), max_obs=2)
+    f = DistFilter.local(2, Np // 2, tp["nlm"], method=sg.FASTSLAM2, seed=1)
+    t0 = time.time()
+    _, ok = f.ctx[0].dist_handshake_test(3)  # shard 1 never takes part
+    assert not ok and time.time() - t0 < 20.0
+    assert not f.ctx[0].dist_collective_ok()
+    f.close()
