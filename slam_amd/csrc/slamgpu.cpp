@@ -1458,11 +1458,13 @@ struct slamgpu_dist_group {
     std::vector<slamgpu_ctx *> ctx;
     std::vector<ncclComm_t> comms;  // one per context when every context has a device of its own
     bool shared = false;            // all contexts on one device and one stream: dist_gather_kernel instead of RCCL
+    bool push = false;              // push collective in use (slamgpu_dist_step runs the flag barrier itself)
 };
 
 namespace {
 int group_gather(slamgpu_dist_group *g) {
     const int k = (int) g->ctx.size();
+    if (g->push) return 0;
     if (g->shared) {
         DistGatherArgs A{};
         A.n_shards = k;
@@ -1513,6 +1515,24 @@ int slamgpu_dist_group_create(slamgpu_ctx **ctxs, int32_t k, slamgpu_dist_group 
     g->ctx.assign(ctxs, ctxs + k);
     g->shared = shared;
     if (!shared) {
+        // every shard has a device (hence hardware queues) of its own: try the push collective first -- a few barriers with
+        // everybody's queued before anybody is waited for -- and keep the RCCL all-gather for when a peer does not arrive
+        bool push = getenv("SLAMGPU_GROUP_NO_PUSH") == nullptr;
+        for (int i = 0; i < k && push; i++) push = slamgpu_dist_handshake_test(ctxs[i], 5, nullptr, nullptr) == 0;
+        for (int i = 0; i < k; i++) {
+            int32_t ok = 0;
+            if (slamgpu_dist_collective_status(ctxs[i], &ok) != 0 || !ok) push = false;
+        }
+        if (push) {
+            for (int i = 0; i < k; i++)
+                if (int rc = slamgpu_dist_set_collective(ctxs[i], SLAMGPU_DIST_PUSH)) {
+                    delete g;
+                    return rc;
+                }
+            g->push = true;
+            *out = g;
+            return 0;
+        }
         if (!rccl()) {
             delete g;
             return fail(SLAMGPU_ERR_HIP, "librccl.so.1 not found: %s", dlerror());
