@@ -329,8 +329,8 @@ int slamgpu_dist_handshake_test(slamgpu_ctx *ctx, int32_t iters, double *usec, i
 int slamgpu_dist_collective_status(slamgpu_ctx *ctx, int32_t *ok);
 
 /* All shards in ONE process (the reference's single backend process driving k GPUs; or k logical shards on one GPU, which
- * must then share one stream): export + connect + communicators (ncclCommInitAll; a copy kernel on a shared device) in
- * one call, then steps for every shard at once.  Contexts are created by the caller as for slamgpu_dist_connect and
+ * must then share one stream): export + connect + the collective (shards on devices of their own: SLAMGPU_DIST_PUSH if its
+ * barrier works, else ncclCommInitAll; a copy kernel on a shared device) in one call, then steps for every shard at once.  Contexts are created by the caller as for slamgpu_dist_connect and
  * destroyed by the caller after the group.  _history combines the shards' partial estimates (xyt[3] per recorded step);
  * _download concatenates the shards in shard order (buffers sized for all k * n particles). */
 typedef struct slamgpu_dist_group slamgpu_dist_group;
