@@ -324,6 +324,11 @@ int slamgpu_dist_gather(slamgpu_ctx *ctx);
  * afterwards whether any barrier of the run timed out.  Switch modes only between settled steps, on every shard alike. */
 #define SLAMGPU_DIST_GATHER 0
 #define SLAMGPU_DIST_PUSH 1
+/* SLAMGPU_DIST_FOLD: as PUSH, but the barrier rides at the head of the NEXT update launch instead of in a kernel of its own:
+ * that launch's helper block announces "my previous launch has completed" to every peer and waits for theirs, every other
+ * block waits for the helper's go word before it requests anything.  One launch per step and nothing else; a flag kernel
+ * only closes slamgpu_dist_settle.  Same requirements and the same bounded spins as PUSH. */
+#define SLAMGPU_DIST_FOLD 2
 int slamgpu_dist_set_collective(slamgpu_ctx *ctx, int32_t mode);
 int slamgpu_dist_handshake_test(slamgpu_ctx *ctx, int32_t iters, double *usec, int32_t *ok);
 int slamgpu_dist_collective_status(slamgpu_ctx *ctx, int32_t *ok);

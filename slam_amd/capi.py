@@ -525,8 +525,9 @@ class SlamGpu:
     def dist_comm_init(self, comm_id, n_ranks, rank):
         _chk(self.L.slamgpu_dist_comm_init(self.h, comm_id, n_ranks, rank))
 
-    def dist_set_collective(self, push):
-        _chk(self.L.slamgpu_dist_set_collective(self.h, 1 if push else 0))
+    def dist_set_collective(self, mode):
+        """0 / False: all-gather, 1 / True: pushed totals + flag kernel, 2: pushed totals + barrier folded into the next launch"""
+        _chk(self.L.slamgpu_dist_set_collective(self.h, int(mode)))
 
     def dist_handshake_test(self, iters=50):
         """(microseconds per barrier, every peer arrived) -- collective"""

@@ -87,6 +87,8 @@ struct PeerPtrs {
     int32_t *gen[2];
     float *lcum[2];
     float *gtot[2];       // the shard's table of everybody's block totals: peers push their totals into it (push collective)
+    uint32_t *flags;      // the shard's flag words (fine-grained): [h] = last sequence number shard h announced here,
+                          // [kMaxShards] error word, [kMaxShards + 1] the "go" word of the folded barrier
 };
 
 struct Buffers {
@@ -223,6 +225,10 @@ struct UpdateArgs {
     int32_t logw;            // the context keeps LOG-weights in poseA.w (slamgpu_config.log_weights)
     int32_t push_totals;     // distributed contexts, push collective: every block stores its totals into EVERY shard's table
                              // (Buffers::peers[h].gtot) instead of leaving them to an all-gather
+    uint32_t fold_seq;       // != 0: the barrier rides at the head of THIS launch (folded collective): the helper block
+                             // announces fold_seq to every peer ("my previous launch has completed") and waits for theirs,
+                             // every other block waits for the helper's go word before it touches anything
+    uint32_t fold_spins;     // bound of the helper's poll (the other blocks wait four times as long)
     int32_t finalize_par;    // parity of the estimate partials the helper block reduces
     int32_t finalize;        // 1: the extra block reduces the previous update's pose-estimate partials
     double *finalize_hist;   // history slot of that estimate (kHistStride doubles) or null

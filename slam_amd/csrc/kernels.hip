@@ -676,6 +676,48 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     // profiles/rocprof_sq_counters_r02_c3_*.txt), ~14 per wave, each a trip to L2 / memory in the middle of the dependent
     // chain.  Instead: ONE coalesced vector load of the whole struct at kernel entry, in flight together with the block
     // totals, parked in LDS; the per-landmark reads below are LDS broadcasts.
+    if constexpr (DIST) {
+        // Folded collective: the barrier between the previous launch and this one, inside this one.  The launch itself is
+        // the statement "my previous launch has completed and released its results" (stream order); the helper block passes
+        // it on to every peer (system-scope release store of the sequence number into the peer's flag word for this shard)
+        // and polls this shard's own flag words until every peer has said the same about ITS previous launch; then it
+        // opens the go word, which every other block of this launch polls before it requests anything: nothing a peer
+        // still reads is overwritten, nothing a peer has not finished writing is read (the block totals pushed into this
+        // shard's table included).  Flag words are fine-grained memory; every spin is bounded and a time-out is reported.
+        if (U.fold_seq != 0) {
+            uint32_t *fl = B.peers[B.shard].flags;
+            if ((int) blockIdx.x == h_grid - 1) {
+                const int t = threadIdx.x;
+                if (t < B.n_shards && t != B.shard) {
+                    __hip_atomic_store(B.peers[t].flags + B.shard, U.fold_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    uint32_t spins = 0;
+                    while ((int32_t) (__hip_atomic_load(fl + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - U.fold_seq) < 0) {
+                        if (__hip_atomic_load(fl + kMaxShards, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || ++spins > U.fold_spins) {
+                            __hip_atomic_store(fl + kMaxShards, U.fold_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // (system scope: what the peers released is visible from here on)
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) __hip_atomic_store(fl + kMaxShards + 1, U.fold_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else if (threadIdx.x == 0) {
+                uint32_t spins = 0;
+                while ((int32_t) (__hip_atomic_load(fl + kMaxShards + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - U.fold_seq) < 0) {
+                    if (++spins > 4u * U.fold_spins) {
+                        __hip_atomic_store(fl + kMaxShards, U.fold_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                // (only the polling wave fences: nothing of this launch has been read yet, so no other wave can hold a stale
+                // line, and 1 500 waves invalidating the L2 at once would cost more than the barrier)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            }
+            __syncthreads();
+        }
+    }
     // HEAD: everything whose address follows from the preloaded arguments is requested now, in one burst
     const bool logw = (h_flags & 4) != 0;
     const bool do_scan = h_plan && !h_scan_global;

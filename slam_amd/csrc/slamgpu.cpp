@@ -180,6 +180,7 @@ struct slamgpu_ctx {
     // push collective (slamgpu_dist_set_collective): the update launch stores its totals into every shard's table and a
     // one-wave flag kernel is the barrier; flags_dev = [kMaxShards] flag words + the error word, fine-grained memory
     bool dist_push = false;
+    bool dist_fold = false;  // push + the barrier folded into the head of the next update launch (SLAMGPU_DIST_FOLD)
     uint32_t *flags_dev = nullptr;
     uint32_t *peer_flags[kMaxShards] = {};
     uint32_t flag_seq = 0;
@@ -878,7 +879,9 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
         c->B.gtot[0] = c->gtot_dev[0];
         c->B.gtot[1] = c->gtot_dev[1];
         c->dist_clean = false;
-        U.push_totals = c->dist_push ? 1 : 0;
+        U.push_totals = (c->dist_push || c->dist_fold) ? 1 : 0;
+        U.fold_seq = c->dist_fold ? ++c->flag_seq : 0;
+        U.fold_spins = 1u << 20;
     }
     // a pending gather's genealogy composition: small packets: by the compute threads themselves; device packets: by copy
     // roles (one role = 256 particles x rows_per_role live rows; at most ~4 roles per particle tile: every role block
@@ -1171,6 +1174,7 @@ namespace {
 // the all-gather that follows an update launch of a distributed context, on the context's stream
 int launch_flags(slamgpu_ctx *c);
 int gather_totals(slamgpu_ctx *c) {
+    if (c->dist_fold) return 0;                // ... and the barrier rides at the head of the next launch
     if (c->dist_push) return launch_flags(c);  // the totals are in every table already: only the barrier is left
     if (!c->comm) return 0;
     const int par = (int) (c->obs_step & 1);
@@ -1307,6 +1311,7 @@ int slamgpu_dist_connect(slamgpu_ctx *c, int32_t n_shards, int32_t shard, const 
         for (int q = 0; q < 2; q++) t.lcum[q] = (float *) p[k++];
         for (int q = 0; q < 2; q++) t.gtot[q] = (float *) p[k++];
         c->peer_flags[h] = (uint32_t *) p[k++];
+        t.flags = c->peer_flags[h];
     }
     HIP_TRY(hipMalloc((void **) &c->peers_dev, sizeof(PeerPtrs) * (size_t) n_shards));
     HIP_TRY(hipMemcpy(c->peers_dev, table.data(), sizeof(PeerPtrs) * (size_t) n_shards, hipMemcpyHostToDevice));
@@ -1374,12 +1379,14 @@ int slamgpu_dist_totals(slamgpu_ctx *c, const float **local_dev, float **gathere
 int slamgpu_dist_set_collective(slamgpu_ctx *c, int32_t mode) {
     if (int rc = check_ctx(c)) return rc;
     if (!c->dist) return fail(SLAMGPU_ERR_INVALID, "not a distributed context");
-    if (mode != SLAMGPU_DIST_GATHER && mode != SLAMGPU_DIST_PUSH) return fail(SLAMGPU_ERR_INVALID, "unknown collective %d", mode);
-    if (mode == SLAMGPU_DIST_PUSH)
+    if (mode != SLAMGPU_DIST_GATHER && mode != SLAMGPU_DIST_PUSH && mode != SLAMGPU_DIST_FOLD)
+        return fail(SLAMGPU_ERR_INVALID, "unknown collective %d", mode);
+    if (mode != SLAMGPU_DIST_GATHER)
         for (int h = 0; h < c->B.n_shards; h++)
             if (!c->peer_flags[h]) return fail(SLAMGPU_ERR_INVALID, "push collective unavailable: shard %d has no flag words (fine-grained memory)", h);
     if (c->unplanned.has && !c->dist_clean) return fail(SLAMGPU_ERR_INVALID, "switch the collective between settled steps (slamgpu_dist_settle)");
     c->dist_push = mode == SLAMGPU_DIST_PUSH;
+    c->dist_fold = mode == SLAMGPU_DIST_FOLD;
     return 0;
 }
 
@@ -1450,6 +1457,7 @@ int slamgpu_dist_settle(slamgpu_ctx *c) {
     c->rng_skew++;
     c->unplanned.has = false;  // the stage this launch leaves is a no-op: weights normalised, nothing to resample
     c->dist_clean = true;
+    if (c->dist_fold) return launch_flags(c);  // no next launch to carry the barrier: a flag kernel closes the step
     return gather_totals(c);
 }
 

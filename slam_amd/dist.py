@@ -152,9 +152,10 @@ class DistFilter:
             gather.connect_comm()
         gather.barrier()
 
-    def use_push(self, iters=20):
-        """switch to the push collective (slamgpu.h: SLAMGPU_DIST_PUSH) after trying `iters` barriers; returns False (and stays
-        with the gather) if a peer did not arrive.  Collective; call between settled steps."""
+    def use_push(self, iters=20, fold=False):
+        """switch to the push collective (slamgpu.h: SLAMGPU_DIST_PUSH; fold=True: SLAMGPU_DIST_FOLD, the barrier inside the
+        next launch) after trying `iters` barriers; returns False (and stays with the gather) if a peer did not arrive.
+        Collective; call between settled steps."""
         try:
             if len(self.ctx) == 1:
                 _, ok = self.ctx[0].dist_handshake_test(iters)
@@ -167,7 +168,7 @@ class DistFilter:
         if not self._agree(ok):
             return False
         for c in self.ctx:
-            c.dist_set_collective(True)
+            c.dist_set_collective(2 if fold else 1)
         self.push = True
         return True
 

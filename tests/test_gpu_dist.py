@@ -32,7 +32,7 @@ def run_dist(sg, tp, Np, G, method, math_mode, seed, check_at=(), push=False):
     from slam_amd.dist import DistFilter
     f = DistFilter.local(G, Np // G, tp["nlm"], method=method, n_effective=int(0.75 * Np), seed=seed, math_mode=math_mode)
     if push:
-        assert f.use_push()
+        assert f.use_push(fold=(push == "fold"))
     Q, R, dt = tp["Q"], tp["R"], float(tp["dt"])
     mid = {}
     cat = lambda parts: {k: np.concatenate([p[k] for p in parts]) for k in ("xv", "Pv", "w", "xf", "Pf")}
@@ -219,8 +219,9 @@ def test_logical_shards_at_the_scaling_bench_size(n):
     same_state(ref, got, "final")
 
 
+@pytest.mark.parametrize("mode", [True, "fold"])
 @pytest.mark.parametrize("G", [1, 2])
-def test_push_collective_matches_single_context(G):
+def test_push_collective_matches_single_context(G, mode):
     """SLAMGPU_DIST_PUSH: block totals stored straight into every shard's table by the update launch, a one-wave flag kernel
     as the barrier (each logical shard on a stream of its own); mid-run reads included.  Two shards at most inside one
     process on one device: the runtime maps the streams of a process onto a few hardware queues, and a shard whose flag
@@ -231,18 +232,19 @@ def test_push_collective_matches_single_context(G):
     Np, nobs = 4096, 70
     tp = host.make_tape(sim_args("example_webmap", "FASTSLAM2", Np, 3), max_obs=nobs)
     ref, href, mref = run_single(sg, tp, Np, sg.FASTSLAM2, 1, 9, check_at=(20,))
-    got, hgot, mgot = run_dist(sg, tp, Np, G, sg.FASTSLAM2, 1, 9, check_at=(20,), push=True)
+    got, hgot, mgot = run_dist(sg, tp, Np, G, sg.FASTSLAM2, 1, 9, check_at=(20,), push=mode)
     assert href[2].sum() >= 3
     same_history(href, hgot)
     same_state(mref[20], mgot[20], 20)
     same_state(ref, got, "final")
 
 
-def test_push_collective_two_processes_over_hip_ipc():
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29657", SLAM_DIST_PUSH="1")
+@pytest.mark.parametrize("mode", ["push", "fold"])
+def test_push_collective_two_processes_over_hip_ipc(mode):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29657", SLAM_DIST_PUSH=mode)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dist_ipc_check.py")], cwd=ROOT, env=env, capture_output=True,
                        text=True, timeout=600)
-    assert r.returncode == 0 and "DIST_IPC_OK push" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.returncode == 0 and "DIST_IPC_OK " + mode in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
 
 
 def test_flag_barrier_reports_a_peer_that_never_arrives():

@@ -66,7 +66,7 @@ def worker(rank, world, Np, nobs, q):
                    first_particle=rank * n, n_particles_global=Np)
     f = DistFilter([c], GlooGather(c, rank, world))
     if os.environ.get("SLAM_DIST_PUSH"):
-        assert f.use_push(), "a peer did not arrive at the flag handshake"
+        assert f.use_push(fold=os.environ["SLAM_DIST_PUSH"] == "fold"), "a peer did not arrive at the flag handshake"
     for st in tp["steps"]:
         f.step(np.array(st["controls"], np.float32).reshape(-1, 3), tp["Q"], float(tp["dt"]), st["zf"], st["idf"], st["zn"], tp["R"])
     hist = f.history_fetch()
@@ -111,7 +111,7 @@ def main():
     for r in range(world):
         assert np.allclose(got[r][1][0], href[0], rtol=0, atol=1e-12)
         assert np.array_equal(got[r][1][2], href[2])
-    print("DIST_IPC_OK" + (" push" if os.environ.get("SLAM_DIST_PUSH") else ""))
+    print("DIST_IPC_OK" + (" " + os.environ["SLAM_DIST_PUSH"] if os.environ.get("SLAM_DIST_PUSH") else ""))
 
 
 if __name__ == "__main__":
