@@ -678,15 +678,15 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     // totals, parked in LDS; the per-landmark reads below are LDS broadcasts.
     if constexpr (DIST) {
         // Folded collective: the barrier between the previous launch and this one, inside this one.  The launch itself is
-        // the statement "my previous launch has completed and released its results" (stream order); the helper block passes
-        // it on to every peer (system-scope release store of the sequence number into the peer's flag word for this shard)
+        // the statement "my previous launch has completed and released its results" (stream order); the first wave of the
+        // first block passes it on to every peer (system-scope release store of the sequence number into the peer's flag word for this shard)
         // and polls this shard's own flag words until every peer has said the same about ITS previous launch; then it
-        // opens the go word, which every other block of this launch polls before it requests anything: nothing a peer
+        // opens the go word, which every block of this launch polls before it requests anything: nothing a peer
         // still reads is overwritten, nothing a peer has not finished writing is read (the block totals pushed into this
         // shard's table included).  Flag words are fine-grained memory; every spin is bounded and a time-out is reported.
         if (U.fold_seq != 0) {
             uint32_t *fl = B.peers[B.shard].flags;
-            if ((int) blockIdx.x == h_grid - 1) {
+            if (blockIdx.x == 0 && threadIdx.x < kWave) {  // (the first block to be dispatched: its first wave is the envoy)
                 const int t = threadIdx.x;
                 if (t < B.n_shards && t != B.shard) {
                     __hip_atomic_store(B.peers[t].flags + B.shard, U.fold_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -696,11 +696,11 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                             __hip_atomic_store(fl + kMaxShards, U.fold_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                             break;
                         }
-                        __builtin_amdgcn_s_sleep(2);
+                        __builtin_amdgcn_s_sleep(1);
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // (system scope: what the peers released is visible from here on)
                 }
-                __syncthreads();
+                // (the wave has reconverged: every lane's peer has arrived or been given up on)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: what the peers released is visible from here on
                 if (threadIdx.x == 0) __hip_atomic_store(fl + kMaxShards + 1, U.fold_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             } else if (threadIdx.x == 0) {
                 uint32_t spins = 0;
@@ -709,11 +709,12 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                         __hip_atomic_store(fl + kMaxShards, U.fold_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                // (only the polling wave fences: nothing of this launch has been read yet, so no other wave can hold a stale
-                // line, and 1 500 waves invalidating the L2 at once would cost more than the barrier)
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                // (no cache invalidation here: caches were invalidated when this launch started and nothing has been read
+                // since, so no wave can hold a stale line of what the peers wrote meanwhile; the go word itself is read past
+                // the caches.  Hundreds of blocks invalidating the L2 at once cost more than the whole barrier.)
+                asm volatile("" ::: "memory");
             }
             __syncthreads();
         }

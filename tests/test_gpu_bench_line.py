@@ -57,7 +57,7 @@ def test_multi_gpu_path_with_one_rank():
     assert r.returncode == 0, r.stderr[-2000:]
     j = one_line(r.stdout)
     check_common(j, 60, 5)
-    assert j["config"]["multi_gpu_path"] == "dist" and j["config"]["collective"] in ("push", "rccl")
+    assert j["config"]["multi_gpu_path"] == "dist" and j["config"]["collective"] in ("fold", "push", "rccl")
     # both collectives were tried alone before the run, and the line says which one it took and why
     assert 0.5 < j["config"]["allgather_us"] < 1e3 and 0.5 < j["config"]["flag_barrier_us"] < 1e3
     assert j["config"]["collective_choice"].startswith(j["config"]["collective"])
@@ -79,7 +79,7 @@ def test_multi_gpu_path_falls_back_to_the_exchange_path_when_the_peer_mappings_f
     assert j["config"]["check_vs_single_context"]["max_abs_diff"] <= 1e-9
 
 
-@pytest.mark.parametrize("collective", ["push", "native", "torch"])
+@pytest.mark.parametrize("collective", ["fold", "push", "native", "torch"])
 def test_multi_gpu_path_every_collective(collective):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29745", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -88,5 +88,5 @@ def test_multi_gpu_path_every_collective(collective):
     assert r.returncode == 0, r.stderr[-2000:]
     j = one_line(r.stdout)
     check_common(j, 60, 5)
-    assert j["config"]["collective"] == {"push": "push", "native": "rccl", "torch": "torch"}[collective]
+    assert j["config"]["collective"] == {"fold": "fold", "push": "push", "native": "rccl", "torch": "torch"}[collective]
     assert j["config"]["check_vs_single_context"]["max_abs_diff"] <= 1e-9
