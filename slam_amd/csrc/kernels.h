@@ -88,8 +88,11 @@ struct PeerPtrs {
     float *lcum[2];
     float *gtot[2];       // the shard's table of everybody's block totals: peers push their totals into it (push collective)
     uint32_t *flags;      // the shard's flag words (fine-grained): [h] = last sequence number shard h announced here,
-                          // [kMaxShards] error word, [kMaxShards + 1] the "go" word of the folded barrier
+                          // [kMaxShards] error word, [kGoBase + kGoStride * j] go word j of the folded barrier
 };
+constexpr int kGoWords = 16;    // copies of the go word (block b polls copy b % kGoWords: one uncached hot spot less)
+constexpr int kGoStride = 64;   // ... 256 bytes apart
+constexpr int kGoBase = 128;
 
 struct Buffers {
     float4 *poseA[2];

@@ -689,7 +689,10 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
             if (blockIdx.x == 0 && threadIdx.x < kWave) {  // (the first block to be dispatched: its first wave is the envoy)
                 const int t = threadIdx.x;
                 if (t < B.n_shards && t != B.shard) {
-                    __hip_atomic_store(B.peers[t].flags + B.shard, U.fold_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    // (relaxed: what this store announces -- the previous launch's results -- was released by that launch's
+                    // end, and the launch boundary orders this store after it; a release here would only write back an L2
+                    // that holds nothing dirty yet, for a microsecond)
+                    __hip_atomic_store(B.peers[t].flags + B.shard, U.fold_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     uint32_t spins = 0;
                     while ((int32_t) (__hip_atomic_load(fl + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - U.fold_seq) < 0) {
                         if (__hip_atomic_load(fl + kMaxShards, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0 || ++spins > U.fold_spins) {
@@ -699,12 +702,14 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                         __builtin_amdgcn_s_sleep(1);
                     }
                 }
-                // (the wave has reconverged: every lane's peer has arrived or been given up on)
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // system scope: what the peers released is visible from here on
-                if (threadIdx.x == 0) __hip_atomic_store(fl + kMaxShards + 1, U.fold_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                // (the wave has reconverged: every lane's peer has arrived or been given up on.  No cache maintenance: see below)
+                asm volatile("" ::: "memory");
+                if (threadIdx.x < kGoWords)
+                    __hip_atomic_store(fl + kGoBase + kGoStride * threadIdx.x, U.fold_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             } else if (threadIdx.x == 0) {
                 uint32_t spins = 0;
-                while ((int32_t) (__hip_atomic_load(fl + kMaxShards + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - U.fold_seq) < 0) {
+                const uint32_t *go = fl + kGoBase + kGoStride * (blockIdx.x % kGoWords);
+                while ((int32_t) (__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - U.fold_seq) < 0) {
                     if (++spins > 4u * U.fold_spins) {
                         __hip_atomic_store(fl + kMaxShards, U.fold_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;

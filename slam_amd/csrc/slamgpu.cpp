@@ -1183,7 +1183,7 @@ int gather_totals(slamgpu_ctx *c) {
 }
 
 constexpr int kDistArrays = 17;
-constexpr int kFlagWords = 2 * kMaxShards;  // flags [0, kMaxShards), error word at kMaxShards
+constexpr int kFlagWords = kGoBase + kGoStride * kGoWords;  // flags [0, kMaxShards), error word at kMaxShards, then the go words
 struct DistBlob {
     int64_t pid;
     int32_t device, ncap, cap_nf, compact;
