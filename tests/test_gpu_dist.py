@@ -262,3 +262,40 @@ def test_flag_barrier_reports_a_peer_that_never_arrives():
     assert not ok and time.time() - t0 < 20.0
     assert not f.ctx[0].dist_collective_ok()
     f.close()
+
+
+@pytest.mark.parametrize("mode", [False, True, "fold"])
+def test_random_reads_between_distributed_steps_do_not_change_results(mode):
+    """observer calls (history fetch, download, settle) at random points of a distributed run -- under each collective --
+    leave every later result identical to the single-context run"""
+    import slam_amd as sg
+    from slam_amd import host
+    from slam_amd.dist import DistFilter
+    Np, nobs, G = 4096, 90, 2
+    tp = host.make_tape(sim_args("example_webmap", "FASTSLAM2", Np, 3), max_obs=nobs)
+    ref, href, _ = run_single(sg, tp, Np, sg.FASTSLAM2, 1, 5)
+    f = DistFilter.local(G, Np // G, tp["nlm"], method=sg.FASTSLAM2, n_effective=int(0.75 * Np), seed=5, math_mode=1)
+    if mode:
+        assert f.use_push(fold=(mode == "fold"))
+    rng = np.random.default_rng(11)
+    hs = []
+    for st in tp["steps"]:
+        f.step(np.array(st["controls"], np.float32).reshape(-1, 3), tp["Q"], float(tp["dt"]), st["zf"], st["idf"], st["zn"], tp["R"])
+        r = rng.integers(0, 12)
+        if r == 0:
+            hs.append(f.history_fetch())
+        elif r == 1:
+            f.download()
+        elif r == 2:
+            f.settle()
+            f.settle()  # (idempotent)
+        elif r == 3:
+            assert f.nf() == st["nf_before"] + st["zn"].shape[0]
+    hs.append(f.history_fetch())
+    got = {k: np.concatenate([p[k] for p in f.download()]) for k in ("xv", "Pv", "w", "xf", "Pf")}
+    if mode:
+        assert f.collective_ok()
+    f.close()
+    hgot = [np.concatenate([h[j] for h in hs]) for j in range(3)]
+    same_history(href, hgot)
+    same_state(ref, got, "final")
