@@ -153,3 +153,19 @@ def test_slam_backend_gpus_k_is_independent_of_k(tmp_path):
     r = subprocess.run([EXE, "-m", os.path.join(DATA, "example_webmap.mat"), "-method", "FASTSLAM2", "-NPARTICLES", "1000", "-gpus", "2"],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "multiple of 512" in r.stderr
+
+
+def test_slam_backend_gpus_k_fastslam1(tmp_path):
+    """the same independence of k for FastSLAM1 (per-particle control noise drawn on the device: Philox keyed by the global
+    particle id, so the streams do not depend on the sharding either)"""
+    def run(k):
+        log = str(tmp_path / ("fs1_gpus%d.csv" % k))
+        cmd = [EXE, "-m", os.path.join(DATA, "example_webmap.mat"), "-method", "FASTSLAM1", "-NPARTICLES", "2048", "-NEFFECTIVE", "1536",
+               "-SWITCH_SEED_RANDOM", "7", "-log", log, "-maxsteps", "4000", "-gpus", str(k)]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "FastSLAM 1" in r.stdout, r.stdout[-800:] + r.stderr[-800:]
+        return np.loadtxt(log, delimiter=",", skiprows=1)
+    a, b = run(2), run(4)
+    assert len(a) >= 400 and np.array_equal(a[:, :7], b[:, :7])
+    err = np.hypot(a[:, 4] - a[:, 1], a[:, 5] - a[:, 2])
+    assert err.mean() < 1.5, err.mean()  # tracks the true path (FastSLAM1 at 2 048 particles: well under a metre and a half)
