@@ -206,6 +206,15 @@ int slamgpu_download(slamgpu_ctx *ctx, float *xv, float *Pv9, float *w, float *x
  * large to copy whole (config 5: 24 GB of landmark records), needs. */
 int slamgpu_download_range(slamgpu_ctx *ctx, int32_t first, int32_t count, float *xv, float *Pv9, float *w, float *xf,
                            float *Pf4);
+/* Read-only view of `count` particles first, first + stride, first + 2 stride, ... in the layout of slamgpu_download
+ * (xv[3 count], Pv[9 count], w[count], xf[2 Nf count], Pf[4 Nf count]; any pointer may be NULL; landmarks = 0 skips the
+ * records).  Unlike slamgpu_download it rewrites nothing: the pose is read through a pending resampling gather, the
+ * landmark records through the genealogy, by one kernel, and the state the next step works on is bit for bit what it
+ * would have been without the call.  What drawParticles / drawFeatureParticles need each iteration
+ * (ParticleSLAMWrapper.cpp:34-54) with a decimation stride, in one launch and five copies.  Single contexts only.
+ * Synchronises. */
+int slamgpu_peek(slamgpu_ctx *ctx, int32_t first, int32_t stride, int32_t count, float *xv, float *Pv9, float *w, float *xf,
+                 float *Pf4);
 int slamgpu_upload(slamgpu_ctx *ctx, int32_t nf, const float *xv, const float *Pv9, const float *w, const float *xf,
                    const float *Pf4);
 int slamgpu_sync(slamgpu_ctx *ctx);

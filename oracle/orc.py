@@ -221,6 +221,11 @@ class Particles:
         self.L.orc_particles_get(self.h, _p(xv), _p(Pv), _p(w), _p(xf), _p(Pf))
         return dict(xv=xv, Pv=Pv, w=w, xf=xf, Pf=Pf, nf=nf)
 
+    def weights(self):
+        w = np.zeros(self.N, f32)
+        self.L.orc_particles_get(self.h, None, None, _p(w), None, None)
+        return w
+
     def set(self, st):
         c = lambda a: np.ascontiguousarray(a, f32)
         self.L.orc_particles_set(self.h, int(st["nf"]), _p(c(st["xv"])), _p(c(st["Pv"])), _p(c(st["w"])),
@@ -284,12 +289,29 @@ class OrcSim(Sim):
         L.orc_sim_algo.argtypes = [C.c_void_p]
         L.orc_sim_noise.argtypes = [C.c_void_p] * 4
         L.orc_sim_ekf_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_sim_observe_local.argtypes = [C.c_void_p]
+        L.orc_sim_observe_local.restype = None
+        L.orc_sim_resample.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_sim_resample.restype = None
         ph = L.orc_sim_particles(self.h)
         self.P = Particles(orc, handle=C.c_void_p(ph)) if ph else None
         self.N = self.P.N if self.P else 0
 
     def set_rng(self, mode, seed):
         self.L.orc_sim_set_rng(self.h, mode, seed)
+
+    def observe_local(self):
+        """observe() without resampleParticles: sensor, association, tape, per-particle update"""
+        self.L.orc_sim_observe_local(self.h)
+
+    def resample(self, forced_did=None, forced_keep=None):
+        """resampleParticles (core.cpp:718-749).  forced_did None: the oracle's own decision and ancestors; True / False:
+        that decision, with forced_keep as the ancestors.  Returns the oracle's OWN ancestors; last_resample() its own
+        Neff and decision."""
+        own = np.zeros(self.N, np.int32)
+        fk = None if forced_keep is None else np.ascontiguousarray(forced_keep, np.int32)
+        self.L.orc_sim_resample(self.h, -1 if forced_did is None else int(bool(forced_did)), _p(fk), _p(own))
+        return own
 
     def set_log_weights(self, on=True):
         self.P.set_log_weights(on)

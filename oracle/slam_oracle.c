@@ -1006,13 +1006,14 @@ void orc_update_local(orc_particles *p, const orc_algo *a, const float *zf, cons
     p->nf += n;
 }
 
-void orc_update(orc_particles *p, const orc_algo *a, const float *zf, const int *idf, int m, const float *zn, int n,
-                const float *R4, const float *normals, const float *sel, int *keep_out, float *neff_out,
-                int *resampled_out) {
+/* resampleParticles (core.cpp:718-749) on a set whose per-particle update has run: normalise, Neff, the reference's own
+ * decision and stratified ancestors.  forced_did < 0: apply them (the reference).  forced_did = 0 / 1: apply THAT decision
+ * and, for 1, the ancestors in forced_keep instead -- tests drive the oracle with the GPU's genealogy this way, so that a
+ * free-running comparison does not decorrelate at the first stratum that lands on the other side of a cumulative-sum
+ * boundary (tests/test_gpu_freerun.py).  keep_out / neff_out / resampled_out always report the oracle's OWN plan. */
+void orc_resample_forced(orc_particles *p, const orc_algo *a, const float *sel, int forced_did, const int *forced_keep,
+                         int *keep_out, float *neff_out, int *resampled_out) {
     int N = p->N;
-    orc_update_local(p, a, zf, idf, m, zn, n, R4, normals);
-
-    /* resampleParticles (core.cpp:718-749) */
     float *w = (float *) malloc(sizeof(float) * (size_t) N);
     int *keep = (int *) malloc(sizeof(int) * (size_t) N);
     memcpy(w, p->w, sizeof(float) * (size_t) N);
@@ -1026,14 +1027,15 @@ void orc_update(orc_particles *p, const orc_algo *a, const float *zf, const int 
         for (int i = 0; i < N; i++) wsd += (double) w[i];
         for (int i = 0; i < N; i++) p->w[i] = p->w[i] - (float) (M + log(wsd));
     } else {
-    float ws = orc_eigen_sum(w, N);
-    for (int i = 0; i < N; i++) p->w[i] = w[i] / ws;
+        float ws = orc_eigen_sum(w, N);
+        for (int i = 0; i < N; i++) p->w[i] = w[i] / ws;
     }
     float nEff = 0;
     orc_stratified_resample(w, N, sel, keep, &nEff);
-    int did = 0;
-    if (a->resample && (nEff < (float) a->n_effective)) {
-        did = 1;
+    const int own = (a->resample && (nEff < (float) a->n_effective)) ? 1 : 0;
+    const int did = forced_did < 0 ? own : (forced_did ? 1 : 0);
+    const int *use = (forced_did > 0 && forced_keep) ? forced_keep : keep;
+    if (did) {
         float *oxv = (float *) malloc(sizeof(float) * 3 * (size_t) N);
         float *oPv = (float *) malloc(sizeof(float) * 9 * (size_t) N);
         float *oxf = (float *) malloc(sizeof(float) * 2 * (size_t) N * p->cap);
@@ -1042,16 +1044,17 @@ void orc_update(orc_particles *p, const orc_algo *a, const float *zf, const int 
         memcpy(oPv, p->Pv, sizeof(float) * 9 * (size_t) N);
         memcpy(oxf, p->xf, sizeof(float) * 2 * (size_t) N * p->cap);
         memcpy(oPf, p->Pf, sizeof(float) * 4 * (size_t) N * p->cap);
+        const size_t nfl = (size_t) p->nf; /* landmarks beyond nf are never read before they are written */
 #ifdef _OPENMP
 #pragma omp parallel for schedule(static) num_threads(g_threads) if (g_threads > 1)
 #endif
         for (int i = 0; i < N; i++) {
-            int k = keep[i];
-            if (k < 0) k = N - 1; /* unfilled keep[] is UB upstream (core.cpp:793,741); clamp */
+            int k = use[i];
+            if (k < 0 || k >= N) k = N - 1; /* unfilled keep[] is UB upstream (core.cpp:793,741); clamp */
             memcpy(p->xv + 3 * i, oxv + 3 * k, 3 * sizeof(float));
             memcpy(p->Pv + 9 * i, oPv + 9 * k, 9 * sizeof(float));
-            memcpy(p->xf + (size_t) i * 2 * p->cap, oxf + (size_t) k * 2 * p->cap, sizeof(float) * 2 * (size_t) p->cap);
-            memcpy(p->Pf + (size_t) i * 4 * p->cap, oPf + (size_t) k * 4 * p->cap, sizeof(float) * 4 * (size_t) p->cap);
+            memcpy(p->xf + (size_t) i * 2 * p->cap, oxf + (size_t) k * 2 * p->cap, sizeof(float) * 2 * nfl);
+            memcpy(p->Pf + (size_t) i * 4 * p->cap, oPf + (size_t) k * 4 * p->cap, sizeof(float) * 4 * nfl);
         }
         float nw = 1.0f / (float) N;
         if (p->logw) nw = logf(nw);
@@ -1063,9 +1066,16 @@ void orc_update(orc_particles *p, const orc_algo *a, const float *zf, const int 
     }
     if (keep_out) memcpy(keep_out, keep, sizeof(int) * (size_t) N);
     if (neff_out) *neff_out = nEff;
-    if (resampled_out) *resampled_out = did;
+    if (resampled_out) *resampled_out = forced_did < 0 ? did : own;
     free(w);
     free(keep);
+}
+
+void orc_update(orc_particles *p, const orc_algo *a, const float *zf, const int *idf, int m, const float *zn, int n,
+                const float *R4, const float *normals, const float *sel, int *keep_out, float *neff_out,
+                int *resampled_out) {
+    orc_update_local(p, a, zf, idf, m, zn, n, R4, normals);
+    orc_resample_forced(p, a, sel, -1, NULL, keep_out, neff_out, resampled_out);
 }
 
 /* ============================================================================================
@@ -1540,7 +1550,9 @@ int orc_sim_control(orc_sim *s) {
     return 0;
 }
 
-void orc_sim_observe(orc_sim *s) {
+/* first half of orc_sim_observe: sensor, association, the step's random tape and the per-particle update -- everything
+ * but resampleParticles */
+void orc_sim_observe_local(orc_sim *s) {
     observe(s);
     if (s->method != 0) {
         int N = s->P->N;
@@ -1555,9 +1567,20 @@ void orc_sim_observe(orc_sim *s) {
         } else {
             orc_philox_update_tape(s->seed, s->obs_step, 0, N, N, need_normals ? s->normals : NULL, s->sel);
         }
-        orc_update(s->P, &s->algo, s->zf, s->idf, s->m, s->zn, s->n, s->Re, s->normals, s->sel, NULL, &s->last_neff,
-                   &s->last_resampled);
+        orc_update_local(s->P, &s->algo, s->zf, s->idf, s->m, s->zn, s->n, s->Re, s->normals);
     }
+}
+
+/* second half: resampleParticles; forced_did / forced_keep as in orc_resample_forced; own_keep (optional) receives the
+ * oracle's own ancestors.  last_resample reports the oracle's OWN Neff and decision. */
+void orc_sim_resample(orc_sim *s, int forced_did, const int *forced_keep, int *own_keep) {
+    if (s->method != 0)
+        orc_resample_forced(s->P, &s->algo, s->sel, forced_did, forced_keep, own_keep, &s->last_neff, &s->last_resampled);
+}
+
+void orc_sim_observe(orc_sim *s) {
+    orc_sim_observe_local(s);
+    orc_sim_resample(s, -1, NULL, NULL);
 }
 
 int orc_sim_step(orc_sim *s) {

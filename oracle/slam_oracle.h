@@ -100,6 +100,10 @@ void orc_update(orc_particles *p, const orc_algo *a, const float *zf, const int 
                 const float *R4, const float *normals, const float *sel, int *keep_out, float *neff_out,
                 int *resampled_out);
 
+/* resampleParticles alone, optionally with an externally supplied decision and ancestor list (see slam_oracle.c) */
+void orc_resample_forced(orc_particles *p, const orc_algo *a, const float *sel, int forced_did, const int *forced_keep,
+                         int *keep_out, float *neff_out, int *resampled_out);
+
 /* The per-particle loop of the update only (no resampleParticles): used by the sharded-path tests. */
 void orc_update_local(orc_particles *p, const orc_algo *a, const float *zf, const int *idf, int m, const float *zn, int n,
                       const float *R4, const float *normals);
@@ -115,6 +119,8 @@ void orc_sim_set_rng(orc_sim *s, int rng_mode, uint64_t seed);
 int orc_sim_step(orc_sim *s);        /* -1 finished, 0 control step, 1 control step + observation update */
 int orc_sim_control(orc_sim *s);     /* first half: control + predict; -1 finished, 1 = observation due */
 void orc_sim_observe(orc_sim *s);    /* second half: observe + associate + update */
+void orc_sim_observe_local(orc_sim *s);  /* ... split again: everything but resampleParticles */
+void orc_sim_resample(orc_sim *s, int forced_did, const int *forced_keep, int *own_keep);
 orc_particles *orc_sim_particles(orc_sim *s);
 int orc_sim_nlandmarks(const orc_sim *s);
 void orc_sim_true(const orc_sim *s, float *x3, float *VnGn);

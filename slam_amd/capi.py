@@ -25,6 +25,7 @@ DECLARED_SYMBOLS = [
     "slamgpu_dist_history_fetch", "slamgpu_dist_gather", "slamgpu_dist_set_collective", "slamgpu_dist_handshake_test",
     "slamgpu_dist_collective_status", "slamgpu_dist_comm_id", "slamgpu_dist_comm_init", "slamgpu_dist_group_create", "slamgpu_dist_group_destroy",
     "slamgpu_dist_group_step", "slamgpu_dist_group_settle", "slamgpu_dist_group_history", "slamgpu_dist_group_download",
+    "slamgpu_peek",
 ]
 
 
@@ -93,6 +94,7 @@ def load_library():
     L.slamgpu_num_landmarks.argtypes = [C.c_void_p]
     L.slamgpu_download.argtypes = [C.c_void_p] * 6
     L.slamgpu_download_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 5
+    L.slamgpu_peek.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 5
     L.slamgpu_upload.argtypes = [C.c_void_p, C.c_int32] + [C.c_void_p] * 5
     L.slamgpu_sync.argtypes = [C.c_void_p]
     L.slamgpu_stream.argtypes = [C.c_void_p]
@@ -417,6 +419,19 @@ class SlamGpu:
         xf = np.zeros((N, nf, 2), np.float32) if landmarks else None
         Pf = np.zeros((N, nf, 2, 2), np.float32) if landmarks else None
         _chk(self.L.slamgpu_download_range(self.h, first, N, _ptr(xv), _ptr(Pv), _ptr(w), _ptr(xf), _ptr(Pf)))
+        return dict(xv=xv, Pv=Pv, w=w, xf=xf, Pf=Pf, nf=nf)
+
+    def peek(self, landmarks=True, first=0, stride=1, count=None):
+        """slamgpu_peek: the same dict as download() for particles first, first + stride, ..., without rewriting any state
+        (pose through a pending gather, records through the genealogy)"""
+        nf = self.nf()
+        N = (self.N - first + stride - 1) // stride if count is None else count
+        xv = np.zeros((N, 3), np.float32)
+        Pv = np.zeros((N, 3, 3), np.float32)
+        w = np.zeros(N, np.float32)
+        xf = np.zeros((N, nf, 2), np.float32) if landmarks else None
+        Pf = np.zeros((N, nf, 2, 2), np.float32) if landmarks else None
+        _chk(self.L.slamgpu_peek(self.h, first, stride, N, _ptr(xv), _ptr(Pv), _ptr(w), _ptr(xf), _ptr(Pf)))
         return dict(xv=xv, Pv=Pv, w=w, xf=xf, Pf=Pf, nf=nf)
 
     def upload(self, st):

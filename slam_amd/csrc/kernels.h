@@ -341,6 +341,18 @@ struct DistFlagArgs {
     uint32_t seq, max_spins;
 };
 
+// Read-only view of particles first, first + stride, ... (count of them) as the reference's vector<Particle> would hold
+// them: pose through a pending lazy gather (keep[]), landmark records through the genealogy.  Nothing is written to the
+// particle state (slamgpu_peek): a plot sink's decimated view, and the parity tests' window onto a genealogy that has been
+// accumulating for hundreds of resamples.
+struct PeekArgs {
+    int32_t first, stride, count, nf;
+    float4 *oa, *ob;     // [count] poseA / poseB as stored
+    float2 *oc;          // [count]
+    float4 *la;          // [nf][count] landmark records
+    float *lb;
+};
+
 struct KernelTable {
     // the step: [resampling stage of the previous update, inline] + [gather] + [fused predicts] + per-particle observation
     // update + in-block weight prefix / totals  (+ helper blocks: genealogy copy, Ctrl words, estimate reduction)
@@ -381,6 +393,7 @@ struct KernelTable {
     void (*shard_finish)(hipStream_t, const Buffers &, const WeightScratch &, double W, double Q, float neff, int resampled);
     void (*dist_gather)(hipStream_t, const DistGatherArgs &);
     void (*dist_flags)(hipStream_t, const DistFlagArgs &);
+    void (*peek)(hipStream_t, const Buffers &, const WeightScratch &, const PeekArgs &);
 };
 
 const KernelTable *kernels_strict();

@@ -2290,8 +2290,40 @@ static void launch_dist_flags(hipStream_t st, const DistFlagArgs &A) {
     hipLaunchKernelGGL(dist_flag_kernel, dim3(1), dim3(kWave), 0, st, A);
 }
 
+// slamgpu_peek: see kernels.h: PeekArgs.  blockIdx.y = group of kLmkPerBlockY landmarks (group 0 also moves the pose).
+__global__ void __launch_bounds__(kBlock) peek_kernel(Buffers B, WeightScratch ws, PeekArgs A) {
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= A.count) return;
+    const int k = A.first + idx * A.stride;
+    const Ctrl *ctrl = B.ctrl;
+    const int cur = ctrl->live[B.slot];
+    const bool pend = ctrl->pend[B.slot] != 0;
+    const int anc = pend ? ws.keep[B.slot][k] : k;
+    const size_t S = (size_t) B.ncap;
+    if (blockIdx.y == 0) {
+        float4 pa = B.poseA[cur][anc];
+        if (pend) pa.w = ctrl->inv_n;  // resampled particles restart at 1/N (core.cpp:744-747)
+        A.oa[idx] = pa;
+        A.ob[idx] = B.poseB[cur][anc];
+        A.oc[idx] = B.poseC[cur][anc];
+    }
+    const int j0 = blockIdx.y * kLmkPerBlockY, j1 = min(A.nf, j0 + kLmkPerBlockY);
+    for (int j = j0; j < j1; j++) {
+        float4 la;
+        float lb;
+        read_through_genealogy(B, B.lmk_live, cur, S, j, anc, la, lb);
+        A.la[(size_t) j * A.count + idx] = la;
+        A.lb[(size_t) j * A.count + idx] = lb;
+    }
+}
+
+static void launch_peek(hipStream_t st, const Buffers &B, const WeightScratch &ws, const PeekArgs &A) {
+    const int gy = A.nf > 0 ? (A.nf + kLmkPerBlockY - 1) / kLmkPerBlockY : 1;
+    hipLaunchKernelGGL(peek_kernel, dim3((A.count + kBlock - 1) / kBlock, gy), dim3(kBlock), 0, st, B, ws, A);
+}
+
 static const KernelTable kTable = {launch_update, launch_resample, launch_scan, launch_gather, launch_flatten, launch_identity, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat, launch_observe, launch_associate,
-                                   launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish, launch_dist_gather, launch_dist_flags};
+                                   launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish, launch_dist_gather, launch_dist_flags, launch_peek};
 
 }  // namespace SLAM_KNS
 

@@ -193,6 +193,8 @@ struct slamgpu_ctx {
     int fresh_row = -1;              // row the last update opened, while nothing but the resample the next update launch
                                      // applies has touched it: records of its landmarks sit in the source slot itself
     bool tables_dirty = true;
+    char *peek_dev = nullptr;        // staging of slamgpu_peek, grown on demand
+    size_t peek_bytes = 0;
     unsigned long long *stamps_dev = nullptr;  // diagnostic (SLAMGPU_STAMPS=1 + libslamgpu_stamps.so): UpdateArgs::stamps
     EstStage unplanned;           // the last update: resampling stage not run yet
     EstStage unreduced;           // an update whose partials exist (est_part[par]) but are not reduced yet
@@ -645,6 +647,7 @@ void slamgpu_destroy(slamgpu_ctx *c) {
         if (c->ws.keep[b]) (void) hipFree(c->ws.keep[b]);
     if (c->hist_dev) (void) hipFree(c->hist_dev);
     if (c->stamps_dev) (void) hipFree(c->stamps_dev);
+    if (c->peek_dev) (void) hipFree(c->peek_dev);
     if (c->comm && rccl()) (void) rccl()->CommDestroy((ncclComm_t) c->comm);
     for (void *p : c->ipc_opened) (void) hipIpcCloseMemHandle(p);
     if (c->peers_dev) (void) hipFree(c->peers_dev);
@@ -2097,6 +2100,90 @@ int slamgpu_download_range(slamgpu_ctx *c, int32_t first, int32_t count, float *
                         P[3] = b;
                     }
                 }
+        }
+    }
+    return 0;
+}
+
+int slamgpu_peek(slamgpu_ctx *c, int32_t first, int32_t stride, int32_t count, float *xv, float *Pv9, float *w, float *xf,
+                 float *Pf4) {
+    if (int rc = check_ctx(c)) return rc;
+    if (c->dist || c->cfg.n_particles_global != c->cfg.n_particles)
+        return fail(SLAMGPU_ERR_INVALID, "slamgpu_peek: single contexts only (shards: slamgpu_download / slamgpu_dist_group_download)");
+    if (first < 0 || count < 0 || stride < 1 || (count > 0 && (int64_t) first + (int64_t) (count - 1) * stride >= c->B.n))
+        return fail(SLAMGPU_ERR_INVALID, "particles %d + k * %d, k < %d, outside [0, %d)", first, stride, count, c->B.n);
+    if (count == 0) return 0;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = flush_predict(c)) return rc;   // (queued predicts belong to the state the caller asks about)
+    if (int rc = flush_stages(c)) return rc;    // the plan of the last update: weights normalised, or ancestors in keep[]
+    if (int rc = sync_tables(c)) return rc;
+    const int nf = (xf || Pf4) ? c->nf : 0;
+    const size_t M = (size_t) count;
+    // device staging: [oa M][ob M][oc M][la nf M][lb nf M], every part 16-byte aligned
+    const size_t o_a = 0, o_b = o_a + 16 * M, o_c = o_b + 16 * M, o_la = (o_c + 8 * M + 15) & ~(size_t) 15,
+                 o_lb = o_la + 16 * M * nf, total = o_lb + 4 * M * nf + 16;
+    if (total > c->peek_bytes) {
+        if (c->peek_dev) (void) hipFree(c->peek_dev);
+        c->peek_dev = nullptr;
+        c->peek_bytes = 0;
+        hipError_t e = hipMalloc((void **) &c->peek_dev, total);
+        if (e != hipSuccess) return fail(SLAMGPU_ERR_ALLOC, "hipMalloc(%zu): %s", total, hipGetErrorString(e));
+        c->peek_bytes = total;
+    }
+    PeekArgs A{};
+    A.first = first;
+    A.stride = stride;
+    A.count = count;
+    A.nf = nf;
+    A.oa = reinterpret_cast<float4 *>(c->peek_dev + o_a);
+    A.ob = reinterpret_cast<float4 *>(c->peek_dev + o_b);
+    A.oc = reinterpret_cast<float2 *>(c->peek_dev + o_c);
+    A.la = reinterpret_cast<float4 *>(c->peek_dev + o_la);
+    A.lb = reinterpret_cast<float *>(c->peek_dev + o_lb);
+    c->B.slot = c->slot;
+    {
+        Timed t(c, "peek");
+        c->k->peek(c->stream, c->B, c->ws, A);
+    }
+    HIP_TRY(hipGetLastError());
+    std::vector<float4> pa(M), pb(M), la(M * (size_t) nf);
+    std::vector<float2> pc(M);
+    std::vector<float> lb(M * (size_t) nf);
+    HIP_TRY(hipMemcpyAsync(pa.data(), A.oa, 16 * M, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(pb.data(), A.ob, 16 * M, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(pc.data(), A.oc, 8 * M, hipMemcpyDeviceToHost, c->stream));
+    if (nf > 0) {
+        HIP_TRY(hipMemcpyAsync(la.data(), A.la, 16 * M * nf, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(lb.data(), A.lb, 4 * M * nf, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < M; i++) {
+        if (xv) {
+            xv[3 * i] = pa[i].x;
+            xv[3 * i + 1] = pa[i].y;
+            xv[3 * i + 2] = pa[i].z;
+        }
+        if (Pv9) {
+            float *P = Pv9 + 9 * i;
+            P[0] = pb[i].x; P[1] = pb[i].y; P[2] = pb[i].w;
+            P[3] = pb[i].y; P[4] = pb[i].z; P[5] = pc[i].x;
+            P[6] = pb[i].w; P[7] = pc[i].x; P[8] = pc[i].y;
+        }
+        if (w) w[i] = pa[i].w;
+        for (int j = 0; j < nf; j++) {
+            const float4 a = la[(size_t) j * M + i];
+            const size_t at = i * (size_t) nf + (size_t) j;
+            if (xf) {
+                xf[at * 2] = a.x;
+                xf[at * 2 + 1] = a.y;
+            }
+            if (Pf4) {
+                float *P = Pf4 + at * 4;
+                P[0] = a.z;
+                P[1] = a.w;
+                P[2] = a.w;
+                P[3] = lb[(size_t) j * M + i];
+            }
         }
     }
     return 0;

@@ -1,0 +1,332 @@
+"""Free-running GPU filter against the oracle, WITHOUT uploads: the GPU's genealogy (epoch rows, row reuse, kRowFreshBit,
+compact-chunk composition, lazy gathers) accumulates over the whole run, hundreds of resamples deep, and is compared with
+the oracle's plain particle copies (core.cpp:718-749) after every observation step.
+
+How two float32 filters are kept comparable over 2 172 steps: the stratified ancestors are a discontinuous function of
+the weights (a stratum a hair on the other side of a cumulative-sum boundary picks the neighbouring particle), so every
+other test in this directory re-uploads the oracle's state after each step (teacher forcing) -- which also resets the
+genealogy to the identity.  Here the GPU is never touched; instead the ORACLE takes the GPU's resampling decision and
+ancestor list at every resample (orc_resample_forced), so both carry the same genealogy and everything else -- poses,
+covariances, landmark records read through the genealogy, weights -- must agree step after step.  The oracle's OWN plan is
+still computed and reported: Neff must agree, the decision may differ only next to the threshold, and its ancestors may
+differ for the share of particles the teacher-forced tests allow.
+
+The state is read with slamgpu_peek, which rewrites nothing (slamgpu_download would flatten the genealogy).  Reading runs
+the resampling stage of the last update as a launch of its own instead of inside the next update launch; an undisturbed run
+of the same inputs (no observer call between steps) is compared bit for bit at the end, history included, so what is checked
+against the oracle is what the product's one-launch-per-step pipeline computes.
+
+Tolerances: 2x what was measured free-running on MI355X (table below); they are wider than the teacher-forced per-step
+bounds of tests/test_gpu_parity.py because the pre-states of a step already differ by what the earlier steps left and the
+weights multiply up over the steps between two resamples.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import sim_args
+from test_gpu_parity import close_cov, sym
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+# Free-running bounds = 2x the maxima measured over whole runs on MI355X (gpurun_out/r3a/freerun_measure.log; per build:
+# strict / fast).  The filter is contractive (every update pulls pose and landmarks towards the same observations), so the
+# differences do not grow with the length of the run: the maxima below are over 2 172 steps x 1 000 particles and over steps
+# 990..1030 x 100 000 particles, at genealogy depths of ~1 300 and ~600 resamples.
+#   pose (m, rad mod 2 pi)      measured 6.1e-4 / 1.1e-3        landmark means (m)   measured 7.7e-4 / 1.4e-3
+#   Pf relative to its scale    measured 2.3e-5 both            estimate (x, y)      measured 3.7e-4
+#   FastSLAM2 weights, worst step: median 4.5e-3 / 1.5e-2, p99 4.7e-2 / 8.5e-2, max 0.10 / 0.18 (teacher-forced per-step
+#     bounds: 1e-3 / 1e-2, 5e-2 / 1e-1, 0.16 / 0.25: the median is what accumulates between resamples)
+#   FastSLAM1 weights max 3.4e-3 / 6.9e-3;  Neff relative 1.3e-2 / 2.6e-2 (FastSLAM1 1e-3 / 2.5e-3)
+FREE_POSE_ATOL = {0: 1.5e-3, 1: 2.5e-3}
+FREE_LMK_ATOL = {0: 2e-3, 1: 3e-3}
+FREE_W = {0: dict(median=1e-2, p99=1e-1, max=0.25), 1: dict(median=3e-2, p99=0.17, max=0.4)}
+FREE_W_FS1 = {0: 8e-3, 1: 1.5e-2}
+FREE_NEFF = {True: {0: 3e-2, 1: 5e-2}, False: {0: 2.5e-3, 1: 5e-3}}
+# The oracle's OWN stratified ancestors against the GPU's (index by index).  The cumulative sum both search is float32 data
+# with ~1e-3 relative noise per weight (FastSLAM2): its error is a fraction of a stratum at N = 1 000 and about one stratum
+# (1e-5) at N = 100 000 -- where the reference's own restart-from-zero float32 sums (core.cpp:813-824) are no better -- so a
+# large share of the strata pick the NEIGHBOURING particle on one side or the other (measured: 7 % / 16 % of the indices
+# differ at N = 1 000, 49 % / 68 % at N = 100 000, where 18 % / 41 % are more than one particle apart and the oracle's list
+# even ends in unfilled entries, keep = -1: the reference's float32 sum stops short of the last strata, core.cpp:800-806).
+# Which list is right?  A float64 cumulative sum of the ORACLE's weights with the same strata is the yardstick ("anc64"):
+# the GPU's list (block offsets in double, float32 only inside a block of 256) must stay within one particle of it for all
+# but a small share -- the weight noise alone moves the sum by a fraction of a stratum -- and does better than the
+# oracle's own list does.
+D_BINS = [0, 1, 2, 3, 5, 9, 17, 33, 1 << 30]  # |ancestor - anc64|: 0, 1, 2, 3-4, 5-8, 9-16, 17-32, more
+# share of the GPU's ancestors more than one particle / more than eight particles from anc64 (2x measured)
+ANC64_FAR = {1000: {0: 0.01, 1: 0.04}, 100000: {0: 0.36, 1: 0.8}}
+ANC_FAR8 = {1000: {0: 0.005, 1: 0.01}, 100000: {0: 0.05, 1: 0.2}}
+MEASURE = bool(os.environ.get("SLAM_FREERUN_MEASURE"))  # collect the maxima, assert nothing about magnitudes
+
+
+def ensure(cond, what):
+    if not MEASURE:
+        assert cond, what
+
+
+def _mk(sg, o, N, method, rng_mode, math_mode, seed):
+    algo = o.algo()
+    return sg.SlamGpu(N, o.nlm, method=2 if method == "FASTSLAM2" else 1, n_effective=algo.n_effective,
+                      use_heading=bool(algo.use_heading), add_predict_noise=bool(algo.add_predict_noise), wheel_base=algo.wheel_base,
+                      sigma_phi=algo.sigma_phi, rng_mode=rng_mode, seed=seed, math_mode=math_mode)
+
+
+def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None, threads=1, mapname="example_webmap"):
+    """Drive oracle + GPU as described in the module docstring.  window = (lo, hi): observation steps (1-based) whose full
+    state is compared; None = every step.  Returns the per-run statistics, the inputs (for the undisturbed replay) and the
+    GPU's final state / history."""
+    fs2 = method == "FASTSLAM2"
+    oracle.set_threads(threads)
+    o = oracle.sim(sim_args(mapname, method, N, seed))
+    if philox:
+        o.set_rng(1, seed)
+    algo = o.algo()
+    Q, R, dt = o.noise()
+    s = _mk(sg, o, N, method, sg.RNG_PHILOX if philox else sg.RNG_TAPE, math_mode, seed)
+    tol = FREE_W[math_mode]
+    st = dict(steps=0, resamples=0, decision_diff=0, anc_diff=0, anc_far=0, anc_maxd=0, anc_tot=0, max_pose=0.0, max_lmk=0.0, max_w_median=0.0, max_w_p99=0.0,
+              max_w=0.0, max_neff_rel=0.0)
+    inputs, ctl = [], []
+    k = 0
+    while k < nobs:
+        a = o.control()
+        if a < 0:
+            inputs.append(dict(ctl=ctl, tail=True))  # control steps after the last observation
+            break
+        x, vg = o.true_pose()
+        noise2 = o.last_noise2() if (algo.add_predict_noise and not philox) else None
+        s.predict(float(vg[0]), float(vg[1]), Q, float(dt), float(x[2]), noise2)
+        ctl.append((float(vg[0]), float(vg[1]), float(x[2]), noise2))
+        if a != 1:
+            continue
+        o.observe_local()
+        ob = o.last_obs()
+        normals, sel = (None, None) if philox else o.last_tape()
+        s.update(ob["zf"], ob["idf"], ob["zn"], R, normals, sel)
+        s.estimate_async()
+        inputs.append(dict(ctl=ctl, zf=ob["zf"], idf=ob["idf"], zn=ob["zn"], normals=normals, sel=sel))
+        ctl = []
+        k += 1
+        ne_g, did_g, _ = s.stats()
+        keep = s.ancestors() if did_g else None
+        if did_g:
+            # yardstick: ancestors from a float64 cumulative sum of the oracle's (not yet normalised) weights, same strata
+            w64 = o.P.weights().astype(np.float64)
+            cum = np.cumsum(w64)
+            sel64 = o.last_tape()[1].astype(np.float64)
+            anc64 = np.minimum(np.searchsorted(cum, sel64 * cum[-1], side="right"), N - 1)
+        own = o.resample(did_g, keep)
+        ne_o, did_o = o.last_resample()
+        tag = "%s N=%d obs %d (m=%d n=%d)" % (method, N, k, ob["zf"].shape[0], ob["zn"].shape[0])
+        st["steps"] += 1
+        st["resamples"] += int(did_g)
+        rel_ne = abs(float(ne_g) / float(ne_o) - 1.0)
+        st["max_neff_rel"] = max(st["max_neff_rel"], rel_ne)
+        ensure(rel_ne <= FREE_NEFF[fs2][math_mode], (tag, ne_g, ne_o))
+        if did_g != did_o:
+            # only next to the threshold: both Neff within the tolerance of NEFFECTIVE
+            st["decision_diff"] += 1
+            ensure(abs(float(ne_o) / algo.n_effective - 1.0) <= FREE_NEFF[fs2][math_mode], (tag, ne_g, ne_o, algo.n_effective))
+        elif did_g:
+            d = np.abs(own.astype(np.int64) - keep)
+            st["anc_diff"] += int(np.count_nonzero(d))
+            st["anc_far"] += int(np.count_nonzero(d > 1))
+            st["anc_maxd"] = max(st["anc_maxd"], int(d.max()))
+            st["anc_tot"] += N
+            st["d_hist"] = st.get("d_hist", 0) + np.histogram(np.abs(anc64 - keep), bins=D_BINS)[0]
+            st["gpu_far64"] = st.get("gpu_far64", 0) + int(np.count_nonzero(np.abs(anc64 - keep) > 1))
+            st["gpu_diff64"] = st.get("gpu_diff64", 0) + int(np.count_nonzero(anc64 != keep))
+            st["own_far64"] = st.get("own_far64", 0) + int(np.count_nonzero(np.abs(anc64 - own) > 1))
+            st["own_diff64"] = st.get("own_diff64", 0) + int(np.count_nonzero(anc64 != own))
+            assert np.all(np.diff(keep) >= 0) and keep.min() >= 0 and keep.max() < N, tag
+        if window is not None and not (window[0] <= k <= window[1]):
+            continue
+        got = s.peek()
+        exp = o.particles()
+        assert got["nf"] == exp["nf"], tag
+        dxv = np.abs(got["xv"].astype(np.float64) - exp["xv"])
+        dxv[:, 2] = np.minimum(dxv[:, 2], np.abs(dxv[:, 2] - 2 * np.pi))  # headings next to +-pi
+        dp = float(dxv.max())
+        st["max_pose"] = max(st["max_pose"], dp)
+        ensure(dp <= FREE_POSE_ATOL[math_mode], (tag, "pose", dp))
+        ensure(close_cov(got["Pv"], sym(exp["Pv"]), 5e-3), (tag, "Pv"))
+        if got["nf"]:
+            dl = float(np.abs(got["xf"] - exp["xf"]).max())
+            st["max_lmk"] = max(st["max_lmk"], dl)
+            ensure(dl <= FREE_LMK_ATOL[math_mode], (tag, "landmarks", dl))
+            ensure(close_cov(got["Pf"], sym(exp["Pf"]), 5e-3), (tag, "Pf"))
+            sc = np.abs(exp["Pf"]).max()
+            st["max_Pf_rel"] = max(st.get("max_Pf_rel", 0.0), float(np.abs(got["Pf"].astype(np.float64) - sym(exp["Pf"])).max() / max(sc, 1e-12)))
+        if did_g:
+            assert np.all(got["w"] == exp["w"]), tag  # 1/N on both sides
+        else:
+            g, e = got["w"].astype(np.float64), exp["w"].astype(np.float64)
+            assert abs(g.sum() - 1.0) <= 1e-4 and abs(e.sum() - 1.0) <= 1e-4, tag
+            rel = np.abs(g / e - 1.0)
+            if fs2:
+                st["max_w_median"] = max(st["max_w_median"], float(np.median(rel)))
+                st["max_w_p99"] = max(st["max_w_p99"], float(np.quantile(rel, 0.99)))
+                st["max_w"] = max(st["max_w"], float(rel.max()))
+                ensure(np.median(rel) <= tol["median"] and np.quantile(rel, 0.99) <= tol["p99"] and rel.max() <= tol["max"],
+                       (tag, np.median(rel), np.quantile(rel, 0.99), rel.max()))
+            else:
+                st["max_w"] = max(st["max_w"], float(rel.max()))
+                ensure(rel.max() <= FREE_W_FS1[math_mode], (tag, rel.max()))
+        eg, eo = got["xv"][:, :2].astype(np.float64).mean(axis=0), o.estimate()[:2]
+        st["max_est"] = max(st.get("max_est", 0.0), float(np.abs(eg - eo).max()))
+        ensure(np.abs(eg - eo).max() <= 1e-3, (tag, eg, eo))
+    hist = s.history_fetch()
+    final = s.download()
+    final_exp = o.particles()
+    s.close()
+    o.close()
+    oracle.set_threads(1)
+    return st, inputs, (Q, R, float(dt)), hist, final, final_exp
+
+
+def undisturbed(sg, oracle, method, N, seed, math_mode, philox, inputs, QRdt, mapname="example_webmap"):
+    """The same inputs through predict / update / estimate_async only (Philox: slamgpu_step): no observer call ever runs a
+    stage out of line -- the product's pipeline."""
+    o = oracle.sim(sim_args(mapname, method, N, seed))  # (only for the algorithm constants)
+    s = _mk(sg, o, N, method, sg.RNG_PHILOX if philox else sg.RNG_TAPE, math_mode, seed)
+    o.close()
+    Q, R, dt = QRdt
+    hist = []
+    for i, st in enumerate(inputs):
+        if st.get("tail"):
+            for (V, G, phi, n2) in st["ctl"]:
+                s.predict(V, G, Q, dt, phi, n2)
+            continue
+        if philox:
+            s.step(np.array([c[:3] for c in st["ctl"]], f32).reshape(-1, 3), Q, dt, st["zf"], st["idf"], st["zn"], R)
+        else:
+            for (V, G, phi, n2) in st["ctl"]:
+                s.predict(V, G, Q, dt, phi, n2)
+            s.update(st["zf"], st["idf"], st["zn"], R, st["normals"], st["sel"])
+            s.estimate_async()
+        if (i & 2047) == 2047:
+            hist.append(s.history_fetch())
+    hist.append(s.history_fetch())
+    final = s.download()
+    s.close()
+    return tuple(np.concatenate([h[j] for h in hist]) for j in range(3)), final
+
+
+def check_ancestors(st, method, math_mode, N):
+    """ANC: the GPU's and the oracle's own ancestor lists against each other and against the float64 yardstick, over all
+    resamples of a run"""
+    if not st["anc_tot"]:
+        return
+    T = float(st["anc_tot"])
+    print("ancestors, GPU vs oracle's own: %.2f %% differ, %.3f %% by more than one particle (largest distance %d); vs float64 "
+          "cumulative sum: GPU %.2f %% differ / %.3f %% by more than one, oracle's own %.2f %% / %.3f %%" % (
+              100 * st["anc_diff"] / T, 100 * st["anc_far"] / T, st["anc_maxd"], 100 * st["gpu_diff64"] / T, 100 * st["gpu_far64"] / T,
+              100 * st["own_diff64"] / T, 100 * st["own_far64"] / T))
+    print("distance of the GPU's ancestors from the float64 yardstick, share per bin 0 | 1 | 2 | 3-4 | 5-8 | 9-16 | 17-32 | more: %s"
+          % " | ".join("%.4f" % (c / T) for c in st["d_hist"]))
+    fs2 = method == "FASTSLAM2"
+    ensure(st["gpu_far64"] / T <= (ANC64_FAR[N][math_mode] if fs2 else 2e-3), st)
+    ensure(st["d_hist"][5:].sum() / T <= (ANC_FAR8[N][math_mode] if fs2 else 1e-3), st)  # more than 8 particles away
+    if N <= 1000:
+        ensure(st["anc_far"] / T <= (0.04 if fs2 else 2e-3), st)
+
+
+def check_final(final, final_exp, math_mode):
+    assert final["nf"] == final_exp["nf"]
+    if MEASURE:
+        return
+    dxv = np.abs(final["xv"].astype(np.float64) - final_exp["xv"])
+    dxv[:, 2] = np.minimum(dxv[:, 2], np.abs(dxv[:, 2] - 2 * np.pi))
+    assert dxv.max() <= FREE_POSE_ATOL[math_mode]
+    assert np.abs(final["xf"] - final_exp["xf"]).max() <= FREE_LMK_ATOL[math_mode]
+    assert close_cov(final["Pf"], sym(final_exp["Pf"]), 5e-3)
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+@pytest.mark.parametrize("method,philox", [("FASTSLAM2", False), ("FASTSLAM2", True), ("FASTSLAM1", False), ("FASTSLAM1", True)],
+                         ids=["fs2-tape", "fs2-philox", "fs1-tape", "fs1-philox"])
+def test_whole_run_ancestor_forced(sg_mod, oracle, method, philox, math_mode):
+    """example_webmap, 1 000 particles, ALL 2 172 observation steps (~1 250 resamples), no upload, every step compared."""
+    N, seed = 1000, 7
+    st, inputs, QRdt, hist, final, final_exp = forced_run(sg_mod, oracle, method, N, seed, 100000, math_mode, philox)
+    assert st["steps"] == 2172 and st["resamples"] > 800, st
+    assert final["nf"] == 35
+    # the oracle's own plan: decisions differ only at the threshold (asserted per step), ancestors for a small share
+    print("free-running %s %s %s: %s" % (method, "philox" if philox else "tape", ["strict", "fast"][math_mode], st))
+    ensure(st["decision_diff"] <= 8, st)  # measured <= 3 of 2 172
+    check_ancestors(st, method, math_mode, N)
+    check_final(final, final_exp, math_mode)
+    # the product's pipeline (no observer calls) computes the same bits
+    hist_u, final_u = undisturbed(sg_mod, oracle, method, N, seed, math_mode, philox, inputs, QRdt)
+    for a, b in zip(hist, hist_u):
+        assert np.array_equal(a, b)
+    for key in ("xv", "Pv", "w", "xf", "Pf"):
+        assert np.array_equal(final[key].view(np.uint32), final_u[key].view(np.uint32)), key
+    print("free-running %s %s %s: %s" % (method, "philox" if philox else "tape", ["strict", "fast"][math_mode], st))
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+def test_bench_window_full_size_ancestor_forced(sg_mod, oracle, math_mode):
+    """BASELINE configs[2] at size: 100 000 particles, Philox, free-running from step 1 with the GPU's ancestors forced into
+    the oracle; full state compared on observation steps 990..1030 (the window bench.py times: 35 landmarks, resample rate
+    ~0.55, genealogy ~600 resamples deep)."""
+    N, seed = 100000, 7
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    st, inputs, QRdt, hist, final, final_exp = forced_run(sg_mod, oracle, "FASTSLAM2", N, seed, 1030, math_mode, True, window=(990, 1030),
+                                                          threads=threads)
+    assert st["steps"] == 1030 and st["resamples"] > 400, st
+    assert final["nf"] == 35
+    print("free-running FASTSLAM2 philox N=100000 %s: %s" % (["strict", "fast"][math_mode], st))
+    check_ancestors(st, "FASTSLAM2", math_mode, N)
+    check_final(final, final_exp, math_mode)
+    hist_u, final_u = undisturbed(sg_mod, oracle, "FASTSLAM2", N, seed, math_mode, True, inputs, QRdt)
+    for a, b in zip(hist, hist_u):
+        assert np.array_equal(a, b)
+    for key in ("xv", "Pv", "w", "xf", "Pf"):
+        assert np.array_equal(final[key].view(np.uint32), final_u[key].view(np.uint32)), key
+    print("free-running FASTSLAM2 philox N=100000 %s: %s" % (["strict", "fast"][math_mode], st))
+
+
+@pytest.fixture(scope="module")
+def sg_mod():
+    import slam_amd
+    assert slam_amd.device_count() >= 1, "GPU tests need a HIP device"
+    return slam_amd
+
+
+def test_peek_equals_download(sg_mod):
+    """slamgpu_peek (read-only, through a pending gather and the genealogy) returns what slamgpu_download (gather + flatten)
+    returns, strided views included, and leaves the run bit-identical to one that was never peeked."""
+    from slam_amd import host
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    N = 3000
+    tape = host.make_tape(["-m", os.path.join(root, "data", "example_webmap.mat"), "-method", "FASTSLAM2", "-NPARTICLES", N,
+                           "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", 4], max_obs=120)
+    out = []
+    for peeking in (True, False):
+        s = sg_mod.SlamGpu(N, tape["nlm"], method=2, n_effective=int(0.75 * N), rng_mode=sg_mod.RNG_PHILOX, seed=6, math_mode=1)
+        for i, stp in enumerate(tape["steps"]):
+            s.step(np.array(stp["controls"], f32).reshape(-1, 3), tape["Q"], float(tape["dt"]), stp["zf"], stp["idf"], stp["zn"], tape["R"])
+            if peeking and i % 7 == 3:
+                p = s.peek(first=5, stride=13)
+                assert p["xv"].shape[0] == (N - 5 + 12) // 13
+        pk = s.peek() if peeking else None
+        h = s.history_fetch()
+        d = s.download()
+        if peeking:
+            for key in ("xv", "Pv", "w", "xf", "Pf"):
+                assert np.array_equal(pk[key].view(np.uint32), d[key].view(np.uint32)), key
+            ps = s.peek(first=7, stride=11, count=50)
+            for key in ("xv", "Pv", "w", "xf", "Pf"):
+                assert np.array_equal(ps[key], d[key][7:7 + 11 * 50:11]), key
+        out.append((d, h))
+        s.close()
+    (a, ha), (b, hb) = out
+    assert 10 < ha[2].sum() < 120
+    for x, y in zip(ha, hb):
+        assert np.array_equal(x, y)
+    for key in ("xv", "Pv", "w", "xf", "Pf"):
+        assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), key
