@@ -39,7 +39,10 @@ typedef enum {
     SLAMGPU_ERR_HIP = -2,       /* a HIP runtime call failed (message in slamgpu_last_error) */
     SLAMGPU_ERR_CAPACITY = -3,  /* landmark capacity exceeded */
     SLAMGPU_ERR_NO_DEVICE = -4, /* no usable GPU: the product path has no CPU fallback */
-    SLAMGPU_ERR_ALLOC = -5
+    SLAMGPU_ERR_ALLOC = -5,
+    SLAMGPU_ERR_BARRIER = -6    /* distributed contexts, push / fold collective: a peer did not arrive at a flag barrier in
+                                   time; every step since then ran unsynchronised and its results are void.  Sticky: destroy
+                                   the contexts (or switch to SLAMGPU_DIST_GATHER and start the run again) */
 } slamgpu_status;
 
 enum { SLAMGPU_FASTSLAM1 = 1, SLAMGPU_FASTSLAM2 = 2 };

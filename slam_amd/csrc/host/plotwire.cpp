@@ -200,6 +200,10 @@ bool ZmtpPairClient::connect(const std::string &host, int port, double timeout_s
         len = fh[1];
         for (int i = 0; i < 7; i++) len = (len << 8) | rest[i];
     }
+    if (len > 4096) {  // (a READY command is a few dozen bytes: the length is the peer's word, never an allocation size)
+        if (err) *err = "plot server sent an oversized ZMTP command";
+        return false;
+    }
     std::vector<char> rb((size_t) len);
     if (len && !read_all(rb.data(), (size_t) len, err)) return false;
     if (!(fh[0] & 0x04) || len < 6 || memcmp(rb.data() + 1, "READY", 5) != 0) {

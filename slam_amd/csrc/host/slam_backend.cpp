@@ -60,7 +60,11 @@ static int run_distributed(Simulator &sim, int k, long maxsteps, FILE *log, Plot
         fprintf(stderr, "-gpus %d needs -rng philox and -assoc known\n", k);
         return EXIT_FAILURE;
     }
-    if (k < 1 || N % (256 * k) != 0) {
+    if (k < 1) {
+        fprintf(stderr, "-gpus needs a positive number of GPUs\n");
+        return EXIT_FAILURE;
+    }
+    if (N % (256 * k) != 0) {
         fprintf(stderr, "-gpus %d: NPARTICLES must be a multiple of %d (e.g. %d)\n", k, 256 * k, (N + 256 * k - 1) / (256 * k) * (256 * k));
         return EXIT_FAILURE;
     }
@@ -391,15 +395,17 @@ int main(int argc, char **argv) {
             if (ctx) {  // drawParticles / drawFeatureParticles (ParticleSLAMWrapper.cpp:34-54), decimated
                 const int nfl = slamgpu_num_landmarks(ctx);
                 px.clear(); py.clear(); fx.clear(); fy.clear();
-                dxv.resize(3);
-                dxf.resize(2 * (size_t) std::max(nfl, 1));
-                for (int i = 0; i < N && !rc; i += stride) {
-                    rc = slamgpu_download_range(ctx, i, 1, dxv.data(), nullptr, nullptr, nfl ? dxf.data() : nullptr, nullptr);
-                    px.push_back(dxv[0]);
-                    py.push_back(dxv[1]);
+                // one strided read-only view per iteration (slamgpu_peek: one kernel, through the genealogy, nothing rewritten)
+                const int cnt = (N + stride - 1) / stride;
+                dxv.resize(3 * (size_t) cnt);
+                dxf.resize(2 * (size_t) std::max(nfl, 1) * (size_t) cnt);
+                rc = slamgpu_peek(ctx, 0, stride, cnt, dxv.data(), nullptr, nullptr, nfl ? dxf.data() : nullptr, nullptr);
+                for (int i = 0; i < cnt && !rc; i++) {
+                    px.push_back(dxv[3 * (size_t) i]);
+                    py.push_back(dxv[3 * (size_t) i + 1]);
                     for (int j = 0; j < nfl; j++) {
-                        fx.push_back(dxf[2 * j]);
-                        fy.push_back(dxf[2 * j + 1]);
+                        fx.push_back(dxf[2 * ((size_t) i * nfl + j)]);
+                        fy.push_back(dxf[2 * ((size_t) i * nfl + j) + 1]);
                     }
                 }
                 plot.setParticles(px, py);

@@ -702,8 +702,12 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                         __builtin_amdgcn_s_sleep(1);
                     }
                 }
-                // (the wave has reconverged: every lane's peer has arrived or been given up on.  No cache maintenance: see below)
-                asm volatile("" ::: "memory");
+                // the wave has reconverged: every lane's peer has arrived or been given up on.  ONE acquire at system scope
+                // by this wave (its CU's vector cache, and whatever the XCD's L2 holds of peer-written lines), so that what the
+                // peers stored before their announcement is what this launch reads: one wave's buffer_inv, not hundreds of
+                // blocks'; the go-word polls of the other blocks stay relaxed
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (threadIdx.x < kGoWords)
                     __hip_atomic_store(fl + kGoBase + kGoStride * threadIdx.x, U.fold_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             } else if (threadIdx.x == 0) {

@@ -1185,6 +1185,19 @@ int gather_totals(slamgpu_ctx *c) {
     return 0;
 }
 
+// The barrier error word of the push / fold collective is sticky (a kernel that finds it set does not wait again): whoever
+// synchronises with the device anyway -- history fetch, settle + read, the status query -- reports it, so that a C caller
+// that never polls slamgpu_dist_collective_status still cannot read results of unsynchronised steps as valid.
+int barrier_check(slamgpu_ctx *c) {
+    if (!c->dist || !c->flags_dev || !(c->dist_push || c->dist_fold)) return 0;
+    uint32_t err = 0;
+    HIP_TRY(hipMemcpy(&err, c->flags_dev + kMaxShards, sizeof err, hipMemcpyDeviceToHost));
+    if (err != 0)
+        return fail(SLAMGPU_ERR_BARRIER, "flag barrier %u of the push collective timed out: a peer did not arrive; the steps since then are void "
+                                         "(recreate the contexts, or use SLAMGPU_DIST_GATHER)", err);
+    return 0;
+}
+
 constexpr int kDistArrays = 17;
 constexpr int kFlagWords = kGoBase + kGoStride * kGoWords;  // flags [0, kMaxShards), error word at kMaxShards, then the go words
 struct DistBlob {
@@ -1588,6 +1601,8 @@ int slamgpu_dist_group_settle(slamgpu_dist_group *g) {
         HIP_TRY(hipSetDevice(c->cfg.device));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    for (slamgpu_ctx *c : g->ctx)
+        if (int rc = barrier_check(c)) return rc;
     return 0;
 }
 
@@ -1820,7 +1835,7 @@ int slamgpu_dist_history_fetch(slamgpu_ctx *c, double *raw4, float *neff, int32_
     *count = n;
     if (int rc = keep_history_tail(c, h, n)) return rc;
     c->est_fresh = false;
-    return 0;
+    return barrier_check(c);
 }
 
 int slamgpu_estimate_fetch(slamgpu_ctx *c, double *xyt, int32_t max_count, int32_t *count) {

@@ -44,6 +44,21 @@ def test_default_line_single_gpu():
     assert j["roofline"]["peak"] == 8000.0 and j["roofline"]["kernel"] == "fs2_update"
     assert j["roofline"]["traffic"] and j["roofline"]["avg_launch_us"] > 5.0  # counters of this workload are committed
     assert 1e9 < j["value"] < 2e10
+    # frac is what the fabric counters saw over the live launch time -- never the reference-formulation figure, which is
+    # reported beside it and may exceed 1
+    r = j["roofline"]
+    assert abs(r["achieved"] - r["traffic"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"] and 0.05 < r["frac"] < 1.0
+    assert r["algorithmic_frac"] > r["frac"]
+    # the other driver-timed workloads of the line: strict build, config 2, config 5, each with its own counter file
+    also = {(e["config"]["baseline_config"], e["config"]["math"]): e for e in j["also"]}
+    assert set(also) == {(3, "strict"), (2, "fast"), (5, "fast")}
+    for key, e in also.items():
+        er = e["roofline"]
+        assert er["traffic"], (key, er["traffic_source"])
+        assert 0.0 < er["frac"] <= 1.0 and abs(er["frac"] - er["achieved"] / er["peak"]) < 1e-9, key
+        assert e["value"] > 0 and abs(e["value"] * e["ms_per_step"] * 1e-3 / e["config"]["particles_total"] - 1.0) < 1e-6
+    assert also[(5, "fast")]["roofline"]["algorithmic_frac"] > 1.0  # the reference's formulation is not a bound for this layout
+    assert also[(3, "strict")]["ms_per_step"] > j["ms_per_step"]
     c = j["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 1e4 and "sample" in c and c["unit"] == j["unit"]
     assert j["config"]["degenerate_steps"] == 0
@@ -57,19 +72,35 @@ def test_multi_gpu_path_with_one_rank():
     assert r.returncode == 0, r.stderr[-2000:]
     j = one_line(r.stdout)
     check_common(j, 60, 5)
-    assert j["config"]["multi_gpu_path"] == "dist" and j["config"]["collective"] in ("fold", "push", "rccl")
-    # both collectives were tried alone before the run, and the line says which one it took and why
+    assert j["config"]["multi_gpu_path"] == "dist" and j["config"]["collective"] == "rccl" and j["config"]["rccl_ranks"] == 1
+    assert j["config"]["ranks_agree_on_neff_history"] is True
+    # both collectives were timed alone before the run, and the line says which one it took and why
     assert 0.5 < j["config"]["allgather_us"] < 1e3 and 0.5 < j["config"]["flag_barrier_us"] < 1e3
     assert j["config"]["collective_choice"].startswith(j["config"]["collective"])
     chk = j["config"]["check_vs_single_context"]
-    assert chk["max_abs_diff"] <= 1e-9, chk  # the distributed run reproduces the single-context estimates
+    assert chk["max_abs_diff"] <= 1e-9 and chk["steps"] >= 1065, chk  # ... over every step, the timed window included
     assert "cpu_baseline" not in j
+    # BASELINE configs[3] as a strong-scaling run in the same line
+    (s4,) = j["also"]
+    assert s4["scaling"] == "strong" and s4["config"]["particles_total"] == 1001472 and s4["config"]["baseline_config"] == 4
+    assert s4["config"]["check_vs_single_context"]["max_abs_diff"] <= 1e-9
+
+
+def test_plain_command_launches_its_own_ranks():
+    """what the driver runs for N > 1: `python bench.py --gpus N ...` with no launcher and no rendezvous in the environment"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded", "--steps", "40", "--warmup", "5", "--no-also"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = one_line(r.stdout)
+    check_common(j, 40, 5)
+    assert j["config"]["multi_gpu_path"] == "dist" and j["config"]["check_vs_single_context"]["max_abs_diff"] <= 1e-9
 
 
 def test_multi_gpu_path_falls_back_to_the_exchange_path_when_the_peer_mappings_fail():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29743", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                HSA_ENABLE_IPC_MODE_LEGACY="0", SLAM_BENCH_FAIL_DIST_SETUP="1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded", "--steps", "60", "--warmup", "5"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded", "--steps", "60", "--warmup", "5", "--no-also"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "falling back to --mgpu exchange" in r.stderr
@@ -84,7 +115,7 @@ def test_multi_gpu_path_every_collective(collective):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29745", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded", "--steps", "60", "--warmup", "5",
-                        "--collective", collective], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+                        "--collective", collective, "--no-also"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     j = one_line(r.stdout)
     check_common(j, 60, 5)
