@@ -892,14 +892,18 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
             float4 a;
             float b;
         };
+        // (the four record-buffer pointers as plain values: selecting between B.lmkA[0] and B.lmkA[1] in place made the
+        // distributed variants index a private copy of the argument struct: 40 bytes of scratch per lane and its set-up)
+        float4 *const lmkA0 = B.lmkA[0], *const lmkA1 = B.lmkA[1];
+        float *const lmkB0 = B.lmkB[0], *const lmkB1 = B.lmkB[1];
         // record of landmark j in slot s of record buffer b (b: bit 30 of the packet's row word, see slot_of / buf_of)
-        auto load_rec = [&](int j, int s, int b) -> Rec {
+        auto load_rec = [&, lmkA0, lmkA1, lmkB0, lmkB1](int j, int s, int b) -> Rec {
             // kPoolBit set: a record that arrived from another shard lives in the arrival pool (kernels.h: Buffers::poolA).
             // Address select, not a branch: the staging arrays these references point into must stay in registers.
             const bool pool = ARR && s < 0;
             size_t at = pool ? (size_t) j * B.pool_cap + (size_t) (s & ~kPoolBit) : (size_t) j * S + (size_t) s;
-            const float4 *pA = pool ? B.poolA : (b ? B.lmkA[1] : B.lmkA[0]);
-            const float *pB = pool ? B.poolB : (b ? B.lmkB[1] : B.lmkB[0]);
+            const float4 *pA = pool ? B.poolA : (b ? lmkA1 : lmkA0);
+            const float *pB = pool ? B.poolB : (b ? lmkB1 : lmkB0);
             if (DIST) {  // s is a global slot id: almost always one of this shard's
                 const int ls = s - B.first;
                 if (ls >= 0 && ls < B.ncap) {
@@ -909,6 +913,9 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                     at = (size_t) j * S + (size_t) (s - h * B.ncap);
                     pA = B.peers[h].lmkA[b];
                     pB = B.peers[h].lmkB[b];
+                    // (a value, not a load the optimiser may sink below the join: it did, by parking the LOCAL pointers in a
+                    // private array so that both arms became "load a pointer from memory": 40 bytes of scratch per lane)
+                    asm volatile("" : "+v"(pA), "+v"(pB));
                 }
             }
             return Rec{pA[at], pB[at]};  // by value: a reference into the staging arrays would pin them to scratch
@@ -919,18 +926,18 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
             lb = r.b;
         };
         // a re-observed landmark's fresh record goes to the particle's own slot of the row's OTHER buffer
-        auto store_lmk = [&](int j, int b, const float4 &la, float lb) {
+        auto store_lmk = [&, lmkA0, lmkA1, lmkB0, lmkB1](int j, int b, const float4 &la, float lb) {
             if constexpr (BIG) {
-                nt_store(&(b ? B.lmkA[0] : B.lmkA[1])[(size_t) j * S + i], la);
-                nt_store(&(b ? B.lmkB[0] : B.lmkB[1])[(size_t) j * S + i], lb);
+                nt_store(&(b ? lmkA0 : lmkA1)[(size_t) j * S + i], la);
+                nt_store(&(b ? lmkB0 : lmkB1)[(size_t) j * S + i], lb);
             } else {
-                (b ? B.lmkA[0] : B.lmkA[1])[(size_t) j * S + i] = la;
-                (b ? B.lmkB[0] : B.lmkB[1])[(size_t) j * S + i] = lb;
+                (b ? lmkA0 : lmkA1)[(size_t) j * S + i] = la;
+                (b ? lmkB0 : lmkB1)[(size_t) j * S + i] = lb;
             }
         };
-        auto store_new = [&](int j, const float4 &la, float lb) {  // a new row starts in record buffer 0 (host: live flag 0)
-            B.lmkA[0][(size_t) j * S + i] = la;
-            B.lmkB[0][(size_t) j * S + i] = lb;
+        auto store_new = [&, lmkA0, lmkB0](int j, const float4 &la, float lb) {  // a new row starts in record buffer 0 (host: live flag 0)
+            lmkA0[(size_t) j * S + i] = la;
+            lmkB0[(size_t) j * S + i] = lb;
         };
 
         // BIG: the packet sits in device memory, written before the launch and never during it: read it through the

@@ -185,8 +185,5 @@ def test_no_kernel_spills_to_scratch(tmp_path):
         sizes = dict(zip(re.findall(r"\.amdhsa_kernel\s+(\S+)", asm), map(int, re.findall(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", asm))))
         assert len(sizes) >= 12
         for kernel, size in sizes.items():
-            # the distributed variants of update_kernel (MODE 2: Li2E as the second template argument) hold more pointers than
-            # there are SGPRs and spill a few of them (<= 48 B, written once at entry): tolerated; an indexed register array
-            # shows up as hundreds of bytes
-            dist_variant = re.search(r"update_kernelILi\dELi2E", kernel) is not None
-            assert size == 0 or (dist_variant and size <= 48), (name, kernel, size)
+            # (no exemption: the distributed variants of update_kernel used to park four pointers in a 40-byte private array)
+            assert size == 0, (name, kernel, size)
