@@ -49,7 +49,6 @@ constexpr int kRowMask = kRowFreshBit - 1;
 constexpr int kPoolBit = (int) 0x80000000;  // genealogy entry: the record lives in the arrival pool (Buffers::poolA/B)
 constexpr int kHistStride = 6;      // doubles per pose-estimate history entry: sum x, sum y, heading, max w, Neff, resampled
 constexpr int kMaxScanBlocks = 8192;
-constexpr int kPivLdsBlocks = 512;   // contexts up to this many blocks (131 072 particles) keep the pivot table in LDS (32 KB)
 // status bits of an update's resampling stage (slamgpu.h: SLAMGPU_STATUS_*)
 constexpr int kStatusBadPacket = 2;   // the kernel did not find its packet where the kernel-argument layout says (never seen)
 constexpr int kStatusDegenerate = 1;  // sum of the weights zero or not finite: the reference normalises to NaN (core.cpp:726-729)  // block totals scanned inside every resample block (LDS)
@@ -246,8 +245,6 @@ constexpr int kAssocBatch = 8;  // observations associated per pass over a parti
 // searching lcum / blk_w [wpar ^ 1]; est_part[q] holds the pose-estimate partials of the last step of parity q.
 struct WeightScratch {
     float *lcum[2];     // [ncap]    inclusive in-block (256 particles) prefix of the raw weights
-    float *piv[2];      // [16*nblocks] every 16th entry of lcum (lcum[16 q + 15]), compact: the first level of the in-block
-                        //           ancestor search, small enough (64 B per block) to be prefetched into LDS by every block
     float *blk_w[2];    // [3*nblocks] block totals T of w, then q = sum (w/T)^2 (scale-free: w^2 may overflow float32): one
                         //           allocation, so a shard's totals travel as one contiguous message ([w(nb) | q(nb)]);
                         //           log-weight contexts: third row = the block's largest log-weight M_b, and w / q / lcum

@@ -331,8 +331,8 @@ struct NoOp {
 };
 
 // after_loads(): called once this function's own global loads have been requested (contexts of at most 512 blocks: at
-// most two totals per thread) -- the place for a caller to request data it needs AFTER the scan (the update kernel's
-// pivot table), so that it queues behind the totals on the in-order return path instead of in front of them.
+// most two totals per thread) -- the place for a caller to request data it needs AFTER the scan, so that it queues behind
+// the totals on the in-order return path instead of in front of them.
 // The loads of the scan (contexts of at most 512 blocks: at most two totals per thread), separated from the arithmetic so
 // that a caller can request them before anything else (update_kernel: at kernel entry, from preloaded arguments).
 struct ScanLoads {
@@ -485,7 +485,7 @@ SLAM_DEV float stratum_prev(const RngArgs &rng, int64_t gid) {
 // exp(M_b - M) like the block totals (scan_block_totals).  Linear weights: factor 1.0, same bits as without it.
 SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const float *__restrict__ lcum_local,
                                int first_block, int nb_local, int64_t n_global, const float *__restrict__ blk_m = nullptr,
-                               double M = 0.0, const float *piv_lds = nullptr, const PeerPtrs *peers = nullptr, int par = 0) {
+                               double M = 0.0, const PeerPtrs *peers = nullptr, int par = 0) {
     int b0 = 0, b1 = nb;
     while (b0 < b1) {
         const int mid = (b0 + b1) >> 1;
@@ -500,17 +500,9 @@ SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const f
     const float *lc = peers ? peers[b0 / nb_local].lcum[par] + (size_t) (b0 % nb_local) * kBlock : lcum_local + (size_t) lb * kBlock;
     // first slot with o + lc > target; the last slot if rounding hides it.  The prefix is non-decreasing, so instead of
     // 8 dependent probes: 16 pivots in flight together (every 16th entry), then the 16 entries of the pivot's segment
-    // (piv_lds: the pivots of every block were prefetched into LDS at kernel entry: one global round trip less)
     float pv[16];
-    if (piv_lds) {
-        const float4 *p4 = reinterpret_cast<const float4 *>(piv_lds + 16 * lb);
-        const float4 a0 = p4[0], a1 = p4[1], a2 = p4[2], a3 = p4[3];
-        pv[0] = a0.x; pv[1] = a0.y; pv[2] = a0.z; pv[3] = a0.w; pv[4] = a1.x; pv[5] = a1.y; pv[6] = a1.z; pv[7] = a1.w;
-        pv[8] = a2.x; pv[9] = a2.y; pv[10] = a2.z; pv[11] = a2.w; pv[12] = a3.x; pv[13] = a3.y; pv[14] = a3.z; pv[15] = a3.w;
-    } else {
 #pragma unroll
-        for (int q = 0; q < 16; q++) pv[q] = lc[16 * q + 15];
-    }
+    for (int q = 0; q < 16; q++) pv[q] = lc[16 * q + 15];
     int seg = 15;
 #pragma unroll
     for (int q = 14; q >= 0; q--)
@@ -524,6 +516,83 @@ SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const f
         if (o + (double) ev[q] * sc > target) r = q;
     const int l0 = 16 * seg + r;
     return min((int64_t) b0 * kBlock + l0, n_global - 1);
+}
+
+// The same search, cooperatively by a WAVE (update_kernel, inline plan).  A wave's 64 consecutive outputs draw strata that lie
+// next to each other, so their ancestors live in one or two source blocks: the wave stages those blocks' in-block prefixes
+// (1 KB each: ONE coalesced 16-byte load per lane and block) in its own LDS window and every lane searches there -- instead
+// of every lane fetching a 64-byte segment of its own, found through a pivot table of ALL blocks (25 KB at 10^5 particles)
+// that every block had to pull into LDS at kernel entry, resampling step or not (round 2; measured equal in time on one GPU,
+// 16.00 against 16.02 us per step, at a thirteenth of the search's traffic and without the table).  Same comparisons on the same values as
+// find_ancestor: the same ancestors, bit for bit.  Lanes whose block falls outside the window (kWinBlocks source blocks:
+// never seen on the bundled maps; possible with degenerate weights) take the per-lane path.  ALL lanes of the wave must call
+// (`valid` = the lane has an output particle); distributed contexts stage peer blocks straight out of the owning GPU's memory.
+constexpr int kWinBlocks = 4;
+SLAM_DEV int64_t find_ancestor_win(double target, bool valid, const double *off, int nb, float *win, const float *__restrict__ lcum_local,
+                                   int nb_local, int64_t n_global, const float *__restrict__ blk_m, double M, const PeerPtrs *peers, int par) {
+    const int lane = threadIdx.x & (kWave - 1);
+    int b0 = 0, b1 = valid ? nb : 0;
+    while (b0 < b1) {
+        const int mid = (b0 + b1) >> 1;
+        if (off[mid + 1] > target) b1 = mid; else b0 = mid + 1;
+    }
+    const bool use = valid && b0 < nb;  // (beyond the last cumulative weight: undefined upstream, clamped below)
+    int lo = use ? b0 : 0x7fffffff, hi = use ? b0 : -1;
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        lo = min(lo, __shfl_xor(lo, d, kWave));
+        hi = max(hi, __shfl_xor(hi, d, kWave));
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    auto block_ptr = [&](int b) -> const float * {
+        return peers ? peers[b / nb_local].lcum[par] + (size_t) (b % nb_local) * kBlock : lcum_local + (size_t) b * kBlock;
+    };
+    // (named scalars, not an array: a conditionally written register array is demoted to scratch)
+    static_assert(kWinBlocks == 4, "four named staging registers below");
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, v2 = v0, v3 = v0;
+    const int nw = hi < 0 ? 0 : hi - lo + 1;  // source blocks this wave's outputs draw from (0: no lane has an output)
+    if (nw > 0) v0 = reinterpret_cast<const float4 *>(block_ptr(lo))[lane];
+    if (nw > 1) v1 = reinterpret_cast<const float4 *>(block_ptr(lo + 1))[lane];
+    if (nw > 2) v2 = reinterpret_cast<const float4 *>(block_ptr(lo + 2))[lane];
+    if (nw > 3) v3 = reinterpret_cast<const float4 *>(block_ptr(lo + 3))[lane];
+    if (nw > 0) reinterpret_cast<float4 *>(win)[lane] = v0;
+    if (nw > 1) reinterpret_cast<float4 *>(win + kBlock)[lane] = v1;
+    if (nw > 2) reinterpret_cast<float4 *>(win + 2 * kBlock)[lane] = v2;
+    if (nw > 3) reinterpret_cast<float4 *>(win + 3 * kBlock)[lane] = v3;
+    __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave execute in order: the reads below see the stores above)
+    if (!use) return n_global - 1;
+    const double o = off[b0];
+    const double sc = blk_m ? block_scale(blk_m[b0], M) : 1.0;
+    float pv[16], ev[16];
+    int seg = 15, r = 15;
+    if (b0 - lo < kWinBlocks) {
+        const float *lc = win + (b0 - lo) * kBlock;
+#pragma unroll
+        for (int q = 0; q < 16; q++) pv[q] = lc[16 * q + 15];
+#pragma unroll
+        for (int q = 14; q >= 0; q--)
+            if (o + (double) pv[q] * sc > target) seg = q;
+        const float4 *l4 = reinterpret_cast<const float4 *>(lc + 16 * seg);
+        const float4 e0 = l4[0], e1 = l4[1], e2 = l4[2], e3 = l4[3];
+        ev[0] = e0.x; ev[1] = e0.y; ev[2] = e0.z; ev[3] = e0.w; ev[4] = e1.x; ev[5] = e1.y; ev[6] = e1.z; ev[7] = e1.w;
+        ev[8] = e2.x; ev[9] = e2.y; ev[10] = e2.z; ev[11] = e2.w; ev[12] = e3.x; ev[13] = e3.y; ev[14] = e3.z; ev[15] = e3.w;
+    } else {
+        const float *lc = block_ptr(b0);
+#pragma unroll
+        for (int q = 0; q < 16; q++) pv[q] = lc[16 * q + 15];
+#pragma unroll
+        for (int q = 14; q >= 0; q--)
+            if (o + (double) pv[q] * sc > target) seg = q;
+        const float4 *l4 = reinterpret_cast<const float4 *>(lc + 16 * seg);
+        const float4 e0 = l4[0], e1 = l4[1], e2 = l4[2], e3 = l4[3];
+        ev[0] = e0.x; ev[1] = e0.y; ev[2] = e0.z; ev[3] = e0.w; ev[4] = e1.x; ev[5] = e1.y; ev[6] = e1.z; ev[7] = e1.w;
+        ev[8] = e2.x; ev[9] = e2.y; ev[10] = e2.z; ev[11] = e2.w; ev[12] = e3.x; ev[13] = e3.y; ev[14] = e3.z; ev[15] = e3.w;
+    }
+#pragma unroll
+    for (int q = 14; q >= 0; q--)
+        if (o + (double) ev[q] * sc > target) r = q;
+    return min((int64_t) b0 * kBlock + 16 * seg + r, n_global - 1);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -542,9 +611,9 @@ SLAM_DEV void copy_genealogy(const Buffers &B, const int32_t *__restrict__ rows,
                              int cur, int role, AncOf anc_of) {
     const int bx = role % ws.nblocks, by = role / ws.nblocks;
     const int k = bx * kBlock + threadIdx.x;
+    int anc = anc_of(k, k < B.n);  // (every lane: the inline plan's search is a wave's joint effort)
     if (k >= B.n) return;
     const size_t S = (size_t) B.ncap;
-    int anc = anc_of(k);
     if (anc < 0) return;  // legacy shards: arrived from another shard, genealogy already in place
     const int32_t *__restrict__ src = cur ? B.gen[1] : B.gen[0];
     int32_t *__restrict__ dst = cur ? B.gen[0] : B.gen[1];
@@ -600,6 +669,9 @@ SLAM_DEV const int32_t *packet_rows(const UpdateArgs &U) { return packet_row(U) 
 constexpr int kBigChunk = SLAM_BIG_CHUNK;
 constexpr int kStage = 8;  // landmarks per particle kept in LDS between the two passes of a small packet
 
+// LDS of the per-wave ancestor windows of a launch that plans inline (host and device agree on the dynamic LDS layout)
+__host__ __device__ constexpr size_t update_window_bytes() { return sizeof(float) * kWinBlocks * kBlock * (kBlock / kWave); }
+
 // staged landmark slots per thread of an update launch (host and device agree on the dynamic LDS layout)
 __host__ __device__ inline int staging_slots(int method, bool big, int m) {
     if (big) return kBigChunk;
@@ -611,15 +683,15 @@ __host__ __device__ inline int staging_slots(int method, bool big, int m) {
 // particle set spans several GPUs whose state arrays are all mapped here (Buffers::peers); the plan runs over the
 // all-gathered block totals of every shard, and whatever an ancestor owns on another GPU is read in place.
 // The leading scalar parameters repeat what the HEAD of the kernel's dependent chain needs (the previous step's block
-// totals and pivots, the Ctrl words, the launch shape) as plain pointers / ints, fetched with the first scalar load of the
-// kernel: the loads of the scan, the pivot table and the packet are requested at once, before any field of the argument
+// totals, the Ctrl words, the launch shape) as plain pointers / ints, fetched with the first scalar load of the
+// kernel: the loads of the scan and the packet are requested at once, before any field of the argument
 // structs is looked at (the compiler fetches those where they are first used: five to six dependent scalar round trips
 // stood between kernel entry and the first vector load before; 16.7 -> 16.05 us per step at 10^5 particles).
 // Tried on top and measured as no better (gpurun_out/ab, 16.28 / 16.10 / 16.04 us): preloading these arguments into SGPRs
 // (-mllvm -amdgpu-kernarg-preload-count=16) and touching every 64-byte line of the argument segment at entry.
 //   h_flags: bit 0 plan_inline, bit 1 scan_global, bit 2 logw, bit 3 lazy
 template <int METHOD, int MODE, bool BIG>
-__global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict__ h_tot, const float *__restrict__ h_piv, Ctrl *h_ctrl,
+__global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict__ h_tot, Ctrl *h_ctrl,
                                                          int h_nb, int h_slot, int h_grid, int h_flags, Buffers B, PredictArgs PA,
                                                          UpdateArgs U, RngArgs rng, WeightScratch ws) {
     constexpr bool ARR = MODE == 1, DIST = MODE == 2;
@@ -631,32 +703,19 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     // staging by the packet (0 / 4 / 8 landmarks) instead of a static 40 KB keeps 5-8 blocks per CU resident at the
     // webmap's 3.5 landmarks per step instead of 3.
     // Layout (every offset a function of the preloaded head arguments only, so that the scan can start before the argument
-    // structs have arrived): [prefix of the block totals][pivot table][staged records A][staged records B]
+    // structs have arrived): [prefix of the block totals][ancestor windows][staged records A][staged records B]
     extern __shared__ __align__(16) unsigned char dyn_lds[];
     const int nbg = DIST ? h_nb * B.n_shards : h_nb;  // blocks of the whole particle set
     const bool h_plan = (h_flags & 1) != 0, h_scan_global = (h_flags & 2) != 0;
-    const bool piv_in_lds = !DIST && h_plan && !h_scan_global && h_nb <= kPivLdsBlocks;
     double *const off = reinterpret_cast<double *>(dyn_lds);
     const size_t off_bytes = (h_plan && !h_scan_global) ? sizeof(double) * (((size_t) nbg + 3) & ~(size_t) 1) : 0;
-    // ... then, inline plan of a context of at most kPivLdsBlocks blocks: [16 * nblocks] floats, the pivot table of the
-    // previous step's in-block prefixes (WeightScratch::piv), requested at kernel entry together with the block totals
-    float *const pivs = reinterpret_cast<float *>(dyn_lds + off_bytes);  // 16-byte aligned
-    const size_t piv_bytes = piv_in_lds ? sizeof(float) * 16 * (size_t) h_nb : 0;
-    float4 *const shA = reinterpret_cast<float4 *>(dyn_lds + off_bytes + piv_bytes);
+    // ... then, launches that plan inline: the per-wave windows of the ancestor search (find_ancestor_win)
+    float *const wins = reinterpret_cast<float *>(dyn_lds + off_bytes);  // 16-byte aligned
+    const size_t win_bytes = h_plan ? update_window_bytes() : 0;
+    float *const win = wins + (threadIdx.x / kWave) * (kWinBlocks * kBlock);  // this wave's window
+    float4 *const shA = reinterpret_cast<float4 *>(dyn_lds + off_bytes + win_bytes);
     const int nslots = staging_slots(METHOD, BIG, U.m);
-    float *const shB = reinterpret_cast<float *>(dyn_lds + off_bytes + piv_bytes + (size_t) nslots * kBlock * sizeof(float4));
-    constexpr int kPivPerThread = kPivLdsBlocks * 16 / 4 / kBlock;  // float4 per thread at the largest table
-    float4 pvreg[kPivPerThread];
-    auto request_pivots = [&]() {
-        if (piv_in_lds) {
-            const float4 *src = reinterpret_cast<const float4 *>(h_piv);
-#pragma unroll
-            for (int t = 0; t < kPivPerThread; t++) {
-                const int at = t * kBlock + (int) threadIdx.x;
-                pvreg[t] = at < h_nb * 4 ? src[at] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    };
+    float *const shB = reinterpret_cast<float *>(dyn_lds + off_bytes + win_bytes + (size_t) nslots * kBlock * sizeof(float4));
     __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
     __shared__ EstItem sh_est[kBlock / kWave];
     SLAM_STAMP(0);  // kernel entry
@@ -734,13 +793,12 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     ScanLoads scl{0.0f, 0.0f, 0.0f, 0.0f, -INFINITY, -INFINITY};
     if (do_scan) {
         scl = scan_issue(h_tot, nbg, h_nb, logw);
-        request_pivots();
     }
     __shared__ int32_t pk[kSmallWords];
     int32_t pkv = 0;
 #ifndef SLAM_NO_PK_LDS
     if constexpr (!BIG) {
-        constexpr size_t a0 = (40 + sizeof(Buffers) + alignof(PredictArgs) - 1) / alignof(PredictArgs) * alignof(PredictArgs);  // (40: the head)
+        constexpr size_t a0 = (32 + sizeof(Buffers) + alignof(PredictArgs) - 1) / alignof(PredictArgs) * alignof(PredictArgs);  // (32: the head)
         constexpr size_t a1 = (a0 + sizeof(PredictArgs) + alignof(UpdateArgs) - 1) / alignof(UpdateArgs) * alignof(UpdateArgs);
         constexpr size_t at = (a1 + offsetof(UpdateArgs, small)) / 4;  // dword offset of U.small in the kernel arguments
         const auto *ka = (const __attribute__((address_space(4))) int32_t *) __builtin_amdgcn_kernarg_segment_ptr();
@@ -789,28 +847,18 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
             ws.est_part[ws.wpar ^ 1][4 * (size_t) nb] = (double) neff;  // travels with the partials into the history
             ws.est_part[ws.wpar ^ 1][4 * (size_t) nb + 1] = (double) ((pend ? 1 : 0) | (weight_status(W, Q) << 1));
         }
-        if (piv_in_lds && pend) {
-#pragma unroll
-            for (int t = 0; t < kPivPerThread; t++) {
-                const int at = t * kBlock + (int) threadIdx.x;
-                if (at < nb * 4) reinterpret_cast<float4 *>(pivs)[at] = pvreg[t];
-            }
-        }
         __syncthreads();
     }
     SLAM_STAMP(2);  // block totals scanned: W, Neff, decision known
     const int out = pend ? cur ^ 1 : cur;
     // (DIST: the GLOBAL index of the ancestor of local particle k; global particle ids key the strata)
-    auto ancestor = [&](int k) -> int {
-        if (!U.plan_inline) return ws.keep[B.slot][k];
-        if (DIST) {
-            const double target = (double) stratum_prev(rng, (int64_t) B.first + k) * W;
-            return (int) find_ancestor(target, offp, nbg, nullptr, 0, nb, rng.n_global, nullptr, 0.0, nullptr, B.peers, ws.wpar ^ 1);
-        }
-        const double target = (double) stratum_prev(rng, (int64_t) k) * W;
-        return (int) min(find_ancestor(target, offp, nb, ws.lcum[ws.wpar ^ 1], 0, nb, (int64_t) B.n,
-                                       logw ? ws.blk_w[ws.wpar ^ 1] + 2 * nb : nullptr, Mx, piv_in_lds ? pivs : nullptr),
-                         (int64_t) B.n - 1);
+    auto ancestor = [&](int k, bool valid) -> int {
+        if (!U.plan_inline) return valid ? ws.keep[B.slot][k] : 0;
+        const int64_t gk = (int64_t) (DIST ? B.first : 0) + k;
+        const double target = valid ? (double) stratum_prev(rng, gk) * W : 0.0;
+        const int64_t ng = DIST ? rng.n_global : (int64_t) B.n;
+        return (int) find_ancestor_win(target, valid, offp, nbg, win, ws.lcum[ws.wpar ^ 1], nb, ng,
+                                       (!DIST && logw) ? ws.blk_w[ws.wpar ^ 1] + 2 * nb : nullptr, Mx, DIST ? B.peers : nullptr, ws.wpar ^ 1);
     };
     if ((int) blockIdx.x >= nb) {
         // ---- helper blocks ---------------------------------------------------------------------------------
@@ -860,11 +908,12 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     float w = logw ? -INFINITY : 0.0f;  // lanes beyond the particle count carry no weight
 
     EstItem ei_prev{0.0, 0.0, -3.0e38f, 0.0f, 0x7fffffff};  // inline plan: this particle's term of the previous step's estimate
+    const int si_plan = pend ? ancestor(i, active) : i;  // (every lane of the block: the windowed search is a wave's joint effort)
     if (active) {
         // where this particle's pose and genealogy are read from: slot i of the live buffers, or its ancestor's slot; or
         // (sharded runs, keep[i] < 0) slot i of the OUTPUT buffers: the particle arrived from another shard and
         // shard_unpack_kernel has already put its pose and genealogy in place
-        int si = pend ? ancestor(i) : i;
+        int si = si_plan;
         SLAM_STAMP(3);  // ancestor found (two dependent rounds of the in-block search)
         int sb = cur;
         if (ARR && si < 0) {
@@ -1448,7 +1497,6 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     for (int k = 0; k < kBlock / kWave; k++)
         if (k < wv) base += sh_w[k];
     ws.lcum[ws.wpar][i] = base + s;
-    if ((threadIdx.x & 15) == 15) ws.piv[ws.wpar][(size_t) bt * 16 + (threadIdx.x >> 4)] = base + s;
     if (threadIdx.x == kBlock - 1) {
         const float T = base + s;
         float q = 0.0f;
@@ -2182,13 +2230,12 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
     const size_t nbg = (size_t) ws.nblocks * (U.arrivals == 2 ? (size_t) B.n_shards : 1);  // distributed: blocks of all shards
     const size_t lds = (size_t) staging_slots(U.method, U.big != nullptr, U.m) * kBlock * (sizeof(float4) + sizeof(float)) +
                        ((U.plan_inline && !U.scan_global) ? sizeof(double) * ((nbg + 3) & ~(size_t) 1) : 0) +
-                       ((U.arrivals != 2 && U.plan_inline && !U.scan_global && ws.nblocks <= kPivLdsBlocks) ? sizeof(float) * 16 * (size_t) ws.nblocks : 0);
+                       (U.plan_inline ? update_window_bytes() : 0);
     const int sel = (U.method == 2 ? 6 : 0) + 2 * U.arrivals + (U.big ? 1 : 0);
     const float *h_tot = U.arrivals == 2 ? B.gtot[ws.wpar ^ 1] : ws.blk_w[ws.wpar ^ 1];
-    const float *h_piv = ws.piv[ws.wpar ^ 1];
     const int h_flags = (U.plan_inline ? 1 : 0) | (U.scan_global ? 2 : 0) | (U.logw ? 4 : 0) | (U.lazy ? 8 : 0);
 #define SLAM_LAUNCH_UPDATE(M, A, G)                                                                                              \
-    hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, h_tot, h_piv, B.ctrl, ws.nblocks, B.slot, grid, \
+    hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, ws.nblocks, B.slot, grid, \
                        h_flags, B, PA, U, rng, ws)
     switch (sel) {
         case 11: SLAM_LAUNCH_UPDATE(2, 2, true); break;

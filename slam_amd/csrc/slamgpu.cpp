@@ -579,7 +579,6 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     c->ws.nblocks = ncap / kBlock;
     for (int b = 0; b < 2; b++) {
         CTX_TRY(hipMalloc((void **) &c->ws.lcum[b], sizeof(float) * S));
-        CTX_TRY(hipMalloc((void **) &c->ws.piv[b], sizeof(float) * 16 * (size_t) c->ws.nblocks));
         CTX_TRY(hipMalloc((void **) &c->ws.blk_w[b], sizeof(float) * 3 * (size_t) c->ws.nblocks));  // [w | w2 (| max log-weight)] contiguous
         CTX_TRY(hipMalloc((void **) &c->ws.est_part[b], sizeof(double) * (4 * (size_t) c->ws.nblocks + 2)));  // + Neff, resampled
         CTX_TRY(hipMalloc((void **) &c->ws.scan[b], sizeof(double) * ((size_t) c->ws.nblocks + 4)));
@@ -638,7 +637,6 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     if (!c->own_totals) c->ws.blk_w[0] = c->own_blk_w;
     for (int b = 0; b < 2; b++) {
         if (c->ws.lcum[b]) (void) hipFree(c->ws.lcum[b]);
-        if (c->ws.piv[b]) (void) hipFree(c->ws.piv[b]);
         if (c->ws.blk_w[b]) (void) hipFree(c->ws.blk_w[b]);
         if (c->ws.est_part[b]) (void) hipFree(c->ws.est_part[b]);
         if (c->ws.scan[b]) (void) hipFree(c->ws.scan[b]);
