@@ -96,8 +96,17 @@ typedef struct {
      * log(sum of the raw weights) as weight_sum.  Single contexts only (not shards).  0 (default): the reference's
      * linear float32 weights, bit-compatible with rounds before this flag existed. */
     int32_t log_weights;
-    int32_t reserved0;
+    /* SLAMGPU_FLAG_* bits (0: none) */
+    int32_t flags;
 } slamgpu_config;
+
+/* slamgpu_config.flags */
+enum {
+    /* The context will be stepped with slamgpu_step_observe (the observation front end on the device): its genealogy is
+     * kept in the plain-row layout whatever the landmark capacity, because the observation packet then lives in device memory
+     * (the compact layout of small maps reads its packet from the kernel arguments, which only the host can write). */
+    SLAMGPU_FLAG_DEVICE_OBSERVE = 1
+};
 
 const char *slamgpu_last_error(void);
 int slamgpu_abi_version(void);
@@ -188,6 +197,26 @@ int slamgpu_ancestors(slamgpu_ctx *ctx, int32_t *keep);
 int slamgpu_set_map(slamgpu_ctx *ctx, const float *lm, int32_t nlm);
 int slamgpu_observe(slamgpu_ctx *ctx, const float xtrue[3], float max_range, const float R[4], int32_t noise, const float *r1,
                     const float *r2, float *z, int32_t *vis, int32_t *nz, float *zf, int32_t *idf, int32_t *m, float *zn, int32_t *n);
+
+/* One iteration of the wrapper's loop with the observation made ON THE DEVICE (fastslam2wrapper.cpp:64-88): the
+ * n_controls control steps since the last observation (as slamgpu_step), then -- for the true vehicle pose xtrue --
+ * getObservations + addObservationNoise + dataAssociationKnown (core.cpp:185-273, 438-449, 91-120) by one kernel that
+ * leaves the observation packet (idf, zf, zn) AND the bookkeeping of the landmark genealogy in device memory, then the update
+ * launch, which reads them there.  Per step the host sends the controls and the pose (<= 100 bytes) and learns nothing about
+ * the observation: no visibility scan over the map on the host, no packet over PCIe (16 KB per step on the 10 000-landmark
+ * map).  Needs slamgpu_set_map, a context created with SLAMGPU_FLAG_DEVICE_OBSERVE, association known.
+ * noise: 0 none; 1 the caller's normals r1[k], r2[k] for the k-th visible landmark (parity with the reference's tape);
+ * 2 Philox(seed; landmark, step) on the device.  normals / strata: particle noise of TAPE-mode contexts, as slamgpu_update.
+ * Landmarks beyond the context's capacity are dropped and reported by slamgpu_observe_fetch / slamgpu_num_landmarks
+ * (SLAMGPU_ERR_CAPACITY).  Do not mix with slamgpu_observe / host-made observations of the same run: the association table
+ * lives on the device. */
+int slamgpu_step_observe(slamgpu_ctx *ctx, const float *controls, int32_t n_controls, const float Q[4], float dt, const float xtrue[3],
+                         float max_range, const float R[4], int32_t noise, const float *r1, const float *r2, const float *normals,
+                         const float *strata, int32_t record_estimate);
+/* The observation packet of the last slamgpu_step_observe, copied back for logging / tests (any pointer may be NULL;
+ * arrays sized for the map): raw observations z[2 nz] and visible landmark ids vis[nz], re-observed zf[2 m] / idf[m],
+ * new zn[2 n].  Synchronises. */
+int slamgpu_observe_fetch(slamgpu_ctx *ctx, float *z, int32_t *vis, int32_t *nz, float *zf, int32_t *idf, int32_t *m, float *zn, int32_t *n);
 
 /* Per-particle gated nearest-neighbour data association (the reference has it for EKF-SLAM only:
  * EKFSLAM::dataAssociate, algorithms/ekfslam.cpp:151-189; applied here to every particle with its own landmark

@@ -25,8 +25,9 @@ DECLARED_SYMBOLS = [
     "slamgpu_dist_history_fetch", "slamgpu_dist_gather", "slamgpu_dist_set_collective", "slamgpu_dist_handshake_test",
     "slamgpu_dist_collective_status", "slamgpu_dist_comm_id", "slamgpu_dist_comm_init", "slamgpu_dist_group_create", "slamgpu_dist_group_destroy",
     "slamgpu_dist_group_step", "slamgpu_dist_group_settle", "slamgpu_dist_group_history", "slamgpu_dist_group_download",
-    "slamgpu_peek",
+    "slamgpu_peek", "slamgpu_step_observe", "slamgpu_observe_fetch",
 ]
+FLAG_DEVICE_OBSERVE = 1
 
 
 class SlamGpuError(RuntimeError):
@@ -41,7 +42,7 @@ class Config(C.Structure):
                 ("resample", C.c_int32), ("n_effective", C.c_int32), ("wheel_base", C.c_float), ("sigma_phi", C.c_float),
                 ("rng_mode", C.c_int32), ("math_mode", C.c_int32), ("seed", C.c_uint64), ("first_particle", C.c_int64),
                 ("n_particles_global", C.c_int64), ("external_stream", C.c_uint64), ("log_weights", C.c_int32),
-                ("reserved0", C.c_int32)]
+                ("flags", C.c_int32)]
 
 
 class ShardPlan(C.Structure):
@@ -88,6 +89,10 @@ def load_library():
     L.slamgpu_associate.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
     L.slamgpu_set_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     L.slamgpu_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32] + [C.c_void_p] * 2 + [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32)]
+    L.slamgpu_step_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    L.slamgpu_observe_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.POINTER(C.c_int32),
+                                        C.c_void_p, C.POINTER(C.c_int32)]
     L.slamgpu_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
     L.slamgpu_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.slamgpu_ancestors.argtypes = [C.c_void_p, C.c_void_p]
@@ -282,7 +287,8 @@ class SlamGpu:
 
     def __init__(self, n_particles, max_landmarks, method=FASTSLAM2, n_effective=None, resample=True, use_heading=False,
                  add_predict_noise=None, wheel_base=4.0, sigma_phi=0.017453292519943, rng_mode=RNG_TAPE, seed=0,
-                 math_mode=MATH_STRICT, device=0, first_particle=0, n_particles_global=0, external_stream=0, log_weights=False):
+                 math_mode=MATH_STRICT, device=0, first_particle=0, n_particles_global=0, external_stream=0, log_weights=False,
+                 device_observe=False):
         self.L = load_library()
         cfg = Config()
         cfg.struct_size = C.sizeof(Config)
@@ -304,6 +310,7 @@ class SlamGpu:
         cfg.n_particles_global = ng
         cfg.external_stream = external_stream
         cfg.log_weights = int(log_weights)
+        cfg.flags = FLAG_DEVICE_OBSERVE if device_observe else 0
         self.cfg = cfg
         self.N = n_particles
         self.h = C.c_void_p()
@@ -599,6 +606,39 @@ class SlamGpu:
         a2 = None if r2 is None else _f32(np.pad(np.asarray(r2, np.float32), (0, max(0, nl - len(r2)))))
         _chk(self.L.slamgpu_observe(self.h, _ptr(_f32(xtrue, 3)), max_range, _ptr(_f32(R, 4)), noise, _ptr(a1), _ptr(a2), _ptr(z), _ptr(vis),
                                     C.byref(nz), _ptr(zf), _ptr(idf), C.byref(m), _ptr(zn), C.byref(n)))
+        return dict(z=z[:nz.value].copy(), vis=vis[:nz.value].copy(), zf=zf[:m.value].copy(), idf=idf[:m.value].copy(), zn=zn[:n.value].copy())
+
+    def prepare_step_observe(self, controls, Q, dt, xtrue, max_range, R, noise=2, r1=None, r2=None, normals=None, strata=None,
+                             record_estimate=True):
+        """slamgpu_step_observe marshalled once (see prepare_step): k predicts + observation made on the device + update"""
+        ctl = _f32(controls).reshape(-1, 3)
+        Q = _f32(Q, 4)
+        R = _f32(R, 4)
+        xt = _f32(xtrue, 3)
+        nl = self._nlm
+        a1 = None if r1 is None else _f32(np.pad(np.asarray(r1, np.float32), (0, max(0, nl - len(r1)))))
+        a2 = None if r2 is None else _f32(np.pad(np.asarray(r2, np.float32), (0, max(0, nl - len(r2)))))
+        nm = None if normals is None else _f32(normals, (self.N, 3))
+        st = None if strata is None else _f32(strata)
+        keep = (ctl, Q, R, xt, a1, a2, nm, st)
+        args = (self.h, _ptr(ctl), ctl.shape[0], _ptr(Q), C.c_float(dt), _ptr(xt), C.c_float(max_range), _ptr(R), int(noise), _ptr(a1), _ptr(a2),
+                _ptr(nm), _ptr(st), 1 if record_estimate else 0)
+        fn = self.L.slamgpu_step_observe
+
+        def call(_keep=keep):
+            _chk(fn(*args))
+        return call
+
+    def step_observe(self, controls, Q, dt, xtrue, max_range, R, **kw):
+        self.prepare_step_observe(controls, Q, dt, xtrue, max_range, R, **kw)()
+
+    def observe_fetch(self):
+        """the observation packet of the last step_observe: dict(z, vis, zf, idf, zn)"""
+        nl = self._nlm
+        z, vis = np.zeros((nl, 2), np.float32), np.zeros(nl, np.int32)
+        zf, idf, zn = np.zeros((nl, 2), np.float32), np.zeros(nl, np.int32), np.zeros((nl, 2), np.float32)
+        nz, m, n = C.c_int32(), C.c_int32(), C.c_int32()
+        _chk(self.L.slamgpu_observe_fetch(self.h, _ptr(z), _ptr(vis), C.byref(nz), _ptr(zf), _ptr(idf), C.byref(m), _ptr(zn), C.byref(n)))
         return dict(z=z[:nz.value].copy(), vis=vis[:nz.value].copy(), zf=zf[:m.value].copy(), idf=idf[:m.value].copy(), zn=zn[:n.value].copy())
 
     def associate(self, z, R, gate_reject=4.0, gate_augment=25.0, want_labels=True):

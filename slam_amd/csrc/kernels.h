@@ -51,6 +51,7 @@ constexpr int kHistStride = 6;      // doubles per pose-estimate history entry: 
 constexpr int kMaxScanBlocks = 8192;
 // status bits of an update's resampling stage (slamgpu.h: SLAMGPU_STATUS_*)
 constexpr int kStatusBadPacket = 2;   // the kernel did not find its packet where the kernel-argument layout says (never seen)
+constexpr int kStatusCapacity = 4;    // device front end: more new landmarks than the context has room for (the surplus was dropped)
 constexpr int kStatusDegenerate = 1;  // sum of the weights zero or not finite: the reference normalises to NaN (core.cpp:726-729)  // block totals scanned inside every resample block (LDS)
 
 // Ctrl.live / Ctrl.pend are double-buffered by a host-side slot number (Buffers::slot): a kernel that changes the
@@ -140,13 +141,16 @@ __host__ __device__ inline size_t gen_index(int compact, size_t ncap, int row, s
     return compact ? (((size_t) (row >> 2) * ncap + k) << 2) + (size_t) (row & 3) : (size_t) row * ncap + k;
 }
 
-struct ObsPacket {          // big packets live in device memory, uploaded once per update
-    int32_t m, n, nf, pad;  // re-observed, new, landmarks before this update
-    float R[4];
-    // followed by: int32 idf[m]; float zf[2m]; float zn[2n]; int32 row[m]; int32 rows[n_rows]
-    // (offsets computed from m, n; row[k] = genealogy row of re-observed landmark k BEFORE this update; rows = the rows
-    //  still in use after it, without the one this update opens: what the copy roles of a pending lazy gather compose;
-    //  n_rows travels in UpdateArgs)
+struct ObsPacket {          // big packets live in device memory: uploaded once per update by the host, or written there by
+                            // observe_book_kernel (the device observation front end: the host never sees them)
+    int32_t m, n, nf, n_rows;   // re-observed, new, landmarks before this update, live genealogy rows a pending gather composes
+    int32_t e_new;              // genealogy row this update opens (-1: it writes no landmark)
+    int32_t status;             // device front end: kStatusCapacity if new landmarks had to be dropped
+    int32_t cap;                // 0: dense layout (host packets): int32 idf[m]; float zf[2m]; float zn[2n]; int32 row[m]; int32 rows[n_rows]
+                                // C > 0: fixed layout (device packets): idf[C] zf[2C] zn[2C] row[C] rows[..], C = landmarks of the map
+    int32_t pad;
+    // (row[k] = genealogy row of re-observed landmark k BEFORE this update | live buffer << 30 | fresh << 29; rows = the
+    //  rows still in use after it, without the one this update opens: what the copy roles of a pending lazy gather compose)
 };
 
 struct SmallObs {           // compact contexts: the packet travels in the kernel argument segment
@@ -207,6 +211,8 @@ struct UpdateArgs {
     int32_t method, m, n, nf;
     float R[4];
     const ObsPacket *big;    // null => use `small`
+    int32_t dev_packet;      // 1: `big` was written by the device front end (observe_book_kernel): m, n, nf, e_new, n_rows and the
+                             // copy-role geometry are read from its header by the kernel; the fields of this struct hold upper bounds
     SmallObs small;
     int32_t lazy;            // 1: single-context pipeline (honour Ctrl.pend, launch the copy + finalise blocks)
     int32_t copy_lo, copy_hi;  // copy roles (particle tile x kRowsPerRole genealogy rows) of a pending lazy gather this launch carries
@@ -302,6 +308,13 @@ struct ShardUnpackArgs {
 };
 
 // ---- observation front end -------------------------------------------------------------
+struct DevBook {           // device-resident genealogy bookkeeping header (slamgpu_step_observe)
+    int32_t nf;            // landmarks known
+    int32_t fresh_row;     // row the last update opened (records of its landmarks sit in the source slot itself), -1: none
+    int32_t status;        // sticky kStatus* bits of the front end
+    int32_t pad;
+};
+
 struct ObserveOut {
     int32_t nz, m, n, nf_after;
 };
@@ -309,7 +322,7 @@ struct ObserveOut {
 struct ObserveArgs {
     const float *lm;       // [2][nlm] landmark map, device
     int32_t *table;        // [nlm] dataAssociationTable: landmark -> feature index, -1 = never seen (device-resident)
-    int32_t nlm, nf;       // map size; features known before this observation
+    int32_t nlm, nf;       // map size; features known before this observation (observe_book_kernel: read from the book instead)
     float x, y, phi;       // true vehicle pose
     float max_range;
     float sr, sb;          // sqrt(R(0,0)), sqrt(R(1,1))
@@ -317,6 +330,14 @@ struct ObserveArgs {
     const float *r1, *r2;  // device, tape mode
     uint32_t k0, k1, step; // Philox key / observation step
     ObserveOut *out;       // device: header, then z[2 nlm], vis[nlm], zf[2 nlm], idf[nlm], zn[2 nlm] (4-byte units, in this order)
+    // observe_book_kernel only: the observation packet of the update launch that follows, and the genealogy bookkeeping the
+    // host otherwise does (slamgpu.cpp: do_update), device-resident
+    ObsPacket *pkt;        // fixed-layout packet (cap = nlm)
+    DevBook *book;
+    int32_t *erow;         // [cap_nf] genealogy row of every landmark
+    int32_t *live;         // [cap_nf] live record buffer of every landmark row
+    int32_t *refcnt;       // [cap_rows] landmarks using each row
+    int32_t cap_nf, cap_rows;
 };
 
 // all-gather of the block totals between distributed contexts that share one device and one stream (rehearsal of the
@@ -378,6 +399,9 @@ struct KernelTable {
     // observation front end on the device (slamgpu_observe): visibility scan + range / bearing + sensor noise + known data
     // association, one block; results into `out` (ObserveOut header, then z[2 cap], vis[cap], zf[2 cap], idf[cap], zn[2 cap])
     void (*observe)(hipStream_t, const ObserveArgs &);
+    // the same + the genealogy bookkeeping of the update that consumes the observation: everything into device memory
+    // (ObserveArgs::pkt / book / erow / live / refcnt); nothing comes back to the host
+    void (*observe_book)(hipStream_t, const ObserveArgs &);
     // per-particle gated nearest-neighbour association of nz observations against every landmark of every particle
     // (slamgpu_associate): labels [n][nz] = landmark index, kAssocNew or kAssocDiscard.  Plain set required (no pending gather).
     void (*associate)(hipStream_t, const Buffers &, int nf, const float *z_dev, int nz, const float *R4, float gate_reject,

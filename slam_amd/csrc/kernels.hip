@@ -638,12 +638,43 @@ SLAM_DEV void copy_genealogy(const Buffers &B, const int32_t *__restrict__ rows,
     }
 }
 
-// device-resident observation packet (kernels.h: ObsPacket): idf[m] zf[2m] zn[2n] row[m] rows[n_rows]
-SLAM_DEV const int32_t *packet_row(const UpdateArgs &U) {
-    const int32_t *idf = reinterpret_cast<const int32_t *>(U.big + 1);
-    return reinterpret_cast<const int32_t *>(reinterpret_cast<const float *>(idf + U.m) + 2 * (U.m + U.n));
+// device-resident observation packet (kernels.h: ObsPacket), dense (written by the host) or fixed layout (written by the
+// device front end): where its arrays start, in 4-byte units behind the header
+struct PacketView {
+    int m, n, nf, e_new, n_rows, rows_per_role;
+    const int32_t *idf, *row, *rows;
+    const float *zf, *zn;
+};
+SLAM_DEV PacketView packet_view(const UpdateArgs &U) {
+    PacketView V;
+    const int32_t *base = reinterpret_cast<const int32_t *>(U.big + 1);
+    int cap = 0;
+    if (U.dev_packet) {
+        // (the header through the constant address space: scalar loads, like the per-landmark entries)
+        const auto *h = (const __attribute__((address_space(4))) ObsPacket *) reinterpret_cast<uintptr_t>(U.big);
+        V.m = h->m;
+        V.n = h->n;
+        V.nf = h->nf;
+        V.e_new = h->e_new;
+        V.n_rows = h->n_rows;
+        cap = h->cap;
+        V.rows_per_role = max(16, ((V.n_rows + 3) / 4 + 3) / 4 * 4);  // (the host's rule, slamgpu.cpp: do_update)
+    } else {
+        V.m = U.m;
+        V.n = U.n;
+        V.nf = U.nf;
+        V.e_new = U.e_new;
+        V.n_rows = U.n_rows;
+        V.rows_per_role = U.rows_per_role;
+    }
+    const int a = cap ? cap : V.m, b = cap ? cap : V.n;
+    V.idf = base;
+    V.zf = reinterpret_cast<const float *>(base + a);
+    V.zn = V.zf + 2 * a;
+    V.row = reinterpret_cast<const int32_t *>(V.zn + 2 * b);
+    V.rows = V.row + a;
+    return V;
 }
-SLAM_DEV const int32_t *packet_rows(const UpdateArgs &U) { return packet_row(U) + U.m; }
 
 // ---------------------------------------------------------------------------------------------------
 // K1: [pending predicts] + per-particle observation update.  FastSLAM2::update body
@@ -883,7 +914,12 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
             if (U.finalize) finish_estimate(B, ws, U.finalize_par, U.finalize_hist, sh_est);
             return;
         }
-        if (BIG && pend) copy_genealogy(B, packet_rows(U), U.n_rows, U.rows_per_role, ws, cur, U.copy_lo + (int) blockIdx.x - nb, ancestor);
+        if constexpr (BIG) {
+            if (pend) {
+                const PacketView V = packet_view(U);
+                copy_genealogy(B, V.rows, V.n_rows, V.rows_per_role, ws, cur, U.copy_lo + (int) blockIdx.x - nb, ancestor);
+            }
+        }
         return;
     }
 #ifndef SLAM_NO_PK_LDS
@@ -904,7 +940,15 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     float4 *__restrict__ poseBo = out ? B.poseB[1] : B.poseB[0];
     float2 *__restrict__ poseCo = out ? B.poseC[1] : B.poseC[0];
     const bool active = i < B.n;
-    const int m = U.m, n = U.n, nf = U.nf;
+    int m = U.m, n = U.n, nf = U.nf, e_new = U.e_new;
+    PacketView PV{};
+    if constexpr (BIG) {
+        PV = packet_view(U);
+        m = PV.m;
+        n = PV.n;
+        nf = PV.nf;
+        e_new = PV.e_new;
+    }
     float w = logw ? -INFINITY : 0.0f;  // lanes beyond the particle count carry no weight
 
     EstItem ei_prev{0.0, 0.0, -3.0e38f, 0.0f, 0x7fffffff};  // inline plan: this particle's term of the previous step's estimate
@@ -999,11 +1043,10 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         IdxP idf, lrow;
         FltP zf, zn;
         if constexpr (BIG) {
-            const int32_t *gi = reinterpret_cast<const int32_t *>(U.big + 1);
-            idf = (IdxP) reinterpret_cast<uintptr_t>(gi);
-            zf = (FltP) reinterpret_cast<uintptr_t>(gi + m);
-            zn = zf + 2 * m;
-            lrow = (IdxP) reinterpret_cast<uintptr_t>(packet_row(U));
+            idf = (IdxP) reinterpret_cast<uintptr_t>(PV.idf);
+            zf = (FltP) reinterpret_cast<uintptr_t>(PV.zf);
+            zn = (FltP) reinterpret_cast<uintptr_t>(PV.zn);
+            lrow = (IdxP) reinterpret_cast<uintptr_t>(PV.row);
         } else {
 #ifndef SLAM_NO_PK_LDS
             idf = pk + offsetof(SmallObs, idf) / 4;
@@ -1436,8 +1479,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
             for (int c = 0; c < kChunks; c++)
                 if (c < nchunks) {
                     int4 q = gq[c];
-                    if (c == (U.e_new >> 2)) {  // (e_new = -1: never)
-                        const int comp = U.e_new & 3, own = B.first + i;
+                    if (c == (e_new >> 2)) {  // (e_new = -1: never)
+                        const int comp = e_new & 3, own = B.first + i;
                         if (comp == 0) q.x = own;
                         else if (comp == 1) q.y = own;
                         else if (comp == 2) q.z = own;
@@ -1445,8 +1488,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                     }
                     o4[(size_t) c * S + i] = q;
                 }
-        } else if (U.e_new >= 0) {
-            genO[gen_index(!BIG, S, U.e_new, (size_t) i)] = B.first + i;
+        } else if (e_new >= 0) {
+            genO[gen_index(!BIG, S, e_new, (size_t) i)] = B.first + i;
         }
         poseAo[i] = make_float4(x, y, th, w);
         if (METHOD == 2 && pose_dirty) {
@@ -1872,6 +1915,176 @@ __global__ void __launch_bounds__(kBlock) observe_kernel(ObserveArgs A) {
         A.out->m = m;
         A.out->n = n;
         A.out->nf_after = A.nf + n;
+    }
+}
+
+// The same front end for the step loop (slamgpu_step_observe): the observation goes straight into the device-resident packet
+// the update launch reads (kernels.h: ObsPacket, fixed layout) -- and with it the genealogy bookkeeping the host does for a
+// packet of its own (slamgpu.cpp: do_update): the row every re-observed landmark leaves (| live buffer | fresh), the row this
+// update opens (the lowest unused one), reference counts, the live-buffer flips, the rows a pending gather still has to
+// compose.  One block of 1 024 threads; the host sends the true pose and learns nothing about the observation.
+constexpr int kObsThreads = 1024;
+SLAM_DEV int block_exclusive_count_n(int flag, int *sh, int &total) {  // block_exclusive_count for kObsThreads threads
+    constexpr int NW = kObsThreads / kWave;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const unsigned long long mask = __ballot(flag);
+    const int before = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) sh[wv] = __popcll(mask);
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        const int c = sh[k];
+        if (k < wv) base += c;
+        tot += c;
+    }
+    total = tot;
+    __syncthreads();
+    return base + before;
+}
+
+__global__ void __launch_bounds__(kObsThreads) observe_book_kernel(ObserveArgs A) {
+    __shared__ int sh[kObsThreads / kWave];
+    __shared__ int sh_min;
+    const int T = kObsThreads, t = threadIdx.x, C = A.nlm;
+    ObsPacket *P = A.pkt;
+    int32_t *base = reinterpret_cast<int32_t *>(P + 1);
+    int32_t *idf = base;
+    float *zf = reinterpret_cast<float *>(base + C);
+    float *zn = zf + 2 * (size_t) C;
+    int32_t *row = reinterpret_cast<int32_t *>(zn + 2 * (size_t) C);
+    int32_t *rows = row + C;
+    float *z = reinterpret_cast<float *>(A.out + 1);
+    int32_t *vis = reinterpret_cast<int32_t *>(z + 2 * (size_t) C);
+    const int nf0 = A.book->nf, fresh = A.book->fresh_row;
+    const float cph = cosf(A.phi), sph = sinf(A.phi);
+    if (t == 0) sh_min = 0x7fffffff;
+    // pass 1: visibility + range / bearing, compacted in landmark order (observe_kernel, core.cpp:185-273)
+    int nz = 0;
+    for (int j0 = 0; j0 < C; j0 += T) {
+        const int j = j0 + t;
+        bool v = false;
+        float dx = 0.f, dy = 0.f;
+        if (j < C) {
+            dx = A.lm[j] - A.x;
+            dy = A.lm[(size_t) C + j] - A.y;
+            const double d2 = (double) dx * (double) dx + (double) dy * (double) dy;
+            v = (fabsf(dx) < A.max_range) && (fabsf(dy) < A.max_range) && ((dx * cph + dy * sph) > 0.0f) &&
+                (d2 < (double) A.max_range * (double) A.max_range);
+        }
+        int tot;
+        const int at = nz + block_exclusive_count_n(v ? 1 : 0, sh, tot);
+        if (v) {
+            const double d2 = (double) dx * (double) dx + (double) dy * (double) dy;
+            vis[at] = j;
+            z[2 * at] = (float) sqrt(d2);
+            z[2 * at + 1] = (float) atan2((double) dy, (double) dx) - A.phi;
+        }
+        nz += tot;
+    }
+    __syncthreads();
+    // sensor noise (core.cpp:438-449)
+    if (A.noise) {
+        for (int c = t; c < nz; c += T) {
+            float g0, g1;
+            if (A.noise == 1) {
+                g0 = A.r1[c];
+                g1 = A.r2[c];
+            } else {
+                U4 r = philox4x32((uint32_t) vis[c], A.step, 3u, 0u, A.k0, A.k1);
+                float g2;
+                box_muller3(r, g0, g1, g2);
+            }
+            z[2 * c] = z[2 * c] + g0 * A.sr;
+            z[2 * c + 1] = z[2 * c + 1] + g1 * A.sb;
+        }
+        __syncthreads();
+    }
+    // pass 2: dataAssociationKnown (core.cpp:91-120): split by the table, in order; new landmarks get indices nf0, nf0 + 1, ...
+    // (new landmarks beyond the context's capacity are dropped and flagged)
+    const int room = A.cap_nf - nf0;
+    int m = 0, n = 0, dropped = 0;
+    for (int c0 = 0; c0 < nz; c0 += T) {
+        const int c = c0 + t;
+        const bool in = c < nz;
+        const int lmk = in ? vis[c] : 0;
+        const int tb = in ? A.table[lmk] : 0;
+        const bool is_new = in && tb < 0;
+        int tot_new, tot_old;
+        const int an = n + block_exclusive_count_n(is_new ? 1 : 0, sh, tot_new);
+        const int ao = m + block_exclusive_count_n((in && !is_new) ? 1 : 0, sh, tot_old);
+        if (is_new) {
+            if (an < room) {
+                zn[2 * an] = z[2 * c];
+                zn[2 * an + 1] = z[2 * c + 1];
+                A.table[lmk] = nf0 + an;
+            }
+        } else if (in) {
+            zf[2 * ao] = z[2 * c];
+            zf[2 * ao + 1] = z[2 * c + 1];
+            idf[ao] = tb;
+        }
+        n += tot_new;
+        m += tot_old;
+    }
+    if (n > room) {
+        dropped = n - room;
+        n = room;
+    }
+    __syncthreads();
+    // the row this update opens: the lowest one no landmark uses
+    int e_new = -1;
+    if (m + n > 0) {
+        int mine = 0x7fffffff;
+        for (int r = t; r < A.cap_rows; r += T)
+            if (A.refcnt[r] == 0) mine = min(mine, r);
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) mine = min(mine, __shfl_xor(mine, d, kWave));
+        if ((t & (kWave - 1)) == 0 && mine != 0x7fffffff) atomicMin(&sh_min, mine);
+        __syncthreads();
+        e_new = sh_min;  // (cap_rows = cap_nf + 1 rows for at most cap_nf landmarks: one is always free)
+    }
+    // the rows the re-observed landmarks leave; they move to e_new and their records to the other buffer
+    for (int k = t; k < m; k += T) {
+        const int j = idf[k];
+        const int r = A.erow[j];
+        row[k] = r | (A.live[j] ? kRowLiveBit : 0) | (r == fresh ? kRowFreshBit : 0);
+        A.live[j] ^= 1;
+        atomicSub(&A.refcnt[r], 1);
+        A.erow[j] = e_new;
+    }
+    for (int k = t; k < n; k += T) {
+        A.erow[nf0 + k] = e_new;
+        A.live[nf0 + k] = 0;  // a new row's first records go to buffer 0
+    }
+    __syncthreads();
+    // the rows still in use, without e_new: what a pending gather composes
+    int n_rows = 0;
+    for (int r0 = 0; r0 < A.cap_rows; r0 += T) {
+        const int r = r0 + t;
+        const bool on = r < A.cap_rows && r != e_new && A.refcnt[r] > 0;
+        int tot;
+        const int at = n_rows + block_exclusive_count_n(on ? 1 : 0, sh, tot);
+        if (on) rows[at] = r;
+        n_rows += tot;
+    }
+    if (t == 0) {
+        if (e_new >= 0) A.refcnt[e_new] = m + n;
+        P->m = m;
+        P->n = n;
+        P->nf = nf0;
+        P->n_rows = n_rows;
+        P->e_new = e_new;
+        P->status = dropped ? kStatusCapacity : 0;
+        P->cap = C;
+        P->pad = 0;
+        A.book->nf = nf0 + n;
+        A.book->fresh_row = e_new;
+        if (dropped) A.book->status |= kStatusCapacity;
+        A.out->nz = nz;
+        A.out->m = m;
+        A.out->n = n;
+        A.out->nf_after = nf0 + n;
     }
 }
 
@@ -2305,6 +2518,9 @@ static void launch_jacobians(hipStream_t st, const float *in, uint32_t n, float 
 }
 
 static void launch_observe(hipStream_t st, const ObserveArgs &A) { hipLaunchKernelGGL(observe_kernel, dim3(1), dim3(kBlock), 0, st, A); }
+static void launch_observe_book(hipStream_t st, const ObserveArgs &A) {
+    hipLaunchKernelGGL(observe_book_kernel, dim3(1), dim3(kObsThreads), 0, st, A);
+}
 
 static void launch_associate(hipStream_t st, const Buffers &B, int nf, const float *z, int nz, const float *R4, float g1, float g2,
                              int32_t *labels) {
@@ -2380,7 +2596,7 @@ static void launch_peek(hipStream_t st, const Buffers &B, const WeightScratch &w
     hipLaunchKernelGGL(peek_kernel, dim3((A.count + kBlock - 1) / kBlock, gy), dim3(kBlock), 0, st, B, ws, A);
 }
 
-static const KernelTable kTable = {launch_update, launch_resample, launch_scan, launch_gather, launch_flatten, launch_identity, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat, launch_observe, launch_associate,
+static const KernelTable kTable = {launch_update, launch_resample, launch_scan, launch_gather, launch_flatten, launch_identity, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat, launch_observe, launch_observe_book, launch_associate,
                                    launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish, launch_dist_gather, launch_dist_flags, launch_peek};
 
 }  // namespace SLAM_KNS

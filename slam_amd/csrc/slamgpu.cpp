@@ -193,6 +193,13 @@ struct slamgpu_ctx {
     int fresh_row = -1;              // row the last update opened, while nothing but the resample the next update launch
                                      // applies has touched it: records of its landmarks sit in the source slot itself
     bool tables_dirty = true;
+    // device-resident genealogy bookkeeping (slamgpu_step_observe): while book_on_device the tables erow_dev / live_dev /
+    // refcnt_dev / book_dev are the truth and the host's vectors are stale; book_pull / book_push hand the ownership over
+    bool book_on_device = false;
+    DevBook *book_dev = nullptr;
+    int32_t *refcnt_dev = nullptr;
+    int32_t *book_host = nullptr;    // pinned staging of book_pull / book_push
+    char *last_pkt_dev = nullptr;    // packet of the last slamgpu_step_observe (slamgpu_observe_fetch)
     char *peek_dev = nullptr;        // staging of slamgpu_peek, grown on demand
     size_t peek_bytes = 0;
     unsigned long long *stamps_dev = nullptr;  // diagnostic (SLAMGPU_STAMPS=1 + libslamgpu_stamps.so): UpdateArgs::stamps
@@ -335,8 +342,78 @@ void rows_reset(slamgpu_ctx *c, int nf) {
     c->tables_dirty = true;
 }
 
+// ---- genealogy bookkeeping on the device (slamgpu_step_observe) <-> on the host ----
+// The device-driven steps keep erow / live flags / reference counts / nf / fresh row in device memory (observe_book_kernel).
+// Anything host-side that needs them (a host-made packet, download, flatten, peek, the landmark count) first pulls them back
+// -- one synchronisation -- and the host is authoritative again; the next device-driven step pushes them.
+// (All copies go through one pinned staging buffer.)
+int book_staging(slamgpu_ctx *c) {
+    if (c->book_host) return 0;
+    const size_t words = sizeof(DevBook) / 4 + 2 * (size_t) c->B.cap_nf + (size_t) c->B.cap_rows;
+    HIP_TRY(hipHostMalloc((void **) &c->book_host, 4 * words, hipHostMallocDefault));
+    HIP_TRY(hipMalloc((void **) &c->book_dev, sizeof(DevBook)));
+    HIP_TRY(hipMalloc((void **) &c->refcnt_dev, sizeof(int32_t) * (size_t) c->B.cap_rows));
+    return 0;
+}
+
+int book_pull(slamgpu_ctx *c) {
+    if (!c->book_on_device) return 0;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const size_t cn = (size_t) c->B.cap_nf, cr = (size_t) c->B.cap_rows;
+    DevBook *hb = reinterpret_cast<DevBook *>(c->book_host);
+    int32_t *h_erow = c->book_host + sizeof(DevBook) / 4, *h_live = h_erow + cn, *h_ref = h_live + cn;
+    HIP_TRY(hipMemcpyAsync(hb, c->book_dev, sizeof(DevBook), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(h_erow, c->erow_dev, 4 * cn, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(h_live, c->live_dev, 4 * cn, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(h_ref, c->refcnt_dev, 4 * cr, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int nf = hb->nf;
+    if (nf < 0 || nf > c->B.cap_nf) return fail(SLAMGPU_ERR_INVALID, "device bookkeeping corrupt: nf = %d", nf);
+    std::copy(h_erow, h_erow + nf, c->erow.begin());
+    std::copy(h_live, h_live + nf, c->live_flag.begin());
+    std::copy(h_ref, h_ref + cr, c->refcnt.begin());
+    c->nf = nf;
+    c->fresh_row = hb->fresh_row;
+    std::fill(c->live_pos.begin(), c->live_pos.end(), -1);
+    c->live_rows.clear();
+    c->free_rows.clear();
+    for (int r = c->B.cap_rows - 1; r >= 0; r--)
+        if (c->refcnt[r] == 0) c->free_rows.push_back(r);  // back() = lowest free row
+    for (int r = 0; r < c->B.cap_rows; r++)
+        if (c->refcnt[r] > 0) rows_add_live(c, r);
+    c->tables_dirty = true;
+    c->book_on_device = false;
+    if (hb->status & kStatusCapacity)
+        return fail(SLAMGPU_ERR_CAPACITY, "the device front end dropped new landmarks: landmark capacity %d exceeded", c->B.cap_nf);
+    return 0;
+}
+
+int book_push(slamgpu_ctx *c) {
+    if (c->book_on_device) return 0;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = book_staging(c)) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));  // (nothing in flight may still read the old tables or the staging buffer)
+    const size_t cn = (size_t) c->B.cap_nf, cr = (size_t) c->B.cap_rows;
+    DevBook *hb = reinterpret_cast<DevBook *>(c->book_host);
+    int32_t *h_erow = c->book_host + sizeof(DevBook) / 4, *h_live = h_erow + cn, *h_ref = h_live + cn;
+    *hb = DevBook{};
+    hb->nf = c->nf;
+    hb->fresh_row = c->fresh_row;
+    std::copy(c->erow.begin(), c->erow.begin() + cn, h_erow);
+    std::copy(c->live_flag.begin(), c->live_flag.begin() + cn, h_live);
+    std::copy(c->refcnt.begin(), c->refcnt.begin() + cr, h_ref);
+    HIP_TRY(hipMemcpyAsync(c->book_dev, hb, sizeof(DevBook), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->erow_dev, h_erow, 4 * cn, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->live_dev, h_live, 4 * cn, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->refcnt_dev, h_ref, 4 * cr, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->book_on_device = true;
+    return 0;
+}
+
 // device copies of the row tables for the kernels that run outside the update launch
 int sync_tables(slamgpu_ctx *c) {
+    if (int rc = book_pull(c)) return rc;
     c->B.erow = c->erow_dev;
     c->B.rows = c->rows_dev;
     c->B.lmk_live = c->live_dev;
@@ -559,7 +636,7 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     }
     c->B.slot = 0;
     c->B.cap_rows = cap_nf + 1;  // at most one row per landmark, plus the one a step opens while the old ones are still read
-    c->B.compact = c->B.cap_rows <= kSmallRows ? 1 : 0;
+    c->B.compact = (c->B.cap_rows <= kSmallRows && !(cfg->flags & SLAMGPU_FLAG_DEVICE_OBSERVE)) ? 1 : 0;
     c->erow.assign((size_t) cap_nf, 0);
     c->live_flag.assign((size_t) cap_nf, 0);
     c->seen_step.assign((size_t) cap_nf, 0);
@@ -646,6 +723,9 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     if (c->hist_dev) (void) hipFree(c->hist_dev);
     if (c->stamps_dev) (void) hipFree(c->stamps_dev);
     if (c->peek_dev) (void) hipFree(c->peek_dev);
+    if (c->book_dev) (void) hipFree(c->book_dev);
+    if (c->refcnt_dev) (void) hipFree(c->refcnt_dev);
+    if (c->book_host) (void) hipHostFree(c->book_host);
     if (c->comm && rccl()) (void) rccl()->CommDestroy((ncclComm_t) c->comm);
     for (void *p : c->ipc_opened) (void) hipIpcCloseMemHandle(p);
     if (c->peers_dev) (void) hipFree(c->peers_dev);
@@ -726,9 +806,115 @@ int slamgpu_predict(slamgpu_ctx *c, float V, float G, const float Q[4], float dt
 namespace {
 
 // FastSLAM{1,2}::update: the per-particle stage, then (single-context case) the resampling stage
+// The launch of an update whose packet is in place (host-made or device-made): queued predicts, the particle-noise tape,
+// the stage bookkeeping.  n_new: new landmarks if the host knows (device packets: -1); n_rows: live genealogy rows a pending
+// gather composes (device packets: -1: the launch carries the copy roles of the largest geometry).
+int issue_update(slamgpu_ctx *c, UpdateArgs &U, int n_new, int n_rows, bool need_normals, const float *normals, const float *strata, bool sharded) {
+    const bool tape = c->cfg.rng_mode == SLAMGPU_RNG_TAPE;
+    const int n = n_new;
+    // pending predicts ride inside the update launch (state stays in registers) unless their noise is a host tape
+    PredictArgs PA{};
+    if (c->pending.nsteps > 0) {
+        compose_predicts(c->pending);
+        PA = c->pending;
+        c->predict_bytes += 72.0 * c->cfg.n_particles * c->pending.nsteps;
+        c->pending.nsteps = 0;
+    }
+
+    if (tape) {
+        HIP_TRY(hipStreamSynchronize(c->stream));  // single-buffered tape staging (parity mode)
+        const int N = c->B.n, S = c->B.ncap;
+        if (need_normals) {
+            for (int i = 0; i < N; i++) {
+                c->tape_host[i] = normals[3 * i];
+                c->tape_host[S + i] = normals[3 * i + 1];
+                c->tape_host[2 * S + i] = normals[3 * i + 2];
+            }
+            HIP_TRY(hipMemcpyAsync(c->normals_dev, c->tape_host, sizeof(float) * 3 * (size_t) S, hipMemcpyHostToDevice, c->stream));
+        }
+        float *sh = c->tape_host + 3 * (size_t) S;
+        memcpy(sh, strata, sizeof(float) * (size_t) n_global(c));
+        HIP_TRY(hipMemcpyAsync(c->strata_dev[c->obs_step & 1], sh, sizeof(float) * (size_t) n_global(c), hipMemcpyHostToDevice, c->stream));
+    }
+
+    RngArgs rng = rng_args(c, c->obs_step);
+    if (c->dist) {
+        rng.step = c->obs_step - c->rng_skew;  // (device noise only: the tape buffers above do not apply)
+        rng.prev_step = c->unplanned.step;
+    }
+    if (sharded && c->unplanned.has)
+        if (int rc = flush_stages(c)) return rc;  // (a context is driven either way, not both; be safe)
+    c->B.slot = c->slot;
+    c->ws.wpar = sharded ? 0 : (int) (c->obs_step & 1);
+    U.lazy = 1;
+    U.arrivals = c->dist ? 2 : (sharded ? 1 : 0);
+    if (c->dist) {
+        c->B.gtot[0] = c->gtot_dev[0];
+        c->B.gtot[1] = c->gtot_dev[1];
+        c->dist_clean = false;
+        U.push_totals = (c->dist_push || c->dist_fold) ? 1 : 0;
+        U.fold_seq = c->dist_fold ? ++c->flag_seq : 0;
+        U.fold_spins = 1u << 20;
+    }
+    // a pending gather's genealogy composition: small packets: by the compute threads themselves; device packets: by copy
+    // roles (one role = 256 particles x rows_per_role live rows; at most ~4 roles per particle tile: every role block
+    // redoes the plan's scan and search)
+    U.rows_per_role = std::max(16, ((std::max(n_rows, 0) + 3) / 4 + 3) / 4 * 4);
+    const int roles = !U.big ? 0 : (n_rows < 0 ? c->ws.nblocks * 4 : c->ws.nblocks * ((n_rows + U.rows_per_role - 1) / U.rows_per_role));
+    U.copy_lo = 0;
+    U.copy_hi = roles;
+    // the resampling stage of the previous update rides in this launch unless something already ran it
+    U.plan_inline = (!sharded && c->unplanned.has) ? 1 : 0;
+    U.scan_global = (U.plan_inline && c->scan_ready) ? 1 : 0;
+    U.do_resample = c->cfg.resample;
+    U.n_effective = c->cfg.n_effective;
+    U.logw = c->cfg.log_weights;
+    U.stamps = c->stamps_dev;
+    U.finalize = c->unreduced.has ? 1 : 0;  // (sharded: this shard's partials of the previous step, shard_finalize_kernel)
+    U.finalize_hist = c->unreduced.hist;
+    U.finalize_par = c->unreduced.par;
+    {
+        Timed t(c, c->cfg.method == SLAMGPU_FASTSLAM2 ? "fs2_update" : "fs1_update");
+        c->k->update(c->stream, c->B, PA, U, rng, c->ws);
+    }
+    HIP_TRY(hipGetLastError());
+    c->slot ^= 1;   // ... and where it left the set (Ctrl.live / pend of the other slot)
+    c->B.slot = c->slot;
+    c->maybe_pending = false;  // whatever gather was pending, this launch performed it
+    if (n >= 0) c->nf += n;
+    if (sharded) {
+        // the resampling stage is driven by the caller through slamgpu_shard_* (needs collectives)
+        c->unreduced.has = false;  // reduced by the helper block of this launch
+        c->est_fresh = false;
+        c->shard_est_fresh = false;
+        return 0;
+    }
+    // stage bookkeeping: the helper block reduced `unreduced`; the inline plan left the partials of `unplanned`;
+    // this update's own resampling stage is now the outstanding one
+    c->unreduced.has = false;
+    if (U.plan_inline) c->unreduced = c->unplanned;
+    c->unplanned.has = true;
+    c->unplanned.par = c->ws.wpar;
+    c->unplanned.step = c->obs_step - c->rng_skew;
+    c->unplanned.nf = c->nf;
+    c->unplanned.hist = c->hist_n < kHistCap ? c->hist_dev + kHistStride * (size_t) c->hist_n : nullptr;
+    c->est_fresh = c->unplanned.hist != nullptr;
+    // large contexts: one block prepares the prefix of this step's block totals for the next launch, instead of every
+    // block of that launch redoing it (a second, tiny launch; negligible at these sizes)
+    c->scan_ready = false;
+    if (c->ws.nblocks > c->scan_min_blocks && !c->dist) {
+        Timed t(c, "scan");
+        c->k->scan(c->stream, c->ws, c->cfg.log_weights);
+        c->scan_ready = true;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n,
               const float R[4], const float *normals, const float *strata, bool sharded) {
     if (m < 0 || n < 0 || !R || (m > 0 && (!zf || !idf)) || (n > 0 && !zn)) return fail(SLAMGPU_ERR_INVALID, "bad observation packet");
+    if (int rc = book_pull(c)) return rc;  // (after device-driven steps the bookkeeping comes back first)
     if (m > c->nf) return fail(SLAMGPU_ERR_INVALID, "m=%d re-observed landmarks but only %d known", m, c->nf);
     if (c->nf + n > c->B.cap_nf) return fail(SLAMGPU_ERR_CAPACITY, "landmark capacity exceeded: %d + %d > %d", c->nf, n, c->B.cap_nf);
     for (int k = 0; k < m; k++)
@@ -809,8 +995,11 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
         hp->m = m;
         hp->n = n;
         hp->nf = c->nf;
-        hp->pad = n_rows;
-        memcpy(hp->R, R, sizeof hp->R);
+        hp->n_rows = n_rows;
+        hp->e_new = e_new;
+        hp->status = 0;
+        hp->cap = 0;  // dense layout
+        hp->pad = 0;
         int32_t *hidf = reinterpret_cast<int32_t *>(hp + 1);
         float *hzf = reinterpret_cast<float *>(hidf + m);
         float *hzn = hzf + 2 * m;
@@ -839,104 +1028,78 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     // [0, live_chunks) on a resample)
     if (c->B.compact && (!dropped.empty() || (e_new >= 0 && c->refcnt[e_new] == 0)))
         std::sort(c->free_rows.begin(), c->free_rows.end(), std::greater<int32_t>());
+    return issue_update(c, U, n, n_rows, need_normals, normals, strata, sharded);
+}
 
-    // pending predicts ride inside the update launch (state stays in registers) unless their noise is a host tape
-    PredictArgs PA{};
-    if (c->pending.nsteps > 0) {
-        compose_predicts(c->pending);
-        PA = c->pending;
-        c->predict_bytes += 72.0 * c->cfg.n_particles * c->pending.nsteps;
-        c->pending.nsteps = 0;
+// FastSLAM{1,2}::update with the observation made on the device (slamgpu_step_observe): observe_book_kernel writes the packet
+// and the genealogy bookkeeping into device memory, the update launch reads them there.
+int do_update_dev(slamgpu_ctx *c, const float xtrue[3], float max_range, const float R[4], int32_t noise, const float *r1,
+                  const float *r2, const float *normals, const float *strata) {
+    if (!c->map_dev) return fail(SLAMGPU_ERR_INVALID, "no map: call slamgpu_set_map first");
+    if (c->B.compact) return fail(SLAMGPU_ERR_INVALID, "create the context with SLAMGPU_FLAG_DEVICE_OBSERVE (its observation packets live in device memory)");
+    if (c->dist || c->cfg.n_particles_global != c->cfg.n_particles) return fail(SLAMGPU_ERR_INVALID, "slamgpu_step_observe: single contexts only");
+    if (c->map_n > c->B.cap_nf) return fail(SLAMGPU_ERR_CAPACITY, "map of %d landmarks, capacity %d", c->map_n, c->B.cap_nf);
+    if (!xtrue || !R || noise < 0 || noise > 2 || (noise == 1 && (!r1 || !r2))) return fail(SLAMGPU_ERR_INVALID, "bad arguments");
+    const bool tape = c->cfg.rng_mode == SLAMGPU_RNG_TAPE;
+    if (tape && !strata) return fail(SLAMGPU_ERR_INVALID, "TAPE mode needs strata[N] (and normals[3N] for FastSLAM2)");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = book_push(c)) return rc;
+    c->obs_step++;
+    const size_t nl = (size_t) c->map_n;
+    if (noise == 1) {
+        HIP_TRY(hipMemcpyAsync(c->obs_r_dev, r1, sizeof(float) * nl, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->obs_r_dev + nl, r2, sizeof(float) * nl, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // pageable sources (parity mode only)
     }
-
-    if (tape) {
-        HIP_TRY(hipStreamSynchronize(c->stream));  // single-buffered tape staging (parity mode)
-        const int N = c->B.n, S = c->B.ncap;
-        if (need_normals) {
-            for (int i = 0; i < N; i++) {
-                c->tape_host[i] = normals[3 * i];
-                c->tape_host[S + i] = normals[3 * i + 1];
-                c->tape_host[2 * S + i] = normals[3 * i + 2];
-            }
-            HIP_TRY(hipMemcpyAsync(c->normals_dev, c->tape_host, sizeof(float) * 3 * (size_t) S, hipMemcpyHostToDevice, c->stream));
-        }
-        float *sh = c->tape_host + 3 * (size_t) S;
-        memcpy(sh, strata, sizeof(float) * (size_t) n_global(c));
-        HIP_TRY(hipMemcpyAsync(c->strata_dev[c->obs_step & 1], sh, sizeof(float) * (size_t) n_global(c), hipMemcpyHostToDevice, c->stream));
-    }
-
-    RngArgs rng = rng_args(c, c->obs_step);
-    if (c->dist) {
-        rng.step = c->obs_step - c->rng_skew;  // (device noise only: the tape buffers above do not apply)
-        rng.prev_step = c->unplanned.step;
-    }
-    if (sharded && c->unplanned.has)
-        if (int rc = flush_stages(c)) return rc;  // (a context is driven either way, not both; be safe)
-    c->B.slot = c->slot;
-    c->ws.wpar = sharded ? 0 : (int) (c->obs_step & 1);
-    U.lazy = 1;
-    U.arrivals = c->dist ? 2 : (sharded ? 1 : 0);
-    if (c->dist) {
-        c->B.gtot[0] = c->gtot_dev[0];
-        c->B.gtot[1] = c->gtot_dev[1];
-        c->dist_clean = false;
-        U.push_totals = (c->dist_push || c->dist_fold) ? 1 : 0;
-        U.fold_seq = c->dist_fold ? ++c->flag_seq : 0;
-        U.fold_spins = 1u << 20;
-    }
-    // a pending gather's genealogy composition: small packets: by the compute threads themselves; device packets: by copy
-    // roles (one role = 256 particles x rows_per_role live rows; at most ~4 roles per particle tile: every role block
-    // redoes the plan's scan and search)
-    U.rows_per_role = std::max(16, ((n_rows + 3) / 4 + 3) / 4 * 4);
-    const int roles = U.big ? c->ws.nblocks * ((n_rows + U.rows_per_role - 1) / U.rows_per_role) : 0;
-    U.copy_lo = 0;
-    U.copy_hi = roles;
-    // the resampling stage of the previous update rides in this launch unless something already ran it
-    U.plan_inline = (!sharded && c->unplanned.has) ? 1 : 0;
-    U.scan_global = (U.plan_inline && c->scan_ready) ? 1 : 0;
-    U.do_resample = c->cfg.resample;
-    U.n_effective = c->cfg.n_effective;
-    U.logw = c->cfg.log_weights;
-    U.stamps = c->stamps_dev;
-    U.finalize = c->unreduced.has ? 1 : 0;  // (sharded: this shard's partials of the previous step, shard_finalize_kernel)
-    U.finalize_hist = c->unreduced.hist;
-    U.finalize_par = c->unreduced.par;
+    const int slot = (int) (c->pkt_seq++ % kRing);
+    if (c->pkt_ev_used[slot]) HIP_TRY(hipEventSynchronize(c->pkt_ev[slot]));
+    char *pd = c->pkt_dev + (size_t) slot * c->pkt_bytes;
+    ObserveArgs A{};
+    A.lm = c->map_dev;
+    A.table = c->table_dev;
+    A.nlm = c->map_n;
+    A.x = xtrue[0];
+    A.y = xtrue[1];
+    A.phi = xtrue[2];
+    A.max_range = max_range;
+    A.sr = sqrtf(R[0]);
+    A.sb = sqrtf(R[3]);
+    A.noise = noise;
+    A.r1 = c->obs_r_dev;
+    A.r2 = c->obs_r_dev + nl;
+    A.k0 = (uint32_t) c->cfg.seed;
+    A.k1 = (uint32_t) (c->cfg.seed >> 32);
+    A.step = ++c->observe_step;
+    A.out = c->obs_out_dev;
+    A.pkt = reinterpret_cast<ObsPacket *>(pd);
+    A.book = c->book_dev;
+    A.erow = c->erow_dev;
+    A.live = c->live_dev;
+    A.refcnt = c->refcnt_dev;
+    A.cap_nf = c->B.cap_nf;
+    A.cap_rows = c->B.cap_rows;
     {
-        Timed t(c, c->cfg.method == SLAMGPU_FASTSLAM2 ? "fs2_update" : "fs1_update");
-        c->k->update(c->stream, c->B, PA, U, rng, c->ws);
+        Timed t(c, "observe");
+        c->k->observe_book(c->stream, A);
     }
     HIP_TRY(hipGetLastError());
-    c->slot ^= 1;   // ... and where it left the set (Ctrl.live / pend of the other slot)
-    c->B.slot = c->slot;
-    c->maybe_pending = false;  // whatever gather was pending, this launch performed it
-    c->nf += n;
-    if (sharded) {
-        // the resampling stage is driven by the caller through slamgpu_shard_* (needs collectives)
-        c->unreduced.has = false;  // reduced by the helper block of this launch
-        c->est_fresh = false;
-        c->shard_est_fresh = false;
-        return 0;
-    }
-    // stage bookkeeping: the helper block reduced `unreduced`; the inline plan left the partials of `unplanned`;
-    // this update's own resampling stage is now the outstanding one
-    c->unreduced.has = false;
-    if (U.plan_inline) c->unreduced = c->unplanned;
-    c->unplanned.has = true;
-    c->unplanned.par = c->ws.wpar;
-    c->unplanned.step = c->obs_step - c->rng_skew;
-    c->unplanned.nf = c->nf;
-    c->unplanned.hist = c->hist_n < kHistCap ? c->hist_dev + kHistStride * (size_t) c->hist_n : nullptr;
-    c->est_fresh = c->unplanned.hist != nullptr;
-    // large contexts: one block prepares the prefix of this step's block totals for the next launch, instead of every
-    // block of that launch redoing it (a second, tiny launch; negligible at these sizes)
-    c->scan_ready = false;
-    if (c->ws.nblocks > c->scan_min_blocks && !c->dist) {
-        Timed t(c, "scan");
-        c->k->scan(c->stream, c->ws, c->cfg.log_weights);
-        c->scan_ready = true;
-    }
-    HIP_TRY(hipGetLastError());
-    return 0;
+    HIP_TRY(hipEventRecord(c->pkt_ev[slot], c->stream));
+    c->pkt_ev_used[slot] = true;
+    c->last_pkt_dev = pd;
+    c->fresh_row = -1;  // (the device's book knows)
+
+    UpdateArgs U{};
+    U.method = c->cfg.method;
+    U.m = c->map_n;  // upper bounds: the kernel reads the packet's header
+    U.n = c->map_n;
+    U.nf = 0;
+    U.e_new = -1;
+    U.n_rows = c->B.cap_rows;
+    U.dev_packet = 1;
+    U.big = reinterpret_cast<const ObsPacket *>(pd);
+    memcpy(U.R, R, sizeof U.R);
+    const bool need_normals = c->cfg.method == SLAMGPU_FASTSLAM2 && normals != nullptr;
+    return issue_update(c, U, -1, -1, need_normals, normals, strata, false);
 }
 
 }  // namespace
@@ -964,6 +1127,46 @@ int slamgpu_step(slamgpu_ctx *c, const float *controls, int32_t n_controls, cons
         if (int rc = slamgpu_predict(c, controls[3 * k], controls[3 * k + 1], Q, dt, controls[3 * k + 2], nullptr)) return rc;
     if (int rc = slamgpu_update(c, zf, idf, m, zn, n, R, normals, strata)) return rc;
     if (record_estimate) return slamgpu_estimate_async(c);
+    return 0;
+}
+
+int slamgpu_step_observe(slamgpu_ctx *c, const float *controls, int32_t n_controls, const float Q[4], float dt, const float xtrue[3],
+                         float max_range, const float R[4], int32_t noise, const float *r1, const float *r2, const float *normals,
+                         const float *strata, int32_t record_estimate) {
+    if (int rc = check_ctx(c)) return rc;
+    if (n_controls < 0 || (n_controls > 0 && (!controls || !Q))) return fail(SLAMGPU_ERR_INVALID, "bad control list");
+    if (n_controls > 0 && c->cfg.add_predict_noise && c->cfg.rng_mode == SLAMGPU_RNG_TAPE)
+        return fail(SLAMGPU_ERR_INVALID, "slamgpu_step_observe cannot carry TAPE-mode predict noise: call slamgpu_predict per control");
+    for (int k = 0; k < n_controls; k++)
+        if (int rc = slamgpu_predict(c, controls[3 * k], controls[3 * k + 1], Q, dt, controls[3 * k + 2], nullptr)) return rc;
+    if (int rc = do_update_dev(c, xtrue, max_range, R, noise, r1, r2, normals, strata)) return rc;
+    if (record_estimate) return slamgpu_estimate_async(c);
+    return 0;
+}
+
+int slamgpu_observe_fetch(slamgpu_ctx *c, float *z, int32_t *vis, int32_t *nz, float *zf, int32_t *idf, int32_t *m, float *zn, int32_t *n) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!c->last_pkt_dev) return fail(SLAMGPU_ERR_INVALID, "no device-made observation yet (slamgpu_step_observe)");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t C = (size_t) c->map_n;
+    std::vector<char> pk(sizeof(ObsPacket) + 4 * 6 * C), ob(sizeof(ObserveOut) + 4 * 3 * C);
+    HIP_TRY(hipMemcpy(pk.data(), c->last_pkt_dev, pk.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ob.data(), c->obs_out_dev, ob.size(), hipMemcpyDeviceToHost));
+    const ObsPacket *h = reinterpret_cast<const ObsPacket *>(pk.data());
+    const int32_t *base = reinterpret_cast<const int32_t *>(h + 1);
+    const ObserveOut *o = reinterpret_cast<const ObserveOut *>(ob.data());
+    const float *hz = reinterpret_cast<const float *>(o + 1);
+    const int32_t *hvis = reinterpret_cast<const int32_t *>(hz + 2 * C);
+    if (z) memcpy(z, hz, sizeof(float) * 2 * (size_t) o->nz);
+    if (vis) memcpy(vis, hvis, sizeof(int32_t) * (size_t) o->nz);
+    if (nz) *nz = o->nz;
+    if (idf) memcpy(idf, base, sizeof(int32_t) * (size_t) h->m);
+    if (zf) memcpy(zf, base + C, sizeof(float) * 2 * (size_t) h->m);
+    if (zn) memcpy(zn, base + 3 * C, sizeof(float) * 2 * (size_t) h->n);
+    if (m) *m = h->m;
+    if (n) *n = h->n;
+    if (h->status & kStatusCapacity) return fail(SLAMGPU_ERR_CAPACITY, "the device front end dropped new landmarks: landmark capacity %d exceeded", c->B.cap_nf);
     return 0;
 }
 
@@ -2036,7 +2239,11 @@ int slamgpu_associate(slamgpu_ctx *c, const float *z, int32_t nz, const float R[
     return 0;
 }
 
-int slamgpu_num_landmarks(slamgpu_ctx *c) { return c ? c->nf : SLAMGPU_ERR_INVALID; }
+int slamgpu_num_landmarks(slamgpu_ctx *c) {
+    if (!c) return SLAMGPU_ERR_INVALID;
+    if (int rc = book_pull(c)) return rc;  // (device-driven steps: the count lives on the device; synchronises)
+    return c->nf;
+}
 
 int slamgpu_sync(slamgpu_ctx *c) {
     if (int rc = check_ctx(c)) return rc;
@@ -2212,6 +2419,7 @@ int slamgpu_upload(slamgpu_ctx *c, int32_t nf, const float *xv, const float *Pv9
     if (int rc = check_ctx(c)) return rc;
     if (nf < 0 || nf > c->B.cap_nf) return fail(SLAMGPU_ERR_CAPACITY, "nf=%d exceeds capacity %d", nf, c->B.cap_nf);
     if (nf > 0 && (!xf || !Pf4)) return fail(SLAMGPU_ERR_INVALID, "nf>0 needs xf and Pf");
+    if (int rc = book_pull(c)) return rc;
     if (int rc = read_ctrl(c, true)) return rc;
     const int cur = c->ctrl_host->live[c->slot], N = c->B.n;
     const size_t S = (size_t) c->B.ncap;

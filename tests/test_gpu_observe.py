@@ -102,3 +102,118 @@ def test_device_front_end_sensor_noise(sg):
     assert 0.8 < d[..., 1].std() / 0.017453292519943 < 1.2                      # sigmaB = 1 degree
     s.close()
     h.close()
+
+
+# ---- the front end wired into the step: slamgpu_step_observe -----------------------------------------------------------------
+@pytest.mark.parametrize("name,mapname,N,seed", [("traj_fs2_webmap_N100_s7", "example_webmap", 100, 7), ("traj_fs2_loop1_N50_s3", "example_loop1", 50, 3)])
+def test_device_made_packets_match_the_reference_tape(sg, name, mapname, N, seed):
+    """slamgpu_step_observe over a whole run, fed only the controls, the true pose and the reference's random draws (sensor
+    normals in visibility order, particle normals, strata: libc rand() in the reference's order, tests/test_host_frontend.py):
+    the observation packets the device makes for itself -- re-observed ids, their observations, the new ones -- against the
+    packets of the reference's own run (tests/golden/traj_*: zf / idf / zn of every observation step)."""
+    from conftest import load_golden
+    from slam_amd import host
+    g = load_golden(name)
+    sim = host.HostSim(sim_args(mapname, "FASTSLAM2", N, seed))
+    lm, _ = sim.map()
+    Q, R, dt = sim.noise()
+    s = sg.SlamGpu(N, sim.nlm, method=2, n_effective=int(g["meta_n_effective"]), use_heading=bool(g["meta_use_heading"]),
+                   wheel_base=float(g["meta_wheel_base"]), sigma_phi=float(g["meta_sigma_phi"]), rng_mode=sg.RNG_TAPE, math_mode=0,
+                   device_observe=True)
+    s.set_map(lm)
+    T = g["ctl"].shape[0]
+    k, ctl, worst = 0, [], 0.0
+    est = []
+    while k < T:
+        r, V, G, phi = sim.control()
+        assert r >= 0
+        ctl.append((V, G, phi))
+        if r != 1:
+            continue
+        m, n = int(g["m"][k]), int(g["n"][k])
+        nz = m + n
+        # the draws of this observation step, in the reference's order: sensor noise (two randn(1, nz): core.cpp:438-449),
+        # then 3 normals per particle if the update samples, then the strata
+        r1 = host.draw_normals(1, nz)[0] if nz else np.zeros(0, f32)
+        r2 = host.draw_normals(1, nz)[0] if nz else np.zeros(0, f32)
+        normals = host.draw_normals(N, 3) if nz else np.zeros((N, 3), f32)
+        cnt, strata = host.draw_strata(N)
+        assert cnt == N
+        s.step_observe(np.array(ctl, f32).reshape(-1, 3), Q, float(dt), sim.true_pose(), float(sim.conf.MAX_RANGE), R, noise=1, r1=r1, r2=r2,
+                       normals=normals, strata=strata)
+        ctl = []
+        if k < 400 or k % 16 == 0:
+            p = s.observe_fetch()
+            assert p["zf"].shape[0] == m and p["zn"].shape[0] == n, k
+            assert np.array_equal(p["idf"], g["idf"][k, :m]), k
+            for got, exp in ((p["zf"], g["zf"][k, :m]), (p["zn"], g["zn"][k, :n])):
+                assert np.array_equal(got[:, 0].view(np.uint32), exp[:, 0].view(np.uint32)), k   # ranges: same bits
+                if got.size:
+                    worst = max(worst, float(np.abs(got[:, 1].astype(np.float64) - exp[:, 1]).max() / 2.384185791015625e-07))
+        k += 1
+    xyt, ne, rs = s.history_fetch()
+    assert s.nf() == int(g["nf"][T - 1]) or s.nf() == int(g["nf"][T - 1]) + int(g["n"][T - 1])
+    # bearings: the device rounds a double atan2 once, the reference calls glibc's atan2f: one ulp apart at most, and the
+    # ulp of the intermediate atan2 - phi (up to 2 pi in magnitude) is two units of 2^-22
+    assert worst <= 2.0 + 1e-9, worst
+    # the filter that ran on those packets is the reference's, until the first differing ancestor (a bearing one ulp off moves
+    # a weight by ~1e-4): identical estimates for the first steps, the same tracking quality over the run
+    assert np.abs(xyt[:10, :2] - g["est"][:10, :2]).max() <= 2e-3
+    err_g = np.hypot(xyt[:, 0] - g["true"][:, 0], xyt[:, 1] - g["true"][:, 1]).mean()
+    err_r = np.hypot(g["est"][:, 0] - g["true"][:, 0], g["est"][:, 1] - g["true"][:, 1]).mean()
+    assert err_g < 1.5 * err_r + 0.05, (err_g, err_r)
+    s.close()
+    sim.close()
+
+
+@pytest.mark.parametrize("mapname", ["example_webmap", "synthetic"])
+def test_device_bookkeeping_equals_host_bookkeeping(sg, tmp_path, mapname):
+    """A run stepped with slamgpu_step_observe (packet and genealogy bookkeeping made on the device) against the same run
+    stepped with slamgpu_step on the packets the device made (fetched back: the host then does the bookkeeping, in the compact
+    layout on the small map): states and histories must be bit-identical, resampling steps included; reads in the middle of
+    the device-driven run (peek / landmark count: the bookkeeping travels to the host and back) must not change a bit."""
+    from slam_amd import host
+    if mapname == "synthetic":
+        lmk = host.synthetic_landmarks(4321, 1000, -130, 100, -100, 90)
+        h0 = host.HostSim(sim_args("example_webmap", "FASTSLAM2", 100, 7))
+        _, wp = h0.map()
+        h0.close()
+        mp = str(tmp_path / "syn1000.mat")
+        host.write_map(mp, lmk, wp)
+        open(str(tmp_path / "syn1000.ini"), "w").write(open(os.path.join(DATA, "example_webmap.ini")).read().replace(
+            "MAX_RANGE           = 60.0", "MAX_RANGE           = 20.0"))
+        args, nobs = ["-m", mp, "-method", "FASTSLAM2", "-SWITCH_SEED_RANDOM", 3], 120
+    else:
+        args, nobs = sim_args(mapname, "FASTSLAM2", 100, 7), 300
+    N = 2048
+    tape = host.make_tape(args, max_obs=nobs)
+    sim = host.HostSim(args)
+    lm, _ = sim.map()
+    max_range = float(sim.conf.MAX_RANGE)
+    sim.close()
+    Q, R, dt = tape["Q"], tape["R"], float(tape["dt"])
+    kw = dict(method=2, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=5, math_mode=1)
+    a = sg.SlamGpu(N, tape["nlm"], device_observe=True, **kw)
+    a.set_map(lm)
+    packets = []
+    for i, st in enumerate(tape["steps"]):
+        a.step_observe(np.array(st["controls"], f32).reshape(-1, 3), Q, dt, st["true"], max_range, R, noise=2)
+        packets.append(a.observe_fetch())
+        if i % 37 == 5:
+            a.peek(first=3, stride=97)
+        if i % 53 == 11:
+            assert a.nf() >= 0
+    ha, da = a.history_fetch(), a.download()
+    a.close()
+    assert max(p["zf"].shape[0] for p in packets) > (12 if mapname == "synthetic" else 3)
+    b = sg.SlamGpu(N, tape["nlm"], **kw)
+    for st, p in zip(tape["steps"], packets):
+        b.step(np.array(st["controls"], f32).reshape(-1, 3), Q, dt, p["zf"], p["idf"], p["zn"], R)
+    hb, db = b.history_fetch(), b.download()
+    b.close()
+    assert 5 < ha[2].sum() < nobs
+    for x, y in zip(ha, hb):
+        assert np.array_equal(x, y)
+    assert da["nf"] == db["nf"]
+    for key in ("xv", "Pv", "w", "xf", "Pf"):
+        assert np.array_equal(da[key].view(np.uint32), db[key].view(np.uint32)), key
