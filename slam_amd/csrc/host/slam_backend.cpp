@@ -47,6 +47,11 @@ static void usage(const char *a0) {
     printf("    -rng parity|philox  -math strict|fast  -log file.csv  -maxsteps n\n");
     printf("    -plot tcp://127.0.0.1:4242|file:<path>|gather:<dir>|none   -plotstride k\n");
     printf("    -gpus k             FastSLAM particle set distributed over k GPUs (k > devices: logical shards on device 0)\n");
+    printf("    -observe host|device  where the observation of a step is made: host (default) or on the GPU (the packet never leaves\n");
+    printf("                        device memory: slamgpu_step_observe; -rng philox, known association, no -plot)\n");
+    printf("    -loop step|batched  step: the wrapper's loop call by call (one predict per control step, estimate every iteration);\n");
+    printf("                        batched (default without -plot, -rng parity, -assoc gated): one slamgpu_step per observation,\n");
+    printf("                        estimates fetched 4096 at a time\n");
     printf("    -KEY value          any ini key, e.g. -NPARTICLES 100000 -NEFFECTIVE 75000 -SWITCH_SEED_RANDOM 7\n");
     printf("    -h  (print usage)\n\n");
 }
@@ -172,6 +177,83 @@ static int run_distributed(Simulator &sim, int k, long maxsteps, FILE *log, Plot
     return rc ? EXIT_FAILURE : 0;
 }
 
+// The wrapper's loop (fastslam2wrapper.cpp:51-117) for a headless run, batched: what the per-iteration form asks of the GPU
+// between two observations -- eight predict calls and eight synchronous pose estimates, only the last of which anything
+// but a plot consumes -- is ONE slamgpu_step per observation (controls + observation + update + recorded estimate, one
+// launch), and the estimates come back 4 096 at a time.  -observe device: the observation itself is made on the GPU
+// (slamgpu_step_observe): the host sends the controls and the true pose.
+static int run_batched(Simulator &sim, slamgpu_ctx *ctx, bool observe_dev, long maxsteps, FILE *log, bool gpubusy) {
+    const Conf &c = sim.conf;
+    struct ObsRow {
+        long iter;
+        float xt[3];
+        double us;
+    };
+    std::vector<ObsRow> rows;
+    std::vector<float> controls, zf, zn;
+    std::vector<int32_t> idf;
+    std::vector<double> xyt(3 * 4096);
+    long iter = 0, nobs = 0;
+    double sq_err = 0, est[3] = {0, 0, 0};
+    int rc = 0;
+    if (observe_dev) rc = slamgpu_set_map(ctx, sim.map.lm.data(), sim.map.nlm);
+    if (!rc && gpubusy) rc = slamgpu_profile(ctx, 1);
+    auto fetch = [&]() -> int {
+        int32_t got = 0;
+        if (int r = slamgpu_history_fetch(ctx, xyt.data(), nullptr, nullptr, nullptr, 4096, &got)) return r;
+        for (int t = 0; t < got && t < (int) rows.size(); t++) {
+            const ObsRow &o = rows[(size_t) t];
+            for (int q = 0; q < 3; q++) est[q] = xyt[3 * (size_t) t + q];
+            sq_err += (est[0] - o.xt[0]) * (est[0] - o.xt[0]) + (est[1] - o.xt[1]) * (est[1] - o.xt[1]);
+            if (log) fprintf(log, "%ld,%.6f,%.6f,%.6f,%.6f,%.6f,%.6f,%.1f\n", o.iter, o.xt[0], o.xt[1], o.xt[2], est[0], est[1], est[2], o.us);
+        }
+        rows.clear();
+        return 0;
+    };
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto t_obs = t_begin;
+    while ((maxsteps < 0 || iter < maxsteps) && !rc) {
+        const int r = sim.control();
+        if (r < 0) break;
+        controls.push_back(sim.Vnoisy);
+        controls.push_back(sim.Gnoisy);
+        controls.push_back(sim.xTrue[2]);
+        iter++;
+        if (r != 1) continue;
+        if (observe_dev) {
+            rc = slamgpu_step_observe(ctx, controls.data(), (int) (controls.size() / 3), sim.Qe, sim.dt, sim.xTrue, c.MAX_RANGE, sim.Re,
+                                      c.SWITCH_SENSOR_NOISE ? 2 : 0, nullptr, nullptr, nullptr, nullptr, 1);
+        } else {
+            sim.observe();
+            sim.associate_known(slamgpu_num_landmarks(ctx), zf, idf, zn);
+            rc = slamgpu_step(ctx, controls.data(), (int) (controls.size() / 3), sim.Qe, sim.dt, zf.data(), idf.data(), (int) idf.size(), zn.data(),
+                              (int) (zn.size() / 2), sim.Re, nullptr, nullptr, 1);
+        }
+        controls.clear();
+        nobs++;
+        const auto now = std::chrono::steady_clock::now();
+        rows.push_back(ObsRow{iter, {sim.xTrue[0], sim.xTrue[1], sim.xTrue[2]}, std::chrono::duration<double, std::micro>(now - t_obs).count()});
+        t_obs = now;
+        if (!rc && rows.size() == 4096) rc = fetch();
+    }
+    if (!rc) rc = fetch();  // (synchronises: everything enqueued has finished)
+    const double wall_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
+    if (rc) fprintf(stderr, "slamgpu: %s\n", slamgpu_last_error());
+    printf("control steps %ld, observation steps %ld, wall time per observation step %.2f us (whole loop, host front end included), "
+           "rms position error %.4f m, final estimate (%.4f, %.4f, %.4f)\n",
+           iter, nobs, nobs ? wall_us / nobs : 0.0, nobs ? std::sqrt(sq_err / nobs) : 0.0, est[0], est[1], est[2]);
+    if (!rc && gpubusy) {
+        double ms = 0, tot = 0;
+        int64_t n = 0;
+        for (const char *k : {"fs2_update", "fs1_update", "resample", "scan", "observe", "finish", "gather", "predict", "estimate"})
+            if (slamgpu_kernel_time(ctx, k, &ms, &n) == 0) tot += ms;
+        printf("GPU busy (sum of kernel times between event pairs) %.2f us per observation step = %.0f %% of the wall time\n",
+               nobs ? 1e3 * tot / nobs : 0.0, wall_us > 0 ? 100.0 * 1e3 * tot / wall_us : 0.0);
+    }
+    printf("landmarks in map: %d\n", slamgpu_num_landmarks(ctx));
+    return rc ? EXIT_FAILURE : 0;
+}
+
 int main(int argc, char **argv) {
     for (int i = 1; i < argc; i++)
         if (strcmp(argv[i], "-h") == 0) {
@@ -221,6 +303,12 @@ int main(int argc, char **argv) {
     const int N = c.NPARTICLES;
     const bool parity = rng == "parity";
     const bool gated = c.s("assoc") == "gated";
+    const bool observe_dev = c.s("observe") == "device";
+    const bool batched = c.method != 0 && !plot.active() && !parity && !gated && c.s("loop") != "step";
+    if (observe_dev && !batched) {
+        fprintf(stderr, "-observe device needs a FastSLAM method, -rng philox, known association and no -plot / -loop step\n");
+        return EXIT_FAILURE;
+    }
     if (c.method != 0) {
         printf("%s\n\n", c.method == 2 ? "FastSLAM 2" : "FastSLAM 1");
         slamgpu_config g{};
@@ -237,6 +325,7 @@ int main(int argc, char **argv) {
         g.rng_mode = parity ? SLAMGPU_RNG_TAPE : SLAMGPU_RNG_PHILOX;
         g.math_mode = math == "strict" ? SLAMGPU_MATH_STRICT : SLAMGPU_MATH_FAST;
         g.seed = (uint64_t) c.SWITCH_SEED_RANDOM;
+        g.flags = observe_dev ? SLAMGPU_FLAG_DEVICE_OBSERVE : 0;
         if (slamgpu_create(&g, &ctx) != 0) {
             fprintf(stderr, "slamgpu_create: %s\n", slamgpu_last_error());
             return EXIT_FAILURE;
@@ -255,6 +344,12 @@ int main(int argc, char **argv) {
         ekf.sigmaPhi = c.sigmaT;
     }
 
+    if (batched) {
+        const int rcb = run_batched(sim, ctx, observe_dev, maxsteps, log, c.s("gpubusy") == "1");
+        if (log) fclose(log);
+        slamgpu_destroy(ctx);
+        return rcb;
+    }
     int stride = c.s("plotstride").empty() ? std::max(1, N / 2000) : std::max(1, atoi(c.s("plotstride").c_str()));
     if (plot.active()) {
         // SLAMWrapper::configurePlot (slamwrapper.cpp:94-110) + addWaypointsAndLandmarks (:112-139) + setPlotRange (:141-172)

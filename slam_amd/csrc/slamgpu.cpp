@@ -199,6 +199,8 @@ struct slamgpu_ctx {
     DevBook *book_dev = nullptr;
     int32_t *refcnt_dev = nullptr;
     int32_t *book_host = nullptr;    // pinned staging of book_pull / book_push
+    hipStream_t obs_stream = nullptr;  // the front-end kernels run here, a step ahead of the update launches (events order them)
+    hipEvent_t obs_ev[kRing]{};        // observe_book of the packet in ring slot k has finished
     char *last_pkt_dev = nullptr;    // packet of the last slamgpu_step_observe (slamgpu_observe_fetch)
     char *peek_dev = nullptr;        // staging of slamgpu_peek, grown on demand
     size_t peek_bytes = 0;
@@ -353,6 +355,8 @@ int book_staging(slamgpu_ctx *c) {
     HIP_TRY(hipHostMalloc((void **) &c->book_host, 4 * words, hipHostMallocDefault));
     HIP_TRY(hipMalloc((void **) &c->book_dev, sizeof(DevBook)));
     HIP_TRY(hipMalloc((void **) &c->refcnt_dev, sizeof(int32_t) * (size_t) c->B.cap_rows));
+    HIP_TRY(hipStreamCreateWithFlags(&c->obs_stream, hipStreamNonBlocking));
+    for (int i = 0; i < kRing; i++) HIP_TRY(hipEventCreateWithFlags(&c->obs_ev[i], hipEventDisableTiming));
     return 0;
 }
 
@@ -362,6 +366,7 @@ int book_pull(slamgpu_ctx *c) {
     const size_t cn = (size_t) c->B.cap_nf, cr = (size_t) c->B.cap_rows;
     DevBook *hb = reinterpret_cast<DevBook *>(c->book_host);
     int32_t *h_erow = c->book_host + sizeof(DevBook) / 4, *h_live = h_erow + cn, *h_ref = h_live + cn;
+    HIP_TRY(hipStreamSynchronize(c->obs_stream));  // (the last front-end kernel writes these tables)
     HIP_TRY(hipMemcpyAsync(hb, c->book_dev, sizeof(DevBook), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(h_erow, c->erow_dev, 4 * cn, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(h_live, c->live_dev, 4 * cn, hipMemcpyDeviceToHost, c->stream));
@@ -726,6 +731,12 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     if (c->book_dev) (void) hipFree(c->book_dev);
     if (c->refcnt_dev) (void) hipFree(c->refcnt_dev);
     if (c->book_host) (void) hipHostFree(c->book_host);
+    for (int i = 0; i < kRing; i++)
+        if (c->obs_ev[i]) (void) hipEventDestroy(c->obs_ev[i]);
+    if (c->obs_stream) {
+        (void) hipStreamSynchronize(c->obs_stream);
+        (void) hipStreamDestroy(c->obs_stream);
+    }
     if (c->comm && rccl()) (void) rccl()->CommDestroy((ncclComm_t) c->comm);
     for (void *p : c->ipc_opened) (void) hipIpcCloseMemHandle(p);
     if (c->peers_dev) (void) hipFree(c->peers_dev);
@@ -1046,13 +1057,17 @@ int do_update_dev(slamgpu_ctx *c, const float xtrue[3], float max_range, const f
     if (int rc = book_push(c)) return rc;
     c->obs_step++;
     const size_t nl = (size_t) c->map_n;
+    // The front-end kernel runs on a stream of its own, ahead of the update launches: packet t is made while update t - 1
+    // still computes (it depends on the true pose and on the previous front-end kernel only); events order the two streams:
+    // update t waits for packet t, and a ring slot is rewritten only after the update that read it has finished.
     if (noise == 1) {
-        HIP_TRY(hipMemcpyAsync(c->obs_r_dev, r1, sizeof(float) * nl, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->obs_r_dev + nl, r2, sizeof(float) * nl, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));  // pageable sources (parity mode only)
+        HIP_TRY(hipStreamSynchronize(c->obs_stream));  // (parity mode only: single-buffered normals, pageable sources)
+        HIP_TRY(hipMemcpyAsync(c->obs_r_dev, r1, sizeof(float) * nl, hipMemcpyHostToDevice, c->obs_stream));
+        HIP_TRY(hipMemcpyAsync(c->obs_r_dev + nl, r2, sizeof(float) * nl, hipMemcpyHostToDevice, c->obs_stream));
+        HIP_TRY(hipStreamSynchronize(c->obs_stream));
     }
     const int slot = (int) (c->pkt_seq++ % kRing);
-    if (c->pkt_ev_used[slot]) HIP_TRY(hipEventSynchronize(c->pkt_ev[slot]));
+    if (c->pkt_ev_used[slot]) HIP_TRY(hipStreamWaitEvent(c->obs_stream, c->pkt_ev[slot], 0));
     char *pd = c->pkt_dev + (size_t) slot * c->pkt_bytes;
     ObserveArgs A{};
     A.lm = c->map_dev;
@@ -1078,13 +1093,10 @@ int do_update_dev(slamgpu_ctx *c, const float xtrue[3], float max_range, const f
     A.refcnt = c->refcnt_dev;
     A.cap_nf = c->B.cap_nf;
     A.cap_rows = c->B.cap_rows;
-    {
-        Timed t(c, "observe");
-        c->k->observe_book(c->stream, A);
-    }
+    c->k->observe_book(c->obs_stream, A);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->pkt_ev[slot], c->stream));
-    c->pkt_ev_used[slot] = true;
+    HIP_TRY(hipEventRecord(c->obs_ev[slot], c->obs_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->obs_ev[slot], 0));
     c->last_pkt_dev = pd;
     c->fresh_row = -1;  // (the device's book knows)
 
@@ -1099,7 +1111,10 @@ int do_update_dev(slamgpu_ctx *c, const float xtrue[3], float max_range, const f
     U.big = reinterpret_cast<const ObsPacket *>(pd);
     memcpy(U.R, R, sizeof U.R);
     const bool need_normals = c->cfg.method == SLAMGPU_FASTSLAM2 && normals != nullptr;
-    return issue_update(c, U, -1, -1, need_normals, normals, strata, false);
+    if (int rc = issue_update(c, U, -1, -1, need_normals, normals, strata, false)) return rc;
+    HIP_TRY(hipEventRecord(c->pkt_ev[slot], c->stream));  // the launch that reads this ring slot: the slot may be rewritten after it
+    c->pkt_ev_used[slot] = true;
+    return 0;
 }
 
 }  // namespace
@@ -1148,6 +1163,7 @@ int slamgpu_observe_fetch(slamgpu_ctx *c, float *z, int32_t *vis, int32_t *nz, f
     if (int rc = check_ctx(c)) return rc;
     if (!c->last_pkt_dev) return fail(SLAMGPU_ERR_INVALID, "no device-made observation yet (slamgpu_step_observe)");
     HIP_TRY(hipSetDevice(c->cfg.device));
+    HIP_TRY(hipStreamSynchronize(c->obs_stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const size_t C = (size_t) c->map_n;
     std::vector<char> pk(sizeof(ObsPacket) + 4 * 6 * C), ob(sizeof(ObserveOut) + 4 * 3 * C);

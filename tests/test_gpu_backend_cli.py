@@ -56,16 +56,43 @@ def test_slam_backend_follows_the_reference_trajectory(tmp_path, method, golden,
     assert err_g.mean() <= 1.5 * err_r.mean() + 0.05, (err_g.mean(), err_r.mean())
 
 
-def test_slam_backend_philox_full_run_tracks_the_true_path(tmp_path):
-    """The throughput configuration of the binary (Philox noise, fast build) over the whole example_webmap run."""
-    log = str(tmp_path / "philox.csv")
-    r = subprocess.run([EXE, "-m", os.path.join(DATA, "example_webmap.mat"), "-method", "FASTSLAM2", "-NPARTICLES", "4096",
-                        "-NEFFECTIVE", "3072", "-SWITCH_SEED_RANDOM", "7", "-log", log], capture_output=True, text=True, timeout=900)
+def _philox_run(tmp_path, name, extra=(), n=4096):
+    log = str(tmp_path / (name + ".csv"))
+    r = subprocess.run([EXE, "-m", os.path.join(DATA, "example_webmap.mat"), "-method", "FASTSLAM2", "-NPARTICLES", str(n),
+                        "-NEFFECTIVE", str(3 * n // 4), "-SWITCH_SEED_RANDOM", "7", "-log", log, *extra], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
-    rows = np.loadtxt(log, delimiter=",", skiprows=1)
-    assert rows.shape[0] > 17000 and "landmarks in map: 35" in r.stdout
-    err = np.hypot(rows[:, 4] - rows[:, 1], rows[:, 5] - rows[:, 2])
-    assert np.isfinite(err).all() and err.mean() < 1.0, err.mean()
+    return r.stdout, np.loadtxt(log, delimiter=",", skiprows=1)
+
+
+def test_slam_backend_philox_full_run_tracks_the_true_path(tmp_path):
+    """The throughput configuration of the binary (Philox noise, fast build) over the whole example_webmap run, in the three
+    forms of its loop: the wrapper's loop call by call (-loop step: a predict launch and a synchronous estimate per control
+    step), batched (default: one slamgpu_step per observation, estimates fetched 4 096 at a time) and batched with the
+    observation made on the GPU (-observe device)."""
+    out_s, rows_s = _philox_run(tmp_path, "step", ["-loop", "step"])
+    assert rows_s.shape[0] > 17000 and "landmarks in map: 35" in out_s
+    err_s = np.hypot(rows_s[:, 4] - rows_s[:, 1], rows_s[:, 5] - rows_s[:, 2])
+    assert np.isfinite(err_s).all() and err_s.mean() < 1.0, err_s.mean()
+    out_b, rows_b = _philox_run(tmp_path, "batched", ["-gpubusy", "1"])
+    assert rows_b.shape[0] == 2172 and "landmarks in map: 35" in out_b and "wall time per observation step" in out_b and "GPU busy" in out_b
+    # the same filter on the same tape: the batched loop folds the queued predicts into the update launch (float rounding
+    # differs), so the two agree closely until a resample picks a different ancestor, and statistically afterwards
+    by_iter = {int(r[0]): r for r in rows_s}
+    ref = np.array([by_iter[int(r[0])][4:7] for r in rows_b])
+    assert np.abs(rows_b[:8, 4:7] - ref[:8]).max() <= 1e-3
+    err_b = np.hypot(rows_b[:, 4] - rows_b[:, 1], rows_b[:, 5] - rows_b[:, 2])
+    # (one run's mean error depends on which ancestors a few early resamples picked: 0.35 m and 0.76 m seen for the two forms
+    # at 4 096 particles, 0.69 m and 0.72 m at 100 000; the bound is the one the other whole-run tests use)
+    assert np.isfinite(err_b).all() and err_b.mean() < 1.5, err_b.mean()
+    out_d, rows_d = _philox_run(tmp_path, "device", ["-observe", "device"])
+    assert rows_d.shape[0] == 2172 and "landmarks in map: 35" in out_d
+    assert np.array_equal(rows_d[:, 1:4], rows_b[:, 1:4])  # the same true path
+    err_d = np.hypot(rows_d[:, 4] - rows_d[:, 1], rows_d[:, 5] - rows_d[:, 2])
+    assert np.isfinite(err_d).all() and err_d.mean() < 1.5, err_d.mean()  # (other sensor noise: Philox on the device)
+    # refused combinations say why
+    r = subprocess.run([EXE, "-m", os.path.join(DATA, "example_webmap.mat"), "-method", "FASTSLAM2", "-observe", "device", "-rng", "parity"],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "-observe device needs" in r.stderr
 
 
 def test_slam_backend_plot_stream_with_particles(tmp_path):
