@@ -229,6 +229,16 @@ int slamgpu_observe_fetch(slamgpu_ctx *ctx, float *z, int32_t *vis, int32_t *nz,
 enum { SLAMGPU_ASSOC_NEW = -1, SLAMGPU_ASSOC_DISCARD = -2 };
 int slamgpu_associate(slamgpu_ctx *ctx, const float *z, int32_t nz, const float R[4], float gate_reject, float gate_augment,
                       int32_t *labels, int32_t *consensus, float *support);
+/* The same with a choice of method and its cost.  mode SLAMGPU_ASSOC_AUTO: the spatial prefilter for maps of 64 landmarks or
+ * more (single contexts), the exhaustive scan otherwise; _EXHAUSTIVE: every particle gates every observation against every
+ * landmark, O(N nz Nf); _GRID: the landmarks are binned into a uniform grid by the bounding boxes of their estimates over all
+ * particles, grown by a radius beyond which no particle's estimate can pass either gate; every (particle, observation) pair
+ * then evaluates the landmarks of one cell only, O(N nz k) -- the labels are the exhaustive scan's, decision for decision.
+ * stats (may be NULL): [0] (particle, observation, landmark) triples evaluated, [1] grid entries, [2] device milliseconds of
+ * the association kernels, [3] 1 if the grid was used. */
+enum { SLAMGPU_ASSOC_AUTO = 0, SLAMGPU_ASSOC_EXHAUSTIVE = 1, SLAMGPU_ASSOC_GRID = 2 };
+int slamgpu_associate_ex(slamgpu_ctx *ctx, const float *z, int32_t nz, const float R[4], float gate_reject, float gate_augment, int32_t mode,
+                         int32_t *labels, int32_t *consensus, float *support, double stats[4]);
 
 int slamgpu_num_landmarks(slamgpu_ctx *ctx);
 /* Particle-major host copies (any pointer may be NULL): xv[3N], Pv[9N] row-major, w[N],

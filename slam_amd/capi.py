@@ -25,8 +25,9 @@ DECLARED_SYMBOLS = [
     "slamgpu_dist_history_fetch", "slamgpu_dist_gather", "slamgpu_dist_set_collective", "slamgpu_dist_handshake_test",
     "slamgpu_dist_collective_status", "slamgpu_dist_comm_id", "slamgpu_dist_comm_init", "slamgpu_dist_group_create", "slamgpu_dist_group_destroy",
     "slamgpu_dist_group_step", "slamgpu_dist_group_settle", "slamgpu_dist_group_history", "slamgpu_dist_group_download",
-    "slamgpu_peek", "slamgpu_step_observe", "slamgpu_observe_fetch",
+    "slamgpu_peek", "slamgpu_step_observe", "slamgpu_observe_fetch", "slamgpu_associate_ex",
 ]
+ASSOC_AUTO, ASSOC_EXHAUSTIVE, ASSOC_GRID = 0, 1, 2
 FLAG_DEVICE_OBSERVE = 1
 
 
@@ -87,6 +88,8 @@ def load_library():
     L.slamgpu_step_status.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     L.slamgpu_kat.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     L.slamgpu_associate.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.slamgpu_associate_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]
     L.slamgpu_set_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     L.slamgpu_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32] + [C.c_void_p] * 2 + [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32)]
     L.slamgpu_step_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int32,
@@ -641,14 +644,19 @@ class SlamGpu:
         _chk(self.L.slamgpu_observe_fetch(self.h, _ptr(z), _ptr(vis), C.byref(nz), _ptr(zf), _ptr(idf), C.byref(m), _ptr(zn), C.byref(n)))
         return dict(z=z[:nz.value].copy(), vis=vis[:nz.value].copy(), zf=zf[:m.value].copy(), idf=idf[:m.value].copy(), zn=zn[:n.value].copy())
 
-    def associate(self, z, R, gate_reject=4.0, gate_augment=25.0, want_labels=True):
-        """per-particle gated nearest-neighbour association (slamgpu_associate): labels [N, nz], consensus [nz], support [nz]"""
+    def associate(self, z, R, gate_reject=4.0, gate_augment=25.0, want_labels=True, mode=ASSOC_AUTO, want_stats=False):
+        """per-particle gated nearest-neighbour association (slamgpu_associate_ex): labels [N, nz], consensus [nz], support [nz]
+        (+ stats dict: triples evaluated, grid entries, device ms, grid used)"""
         z = _f32(z).reshape(-1, 2)
         nz = z.shape[0]
         lab = np.zeros((self.N, nz), np.int32) if want_labels else None
         cons = np.zeros(nz, np.int32)
         sup = np.zeros(nz, np.float32)
-        _chk(self.L.slamgpu_associate(self.h, _ptr(z), nz, _ptr(_f32(R, 4)), gate_reject, gate_augment, _ptr(lab), _ptr(cons), _ptr(sup)))
+        st = np.zeros(4, np.float64)
+        _chk(self.L.slamgpu_associate_ex(self.h, _ptr(z), nz, _ptr(_f32(R, 4)), gate_reject, gate_augment, int(mode), _ptr(lab), _ptr(cons), _ptr(sup),
+                                         _ptr(st)))
+        if want_stats:
+            return lab, cons, sup, dict(triples=st[0], grid_entries=st[1], ms=st[2], grid=bool(st[3]))
         return lab, cons, sup
 
     def debug_stamps(self, max_blocks=8192):

@@ -371,6 +371,45 @@ struct PeekArgs {
     float *lb;
 };
 
+// ---- gated association with a spatial prefilter (slamgpu_associate_ex) ------------------------------------------------------
+// Per landmark j, over ALL particles: the bounding box of its position estimates and the largest trace of its covariance
+// (lmk_box_kernel, recomputed when the landmark is written), and from them a radius rho_j such that a particle's estimate of j
+// farther than rho_j from the world point an observation implies cannot pass either gate for that particle
+// (nis >= v_i^2 / S_ii, S_00 <= tr Pf + R00, S_11 <= tr Pf / d^2 + R11).  The landmarks are binned into a uniform grid over
+// the region the observations can point into; every (particle, observation) pair then evaluates the landmarks of ONE cell.
+struct LmkBox {
+    float xmin, xmax, ymin, ymax, tmax, pad[3];
+};
+struct AssocGeom {
+    float x0, y0, inv_cs, cs;     // grid origin, 1 / cell size, cell size
+    int32_t nx, ny;
+    float px0, px1, py0, py1;     // bounding box of the particle poses
+    float zmax;                   // largest observed range
+    int32_t total, overflow;      // grid entries written / the entry buffer was too small (the caller falls back to brute force)
+    unsigned long long pairs;     // (particle, observation, landmark) triples evaluated by associate_grid_kernel
+};
+constexpr int kAssocMaxCells = 64;  // per axis
+// weighted vote per observation, on the device: a small open-addressing table per observation (the labels one observation
+// draws from 10^5 particles are the handful of landmarks of one grid cell, NEW and DISCARD)
+constexpr int kVoteSlots = 32;
+constexpr int kVoteEmpty = (int) 0x80000000;
+struct VoteSlot {
+    int32_t key;   // label, kVoteEmpty: unused
+    float w;       // sum of the weights of the particles that chose it
+};
+struct AssocGridArgs {
+    const LmkBox *box;            // [nf]
+    AssocGeom *geom;
+    int32_t *cell_start;          // [nx * ny + 1] exclusive prefix of the cell populations
+    int32_t *cell_fill;           // [nx * ny] cursors of the fill pass
+    int32_t *items;               // [cap_items] landmark ids, cell after cell
+    int32_t cap_items, nf, nz;
+    const float *z;               // [2 nz] observations (range, bearing), device
+    float r00, r11, G;            // R diagonal; G = max(gate_reject, gate_augment) with the safety margin
+    VoteSlot *votes;              // [nz][kVoteSlots] or null: the weighted vote per observation (AssocGeom::overflow bit 1: a table filled up)
+    int32_t logw;                 // the context keeps log-weights
+};
+
 struct KernelTable {
     // the step: [resampling stage of the previous update, inline] + [gather] + [fused predicts] + per-particle observation
     // update + in-block weight prefix / totals  (+ helper blocks: genealogy copy, Ctrl words, estimate reduction)
@@ -415,6 +454,14 @@ struct KernelTable {
     void (*dist_gather)(hipStream_t, const DistGatherArgs &);
     void (*dist_flags)(hipStream_t, const DistFlagArgs &);
     void (*peek)(hipStream_t, const Buffers &, const WeightScratch &, const PeekArgs &);
+    // bounding boxes of the listed landmarks (ids on the device) over all particle slots of their live record buffer
+    void (*lmk_box)(hipStream_t, const Buffers &, const int32_t *ids_dev, int count, LmkBox *box_dev);
+    // geometry + grid of the landmark boxes for one association call (four small launches)
+    void (*assoc_grid)(hipStream_t, const Buffers &, const AssocGridArgs &);
+    // slamgpu_associate through the grid: the same labels as `associate`, evaluating only the landmarks of one cell per
+    // (particle, observation)
+    void (*associate_grid)(hipStream_t, const Buffers &, const AssocGridArgs &, const float *R4, float gate_reject, float gate_augment,
+                           int32_t *labels_dev);
 };
 
 const KernelTable *kernels_strict();

@@ -2150,6 +2150,293 @@ __global__ void __launch_bounds__(kBlock) associate_kernel(Buffers B, int nf, co
 }
 
 // ---------------------------------------------------------------------------------------------------
+// The same association with a spatial prefilter (kernels.h: LmkBox / AssocGeom): O(N * nz * k) landmark evaluations instead
+// of O(N * nz * Nf), k = the landmarks one grid cell holds.  Which landmarks a (particle, observation) pair may skip is
+// decided by bounds that hold for every particle (below), so the labels are those of associate_kernel, decision for decision.
+// ---------------------------------------------------------------------------------------------------
+// one block per listed landmark: box of its estimates and largest covariance trace over all particle slots of the live buffer
+// (a resample only removes particles from that set: the box stays valid until the landmark is written again)
+__global__ void __launch_bounds__(kBlock) lmk_box_kernel(Buffers B, const int32_t *__restrict__ ids, int count, LmkBox *__restrict__ box) {
+    __shared__ float sh[5][kBlock / kWave];
+    const int j = ids[blockIdx.x];
+    const int b = B.lmk_live[j];
+    const float4 *__restrict__ a = B.lmkA[b] + (size_t) j * B.ncap;
+    const float *__restrict__ c = B.lmkB[b] + (size_t) j * B.ncap;
+    float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY, t = 0.0f;
+    for (int k = threadIdx.x; k < B.n; k += kBlock) {
+        const float4 v = a[k];
+        x0 = fminf(x0, v.x);
+        x1 = fmaxf(x1, v.x);
+        y0 = fminf(y0, v.y);
+        y1 = fmaxf(y1, v.y);
+        t = fmaxf(t, fabsf(v.z) + fabsf(c[k]));  // tr Pf >= its largest eigenvalue
+    }
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, d, kWave));
+        x1 = fmaxf(x1, __shfl_xor(x1, d, kWave));
+        y0 = fminf(y0, __shfl_xor(y0, d, kWave));
+        y1 = fmaxf(y1, __shfl_xor(y1, d, kWave));
+        t = fmaxf(t, __shfl_xor(t, d, kWave));
+    }
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    if (lane == 0) {
+        sh[0][wv] = x0; sh[1][wv] = x1; sh[2][wv] = y0; sh[3][wv] = y1; sh[4][wv] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        LmkBox o{};
+        o.xmin = fminf(fminf(sh[0][0], sh[0][1]), fminf(sh[0][2], sh[0][3]));
+        o.xmax = fmaxf(fmaxf(sh[1][0], sh[1][1]), fmaxf(sh[1][2], sh[1][3]));
+        o.ymin = fminf(fminf(sh[2][0], sh[2][1]), fminf(sh[2][2], sh[2][3]));
+        o.ymax = fmaxf(fmaxf(sh[3][0], sh[3][1]), fmaxf(sh[3][2], sh[3][3]));
+        o.tmax = fmaxf(fmaxf(sh[4][0], sh[4][1]), fmaxf(sh[4][2], sh[4][3]));
+        box[j] = o;
+    }
+}
+
+// one block: bounding box of the particle poses, largest observed range => the grid over the region the observations can
+// point into (pose box grown by the largest range)
+__global__ void __launch_bounds__(kBlock) assoc_geom_kernel(Buffers B, AssocGridArgs A) {
+    __shared__ float sh[5][kBlock / kWave];
+    const int cur = B.ctrl->live[B.slot];
+    float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY, zm = 0.0f;
+    for (int k = threadIdx.x; k < B.n; k += kBlock) {
+        const float4 v = B.poseA[cur][k];
+        x0 = fminf(x0, v.x);
+        x1 = fmaxf(x1, v.x);
+        y0 = fminf(y0, v.y);
+        y1 = fmaxf(y1, v.y);
+    }
+    for (int q = threadIdx.x; q < A.nz; q += kBlock) zm = fmaxf(zm, fabsf(A.z[2 * q]));
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        x0 = fminf(x0, __shfl_xor(x0, d, kWave));
+        x1 = fmaxf(x1, __shfl_xor(x1, d, kWave));
+        y0 = fminf(y0, __shfl_xor(y0, d, kWave));
+        y1 = fmaxf(y1, __shfl_xor(y1, d, kWave));
+        zm = fmaxf(zm, __shfl_xor(zm, d, kWave));
+    }
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    if (lane == 0) {
+        sh[0][wv] = x0; sh[1][wv] = x1; sh[2][wv] = y0; sh[3][wv] = y1; sh[4][wv] = zm;
+    }
+    __syncthreads();
+    for (int cidx = threadIdx.x; cidx < kAssocMaxCells * kAssocMaxCells + 1; cidx += kBlock) {
+        A.cell_start[cidx] = 0;
+        if (cidx < kAssocMaxCells * kAssocMaxCells) A.cell_fill[cidx] = 0;
+    }
+    if (threadIdx.x == 0) {
+        AssocGeom g{};
+        g.px0 = fminf(fminf(sh[0][0], sh[0][1]), fminf(sh[0][2], sh[0][3]));
+        g.px1 = fmaxf(fmaxf(sh[1][0], sh[1][1]), fmaxf(sh[1][2], sh[1][3]));
+        g.py0 = fminf(fminf(sh[2][0], sh[2][1]), fminf(sh[2][2], sh[2][3]));
+        g.py1 = fmaxf(fmaxf(sh[3][0], sh[3][1]), fmaxf(sh[3][2], sh[3][3]));
+        g.zmax = fmaxf(fmaxf(sh[4][0], sh[4][1]), fmaxf(sh[4][2], sh[4][3]));
+        const float margin = 1.0f + 1e-3f * (fabsf(g.px0) + fabsf(g.px1) + fabsf(g.py0) + fabsf(g.py1) + g.zmax);
+        g.x0 = g.px0 - g.zmax - margin;
+        g.y0 = g.py0 - g.zmax - margin;
+        const float ex = (g.px1 + g.zmax + margin) - g.x0, ey = (g.py1 + g.zmax + margin) - g.y0;
+        g.cs = fmaxf(fmaxf(ex, ey) / (float) kAssocMaxCells, 0.5f);
+        g.inv_cs = 1.0f / g.cs;
+        g.nx = min(kAssocMaxCells, (int) (ex * g.inv_cs) + 1);
+        g.ny = min(kAssocMaxCells, (int) (ey * g.inv_cs) + 1);
+        g.total = 0;
+        g.overflow = 0;
+        g.pairs = 0ull;
+        *A.geom = g;
+    }
+}
+
+// A particle's estimate l of landmark j can pass a gate (nis < G) for an observation (r, b) only if it lies within rho of the
+// world point p the observation implies for that particle.  With d = |l - pose|, e = |d - r| and D the wrapped bearing residual:
+//   |l - p|^2 = (d - r)^2 + 2 d r (1 - cos D) <= e^2 + d r D^2,  so  |l - p| <= e + sqrt(d r) |D| <= e + d |D| + (e / 2) |D|
+//   (r <= d + e), and gate by gate (nis >= v_i^2 / S_ii for a positive definite S):
+//   e = |v0| < sqrt(G S00) <= sqrt(G (t + R00)),   d |D| = d |v1| < d sqrt(G S11) <= sqrt(G (t + d^2 R11)),   |D| <= pi,
+// t = tr Pf (>= its largest eigenvalue; the rows of Hf have norms 1 and 1 / d).  Over all particles: t <= tmax_j and
+// d <= the largest distance between the pose box and the landmark's box.
+SLAM_DEV float assoc_radius(const LmkBox &bx, const AssocGeom &g, float r00, float r11, float G) {
+    const float dx = fmaxf(fabsf(bx.xmax - g.px0), fabsf(g.px1 - bx.xmin)), dy = fmaxf(fabsf(bx.ymax - g.py0), fabsf(g.py1 - bx.ymin));
+    const float D2 = dx * dx + dy * dy;
+    const float rho = (1.0f + 0.5f * 3.14159274f) * sqrtf(G * (bx.tmax + r00)) + sqrtf(G * (bx.tmax + D2 * r11));
+    return rho * 1.01f + 1e-3f;  // (rounding of the bound itself and of the kernels' own arithmetic)
+}
+
+// cells the grown box of landmark j overlaps (clipped to the grid); false: none
+SLAM_DEV bool assoc_cells(const LmkBox &bx, const AssocGeom &g, float rho, int &cx0, int &cx1, int &cy0, int &cy1) {
+    if (!(bx.xmin <= bx.xmax)) return false;  // (no particle slot: n = 0)
+    const float fx0 = (bx.xmin - rho - g.x0) * g.inv_cs, fx1 = (bx.xmax + rho - g.x0) * g.inv_cs;
+    const float fy0 = (bx.ymin - rho - g.y0) * g.inv_cs, fy1 = (bx.ymax + rho - g.y0) * g.inv_cs;
+    if (fx1 < 0.0f || fy1 < 0.0f || fx0 >= (float) g.nx || fy0 >= (float) g.ny) return false;
+    cx0 = max(0, (int) floorf(fx0) - 1);  // (one cell of slack on every side: the point's own cell index is rounded too)
+    cy0 = max(0, (int) floorf(fy0) - 1);
+    cx1 = min(g.nx - 1, (int) floorf(fx1) + 1);
+    cy1 = min(g.ny - 1, (int) floorf(fy1) + 1);
+    return true;
+}
+
+__global__ void __launch_bounds__(kBlock) assoc_count_kernel(AssocGridArgs A, int fill) {
+    const int j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= A.nf) return;
+    const AssocGeom g = *A.geom;
+    const LmkBox bx = A.box[j];
+    int cx0, cx1, cy0, cy1;
+    if (!assoc_cells(bx, g, assoc_radius(bx, g, A.r00, A.r11, A.G), cx0, cx1, cy0, cy1)) return;
+    for (int cy = cy0; cy <= cy1; cy++)
+        for (int cx = cx0; cx <= cx1; cx++) {
+            const int cell = cy * g.nx + cx;
+            if (!fill) {
+                atomicAdd(&A.cell_start[cell + 1], 1);
+            } else {
+                const int at = A.cell_start[cell] + atomicAdd(&A.cell_fill[cell], 1);
+                if (at < A.cap_items) A.items[at] = j;
+            }
+        }
+}
+
+// one block: cell populations -> exclusive prefix (cell_start[c + 1] held the population of cell c)
+__global__ void __launch_bounds__(kBlock) assoc_scan_kernel(AssocGridArgs A) {
+    __shared__ int sh[kBlock / kWave];
+    __shared__ int carry;
+    const AssocGeom g = *A.geom;
+    const int nc = g.nx * g.ny;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < nc; c0 += kBlock) {
+        const int c = c0 + (int) threadIdx.x;
+        const int v = c < nc ? A.cell_start[c + 1] : 0;
+        // inclusive scan of v over the block
+        int s = v;
+        const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int o = __shfl_up(s, d, kWave);
+            if (lane >= d) s += o;
+        }
+        if (lane == kWave - 1) sh[wv] = s;
+        __syncthreads();
+        int base = carry;
+        for (int k = 0; k < wv; k++) base += sh[k];
+        const int incl = base + s;
+        __syncthreads();
+        if (c < nc) A.cell_start[c + 1] = incl;
+        if (threadIdx.x == kBlock - 1) carry = incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        A.cell_start[0] = 0;
+        A.geom->total = carry;
+        A.geom->overflow = carry > A.cap_items ? 1 : 0;
+    }
+}
+
+constexpr int kAssocObsPerBlock = 4;
+
+// one vote into the table of an observation: open addressing, linear probing; returns false if the table is full
+SLAM_DEV bool vote_add(VoteSlot *tab, int label, float w) {
+    unsigned h = ((unsigned) label * 2654435761u) >> 27;  // 5 bits
+    for (int p = 0; p < kVoteSlots; p++) {
+        VoteSlot *sl = tab + ((h + p) & (kVoteSlots - 1));
+        int k = __hip_atomic_load(&sl->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k == kVoteEmpty) {
+            int expected = kVoteEmpty;
+            if (__hip_atomic_compare_exchange_strong(&sl->key, &expected, label, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) k = label;
+            else k = expected;
+        }
+        if (k == label) {
+            atomicAdd(&sl->w, w);
+            return true;
+        }
+    }
+    return false;
+}
+
+__global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, AssocGridArgs A, float r00, float r01, float r10, float r11, float gate1,
+                                                                 float gate2, int32_t *__restrict__ labels) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const AssocGeom g = *A.geom;
+    if (g.overflow & 1) return;  // (the entry buffer was too small: the caller runs the exhaustive scan)
+    unsigned long long pairs = 0;
+    const bool on = i < B.n;
+    const int cur = B.ctrl->live[B.slot];
+    const size_t S = (size_t) B.ncap;
+    const float4 pa = on ? B.poseA[cur][i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float wi = on ? (A.logw ? expf(pa.w) : pa.w) : 0.0f;
+    const int lane = threadIdx.x & (kWave - 1);
+    bool full = false;
+    // blockIdx.y = a group of kAssocObsPerBlock observations: a particle's observations are independent of each other, and one
+    // thread walking all of them alone (1 300 on the 10 000-landmark map, ~65 dependent record reads each) left the
+    // machine two thirds empty and every read exposed: 225 ms per call at 10^5 particles
+    const int q_lo = blockIdx.y * kAssocObsPerBlock, q_hi = min(A.nz, q_lo + kAssocObsPerBlock);
+    const float e_gate = (1.0f + 0.5f * 3.14159274f) * 1.01f;
+    for (int q = q_lo; q < q_hi; q++) {
+        int label = kVoteEmpty;
+        if (on) {
+            const float zr = A.z[2 * q], zb = A.z[2 * q + 1];
+            float sn, cs;
+            sincosf(pa.z + zb, &sn, &cs);
+            const float px = pa.x + zr * cs, py = pa.y + zr * sn;
+            const int cx = min(max((int) floorf((px - g.x0) * g.inv_cs), 0), g.nx - 1);
+            const int cy = min(max((int) floorf((py - g.y0) * g.inv_cs), 0), g.ny - 1);
+            const int cell = cy * g.nx + cx;
+            float nbest = INFINITY, outer = INFINITY;
+            int jbest = -1;
+            for (int at = A.cell_start[cell]; at < A.cell_start[cell + 1]; at++) {
+                const int j = A.items[at];
+                {
+                    // radial pre-test on the landmark's box alone (32 bytes, shared by the wave, before the particle's own
+                    // record is fetched): every estimate of j lies in the box, so its distance d from this pose is within
+                    // [dmin, dmax] of the box; a gate needs |d - r| < sqrt(G (t + R00)) (assoc_radius)
+                    const LmkBox bx = A.box[j];
+                    const float ex = fmaxf(fmaxf(bx.xmin - pa.x, pa.x - bx.xmax), 0.0f), ey = fmaxf(fmaxf(bx.ymin - pa.y, pa.y - bx.ymax), 0.0f);
+                    const float fx = fmaxf(fabsf(bx.xmin - pa.x), fabsf(bx.xmax - pa.x)), fy = fmaxf(fabsf(bx.ymin - pa.y), fabsf(bx.ymax - pa.y));
+                    const float dmin = sqrtf(ex * ex + ey * ey), dmax = sqrtf(fx * fx + fy * fy);
+                    const float e = e_gate * sqrtf(A.G * (bx.tmax + A.r00)) + 1e-3f;
+                    if (zr + e < dmin * 0.999f || zr - e > dmax * 1.001f) continue;
+                }
+                float4 la;
+                float lb;
+                read_through_genealogy(B, B.lmk_live, cur, S, j, i, la, lb);
+                const Jac jc = jacobian(pa.x, pa.y, pa.z, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
+                float i00, i01, i10, i11;
+                inverse2(jc.s00, jc.s01, jc.s10, jc.s11, i00, i01, i10, i11);
+                const float ldet = logf(determinant2(jc.s00, jc.s01, jc.s10, jc.s11));
+                const float v0 = zr - jc.zp0;
+                const float v1 = trig_offset(zb - jc.zp1);
+                const float t0 = v0 * i00 + v1 * i10, t1 = v0 * i01 + v1 * i11;
+                const float nis = t0 * v0 + t1 * v1;
+                const float nd = nis + ldet;
+                pairs++;
+                // (the cell's landmarks come in no particular order: ties go to the lower index, as in the ascending scan)
+                if (nis < gate1 && (nd < nbest || (nd == nbest && j < jbest))) {
+                    nbest = nd;
+                    jbest = j;
+                } else if (nis < outer) {
+                    outer = nis;
+                }
+            }
+            label = jbest > -1 ? jbest : (outer > gate2 ? kAssocNew : kAssocDiscard);
+            if (labels) labels[(size_t) i * A.nz + q] = label;
+        }
+        if (A.votes) {
+            // a wave's particles nearly always agree: one atomic per wave and distinct label, not one per particle
+            unsigned long long todo = __ballot(on);
+            while (todo) {
+                const int src = __ffsll((long long) todo) - 1;
+                const int lab0 = __builtin_amdgcn_readlane(label, src);
+                const bool mine = on && label == lab0;
+                const float ws = wave_sum_f(mine ? wi : 0.0f);
+                if (lane == src && !vote_add(A.votes + (size_t) q * kVoteSlots, lab0, ws)) full = true;
+                todo &= ~__ballot(mine);
+            }
+        }
+    }
+    if (__ballot(full) && lane == 0) atomicOr(&A.geom->overflow, 2);
+    pairs = (unsigned long long) wave_sum_d((double) pairs);
+    if (lane == 0 && pairs) atomicAdd(&A.geom->pairs, pairs);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Sharded resampling (particles partitioned over contexts / GPUs in contiguous blocks of 256).  The host
 // layer all-gathers the per-block totals (4 B + 4 B per 256 particles); every shard then runs the same
 // scan, so the decision and every ancestor are independent of the number of shards.
@@ -2596,8 +2883,26 @@ static void launch_peek(hipStream_t st, const Buffers &B, const WeightScratch &w
     hipLaunchKernelGGL(peek_kernel, dim3((A.count + kBlock - 1) / kBlock, gy), dim3(kBlock), 0, st, B, ws, A);
 }
 
+static void launch_lmk_box(hipStream_t st, const Buffers &B, const int32_t *ids, int count, LmkBox *box) {
+    if (count > 0) hipLaunchKernelGGL(lmk_box_kernel, dim3(count), dim3(kBlock), 0, st, B, ids, count, box);
+}
+
+static void launch_assoc_grid(hipStream_t st, const Buffers &B, const AssocGridArgs &A) {
+    hipLaunchKernelGGL(assoc_geom_kernel, dim3(1), dim3(kBlock), 0, st, B, A);
+    const int gb = (A.nf + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(assoc_count_kernel, dim3(gb), dim3(kBlock), 0, st, A, 0);
+    hipLaunchKernelGGL(assoc_scan_kernel, dim3(1), dim3(kBlock), 0, st, A);
+    hipLaunchKernelGGL(assoc_count_kernel, dim3(gb), dim3(kBlock), 0, st, A, 1);
+}
+
+static void launch_associate_grid(hipStream_t st, const Buffers &B, const AssocGridArgs &A, const float *R4, float g1, float g2, int32_t *labels) {
+    hipLaunchKernelGGL(associate_grid_kernel, dim3(B.ncap / kBlock, (A.nz + kAssocObsPerBlock - 1) / kAssocObsPerBlock), dim3(kBlock), 0, st, B, A,
+                       R4[0], R4[1], R4[2], R4[3], g1, g2, labels);
+}
+
 static const KernelTable kTable = {launch_update, launch_resample, launch_scan, launch_gather, launch_flatten, launch_identity, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat, launch_observe, launch_observe_book, launch_associate,
-                                   launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish, launch_dist_gather, launch_dist_flags, launch_peek};
+                                   launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish, launch_dist_gather, launch_dist_flags, launch_peek, launch_lmk_box, launch_assoc_grid,
+                                   launch_associate_grid};
 
 }  // namespace SLAM_KNS
 

@@ -202,6 +202,13 @@ struct slamgpu_ctx {
     hipStream_t obs_stream = nullptr;  // the front-end kernels run here, a step ahead of the update launches (events order them)
     hipEvent_t obs_ev[kRing]{};        // observe_book of the packet in ring slot k has finished
     char *last_pkt_dev = nullptr;    // packet of the last slamgpu_step_observe (slamgpu_observe_fetch)
+    // gated association with the spatial prefilter (slamgpu_associate_ex): per-landmark boxes over all particles, refreshed
+    // for the landmarks written since (box_dirty), and the grid buffers
+    LmkBox *box_dev = nullptr;
+    std::vector<char> box_dirty;
+    int32_t *assoc_ids_dev = nullptr, *cell_start_dev = nullptr, *cell_fill_dev = nullptr, *items_dev = nullptr;
+    AssocGeom *geom_dev = nullptr;
+    int32_t cap_items = 0;
     char *peek_dev = nullptr;        // staging of slamgpu_peek, grown on demand
     size_t peek_bytes = 0;
     unsigned long long *stamps_dev = nullptr;  // diagnostic (SLAMGPU_STAMPS=1 + libslamgpu_stamps.so): UpdateArgs::stamps
@@ -388,6 +395,7 @@ int book_pull(slamgpu_ctx *c) {
         if (c->refcnt[r] > 0) rows_add_live(c, r);
     c->tables_dirty = true;
     c->book_on_device = false;
+    std::fill(c->box_dirty.begin(), c->box_dirty.end(), 1);  // (which landmarks the device-driven steps wrote is not known here)
     if (hb->status & kStatusCapacity)
         return fail(SLAMGPU_ERR_CAPACITY, "the device front end dropped new landmarks: landmark capacity %d exceeded", c->B.cap_nf);
     return 0;
@@ -645,6 +653,7 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     c->erow.assign((size_t) cap_nf, 0);
     c->live_flag.assign((size_t) cap_nf, 0);
     c->seen_step.assign((size_t) cap_nf, 0);
+    c->box_dirty.assign((size_t) cap_nf, 1);
     CTX_TRY(hipMalloc((void **) &c->live_dev, sizeof(int32_t) * (size_t) cap_nf));
     c->refcnt.assign((size_t) c->B.cap_rows, 0);
     c->live_pos.assign((size_t) c->B.cap_rows, -1);
@@ -728,6 +737,9 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     if (c->hist_dev) (void) hipFree(c->hist_dev);
     if (c->stamps_dev) (void) hipFree(c->stamps_dev);
     if (c->peek_dev) (void) hipFree(c->peek_dev);
+    for (void *p_ : {(void *) c->box_dev, (void *) c->assoc_ids_dev, (void *) c->cell_start_dev, (void *) c->cell_fill_dev, (void *) c->items_dev,
+                     (void *) c->geom_dev})
+        if (p_) (void) hipFree(p_);
     if (c->book_dev) (void) hipFree(c->book_dev);
     if (c->refcnt_dev) (void) hipFree(c->refcnt_dev);
     if (c->book_host) (void) hipHostFree(c->book_host);
@@ -958,8 +970,10 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
         }
         c->erow[idf[k]] = e_new;
         c->refcnt[e_new]++;
+        c->box_dirty[idf[k]] = 1;
     }
     for (int k = 0; k < n; k++) {
+        c->box_dirty[c->nf + k] = 1;
         c->erow[c->nf + k] = e_new;
         c->refcnt[e_new]++;
         c->live_flag[c->nf + k] = 0;  // a new row's first records go to buffer 0
@@ -2173,7 +2187,38 @@ int slamgpu_observe(slamgpu_ctx *c, const float xtrue[3], float max_range, const
 
 int slamgpu_associate(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4], float gate_reject, float gate_augment,
                       int32_t *labels, int32_t *consensus, float *support) {
+    return slamgpu_associate_ex(c, z, nz, R, gate_reject, gate_augment, SLAMGPU_ASSOC_AUTO, labels, consensus, support, nullptr);
+}
+
+namespace {
+// the update's association is per step: one observation per landmark (the better-supported one wins)
+void assoc_resolve(int nz, std::vector<int32_t> &best, const std::vector<double> &share, int32_t *consensus, float *support) {
+    // (by landmark, not pairwise: 1.3 k observations per step on the 10 000-landmark map)
+    std::map<int32_t, int> owner;
+    for (int q = 0; q < nz; q++) {
+        if (best[q] < 0) continue;
+        auto it = owner.find(best[q]);
+        if (it == owner.end()) {
+            owner[best[q]] = q;
+        } else if (share[q] > share[(size_t) it->second]) {
+            best[(size_t) it->second] = SLAMGPU_ASSOC_DISCARD;
+            it->second = q;
+        } else {
+            best[q] = SLAMGPU_ASSOC_DISCARD;
+        }
+    }
+    for (int q = 0; q < nz; q++) {
+        if (consensus) consensus[q] = best[q];
+        if (support) support[q] = (float) share[q];
+    }
+}
+}  // namespace
+
+int slamgpu_associate_ex(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4], float gate_reject, float gate_augment, int32_t mode,
+                         int32_t *labels, int32_t *consensus, float *support, double stats[4]) {
     if (int rc = check_ctx(c)) return rc;
+    if (mode < SLAMGPU_ASSOC_AUTO || mode > SLAMGPU_ASSOC_GRID) return fail(SLAMGPU_ERR_INVALID, "unknown association mode %d", mode);
+    if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0.0;
     if (nz < 0 || (nz > 0 && !z) || !R) return fail(SLAMGPU_ERR_INVALID, "bad observation list");
     if (nz == 0) return 0;
     static_assert(SLAMGPU_ASSOC_NEW == kAssocNew && SLAMGPU_ASSOC_DISCARD == kAssocDiscard, "public / device labels");
@@ -2182,40 +2227,165 @@ int slamgpu_associate(slamgpu_ctx *c, const float *z, int32_t nz, const float R[
     if (int rc = materialize(c)) return rc;  // plain set: particle k in slot k
     if (int rc = sync_tables(c)) return rc;
     const int N = c->B.n;
+    const bool single = !c->dist && c->cfg.n_particles_global == c->cfg.n_particles && c->pool_used == 0;
+    if (mode == SLAMGPU_ASSOC_GRID && !single)
+        return fail(SLAMGPU_ERR_INVALID, "the association grid needs a single context (shards: SLAMGPU_ASSOC_EXHAUSTIVE)");
+    bool grid = single && (mode == SLAMGPU_ASSOC_GRID || (mode == SLAMGPU_ASSOC_AUTO && c->nf >= 64));
+    const bool want_vote = consensus || support;
     float *z_dev = nullptr;
     int32_t *lab_dev = nullptr;
-    HIP_TRY(hipMalloc((void **) &z_dev, sizeof(float) * 2 * (size_t) nz));
-    hipError_t e = hipMalloc((void **) &lab_dev, sizeof(int32_t) * (size_t) N * nz);
-    if (e != hipSuccess) {
-        (void) hipFree(z_dev);
-        return fail(SLAMGPU_ERR_ALLOC, "hipMalloc: %s", hipGetErrorString(e));
-    }
+    VoteSlot *votes_dev = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int rc = 0;
-    std::vector<int32_t> lab((size_t) N * nz);
-    std::vector<float4> pa;
     auto step = [&](hipError_t er, const char *what) {
-        if (!rc && er != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "%s: %s", what, hipGetErrorString(er));
+        if (!rc && er != hipSuccess) rc = fail(er == hipErrorOutOfMemory ? SLAMGPU_ERR_ALLOC : SLAMGPU_ERR_HIP, "%s: %s", what, hipGetErrorString(er));
     };
+    auto need_labels = [&]() {  // [N][nz] labels on the device: only when the caller wants them, or the vote is taken on the host
+        if (!lab_dev) step(hipMalloc((void **) &lab_dev, sizeof(int32_t) * (size_t) N * nz), "hipMalloc(labels)");
+    };
+    step(hipMalloc((void **) &z_dev, sizeof(float) * 2 * (size_t) nz), "hipMalloc");
     step(hipMemcpyAsync(z_dev, z, sizeof(float) * 2 * (size_t) nz, hipMemcpyHostToDevice, c->stream), "H2D");
     step(hipStreamSynchronize(c->stream), "sync");
-    if (!rc) {
-        c->B.slot = c->slot;
-        {
+    if (stats) {
+        step(hipEventCreate(&ev0), "event");
+        step(hipEventCreate(&ev1), "event");
+    }
+    std::vector<int32_t> best((size_t) nz, SLAMGPU_ASSOC_DISCARD);
+    std::vector<double> share((size_t) nz, 0.0);
+    bool voted = false;
+    c->B.slot = c->slot;
+    if (!rc && grid) {
+        // boxes of the landmarks written since the last call, then geometry + grid, then the pruned scan with the vote
+        const int cap_nf = c->B.cap_nf;
+        if (!c->box_dev) {
+            // (a landmark whose estimates are scattered over the whole region lands in every cell: room for that on small
+            // maps, 64 cells per landmark + 4 Mi entries on large ones; beyond it the exhaustive scan takes over)
+            c->cap_items = (int32_t) std::min<int64_t>((int64_t) cap_nf * kAssocMaxCells * kAssocMaxCells, 64 * (int64_t) cap_nf + (4 << 20));
+            step(hipMalloc((void **) &c->box_dev, sizeof(LmkBox) * (size_t) cap_nf), "hipMalloc");
+            step(hipMalloc((void **) &c->assoc_ids_dev, sizeof(int32_t) * (size_t) cap_nf), "hipMalloc");
+            step(hipMalloc((void **) &c->cell_start_dev, sizeof(int32_t) * (kAssocMaxCells * kAssocMaxCells + 1)), "hipMalloc");
+            step(hipMalloc((void **) &c->cell_fill_dev, sizeof(int32_t) * (kAssocMaxCells * kAssocMaxCells)), "hipMalloc");
+            step(hipMalloc((void **) &c->items_dev, sizeof(int32_t) * (size_t) c->cap_items), "hipMalloc");
+            step(hipMalloc((void **) &c->geom_dev, sizeof(AssocGeom)), "hipMalloc");
+        }
+        std::vector<int32_t> ids;
+        for (int j = 0; j < c->nf; j++)
+            if (c->box_dirty[j]) ids.push_back(j);
+        if (!rc && !ids.empty()) {
+            step(hipMemcpyAsync(c->assoc_ids_dev, ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice, c->stream), "H2D");
+            step(hipStreamSynchronize(c->stream), "sync");  // (pageable source)
+        }
+        if (labels) need_labels();
+        if (want_vote) {
+            step(hipMalloc((void **) &votes_dev, sizeof(VoteSlot) * kVoteSlots * (size_t) nz), "hipMalloc");
+            // key = kVoteEmpty (0x80000000), weight = -0.0f (the same bits): -0.0 + w = w
+            if (!rc) step(hipMemsetD32Async((hipDeviceptr_t) votes_dev, (int) 0x80000000, 2 * kVoteSlots * (size_t) nz, c->stream), "memset");
+        }
+        AssocGridArgs G{};
+        G.box = c->box_dev;
+        G.geom = c->geom_dev;
+        G.cell_start = c->cell_start_dev;
+        G.cell_fill = c->cell_fill_dev;
+        G.items = c->items_dev;
+        G.cap_items = c->cap_items;
+        G.nf = c->nf;
+        G.nz = nz;
+        G.z = z_dev;
+        G.r00 = R[0];
+        G.r11 = R[3];
+        G.G = std::max(gate_reject, gate_augment) * 1.001f;
+        G.votes = votes_dev;
+        G.logw = c->cfg.log_weights;
+        AssocGeom hg{};
+        if (!rc) {
+            if (ev0) step(hipEventRecord(ev0, c->stream), "event");
             Timed t(c, "associate");
-            c->k->associate(c->stream, c->B, c->nf, z_dev, nz, R, gate_reject, gate_augment, lab_dev);
+            if (!ids.empty()) c->k->lmk_box(c->stream, c->B, c->assoc_ids_dev, (int) ids.size(), c->box_dev);
+            c->k->assoc_grid(c->stream, c->B, G);
+            c->k->associate_grid(c->stream, c->B, G, R, gate_reject, gate_augment, lab_dev);
         }
         step(hipGetLastError(), "launch");
-        step(hipMemcpyAsync(lab.data(), lab_dev, sizeof(int32_t) * lab.size(), hipMemcpyDeviceToHost, c->stream), "D2H");
+        if (ev1) step(hipEventRecord(ev1, c->stream), "event");
+        step(hipMemcpyAsync(&hg, c->geom_dev, sizeof hg, hipMemcpyDeviceToHost, c->stream), "D2H");
         step(hipStreamSynchronize(c->stream), "sync");
+        if (!rc) {
+            for (int j : ids) c->box_dirty[j] = 0;
+            if (hg.overflow & 1) {
+                if (mode == SLAMGPU_ASSOC_GRID) rc = fail(SLAMGPU_ERR_CAPACITY, "association grid: %d entries exceed the buffer of %d", hg.total, c->cap_items);
+                grid = false;  // (auto: the exhaustive scan instead)
+            } else {
+                if (stats) {
+                    stats[0] = (double) hg.pairs;
+                    stats[1] = (double) hg.total;
+                    stats[3] = 1.0;
+                }
+                if (want_vote && !(hg.overflow & 2)) {
+                    // the vote was taken on the device: one small table per observation comes back
+                    std::vector<VoteSlot> tab((size_t) kVoteSlots * nz);
+                    step(hipMemcpy(tab.data(), votes_dev, sizeof(VoteSlot) * tab.size(), hipMemcpyDeviceToHost), "D2H");
+                    for (int q = 0; q < nz && !rc; q++) {
+                        double wsum = 0, bw = -1;
+                        int32_t bk = SLAMGPU_ASSOC_DISCARD;
+                        for (int p = 0; p < kVoteSlots; p++) {
+                            const VoteSlot &v = tab[(size_t) q * kVoteSlots + p];
+                            if (v.key == kVoteEmpty) continue;
+                            wsum += (double) v.w;
+                            // (the largest share; ties go to the smaller label, as the ordered map of the host vote does)
+                            if ((double) v.w > bw || ((double) v.w == bw && v.key < bk)) {
+                                bw = (double) v.w;
+                                bk = v.key;
+                            }
+                        }
+                        best[(size_t) q] = bk;
+                        share[(size_t) q] = wsum > 0 ? bw / wsum : 0.0;
+                    }
+                    voted = true;
+                } else if (want_vote) {
+                    // (more than 32 distinct labels for one observation: take the vote on the host from the full label array)
+                    need_labels();
+                    if (!rc) {
+                        G.votes = nullptr;
+                        c->k->associate_grid(c->stream, c->B, G, R, gate_reject, gate_augment, lab_dev);
+                        step(hipGetLastError(), "launch");
+                    }
+                }
+            }
+        }
     }
-    (void) hipFree(z_dev);
-    (void) hipFree(lab_dev);
+    if (!rc && !grid) {
+        need_labels();
+        if (!rc) {
+            if (ev0) step(hipEventRecord(ev0, c->stream), "event");
+            {
+                Timed t(c, "associate");
+                c->k->associate(c->stream, c->B, c->nf, z_dev, nz, R, gate_reject, gate_augment, lab_dev);
+            }
+            if (ev1) step(hipEventRecord(ev1, c->stream), "event");
+            if (stats) stats[0] = (double) N * (double) nz * (double) c->nf;
+            step(hipGetLastError(), "launch");
+        }
+    }
+    std::vector<int32_t> lab;
+    if (!rc && lab_dev) {
+        lab.resize((size_t) N * nz);
+        step(hipMemcpyAsync(lab.data(), lab_dev, sizeof(int32_t) * lab.size(), hipMemcpyDeviceToHost, c->stream), "D2H");
+    }
+    step(hipStreamSynchronize(c->stream), "sync");
+    if (!rc && stats && ev0 && ev1) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) stats[2] = ms;
+    }
+    if (ev0) (void) hipEventDestroy(ev0);
+    if (ev1) (void) hipEventDestroy(ev1);
+    if (z_dev) (void) hipFree(z_dev);
+    if (lab_dev) (void) hipFree(lab_dev);
+    if (votes_dev) (void) hipFree(votes_dev);
     if (rc) return rc;
     if (labels) memcpy(labels, lab.data(), sizeof(int32_t) * lab.size());
-    if (consensus || support) {
+    if (want_vote && !voted) {
         if (int rc2 = read_ctrl(c, true)) return rc2;
         const int cur = c->ctrl_host->live[c->slot];
-        pa.resize((size_t) N);
+        std::vector<float4> pa((size_t) N);
         HIP_TRY(hipMemcpy(pa.data(), c->B.poseA[cur], sizeof(float4) * (size_t) N, hipMemcpyDeviceToHost));
         // weights (log-weight contexts: exp(l - max l)), normalised
         std::vector<double> w((size_t) N);
@@ -2225,8 +2395,6 @@ int slamgpu_associate(slamgpu_ctx *c, const float *z, int32_t nz, const float R[
             w[i] = c->cfg.log_weights ? exp((double) pa[i].w - wmax) : (double) pa[i].w;
             wsum += w[i];
         }
-        std::vector<int32_t> best((size_t) nz);
-        std::vector<double> share((size_t) nz);
         for (int q = 0; q < nz; q++) {
             std::map<int32_t, double> votes;
             for (int i = 0; i < N; i++) votes[lab[(size_t) i * nz + q]] += w[i];
@@ -2237,21 +2405,11 @@ int slamgpu_associate(slamgpu_ctx *c, const float *z, int32_t nz, const float R[
                     bw = kv.second;
                     b = kv.first;
                 }
-            best[q] = b;
-            share[q] = wsum > 0 ? bw / wsum : 0.0;
-        }
-        // the update's association is per step: one observation per landmark (the better-supported one wins)
-        for (int q = 0; q < nz; q++)
-            for (int p = 0; p < q; p++)
-                if (best[q] >= 0 && best[q] == best[p]) {
-                    if (share[q] > share[p]) best[p] = SLAMGPU_ASSOC_DISCARD;
-                    else best[q] = SLAMGPU_ASSOC_DISCARD;
-                }
-        for (int q = 0; q < nz; q++) {
-            if (consensus) consensus[q] = best[q];
-            if (support) support[q] = (float) share[q];
+            best[(size_t) q] = b;
+            share[(size_t) q] = wsum > 0 ? bw / wsum : 0.0;
         }
     }
+    if (want_vote) assoc_resolve(nz, best, share, consensus, support);
     return 0;
 }
 
@@ -2480,6 +2638,7 @@ int slamgpu_upload(slamgpu_ctx *c, int32_t nf, const float *xv, const float *Pv9
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->nf = nf;
     rows_reset(c, nf);
+    std::fill(c->box_dirty.begin(), c->box_dirty.end(), 1);
     c->est_fresh = false;
     c->shard_est_fresh = false;
     return 0;

@@ -69,3 +69,65 @@ def test_device_association_matches_the_reference_decisions(kat_assoc, math_mode
         pos = cons[cons >= 0]
         assert len(set(pos.tolist())) == len(pos)  # one observation per landmark
     assert checked >= 1600 and skipped <= 40, (checked, skipped)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+def test_grid_prefilter_never_changes_a_reference_decision(kat_assoc, math_mode):
+    """slamgpu_associate_ex, SLAMGPU_ASSOC_GRID against SLAMGPU_ASSOC_EXHAUSTIVE on the reference's decision vectors: the
+    prefilter skips a landmark only where a bound that holds for every particle rules both gates out, so the label arrays must
+    be identical -- every group, every particle, every observation, borderline cases included."""
+    import slam_amd as sg
+    g1, g2 = (float(x) for x in kat_assoc["gates"])
+    R = np.array([[0.1 ** 2, 0], [0, 0.017453292519943 ** 2]], f32)
+    same = 0
+    for g in range(int(kat_assoc["n_groups"])):
+        xv, xf, Pf, z = (kat_assoc["g%d_%s" % (g, k)] for k in ("xv", "xf", "Pf", "z"))
+        N, nf = xv.shape[0], xf.shape[1]
+        s = sg.SlamGpu(N, 32, method=2, rng_mode=sg.RNG_PHILOX, math_mode=math_mode)
+        s.upload(dict(nf=nf, xv=xv, Pv=np.zeros((N, 3, 3), f32), w=np.full(N, 1.0 / N, f32), xf=xf, Pf=Pf))
+        a, ca, _ = s.associate(z, R, g1, g2, mode=sg.capi.ASSOC_EXHAUSTIVE)
+        b, cb, _, st = s.associate(z, R, g1, g2, mode=sg.capi.ASSOC_GRID, want_stats=True)
+        s.close()
+        assert st["grid"] and np.array_equal(a, b) and np.array_equal(ca, cb), g
+        same += a.size
+    assert same == 10 * 16 * 11
+
+
+@pytest.mark.gpu
+def test_grid_prefilter_on_a_running_filter(tmp_path):
+    """The same identity on the state of a running filter, where it is meant to pay: 4 096 particles on a synthetic
+    1 000-landmark map (MAX_RANGE 30), the step's real observations plus shifted ones (new-landmark and discard outcomes);
+    the grid evaluates a small fraction of the N * nz * Nf triples of the exhaustive scan."""
+    import slam_amd as sg
+    from conftest import DATA, sim_args
+    from slam_amd import host
+    lm = host.synthetic_landmarks(777, 1000, -130, 100, -100, 90)
+    h0 = host.HostSim(sim_args("example_webmap", "FASTSLAM2", 100, 7))
+    _, wp = h0.map()
+    h0.close()
+    mp = str(tmp_path / "syn1000.mat")
+    host.write_map(mp, lm, wp)
+    open(str(tmp_path / "syn1000.ini"), "w").write(open(os.path.join(DATA, "example_webmap.ini")).read().replace(
+        "MAX_RANGE           = 60.0", "MAX_RANGE           = 30.0"))
+    N = 4096
+    tape = host.make_tape(["-m", mp, "-method", "FASTSLAM2", "-SWITCH_SEED_RANDOM", 3], max_obs=150)
+    s = sg.SlamGpu(N, tape["nlm"], method=2, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=9, math_mode=1)
+    R = tape["R"]
+    rng = np.random.default_rng(5)
+    checked = kinds = 0
+    for i, st in enumerate(tape["steps"]):
+        if i % 25 == 24:
+            z = np.concatenate([st["zf"], st["zn"]]).reshape(-1, 2)
+            z2 = z.copy()
+            z2[:, 0] += rng.normal(0, 0.4, z.shape[0]).astype(f32)   # some of these fall between the gates or outside both
+            zz = np.concatenate([z, z2])
+            a, ca, _, sa = s.associate(zz, R, 4.0, 25.0, mode=sg.capi.ASSOC_EXHAUSTIVE, want_stats=True)
+            b, cb, _, sb = s.associate(zz, R, 4.0, 25.0, mode=sg.capi.ASSOC_GRID, want_stats=True)
+            assert sb["grid"] and np.array_equal(a, b) and np.array_equal(ca, cb), i
+            assert sb["triples"] < 0.1 * sa["triples"], (i, sb, sa)
+            checked += a.size
+            kinds |= (1 if (a >= 0).any() else 0) | (2 if (a == -1).any() else 0) | (4 if (a == -2).any() else 0)
+        s.step(np.array(st["controls"], f32).reshape(-1, 3), tape["Q"], float(tape["dt"]), st["zf"], st["idf"], st["zn"], R)
+    s.close()
+    assert checked > 1e6 and kinds == 7
