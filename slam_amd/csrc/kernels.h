@@ -220,6 +220,10 @@ struct UpdateArgs {
     int32_t n_rows;          // device packets: live rows a pending gather composes (the packet's rows), by copy roles
     int32_t rows_per_role;   // ... of this many rows each.  (Compact contexts: the compute threads copy all their chunks.)
     int32_t live_chunks;     // compact contexts: chunks [0, live_chunks) hold every row in use (rows are opened lowest-first)
+    int32_t n_cons;          // compact contexts: landmarks CONSOLIDATED by this launch: idf[m + c] / row[m + c], c < n_cons, name landmarks
+                             // that are not observed but whose record is rewritten, unchanged, into the particle's own slot of the
+                             // row's other buffer -- they join the row this update opens, and the stale rows they leave stop costing
+                             // 4 bytes per particle and resample (slamgpu.cpp: do_update)
     int32_t all_fresh;       // compact contexts: every staged re-observed landmark carries kRowFreshBit: their records are
                              // requested together with the pose, one dependent round trip earlier
     // Inline planning: the resampling stage of the PREVIOUS update (Neff, decision, ancestors, pose-estimate partials)

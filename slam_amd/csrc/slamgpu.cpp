@@ -86,6 +86,7 @@ const Rccl *rccl() {
     } while (0)
 
 constexpr int kRing = 64;       // big-packet staging slots
+constexpr int kConsolidateAbove = 6;  // compact contexts: genealogy rows alive before stale rows are consolidated (3..8 measure alike; profiles/consolidate_sweep_r03.txt)
 constexpr int kHistCap = 4096;  // asynchronous pose-estimate history entries
 
 struct EventPair {
@@ -159,6 +160,8 @@ struct slamgpu_ctx {
         double *hist = nullptr;   // history slot its estimate belongs to (or null)
     };
     bool scan_ready = false;      // scan_kernel ran on the last update's block totals (large contexts)
+    bool consolidate = true;      // row consolidation of compact contexts (do_update); SLAMGPU_NO_CONSOLIDATE=1 turns it off
+    int consolidate_above = kConsolidateAbove;  // (SLAMGPU_CONSOLIDATE_ABOVE: diagnostic)
     int scan_min_blocks = 1024;   // contexts with more blocks of 256 particles than this use scan_kernel (262 144 particles)
     // Genealogy bookkeeping (kernels.h: gen).  The association is global, so the host knows which genealogy row every
     // landmark uses: a step that writes landmarks opens a new row for them; a row whose last landmark moved on is recycled.
@@ -608,6 +611,8 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     if (c->cfg.n_particles_global <= 0) c->cfg.n_particles_global = c->cfg.n_particles;
     c->k = cfg->math_mode == SLAMGPU_MATH_FAST ? kernels_fast() : kernels_strict();
     if (const char *e = getenv("SLAMGPU_SCAN_MIN_BLOCKS")) c->scan_min_blocks = atoi(e);  // diagnostic
+    c->consolidate = getenv("SLAMGPU_NO_CONSOLIDATE") == nullptr;                          // diagnostic / tests
+    if (const char *e = getenv("SLAMGPU_CONSOLIDATE_ABOVE")) c->consolidate_above = atoi(e);
     const bool want_stamps = getenv("SLAMGPU_STAMPS") != nullptr;                         // diagnostic
     const int cap_nf = cfg->max_landmarks > 0 ? cfg->max_landmarks : 1;
     c->B.n = n;
@@ -953,11 +958,35 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
         if (c->seen_step[idf[k]] == c->obs_step) return fail(SLAMGPU_ERR_INVALID, "landmark %d re-observed twice in one update", idf[k]);
         c->seen_step[idf[k]] = c->obs_step;
     }
+    // Row consolidation (compact contexts): when more than kConsolidateAbove genealogy rows are alive, the landmarks this
+    // update does NOT observe are rewritten by the launch, unchanged, into the particles' own slots and join the row it opens
+    // (the kernel treats them like re-observed landmarks with a no-op update: UpdateArgs::n_cons).  A landmark goes out of
+    // view every ~60 steps on example_webmap, so after one consolidation the map lives in one or two rows for hundreds of
+    // steps, and a resample composes one 16-byte chunk per particle instead of eight.  Values never change: results are bit
+    // for bit those of a run without it (SLAMGPU_NO_CONSOLIDATE=1, tests/test_gpu_parity.py).
+    std::vector<int32_t> cons;
+    if (c->B.compact && !sharded && !c->dist && c->consolidate && (int) c->live_rows.size() > c->consolidate_above) {
+        for (int j = 0; j < c->nf && m + (int) cons.size() < kSmallObs; j++)
+            if (c->seen_step[j] != c->obs_step) cons.push_back(j);
+        // (only worth a launch's while if it empties rows: every row but the one opened now, or as many landmarks as fit)
+    }
+    const int nc = (int) cons.size();
     int e_new = -1;
-    std::vector<int32_t> rows_of((size_t) m), dropped;
-    if (m + n > 0) {
+    std::vector<int32_t> rows_of((size_t) m + nc), dropped;
+    if (m + n + nc > 0) {
         e_new = c->free_rows.back();
         c->free_rows.pop_back();
+    }
+    for (int q = 0; q < nc; q++) {
+        const int j = cons[(size_t) q], r = c->erow[j];
+        rows_of[(size_t) m + q] = r | (c->live_flag[j] ? kRowLiveBit : 0) | (r == c->fresh_row ? kRowFreshBit : 0);
+        c->live_flag[j] ^= 1;
+        if (--c->refcnt[r] == 0) {
+            rows_remove_live(c, r);
+            dropped.push_back(r);
+        }
+        c->erow[j] = e_new;
+        c->refcnt[e_new]++;
     }
     for (int k = 0; k < m; k++) {
         const int r = c->erow[idf[k]];
@@ -1006,6 +1035,11 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
             U.small.zf[2 * k] = zf[2 * k];
             U.small.zf[2 * k + 1] = zf[2 * k + 1];
         }
+        for (int q = 0; q < nc; q++) {  // the consolidated landmarks ride behind the re-observed ones
+            U.small.idf[m + q] = cons[(size_t) q];
+            U.small.row[m + q] = rows_of[(size_t) m + q];
+        }
+        U.n_cons = nc;
         for (int k = 0; k < n; k++) {
             U.small.zn[2 * k] = zn[2 * k];
             U.small.zn[2 * k + 1] = zn[2 * k + 1];

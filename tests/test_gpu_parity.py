@@ -650,3 +650,38 @@ def test_queued_predicts_vs_oracle_sequence(sg, oracle, math_mode):
     s.close()
     assert np.abs(got["xv"] - exp["xv"]).max() <= 5e-5, np.abs(got["xv"] - exp["xv"]).max()
     assert close_cov(got["Pv"], sym(exp["Pv"]), 2e-4)
+
+
+def test_row_consolidation_changes_no_bit(sg, monkeypatch):
+    """Compact contexts consolidate stale genealogy rows (slamgpu.cpp: do_update: landmarks out of view are rewritten,
+    unchanged, into the particles' own slots by an update launch and join the row it opens).  Records move, values do not:
+    a whole example_webmap run must be bit for bit the run without consolidation, history included, both methods."""
+    import os
+    from slam_amd import host
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    N = 2048
+    for method, mid in (("FASTSLAM2", 2), ("FASTSLAM1", 1)):
+        tape = host.make_tape(["-m", os.path.join(root, "data", "example_webmap.mat"), "-method", method, "-NPARTICLES", N,
+                               "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", 4])
+        out = []
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("SLAMGPU_NO_CONSOLIDATE", "1")
+            else:
+                monkeypatch.delenv("SLAMGPU_NO_CONSOLIDATE", raising=False)
+            s = sg.SlamGpu(N, tape["nlm"], method=mid, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=6, math_mode=1)
+            for i, st in enumerate(tape["steps"]):
+                s.step(np.array(st["controls"], f32).reshape(-1, 3), tape["Q"], float(tape["dt"]), st["zf"], st["idf"], st["zn"], tape["R"])
+                if i == 700:
+                    mid_state = s.peek()  # (through the genealogy, mid-run: consolidated or not, the same view)
+            h = s.history_fetch()
+            out.append((s.download(), h, mid_state))
+            s.close()
+        monkeypatch.delenv("SLAMGPU_NO_CONSOLIDATE", raising=False)
+        (a, ha, ma), (b, hb, mb) = out
+        assert len(ha[0]) == len(tape["steps"]) and 500 < ha[2].sum()
+        for x, y in zip(ha, hb):
+            assert np.array_equal(x, y), method
+        for key in ("xv", "Pv", "w", "xf", "Pf"):
+            assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), (method, key)
+            assert np.array_equal(ma[key].view(np.uint32), mb[key].view(np.uint32)), (method, key, "mid-run")
