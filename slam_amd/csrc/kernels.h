@@ -158,8 +158,43 @@ struct SmallObs {           // compact contexts: the packet travels in the kerne
     int32_t row[kSmallObs];          // genealogy row (| live record buffer << 30) of each re-observed landmark before this update
     float zf[2 * kSmallObs];
     float zn[2 * kSmallObs];
+    int32_t head[8];                 // front-end launches (FrontArgs): the header the launch worked out for itself (kFrontHead*)
     uint32_t magic, pad;             // kSmallMagic: the update kernel copies this struct out of its kernel-argument segment
                                      // with vector loads at a computed offset and refuses to run on anything else
+};
+enum { kFrontHeadM = 0, kFrontHeadN, kFrontHeadNf, kFrontHeadENew, kFrontHeadChunks, kFrontHeadFresh, kFrontHeadCons, kFrontHeadStatus };
+
+// Compact contexts, slamgpu_step_observe: the observation front end runs INSIDE the update launch.  The maps of compact
+// contexts have at most 39 landmarks: one wave holds one landmark of the map per lane, so get_observations (core.cpp:185-273,
+// :438-449), dataAssociationKnown (core.cpp:91-120) and the genealogy bookkeeping of slamgpu.cpp: do_update are a few
+// ballots.  EVERY block's first wave works the packet out for itself from the state the previous launch left (a pure
+// function of that state and these arguments: no block waits for another, no second stream, no event) and parks it in the
+// LDS words a host-made packet would occupy; block 0 also stores the successor state -- into the OTHER copy, which no block
+// of this launch reads -- and the packet, for slamgpu_observe_fetch.
+struct FrontLm {       // one landmark of the map (its coordinates ride in the kernel arguments: UpdateArgs::small.zn)
+    int32_t idf;       // feature index (dataAssociationTable), -1: never seen
+    int32_t row;       // genealogy row | live record buffer << 30 (kRowLiveBit)
+};
+struct FrontHdr {
+    int32_t nf, fresh_row, status, pad;
+};
+constexpr int kFrontLanes = 64;
+struct FrontState {    // what one launch leaves for the next: two copies, read / written alternately
+    FrontHdr hdr;
+    FrontLm lm[kFrontLanes];
+};
+struct ObserveOut;
+struct FrontArgs {
+    int32_t on;                 // 0: host-made packet (UpdateArgs::small)
+    int32_t nlm, cap_nf, noise; // noise: 0 none, 1 tape (UpdateArgs::small.zf[c] / zf[kSmallObs + c]: one normal pair per visible landmark), 2 Philox
+                                // (the map: UpdateArgs::small.zn[t] / zn[kSmallObs + t] = x / y of landmark t)
+    float x, y, phi, max_range, sr, sb;
+    uint32_t k0, k1, step;
+    int32_t cons_above;         // consolidate stale rows when more than this many are alive (< 0: never)
+    const FrontState *state_in; // (also the kernel's leading parameter h_front: requested before this struct has arrived)
+    FrontState *state_out;
+    ObserveOut *out;            // observe_kernel's output block (z, vis, ...), written by block 0
+    ObsPacket *pkt;             // fixed-layout copy of the packet (cap = nlm), written by block 0
 };
 constexpr uint32_t kSmallMagic = 0x534c414du;
 constexpr int kSmallWords = (int) (sizeof(SmallObs) / 4);
@@ -214,6 +249,7 @@ struct UpdateArgs {
     int32_t dev_packet;      // 1: `big` was written by the device front end (observe_book_kernel): m, n, nf, e_new, n_rows and the
                              // copy-role geometry are read from its header by the kernel; the fields of this struct hold upper bounds
     SmallObs small;
+    FrontArgs front;
     int32_t lazy;            // 1: single-context pipeline (honour Ctrl.pend, launch the copy + finalise blocks)
     int32_t copy_lo, copy_hi;  // copy roles (particle tile x kRowsPerRole genealogy rows) of a pending lazy gather this launch carries
     int32_t e_new;           // genealogy row this update opens for the landmarks it writes (-1: it writes none)

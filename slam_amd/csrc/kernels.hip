@@ -677,6 +677,204 @@ SLAM_DEV PacketView packet_view(const UpdateArgs &U) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Observation front end of a compact context, inside the update launch (kernels.h: FrontArgs).  Called by the first wave of a
+// block; lane t owns landmark t of the map (state `s`, read from the copy the previous launch left).  Same arithmetic, same
+// order of the visible landmarks and of the new features as observe_book_kernel (and so as the reference's
+// get_observations + add_observation_noise + dataAssociationKnown: core.cpp:185-273, :438-449, :91-120); the genealogy
+// bookkeeping is the host's for a packet of its own (slamgpu.cpp: do_update), row consolidation included.
+// ---------------------------------------------------------------------------------------------------
+// the two normals of one landmark's sensor noise (device draws): Box-Muller on one Philox block; the fast build takes the
+// hardware transcendentals (the precise sinf / cosf / logf cost the launch 1.4 us on its critical path)
+SLAM_DEV void sensor_normals(U4 r, float &g0, float &g1) {
+    float g2;
+#ifdef SLAM_FAST_MATH
+    box_muller3_fast(r, g0, g1, g2);
+#else
+    box_muller3(r, g0, g1, g2);
+#endif
+}
+
+// Two halves, so that the arithmetic (double-precision sqrt / atan2, the Philox draw) runs while the state is still in flight:
+// front_observe needs the kernel arguments only, front_book the state.
+struct FrontObs {
+    bool v;          // this lane's landmark is visible
+    int c, nz;       // its rank among the visible ones; how many there are
+    float z0, z1;    // range, bearing (noise applied)
+};
+// A single wave runs all of this as one dependent chain of ~500 instructions (1.4 us at the head of the launch, measured), so
+// the block's four waves share it: wave 0 the geometry (double-precision sqrt / atan2: needs the map), wave 1 the device
+// draw of the sensor noise, wave 2 the heading's sine and cosine (both need the kernel arguments only), wave 3 clears the
+// packet's LDS words; all of it while the loads of the head are in flight; one barrier; then wave 0 alone: ballots and the book.
+struct FrontGeom {
+    float dx, dy, z0, z1;
+    double d2;
+};
+SLAM_DEV FrontGeom front_geometry(const FrontArgs &F, float lx, float ly) {
+    FrontGeom g;
+    g.dx = lx - F.x;
+    g.dy = ly - F.y;
+    g.d2 = (double) g.dx * (double) g.dx + (double) g.dy * (double) g.dy;
+    g.z0 = (float) sqrt(g.d2);
+    g.z1 = (float) atan2((double) g.dy, (double) g.dx) - F.phi;
+    return g;
+}
+SLAM_DEV void front_draw(const FrontArgs &F, int t, float *aux) {  // aux[t], aux[kWave + t]: the two normals of landmark t
+    float g0 = 0.f, g1 = 0.f;
+    if (F.noise == 2) {
+        U4 r = philox4x32((uint32_t) t, F.step, 3u, 0u, F.k0, F.k1);
+        sensor_normals(r, g0, g1);
+    }
+    aux[t] = g0;
+    aux[kWave + t] = g1;
+}
+SLAM_DEV FrontObs front_observe(const FrontArgs &F, const FrontGeom g, const float *aux, const __attribute__((address_space(4))) float *tape) {
+    const int t = (int) threadIdx.x;  // < kWave
+    const unsigned long long lt = (1ull << t) - 1ull;
+    const float cph = aux[2 * kWave], sph = aux[2 * kWave + 1];
+    FrontObs o;
+    o.v = t < F.nlm && (fabsf(g.dx) < F.max_range) && (fabsf(g.dy) < F.max_range) && ((g.dx * cph + g.dy * sph) > 0.0f) &&
+          (g.d2 < (double) F.max_range * (double) F.max_range);
+    const unsigned long long V = __ballot(o.v);
+    o.c = __popcll(V & lt);
+    o.nz = __popcll(V);
+    o.z0 = g.z0;
+    o.z1 = g.z1;
+    if (o.v && F.noise) {  // sensor noise (core.cpp:438-449)
+        float g0 = aux[t], g1 = aux[kWave + t];
+        if (F.noise == 1) {
+            g0 = tape[o.c];
+            g1 = tape[kSmallObs + o.c];
+        }
+        o.z0 = o.z0 + g0 * F.sr;
+        o.z1 = o.z1 + g1 * F.sb;
+    }
+    return o;
+}
+
+// sets of the genealogy rows (< 64) named by the lanes with `a` / with `b`, through four LDS words: one atomic round trip
+// instead of two six-level shuffle reductions
+SLAM_DEV void wave_row_sets(bool a, bool b, int r, uint32_t *sh4, unsigned long long &sa, unsigned long long &sb) {
+    if (threadIdx.x < 4) sh4[threadIdx.x] = 0u;
+    if (a) atomicOr(&sh4[r >> 5], 1u << (r & 31));
+    if (b) atomicOr(&sh4[2 + (r >> 5)], 1u << (r & 31));
+    __builtin_amdgcn_wave_barrier();
+    const volatile uint32_t *v = sh4;
+    const uint32_t a0 = v[0], a1 = v[1], b0 = v[2], b1 = v[3];
+    sa = ((unsigned long long) a1 << 32) | a0;
+    sb = ((unsigned long long) b1 << 32) | b0;
+}
+
+SLAM_DEV void front_book(const FrontArgs &F, const FrontObs ob, const FrontLm s, const FrontHdr hd, int32_t *pk, uint32_t *sh4, bool writer) {
+    const int t = (int) threadIdx.x;  // < kWave
+    const unsigned long long lt = (1ull << t) - 1ull;
+    const bool has_lm = t < F.nlm, v = ob.v;
+    const int nf0 = hd.nf, fresh = hd.fresh_row, C = F.nlm, c = ob.c;
+    const float z0 = ob.z0, z1 = ob.z1;
+    // dataAssociationKnown: split by the table, in order; new landmarks get indices nf0, nf0 + 1, ... (beyond the
+    // context's capacity: dropped and flagged)
+    const bool has = has_lm && s.idf >= 0;
+    const bool known = v && has, unseen = v && !has;
+    const unsigned long long Mk = __ballot(known), Mn = __ballot(unseen);
+    const int m = __popcll(Mk), room = F.cap_nf - nf0;
+    int n = __popcll(Mn);
+    const int dropped = n > room ? n - room : 0;
+    n -= dropped;
+    const int ko = __popcll(Mk & lt), kn = __popcll(Mn & lt);
+    const bool added = unseen && kn < room;
+    // genealogy rows: in use before; consolidation of the landmarks not observed; the row this update opens (the lowest
+    // unused one); in use after, without it
+    const int r = s.row & kRowMask;
+    // (`rest`: rows of the landmarks not re-observed.  With a consolidation every one of those moves too -- a compact context
+    // has fewer landmarks than a packet has entries -- and no old row stays in use; should that ever not hold, a second pass)
+    unsigned long long before, rest;
+    wave_row_sets(has, has && !known, r, sh4, before, rest);
+    const bool cons_on = F.cons_above >= 0 && __popcll(before) > F.cons_above;
+    const bool cand = cons_on && has && !known;
+    const unsigned long long Mc = __ballot(cand);
+    const int qc = __popcll(Mc & lt);
+    const bool is_cons = cand && (m + qc < kSmallObs);
+    const int nc = min(__popcll(Mc), max(kSmallObs - m, 0));
+    const bool any = m + n + nc > 0;
+    const int e_new = any ? (int) __ffsll(~before) - 1 : -1;
+    const bool moved = known || is_cons;
+    unsigned long long after = cons_on ? 0ull : rest;
+    if (cons_on && __popcll(Mc) > nc) {
+        unsigned long long dummy;
+        wave_row_sets(has && !moved, false, r, sh4, after, dummy);
+    }
+    const int top = max(e_new, after ? 63 - (int) __clzll(after) : -1);
+    const int word = s.row | (r == fresh ? kRowFreshBit : 0);
+    const unsigned long long stale = __ballot(known && ko < 8 && !(word & kRowFreshBit));
+    int32_t *p_idf = pk + offsetof(SmallObs, idf) / 4, *p_row = pk + offsetof(SmallObs, row) / 4;
+    float *p_zf = reinterpret_cast<float *>(pk + offsetof(SmallObs, zf) / 4), *p_zn = reinterpret_cast<float *>(pk + offsetof(SmallObs, zn) / 4);
+    if (known) {
+        p_idf[ko] = s.idf;
+        p_row[ko] = word;
+        p_zf[2 * ko] = z0;
+        p_zf[2 * ko + 1] = z1;
+    }
+    if (is_cons) {
+        p_idf[m + qc] = s.idf;
+        p_row[m + qc] = word;
+    }
+    if (added) {
+        p_zn[2 * kn] = z0;
+        p_zn[2 * kn + 1] = z1;
+    }
+    const int status = dropped ? kStatusCapacity : 0;
+    if (t == 0) {
+        int32_t *h = pk + offsetof(SmallObs, head) / 4;
+        h[kFrontHeadM] = m;
+        h[kFrontHeadN] = n;
+        h[kFrontHeadNf] = nf0;
+        h[kFrontHeadENew] = e_new;
+        h[kFrontHeadChunks] = (top >> 2) + 1;  // (top = -1: 0 chunks)
+        h[kFrontHeadFresh] = stale == 0 ? 1 : 0;
+        h[kFrontHeadCons] = nc;
+        h[kFrontHeadStatus] = status;
+        pk[offsetof(SmallObs, magic) / 4] = (int32_t) kSmallMagic;
+    }
+    if (writer) {
+        // the successor state: moved landmarks live in the row opened now, their records in the row's other buffer; a new
+        // landmark's first records go to buffer 0
+        FrontLm o = s;
+        if (moved) o.row = e_new | ((s.row & kRowLiveBit) ^ kRowLiveBit);
+        if (added) {
+            o.idf = nf0 + kn;
+            o.row = e_new;
+        }
+        if (has_lm) F.state_out->lm[t] = o;
+        if (t == 0) F.state_out->hdr = FrontHdr{nf0 + n, e_new, hd.status | status, 0};
+        // ... and the observation itself, for slamgpu_observe_fetch (observe_kernel's block + a fixed-layout packet)
+        float *oz = reinterpret_cast<float *>(F.out + 1);
+        int32_t *ovis = reinterpret_cast<int32_t *>(oz + 2 * (size_t) C);
+        ObsPacket *P = F.pkt;
+        int32_t *base = reinterpret_cast<int32_t *>(P + 1);
+        float *fzf = reinterpret_cast<float *>(base + C), *fzn = fzf + 2 * (size_t) C;
+        int32_t *frow = reinterpret_cast<int32_t *>(fzn + 2 * (size_t) C);
+        if (v) {
+            oz[2 * c] = z0;
+            oz[2 * c + 1] = z1;
+            ovis[c] = t;
+        }
+        if (known) {
+            base[ko] = s.idf;
+            fzf[2 * ko] = z0;
+            fzf[2 * ko + 1] = z1;
+            frow[ko] = word;
+        }
+        if (added) {
+            fzn[2 * kn] = z0;
+            fzn[2 * kn + 1] = z1;
+        }
+        if (t == 0) {
+            *F.out = ObserveOut{ob.nz, m, n, nf0 + n};
+            *P = ObsPacket{m, n, nf0, (int32_t) __popcll(after), e_new, status, C, 0};
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // K1: [pending predicts] + per-particle observation update.  FastSLAM2::update body
 // (fastslam2.cpp:26-45): sampleProposal (:290-368) + likelihoodGivenXv (:370-400) fused with
 // featureUpdate (core.cpp:132-175; both evaluate their Jacobians at the same sampled pose) + addFeature
@@ -720,10 +918,10 @@ __host__ __device__ inline int staging_slots(int method, bool big, int m) {
 // stood between kernel entry and the first vector load before; 16.7 -> 16.05 us per step at 10^5 particles).
 // Tried on top and measured as no better (gpurun_out/ab, 16.28 / 16.10 / 16.04 us): preloading these arguments into SGPRs
 // (-mllvm -amdgpu-kernarg-preload-count=16) and touching every 64-byte line of the argument segment at entry.
-//   h_flags: bit 0 plan_inline, bit 1 scan_global, bit 2 logw, bit 3 lazy
+//   h_flags: bit 0 plan_inline, bit 1 scan_global, bit 2 logw, bit 3 lazy, bit 4 front end inside the launch (h_front)
 template <int METHOD, int MODE, bool BIG>
 __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict__ h_tot, Ctrl *h_ctrl,
-                                                         int h_nb, int h_slot, int h_grid, int h_flags, Buffers B, PredictArgs PA,
+                                                         const FrontState *h_front, int h_nb, int h_slot, int h_grid, int h_flags, Buffers B, PredictArgs PA,
                                                          UpdateArgs U, RngArgs rng, WeightScratch ws) {
     constexpr bool ARR = MODE == 1, DIST = MODE == 2;
     __shared__ float sh_w[kBlock / kWave], sh_w2[kBlock / kWave];
@@ -819,6 +1017,25 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         }
     }
     // HEAD: everything whose address follows from the preloaded arguments is requested now, in one burst
+    const bool front = !BIG && MODE == 0 && (h_flags & 16) != 0;
+    FrontLm f_lm{-1, 0};
+    FrontHdr f_hd{0, -1, 0, 0};
+    float f_x = 0.f, f_y = 0.f;
+    // dword offsets in the kernel-argument segment (40: the head)
+    constexpr size_t ka0 = (40 + sizeof(Buffers) + alignof(PredictArgs) - 1) / alignof(PredictArgs) * alignof(PredictArgs);
+    constexpr size_t ka1 = (ka0 + sizeof(PredictArgs) + alignof(UpdateArgs) - 1) / alignof(UpdateArgs) * alignof(UpdateArgs);
+    constexpr size_t ka_small = (ka1 + offsetof(UpdateArgs, small)) / 4;
+    if constexpr (!BIG && MODE == 0) {
+        if (front && threadIdx.x < kWave) {
+            // front-end launches: this wave's oldest loads: the map (kernel arguments), then the state the previous launch left
+            const auto *kf = (const __attribute__((address_space(4))) float *) __builtin_amdgcn_kernarg_segment_ptr();
+            const int t = min((int) threadIdx.x, kSmallObs - 1);
+            f_x = kf[ka_small + offsetof(SmallObs, zn) / 4 + t];
+            f_y = kf[ka_small + offsetof(SmallObs, zn) / 4 + kSmallObs + t];
+            f_hd = h_front->hdr;
+            f_lm = h_front->lm[threadIdx.x];
+        }
+    }
     const bool logw = (h_flags & 4) != 0;
     const bool do_scan = h_plan && !h_scan_global;
     ScanLoads scl{0.0f, 0.0f, 0.0f, 0.0f, -INFINITY, -INFINITY};
@@ -826,18 +1043,47 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         scl = scan_issue(h_tot, nbg, h_nb, logw);
     }
     __shared__ int32_t pk[kSmallWords];
+    __shared__ uint32_t f_sets[4];
+    __shared__ float f_aux[2 * kWave + 2];
     int32_t pkv = 0;
 #ifndef SLAM_NO_PK_LDS
     if constexpr (!BIG) {
-        constexpr size_t a0 = (32 + sizeof(Buffers) + alignof(PredictArgs) - 1) / alignof(PredictArgs) * alignof(PredictArgs);  // (32: the head)
-        constexpr size_t a1 = (a0 + sizeof(PredictArgs) + alignof(UpdateArgs) - 1) / alignof(UpdateArgs) * alignof(UpdateArgs);
-        constexpr size_t at = (a1 + offsetof(UpdateArgs, small)) / 4;  // dword offset of U.small in the kernel arguments
+        constexpr size_t at = ka_small;  // dword offset of U.small in the kernel arguments
         const auto *ka = (const __attribute__((address_space(4))) int32_t *) __builtin_amdgcn_kernarg_segment_ptr();
-        if (threadIdx.x < kSmallWords) pkv = ka[at + threadIdx.x];  // (parked in LDS below, once the scan's loads are out too)
+        if (!front && threadIdx.x < kSmallWords) pkv = ka[at + threadIdx.x];  // (parked in LDS below, once the scan's loads are out too)
     }
 #endif
     const int cur = h_ctrl->live[h_slot];  // ... and the Ctrl words
     const bool pend_word = h_ctrl->pend[h_slot] != 0;
+#ifndef SLAM_NO_PK_LDS
+    if constexpr (!BIG && MODE == 0) {
+        // front-end launches: the packet is worked out here, while the scan's loads and the Ctrl words are in flight
+        if (front && (int) blockIdx.x < h_nb) {
+            const int fw = threadIdx.x / kWave, ft = threadIdx.x & (kWave - 1);
+            FrontGeom fg{};
+            if (fw == 0) {
+                fg = front_geometry(U.front, f_x, f_y);
+            } else if (fw == 1) {
+                front_draw(U.front, ft, f_aux);
+            } else if (fw == 2) {
+                const float cph = cosf(U.front.phi), sph = sinf(U.front.phi);
+                if (ft == 0) {
+                    f_aux[2 * kWave] = cph;
+                    f_aux[2 * kWave + 1] = sph;
+                }
+            } else {
+                // (every word a host-made packet would carry is defined: loops further down read clamped entries past m and n)
+                for (int w = ft; w < kSmallWords; w += kWave) pk[w] = 0;
+            }
+            __syncthreads();
+            if (fw == 0) {
+                const auto *kf = (const __attribute__((address_space(4))) float *) __builtin_amdgcn_kernarg_segment_ptr();
+                const FrontObs ob = front_observe(U.front, fg, f_aux, kf + ka_small + offsetof(SmallObs, zf) / 4);
+                front_book(U.front, ob, f_lm, f_hd, pk, f_sets, blockIdx.x == 0);
+            }
+        }
+    }
+#endif
     int bt = (int) blockIdx.x;
 #ifndef SLAM_NO_XCD_TILES
     if (bt < nb) {
@@ -924,7 +1170,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     }
 #ifndef SLAM_NO_PK_LDS
     if constexpr (!BIG) {
-        if (threadIdx.x < kSmallWords) pk[threadIdx.x] = pkv;
+        if (!front && threadIdx.x < kSmallWords) pk[threadIdx.x] = pkv;
         __syncthreads();
         if ((uint32_t) pk[offsetof(SmallObs, magic) / 4] != kSmallMagic) {  // (layout guard: never seen)
             if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->status = kStatusBadPacket;
@@ -941,6 +1187,20 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     float2 *__restrict__ poseCo = out ? B.poseC[1] : B.poseC[0];
     const bool active = i < B.n;
     int m = U.m, n = U.n, nf = U.nf, e_new = U.e_new;
+    int live_chunks = U.live_chunks, n_cons = U.n_cons;
+    bool all_fresh = U.all_fresh != 0;
+    if constexpr (!BIG && MODE == 0) {
+        if (front) {  // the header front_make left in LDS (uniform: kept in scalar registers)
+            const int32_t *h = pk + offsetof(SmallObs, head) / 4;
+            m = __builtin_amdgcn_readfirstlane(h[kFrontHeadM]);
+            n = __builtin_amdgcn_readfirstlane(h[kFrontHeadN]);
+            nf = __builtin_amdgcn_readfirstlane(h[kFrontHeadNf]);
+            e_new = __builtin_amdgcn_readfirstlane(h[kFrontHeadENew]);
+            live_chunks = __builtin_amdgcn_readfirstlane(h[kFrontHeadChunks]);
+            all_fresh = __builtin_amdgcn_readfirstlane(h[kFrontHeadFresh]) != 0;
+            n_cons = __builtin_amdgcn_readfirstlane(h[kFrontHeadCons]);
+        }
+    }
     PacketView PV{};
     if constexpr (BIG) {
         PV = packet_view(U);
@@ -1155,16 +1415,16 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         // pose, stored when it arrives, with the row this update opens already set to "own slot".
         constexpr int kChunks = (kSmallRows + 3) / 4;
         const bool copy_inline = !BIG && pend && sb == cur;  // (an arrival's genealogy is already in place)
-        const int nchunks = U.live_chunks;  // chunks holding a row in use after this update (incl. the one it opens)
+        const int nchunks = live_chunks;  // chunks holding a row in use after this update (incl. the one it opens)
         int4 gq[kChunks];
         float4 pa = poseA[si];
         // the slots of the (first kStage) re-observed landmarks are fetched now, with the pose: they depend on nothing but
         // the source slot, so the records are one round trip behind the pose, not two
         int ts[kStage];
-        const bool early_records = !BIG && METHOD == 2 && m > 0 && U.all_fresh;
+        const bool early_records = !BIG && METHOD == 2 && m > 0 && all_fresh;
         if (!BIG) {
 #pragma unroll
-            for (int k = 0; k < kStage; k++) ts[k] = U.all_fresh ? (DIST ? gsrc : si) : slot_of(min(k, max(m - 1, 0)));
+            for (int k = 0; k < kStage; k++) ts[k] = all_fresh ? (DIST ? gsrc : si) : slot_of(min(k, max(m - 1, 0)));
             if (early_records) {  // fresh landmarks: the record sits in the source slot: requested with the pose
                 if (m <= kStage / 2) issue_records(std::integral_constant<int, kStage / 2>{}, ts);
                 else issue_records(std::integral_constant<int, kStage>{}, ts);
@@ -1476,7 +1736,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         // -- one 40-byte move per particle and landmark, once, instead of 4 bytes per particle, row and resample for the rest of
         // the run (the genealogy composition is ~1.8 us of a 16 us step at 10^5 particles when 25 rows are alive)
         if constexpr (!BIG) {
-            for (int c = 0; c < U.n_cons; c++) {
+            for (int c = 0; c < n_cons; c++) {
                 float4 la;
                 float lb;
                 load_lmk(idf[m + c], slot_of(m + c), buf_of(m + c), la, lb);
@@ -1891,8 +2151,7 @@ __global__ void __launch_bounds__(kBlock) observe_kernel(ObserveArgs A) {
                 g1 = A.r2[c];
             } else {
                 U4 r = philox4x32((uint32_t) vis[c], A.step, 3u, 0u, A.k0, A.k1);
-                float g2;
-                box_muller3(r, g0, g1, g2);
+                sensor_normals(r, g0, g1);
             }
             z[2 * c] = z[2 * c] + g0 * A.sr;
             z[2 * c + 1] = z[2 * c + 1] + g1 * A.sb;
@@ -2004,8 +2263,7 @@ __global__ void __launch_bounds__(kObsThreads) observe_book_kernel(ObserveArgs A
                 g1 = A.r2[c];
             } else {
                 U4 r = philox4x32((uint32_t) vis[c], A.step, 3u, 0u, A.k0, A.k1);
-                float g2;
-                box_muller3(r, g0, g1, g2);
+                sensor_normals(r, g0, g1);
             }
             z[2 * c] = z[2 * c] + g0 * A.sr;
             z[2 * c + 1] = z[2 * c + 1] + g1 * A.sb;
@@ -2745,9 +3003,9 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
                        (U.plan_inline ? update_window_bytes() : 0);
     const int sel = (U.method == 2 ? 6 : 0) + 2 * U.arrivals + (U.big ? 1 : 0);
     const float *h_tot = U.arrivals == 2 ? B.gtot[ws.wpar ^ 1] : ws.blk_w[ws.wpar ^ 1];
-    const int h_flags = (U.plan_inline ? 1 : 0) | (U.scan_global ? 2 : 0) | (U.logw ? 4 : 0) | (U.lazy ? 8 : 0);
+    const int h_flags = (U.plan_inline ? 1 : 0) | (U.scan_global ? 2 : 0) | (U.logw ? 4 : 0) | (U.lazy ? 8 : 0) | (U.front.on ? 16 : 0);
 #define SLAM_LAUNCH_UPDATE(M, A, G)                                                                                              \
-    hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, ws.nblocks, B.slot, grid, \
+    hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid, \
                        h_flags, B, PA, U, rng, ws)
     switch (sel) {
         case 11: SLAM_LAUNCH_UPDATE(2, 2, true); break;

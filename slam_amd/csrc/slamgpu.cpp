@@ -86,6 +86,7 @@ const Rccl *rccl() {
     } while (0)
 
 constexpr int kRing = 64;       // big-packet staging slots
+constexpr int kStageBound = 8;  // = kStage of kernels.hip: re-observed landmarks whose records an update launch stages in LDS
 constexpr int kConsolidateAbove = 6;  // compact contexts: genealogy rows alive before stale rows are consolidated (3..8 measure alike; profiles/consolidate_sweep_r03.txt)
 constexpr int kHistCap = 4096;  // asynchronous pose-estimate history entries
 
@@ -205,6 +206,13 @@ struct slamgpu_ctx {
     hipStream_t obs_stream = nullptr;  // the front-end kernels run here, a step ahead of the update launches (events order them)
     hipEvent_t obs_ev[kRing]{};        // observe_book of the packet in ring slot k has finished
     char *last_pkt_dev = nullptr;    // packet of the last slamgpu_step_observe (slamgpu_observe_fetch)
+    // compact contexts: the front end runs inside the update launch (kernels.h: FrontArgs); its state lives in two device
+    // copies, read / written alternately (front_par: the one the next launch reads)
+    std::vector<float> map_host;     // [2][map_n], as slamgpu_set_map received it
+    FrontState *front_dev = nullptr, *front_host = nullptr;
+    ObsPacket *front_pkt_dev = nullptr;
+    int front_par = 0;
+    bool front_ready = false;
     // gated association with the spatial prefilter (slamgpu_associate_ex): per-landmark boxes over all particles, refreshed
     // for the landmarks written since (box_dirty), and the grid buffers
     LmkBox *box_dev = nullptr;
@@ -370,9 +378,69 @@ int book_staging(slamgpu_ctx *c) {
     return 0;
 }
 
+// the row lists follow from the reference counts (book_pull)
+void book_rebuild(slamgpu_ctx *c) {
+    std::fill(c->live_pos.begin(), c->live_pos.end(), -1);
+    c->live_rows.clear();
+    c->free_rows.clear();
+    for (int r = c->B.cap_rows - 1; r >= 0; r--)
+        if (c->refcnt[r] == 0) c->free_rows.push_back(r);  // back() = lowest free row
+    for (int r = 0; r < c->B.cap_rows; r++)
+        if (c->refcnt[r] > 0) rows_add_live(c, r);
+    c->tables_dirty = true;
+    c->book_on_device = false;
+    std::fill(c->box_dirty.begin(), c->box_dirty.end(), 1);  // (which landmarks the device-driven steps wrote is not known here)
+}
+
+// compact contexts: the front end's state (kernels.h: FrontState), both copies holding the map, no landmark seen yet
+int front_setup(slamgpu_ctx *c) {
+    if (c->front_ready) return 0;
+    if (c->map_n > kFrontLanes || c->map_n > kSmallObs - 1) return fail(SLAMGPU_ERR_CAPACITY, "map of %d landmarks in a compact context", c->map_n);
+    if (!c->front_dev) {
+        HIP_TRY(hipMalloc((void **) &c->front_dev, 2 * sizeof(FrontState)));
+        HIP_TRY(hipHostMalloc((void **) &c->front_host, sizeof(FrontState), hipHostMallocDefault));
+        HIP_TRY(hipMalloc((void **) &c->front_pkt_dev, sizeof(ObsPacket) + 4 * (6 * (size_t) kFrontLanes + kSmallRows)));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    FrontState *h = c->front_host;
+    memset(h, 0, sizeof *h);
+    h->hdr = FrontHdr{0, -1, 0, 0};
+    for (int t = 0; t < kFrontLanes; t++) h->lm[t] = FrontLm{-1, 0};
+    for (int q = 0; q < 2; q++) HIP_TRY(hipMemcpy(c->front_dev + q, h, sizeof *h, hipMemcpyHostToDevice));
+    c->front_par = 0;
+    c->front_ready = true;
+    return 0;
+}
+
 int book_pull(slamgpu_ctx *c) {
     if (!c->book_on_device) return 0;
     HIP_TRY(hipSetDevice(c->cfg.device));
+    if (c->B.compact) {
+        FrontState *h = c->front_host;
+        HIP_TRY(hipMemcpyAsync(h, c->front_dev + c->front_par, sizeof *h, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        const int nf = h->hdr.nf;
+        if (nf < 0 || nf > c->B.cap_nf) return fail(SLAMGPU_ERR_INVALID, "device bookkeeping corrupt: nf = %d", nf);
+        std::fill(c->refcnt.begin(), c->refcnt.end(), 0);
+        int seen = 0;
+        for (int t = 0; t < c->map_n; t++) {
+            const FrontLm &l = h->lm[t];
+            if (l.idf < 0) continue;
+            const int r = l.row & kRowMask;
+            if (l.idf >= nf || r >= c->B.cap_rows) return fail(SLAMGPU_ERR_INVALID, "device bookkeeping corrupt: landmark %d -> feature %d, row %d", t, l.idf, r);
+            c->erow[l.idf] = r;
+            c->live_flag[l.idf] = (l.row & kRowLiveBit) ? 1 : 0;
+            c->refcnt[r]++;
+            seen++;
+        }
+        if (seen != nf) return fail(SLAMGPU_ERR_INVALID, "device bookkeeping corrupt: %d landmarks of the map seen, nf = %d", seen, nf);
+        c->nf = nf;
+        c->fresh_row = h->hdr.fresh_row;
+        book_rebuild(c);
+        if (h->hdr.status & kStatusCapacity)
+            return fail(SLAMGPU_ERR_CAPACITY, "the device front end dropped new landmarks: landmark capacity %d exceeded", c->B.cap_nf);
+        return 0;
+    }
     const size_t cn = (size_t) c->B.cap_nf, cr = (size_t) c->B.cap_rows;
     DevBook *hb = reinterpret_cast<DevBook *>(c->book_host);
     int32_t *h_erow = c->book_host + sizeof(DevBook) / 4, *h_live = h_erow + cn, *h_ref = h_live + cn;
@@ -389,16 +457,7 @@ int book_pull(slamgpu_ctx *c) {
     std::copy(h_ref, h_ref + cr, c->refcnt.begin());
     c->nf = nf;
     c->fresh_row = hb->fresh_row;
-    std::fill(c->live_pos.begin(), c->live_pos.end(), -1);
-    c->live_rows.clear();
-    c->free_rows.clear();
-    for (int r = c->B.cap_rows - 1; r >= 0; r--)
-        if (c->refcnt[r] == 0) c->free_rows.push_back(r);  // back() = lowest free row
-    for (int r = 0; r < c->B.cap_rows; r++)
-        if (c->refcnt[r] > 0) rows_add_live(c, r);
-    c->tables_dirty = true;
-    c->book_on_device = false;
-    std::fill(c->box_dirty.begin(), c->box_dirty.end(), 1);  // (which landmarks the device-driven steps wrote is not known here)
+    book_rebuild(c);
     if (hb->status & kStatusCapacity)
         return fail(SLAMGPU_ERR_CAPACITY, "the device front end dropped new landmarks: landmark capacity %d exceeded", c->B.cap_nf);
     return 0;
@@ -407,6 +466,30 @@ int book_pull(slamgpu_ctx *c) {
 int book_push(slamgpu_ctx *c) {
     if (c->book_on_device) return 0;
     HIP_TRY(hipSetDevice(c->cfg.device));
+    if (c->B.compact) {
+        // the landmark -> feature table lives in the front end's state and nowhere else: every feature the context knows must
+        // have come from it (a context is driven by one front end, the host's or the device's, from its first landmark on)
+        if (int rc = front_setup(c)) return rc;
+        FrontState *h = c->front_host;
+        HIP_TRY(hipMemcpyAsync(h, c->front_dev + c->front_par, sizeof *h, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // (and nothing in flight still reads this copy)
+        int seen = 0;
+        for (int t = 0; t < c->map_n; t++) {
+            FrontLm &l = h->lm[t];
+            if (l.idf < 0) continue;
+            if (l.idf >= c->nf) return fail(SLAMGPU_ERR_INVALID, "the device's landmark table knows feature %d, the context only %d", l.idf, c->nf);
+            l.row = c->erow[l.idf] | (c->live_flag[l.idf] ? kRowLiveBit : 0);
+            seen++;
+        }
+        if (seen != c->nf)
+            return fail(SLAMGPU_ERR_INVALID, "slamgpu_step_observe on a compact context: %d of its %d landmarks came from host-made packets, "
+                        "which the device's landmark table does not know", c->nf - seen, c->nf);
+        h->hdr = FrontHdr{c->nf, c->fresh_row, 0, 0};
+        HIP_TRY(hipMemcpyAsync(c->front_dev + c->front_par, h, sizeof *h, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->book_on_device = true;
+        return 0;
+    }
     if (int rc = book_staging(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));  // (nothing in flight may still read the old tables or the staging buffer)
     const size_t cn = (size_t) c->B.cap_nf, cr = (size_t) c->B.cap_rows;
@@ -654,7 +737,8 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     }
     c->B.slot = 0;
     c->B.cap_rows = cap_nf + 1;  // at most one row per landmark, plus the one a step opens while the old ones are still read
-    c->B.compact = (c->B.cap_rows <= kSmallRows && !(cfg->flags & SLAMGPU_FLAG_DEVICE_OBSERVE)) ? 1 : 0;
+    c->B.compact = c->B.cap_rows <= kSmallRows ? 1 : 0;
+    if (getenv("SLAMGPU_NO_COMPACT")) c->B.compact = 0;  // diagnostic: plain rows for a small map
     c->erow.assign((size_t) cap_nf, 0);
     c->live_flag.assign((size_t) cap_nf, 0);
     c->seen_step.assign((size_t) cap_nf, 0);
@@ -760,6 +844,9 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     for (int b = 0; b < 2; b++)
         if (c->gtot_dev[b]) (void) hipFree(c->gtot_dev[b]);
     if (c->flags_dev) (void) hipFree(c->flags_dev);
+    if (c->front_dev) (void) hipFree(c->front_dev);
+    if (c->front_host) (void) hipHostFree(c->front_host);
+    if (c->front_pkt_dev) (void) hipFree(c->front_pkt_dev);
     if (c->map_dev) (void) hipFree(c->map_dev);
     if (c->obs_r_dev) (void) hipFree(c->obs_r_dev);
     if (c->table_dev) (void) hipFree(c->table_dev);
@@ -1095,7 +1182,8 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
 int do_update_dev(slamgpu_ctx *c, const float xtrue[3], float max_range, const float R[4], int32_t noise, const float *r1,
                   const float *r2, const float *normals, const float *strata) {
     if (!c->map_dev) return fail(SLAMGPU_ERR_INVALID, "no map: call slamgpu_set_map first");
-    if (c->B.compact) return fail(SLAMGPU_ERR_INVALID, "create the context with SLAMGPU_FLAG_DEVICE_OBSERVE (its observation packets live in device memory)");
+    if (!c->B.compact && !(c->cfg.flags & SLAMGPU_FLAG_DEVICE_OBSERVE))
+        return fail(SLAMGPU_ERR_INVALID, "create the context with SLAMGPU_FLAG_DEVICE_OBSERVE (its observation packets live in device memory)");
     if (c->dist || c->cfg.n_particles_global != c->cfg.n_particles) return fail(SLAMGPU_ERR_INVALID, "slamgpu_step_observe: single contexts only");
     if (c->map_n > c->B.cap_nf) return fail(SLAMGPU_ERR_CAPACITY, "map of %d landmarks, capacity %d", c->map_n, c->B.cap_nf);
     if (!xtrue || !R || noise < 0 || noise > 2 || (noise == 1 && (!r1 || !r2))) return fail(SLAMGPU_ERR_INVALID, "bad arguments");
@@ -1104,6 +1192,50 @@ int do_update_dev(slamgpu_ctx *c, const float xtrue[3], float max_range, const f
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = book_push(c)) return rc;
     c->obs_step++;
+    if (c->B.compact) {
+        // compact context: no front-end launch at all: every block of the update launch works the packet out for itself from
+        // the state the previous launch left (kernels.h: FrontArgs; kernels.hip: front_make)
+        UpdateArgs U{};
+        U.method = c->cfg.method;
+        U.m = kStageBound;  // (sizes the launch's record staging: the kernel learns m from the packet it makes)
+        U.e_new = -1;
+        U.small.magic = kSmallMagic;
+        for (int q = 0; q < c->map_n; q++) {  // the map rides in the words of the new landmarks' observations
+            U.small.zn[q] = c->map_host[(size_t) q];
+            U.small.zn[kSmallObs + q] = c->map_host[(size_t) c->map_n + q];
+        }
+        if (noise == 1)
+            for (int q = 0; q < c->map_n; q++) {
+                U.small.zf[q] = r1[q];
+                U.small.zf[kSmallObs + q] = r2[q];
+            }
+        FrontArgs &F = U.front;
+        F.on = 1;
+        F.nlm = c->map_n;
+        F.cap_nf = c->B.cap_nf;
+        F.noise = noise;
+        F.x = xtrue[0];
+        F.y = xtrue[1];
+        F.phi = xtrue[2];
+        F.max_range = max_range;
+        F.sr = sqrtf(R[0]);
+        F.sb = sqrtf(R[3]);
+        F.k0 = (uint32_t) c->cfg.seed;
+        F.k1 = (uint32_t) (c->cfg.seed >> 32);
+        F.step = ++c->observe_step;
+        F.cons_above = c->consolidate ? c->consolidate_above : -1;
+        F.state_in = c->front_dev + c->front_par;
+        F.state_out = c->front_dev + (c->front_par ^ 1);
+        F.out = c->obs_out_dev;
+        F.pkt = c->front_pkt_dev;
+        memcpy(U.R, R, sizeof U.R);
+        const bool need_normals = c->cfg.method == SLAMGPU_FASTSLAM2 && normals != nullptr;
+        if (int rc = issue_update(c, U, -1, -1, need_normals, normals, strata, false)) return rc;
+        c->front_par ^= 1;
+        c->last_pkt_dev = reinterpret_cast<char *>(c->front_pkt_dev);
+        c->fresh_row = -1;  // (the device's book knows)
+        return 0;
+    }
     const size_t nl = (size_t) c->map_n;
     // The front-end kernel runs on a stream of its own, ahead of the update launches: packet t is made while update t - 1
     // still computes (it depends on the true pose and on the previous front-end kernel only); events order the two streams:
@@ -1211,7 +1343,7 @@ int slamgpu_observe_fetch(slamgpu_ctx *c, float *z, int32_t *vis, int32_t *nz, f
     if (int rc = check_ctx(c)) return rc;
     if (!c->last_pkt_dev) return fail(SLAMGPU_ERR_INVALID, "no device-made observation yet (slamgpu_step_observe)");
     HIP_TRY(hipSetDevice(c->cfg.device));
-    HIP_TRY(hipStreamSynchronize(c->obs_stream));
+    if (c->obs_stream) HIP_TRY(hipStreamSynchronize(c->obs_stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const size_t C = (size_t) c->map_n;
     std::vector<char> pk(sizeof(ObsPacket) + 4 * 6 * C), ob(sizeof(ObserveOut) + 4 * 3 * C);
@@ -2160,6 +2292,8 @@ int slamgpu_set_map(slamgpu_ctx *c, const float *lm, int32_t nlm) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->map_n = nlm;
     c->obs_nf = 0;
+    c->map_host.assign(lm, lm + 2 * n);
+    c->front_ready = false;  // (a new map starts a new landmark table)
     return 0;
 }
 

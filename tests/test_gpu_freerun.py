@@ -56,9 +56,12 @@ FREE_NEFF = {True: {0: 3e-2, 1: 5e-2}, False: {0: 2.5e-3, 1: 5e-3}}
 # but a small share -- the weight noise alone moves the sum by a fraction of a stratum -- and does better than the
 # oracle's own list does.
 D_BINS = [0, 1, 2, 3, 5, 9, 17, 33, 1 << 30]  # |ancestor - anc64|: 0, 1, 2, 3-4, 5-8, 9-16, 17-32, more
-# share of the GPU's ancestors more than one particle / more than eight particles from anc64 (2x measured)
+# share of the GPU's ancestors more than one particle / more than eight particles from anc64: 2x the shares measured
+# (gpurun_out/full/gpu_all.log, strict / fast: more than one 0.0047 / 0.0185 at N = 1 000 and 0.178 / 0.403 at N = 100 000;
+# more than eight 3.8e-5 / 1.0e-4 and 0.0058 / 0.0446; histogram per bin at N = 100 000, 0 | 1 | 2 | 3-4 | 5-8 | 9-16 | 17-32 | more:
+# strict 0.531 0.291 0.088 0.060 0.024 0.0051 0.0006 0.0001, fast 0.326 0.271 0.132 0.133 0.093 0.036 0.0072 0.0012)
 ANC64_FAR = {1000: {0: 0.01, 1: 0.04}, 100000: {0: 0.36, 1: 0.8}}
-ANC_FAR8 = {1000: {0: 0.005, 1: 0.01}, 100000: {0: 0.05, 1: 0.2}}
+ANC_FAR8 = {1000: {0: 1e-4, 1: 2.5e-4}, 100000: {0: 0.012, 1: 0.09}}
 MEASURE = bool(os.environ.get("SLAM_FREERUN_MEASURE"))  # collect the maxima, assert nothing about magnitudes
 
 

@@ -166,13 +166,21 @@ def test_device_made_packets_match_the_reference_tape(sg, name, mapname, N, seed
     sim.close()
 
 
-@pytest.mark.parametrize("mapname", ["example_webmap", "synthetic"])
-def test_device_bookkeeping_equals_host_bookkeeping(sg, tmp_path, mapname):
+@pytest.mark.parametrize("mapname", ["example_webmap", "example_webmap:plain", "synthetic"])
+def test_device_bookkeeping_equals_host_bookkeeping(sg, tmp_path, mapname, monkeypatch):
     """A run stepped with slamgpu_step_observe (packet and genealogy bookkeeping made on the device) against the same run
     stepped with slamgpu_step on the packets the device made (fetched back: the host then does the bookkeeping, in the compact
     layout on the small map): states and histories must be bit-identical, resampling steps included; reads in the middle of
-    the device-driven run (peek / landmark count: the bookkeeping travels to the host and back) must not change a bit."""
+    the device-driven run (peek / landmark count: the bookkeeping travels to the host and back) must not change a bit.
+    Three device paths: the small map's compact context (the front end inside the update launch, row consolidation
+    included: 1 200 observation steps), the same map with plain rows (front-end kernel on a stream of its own), a 1 000-landmark map."""
     from slam_amd import host
+    if mapname.endswith(":plain"):
+        mapname = mapname.split(":")[0]
+        monkeypatch.setenv("SLAMGPU_NO_COMPACT", "1")
+        plain = True
+    else:
+        plain = False
     if mapname == "synthetic":
         lmk = host.synthetic_landmarks(4321, 1000, -130, 100, -100, 90)
         h0 = host.HostSim(sim_args("example_webmap", "FASTSLAM2", 100, 7))
@@ -184,7 +192,7 @@ def test_device_bookkeeping_equals_host_bookkeeping(sg, tmp_path, mapname):
             "MAX_RANGE           = 60.0", "MAX_RANGE           = 20.0"))
         args, nobs = ["-m", mp, "-method", "FASTSLAM2", "-SWITCH_SEED_RANDOM", 3], 120
     else:
-        args, nobs = sim_args(mapname, "FASTSLAM2", 100, 7), 300
+        args, nobs = sim_args(mapname, "FASTSLAM2", 100, 7), (300 if plain else 1200)
     N = 2048
     tape = host.make_tape(args, max_obs=nobs)
     sim = host.HostSim(args)
@@ -206,6 +214,7 @@ def test_device_bookkeeping_equals_host_bookkeeping(sg, tmp_path, mapname):
     ha, da = a.history_fetch(), a.download()
     a.close()
     assert max(p["zf"].shape[0] for p in packets) > (12 if mapname == "synthetic" else 3)
+    monkeypatch.delenv("SLAMGPU_NO_COMPACT", raising=False)
     b = sg.SlamGpu(N, tape["nlm"], **kw)
     for st, p in zip(tape["steps"], packets):
         b.step(np.array(st["controls"], f32).reshape(-1, 3), Q, dt, p["zf"], p["idf"], p["zn"], R)
@@ -217,3 +226,20 @@ def test_device_bookkeeping_equals_host_bookkeeping(sg, tmp_path, mapname):
     assert da["nf"] == db["nf"]
     for key in ("xv", "Pv", "w", "xf", "Pf"):
         assert np.array_equal(da[key].view(np.uint32), db[key].view(np.uint32)), key
+
+
+def test_one_front_end_per_compact_context(sg):
+    """The landmark -> feature table of a compact context lives in the front end's device state: landmarks made from
+    host packets are unknown to it, and slamgpu_step_observe says so instead of seeing them as new ones."""
+    from slam_amd import host
+    sim = host.HostSim(sim_args("example_webmap", "FASTSLAM2", 100, 7))
+    lm, _ = sim.map()
+    Q, R, dt = sim.noise()
+    s = sg.SlamGpu(512, sim.nlm, method=2, n_effective=384, rng_mode=sg.RNG_PHILOX, seed=1, math_mode=1, device_observe=True)
+    s.set_map(lm)
+    ctl = np.array([[3.0, 0.0, 0.0]], f32)
+    s.step(ctl, Q, float(dt), np.zeros((0, 2), f32), np.zeros(0, np.int32), np.array([[10.0, 0.1]], f32), R)
+    with pytest.raises(sg.SlamGpuError, match="host-made packets"):
+        s.step_observe(ctl, Q, float(dt), sim.true_pose(), float(sim.conf.MAX_RANGE), R, noise=2)
+    s.close()
+    sim.close()
