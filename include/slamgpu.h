@@ -241,6 +241,13 @@ int slamgpu_associate_ex(slamgpu_ctx *ctx, const float *z, int32_t nz, const flo
                          int32_t *labels, int32_t *consensus, float *support, double stats[4]);
 
 int slamgpu_num_landmarks(slamgpu_ctx *ctx);
+
+/* Introspection: genealogy rows in use (what a resample composes per particle: 4 bytes each) and the context's row capacity.
+ * Every update that writes landmarks opens a row; rows whose landmarks have all moved on are reused; updates consolidate the
+ * landmarks of stale rows so that the rows in use stay bounded (a handful on maps of up to 39 landmarks, ~2 000 on big maps).
+ * No counterpart in the reference (its resample copies whole particles, core.cpp:735-749).  Synchronises after
+ * slamgpu_step_observe steps. */
+int slamgpu_genealogy_rows(slamgpu_ctx *ctx, int32_t *in_use, int32_t *capacity);
 /* Particle-major host copies (any pointer may be NULL): xv[3N], Pv[9N] row-major, w[N],
  * xf[2*Nf*N], Pf[4*Nf*N] row-major — the layout of vector<Particle> flattened. Synchronises. */
 int slamgpu_download(slamgpu_ctx *ctx, float *xv, float *Pv9, float *w, float *xf, float *Pf4);

@@ -641,7 +641,7 @@ SLAM_DEV void copy_genealogy(const Buffers &B, const int32_t *__restrict__ rows,
 // device-resident observation packet (kernels.h: ObsPacket), dense (written by the host) or fixed layout (written by the
 // device front end): where its arrays start, in 4-byte units behind the header
 struct PacketView {
-    int m, n, nf, e_new, n_rows, rows_per_role;
+    int m, n, nf, e_new, n_rows, rows_per_role, n_cons;
     const int32_t *idf, *row, *rows;
     const float *zf, *zn;
 };
@@ -667,12 +667,14 @@ SLAM_DEV PacketView packet_view(const UpdateArgs &U) {
         V.n_rows = U.n_rows;
         V.rows_per_role = U.rows_per_role;
     }
-    const int a = cap ? cap : V.m, b = cap ? cap : V.n;
+    // (host-made packets: the landmarks the launch consolidates ride behind the re-observed ones in idf[] and row[])
+    V.n_cons = U.dev_packet ? 0 : U.n_cons;
+    const int a = cap ? cap : V.m, ai = cap ? cap : V.m + V.n_cons, b = cap ? cap : V.n;
     V.idf = base;
-    V.zf = reinterpret_cast<const float *>(base + a);
+    V.zf = reinterpret_cast<const float *>(base + ai);
     V.zn = V.zf + 2 * a;
     V.row = reinterpret_cast<const int32_t *>(V.zn + 2 * b);
-    V.rows = V.row + a;
+    V.rows = V.row + ai;
     return V;
 }
 
@@ -1208,6 +1210,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         n = PV.n;
         nf = PV.nf;
         e_new = PV.e_new;
+        n_cons = PV.n_cons;
     }
     float w = logw ? -INFINITY : 0.0f;  // lanes beyond the particle count carry no weight
 
@@ -1731,16 +1734,33 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
             add_feature(x, y, th, zn[2 * k], zn[2 * k + 1], r00, r01, r10, r11, la.x, la.y, la.z, la.w, lb);
             store_new(nf + k, la, lb);
         }
-        // Row consolidation (compact contexts, rare: slamgpu.cpp: do_update): landmarks out of view whose rows have gone stale
-        // are rewritten, unchanged, into this particle's own slot of the row's other buffer and join the row this update opens
-        // -- one 40-byte move per particle and landmark, once, instead of 4 bytes per particle, row and resample for the rest of
-        // the run (the genealogy composition is ~1.8 us of a 16 us step at 10^5 particles when 25 rows are alive)
+        // Row consolidation (slamgpu.cpp: do_update): landmarks out of view whose rows have gone stale are rewritten, unchanged,
+        // into this particle's own slot of the row's other buffer and join the row this update opens -- one 40-byte move per
+        // particle and landmark, once, instead of 4 bytes per particle, row and resample for the rest of the run (compact
+        // contexts: the genealogy composition is ~1.8 us of a 16 us step at 10^5 particles when 25 rows are alive; big maps: a
+        // row goes stale every step, and without this a resample's copy grows with the length of the run)
         if constexpr (!BIG) {
             for (int c = 0; c < n_cons; c++) {
                 float4 la;
                 float lb;
                 load_lmk(idf[m + c], slot_of(m + c), buf_of(m + c), la, lb);
                 store_lmk(idf[m + c], buf_of(m + c), la, lb);
+            }
+        } else {
+            // (four at a time: slots, then records, in flight together)
+            for (int c0 = 0; c0 < n_cons; c0 += 4) {
+                int sl[4];
+                Rec rc[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) sl[q] = slot_of(m + min(c0 + q, n_cons - 1));
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int k = m + min(c0 + q, n_cons - 1);
+                    rc[q] = load_rec(idf[k], sl[q], buf_of(k));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    if (c0 + q < n_cons) store_lmk(idf[m + c0 + q], buf_of(m + c0 + q), rc[q].a, rc[q].b);
             }
         }
         // the landmarks this update wrote are in this particle's own slot now: that is what the genealogy row this update

@@ -86,6 +86,8 @@ const Rccl *rccl() {
     } while (0)
 
 constexpr int kRing = 64;       // big-packet staging slots
+constexpr int kPlainRowsTarget = 2048;  // plain-row contexts: genealogy rows in use before updates start consolidating the emptiest ones
+constexpr int kPlainConsBudget = 32;  // ... landmarks moved per update, at least
 constexpr int kStageBound = 8;  // = kStage of kernels.hip: re-observed landmarks whose records an update launch stages in LDS
 constexpr int kConsolidateAbove = 6;  // compact contexts: genealogy rows alive before stale rows are consolidated (3..8 measure alike; profiles/consolidate_sweep_r03.txt)
 constexpr int kHistCap = 4096;  // asynchronous pose-estimate history entries
@@ -163,6 +165,7 @@ struct slamgpu_ctx {
     bool scan_ready = false;      // scan_kernel ran on the last update's block totals (large contexts)
     bool consolidate = true;      // row consolidation of compact contexts (do_update); SLAMGPU_NO_CONSOLIDATE=1 turns it off
     int consolidate_above = kConsolidateAbove;  // (SLAMGPU_CONSOLIDATE_ABOVE: diagnostic)
+    int plain_rows_target = kPlainRowsTarget;   // (SLAMGPU_PLAIN_ROWS_TARGET: diagnostic / tests)
     int scan_min_blocks = 1024;   // contexts with more blocks of 256 particles than this use scan_kernel (262 144 particles)
     // Genealogy bookkeeping (kernels.h: gen).  The association is global, so the host knows which genealogy row every
     // landmark uses: a step that writes landmarks opens a new row for them; a row whose last landmark moved on is recycled.
@@ -696,6 +699,7 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     if (const char *e = getenv("SLAMGPU_SCAN_MIN_BLOCKS")) c->scan_min_blocks = atoi(e);  // diagnostic
     c->consolidate = getenv("SLAMGPU_NO_CONSOLIDATE") == nullptr;                          // diagnostic / tests
     if (const char *e = getenv("SLAMGPU_CONSOLIDATE_ABOVE")) c->consolidate_above = atoi(e);
+    if (const char *e = getenv("SLAMGPU_PLAIN_ROWS_TARGET")) c->plain_rows_target = atoi(e);
     const bool want_stamps = getenv("SLAMGPU_STAMPS") != nullptr;                         // diagnostic
     const int cap_nf = cfg->max_landmarks > 0 ? cfg->max_landmarks : 1;
     c->B.n = n;
@@ -1057,6 +1061,30 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
             if (c->seen_step[j] != c->obs_step) cons.push_back(j);
         // (only worth a launch's while if it empties rows: every row but the one opened now, or as many landmarks as fit)
     }
+    // Plain rows (big maps): every update opens a row, and the landmarks that went out of view stay behind in the rows of the
+    // steps that saw them last (~40 per row on BASELINE config 5's map), one more stale row per step, 8 bytes per particle and
+    // row for every resample from then on: a copy that grows with the length of the run.  Up to ~1 000 rows the copy roles
+    // hide it behind the compute blocks (measured at config 5, steps 1008..1028: 994 rows in use 1.239 ms per step; held at
+    // 117 rows by consolidating 81 landmarks per step 1.314 ms: the moves ride in the compute blocks, the copies do not), so
+    // the bound is set where the copy would start to show: past kPlainRowsTarget rows in use each update also moves the
+    // landmarks of the emptiest rows (at most max(kPlainConsBudget, m / 16), 40 bytes per particle each) into the row it
+    // opens, and the rows in use stop growing.
+    if (!c->B.compact && !sharded && !c->dist && c->consolidate && (int) c->live_rows.size() > c->plain_rows_target) {
+        const int budget = std::max(kPlainConsBudget, m / 16);
+        std::vector<int32_t> order(c->live_rows);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return c->refcnt[a] != c->refcnt[b] ? c->refcnt[a] < c->refcnt[b] : a < b; });
+        std::vector<char> take((size_t) c->B.cap_rows, 0);
+        int planned = 0, rows_taken = 0;
+        for (int r : order) {
+            if (planned >= budget || (int) c->live_rows.size() - rows_taken <= c->plain_rows_target) break;
+            take[(size_t) r] = 1;
+            planned += c->refcnt[r];
+            rows_taken++;
+        }
+        if (planned > 0)
+            for (int j = 0; j < c->nf && (int) cons.size() < budget; j++)
+                if (take[(size_t) c->erow[j]] && c->seen_step[j] != c->obs_step) cons.push_back(j);
+    }
     const int nc = (int) cons.size();
     int e_new = -1;
     std::vector<int32_t> rows_of((size_t) m + nc), dropped;
@@ -1147,17 +1175,19 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
         hp->cap = 0;  // dense layout
         hp->pad = 0;
         int32_t *hidf = reinterpret_cast<int32_t *>(hp + 1);
-        float *hzf = reinterpret_cast<float *>(hidf + m);
+        float *hzf = reinterpret_cast<float *>(hidf + m + nc);
         float *hzn = hzf + 2 * m;
         if (m) {
             memcpy(hidf, idf, sizeof(int32_t) * m);
             memcpy(hzf, zf, sizeof(float) * 2 * m);
         }
+        if (nc) memcpy(hidf + m, cons.data(), sizeof(int32_t) * nc);  // the consolidated landmarks ride behind the re-observed ones
         if (n) memcpy(hzn, zn, sizeof(float) * 2 * n);
         int32_t *hrow = reinterpret_cast<int32_t *>(hzn + 2 * n);
-        if (m) memcpy(hrow, rows_of.data(), sizeof(int32_t) * m);
-        if (n_rows) memcpy(hrow + m, c->live_rows.data(), sizeof(int32_t) * n_rows);
-        const size_t used = sizeof(ObsPacket) + sizeof(int32_t) * m + sizeof(float) * 2 * (m + n) + sizeof(int32_t) * ((size_t) m + n_rows);
+        if (m + nc) memcpy(hrow, rows_of.data(), sizeof(int32_t) * ((size_t) m + nc));
+        if (n_rows) memcpy(hrow + m + nc, c->live_rows.data(), sizeof(int32_t) * n_rows);
+        const size_t used = sizeof(ObsPacket) + sizeof(int32_t) * ((size_t) m + nc) + sizeof(float) * 2 * (m + n) + sizeof(int32_t) * ((size_t) m + nc + n_rows);
+        U.n_cons = nc;
         char *pd = c->pkt_dev + (size_t) slot * c->pkt_bytes;
         HIP_TRY(hipMemcpyAsync(pd, ph, used, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipEventRecord(c->pkt_ev[slot], c->stream));
@@ -2585,6 +2615,14 @@ int slamgpu_num_landmarks(slamgpu_ctx *c) {
     if (!c) return SLAMGPU_ERR_INVALID;
     if (int rc = book_pull(c)) return rc;  // (device-driven steps: the count lives on the device; synchronises)
     return c->nf;
+}
+
+int slamgpu_genealogy_rows(slamgpu_ctx *c, int32_t *in_use, int32_t *capacity) {
+    if (int rc = check_ctx(c)) return rc;
+    if (int rc = book_pull(c)) return rc;
+    if (in_use) *in_use = (int32_t) c->live_rows.size();
+    if (capacity) *capacity = c->B.cap_rows;
+    return 0;
 }
 
 int slamgpu_sync(slamgpu_ctx *c) {

@@ -400,13 +400,15 @@ def test_full_size_philox_vs_oracle(sg, oracle, math_mode):
     Q, R, dt = o.noise()
     s = sg.SlamGpu(N, o.nlm, method=2, n_effective=algo.n_effective, wheel_base=algo.wheel_base, rng_mode=sg.RNG_PHILOX, seed=7,
                    math_mode=math_mode)
-    k = 0
-    while k < 5:
+    k = resamples = 0
+    while k < 8:   # (the sixth observation step is the first that resamples)
         a = o.control()
         x, vg = o.true_pose()
         s.predict(float(vg[0]), float(vg[1]), Q, float(dt), float(x[2]))
         if a == 1:
-            o.observe()
+            o.observe_local()
+            pre = o.particles()   # the set the resampling stage draws from
+            own_keep = o.resample()
             ob = o.last_obs()
             s.update(ob["zf"], ob["idf"], ob["zn"], R)
             k += 1
@@ -418,11 +420,18 @@ def test_full_size_philox_vs_oracle(sg, oracle, math_mode):
             assert np.isfinite(got["w"]).all() and np.isfinite(got["xv"]).all()
             np.testing.assert_allclose(got["w"].sum(dtype=np.float64), 1.0, rtol=1e-4)  # normalised (or N * 1/N)
             if did_g:
+                resamples += 1
                 keep = s.ancestors()
                 assert np.all(np.diff(keep) >= 0) and keep.min() >= 0 and keep.max() < N   # monotone ancestors
                 assert np.all(got["w"] == np.float32(1.0) / np.float32(N))
-                bad = np.abs(got["xv"] - exp["xv"]).max(axis=1) > POSE_ATOL
-                assert bad.mean() <= W_AGG[math_mode]["ancestors"] * 1.5, (k, bad.mean())
+                # every particle is its ancestor's pre-resample self (at this size a large share of the strata pick the
+                # neighbour of the oracle's choice -- float32 cumulative sums, tests/test_gpu_freerun.py -- so the comparison
+                # goes through the GPU's own ancestors: all particles, no share exempted)
+                assert np.abs(got["xv"] - pre["xv"][keep]).max() <= 5e-4, (k, np.abs(got["xv"] - pre["xv"][keep]).max())
+                assert np.abs(got["xf"] - pre["xf"][keep]).max() <= POSE_ATOL * 5, k
+                # ... and the ancestors themselves are the oracle's up to a few neighbours for most strata
+                d = np.abs(keep.astype(np.int64) - own_keep.astype(np.int64))
+                assert (d > 8).mean() <= 0.1, (k, (d > 8).mean())
             else:
                 # same Philox bits; Box-Muller through device libm (fast build: the hardware v_log / v_sin / v_cos) instead of
                 # glibc: poses agree to ~1e-5
@@ -432,6 +441,7 @@ def test_full_size_philox_vs_oracle(sg, oracle, math_mode):
                     (k, np.median(rel), np.quantile(rel, 0.99))
             np.testing.assert_allclose(s.estimate()[:2], o.estimate()[:2], atol=2e-3)
             s.upload(exp)
+    assert resamples >= 1
     s.close()
     o.close()
 
@@ -685,3 +695,49 @@ def test_row_consolidation_changes_no_bit(sg, monkeypatch):
         for key in ("xv", "Pv", "w", "xf", "Pf"):
             assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), (method, key)
             assert np.array_equal(ma[key].view(np.uint32), mb[key].view(np.uint32)), (method, key, "mid-run")
+
+
+def test_plain_row_consolidation_changes_no_bit(sg, tmp_path, monkeypatch):
+    """Plain-row contexts (big maps) move the landmarks of their emptiest stale rows into the row each update opens once more
+    than a target number of rows is in use (slamgpu.cpp: do_update).  A 1 000-landmark run with the target forced down to 6
+    rows (so that every step consolidates) against the same run without: histories, final state, a mid-run view through the
+    genealogy: bit for bit; and the rows in use stay bounded where they otherwise grow with every step."""
+    import os
+    from slam_amd import host
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lmk = host.synthetic_landmarks(4321, 1000, -130, 100, -100, 90)
+    h0 = host.HostSim(["-m", os.path.join(root, "data", "example_webmap.mat"), "-method", "FASTSLAM2"])
+    _, wp = h0.map()
+    h0.close()
+    mp = str(tmp_path / "syn1000.mat")
+    host.write_map(mp, lmk, wp)
+    open(str(tmp_path / "syn1000.ini"), "w").write(open(os.path.join(root, "data", "example_webmap.ini")).read().replace(
+        "MAX_RANGE           = 60.0", "MAX_RANGE           = 20.0"))
+    N = 1024
+    tape = host.make_tape(["-m", mp, "-method", "FASTSLAM2", "-NPARTICLES", N, "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", 3], max_obs=400)
+    out = []
+    for off in (False, True):
+        monkeypatch.setenv("SLAMGPU_PLAIN_ROWS_TARGET", "6")
+        if off:
+            monkeypatch.setenv("SLAMGPU_NO_CONSOLIDATE", "1")
+        else:
+            monkeypatch.delenv("SLAMGPU_NO_CONSOLIDATE", raising=False)
+        s = sg.SlamGpu(N, tape["nlm"], method=2, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=6, math_mode=1)
+        for i, st in enumerate(tape["steps"]):
+            s.step(np.array(st["controls"], f32).reshape(-1, 3), tape["Q"], float(tape["dt"]), st["zf"], st["idf"], st["zn"], tape["R"])
+            if i == 250:
+                mid_state = s.peek(first=1, stride=3)
+        h = s.history_fetch()
+        rows = s.live_rows()  # (before the download: it flattens the genealogy)
+        out.append((s.download(), h, mid_state, rows))
+        s.close()
+    monkeypatch.delenv("SLAMGPU_NO_CONSOLIDATE", raising=False)
+    monkeypatch.delenv("SLAMGPU_PLAIN_ROWS_TARGET", raising=False)
+    (a, ha, ma, ra), (b, hb, mb, rb) = out
+    assert len(ha[0]) == len(tape["steps"]) and 50 < ha[2].sum()
+    assert ra <= 8 and rb > 40, (ra, rb)
+    for x, y in zip(ha, hb):
+        assert np.array_equal(x, y)
+    for key in ("xv", "Pv", "w", "xf", "Pf"):
+        assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), key
+        assert np.array_equal(ma[key].view(np.uint32), mb[key].view(np.uint32)), (key, "mid-run")
