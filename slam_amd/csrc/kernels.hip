@@ -1747,20 +1747,22 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                 store_lmk(idf[m + c], buf_of(m + c), la, lb);
             }
         } else {
-            // (four at a time: slots, then records, in flight together)
+            // (four at a time: slots, then records, in flight together; named values, not arrays: a register array that is
+            // written under a condition is demoted to scratch)
             for (int c0 = 0; c0 < n_cons; c0 += 4) {
-                int sl[4];
-                Rec rc[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) sl[q] = slot_of(m + min(c0 + q, n_cons - 1));
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int k = m + min(c0 + q, n_cons - 1);
-                    rc[q] = load_rec(idf[k], sl[q], buf_of(k));
-                }
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    if (c0 + q < n_cons) store_lmk(idf[m + c0 + q], buf_of(m + c0 + q), rc[q].a, rc[q].b);
+                const int k0 = m + c0, k1 = m + min(c0 + 1, n_cons - 1), k2 = m + min(c0 + 2, n_cons - 1), k3 = m + min(c0 + 3, n_cons - 1);
+                const int s0 = slot_of(k0), s1 = slot_of(k1), s2 = slot_of(k2), s3 = slot_of(k3);
+                float4 a0, a1, a2, a3;
+                float b0, b1, b2, b3;
+                load_lmk(idf[k0], s0, buf_of(k0), a0, b0);
+                load_lmk(idf[k1], s1, buf_of(k1), a1, b1);
+                load_lmk(idf[k2], s2, buf_of(k2), a2, b2);
+                load_lmk(idf[k3], s3, buf_of(k3), a3, b3);
+                // (past the end the indices repeat the last landmark: the same record stored again, by the same thread)
+                store_lmk(idf[k0], buf_of(k0), a0, b0);
+                store_lmk(idf[k1], buf_of(k1), a1, b1);
+                store_lmk(idf[k2], buf_of(k2), a2, b2);
+                store_lmk(idf[k3], buf_of(k3), a3, b3);
             }
         }
         // the landmarks this update wrote are in this particle's own slot now: that is what the genealogy row this update
