@@ -102,9 +102,10 @@ typedef struct {
 
 /* slamgpu_config.flags */
 enum {
-    /* The context will be stepped with slamgpu_step_observe (the observation front end on the device): its genealogy is
-     * kept in the plain-row layout whatever the landmark capacity, because the observation packet then lives in device memory
-     * (the compact layout of small maps reads its packet from the kernel arguments, which only the host can write). */
+    /* The context will be stepped with slamgpu_step_observe (the observation front end on the device).  Needed for landmark
+     * capacities above 39: such a context keeps its observation packets in device memory (a ring written by the front-end
+     * kernel).  Contexts of up to 39 landmarks make the observation inside the update launch and accept slamgpu_step_observe
+     * with or without the flag. */
     SLAMGPU_FLAG_DEVICE_OBSERVE = 1
 };
 
@@ -204,12 +205,15 @@ int slamgpu_observe(slamgpu_ctx *ctx, const float xtrue[3], float max_range, con
  * leaves the observation packet (idf, zf, zn) AND the bookkeeping of the landmark genealogy in device memory, then the update
  * launch, which reads them there.  Per step the host sends the controls and the pose (<= 100 bytes) and learns nothing about
  * the observation: no visibility scan over the map on the host, no packet over PCIe (16 KB per step on the 10 000-landmark
- * map).  Needs slamgpu_set_map, a context created with SLAMGPU_FLAG_DEVICE_OBSERVE, association known.
+ * map).  Needs slamgpu_set_map and known association; landmark capacities above 39 also SLAMGPU_FLAG_DEVICE_OBSERVE at
+ * creation.  Maps of up to 39 landmarks: the observation is made inside the update launch itself (every block works the
+ * packet out from the state the previous launch left: no front-end kernel, no second stream); bigger maps: a front-end
+ * kernel on a stream of its own, a step ahead of the update launches.
  * noise: 0 none; 1 the caller's normals r1[k], r2[k] for the k-th visible landmark (parity with the reference's tape);
  * 2 Philox(seed; landmark, step) on the device.  normals / strata: particle noise of TAPE-mode contexts, as slamgpu_update.
  * Landmarks beyond the context's capacity are dropped and reported by slamgpu_observe_fetch / slamgpu_num_landmarks
  * (SLAMGPU_ERR_CAPACITY).  Do not mix with slamgpu_observe / host-made observations of the same run: the association table
- * lives on the device. */
+ * lives on the device (contexts of up to 39 landmarks refuse the mix: SLAMGPU_ERR_INVALID). */
 int slamgpu_step_observe(slamgpu_ctx *ctx, const float *controls, int32_t n_controls, const float Q[4], float dt, const float xtrue[3],
                          float max_range, const float R[4], int32_t noise, const float *r1, const float *r2, const float *normals,
                          const float *strata, int32_t record_estimate);
