@@ -166,7 +166,7 @@ def test_device_made_packets_match_the_reference_tape(sg, name, mapname, N, seed
     sim.close()
 
 
-@pytest.mark.parametrize("mapname", ["example_webmap", "example_webmap:plain", "synthetic"])
+@pytest.mark.parametrize("mapname", ["example_webmap", "example_webmap:fs1", "example_webmap:plain", "synthetic"])
 def test_device_bookkeeping_equals_host_bookkeeping(sg, tmp_path, mapname, monkeypatch):
     """A run stepped with slamgpu_step_observe (packet and genealogy bookkeeping made on the device) against the same run
     stepped with slamgpu_step on the packets the device made (fetched back: the host then does the bookkeeping, in the compact
@@ -175,12 +175,13 @@ def test_device_bookkeeping_equals_host_bookkeeping(sg, tmp_path, mapname, monke
     Three device paths: the small map's compact context (the front end inside the update launch, row consolidation
     included: 1 200 observation steps), the same map with plain rows (front-end kernel on a stream of its own), a 1 000-landmark map."""
     from slam_amd import host
+    method = 1 if mapname.endswith(":fs1") else 2   # (FastSLAM 1 through the same front end: update_kernel<1, 0, false>)
     if mapname.endswith(":plain"):
-        mapname = mapname.split(":")[0]
         monkeypatch.setenv("SLAMGPU_NO_COMPACT", "1")
         plain = True
     else:
         plain = False
+    mapname = mapname.split(":")[0]
     if mapname == "synthetic":
         lmk = host.synthetic_landmarks(4321, 1000, -130, 100, -100, 90)
         h0 = host.HostSim(sim_args("example_webmap", "FASTSLAM2", 100, 7))
@@ -192,7 +193,7 @@ def test_device_bookkeeping_equals_host_bookkeeping(sg, tmp_path, mapname, monke
             "MAX_RANGE           = 60.0", "MAX_RANGE           = 20.0"))
         args, nobs = ["-m", mp, "-method", "FASTSLAM2", "-SWITCH_SEED_RANDOM", 3], 120
     else:
-        args, nobs = sim_args(mapname, "FASTSLAM2", 100, 7), (300 if plain else 1200)
+        args, nobs = sim_args(mapname, "FASTSLAM2" if method == 2 else "FASTSLAM1", 100, 7), (300 if plain else 1200)
     N = 2048
     tape = host.make_tape(args, max_obs=nobs)
     sim = host.HostSim(args)
@@ -200,7 +201,7 @@ def test_device_bookkeeping_equals_host_bookkeeping(sg, tmp_path, mapname, monke
     max_range = float(sim.conf.MAX_RANGE)
     sim.close()
     Q, R, dt = tape["Q"], tape["R"], float(tape["dt"])
-    kw = dict(method=2, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=5, math_mode=1)
+    kw = dict(method=method, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=5, math_mode=1)
     a = sg.SlamGpu(N, tape["nlm"], device_observe=True, **kw)
     a.set_map(lm)
     packets = []
@@ -221,6 +222,7 @@ def test_device_bookkeeping_equals_host_bookkeeping(sg, tmp_path, mapname, monke
     hb, db = b.history_fetch(), b.download()
     b.close()
     assert 5 < ha[2].sum() < nobs
+    assert np.isfinite(ha[1]).all()
     for x, y in zip(ha, hb):
         assert np.array_equal(x, y)
     assert da["nf"] == db["nf"]
