@@ -1056,7 +1056,7 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     // steps, and a resample composes one 16-byte chunk per particle instead of eight.  Values never change: results are bit
     // for bit those of a run without it (SLAMGPU_NO_CONSOLIDATE=1, tests/test_gpu_parity.py).
     std::vector<int32_t> cons;
-    if (c->B.compact && !sharded && !c->dist && c->consolidate && (int) c->live_rows.size() > c->consolidate_above) {
+    if (c->B.compact && !sharded && c->consolidate && (int) c->live_rows.size() > c->consolidate_above) {
         for (int j = 0; j < c->nf && m + (int) cons.size() < kSmallObs; j++)
             if (c->seen_step[j] != c->obs_step) cons.push_back(j);
         // (only worth a launch's while if it empties rows: every row but the one opened now, or as many landmarks as fit)
