@@ -148,7 +148,7 @@ struct ObsPacket {          // big packets live in device memory: uploaded once 
     int32_t status;             // device front end: kStatusCapacity if new landmarks had to be dropped
     int32_t cap;                // 0: dense layout (host packets): int32 idf[m]; float zf[2m]; float zn[2n]; int32 row[m]; int32 rows[n_rows]
                                 // C > 0: fixed layout (device packets): idf[C] zf[2C] zn[2C] row[C] rows[..], C = landmarks of the map
-    int32_t pad;
+    int32_t pad;                // device-made packets: landmarks the launch consolidates (idf / row entries behind the re-observed ones)
     // (row[k] = genealogy row of re-observed landmark k BEFORE this update | live buffer << 30 | fresh << 29; rows = the
     //  rows still in use after it, without the one this update opens: what the copy roles of a pending lazy gather compose)
 };
@@ -378,6 +378,9 @@ struct ObserveArgs {
     int32_t *live;         // [cap_nf] live record buffer of every landmark row
     int32_t *refcnt;       // [cap_rows] landmarks using each row
     int32_t cap_nf, cap_rows;
+    int32_t cons_target;   // consolidate stale rows when more than this many are in use (< 0: never), at most
+    int32_t cons_budget;   // max(cons_budget, visible / 16) landmarks per update
+    int32_t *take;         // [cap_rows] scratch
 };
 
 // all-gather of the block totals between distributed contexts that share one device and one stream (rehearsal of the

@@ -668,7 +668,7 @@ SLAM_DEV PacketView packet_view(const UpdateArgs &U) {
         V.rows_per_role = U.rows_per_role;
     }
     // (host-made packets: the landmarks the launch consolidates ride behind the re-observed ones in idf[] and row[])
-    V.n_cons = U.dev_packet ? 0 : U.n_cons;
+    V.n_cons = U.dev_packet ? ((const __attribute__((address_space(4))) ObsPacket *) reinterpret_cast<uintptr_t>(U.big))->pad : U.n_cons;
     const int a = cap ? cap : V.m, ai = cap ? cap : V.m + V.n_cons, b = cap ? cap : V.n;
     V.idf = base;
     V.zf = reinterpret_cast<const float *>(base + ai);
@@ -2236,6 +2236,29 @@ SLAM_DEV int block_exclusive_count_n(int flag, int *sh, int &total) {  // block_
     return base + before;
 }
 
+SLAM_DEV int block_exclusive_sum_n(int v, int *sh, int &total) {  // the same for values (wave scan by shuffles)
+    constexpr int NW = kObsThreads / kWave;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int o = __shfl_up(inc, d, kWave);
+        if (lane >= d) inc += o;
+    }
+    if (lane == kWave - 1) sh[wv] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+        const int c = sh[k];
+        if (k < wv) base += c;
+        tot += c;
+    }
+    total = tot;
+    __syncthreads();
+    return base + inc - v;
+}
+
 __global__ void __launch_bounds__(kObsThreads) observe_book_kernel(ObserveArgs A) {
     __shared__ int sh[kObsThreads / kWave];
     __shared__ int sh_min;
@@ -2324,9 +2347,22 @@ __global__ void __launch_bounds__(kObsThreads) observe_book_kernel(ObserveArgs A
         n = room;
     }
     __syncthreads();
+    // Row consolidation (as slamgpu.cpp: do_update does for host-made packets): past cons_target rows in use, the landmarks of
+    // stale rows -- taken in row order while they fit the budget -- are handed to the update launch behind the re-observed ones
+    // (a no-op update that rewrites their records into the particles' own slots) and join the row this update opens.
+    int n_live = 0;
+    if (A.cons_target >= 0) {
+        for (int r0 = 0; r0 < A.cap_rows; r0 += T) {
+            const int r = r0 + t;
+            int tot;
+            block_exclusive_count_n((r < A.cap_rows && A.refcnt[r] > 0) ? 1 : 0, sh, tot);
+            n_live += tot;
+        }
+    }
+    const bool want_cons = A.cons_target >= 0 && n_live > A.cons_target;
     // the row this update opens: the lowest one no landmark uses
     int e_new = -1;
-    if (m + n > 0) {
+    if (m + n > 0 || want_cons) {
         int mine = 0x7fffffff;
         for (int r = t; r < A.cap_rows; r += T)
             if (A.refcnt[r] == 0) mine = min(mine, r);
@@ -2350,6 +2386,39 @@ __global__ void __launch_bounds__(kObsThreads) observe_book_kernel(ObserveArgs A
         A.live[nf0 + k] = 0;  // a new row's first records go to buffer 0
     }
     __syncthreads();
+    int nc = 0;
+    if (want_cons) {
+        // (the re-observed landmarks have left their rows: what the counts say now is what stays behind)
+        const int budget = max(A.cons_budget, nz / 16), spare = n_live - A.cons_target;
+        int cum = 0, taken = 0;
+        for (int r0 = 0; r0 < A.cap_rows; r0 += T) {
+            const int r = r0 + t;
+            const int cnt = (r < A.cap_rows && r != e_new) ? A.refcnt[r] : 0;
+            int tot_c, tot_r;
+            const int before_c = cum + block_exclusive_sum_n(cnt, sh, tot_c);
+            const int before_r = taken + block_exclusive_count_n(cnt > 0 ? 1 : 0, sh, tot_r);
+            if (r < A.cap_rows) A.take[r] = (cnt > 0 && before_c + cnt <= budget && before_r < spare) ? 1 : 0;
+            cum += tot_c;
+            taken += tot_r;
+        }
+        __syncthreads();
+        for (int j0 = 0; j0 < nf0; j0 += T) {
+            const int j = j0 + t;
+            const int r = j < nf0 ? A.erow[j] : 0;
+            const bool mv = j < nf0 && r != e_new && A.take[r] != 0;
+            int tot;
+            const int at = m + nc + block_exclusive_count_n(mv ? 1 : 0, sh, tot);
+            if (mv) {
+                idf[at] = j;
+                row[at] = r | (A.live[j] ? kRowLiveBit : 0) | (r == fresh ? kRowFreshBit : 0);
+                A.live[j] ^= 1;
+                atomicSub(&A.refcnt[r], 1);
+                A.erow[j] = e_new;
+            }
+            nc += tot;
+        }
+        __syncthreads();
+    }
     // the rows still in use, without e_new: what a pending gather composes
     int n_rows = 0;
     for (int r0 = 0; r0 < A.cap_rows; r0 += T) {
@@ -2361,7 +2430,7 @@ __global__ void __launch_bounds__(kObsThreads) observe_book_kernel(ObserveArgs A
         n_rows += tot;
     }
     if (t == 0) {
-        if (e_new >= 0) A.refcnt[e_new] = m + n;
+        if (e_new >= 0) A.refcnt[e_new] = m + n + nc;
         P->m = m;
         P->n = n;
         P->nf = nf0;
@@ -2369,7 +2438,7 @@ __global__ void __launch_bounds__(kObsThreads) observe_book_kernel(ObserveArgs A
         P->e_new = e_new;
         P->status = dropped ? kStatusCapacity : 0;
         P->cap = C;
-        P->pad = 0;
+        P->pad = nc;  // landmarks consolidated by the update launch: idf[m .. m + nc), row[m .. m + nc)
         A.book->nf = nf0 + n;
         A.book->fresh_row = e_new;
         if (dropped) A.book->status |= kStatusCapacity;

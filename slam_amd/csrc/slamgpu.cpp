@@ -204,7 +204,7 @@ struct slamgpu_ctx {
     // refcnt_dev / book_dev are the truth and the host's vectors are stale; book_pull / book_push hand the ownership over
     bool book_on_device = false;
     DevBook *book_dev = nullptr;
-    int32_t *refcnt_dev = nullptr;
+    int32_t *refcnt_dev = nullptr, *take_dev = nullptr;
     int32_t *book_host = nullptr;    // pinned staging of book_pull / book_push
     hipStream_t obs_stream = nullptr;  // the front-end kernels run here, a step ahead of the update launches (events order them)
     hipEvent_t obs_ev[kRing]{};        // observe_book of the packet in ring slot k has finished
@@ -376,6 +376,7 @@ int book_staging(slamgpu_ctx *c) {
     HIP_TRY(hipHostMalloc((void **) &c->book_host, 4 * words, hipHostMallocDefault));
     HIP_TRY(hipMalloc((void **) &c->book_dev, sizeof(DevBook)));
     HIP_TRY(hipMalloc((void **) &c->refcnt_dev, sizeof(int32_t) * (size_t) c->B.cap_rows));
+    HIP_TRY(hipMalloc((void **) &c->take_dev, sizeof(int32_t) * (size_t) c->B.cap_rows));
     HIP_TRY(hipStreamCreateWithFlags(&c->obs_stream, hipStreamNonBlocking));
     for (int i = 0; i < kRing; i++) HIP_TRY(hipEventCreateWithFlags(&c->obs_ev[i], hipEventDisableTiming));
     return 0;
@@ -835,6 +836,7 @@ void slamgpu_destroy(slamgpu_ctx *c) {
         if (p_) (void) hipFree(p_);
     if (c->book_dev) (void) hipFree(c->book_dev);
     if (c->refcnt_dev) (void) hipFree(c->refcnt_dev);
+    if (c->take_dev) (void) hipFree(c->take_dev);
     if (c->book_host) (void) hipHostFree(c->book_host);
     for (int i = 0; i < kRing; i++)
         if (c->obs_ev[i]) (void) hipEventDestroy(c->obs_ev[i]);
@@ -1303,6 +1305,9 @@ int do_update_dev(slamgpu_ctx *c, const float xtrue[3], float max_range, const f
     A.refcnt = c->refcnt_dev;
     A.cap_nf = c->B.cap_nf;
     A.cap_rows = c->B.cap_rows;
+    A.cons_target = c->consolidate ? c->plain_rows_target : -1;
+    A.cons_budget = kPlainConsBudget;
+    A.take = c->take_dev;
     c->k->observe_book(c->obs_stream, A);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->obs_ev[slot], c->obs_stream));

@@ -166,7 +166,7 @@ def test_device_made_packets_match_the_reference_tape(sg, name, mapname, N, seed
     sim.close()
 
 
-@pytest.mark.parametrize("mapname", ["example_webmap", "example_webmap:fs1", "example_webmap:plain", "synthetic"])
+@pytest.mark.parametrize("mapname", ["example_webmap", "example_webmap:fs1", "example_webmap:plain", "synthetic", "synthetic:cons"])
 def test_device_bookkeeping_equals_host_bookkeeping(sg, tmp_path, mapname, monkeypatch):
     """A run stepped with slamgpu_step_observe (packet and genealogy bookkeeping made on the device) against the same run
     stepped with slamgpu_step on the packets the device made (fetched back: the host then does the bookkeeping, in the compact
@@ -176,6 +176,9 @@ def test_device_bookkeeping_equals_host_bookkeeping(sg, tmp_path, mapname, monke
     included: 1 200 observation steps), the same map with plain rows (front-end kernel on a stream of its own), a 1 000-landmark map."""
     from slam_amd import host
     method = 1 if mapname.endswith(":fs1") else 2   # (FastSLAM 1 through the same front end: update_kernel<1, 0, false>)
+    cons = mapname.endswith(":cons")                # (plain rows held at ~6 by consolidation, on the device and on the host)
+    if cons:
+        monkeypatch.setenv("SLAMGPU_PLAIN_ROWS_TARGET", "6")
     if mapname.endswith(":plain"):
         monkeypatch.setenv("SLAMGPU_NO_COMPACT", "1")
         plain = True
@@ -212,8 +215,9 @@ def test_device_bookkeeping_equals_host_bookkeeping(sg, tmp_path, mapname, monke
             a.peek(first=3, stride=97)
         if i % 53 == 11:
             assert a.nf() >= 0
-    ha, da = a.history_fetch(), a.download()
+    ha, rows_a, da = a.history_fetch(), a.live_rows(), a.download()
     a.close()
+    assert rows_a <= 24 if cons else (rows_a > 40 if mapname == "synthetic" else True), rows_a
     assert max(p["zf"].shape[0] for p in packets) > (12 if mapname == "synthetic" else 3)
     monkeypatch.delenv("SLAMGPU_NO_COMPACT", raising=False)
     b = sg.SlamGpu(N, tape["nlm"], **kw)
