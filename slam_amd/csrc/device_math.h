@@ -343,6 +343,30 @@ SLAM_DEV double wave_last_d(double v) {
     const int lo = __builtin_amdgcn_readlane((int) (b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int) (b >> 32), 63);
     return __longlong_as_double(((long long) hi << 32) | (unsigned int) lo);
 }
+// minimum / maximum over the 64 lanes (DPP scan, result read from lane 63): six cross-lane moves inside the VALU instead of
+// six LDS-crossbar shuffles per value
+template <int CTRL, int ROW_MASK>
+SLAM_DEV int dpp_i_or(int v, int otherwise) { return __builtin_amdgcn_update_dpp(otherwise, v, CTRL, ROW_MASK, 0xf, false); }
+SLAM_DEV int wave_min_i(int v) {
+    constexpr int id = 0x7fffffff;
+    v = min(v, dpp_i_or<0x111, 0xf>(v, id));
+    v = min(v, dpp_i_or<0x112, 0xf>(v, id));
+    v = min(v, dpp_i_or<0x114, 0xf>(v, id));
+    v = min(v, dpp_i_or<0x118, 0xf>(v, id));
+    v = min(v, dpp_i_or<0x142, 0xa>(v, id));
+    v = min(v, dpp_i_or<0x143, 0xc>(v, id));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+SLAM_DEV int wave_max_i(int v) {
+    constexpr int id = (int) 0x80000000;
+    v = max(v, dpp_i_or<0x111, 0xf>(v, id));
+    v = max(v, dpp_i_or<0x112, 0xf>(v, id));
+    v = max(v, dpp_i_or<0x114, 0xf>(v, id));
+    v = max(v, dpp_i_or<0x118, 0xf>(v, id));
+    v = max(v, dpp_i_or<0x142, 0xa>(v, id));
+    v = max(v, dpp_i_or<0x143, 0xc>(v, id));
+    return __builtin_amdgcn_readlane(v, 63);
+}
 SLAM_DEV float wave_sum_f(float v) { return wave_last_f(wave_scan_f(v)); }
 SLAM_DEV double wave_sum_d(double v) { return wave_last_d(wave_scan_d(v)); }
 

@@ -528,23 +528,41 @@ SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const f
 // never seen on the bundled maps; possible with degenerate weights) take the per-lane path.  ALL lanes of the wave must call
 // (`valid` = the lane has an output particle); distributed contexts stage peer blocks straight out of the owning GPU's memory.
 constexpr int kWinBlocks = 4;
-SLAM_DEV int64_t find_ancestor_win(double target, bool valid, const double *off, int nb, float *win, const float *__restrict__ lcum_local,
+SLAM_DEV int64_t find_ancestor_win(double target, bool valid, int guess, const double *off, int nb, float *win, const float *__restrict__ lcum_local,
                                    int nb_local, int64_t n_global, const float *__restrict__ blk_m, double M, const PeerPtrs *peers, int par) {
     const int lane = threadIdx.x & (kWave - 1);
-    int b0 = 0, b1 = valid ? nb : 0;
-    while (b0 < b1) {
-        const int mid = (b0 + b1) >> 1;
-        if (off[mid + 1] > target) b1 = mid; else b0 = mid + 1;
+    // The source block: the first b with off[b + 1] > target (nb: none).  Stratified ancestors sit near their offspring, so
+    // the search starts at the block the caller names (the particle's own) and gallops outwards -- two or three dependent LDS
+    // reads in the common case instead of the nine of a bisection over all blocks -- then bisects the bracket it found: the
+    // same answer, the predicate is monotone.
+    int b0 = 0;
+    if (valid) {
+        const int g = min(max(guess, 0), nb - 1);
+        int s_lo, s_hi;
+        if (off[g + 1] > target) {  // the answer is at or below g
+            s_hi = g;
+            s_lo = g - 1;
+            for (int step = 1; s_lo >= 0 && off[s_lo + 1] > target; step <<= 1) {
+                s_hi = s_lo;
+                s_lo -= step;
+            }
+            s_lo = max(s_lo, -1) + 1;
+        } else {                    // above g
+            s_lo = s_hi = g + 1;
+            for (int step = 1; s_hi < nb && !(off[s_hi + 1] > target); step <<= 1) {
+                s_lo = s_hi + 1;
+                s_hi += step;
+            }
+            s_hi = min(s_hi, nb);
+        }
+        while (s_lo < s_hi) {
+            const int mid = (s_lo + s_hi) >> 1;
+            if (off[mid + 1] > target) s_hi = mid; else s_lo = mid + 1;
+        }
+        b0 = s_lo;
     }
     const bool use = valid && b0 < nb;  // (beyond the last cumulative weight: undefined upstream, clamped below)
-    int lo = use ? b0 : 0x7fffffff, hi = use ? b0 : -1;
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) {
-        lo = min(lo, __shfl_xor(lo, d, kWave));
-        hi = max(hi, __shfl_xor(hi, d, kWave));
-    }
-    lo = __builtin_amdgcn_readfirstlane(lo);
-    hi = __builtin_amdgcn_readfirstlane(hi);
+    const int lo = wave_min_i(use ? b0 : 0x7fffffff), hi = wave_max_i(use ? b0 : -1);
     auto block_ptr = [&](int b) -> const float * {
         return peers ? peers[b / nb_local].lcum[par] + (size_t) (b % nb_local) * kBlock : lcum_local + (size_t) b * kBlock;
     };
@@ -1136,7 +1154,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         const int64_t gk = (int64_t) (DIST ? B.first : 0) + k;
         const double target = valid ? (double) stratum_prev(rng, gk) * W : 0.0;
         const int64_t ng = DIST ? rng.n_global : (int64_t) B.n;
-        return (int) find_ancestor_win(target, valid, offp, nbg, win, ws.lcum[ws.wpar ^ 1], nb, ng,
+        return (int) find_ancestor_win(target, valid, (int) (gk >> 8), offp, nbg, win, ws.lcum[ws.wpar ^ 1], nb, ng,
                                        (!DIST && logw) ? ws.blk_w[ws.wpar ^ 1] + 2 * nb : nullptr, Mx, DIST ? B.peers : nullptr, ws.wpar ^ 1);
     };
     if ((int) blockIdx.x >= nb) {
