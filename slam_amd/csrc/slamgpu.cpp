@@ -2310,6 +2310,7 @@ int slamgpu_ancestors(slamgpu_ctx *c, int32_t *keep) {
 int slamgpu_set_map(slamgpu_ctx *c, const float *lm, int32_t nlm) {
     if (int rc = check_ctx(c)) return rc;
     if (!lm || nlm <= 0) return fail(SLAMGPU_ERR_INVALID, "empty map");
+    if (int rc = book_pull(c)) return rc;  // (a new map starts a new landmark table: the book goes back to the host first)
     HIP_TRY(hipSetDevice(c->cfg.device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (void *p : {(void *) c->map_dev, (void *) c->obs_r_dev, (void *) c->table_dev, (void *) c->obs_out_dev})
