@@ -43,10 +43,15 @@ for case in range(CASES):
         a.step_observe(np.array(st["controls"], f32).reshape(-1, 3), Q, dt, st["true"], max_range, R, noise=2)
         packets.append(a.observe_fetch())
         if i % pk == pk - 1:
-            if rng.random() < 0.5:
+            what = rng.random()
+            if what < 0.4:
                 a.peek(first=int(rng.integers(0, 7)), stride=int(rng.integers(3, 50)))
-            else:
+            elif what < 0.7:
                 a.nf()
+            elif what < 0.85:
+                a.download()        # (flattens the genealogy: every landmark back in row 0, the book pushed again)
+            else:
+                a.estimate()
     ha, rows, da = a.history_fetch(), a.live_rows(), a.download()
     a.close()
     b = sg.SlamGpu(N, tape["nlm"], **kw)
