@@ -33,8 +33,9 @@ def test_algorithmic_and_design_bytes():
 
 
 def test_traffic_file_of_the_matching_build_is_quoted():
-    tj, exact, note = bench.load_traffic(3, "fast", 100000, 16.1)
-    assert exact and tj["config"] == 3 and abs(tj["bench_avg_launch_us"] - 16.1) < 1.0, note
+    tj, exact, note = bench.load_traffic(3, "fast", 100000, 15.0)
+    # (the latest round's `final` collection of this workload, whatever the launch time of the box that made it)
+    assert exact and tj["config"] == 3 and "_final_c3.json" in note and 10.0 < tj["bench_avg_launch_us"] < 20.0, note
     tj5, exact5, _ = bench.load_traffic(5, "fast", 100000, 1650.0)
     assert exact5 and tj5["config"] == 5 and tj5["kernels"]["fs2_update"]["hbm_bytes_per_launch"] > 1e9
     _, exact_other, note_other = bench.load_traffic(3, "fast", 12345, 16.1)
