@@ -24,9 +24,11 @@ using namespace slamgpu;
 #define SLAM_STAMP(k)
 #endif
 
-// Streaming (nontemporal) stores for the big-map kernel's landmark records: at config 5 a launch writes 2.6 GB of records
-// that nobody reads before the next launch; kept out of the L2's write-back path they cost 3 % less of the step (1.63 ->
-// 1.58 ms).  NOT for the small-map kernel (its 20 MB of results are what the next launch reads first: 16.0 -> 16.5 us).
+// Streaming (nontemporal) stores for what a launch leaves for the NEXT launch (records, pose, genealogy, weight prefix): the
+// L2 does not survive the kernel boundary, and whatever is still dirty in it when the kernel ends is written back ON the
+// boundary (MI355X_MICROARCH.md: + bytes / 6 TB/s).  Big maps (2.6 GB of records per launch): 1.63 -> 1.58 ms; small maps
+// (10 MB per launch): 14.65 -> 14.35-14.45 us per step in round 3 (round 2 had measured the opposite, 16.0 -> 16.5 us, on
+// the kernel of that time).
 typedef float nt_v4f __attribute__((ext_vector_type(4)));
 SLAM_DEV void nt_store(float4 *p, float4 v) { __builtin_nontemporal_store((nt_v4f){v.x, v.y, v.z, v.w}, reinterpret_cast<nt_v4f *>(p)); }
 SLAM_DEV void nt_store(float *p, float v) { __builtin_nontemporal_store(v, p); }
@@ -1301,17 +1303,12 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         };
         // a re-observed landmark's fresh record goes to the particle's own slot of the row's OTHER buffer
         auto store_lmk = [&, lmkA0, lmkA1, lmkB0, lmkB1](int j, int b, const float4 &la, float lb) {
-            if constexpr (BIG) {
-                nt_store(&(b ? lmkA0 : lmkA1)[(size_t) j * S + i], la);
-                nt_store(&(b ? lmkB0 : lmkB1)[(size_t) j * S + i], lb);
-            } else {
-                (b ? lmkA0 : lmkA1)[(size_t) j * S + i] = la;
-                (b ? lmkB0 : lmkB1)[(size_t) j * S + i] = lb;
-            }
+            nt_store(&(b ? lmkA0 : lmkA1)[(size_t) j * S + i], la);
+            nt_store(&(b ? lmkB0 : lmkB1)[(size_t) j * S + i], lb);
         };
         auto store_new = [&, lmkA0, lmkB0](int j, const float4 &la, float lb) {  // a new row starts in record buffer 0 (host: live flag 0)
-            lmkA0[(size_t) j * S + i] = la;
-            lmkB0[(size_t) j * S + i] = lb;
+            nt_store(&lmkA0[(size_t) j * S + i], la);
+            nt_store(&lmkB0[(size_t) j * S + i], lb);
         };
 
         // BIG: the packet sits in device memory, written before the launch and never during it: read it through the
@@ -1812,15 +1809,17 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                         else if (comp == 2) q.z = own;
                         else q.w = own;
                     }
-                    o4[(size_t) c * S + i] = q;
+                    __builtin_nontemporal_store((int __attribute__((ext_vector_type(4)))){q.x, q.y, q.z, q.w},
+                                                reinterpret_cast<int __attribute__((ext_vector_type(4))) *>(&o4[(size_t) c * S + i]));
                 }
         } else if (e_new >= 0) {
             genO[gen_index(!BIG, S, e_new, (size_t) i)] = B.first + i;
         }
-        poseAo[i] = make_float4(x, y, th, w);
+        nt_store(&poseAo[i], make_float4(x, y, th, w));
         if (METHOD == 2 && pose_dirty) {
-            poseBo[i] = make_float4(q00, q10, q11, q20);
-            poseCo[i] = make_float2(q21, q22);
+            nt_store(&poseBo[i], make_float4(q00, q10, q11, q20));
+            __builtin_nontemporal_store(q21, &poseCo[i].x);
+            __builtin_nontemporal_store(q22, &poseCo[i].y);
         }
     }
 
@@ -1865,7 +1864,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
 #pragma unroll
     for (int k = 0; k < kBlock / kWave; k++)
         if (k < wv) base += sh_w[k];
-    ws.lcum[ws.wpar][i] = base + s;
+    __builtin_nontemporal_store(base + s, &ws.lcum[ws.wpar][i]);
     if (threadIdx.x == kBlock - 1) {
         const float T = base + s;
         float q = 0.0f;
