@@ -301,6 +301,49 @@ def main():
     make_ekf(R, "traj_ekf_webmap_s7", "example_webmap", 7)
 
 
+def main_maps():
+    """Round 4: the two bundled maps that had no reference-held fixture.  example_loop2 (25 landmarks, heading known,
+    compact genealogy) and example_loop902 (117 landmarks, heading known, MAX_RANGE 10: the only reference-runnable
+    workload on the plain-row kernel with the reference's linear weights).  Same protocol as main(): reference objects =
+    truth, oracle asserted bit-identical at every observation step, tape taken from the oracle."""
+    orc.build_ref()
+    orc.build_oracle()
+    R = orc.Reference()
+    O = orc.Oracle()
+    data = os.path.join(ROOT, "data")
+
+    def args(mapname, method, N, seed):
+        return ["-m", os.path.join(data, mapname + ".mat"), "-method", method, "-NPARTICLES", N,
+                "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", seed]
+
+    def pick(ref, extra=()):
+        m = np.array([r["obs"]["zf"].shape[0] for r in ref])
+        n = np.array([r["obs"]["zn"].shape[0] for r in ref])
+        res = np.array([r["resampled"] for r in ref])
+        steps = {1, 2, 3, int(np.argmax(m)) + 1, len(ref)} | set(extra)
+        both = np.where((m > 0) & (n > 0))[0]
+        if len(both):
+            steps.add(int(both[len(both) // 2]) + 1)
+        steps.add(int(np.where(res)[0][0]) + 1)
+        steps.add(int(np.where(~res & (m > 0))[0][5]) + 1)
+        steps.add(int(np.where(res & (m >= 4))[0][-1]) + 1)
+        steps.add(int(np.where(~res & (m >= 3))[0][-1]) + 1)
+        return steps
+
+    for mapname, seed in (("example_loop2", 7), ("example_loop902", 3)):
+        short = mapname.replace("example_", "")
+        for method, tag in (("FASTSLAM2", "fs2"), ("FASTSLAM1", "fs1")):
+            a = args(mapname, method, 100, seed)
+            ref, _, _, _ = run_pair(R, O, a, set(), 10 ** 9)
+            steps = pick(ref, extra=(len(ref) // 2,))
+            ref, snaps, preds, meta = run_pair(R, O, a, steps, 10 ** 9, pred_snaps={1, 2, 9, 10, 400})
+            save_traj("traj_%s_%s_N100_s%d" % (tag, short, seed), ref, snaps, preds, meta)
+    # loop902 at N = 1000: prefix deep enough that every particle carries > 40 landmarks (plain rows well populated)
+    a = args("example_loop902", "FASTSLAM2", 1000, 3)
+    ref, snaps, preds, meta = run_pair(R, O, a, {2, 880}, 900)
+    save_traj("traj_fs2_loop902_N1000_s3", ref, snaps, preds, meta)
+
+
 def make_ekf(R, name, mapname, seed, extra=()):
     """EKF-SLAM (config 1) reference run: pose, state dimension and trace(P) after every control step."""
     a = ["-m", os.path.join(ROOT, "data", mapname + ".mat"), "-method", "EKF1", "-SWITCH_SEED_RANDOM", seed] + list(extra)
@@ -373,5 +416,7 @@ if __name__ == "__main__":
         make_assoc_kats(orc.Reference())  # per-particle association decisions (added in round 2)
     elif len(sys.argv) > 1 and sys.argv[1] == "log":
         make_log_kats(orc.Reference())  # only the logflag = 1 vectors (added in round 2)
+    elif len(sys.argv) > 1 and sys.argv[1] == "maps":
+        main_maps()  # example_loop2 / example_loop902 trajectories (added in round 4)
     else:
         main()

@@ -105,7 +105,9 @@ def test_device_front_end_sensor_noise(sg):
 
 
 # ---- the front end wired into the step: slamgpu_step_observe -----------------------------------------------------------------
-@pytest.mark.parametrize("name,mapname,N,seed", [("traj_fs2_webmap_N100_s7", "example_webmap", 100, 7), ("traj_fs2_loop1_N50_s3", "example_loop1", 50, 3)])
+@pytest.mark.parametrize("name,mapname,N,seed", [("traj_fs2_webmap_N100_s7", "example_webmap", 100, 7), ("traj_fs2_loop1_N50_s3", "example_loop1", 50, 3),
+                                                 ("traj_fs2_loop2_N100_s7", "example_loop2", 100, 7),
+                                                 ("traj_fs2_loop902_N100_s3", "example_loop902", 100, 3)])
 def test_device_made_packets_match_the_reference_tape(sg, name, mapname, N, seed):
     """slamgpu_step_observe over a whole run, fed only the controls, the true pose and the reference's random draws (sensor
     normals in visibility order, particle normals, strata: libc rand() in the reference's order, tests/test_host_frontend.py):

@@ -134,17 +134,23 @@ def test_jacobians_seam1(sg, kat):
 
 @pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
 @pytest.mark.parametrize("name,method", [("traj_fs2_webmap_N100_s7", 2), ("traj_fs1_webmap_N100_s7", 1),
-                                         ("traj_fs2_webmap_N1000_s1", 2), ("traj_fs2_loop1_N50_s3", 2)])
+                                         ("traj_fs2_webmap_N1000_s1", 2), ("traj_fs2_loop1_N50_s3", 2),
+                                         ("traj_fs2_loop2_N100_s7", 2), ("traj_fs1_loop2_N100_s7", 1),
+                                         ("traj_fs2_loop902_N100_s3", 2), ("traj_fs1_loop902_N100_s3", 1),
+                                         ("traj_fs2_loop902_N1000_s3", 2)])
 def test_teacher_forced_update_vs_golden(sg, name, method, math_mode):
     """Upload the reference's pre-update particle set, run ONE slamgpu_update with the reference's tape,
-    compare with the reference's post-update particle set."""
+    compare with the reference's post-update particle set.  Every bundled map: example_loop902 (117 landmarks: capacity
+    above kSmallRows) is the reference-pinned run of the plain-row kernel, update_kernel<.,0,true>, with the reference's
+    linear weights and SWITCH_HEADING_KNOWN (fastslam2.cpp:113-125)."""
     g = load_golden(name)
+    cap = max(40, int(g["nf"].max()))
     for k in g["snap_steps"]:
         pre = {key: g["snap%d_pre_%s" % (k, key)] for key in ("xv", "Pv", "w", "xf", "Pf")}
         exp = {key: g["snap%d_post_%s" % (k, key)] for key in ("xv", "Pv", "w", "xf", "Pf")}
         N = pre["w"].shape[0]
         pre["nf"] = pre["xf"].shape[1]
-        s = sg.SlamGpu(N, 40, method=method, n_effective=int(g["meta_n_effective"]), use_heading=bool(g["meta_use_heading"]),
+        s = sg.SlamGpu(N, cap, method=method, n_effective=int(g["meta_n_effective"]), use_heading=bool(g["meta_use_heading"]),
                        wheel_base=float(g["meta_wheel_base"]), sigma_phi=float(g["meta_sigma_phi"]), rng_mode=sg.RNG_TAPE,
                        math_mode=math_mode)
         s.upload(pre)
@@ -171,7 +177,7 @@ def test_teacher_forced_update_vs_golden(sg, name, method, math_mode):
 
 
 def test_teacher_forced_predict_vs_golden(sg):
-    for name in ("traj_fs2_webmap_N100_s7", "traj_fs2_loop1_N50_s3"):
+    for name in ("traj_fs2_webmap_N100_s7", "traj_fs2_loop1_N50_s3", "traj_fs2_loop2_N100_s7", "traj_fs2_loop902_N100_s3"):
         g = load_golden(name)
         for c in g["pred_steps"]:
             xv, Pv = g["pred%d_pre_xv" % c], g["pred%d_pre_Pv" % c]

@@ -56,7 +56,9 @@ def test_conf_defaults_and_overrides():
 
 
 @pytest.mark.parametrize("name,mapname,method,N,seed", [("traj_fs2_webmap_N100_s7", "example_webmap", "FASTSLAM2", 100, 7),
-                                                          ("traj_fs2_loop1_N50_s3", "example_loop1", "FASTSLAM2", 50, 3)])
+                                                          ("traj_fs2_loop1_N50_s3", "example_loop1", "FASTSLAM2", 50, 3),
+                                                          ("traj_fs2_loop2_N100_s7", "example_loop2", "FASTSLAM2", 100, 7),
+                                                          ("traj_fs2_loop902_N100_s3", "example_loop902", "FASTSLAM2", 100, 3)])
 def test_observation_tape_matches_reference(name, mapname, method, N, seed):
     """With the particle-noise draws interleaved in the reference's order (4 rand() per particle when the update
     samples, N for the strata), the host front end reproduces the reference's observation tape bit for bit."""

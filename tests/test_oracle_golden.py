@@ -118,7 +118,13 @@ TRAJ = [("traj_fs2_webmap_N100_s7", "example_webmap", "FASTSLAM2", 100, 7, 2172)
         ("traj_fs1_webmap_N100_s7", "example_webmap", "FASTSLAM1", 100, 7, 2172),
         ("traj_fs2_webmap_N1000_s1", "example_webmap", "FASTSLAM2", 1000, 1, 60),
         ("traj_fs2_webmap_N5000_s12345", "example_webmap", "FASTSLAM2", 5000, 12345, 8),
-        ("traj_fs2_loop1_N50_s3", "example_loop1", "FASTSLAM2", 50, 3, 400)]
+        ("traj_fs2_loop1_N50_s3", "example_loop1", "FASTSLAM2", 50, 3, 400),
+        # round 4: every bundled map has a reference-held trajectory (whole runs; loop902 = 117 landmarks, heading known)
+        ("traj_fs2_loop2_N100_s7", "example_loop2", "FASTSLAM2", 100, 7, 1589),
+        ("traj_fs1_loop2_N100_s7", "example_loop2", "FASTSLAM1", 100, 7, 1589),
+        ("traj_fs2_loop902_N100_s3", "example_loop902", "FASTSLAM2", 100, 3, 4302),
+        ("traj_fs1_loop902_N100_s3", "example_loop902", "FASTSLAM1", 100, 3, 4302),
+        ("traj_fs2_loop902_N1000_s3", "example_loop902", "FASTSLAM2", 1000, 3, 120)]
 
 
 @pytest.mark.parametrize("name,mapname,method,N,seed,nobs", TRAJ)
@@ -154,7 +160,10 @@ def test_trajectory(oracle, name, mapname, method, N, seed, nobs):
 
 
 @pytest.mark.parametrize("name,method", [("traj_fs2_webmap_N100_s7", 2), ("traj_fs1_webmap_N100_s7", 1),
-                                         ("traj_fs2_webmap_N1000_s1", 2), ("traj_fs2_loop1_N50_s3", 2)])
+                                         ("traj_fs2_webmap_N1000_s1", 2), ("traj_fs2_loop1_N50_s3", 2),
+                                         ("traj_fs2_loop2_N100_s7", 2), ("traj_fs1_loop2_N100_s7", 1),
+                                         ("traj_fs2_loop902_N100_s3", 2), ("traj_fs1_loop902_N100_s3", 1),
+                                         ("traj_fs2_loop902_N1000_s3", 2)])
 def test_teacher_forced_updates(oracle, name, method):
     """orc_update on the reference's pre-update state + tape reproduces the reference's post-update state."""
     from oracle import orc
@@ -165,7 +174,7 @@ def test_teacher_forced_updates(oracle, name, method):
         pre = {key: g["snap%d_pre_%s" % (k, key)] for key in ("xv", "Pv", "w", "xf", "Pf")}
         N = pre["w"].shape[0]
         pre["nf"] = pre["xf"].shape[1]
-        P = oracle.particles(N, 64)
+        P = oracle.particles(N, max(64, pre["nf"] + 8))
         P.set(pre)
         m, n = g["m"][k - 1], g["n"][k - 1]
         keep, neff, did = P.update(algo, g["zf"][k - 1, :m], g["idf"][k - 1, :m], g["zn"][k - 1, :n], g["meta_R"],
@@ -179,7 +188,7 @@ def test_teacher_forced_updates(oracle, name, method):
 
 def test_teacher_forced_predict(oracle):
     from oracle import orc
-    for name in ("traj_fs2_webmap_N100_s7", "traj_fs2_loop1_N50_s3"):
+    for name in ("traj_fs2_webmap_N100_s7", "traj_fs2_loop1_N50_s3", "traj_fs2_loop2_N100_s7", "traj_fs2_loop902_N100_s3"):
         g = load_golden(name)
         algo = orc.Algo(2, int(g["meta_use_heading"]), 0, 1, int(g["meta_n_effective"]), float(g["meta_wheel_base"]),
                         float(g["meta_sigma_phi"]))
