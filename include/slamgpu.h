@@ -57,8 +57,12 @@ enum {
 
 /* status bits of an update's resampling stage (slamgpu_step_status, slamgpu_history_fetch) */
 enum {
-    SLAMGPU_STATUS_DEGENERATE = 1 /* the sum of the weights was zero or not finite: the reference normalises to NaN here
-                                     (core.cpp:726-729) and so does the device; the step is flagged instead of hidden */
+    SLAMGPU_STATUS_DEGENERATE = 1, /* the sum of the weights was zero or not finite: the reference normalises to NaN here
+                                      (core.cpp:726-729) and so does the device; the step is flagged instead of hidden */
+    SLAMGPU_STATUS_CAPACITY = 4    /* slamgpu_step_observe: the device front end saw more new landmarks than the context has room
+                                      for and dropped the surplus.  Sticky for the life of the context (slamgpu_step_status);
+                                      the first call that brings the device's bookkeeping back to the host also returns
+                                      SLAMGPU_ERR_CAPACITY, once */
 };
 
 typedef struct slamgpu_ctx slamgpu_ctx;
@@ -209,7 +213,9 @@ int slamgpu_observe(slamgpu_ctx *ctx, const float xtrue[3], float max_range, con
  * creation.  Maps of up to 39 landmarks: the observation is made inside the update launch itself (every block works the
  * packet out from the state the previous launch left: no front-end kernel, no second stream); bigger maps: a front-end
  * kernel on a stream of its own, a step ahead of the update launches.
- * noise: 0 none; 1 the caller's normals r1[k], r2[k] for the k-th visible landmark (parity with the reference's tape);
+ * noise: 0 none; 1 the caller's normals r1[k], r2[k] for the k-th visible landmark (parity with the reference's tape):
+ * BOTH ARRAYS MUST HOLD AT LEAST nlm FLOATS (the map size given to slamgpu_set_map) -- the whole arrays are copied to the
+ * device before the number of visible landmarks is known there; entries past the visible count are ignored;
  * 2 Philox(seed; landmark, step) on the device.  normals / strata: particle noise of TAPE-mode contexts, as slamgpu_update.
  * Landmarks beyond the context's capacity are dropped and reported by slamgpu_observe_fetch / slamgpu_num_landmarks
  * (SLAMGPU_ERR_CAPACITY).  Do not mix with slamgpu_observe / host-made observations of the same run: the association table

@@ -418,7 +418,10 @@ class SlamGpu:
         return keep
 
     def nf(self):
-        return self.L.slamgpu_num_landmarks(self.h)
+        n = self.L.slamgpu_num_landmarks(self.h)
+        if n < 0:  # a negative slamgpu_status (e.g. SLAMGPU_ERR_CAPACITY from the device front end), never a count
+            _chk(n)
+        return n
 
     def live_rows(self):
         """genealogy rows in use (slamgpu_genealogy_rows)"""

@@ -38,6 +38,17 @@
 
 using namespace slamhost;
 
+// slamgpu_num_landmarks returns a negative slamgpu_status on failure (e.g. the device front end reported a capacity overflow):
+// never hand that to the association as a count
+static int landmark_count(slamgpu_ctx *ctx, int &rc) {
+    const int nf = slamgpu_num_landmarks(ctx);
+    if (nf < 0) {
+        rc = nf;
+        return 0;
+    }
+    return nf;
+}
+
 static void usage(const char *a0) {
     printf("%s\n", a0);
     printf("    -m                  [s] input map file name\n");
@@ -155,7 +166,9 @@ static int run_distributed(Simulator &sim, int k, long maxsteps, FILE *log, Plot
         iter++;
         if (r != 1) continue;
         sim.observe();
-        sim.associate_known(slamgpu_num_landmarks(ctx[0]), zf, idf, zn);
+        const int nf_now = landmark_count(ctx[0], rc);
+        if (rc) break;
+        sim.associate_known(nf_now, zf, idf, zn);
         rc = slamgpu_dist_group_step(grp, controls.data(), (int) (controls.size() / 3), sim.Qe, sim.dt, zf.data(), idf.data(), (int) idf.size(),
                                      zn.data(), (int) (zn.size() / 2), sim.Re, 1);
         controls.clear();
@@ -225,7 +238,9 @@ static int run_batched(Simulator &sim, slamgpu_ctx *ctx, bool observe_dev, long 
                                       c.SWITCH_SENSOR_NOISE ? 2 : 0, nullptr, nullptr, nullptr, nullptr, 1);
         } else {
             sim.observe();
-            sim.associate_known(slamgpu_num_landmarks(ctx), zf, idf, zn);
+            const int nf_now = landmark_count(ctx, rc);
+            if (rc) break;
+            sim.associate_known(nf_now, zf, idf, zn);
             rc = slamgpu_step(ctx, controls.data(), (int) (controls.size() / 3), sim.Qe, sim.dt, zf.data(), idf.data(), (int) idf.size(), zn.data(),
                               (int) (zn.size() / 2), sim.Re, nullptr, nullptr, 1);
         }
@@ -447,7 +462,12 @@ int main(int argc, char **argv) {
                         break;
                     }
                 } else {
-                    sim.associate_known(slamgpu_num_landmarks(ctx), zf, idf, zn);
+                    const int nf_now = landmark_count(ctx, rc);
+                    if (rc) {
+                        fprintf(stderr, "slamgpu: %s\n", slamgpu_last_error());
+                        break;
+                    }
+                    sim.associate_known(nf_now, zf, idf, zn);
                 }
                 const float *nm = nullptr, *st = nullptr;
                 if (parity) {
@@ -488,7 +508,7 @@ int main(int argc, char **argv) {
             mark = now;
             plot.setCurrentIteration((uint32_t) iter);
             if (ctx) {  // drawParticles / drawFeatureParticles (ParticleSLAMWrapper.cpp:34-54), decimated
-                const int nfl = slamgpu_num_landmarks(ctx);
+                const int nfl = std::max(0, slamgpu_num_landmarks(ctx));
                 px.clear(); py.clear(); fx.clear(); fy.clear();
                 // one strided read-only view per iteration (slamgpu_peek: one kernel, through the genealogy, nothing rewritten)
                 const int cnt = (N + stride - 1) / stride;

@@ -203,6 +203,7 @@ struct slamgpu_ctx {
     // device-resident genealogy bookkeeping (slamgpu_step_observe): while book_on_device the tables erow_dev / live_dev /
     // refcnt_dev / book_dev are the truth and the host's vectors are stale; book_pull / book_push hand the ownership over
     bool book_on_device = false;
+    int32_t front_status = 0;        // sticky kStatus* bits of the device front end seen by book_pull (carried back by book_push)
     DevBook *book_dev = nullptr;
     int32_t *refcnt_dev = nullptr, *take_dev = nullptr;
     int32_t *book_host = nullptr;    // pinned staging of book_pull / book_push
@@ -441,7 +442,9 @@ int book_pull(slamgpu_ctx *c) {
         c->nf = nf;
         c->fresh_row = h->hdr.fresh_row;
         book_rebuild(c);
-        if (h->hdr.status & kStatusCapacity)
+        const bool first_seen = (h->hdr.status & kStatusCapacity) && !(c->front_status & kStatusCapacity);
+        c->front_status |= h->hdr.status;
+        if (first_seen)  // (reported as an error once; the bit stays: slamgpu_step_status)
             return fail(SLAMGPU_ERR_CAPACITY, "the device front end dropped new landmarks: landmark capacity %d exceeded", c->B.cap_nf);
         return 0;
     }
@@ -462,7 +465,9 @@ int book_pull(slamgpu_ctx *c) {
     c->nf = nf;
     c->fresh_row = hb->fresh_row;
     book_rebuild(c);
-    if (hb->status & kStatusCapacity)
+    const bool first_seen = (hb->status & kStatusCapacity) && !(c->front_status & kStatusCapacity);
+    c->front_status |= hb->status;
+    if (first_seen)
         return fail(SLAMGPU_ERR_CAPACITY, "the device front end dropped new landmarks: landmark capacity %d exceeded", c->B.cap_nf);
     return 0;
 }
@@ -488,7 +493,7 @@ int book_push(slamgpu_ctx *c) {
         if (seen != c->nf)
             return fail(SLAMGPU_ERR_INVALID, "slamgpu_step_observe on a compact context: %d of its %d landmarks came from host-made packets, "
                         "which the device's landmark table does not know", c->nf - seen, c->nf);
-        h->hdr = FrontHdr{c->nf, c->fresh_row, 0, 0};
+        h->hdr = FrontHdr{c->nf, c->fresh_row, c->front_status, 0};
         HIP_TRY(hipMemcpyAsync(c->front_dev + c->front_par, h, sizeof *h, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->book_on_device = true;
@@ -502,6 +507,7 @@ int book_push(slamgpu_ctx *c) {
     *hb = DevBook{};
     hb->nf = c->nf;
     hb->fresh_row = c->fresh_row;
+    hb->status = c->front_status;
     std::copy(c->erow.begin(), c->erow.begin() + cn, h_erow);
     std::copy(c->live_flag.begin(), c->live_flag.begin() + cn, h_live);
     std::copy(c->refcnt.begin(), c->refcnt.begin() + cr, h_ref);
@@ -2287,7 +2293,7 @@ int slamgpu_step_status(slamgpu_ctx *c, int32_t *status) {
     if (int rc = check_ctx(c)) return rc;
     if (!status) return fail(SLAMGPU_ERR_INVALID, "null output");
     if (int rc = read_ctrl(c)) return rc;
-    *status = c->ctrl_host->status;
+    *status = c->ctrl_host->status | (c->front_status & kStatusCapacity);
     return 0;
 }
 
@@ -2646,6 +2652,9 @@ int slamgpu_download_range(slamgpu_ctx *c, int32_t first, int32_t count, float *
     if (int rc = check_ctx(c)) return rc;
     if (first < 0 || count < 0 || (int64_t) first + count > c->B.n)
         return fail(SLAMGPU_ERR_INVALID, "particle range [%d, %d) outside [0, %d)", first, first + count, c->B.n);
+    // after device-driven steps the landmark count and the genealogy book live on the device: bring them back BEFORE deciding
+    // from c->nf whether the records need flattening (a C caller need not have asked for the count first)
+    if (int rc = book_pull(c)) return rc;
     if ((xf || Pf4) && c->nf > 0) {
         if (int rc = flush_predict(c)) return rc;
         if (int rc = flatten(c)) return rc;  // records into their particles' own slots

@@ -125,7 +125,7 @@ def test_device_made_packets_match_the_reference_tape(sg, name, mapname, N, seed
     s.set_map(lm)
     T = g["ctl"].shape[0]
     k, ctl, worst = 0, [], 0.0
-    est = []
+    hist = []
     while k < T:
         r, V, G, phi = sim.control()
         assert r >= 0
@@ -153,7 +153,11 @@ def test_device_made_packets_match_the_reference_tape(sg, name, mapname, N, seed
                 if got.size:
                     worst = max(worst, float(np.abs(got[:, 1].astype(np.float64) - exp[:, 1]).max() / 2.384185791015625e-07))
         k += 1
-    xyt, ne, rs = s.history_fetch()
+        if k % 2048 == 0:   # (the device-side history holds 4 096 steps; example_loop902 runs 4 302)
+            hist.append(s.history_fetch()[0])
+    hist.append(s.history_fetch()[0])
+    xyt = np.concatenate(hist)
+    assert xyt.shape[0] == T
     assert s.nf() == int(g["nf"][T - 1]) or s.nf() == int(g["nf"][T - 1]) + int(g["n"][T - 1])
     # bearings: the device rounds a double atan2 once, the reference calls glibc's atan2f: one ulp apart at most, and the
     # ulp of the intermediate atan2 - phi (up to 2 pi in magnitude) is two units of 2^-22
@@ -251,3 +255,73 @@ def test_one_front_end_per_compact_context(sg):
         s.step_observe(ctl, Q, float(dt), sim.true_pose(), float(sim.conf.MAX_RANGE), R, noise=2)
     s.close()
     sim.close()
+
+
+@pytest.mark.parametrize("plain", [False, True], ids=["compact", "plain_rows"])
+def test_c_download_straight_after_device_steps(sg, monkeypatch, plain):
+    """A C caller may call slamgpu_download with capacity-sized buffers right after device-driven steps and ask for the
+    landmark count afterwards (round-3 advisor finding: the host's count was stale then, the genealogy was not composed and
+    the records came back slot-major).  The entry is called directly here -- no slamgpu_num_landmarks before it, as the Python
+    wrapper would do -- and compared with a twin context read the usual way."""
+    import ctypes as C
+    from slam_amd import host
+    from slam_amd.capi import _chk, _ptr
+    if plain:
+        monkeypatch.setenv("SLAMGPU_NO_COMPACT", "1")
+    args = sim_args("example_webmap", "FASTSLAM2", 100, 7)
+    tape = host.make_tape(args, max_obs=150)
+    sim = host.HostSim(args)
+    lm, _ = sim.map()
+    max_range = float(sim.conf.MAX_RANGE)
+    sim.close()
+    N, cap = 1024, tape["nlm"]
+    out = []
+    for direct in (True, False):
+        s = sg.SlamGpu(N, cap, method=2, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=5, math_mode=1, device_observe=True)
+        s.set_map(lm)
+        for st in tape["steps"]:
+            s.step_observe(np.array(st["controls"], f32).reshape(-1, 3), tape["Q"], float(tape["dt"]), st["true"], max_range, tape["R"], noise=2)
+        if direct:
+            xv, Pv, w = np.zeros((N, 3), f32), np.zeros((N, 9), f32), np.zeros(N, f32)
+            xf, Pf = np.full(N * cap * 2, np.nan, f32), np.full(N * cap * 4, np.nan, f32)
+            _chk(s.L.slamgpu_download(s.h, _ptr(xv), _ptr(Pv), _ptr(w), _ptr(xf), _ptr(Pf)))
+            nf = s.nf()
+            assert nf > 10
+            out.append(dict(nf=nf, xv=xv, w=w, xf=xf[:N * nf * 2].reshape(N, nf, 2), Pf=Pf[:N * nf * 4].reshape(N, nf, 2, 2)))
+        else:
+            out.append(s.download())
+        s.close()
+    a, b = out
+    assert a["nf"] == b["nf"]
+    for key in ("xv", "w", "xf", "Pf"):
+        assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), key
+    assert np.isfinite(a["xf"]).all()
+
+
+def test_capacity_overflow_of_the_device_front_end_stays_flagged(sg):
+    """More landmarks in view than the context has room for: the device front end drops the surplus and says so.  The first
+    call that brings the bookkeeping back reports SLAMGPU_ERR_CAPACITY; after that the run goes on, but slamgpu_step_status keeps
+    SLAMGPU_STATUS_CAPACITY set -- also after further device-driven steps (the bit travels back to the device with the book)."""
+    from slam_amd import host
+    args = sim_args("example_webmap", "FASTSLAM2", 100, 7)
+    tape = host.make_tape(args, max_obs=12)
+    sim = host.HostSim(args)
+    lm, _ = sim.map()
+    max_range = float(sim.conf.MAX_RANGE)
+    sim.close()
+    N = 512
+    s = sg.SlamGpu(N, 4, method=2, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=5, math_mode=1, device_observe=True)
+    s.set_map(lm)  # 35 landmarks in the map, room for 4 (six are seen on the first observation)
+    step = lambda st: s.step_observe(np.array(st["controls"], f32).reshape(-1, 3), tape["Q"], float(tape["dt"]), st["true"], max_range, tape["R"], noise=2)
+    for st in tape["steps"][:4]:
+        step(st)
+    with pytest.raises(sg.SlamGpuError) as e:
+        s.nf()
+    assert e.value.code == -3
+    assert s.nf() == 4           # reported once; the count is usable afterwards
+    assert s.status() & 4
+    for st in tape["steps"][4:8]:
+        step(st)                  # the book goes back to the device, the bit with it
+    assert s.nf() == 4
+    assert s.status() & 4
+    s.close()
