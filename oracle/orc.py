@@ -12,6 +12,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "liboracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libslamref.so")
+# the same objects built with -DJACOBIAN_ACCELERATOR and tests/cabi/accel_shim.h: computeJacobians runs on the GPU
+REF_ACCEL_SO = os.path.join(HERE, "_ref", "libslamref_accel.so")
 
 f32 = np.float32
 fp = C.POINTER(C.c_float)
@@ -511,10 +513,17 @@ class Oracle(_FuncLib):
 class Reference(_FuncLib):
     """The reference's own objects behind oracle/ref_driver.cpp (authoring container only)."""
 
-    def __init__(self):
-        if not have_ref():
-            raise RuntimeError("oracle/_ref/libslamref.so not built (needs /root/reference)")
-        super().__init__(REF_SO, "ref_")
+    def __init__(self, accel=False):
+        if accel:
+            if not os.path.exists(REF_ACCEL_SO):
+                raise RuntimeError("oracle/_ref/libslamref_accel.so not built (needs /root/reference and libslamgpu.so)")
+            super().__init__(REF_ACCEL_SO, "ref_")
+            if self.lib.ref_accel_init() != 0:
+                raise RuntimeError("the reference's AcceleratorHandler (tests/cabi/accel_shim.h) found no GPU")
+        else:
+            if not have_ref():
+                raise RuntimeError("oracle/_ref/libslamref.so not built (needs /root/reference)")
+            super().__init__(REF_SO, "ref_")
         L = self.lib
         L.ref_rand_stream.argtypes = [C.c_uint, C.c_int, C.c_void_p]
         L.ref_randn.argtypes = [C.c_uint, C.c_int, C.c_int, C.c_void_p]

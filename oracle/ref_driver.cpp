@@ -29,6 +29,21 @@
 using namespace std;
 using namespace Eigen;
 
+#ifdef REF_DRIVER_ACCEL
+// -DJACOBIAN_ACCELERATOR build (oracle/Makefile: refaccel): the global the reference defines in
+// SLAMBackendApplication.cpp:11-14 and creates before its wrapper (:22-24); here on first use.
+AcceleratorHandler *acceleratorHandler = nullptr;
+extern "C" int ref_accel_init() {
+    try {
+        if (!acceleratorHandler) acceleratorHandler = new AcceleratorHandler();
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "ref_accel_init: %s\n", e.what());
+        return -1;
+    }
+}
+#endif
+
 namespace {
 
 struct OpenFS2 : FastSLAM2 {

@@ -1,0 +1,47 @@
+"""CPU side of the executable boundary (tests/cabi): the two reference-side bindings INTEGRATION.md documents compile with
+plain g++ against include/slamgpu.h, the harness library links, and -- where the reference tree is present (authoring
+container) -- they compile against the reference's own headers and Eigen, the adapter instantiated with the reference's
+Particle / VectorXf / MatrixXf and called the way fastslam2wrapper.cpp:64,88 calls its algorithm object, the handler in the
+place of AcceleratorHandler.h inside the reference's -DJACOBIAN_ACCELERATOR branch of core.cpp."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+
+
+def test_harness_builds_and_exports():
+    import slam_amd
+    slam_amd.load_library()   # libslamgpu.so must exist for the link (built by __graft_entry__.build())
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "cabi")])
+    L = C.CDLL(os.path.join(HERE, "cabi", "libcabi_driver.so"))
+    for sym in ("cabi_compute_jacobians", "cabi_algo_create", "cabi_algo_predict", "cabi_algo_update", "cabi_algo_estimate",
+                "cabi_algo_landmarks", "cabi_algo_fetch", "cabi_algo_destroy", "cabi_last_error"):
+        assert hasattr(L, sym), sym
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src", "backend")), reason="reference tree absent (GPU box)")
+def test_bindings_compile_against_the_reference_headers(tmp_path):
+    flags = ["g++", "-std=c++11", "-fsyntax-only", "-w", "-msse", "-D__STDC_CONSTANT_MACROS", "-I" + os.path.join(ROOT, "include"),
+             "-I" + os.path.join(HERE, "cabi"), "-I" + REF, "-I" + os.path.join(REF, "src", "backend"), "-I" + os.path.join(REF, "libs", "eigen3")]
+    # seam 1: the reference's core.cpp, accelerator branch, with the drop-in class where AcceleratorHandler.h would be
+    subprocess.check_call(flags + ["-DJACOBIAN_ACCELERATOR", "-DSLAM_OCMHANDLER_H", "-include", os.path.join(HERE, "cabi", "accel_shim.h"),
+                                   os.path.join(REF, "src", "backend", "core.cpp")])
+    # seam 2: the adapter over the reference's types, called with the wrapper's argument lists
+    tu = tmp_path / "adapter_tu.cpp"
+    tu.write_text('''
+#include "core.h"
+#include "fastslam2gpu_adapter.h"
+template class FastSLAMGpuT<Particle, VectorXf, MatrixXf>;
+typedef FastSLAMGpuT<Particle, VectorXf, MatrixXf> FastSLAM2Gpu;
+void wrapper_calls(FastSLAM2Gpu *algorithm, vector<Particle> &particles, VectorXf &xTrue, float Vn, float Gn, MatrixXf &Qe, float dt,
+                   vector<VectorXf> &zf, vector<VectorXf> &zn, vector<int> &idf, vector<VectorXf> &z, VectorXf &table, MatrixXf &Re) {
+    algorithm->predict(particles, xTrue, Vn, Gn, Qe, dt);
+    algorithm->update(particles, zf, zn, idf, z, table, Re);
+}
+''')
+    subprocess.check_call(flags + [str(tu)])

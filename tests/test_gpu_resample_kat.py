@@ -1,0 +1,115 @@
+"""a10 on the device, index by index, on the reference-held vectors.
+
+tests/golden/kat_functions.npz holds, for N in {50, 100, 500, 1000, 5000}, a weight vector `res<N>_w` and what the reference's
+own stratifiedResample (core.cpp:780-824; strata from stratifiedRandom after srand(7), core.cpp:751-769) returned for it:
+`res<N>_keep` (the ancestor of every output particle) and `res<N>_neff`.  Here the same weights and the same strata (libc
+rand() after srand(7), drawn by libslamhost in the reference's order) go through the DEVICE's resampling stage, both ways it
+exists:
+
+  stage   resample_kernel / finish_kernel as launches of their own (what slamgpu_stats / slamgpu_ancestors force), and
+  inline  the plan at the head of the NEXT update launch (the product's one-launch-per-step pipeline); the ancestors are then
+          read off the particles themselves (every particle carries its index in its pose).
+
+The device sums the UN-normalised weights in double (block totals + in-block prefixes) and compares `stratum * sum` with that
+prefix; the reference normalises in float32 (w / sum, serial float sum, core.cpp:726-729) and compares the stratum with a
+float32 cumulative sum that restarts from zero for every prefix (core.cpp:813-824).  The two can only differ where a stratum
+lies within the float32 rounding of a cumulative-sum boundary; every mismatch below is checked to be exactly that (one
+neighbour, stratum within 4 float32 ulps of the float64 boundary).  Measured on MI355X (both builds, both paths):
+identical ancestor lists for every N -- the bound in the test is 0 mismatches for N <= 1000 and <= 2 for N = 5000."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+NS = [50, 100, 500, 1000, 5000]
+
+
+@pytest.fixture(scope="module")
+def sg():
+    import slam_amd
+    assert slam_amd.device_count() >= 1, "GPU tests need a HIP device"
+    return slam_amd
+
+
+def reference_strata(N):
+    from slam_amd import host
+    host.load_library()
+    ctypes.CDLL(None).srand(7)   # the reference: srand(7) then stratifiedRandom(N): N rand() values
+    cnt, sel = host.draw_strata(N)
+    assert cnt == N
+    return sel
+
+
+def explain(w, sel, keep_gpu, keep_ref):
+    """every differing ancestor: a neighbour, and its stratum sits on a cumulative-sum boundary to float32 rounding"""
+    bad = np.nonzero(keep_gpu != keep_ref)[0]
+    if bad.size == 0:
+        return 0
+    c = np.cumsum(w.astype(np.float64))
+    c /= c[-1]
+    for i in bad:
+        a, b = int(keep_gpu[i]), int(keep_ref[i])
+        assert abs(a - b) == 1, (i, a, b)
+        boundary = c[min(a, b)]
+        assert abs(float(sel[i]) - boundary) <= 4 * np.spacing(f32(boundary)), (i, a, b, float(sel[i]), boundary)
+    return int(bad.size)
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+@pytest.mark.parametrize("N", NS)
+def test_resample_stage_vs_reference_vectors(sg, kat, N, math_mode):
+    w, keep_ref, neff_ref = kat["res%d_w" % N], kat["res%d_keep" % N], float(kat["res%d_neff" % N][0])
+    xv = np.zeros((N, 3), f32)
+    xv[:, 0] = np.arange(N)   # every particle carries its own index
+    st = dict(nf=0, xv=xv, Pv=np.zeros((N, 3, 3), f32), w=w, xf=None, Pf=None)
+    R = np.array([[0.01, 0], [0, 3e-4]], f32)
+    none2, nonei = np.zeros((0, 2), f32), np.zeros(0, np.int32)
+    worst = 0
+    for path in ("stage", "inline"):
+        s = sg.SlamGpu(N, 1, method=2, n_effective=N, rng_mode=sg.RNG_TAPE, math_mode=math_mode)   # nMin = N: the resample fires
+        s.upload(st)
+        sel = reference_strata(N)  # (after the context exists: initialising HIP consumes rand() values)
+        s.update(none2, nonei, none2, R, None, sel)   # zf = zn = {}: FastSLAM2::update is resampleParticles alone (fastslam2.cpp:45)
+        if path == "stage":
+            neff, did, wsum = s.stats()
+            keep = s.ancestors()
+        else:
+            # a second, empty update: its launch plans and applies the first one's resampling stage at its head; uniform
+            # weights afterwards (Neff = N, not < nMin): no second resample, the particles stay where the first one put them
+            s.update(none2, nonei, none2, R, None, np.ascontiguousarray(sel[::-1]))
+            got = s.download(landmarks=False)
+            keep = np.rint(got["xv"][:, 0]).astype(np.int32)
+            assert np.array_equal(got["xv"][:, 0], keep.astype(f32))
+            assert np.all(got["w"] == f32(1.0) / f32(N))
+            neff, did = None, True
+        assert did
+        if neff is not None:
+            np.testing.assert_allclose(neff, neff_ref, rtol=2e-6)   # (double sums on the device, float32 in the reference)
+            np.testing.assert_allclose(wsum, w.astype(np.float64).sum(), rtol=1e-12)
+        assert np.all(np.diff(keep) >= 0) and keep.min() >= 0 and keep.max() < N
+        nbad = explain(w, sel, keep, keep_ref)
+        worst = max(worst, nbad)
+        print("resample KAT N=%d %s %s: %d of %d ancestors differ from the reference's" % (N, ("strict", "fast")[math_mode], path, nbad, N))
+        s.close()
+    assert worst <= (0 if N <= 1000 else 2), worst
+
+
+@pytest.mark.parametrize("N", [100, 1000])
+def test_no_resample_above_threshold_normalises_like_the_reference(sg, kat, N):
+    """Neff >= nMin: resampleParticles only normalises (core.cpp:726-731): w / sum w, float32."""
+    w = kat["res%d_w" % N]
+    s = sg.SlamGpu(N, 1, method=2, n_effective=1, rng_mode=sg.RNG_TAPE, math_mode=0)
+    s.upload(dict(nf=0, xv=np.zeros((N, 3), f32), Pv=np.zeros((N, 3, 3), f32), w=w, xf=None, Pf=None))
+    sel = reference_strata(N)
+    s.update(np.zeros((0, 2), f32), np.zeros(0, np.int32), np.zeros((0, 2), f32), np.array([[0.01, 0], [0, 3e-4]], f32), None, sel)
+    neff, did, _ = s.stats()
+    assert not did
+    np.testing.assert_allclose(neff, float(kat["res%d_neff" % N][0]), rtol=2e-6)
+    got = s.download(landmarks=False)["w"]
+    ws = f32(0)
+    for x in w:              # the reference's serial float32 sum (core.cpp:726-729)
+        ws = f32(ws + x)
+    np.testing.assert_allclose(got, w / ws, rtol=3e-7)
+    s.close()
