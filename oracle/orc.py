@@ -213,13 +213,13 @@ class Particles:
     def nf(self):
         return self.L.orc_particles_nf(self.h)
 
-    def get(self):
+    def get(self, landmarks=True):
         nf, N = self.nf(), self.N
         xv = np.zeros((N, 3), f32)
         Pv = np.zeros((N, 3, 3), f32)
         w = np.zeros(N, f32)
-        xf = np.zeros((N, nf, 2), f32)
-        Pf = np.zeros((N, nf, 2, 2), f32)
+        xf = np.zeros((N, nf, 2), f32) if landmarks else None
+        Pf = np.zeros((N, nf, 2, 2), f32) if landmarks else None
         self.L.orc_particles_get(self.h, _p(xv), _p(Pv), _p(w), _p(xf), _p(Pf))
         return dict(xv=xv, Pv=Pv, w=w, xf=xf, Pf=Pf, nf=nf)
 
@@ -324,8 +324,8 @@ class OrcSim(Sim):
     def estimate(self):
         return self.P.estimate()
 
-    def particles(self):
-        return self.P.get()
+    def particles(self, landmarks=True):
+        return self.P.get(landmarks)
 
     def algo(self):
         return self.L.orc_sim_algo(self.h).contents

@@ -70,26 +70,32 @@ def ensure(cond, what):
         assert cond, what
 
 
-def _mk(sg, o, N, method, rng_mode, math_mode, seed):
+def _mk(sg, o, N, method, rng_mode, math_mode, seed, log_weights=False):
     algo = o.algo()
     return sg.SlamGpu(N, o.nlm, method=2 if method == "FASTSLAM2" else 1, n_effective=algo.n_effective,
                       use_heading=bool(algo.use_heading), add_predict_noise=bool(algo.add_predict_noise), wheel_base=algo.wheel_base,
-                      sigma_phi=algo.sigma_phi, rng_mode=rng_mode, seed=seed, math_mode=math_mode)
+                      sigma_phi=algo.sigma_phi, rng_mode=rng_mode, seed=seed, math_mode=math_mode, log_weights=log_weights)
 
 
-def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None, threads=1, mapname="example_webmap"):
+def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None, threads=1, mapname="example_webmap", args=None,
+               log_weights=False, full_at=None, tol_scale=1.0, on_step=None):
     """Drive oracle + GPU as described in the module docstring.  window = (lo, hi): observation steps (1-based) whose full
-    state is compared; None = every step.  Returns the per-run statistics, the inputs (for the undisturbed replay) and the
-    GPU's final state / history."""
+    state is compared; None = every step.  full_at(k) (optional): on steps inside the window where it is false only the poses
+    and the weights are read and compared (big maps: the landmark records of a step are tens of MB).  args: the simulation's
+    command line when it is not a bundled map; log_weights: both sides keep log-weights.  Returns the per-run statistics,
+    the inputs (for the undisturbed replay) and the GPU's final state / history."""
     fs2 = method == "FASTSLAM2"
     oracle.set_threads(threads)
-    o = oracle.sim(sim_args(mapname, method, N, seed))
+    o = oracle.sim(args if args is not None else sim_args(mapname, method, N, seed))
     if philox:
         o.set_rng(1, seed)
+    if log_weights:
+        o.set_log_weights(True)
     algo = o.algo()
     Q, R, dt = o.noise()
-    s = _mk(sg, o, N, method, sg.RNG_PHILOX if philox else sg.RNG_TAPE, math_mode, seed)
-    tol = FREE_W[math_mode]
+    s = _mk(sg, o, N, method, sg.RNG_PHILOX if philox else sg.RNG_TAPE, math_mode, seed, log_weights)
+    tol = {key: v * tol_scale for key, v in FREE_W[math_mode].items()}
+    hist_parts = []
     st = dict(steps=0, resamples=0, decision_diff=0, anc_diff=0, anc_far=0, anc_maxd=0, anc_tot=0, max_pose=0.0, max_lmk=0.0, max_w_median=0.0, max_w_p99=0.0,
               max_w=0.0, max_neff_rel=0.0)
     inputs, ctl = [], []
@@ -113,11 +119,15 @@ def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None
         inputs.append(dict(ctl=ctl, zf=ob["zf"], idf=ob["idf"], zn=ob["zn"], normals=normals, sel=sel))
         ctl = []
         k += 1
+        if (k & 2047) == 0:   # (the device-side history holds 4 096 steps)
+            hist_parts.append(s.history_fetch())
         ne_g, did_g, _ = s.stats()
         keep = s.ancestors() if did_g else None
         if did_g:
             # yardstick: ancestors from a float64 cumulative sum of the oracle's (not yet normalised) weights, same strata
             w64 = o.P.weights().astype(np.float64)
+            if log_weights:
+                w64 = np.exp(w64 - w64.max())
             cum = np.cumsum(w64)
             sel64 = o.last_tape()[1].astype(np.float64)
             anc64 = np.minimum(np.searchsorted(cum, sel64 * cum[-1], side="right"), N - 1)
@@ -145,11 +155,16 @@ def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None
             st["own_far64"] = st.get("own_far64", 0) + int(np.count_nonzero(np.abs(anc64 - own) > 1))
             st["own_diff64"] = st.get("own_diff64", 0) + int(np.count_nonzero(anc64 != own))
             assert np.all(np.diff(keep) >= 0) and keep.min() >= 0 and keep.max() < N, tag
+        if on_step:
+            on_step(k, s)
         if window is not None and not (window[0] <= k <= window[1]):
             continue
-        got = s.peek()
-        exp = o.particles()
+        full = full_at is None or full_at(k)
+        got = s.peek(landmarks=full)
+        exp = o.particles(landmarks=full)
         assert got["nf"] == exp["nf"], tag
+        if not full:
+            got["nf"] = 0
         dxv = np.abs(got["xv"].astype(np.float64) - exp["xv"])
         dxv[:, 2] = np.minimum(dxv[:, 2], np.abs(dxv[:, 2] - 2 * np.pi))  # headings next to +-pi
         dp = float(dxv.max())
@@ -164,10 +179,19 @@ def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None
             sc = np.abs(exp["Pf"]).max()
             st["max_Pf_rel"] = max(st.get("max_Pf_rel", 0.0), float(np.abs(got["Pf"].astype(np.float64) - sym(exp["Pf"])).max() / max(sc, 1e-12)))
         if did_g:
-            assert np.all(got["w"] == exp["w"]), tag  # 1/N on both sides
+            if log_weights:   # log(1/N) on both sides, each from its own logf
+                assert np.abs(got["w"] - exp["w"]).max() <= 2e-6 * abs(np.log(N)), tag
+            else:
+                assert np.all(got["w"] == exp["w"]), tag  # 1/N on both sides
         else:
             g, e = got["w"].astype(np.float64), exp["w"].astype(np.float64)
-            assert abs(g.sum() - 1.0) <= 1e-4 and abs(e.sum() - 1.0) <= 1e-4, tag
+            if log_weights:   # compared as weights: exp(l), normalised on both sides
+                assert np.isfinite(g).all() and np.isfinite(e).all(), tag
+                g, e = np.exp(g), np.exp(e)
+                assert abs(g.sum() - 1.0) <= 2e-3 and abs(e.sum() - 1.0) <= 2e-3, (tag, g.sum(), e.sum())
+                g, e = g / g.sum(), e / e.sum()
+            else:
+                assert abs(g.sum() - 1.0) <= 1e-4 and abs(e.sum() - 1.0) <= 1e-4, tag
             rel = np.abs(g / e - 1.0)
             if fs2:
                 st["max_w_median"] = max(st["max_w_median"], float(np.median(rel)))
@@ -181,7 +205,9 @@ def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None
         eg, eo = got["xv"][:, :2].astype(np.float64).mean(axis=0), o.estimate()[:2]
         st["max_est"] = max(st.get("max_est", 0.0), float(np.abs(eg - eo).max()))
         ensure(np.abs(eg - eo).max() <= 1e-3, (tag, eg, eo))
-    hist = s.history_fetch()
+    hist_parts.append(s.history_fetch())
+    hist = tuple(np.concatenate([h[j] for h in hist_parts]) for j in range(3))
+    st["rows_in_use"] = s.live_rows()
     final = s.download()
     final_exp = o.particles()
     s.close()
@@ -190,11 +216,11 @@ def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None
     return st, inputs, (Q, R, float(dt)), hist, final, final_exp
 
 
-def undisturbed(sg, oracle, method, N, seed, math_mode, philox, inputs, QRdt, mapname="example_webmap"):
+def undisturbed(sg, oracle, method, N, seed, math_mode, philox, inputs, QRdt, mapname="example_webmap", args=None, log_weights=False):
     """The same inputs through predict / update / estimate_async only (Philox: slamgpu_step): no observer call ever runs a
     stage out of line -- the product's pipeline."""
-    o = oracle.sim(sim_args(mapname, method, N, seed))  # (only for the algorithm constants)
-    s = _mk(sg, o, N, method, sg.RNG_PHILOX if philox else sg.RNG_TAPE, math_mode, seed)
+    o = oracle.sim(args if args is not None else sim_args(mapname, method, N, seed))  # (only for the algorithm constants)
+    s = _mk(sg, o, N, method, sg.RNG_PHILOX if philox else sg.RNG_TAPE, math_mode, seed, log_weights)
     o.close()
     Q, R, dt = QRdt
     hist = []
@@ -291,6 +317,83 @@ def test_bench_window_full_size_ancestor_forced(sg_mod, oracle, math_mode):
     for key in ("xv", "Pv", "w", "xf", "Pf"):
         assert np.array_equal(final[key].view(np.uint32), final_u[key].view(np.uint32)), key
     print("free-running FASTSLAM2 philox N=100000 %s: %s" % (["strict", "fast"][math_mode], st))
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+def test_loop902_whole_run_ancestor_forced_plain_rows(sg_mod, oracle, math_mode):
+    """example_loop902 (117 landmarks: plain genealogy rows, update_kernel<2, 0, true>, the reference's LINEAR weights,
+    SWITCH_HEADING_KNOWN: the heading observation of fastslam2.cpp:113-125 in every predict), 1 000 particles, the libc rand()
+    tape, ALL 4 302 observation steps (two laps: every landmark is re-observed after ~2 150 steps out of view), no upload,
+    every step compared; then the undisturbed pipeline bit for bit."""
+    N, seed = 1000, 3
+    st, inputs, QRdt, hist, final, final_exp = forced_run(sg_mod, oracle, "FASTSLAM2", N, seed, 100000, math_mode, False, mapname="example_loop902")
+    print("free-running FASTSLAM2 tape example_loop902 %s: %s" % (["strict", "fast"][math_mode], st))
+    assert st["steps"] == 4302 and st["resamples"] > 1500, st
+    assert final["nf"] == 117
+    ensure(st["decision_diff"] <= 12, st)
+    check_ancestors(st, "FASTSLAM2", math_mode, N)
+    check_final(final, final_exp, math_mode)
+    hist_u, final_u = undisturbed(sg_mod, oracle, "FASTSLAM2", N, seed, math_mode, False, inputs, QRdt, mapname="example_loop902")
+    for a, b in zip(hist, hist_u):
+        assert np.array_equal(a, b)
+    for key in ("xv", "Pv", "w", "xf", "Pf"):
+        assert np.array_equal(final[key].view(np.uint32), final_u[key].view(np.uint32)), key
+
+
+@pytest.fixture(scope="module")
+def synmap10k(tmp_path_factory):
+    from conftest import DATA
+    from slam_amd import host
+    d = tmp_path_factory.mktemp("free10k")
+    lm = host.synthetic_landmarks(12345, 10000, -130, 100, -100, 90)   # BASELINE configs[4]'s map (SURVEY.md 8(d))
+    h = host.HostSim(sim_args("example_webmap", "FASTSLAM2", 100, 7))
+    _, wp = h.map()
+    h.close()
+    mp = str(d / "synthetic10k.mat")
+    host.write_map(mp, lm, wp)
+    open(str(d / "synthetic10k.ini"), "w").write(open(os.path.join(DATA, "example_webmap.ini")).read())
+    return mp
+
+
+# log-weights over ~1.2 k landmarks per step: the sum of that many float32 log-likelihood terms carries more rounding than the
+# webmap's 3-7 factors; bounds = FREE_W x this factor (2x the measured maxima, gpurun_out/r4_free10k.log)
+W_SCALE_10K = 2.0
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+def test_config5_map_whole_run_ancestor_forced_log_weights(sg_mod, oracle, synmap10k, math_mode, monkeypatch):
+    """BASELINE configs[4]'s map (10 000 landmarks, MAX_RANGE 60: ~1.2 k re-observed landmarks per step) at 256 particles in
+    log-weights, Philox, ALL 2 172 observation steps free-running with the GPU's ancestors forced into the oracle: the deep
+    genealogy of a big map (a new row per step, copy roles, row reuse, plain-row consolidation) against the oracle's plain
+    particle copies.  Poses and weights are compared on every step, the full landmark state (61 MB per read) on every 64th step, on
+    the steps around the point where the rows in use first reach the consolidation target, and on the last one."""
+    N, seed = 256, 7
+    target = 1024
+    monkeypatch.setenv("SLAMGPU_PLAIN_ROWS_TARGET", str(target))   # (default 2 048: reached only near the end of this run)
+    args = ["-m", synmap10k, "-method", "FASTSLAM2", "-NPARTICLES", N, "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", seed, "-MAX_RANGE", 60]
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    rows, crossed = [], []
+
+    def on_step(k, s):
+        r = s.live_rows()
+        rows.append(r)
+        if r >= target and not crossed:
+            crossed.append(k)
+    full_at = lambda k: k % 64 == 0 or k >= 2171 or (crossed and k - crossed[0] in (0, 1, 2, 8, 40))
+    st, inputs, QRdt, hist, final, final_exp = forced_run(sg_mod, oracle, "FASTSLAM2", N, seed, 100000, math_mode, True, threads=threads, args=args,
+                                                          log_weights=True, full_at=full_at, tol_scale=W_SCALE_10K, on_step=on_step)
+    print("free-running FASTSLAM2 philox 10k-landmark map N=256 log-weights %s: %s; rows in use: max %d, final %d, target first reached at step %s"
+          % (["strict", "fast"][math_mode], st, max(rows), rows[-1], crossed[:1]))
+    assert st["steps"] == 2172 and st["resamples"] > 1000, st
+    assert final["nf"] > 9000
+    assert crossed and max(rows) <= target + 64, (crossed, max(rows))   # consolidation engaged and held the rows at the target
+    ensure(st["decision_diff"] <= 12, st)
+    check_final(final, final_exp, math_mode)
+    hist_u, final_u = undisturbed(sg_mod, oracle, "FASTSLAM2", N, seed, math_mode, True, inputs, QRdt, args=args, log_weights=True)
+    for a, b in zip(hist, hist_u):
+        assert np.array_equal(a, b)
+    for key in ("xv", "Pv", "w", "xf", "Pf"):
+        assert np.array_equal(final[key].view(np.uint32), final_u[key].view(np.uint32)), key
 
 
 @pytest.fixture(scope="module")
