@@ -31,7 +31,11 @@
 extern "C" {
 #endif
 
-#define SLAMGPU_ABI_VERSION 2
+/* 3 (round 4): SLAMGPU_STATUS_CAPACITY; slamgpu_run_observe; the round-1 exchange path, the push / fold collectives, the raw
+ *    device-buffer helpers and slamgpu_debug_stamps moved behind SLAMGPU_EXPERIMENTAL (still exported, no longer stable).
+ * Everything declared outside the SLAMGPU_EXPERIMENTAL block at the end of this file is STABLE: same name, same argument
+ * meaning and same error behaviour for a given SLAMGPU_ABI_VERSION. */
+#define SLAMGPU_ABI_VERSION 3
 
 typedef enum {
     SLAMGPU_OK = 0,
@@ -278,6 +282,103 @@ int slamgpu_upload(slamgpu_ctx *ctx, int32_t nf, const float *xv, const float *P
                    const float *Pf4);
 int slamgpu_sync(slamgpu_ctx *ctx);
 
+/* ---- distributed operation (the multi-GPU path: nothing migrates) ---------------------------------------------------
+ * One context per GPU; shard g holds the contiguous global particles [g*n, (g+1)*n), n a multiple of 256; contexts may
+ * live in one process (peer access) or one process per GPU (hipIpc).  Every context maps every other shard's state arrays
+ * (slamgpu_dist_export / slamgpu_dist_connect); from then on a filter step is
+ *
+ *     slamgpu_dist_step   ONE kernel launch per shard: the queued predicts, the resampling stage of the PREVIOUS step
+ *                         (every shard scans the same all-gathered block totals: identical Neff, decision and ancestors
+ *                         everywhere, independent of the number of shards) and the per-particle update.  A particle
+ *                         whose ancestor lives on another GPU reads that ancestor's pose and genealogy in place over xGMI;
+ *                         genealogy entries are global slot ids, so landmark records stay on the GPU that wrote them until
+ *                         the landmark is observed again.  No pack / send / unpack, no host synchronisation.
+ *     ALL-GATHER          of this step's block totals (slamgpu_dist_totals: 8 B per 256 particles per shard), stream-ordered
+ *                         on the context's stream: by the library itself once slamgpu_dist_comm_init has run (RCCL), else
+ *                         by the caller (torch.distributed, MPI, device copies for contexts of one process).  It is also
+ *                         the only barrier the scheme needs: a shard's next launch starts after every shard's current
+ *                         launch has finished.
+ *
+ * Together the two are resampleParticles (core.cpp:718-824) and the predict / update calls of the wrapper loop
+ * (fastslam2wrapper.cpp:64,88) for a particle set that spans GPUs; results do not depend on the number of shards.
+ * The pose estimate of a step (ParticleSLAMWrapper.cpp:56-77) is this shard's raw partial (slamgpu_dist_history_fetch: sum x,
+ * sum y, heading and weight of the local maximum); combine across shards in shard order.  slamgpu_dist_settle (collective:
+ * every shard, followed by the all-gather) applies the pending resampling stage so that slamgpu_download* can read the set.
+ * Linear weights and SLAMGPU_RNG_PHILOX only. */
+int slamgpu_dist_export_size(void);
+int slamgpu_dist_export(slamgpu_ctx *ctx, void *blob);
+int slamgpu_dist_connect(slamgpu_ctx *ctx, int32_t n_shards, int32_t shard, const void *blobs);
+int slamgpu_dist_step(slamgpu_ctx *ctx, const float *controls, int32_t n_controls, const float Q[4], float dt, const float *zf,
+                      const int32_t *idf, int32_t m, const float *zn, int32_t n, const float R[4], int32_t record_estimate);
+/* buffers of the all-gather that follows the last slamgpu_dist_step / _settle: this shard's totals (floats_per_shard
+ * floats) go to slot `shard` of every context's `gathered` (n_shards * floats_per_shard floats) */
+int slamgpu_dist_totals(slamgpu_ctx *ctx, const float **local_dev, float **gathered_dev, int32_t *floats_per_shard);
+int slamgpu_dist_settle(slamgpu_ctx *ctx);
+/* the recorded steps of this shard (settled): raw partial of the estimate (sum x, sum y, heading and weight of the local
+ * maximum-weight particle; combine in shard order, strict > on the weight) and the stage's Neff / resampled / status,
+ * which are identical on every shard */
+int slamgpu_dist_history_fetch(slamgpu_ctx *ctx, double *raw4, float *neff, int32_t *resampled, int32_t *status, int32_t max_count,
+                               int32_t *count);
+
+/* RCCL inside the library (bound at run time: dlopen librccl.so.1): one process per GPU.  Rank 0 makes an id
+ * (SLAMGPU_DIST_COMM_ID_BYTES bytes) and hands it to every rank by whatever means the launcher has; after
+ * slamgpu_dist_comm_init (collective), slamgpu_dist_step and slamgpu_dist_settle enqueue the all-gather themselves on
+ * the context's stream: a filter step is one C call, one launch and one collective, and never waits on the host. */
+#define SLAMGPU_DIST_COMM_ID_BYTES 128
+int slamgpu_dist_comm_id(void *id, int32_t bytes);
+int slamgpu_dist_comm_init(slamgpu_ctx *ctx, const void *id, int32_t n_ranks, int32_t rank);
+/* the all-gather of the last step's totals once more (collective, idempotent): lets a harness time the collective alone */
+int slamgpu_dist_gather(slamgpu_ctx *ctx);
+
+
+/* All shards in ONE process (the reference's single backend process driving k GPUs; or k logical shards on one GPU, which
+ * must then share one stream): export + connect + the collective (shards on devices of their own: SLAMGPU_DIST_PUSH if its
+ * barrier works, else ncclCommInitAll; a copy kernel on a shared device) in one call, then steps for every shard at once.  Contexts are created by the caller as for slamgpu_dist_connect and
+ * destroyed by the caller after the group.  _history combines the shards' partial estimates (xyt[3] per recorded step);
+ * _download concatenates the shards in shard order (buffers sized for all k * n particles). */
+typedef struct slamgpu_dist_group slamgpu_dist_group;
+int slamgpu_dist_group_create(slamgpu_ctx **ctxs, int32_t k, slamgpu_dist_group **out);
+void slamgpu_dist_group_destroy(slamgpu_dist_group *g);
+int slamgpu_dist_group_step(slamgpu_dist_group *g, const float *controls, int32_t n_controls, const float Q[4], float dt,
+                            const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n, const float R[4],
+                            int32_t record_estimate);
+int slamgpu_dist_group_settle(slamgpu_dist_group *g);
+int slamgpu_dist_group_history(slamgpu_dist_group *g, double *xyt, float *neff, int32_t *resampled, int32_t *status,
+                               int32_t max_count, int32_t *count);
+int slamgpu_dist_group_download(slamgpu_dist_group *g, float *xv, float *Pv9, float *w, float *xf, float *Pf4);
+
+
+/* ---- measurement / plumbing ------------------------------------------------------------------------ */
+/* HIP stream the context launches on (hipStream_t as void*), so a harness can record events on it. */
+void *slamgpu_stream(slamgpu_ctx *ctx);
+/* Device time of a region of the context's stream: two HIP events recorded on that stream (start now / stop now);
+ * stop synchronises on its event and returns the milliseconds between the two.  Unlike the per-launch event pairs of
+ * slamgpu_profile this perturbs nothing inside the region. */
+int slamgpu_timer_start(slamgpu_ctx *ctx);
+int slamgpu_timer_stop(slamgpu_ctx *ctx, double *ms);
+
+/* Device-time accounting: when enabled every kernel launch is bracketed by HIP events on the context
+ * stream; slamgpu_kernel_time returns accumulated milliseconds and launch count for a kernel name
+ * ("fs2_update", "weights_scan", "resample", "predict", "estimate", ...). */
+int slamgpu_profile(slamgpu_ctx *ctx, int32_t enable);
+int slamgpu_kernel_time(slamgpu_ctx *ctx, const char *kernel, double *ms, int64_t *launches);
+/* Algorithmic bytes moved by the update path so far (SURVEY.md §8(d) formula, accumulated per step). */
+int slamgpu_algorithmic_bytes(slamgpu_ctx *ctx, double *update_bytes, double *predict_bytes);
+
+/* =================================================================================================================
+ * EXPERIMENTAL / DIAGNOSTIC entry points.  Exported by the library, NOT part of the stable ABI: they may change or go
+ * away without a bump of SLAMGPU_ABI_VERSION.  Declared only when SLAMGPU_EXPERIMENTAL is defined before this header is
+ * included.  What is here and why:
+ *   - slamgpu_shard_*           round 1's exchange path (pack / all-to-all / unpack of migrating offspring, the caller's
+ *                               collectives).  Superseded by the distributed contexts above (nothing migrates); kept as the
+ *                               fallback of bench.py --mgpu exchange when peer mappings cannot be set up.
+ *   - push / fold collectives   hand-made alternatives to the RCCL all-gather of slamgpu_dist_step; have only ever run
+ *                               between contexts of ONE physical GPU.  Default everywhere: SLAMGPU_DIST_GATHER.
+ *   - slamgpu_dev_*             raw device buffers for the callers of the exchange path
+ *   - slamgpu_debug_stamps      instrumented build only
+ * ================================================================================================================= */
+#ifdef SLAMGPU_EXPERIMENTAL
+
 /* ---- sharded operation: particles partitioned over contexts (one per GPU) ---------------------------
  * The reference has no multi-device path; this is the build's data-parallel extension of
  * resampleParticles (core.cpp:718-824).  Shard g holds the contiguous global particles
@@ -331,53 +432,6 @@ int slamgpu_shard_estimate(slamgpu_ctx *ctx, double out[4]);
  * history and fetched together (one synchronisation + one all-gather for many steps) */
 int slamgpu_shard_estimate_async(slamgpu_ctx *ctx);
 int slamgpu_shard_estimate_fetch(slamgpu_ctx *ctx, double *raw4, int32_t max_count, int32_t *count);
-/* ---- distributed operation (the multi-GPU path: nothing migrates) ---------------------------------------------------
- * One context per GPU; shard g holds the contiguous global particles [g*n, (g+1)*n), n a multiple of 256; contexts may
- * live in one process (peer access) or one process per GPU (hipIpc).  Every context maps every other shard's state arrays
- * (slamgpu_dist_export / slamgpu_dist_connect); from then on a filter step is
- *
- *     slamgpu_dist_step   ONE kernel launch per shard: the queued predicts, the resampling stage of the PREVIOUS step
- *                         (every shard scans the same all-gathered block totals: identical Neff, decision and ancestors
- *                         everywhere, independent of the number of shards) and the per-particle update.  A particle
- *                         whose ancestor lives on another GPU reads that ancestor's pose and genealogy in place over xGMI;
- *                         genealogy entries are global slot ids, so landmark records stay on the GPU that wrote them until
- *                         the landmark is observed again.  No pack / send / unpack, no host synchronisation.
- *     ALL-GATHER          of this step's block totals (slamgpu_dist_totals: 8 B per 256 particles per shard), stream-ordered
- *                         on the context's stream: by the library itself once slamgpu_dist_comm_init has run (RCCL), else
- *                         by the caller (torch.distributed, MPI, device copies for contexts of one process).  It is also
- *                         the only barrier the scheme needs: a shard's next launch starts after every shard's current
- *                         launch has finished.
- *
- * Together the two are resampleParticles (core.cpp:718-824) and the predict / update calls of the wrapper loop
- * (fastslam2wrapper.cpp:64,88) for a particle set that spans GPUs; results do not depend on the number of shards.
- * The pose estimate of a step (ParticleSLAMWrapper.cpp:56-77) is this shard's raw partial (slamgpu_dist_history_fetch: sum x,
- * sum y, heading and weight of the local maximum); combine across shards in shard order.  slamgpu_dist_settle (collective:
- * every shard, followed by the all-gather) applies the pending resampling stage so that slamgpu_download* can read the set.
- * Linear weights and SLAMGPU_RNG_PHILOX only. */
-int slamgpu_dist_export_size(void);
-int slamgpu_dist_export(slamgpu_ctx *ctx, void *blob);
-int slamgpu_dist_connect(slamgpu_ctx *ctx, int32_t n_shards, int32_t shard, const void *blobs);
-int slamgpu_dist_step(slamgpu_ctx *ctx, const float *controls, int32_t n_controls, const float Q[4], float dt, const float *zf,
-                      const int32_t *idf, int32_t m, const float *zn, int32_t n, const float R[4], int32_t record_estimate);
-/* buffers of the all-gather that follows the last slamgpu_dist_step / _settle: this shard's totals (floats_per_shard
- * floats) go to slot `shard` of every context's `gathered` (n_shards * floats_per_shard floats) */
-int slamgpu_dist_totals(slamgpu_ctx *ctx, const float **local_dev, float **gathered_dev, int32_t *floats_per_shard);
-int slamgpu_dist_settle(slamgpu_ctx *ctx);
-/* the recorded steps of this shard (settled): raw partial of the estimate (sum x, sum y, heading and weight of the local
- * maximum-weight particle; combine in shard order, strict > on the weight) and the stage's Neff / resampled / status,
- * which are identical on every shard */
-int slamgpu_dist_history_fetch(slamgpu_ctx *ctx, double *raw4, float *neff, int32_t *resampled, int32_t *status, int32_t max_count,
-                               int32_t *count);
-
-/* RCCL inside the library (bound at run time: dlopen librccl.so.1): one process per GPU.  Rank 0 makes an id
- * (SLAMGPU_DIST_COMM_ID_BYTES bytes) and hands it to every rank by whatever means the launcher has; after
- * slamgpu_dist_comm_init (collective), slamgpu_dist_step and slamgpu_dist_settle enqueue the all-gather themselves on
- * the context's stream: a filter step is one C call, one launch and one collective, and never waits on the host. */
-#define SLAMGPU_DIST_COMM_ID_BYTES 128
-int slamgpu_dist_comm_id(void *id, int32_t bytes);
-int slamgpu_dist_comm_init(slamgpu_ctx *ctx, const void *id, int32_t n_ranks, int32_t rank);
-/* the all-gather of the last step's totals once more (collective, idempotent): lets a harness time the collective alone */
-int slamgpu_dist_gather(slamgpu_ctx *ctx);
 
 /* The collective between two launches, two ways:
  *   SLAMGPU_DIST_GATHER (default)  an all-gather of the block totals after every launch (RCCL inside the library after
@@ -401,22 +455,6 @@ int slamgpu_dist_set_collective(slamgpu_ctx *ctx, int32_t mode);
 int slamgpu_dist_handshake_test(slamgpu_ctx *ctx, int32_t iters, double *usec, int32_t *ok);
 int slamgpu_dist_collective_status(slamgpu_ctx *ctx, int32_t *ok);
 
-/* All shards in ONE process (the reference's single backend process driving k GPUs; or k logical shards on one GPU, which
- * must then share one stream): export + connect + the collective (shards on devices of their own: SLAMGPU_DIST_PUSH if its
- * barrier works, else ncclCommInitAll; a copy kernel on a shared device) in one call, then steps for every shard at once.  Contexts are created by the caller as for slamgpu_dist_connect and
- * destroyed by the caller after the group.  _history combines the shards' partial estimates (xyt[3] per recorded step);
- * _download concatenates the shards in shard order (buffers sized for all k * n particles). */
-typedef struct slamgpu_dist_group slamgpu_dist_group;
-int slamgpu_dist_group_create(slamgpu_ctx **ctxs, int32_t k, slamgpu_dist_group **out);
-void slamgpu_dist_group_destroy(slamgpu_dist_group *g);
-int slamgpu_dist_group_step(slamgpu_dist_group *g, const float *controls, int32_t n_controls, const float Q[4], float dt,
-                            const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n, const float R[4],
-                            int32_t record_estimate);
-int slamgpu_dist_group_settle(slamgpu_dist_group *g);
-int slamgpu_dist_group_history(slamgpu_dist_group *g, double *xyt, float *neff, int32_t *resampled, int32_t *status,
-                               int32_t max_count, int32_t *count);
-int slamgpu_dist_group_download(slamgpu_dist_group *g, float *xv, float *Pv9, float *w, float *xf, float *Pf4);
-
 /* Plain device-memory helpers for callers that have no allocator of their own (tests, the C++ host): buffers
  * for the gathered block totals and the send / receive records.  copy is device-to-device, ordered on the
  * context's stream and synchronised before returning. */
@@ -425,27 +463,13 @@ int slamgpu_dev_free(slamgpu_ctx *ctx, void *ptr);
 int slamgpu_dev_copy(slamgpu_ctx *ctx, void *dst, const void *src, uint64_t bytes);
 int slamgpu_dev_copy_async(slamgpu_ctx *ctx, void *dst, const void *src, uint64_t bytes); /* ordered on the stream, no wait */
 
-/* ---- measurement / plumbing ------------------------------------------------------------------------ */
-/* HIP stream the context launches on (hipStream_t as void*), so a harness can record events on it. */
-void *slamgpu_stream(slamgpu_ctx *ctx);
-/* Device time of a region of the context's stream: two HIP events recorded on that stream (start now / stop now);
- * stop synchronises on its event and returns the milliseconds between the two.  Unlike the per-launch event pairs of
- * slamgpu_profile this perturbs nothing inside the region. */
-int slamgpu_timer_start(slamgpu_ctx *ctx);
-int slamgpu_timer_stop(slamgpu_ctx *ctx, double *ms);
-
-/* Device-time accounting: when enabled every kernel launch is bracketed by HIP events on the context
- * stream; slamgpu_kernel_time returns accumulated milliseconds and launch count for a kernel name
- * ("fs2_update", "weights_scan", "resample", "predict", "estimate", ...). */
-int slamgpu_profile(slamgpu_ctx *ctx, int32_t enable);
-int slamgpu_kernel_time(slamgpu_ctx *ctx, const char *kernel, double *ms, int64_t *launches);
-/* Algorithmic bytes moved by the update path so far (SURVEY.md §8(d) formula, accumulated per step). */
-int slamgpu_algorithmic_bytes(slamgpu_ctx *ctx, double *update_bytes, double *predict_bytes);
 /* Diagnostic: wall-clock stamps (100 MHz) of the LAST update launch at the levels of its dependent-load chain, 16 per
  * compute block (slot meaning: tools/stamps.py).  Only the instrumented build (slam_amd/libslamgpu_stamps.so, `make
  * stamps`) writes them, and only for contexts created with SLAMGPU_STAMPS=1 in the environment; otherwise an error
  * (or zeros).  Synchronises. */
 int slamgpu_debug_stamps(slamgpu_ctx *ctx, uint64_t *out, int32_t max_blocks, int32_t *nblocks);
+
+#endif /* SLAMGPU_EXPERIMENTAL */
 
 #ifdef __cplusplus
 }

@@ -914,10 +914,7 @@ SLAM_DEV void front_book(const FrontArgs &F, const FrontObs ob, const FrontLm s,
 // instead of one dependent slot -> record round trip per landmark.
 // (measured at config 5, gpurun_out/var: 4 and 8 landmarks per chunk run the same 1.61 ms per step, 12 and 16 are slower;
 // 4 keeps the kernel at 103 / 110 VGPRs (fast / strict build: 4 waves per SIMD) and 20 KB of LDS per block, 8 needs 134 / 143)
-#ifndef SLAM_BIG_CHUNK
-#define SLAM_BIG_CHUNK 4
-#endif
-constexpr int kBigChunk = SLAM_BIG_CHUNK;
+constexpr int kBigChunk = 4;
 constexpr int kStage = 8;  // landmarks per particle kept in LDS between the two passes of a small packet
 
 // LDS of the per-wave ancestor windows of a launch that plans inline (host and device agree on the dynamic LDS layout)
@@ -1068,16 +1065,13 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     __shared__ uint32_t f_sets[4];
     __shared__ float f_aux[2 * kWave + 2];
     int32_t pkv = 0;
-#ifndef SLAM_NO_PK_LDS
     if constexpr (!BIG) {
         constexpr size_t at = ka_small;  // dword offset of U.small in the kernel arguments
         const auto *ka = (const __attribute__((address_space(4))) int32_t *) __builtin_amdgcn_kernarg_segment_ptr();
         if (!front && threadIdx.x < kSmallWords) pkv = ka[at + threadIdx.x];  // (parked in LDS below, once the scan's loads are out too)
     }
-#endif
     const int cur = h_ctrl->live[h_slot];  // ... and the Ctrl words
     const bool pend_word = h_ctrl->pend[h_slot] != 0;
-#ifndef SLAM_NO_PK_LDS
     if constexpr (!BIG && MODE == 0) {
         // front-end launches: the packet is worked out here, while the scan's loads and the Ctrl words are in flight
         if (front && (int) blockIdx.x < h_nb) {
@@ -1105,14 +1099,11 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
             }
         }
     }
-#endif
     int bt = (int) blockIdx.x;
-#ifndef SLAM_NO_XCD_TILES
     if (bt < nb) {
         const int x = bt & 7, j = bt >> 3, q = nb >> 3, r = nb & 7;
         bt = x < r ? x * (q + 1) + j : r * (q + 1) + (x - r) * q + j;
     }
-#endif
     SLAM_STAMP(1);  // Ctrl words arrived
     // Where does particle i of the set this update works on come from?
     //   plan_inline: the resampling stage of the previous update has not run: every block redoes its scan of the block
@@ -1190,7 +1181,6 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         }
         return;
     }
-#ifndef SLAM_NO_PK_LDS
     if constexpr (!BIG) {
         if (!front && threadIdx.x < kSmallWords) pk[threadIdx.x] = pkv;
         __syncthreads();
@@ -1199,7 +1189,6 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
             return;
         }
     }
-#endif
     const int i = bt * kBlock + threadIdx.x;
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     // select (not index) the buffers: an indexed read of the pointer table in the kernel-argument segment
@@ -1326,17 +1315,10 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
             zn = (FltP) reinterpret_cast<uintptr_t>(PV.zn);
             lrow = (IdxP) reinterpret_cast<uintptr_t>(PV.row);
         } else {
-#ifndef SLAM_NO_PK_LDS
             idf = pk + offsetof(SmallObs, idf) / 4;
             lrow = pk + offsetof(SmallObs, row) / 4;
             zf = reinterpret_cast<const float *>(pk + offsetof(SmallObs, zf) / 4);
             zn = reinterpret_cast<const float *>(pk + offsetof(SmallObs, zn) / 4);
-#else
-            idf = U.small.idf;
-            zf = U.small.zf;
-            zn = U.small.zn;
-            lrow = U.small.row;
-#endif
         }
         // re-observed landmark k of this particle: the slot comes from the genealogy row the landmark uses (kernels.h:
         // gen), the buffer from the row's live flag; a landmark this update writes goes to the particle's OWN slot of the
@@ -1417,13 +1399,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                     load_slots(k0 + 2 * CH);  // (clamped: harmless re-reads past the end)
                 }
                 const int kn = min(CH, m - k0);
-#ifdef SLAM_BIG_UNROLL
-#pragma unroll
-                for (int k = 0; k < CH; k++)
-                    if (k < kn) body(k0 + k, shA[(k) * kBlock + threadIdx.x], shB[(k) * kBlock + threadIdx.x]);
-#else
                 for (int k = 0; k < kn; k++) body(k0 + k, shA[(k) * kBlock + threadIdx.x], shB[(k) * kBlock + threadIdx.x]);
-#endif
             }
         };
 

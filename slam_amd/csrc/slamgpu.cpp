@@ -1,6 +1,7 @@
 // libslamgpu.so — C ABI over the gfx950 kernels (include/slamgpu.h).  Host side only: owns the device
 // buffers, the HIP stream, the pinned staging rings and the lazy predict queue.  No CPU compute path:
 // if there is no usable GPU every entry point fails with SLAMGPU_ERR_NO_DEVICE.
+#define SLAMGPU_EXPERIMENTAL 1  // (the library defines every entry point, the experimental ones included)
 #include "../../include/slamgpu.h"
 
 #include <hip/hip_runtime.h>

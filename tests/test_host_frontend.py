@@ -18,7 +18,7 @@ def test_slamgpu_exports_every_declared_symbol():
     assert declared and sorted(slam_amd.DECLARED_SYMBOLS) == declared
     for s in declared:
         assert hasattr(L, s), s
-    assert L.slamgpu_abi_version() == 2
+    assert L.slamgpu_abi_version() == 3
 
 
 def test_slamhost_exports_every_declared_symbol():
