@@ -78,12 +78,18 @@ def _mk(sg, o, N, method, rng_mode, math_mode, seed, log_weights=False):
 
 
 def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None, threads=1, mapname="example_webmap", args=None,
-               log_weights=False, full_at=None, tol_scale=1.0, on_step=None):
+               log_weights=False, full_at=None, w_tol=None, on_step=None, weights_comparable=True, anchor_at=None, pose_atol=None, lmk_atol=None):
     """Drive oracle + GPU as described in the module docstring.  window = (lo, hi): observation steps (1-based) whose full
     state is compared; None = every step.  full_at(k) (optional): on steps inside the window where it is false only the poses
     and the weights are read and compared (big maps: the landmark records of a step are tens of MB).  args: the simulation's
-    command line when it is not a bundled map; log_weights: both sides keep log-weights.  Returns the per-run statistics,
-    the inputs (for the undisturbed replay) and the GPU's final state / history."""
+    command line when it is not a bundled map; log_weights: both sides keep log-weights.  w_tol: this workload's free-running
+    weight bounds (default FREE_W).  weights_comparable = False: the free-running weights / Neff are recorded but not bounded
+    (a weight that is a product of ~1.2 k likelihoods moves by tens of percent for a pre-state difference of 1e-3 m; see
+    test_config5_map_*); anchor_at(k): step k is ALSO checked teacher-forced from the GPU's OWN free-running state: the GPU's
+    full state after step k - 1 (read through its genealogy) goes into a scratch oracle set, which takes the same predicts,
+    packet and normals, and must land on the GPU's state after step k within the per-step tolerances of
+    tests/test_gpu_parity.py (st["anchored"] counts them).  Returns the per-run statistics, the inputs (for the undisturbed
+    replay) and the GPU's final state / history."""
     fs2 = method == "FASTSLAM2"
     oracle.set_threads(threads)
     o = oracle.sim(args if args is not None else sim_args(mapname, method, N, seed))
@@ -94,8 +100,12 @@ def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None
     algo = o.algo()
     Q, R, dt = o.noise()
     s = _mk(sg, o, N, method, sg.RNG_PHILOX if philox else sg.RNG_TAPE, math_mode, seed, log_weights)
-    tol = {key: v * tol_scale for key, v in FREE_W[math_mode].items()}
+    tol = w_tol if w_tol is not None else FREE_W[math_mode]
+    pose_atol = FREE_POSE_ATOL[math_mode] if pose_atol is None else pose_atol
+    lmk_atol = FREE_LMK_ATOL[math_mode] if lmk_atol is None else lmk_atol
     hist_parts = []
+    anchor = None      # the GPU's full state after the previous step, when the next step is an anchored one
+    P2 = None
     st = dict(steps=0, resamples=0, decision_diff=0, anc_diff=0, anc_far=0, anc_maxd=0, anc_tot=0, max_pose=0.0, max_lmk=0.0, max_w_median=0.0, max_w_p99=0.0,
               max_w=0.0, max_neff_rel=0.0)
     inputs, ctl = [], []
@@ -138,11 +148,11 @@ def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None
         st["resamples"] += int(did_g)
         rel_ne = abs(float(ne_g) / float(ne_o) - 1.0)
         st["max_neff_rel"] = max(st["max_neff_rel"], rel_ne)
-        ensure(rel_ne <= FREE_NEFF[fs2][math_mode], (tag, ne_g, ne_o))
+        ensure(not weights_comparable or rel_ne <= FREE_NEFF[fs2][math_mode], (tag, ne_g, ne_o))
         if did_g != did_o:
             # only next to the threshold: both Neff within the tolerance of NEFFECTIVE
             st["decision_diff"] += 1
-            ensure(abs(float(ne_o) / algo.n_effective - 1.0) <= FREE_NEFF[fs2][math_mode], (tag, ne_g, ne_o, algo.n_effective))
+            ensure(not weights_comparable or abs(float(ne_o) / algo.n_effective - 1.0) <= FREE_NEFF[fs2][math_mode], (tag, ne_g, ne_o, algo.n_effective))
         elif did_g:
             d = np.abs(own.astype(np.int64) - keep)
             st["anc_diff"] += int(np.count_nonzero(d))
@@ -159,8 +169,46 @@ def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None
             on_step(k, s)
         if window is not None and not (window[0] <= k <= window[1]):
             continue
-        full = full_at is None or full_at(k)
+        anchored = anchor is not None
+        want_anchor = anchor_at is not None and anchor_at(k + 1)
+        full = full_at is None or full_at(k) or anchored or want_anchor
         got = s.peek(landmarks=full)
+        if anchored:
+            # teacher-forced from the GPU's own state of one step ago (see the docstring)
+            from test_gpu_parity import POSE_ATOL, W_TOL
+            if P2 is None:
+                P2 = oracle.particles(N, o.nlm)
+                if log_weights:
+                    P2.set_log_weights(True)
+            P2.set(dict(nf=anchor["nf"], xv=anchor["xv"], Pv=anchor["Pv"], w=anchor["w"], xf=anchor["xf"], Pf=anchor["Pf"]))
+            for (V, G, phi, n2) in inputs[-1]["ctl"]:
+                P2.predict(algo, V, G, Q, float(dt), phi, n2)
+            nm = o.last_tape()[0]
+            P2.update_local(algo, ob["zf"], ob["idf"], ob["zn"], R, np.ascontiguousarray(nm))
+            e2 = P2.get()
+            src = keep if did_g else np.arange(N)
+            da = np.abs(got["xv"].astype(np.float64) - e2["xv"][src])
+            da[:, 2] = np.minimum(da[:, 2], np.abs(da[:, 2] - 2 * np.pi))
+            st["anchored"] = st.get("anchored", 0) + 1
+            st["anch_pose"] = max(st.get("anch_pose", 0.0), float(da.max()))
+            st["anch_lmk"] = max(st.get("anch_lmk", 0.0), float(np.abs(got["xf"] - e2["xf"][src]).max()))
+            ensure(da.max() <= POSE_ATOL, (tag, "anchored pose", da.max()))
+            ensure(np.abs(got["xf"] - e2["xf"][src]).max() <= 5 * POSE_ATOL, (tag, "anchored landmarks"))
+            ensure(close_cov(got["Pf"], sym(e2["Pf"][src])), (tag, "anchored Pf"))
+            if not did_g and ob["zf"].shape[0] > 0:
+                lg, le = got["w"].astype(np.float64), e2["w"].astype(np.float64)
+                if log_weights:
+                    lg, le = np.exp(lg - lg.max()), np.exp(le - le.max())
+                lg, le = lg / lg.sum(), le / le.sum()
+                rel = np.abs(lg / le - 1.0)
+                st["anch_w"] = st.get("anch_w", 0) + 1
+                st["anch_w_median"] = max(st.get("anch_w_median", 0.0), float(np.median(rel)))
+                st["anch_w_p99"] = max(st.get("anch_w_p99", 0.0), float(np.quantile(rel, 0.99)))
+                st["anch_w_max"] = max(st.get("anch_w_max", 0.0), float(rel.max()))
+                t2 = W_TOL[math_mode]
+                ensure(np.median(rel) <= t2["median"] and np.quantile(rel, 0.99) <= t2["p99"] and rel.max() <= t2["max"],
+                       (tag, "anchored weights", np.median(rel), np.quantile(rel, 0.99), rel.max()))
+        anchor = got if want_anchor else None
         exp = o.particles(landmarks=full)
         assert got["nf"] == exp["nf"], tag
         if not full:
@@ -169,12 +217,12 @@ def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None
         dxv[:, 2] = np.minimum(dxv[:, 2], np.abs(dxv[:, 2] - 2 * np.pi))  # headings next to +-pi
         dp = float(dxv.max())
         st["max_pose"] = max(st["max_pose"], dp)
-        ensure(dp <= FREE_POSE_ATOL[math_mode], (tag, "pose", dp))
+        ensure(dp <= pose_atol, (tag, "pose", dp))
         ensure(close_cov(got["Pv"], sym(exp["Pv"]), 5e-3), (tag, "Pv"))
         if got["nf"]:
             dl = float(np.abs(got["xf"] - exp["xf"]).max())
             st["max_lmk"] = max(st["max_lmk"], dl)
-            ensure(dl <= FREE_LMK_ATOL[math_mode], (tag, "landmarks", dl))
+            ensure(dl <= lmk_atol, (tag, "landmarks", dl))
             ensure(close_cov(got["Pf"], sym(exp["Pf"]), 5e-3), (tag, "Pf"))
             sc = np.abs(exp["Pf"]).max()
             st["max_Pf_rel"] = max(st.get("max_Pf_rel", 0.0), float(np.abs(got["Pf"].astype(np.float64) - sym(exp["Pf"])).max() / max(sc, 1e-12)))
@@ -197,7 +245,7 @@ def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None
                 st["max_w_median"] = max(st["max_w_median"], float(np.median(rel)))
                 st["max_w_p99"] = max(st["max_w_p99"], float(np.quantile(rel, 0.99)))
                 st["max_w"] = max(st["max_w"], float(rel.max()))
-                ensure(np.median(rel) <= tol["median"] and np.quantile(rel, 0.99) <= tol["p99"] and rel.max() <= tol["max"],
+                ensure(not weights_comparable or (np.median(rel) <= tol["median"] and np.quantile(rel, 0.99) <= tol["p99"] and rel.max() <= tol["max"]),
                        (tag, np.median(rel), np.quantile(rel, 0.99), rel.max()))
             else:
                 st["max_w"] = max(st["max_w"], float(rel.max()))
@@ -208,6 +256,8 @@ def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None
     hist_parts.append(s.history_fetch())
     hist = tuple(np.concatenate([h[j] for h in hist_parts]) for j in range(3))
     st["rows_in_use"] = s.live_rows()
+    if P2 is not None:
+        P2.close()
     final = s.download()
     final_exp = o.particles()
     s.close()
@@ -263,14 +313,14 @@ def check_ancestors(st, method, math_mode, N):
         ensure(st["anc_far"] / T <= (0.04 if fs2 else 2e-3), st)
 
 
-def check_final(final, final_exp, math_mode):
+def check_final(final, final_exp, math_mode, pose_atol=None, lmk_atol=None):
     assert final["nf"] == final_exp["nf"]
     if MEASURE:
         return
     dxv = np.abs(final["xv"].astype(np.float64) - final_exp["xv"])
     dxv[:, 2] = np.minimum(dxv[:, 2], np.abs(dxv[:, 2] - 2 * np.pi))
-    assert dxv.max() <= FREE_POSE_ATOL[math_mode]
-    assert np.abs(final["xf"] - final_exp["xf"]).max() <= FREE_LMK_ATOL[math_mode]
+    assert dxv.max() <= (pose_atol or FREE_POSE_ATOL[math_mode])
+    assert np.abs(final["xf"] - final_exp["xf"]).max() <= (lmk_atol or FREE_LMK_ATOL[math_mode])
     assert close_cov(final["Pf"], sym(final_exp["Pf"]), 5e-3)
 
 
@@ -326,7 +376,12 @@ def test_loop902_whole_run_ancestor_forced_plain_rows(sg_mod, oracle, math_mode)
     tape, ALL 4 302 observation steps (two laps: every landmark is re-observed after ~2 150 steps out of view), no upload,
     every step compared; then the undisturbed pipeline bit for bit."""
     N, seed = 1000, 3
-    st, inputs, QRdt, hist, final, final_exp = forced_run(sg_mod, oracle, "FASTSLAM2", N, seed, 100000, math_mode, False, mapname="example_loop902")
+    # free-running weight bounds of THIS run = 2x its measured maxima (gpurun_out/r4_free.log, strict / fast: worst step median
+    # 1.07e-2 / 1.9e-2, p99 7.5e-2 / 0.115, max 0.148 / 0.257; poses 4.3e-4 / 2.5e-4 m, landmarks 1.9e-4 / 2.0e-4 m, Neff 5.7e-3 / 1.1e-2:
+    # the heading observation keeps Pv better conditioned than on example_webmap, the poses agree better, the weights alike)
+    w_tol = {0: dict(median=2.2e-2, p99=0.15, max=0.3), 1: dict(median=4e-2, p99=0.23, max=0.52)}[math_mode]
+    st, inputs, QRdt, hist, final, final_exp = forced_run(sg_mod, oracle, "FASTSLAM2", N, seed, 100000, math_mode, False, mapname="example_loop902",
+                                                          w_tol=w_tol)
     print("free-running FASTSLAM2 tape example_loop902 %s: %s" % (["strict", "fast"][math_mode], st))
     assert st["steps"] == 4302 and st["resamples"] > 1500, st
     assert final["nf"] == 117
@@ -355,10 +410,6 @@ def synmap10k(tmp_path_factory):
     return mp
 
 
-# log-weights over ~1.2 k landmarks per step: the sum of that many float32 log-likelihood terms carries more rounding than the
-# webmap's 3-7 factors; bounds = FREE_W x this factor (2x the measured maxima, gpurun_out/r4_free10k.log)
-W_SCALE_10K = 2.0
-
 
 @pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
 def test_config5_map_whole_run_ancestor_forced_log_weights(sg_mod, oracle, synmap10k, math_mode, monkeypatch):
@@ -368,8 +419,10 @@ def test_config5_map_whole_run_ancestor_forced_log_weights(sg_mod, oracle, synma
     particle copies.  Poses and weights are compared on every step, the full landmark state (61 MB per read) on every 64th step, on
     the steps around the point where the rows in use first reach the consolidation target, and on the last one."""
     N, seed = 256, 7
-    target = 1024
-    monkeypatch.setenv("SLAMGPU_PLAIN_ROWS_TARGET", str(target))   # (default 2 048: reached only near the end of this run)
+    # rows in use on this map level off at ~1 020 (measured: a row is recycled when its last landmark is observed again), so the
+    # default consolidation target of 2 048 rows is never reached; 512 makes the consolidation part of most of the run
+    target = 512
+    monkeypatch.setenv("SLAMGPU_PLAIN_ROWS_TARGET", str(target))
     args = ["-m", synmap10k, "-method", "FASTSLAM2", "-NPARTICLES", N, "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", seed, "-MAX_RANGE", 60]
     threads = max(1, min(16, len(os.sched_getaffinity(0))))
     rows, crossed = [], []
@@ -380,15 +433,21 @@ def test_config5_map_whole_run_ancestor_forced_log_weights(sg_mod, oracle, synma
         if r >= target and not crossed:
             crossed.append(k)
     full_at = lambda k: k % 64 == 0 or k >= 2171 or (crossed and k - crossed[0] in (0, 1, 2, 8, 40))
+    # Free-running WEIGHTS are not comparable on this map: a weight is a product of ~1.2 k likelihoods with sigma_r = 0.1 m, so two
+    # pre-states 1e-3 m apart (what a free run accumulates: measured 5.6e-4 / 2.0e-3 m) already move it by tens of percent
+    # (measured worst-step median 6.5e-2 / 0.41) and Neff with it.  The weights are therefore checked where they are well
+    # defined: every 32nd step teacher-forced from the GPU's OWN free-running state (anchor_at), per-step bounds W_TOL.
+    anchor_at = lambda k: k % 32 == 1 and k > 1
     st, inputs, QRdt, hist, final, final_exp = forced_run(sg_mod, oracle, "FASTSLAM2", N, seed, 100000, math_mode, True, threads=threads, args=args,
-                                                          log_weights=True, full_at=full_at, tol_scale=W_SCALE_10K, on_step=on_step)
+                                                          log_weights=True, full_at=full_at, on_step=on_step, weights_comparable=False,
+                                                          anchor_at=anchor_at, pose_atol=(1.5e-3, 4e-3)[math_mode], lmk_atol=(2e-3, 7.5e-3)[math_mode])
     print("free-running FASTSLAM2 philox 10k-landmark map N=256 log-weights %s: %s; rows in use: max %d, final %d, target first reached at step %s"
           % (["strict", "fast"][math_mode], st, max(rows), rows[-1], crossed[:1]))
     assert st["steps"] == 2172 and st["resamples"] > 1000, st
     assert final["nf"] > 9000
     assert crossed and max(rows) <= target + 64, (crossed, max(rows))   # consolidation engaged and held the rows at the target
-    ensure(st["decision_diff"] <= 12, st)
-    check_final(final, final_exp, math_mode)
+    assert st.get("anchored", 0) >= 60 and st.get("anch_w", 0) >= 15, st
+    check_final(final, final_exp, math_mode, (1.5e-3, 4e-3)[math_mode], (2e-3, 7.5e-3)[math_mode])
     hist_u, final_u = undisturbed(sg_mod, oracle, "FASTSLAM2", N, seed, math_mode, True, inputs, QRdt, args=args, log_weights=True)
     for a, b in zip(hist, hist_u):
         assert np.array_equal(a, b)

@@ -296,32 +296,3 @@ def test_c_download_straight_after_device_steps(sg, monkeypatch, plain):
     for key in ("xv", "w", "xf", "Pf"):
         assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), key
     assert np.isfinite(a["xf"]).all()
-
-
-def test_capacity_overflow_of_the_device_front_end_stays_flagged(sg):
-    """More landmarks in view than the context has room for: the device front end drops the surplus and says so.  The first
-    call that brings the bookkeeping back reports SLAMGPU_ERR_CAPACITY; after that the run goes on, but slamgpu_step_status keeps
-    SLAMGPU_STATUS_CAPACITY set -- also after further device-driven steps (the bit travels back to the device with the book)."""
-    from slam_amd import host
-    args = sim_args("example_webmap", "FASTSLAM2", 100, 7)
-    tape = host.make_tape(args, max_obs=12)
-    sim = host.HostSim(args)
-    lm, _ = sim.map()
-    max_range = float(sim.conf.MAX_RANGE)
-    sim.close()
-    N = 512
-    s = sg.SlamGpu(N, 4, method=2, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=5, math_mode=1, device_observe=True)
-    s.set_map(lm)  # 35 landmarks in the map, room for 4 (six are seen on the first observation)
-    step = lambda st: s.step_observe(np.array(st["controls"], f32).reshape(-1, 3), tape["Q"], float(tape["dt"]), st["true"], max_range, tape["R"], noise=2)
-    for st in tape["steps"][:4]:
-        step(st)
-    with pytest.raises(sg.SlamGpuError) as e:
-        s.nf()
-    assert e.value.code == -3
-    assert s.nf() == 4           # reported once; the count is usable afterwards
-    assert s.status() & 4
-    for st in tape["steps"][4:8]:
-        step(st)                  # the book goes back to the device, the bit with it
-    assert s.nf() == 4
-    assert s.status() & 4
-    s.close()

@@ -87,7 +87,7 @@ def test_resample_stage_vs_reference_vectors(sg, kat, N, math_mode):
         assert did
         if neff is not None:
             np.testing.assert_allclose(neff, neff_ref, rtol=2e-6)   # (double sums on the device, float32 in the reference)
-            np.testing.assert_allclose(wsum, w.astype(np.float64).sum(), rtol=1e-12)
+            np.testing.assert_allclose(wsum, w.astype(np.float64).sum(), rtol=2e-7)   # (float32 prefixes inside a block of 256, double across blocks)
         assert np.all(np.diff(keep) >= 0) and keep.min() >= 0 and keep.max() < N
         nbad = explain(w, sel, keep, keep_ref)
         worst = max(worst, nbad)
@@ -111,5 +111,6 @@ def test_no_resample_above_threshold_normalises_like_the_reference(sg, kat, N):
     ws = f32(0)
     for x in w:              # the reference's serial float32 sum (core.cpp:726-729)
         ws = f32(ws + x)
-    np.testing.assert_allclose(got, w / ws, rtol=3e-7)
+    # the device divides by its double-precision sum rounded once; the reference's serial float32 sum is a few ulps off that at N = 1 000
+    np.testing.assert_allclose(got, w / ws, rtol=1e-6)
     s.close()

@@ -10,7 +10,7 @@ ARGS=${@:---no-cpu-baseline}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --single-pass $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err || echo "trace rc=$?"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --single-pass $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err || echo "fetch rc=$?"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --single-pass $ARGS > $OUT/bench_write.json 2> $OUT/write.err || echo "write rc=$?"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py --single-pass --repeats 1 $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err || echo "trace rc=$?"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --single-pass --repeats 1 $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err || echo "fetch rc=$?"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --single-pass --repeats 1 $ARGS > $OUT/bench_write.json 2> $OUT/write.err || echo "write rc=$?"
 python3 tools/profile_summary.py $OUT $TAG

@@ -7,8 +7,8 @@ ARGS=${@:---no-cpu-baseline}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 bench.py --single-pass $ARGS > $OUT/bench_sq.json 2> $OUT/sq.err || echo "sq rc=$?"
-rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -- python3 bench.py --single-pass $ARGS > $OUT/bench_sq2.json 2> $OUT/sq2.err || echo "sq2 rc=$?"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 bench.py --single-pass --repeats 1 $ARGS > $OUT/bench_sq.json 2> $OUT/sq.err || echo "sq rc=$?"
+rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -- python3 bench.py --single-pass --repeats 1 $ARGS > $OUT/bench_sq2.json 2> $OUT/sq2.err || echo "sq2 rc=$?"
 python3 - <<PY
 import csv, glob, collections, json
 steps = None

@@ -8,7 +8,7 @@ wave's outstanding memory operations and records the 100 MHz wall clock at ten p
 over blocks and launches of the time since the EARLIEST block entered the kernel, split by whether the launch had to
 perform the previous step's resampling (inline plan fired) or not.
 
-usage: python tools/stamps.py [N] [samples] [host|device]   (writes a table to stdout; copy into profiles/)
+usage: python tools/stamps.py [N] [samples] [host|device] [FASTSLAM2|FASTSLAM1]   (writes a table to stdout; copy into profiles/)
        device: the steps are slamgpu_step_observe calls (the observation front end inside the update launch)"""
 import os
 import sys
@@ -24,12 +24,14 @@ from slam_amd import host  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 SAMPLES = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 DEVICE = len(sys.argv) > 3 and sys.argv[3] == "device"
+METHOD = sys.argv[4] if len(sys.argv) > 4 else "FASTSLAM2"
+MID = 2 if METHOD == "FASTSLAM2" else 1
 START = 1000
 LEVELS = ["0 kernel entry (first block = 0)", "1 Ctrl words arrived", "2 block totals scanned (W, Neff, decision)",
           "3 ancestor found", "4 pose + genealogy arrived", "5 records staged in LDS", "6 proposal pass done",
           "7 second pass done, record stores landed", "8 pose / genealogy stores landed", "9 weight prefix + totals written"]
 
-tape = host.make_tape(["-m", os.path.join(ROOT, "data", "example_webmap.mat"), "-method", "FASTSLAM2", "-NPARTICLES", N,
+tape = host.make_tape(["-m", os.path.join(ROOT, "data", "example_webmap.mat"), "-method", METHOD, "-NPARTICLES", N,
                        "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", 7], max_obs=START + SAMPLES + 2)
 Q, R, dt = tape["Q"], tape["R"], float(tape["dt"])
 _sim = host.HostSim(["-m", os.path.join(ROOT, "data", "example_webmap.mat"), "-method", "FASTSLAM2"])
@@ -39,7 +41,7 @@ _sim.close()
 
 
 def make():
-    s = slam_amd.SlamGpu(N, tape["nlm"], method=2, n_effective=int(0.75 * N), rng_mode=slam_amd.RNG_PHILOX, seed=7, math_mode=1, device_observe=DEVICE)
+    s = slam_amd.SlamGpu(N, tape["nlm"], method=MID, n_effective=int(0.75 * N), rng_mode=slam_amd.RNG_PHILOX, seed=7, math_mode=1, device_observe=DEVICE)
     if DEVICE:
         s.set_map(LM)
         calls = [s.prepare_step_observe(np.array(st["controls"], np.float32).reshape(-1, 3), Q, dt, st["true"], MAX_RANGE, R, noise=2) for st in tape["steps"]]
@@ -104,6 +106,7 @@ def table(title, stamp_sets):
 
 
 print("observation front end: %s" % ("inside the update launch (slamgpu_step_observe)" if DEVICE else "host (slamgpu_step)"))
+print("method %s" % METHOD)
 print("N = %d particles, steps %d..%d of the example_webmap run, fast build, instrumented (thread 0 of each block drains vmcnt/lgkmcnt at each stamp)" % (N, START, START + SAMPLES))
 table("update launches that do NOT plan inline (previous stage already ran: pose read at slot i or through keep[])", last)
 fired = [st for (kk, st) in pairs if res2[kk - START - 1]]
