@@ -39,8 +39,34 @@ SLAM_DEV void nt_store(float *p, float v) { __builtin_nontemporal_store(v, p); }
 // FastSLAM1::predictState (fastslam1.cpp:37-54).  P is the full 3x3 (the reference's Pv is not kept
 // symmetric by its own float arithmetic; only the stored form is packed).
 // ---------------------------------------------------------------------------------------------------
+// Per-particle control noise of the queued predicts (multivariateGauss((V, G), Q): fastslam1.cpp:44, fastslam2.cpp:91), device
+// draws: Philox + Box-Muller per (particle, control step) depend on NOTHING the launch has to wait for, and they are most of a
+// FastSLAM1 step's arithmetic (two 32-bit multiply pairs per Philox round at quarter rate: ~0.3 us per draw for a wave that has
+// its SIMD to itself).  In small contexts (at most one block per CU: the launch is a latency chain, BASELINE config 2)
+// update_kernel draws them while the head of its dependent-load chain is in flight -- half behind the block totals, half
+// behind the pose -- into LDS ([2 nsteps][256] floats: column = thread, so no barrier and no bank conflict) instead of inside the
+// predict loop after the pose has arrived.  Same function, same counter, same values: results are bit for bit those of
+// drawing in the loop.  (Registers were tried first: a 16-wide vector indexed by the loop counter is demoted to scratch.)
+constexpr int kHoistNoiseMaxBlocks = 256;  // (larger contexts have other waves to issue while one waits, and need their LDS)
+__host__ __device__ inline bool hoist_predict_noise(const PredictArgs &A, int rng_mode, int nblocks) {
+    return A.nsteps > 0 && A.add_noise != 0 && rng_mode != 0 && nblocks <= kHoistNoiseMaxBlocks;
+}
+SLAM_DEV void draw_predict_noise(const PredictArgs &A, const RngArgs &rng, int i, int lo, int hi, float *pnl) {
+    for (int s = lo; s < hi; s++) {
+        float g0, g1, g2;
+        U4 r = philox4x32((uint32_t) (rng.first_particle + i), A.steps[s].step, 2u, 0u, rng.k0, rng.k1);
+#ifdef SLAM_FAST_MATH
+        if (A.method == 1 && !A.use_heading) box_muller3_fast(r, g0, g1, g2);  // (what predict_steps_fs1_fast draws)
+        else
+#endif
+            box_muller3(r, g0, g1, g2);
+        pnl[(2 * s) * kBlock + threadIdx.x] = g0;
+        pnl[(2 * s + 1) * kBlock + threadIdx.x] = g1;
+    }
+}
+
 SLAM_DEV void predict_steps(float &x, float &y, float &th, float P[9], const PredictArgs &A, const RngArgs &rng, int i,
-                            size_t S) {
+                            size_t S, const float *pre = nullptr) {
     const bool fs2 = A.method == 2;
     const float dt = A.dt, wb = A.wheel_base;
     const float Q00 = A.Q[0], Q01 = A.Q[1], Q10 = A.Q[2], Q11 = A.Q[3];
@@ -88,6 +114,9 @@ SLAM_DEV void predict_steps(float &x, float &y, float &th, float P[9], const Pre
             if (rng.mode == 0) {
                 g0 = rng.normals[((size_t) s * 2 + 0) * S + i];
                 g1 = rng.normals[((size_t) s * 2 + 1) * S + i];
+            } else if (pre) {
+                g0 = pre[(2 * s) * kBlock + threadIdx.x];
+                g1 = pre[(2 * s + 1) * kBlock + threadIdx.x];
             } else {
                 U4 r = philox4x32((uint32_t) (rng.first_particle + i), A.steps[s].step, 2u, 0u, rng.k0, rng.k1);
                 box_muller3(r, g0, g1, g2);
@@ -152,7 +181,8 @@ SLAM_DEV void predict_steps(float &x, float &y, float &th, float P[9], const Pre
 // chol(Q) is step- and particle-independent, the first sincos of predict_steps is dead when the controls are resampled,
 // Box-Muller and the trigonometry use the bounded-angle polynomials / hardware transcendentals of this build
 // (1.5 ulp, tools/check_fast_math.py).  BASELINE config 2 (1 000 particles): 19.8 -> see DESIGN.md section 5.
-SLAM_DEV void predict_steps_fs1_fast(float &x, float &y, float &th, const PredictArgs &A, const RngArgs &rng, int i, size_t S) {
+SLAM_DEV void predict_steps_fs1_fast(float &x, float &y, float &th, const PredictArgs &A, const RngArgs &rng, int i, size_t S,
+                                     const float *pre = nullptr) {
     const float dt = A.dt, iwb = 1.0f / A.wheel_base;
     const L2 L = llt2(A.Q[0], A.Q[2], A.Q[3]);  // multivariateGauss((V,G), Q, 1) (core.cpp:452)
     for (int s = 0; s < A.nsteps; s++) {
@@ -160,6 +190,9 @@ SLAM_DEV void predict_steps_fs1_fast(float &x, float &y, float &th, const Predic
         if (rng.mode == 0) {
             g0 = rng.normals[((size_t) s * 2 + 0) * S + i];
             g1 = rng.normals[((size_t) s * 2 + 1) * S + i];
+        } else if (pre) {
+            g0 = pre[(2 * s) * kBlock + threadIdx.x];
+            g1 = pre[(2 * s + 1) * kBlock + threadIdx.x];
         } else {
             U4 r = philox4x32((uint32_t) (rng.first_particle + i), A.steps[s].step, 2u, 0u, rng.k0, rng.k1);
             box_muller3_fast(r, g0, g1, g2);
@@ -923,7 +956,7 @@ __host__ __device__ constexpr size_t update_window_bytes() { return sizeof(float
 // staged landmark slots per thread of an update launch (host and device agree on the dynamic LDS layout)
 __host__ __device__ inline int staging_slots(int method, bool big, int m) {
     if (big) return kBigChunk;
-    if (method != 2 || m <= 0) return 0;
+    if (m <= 0) return 0;
     return m <= kStage / 2 ? kStage / 2 : kStage;
 }
 
@@ -937,7 +970,8 @@ __host__ __device__ inline int staging_slots(int method, bool big, int m) {
 // stood between kernel entry and the first vector load before; 16.7 -> 16.05 us per step at 10^5 particles).
 // Tried on top and measured as no better (gpurun_out/ab, 16.28 / 16.10 / 16.04 us): preloading these arguments into SGPRs
 // (-mllvm -amdgpu-kernarg-preload-count=16) and touching every 64-byte line of the argument segment at entry.
-//   h_flags: bit 0 plan_inline, bit 1 scan_global, bit 2 logw, bit 3 lazy, bit 4 front end inside the launch (h_front)
+//   h_flags: bit 0 plan_inline, bit 1 scan_global, bit 2 logw, bit 3 lazy, bit 4 front end inside the launch (h_front),
+//            bit 5 the predicts' control noise is drawn at the head of the launch (draw_predict_noise)
 template <int METHOD, int MODE, bool BIG>
 __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict__ h_tot, Ctrl *h_ctrl,
                                                          const FrontState *h_front, int h_nb, int h_slot, int h_grid, int h_flags, Buffers B, PredictArgs PA,
@@ -1103,6 +1137,17 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     if (bt < nb) {
         const int x = bt & 7, j = bt >> 3, q = nb >> 3, r = nb & 7;
         bt = x < r ? x * (q + 1) + j : r * (q + 1) + (x - r) * q + j;
+    }
+    // control noise of the queued predicts (draw_predict_noise): the first half is drawn here, behind the head's loads (block totals,
+    // packet, Ctrl words: all requested above) and in front of the first wait for them
+    // (LDS behind the staged records: [2 nsteps][256] floats, launch_update sizes it with the same rule)
+    float *const pnl = shB + (size_t) nslots * kBlock;
+    const bool hoist_noise = MODE == 0 && (h_flags & 32) != 0 && (int) blockIdx.x < nb;  // (single contexts)
+    const int n_early = hoist_noise ? (PA.nsteps + 1) / 2 : 0;
+    if (hoist_noise) {
+        __builtin_amdgcn_sched_barrier(0);
+        draw_predict_noise(PA, rng, bt * kBlock + (int) threadIdx.x, 0, n_early, pnl);
+        __builtin_amdgcn_sched_barrier(0);
     }
     SLAM_STAMP(1);  // Ctrl words arrived
     // Where does particle i of the set this update works on come from?
@@ -1415,7 +1460,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         // the slots of the (first kStage) re-observed landmarks are fetched now, with the pose: they depend on nothing but
         // the source slot, so the records are one round trip behind the pose, not two
         int ts[kStage];
-        const bool early_records = !BIG && METHOD == 2 && m > 0 && all_fresh;
+        const bool early_records = !BIG && m > 0 && all_fresh;
         if (!BIG) {
 #pragma unroll
             for (int k = 0; k < kStage; k++) ts[k] = all_fresh ? (DIST ? gsrc : si) : slot_of(min(k, max(m - 1, 0)));
@@ -1435,6 +1480,11 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
             box_muller3(r, hg0, hg1, hg2);
 #endif
             asm volatile("" : "+v"(hg0), "+v"(hg1), "+v"(hg2));  // (pinned above the wait for the pose)
+        }
+        if (hoist_noise) {  // ... and the second half of the predicts' control noise (draw_predict_noise)
+            __builtin_amdgcn_sched_barrier(0);
+            draw_predict_noise(PA, rng, i, n_early, PA.nsteps, pnl);
+            __builtin_amdgcn_sched_barrier(0);
         }
         SLAM_STAMP(4);  // pose + genealogy of the ancestor arrived
         float x = pa.x, y = pa.y, th = pa.z;
@@ -1466,12 +1516,12 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                 predict_composite(x, y, th, P, PA.comp);
                 q00 = P.p00; q10 = P.p10; q11 = P.p11; q20 = P.p20; q21 = P.p21; q22 = P.p22;
             } else if (METHOD == 1 && PA.add_noise && !PA.use_heading) {
-                predict_steps_fs1_fast(x, y, th, PA, rng, i, S);
+                predict_steps_fs1_fast(x, y, th, PA, rng, i, S, hoist_noise ? pnl : nullptr);
             } else
 #endif
             {
                 float P[9] = {q00, q10, q20, q10, q11, q21, q20, q21, q22};
-                predict_steps(x, y, th, P, PA, rng, i, S);
+                predict_steps(x, y, th, P, PA, rng, i, S, hoist_noise ? pnl : nullptr);
                 q00 = P[0]; q10 = P[3]; q11 = P[4]; q20 = P[6]; q21 = P[7]; q22 = P[8];
             }
             pose_dirty = true;
@@ -1719,10 +1769,19 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                 if constexpr (BIG) {
                     pipeline(one_pass);
                 } else {
+                    // staged like FastSLAM2's (round 4): the slots were requested with the pose and the records one trip behind
+                    // them, all in flight together, instead of a slot -> record chain of two dependent trips per landmark
+                    // (config 2: ~9 of the launch's 15 us lay between the arrival of the pose and its store)
+                    stage_landmarks(ts, early_records);
                     for (int k = 0; k < m; k++) {
                         float4 la;
                         float lb;
-                        load_lmk(idf[k], slot_of(k), buf_of(k), la, lb);
+                        if (k < kStage) {
+                            la = shA[(k) * kBlock + threadIdx.x];
+                            lb = shB[(k) * kBlock + threadIdx.x];
+                        } else {
+                            load_lmk(idf[k], slot_of(k), buf_of(k), la, lb);
+                        }
                         one_pass(k, la, lb);
                     }
                 }
@@ -3098,10 +3157,12 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
     const size_t nbg = (size_t) ws.nblocks * (U.arrivals == 2 ? (size_t) B.n_shards : 1);  // distributed: blocks of all shards
     const size_t lds = (size_t) staging_slots(U.method, U.big != nullptr, U.m) * kBlock * (sizeof(float4) + sizeof(float)) +
                        ((U.plan_inline && !U.scan_global) ? sizeof(double) * ((nbg + 3) & ~(size_t) 1) : 0) +
-                       (U.plan_inline ? update_window_bytes() : 0);
+                       (U.plan_inline ? update_window_bytes() : 0) +
+                       ((U.arrivals == 0 && hoist_predict_noise(PA, rng.mode, ws.nblocks)) ? sizeof(float) * 2 * (size_t) PA.nsteps * kBlock : 0);
     const int sel = (U.method == 2 ? 6 : 0) + 2 * U.arrivals + (U.big ? 1 : 0);
     const float *h_tot = U.arrivals == 2 ? B.gtot[ws.wpar ^ 1] : ws.blk_w[ws.wpar ^ 1];
-    const int h_flags = (U.plan_inline ? 1 : 0) | (U.scan_global ? 2 : 0) | (U.logw ? 4 : 0) | (U.lazy ? 8 : 0) | (U.front.on ? 16 : 0);
+    const int h_flags = (U.plan_inline ? 1 : 0) | (U.scan_global ? 2 : 0) | (U.logw ? 4 : 0) | (U.lazy ? 8 : 0) | (U.front.on ? 16 : 0) |
+                        ((U.arrivals == 0 && hoist_predict_noise(PA, rng.mode, ws.nblocks)) ? 32 : 0);
 #define SLAM_LAUNCH_UPDATE(M, A, G)                                                                                              \
     hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid, \
                        h_flags, B, PA, U, rng, ws)

@@ -482,6 +482,45 @@ def test_step_call_equals_separate_calls(sg):
     assert sa == sb
 
 
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+@pytest.mark.parametrize("method,N", [("FASTSLAM1", 1000), ("FASTSLAM1", 70000), ("FASTSLAM2", 1000)])
+def test_predict_noise_drawn_at_the_head_of_the_launch_changes_no_bit(sg, method, N, math_mode):
+    """Contexts of at most 256 blocks draw the per-particle control noise of the queued predicts (FastSLAM1: always on,
+    fastslam1wrapper.cpp:20; FastSLAM2: SWITCH_PREDICT_NOISE) at the head of the update launch, while its first loads are in
+    flight (kernels.hip: draw_predict_noise), and FastSLAM1 stages its landmark records like FastSLAM2.  Same Philox counters,
+    same Box-Muller: the run must equal, bit for bit, the run whose predicts are flushed as launches of their own
+    (predict_kernel draws inside its loop) before every update -- BASELINE configs[1]'s size, a size beyond the 256-block rule,
+    and FastSLAM2 with predict noise."""
+    import os
+    from slam_amd import host
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tape = host.make_tape(["-m", os.path.join(root, "data", "example_webmap.mat"), "-method", method, "-NPARTICLES", N,
+                           "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", 3], max_obs=80)
+    mid = 2 if method == "FASTSLAM2" else 1
+    runs = []
+    for mode in ("one launch", "predicts flushed"):
+        s = sg.SlamGpu(N, tape["nlm"], method=mid, n_effective=int(0.75 * N), add_predict_noise=True, rng_mode=sg.RNG_PHILOX, seed=11,
+                       math_mode=math_mode)
+        for st in tape["steps"]:
+            if mode == "one launch":
+                s.step(np.array(st["controls"], f32).reshape(-1, 3), tape["Q"], float(tape["dt"]), st["zf"], st["idf"], st["zn"], tape["R"])
+            else:
+                for (V, G, phi) in st["controls"]:
+                    s.predict(V, G, tape["Q"], float(tape["dt"]), phi)
+                s.sync()   # the queued predicts run now, as predict_kernel
+                s.update(st["zf"], st["idf"], st["zn"], tape["R"])
+                s.estimate_async()
+        h = s.history_fetch()
+        runs.append((s.download(), h))
+        s.close()
+    (a, ha), (b, hb) = runs
+    assert 5 < ha[2].sum() < 80
+    for x, y in zip(ha, hb):
+        assert np.array_equal(x, y)
+    for key in ("xv", "Pv", "w", "xf", "Pf"):
+        assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), key
+
+
 def test_history_carries_the_resampling_record(sg):
     """slamgpu_history_fetch: per-step Neff / resampled, identical to what slamgpu_stats reports step by step."""
     import os
