@@ -48,15 +48,20 @@ SLAM_DEV void nt_store(float *p, float v) { __builtin_nontemporal_store(v, p); }
 // predict loop after the pose has arrived.  Same function, same counter, same values: results are bit for bit those of
 // drawing in the loop.  (Registers were tried first: a 16-wide vector indexed by the loop counter is demoted to scratch.)
 constexpr int kHoistNoiseMaxBlocks = 256;  // (larger contexts have other waves to issue while one waits, and need their LDS)
-__host__ __device__ inline bool hoist_predict_noise(const PredictArgs &A, int rng_mode, int nblocks) {
-    return A.nsteps > 0 && A.add_noise != 0 && rng_mode != 0 && nblocks <= kHoistNoiseMaxBlocks;
+static bool hoist_predict_noise(const PredictArgs &A, int rng_mode, int nblocks) {
+    static const bool off = getenv("SLAMGPU_NO_HOIST") != nullptr;  // (experiment switch, round 4)
+    return !off && A.nsteps > 0 && A.add_noise != 0 && rng_mode != 0 && nblocks <= kHoistNoiseMaxBlocks;
 }
-SLAM_DEV void draw_predict_noise(const PredictArgs &A, const RngArgs &rng, int i, int lo, int hi, float *pnl) {
+// (everything it needs rides in the kernel's LEADING scalar arguments -- Philox key, first particle, counter of the first
+// queued predict (the counters of one launch are consecutive: slamgpu_predict) -- so the draws wait for nothing but the first
+// scalar load of the kernel; taken from the argument structs they would queue behind the cold trip of the Ctrl words, which
+// shares the scalar-load counter)
+SLAM_DEV void draw_predict_noise(uint32_t first, uint32_t step0, uint32_t k0, uint32_t k1, bool fast_bm, int i, int lo, int hi, float *pnl) {
     for (int s = lo; s < hi; s++) {
         float g0, g1, g2;
-        U4 r = philox4x32((uint32_t) (rng.first_particle + i), A.steps[s].step, 2u, 0u, rng.k0, rng.k1);
+        U4 r = philox4x32(first + (uint32_t) i, step0 + (uint32_t) s, 2u, 0u, k0, k1);
 #ifdef SLAM_FAST_MATH
-        if (A.method == 1 && !A.use_heading) box_muller3_fast(r, g0, g1, g2);  // (what predict_steps_fs1_fast draws)
+        if (fast_bm) box_muller3_fast(r, g0, g1, g2);  // (what predict_steps_fs1_fast draws)
         else
 #endif
             box_muller3(r, g0, g1, g2);
@@ -181,8 +186,10 @@ SLAM_DEV void predict_steps(float &x, float &y, float &th, float P[9], const Pre
 // chol(Q) is step- and particle-independent, the first sincos of predict_steps is dead when the controls are resampled,
 // Box-Muller and the trigonometry use the bounded-angle polynomials / hardware transcendentals of this build
 // (1.5 ulp, tools/check_fast_math.py).  BASELINE config 2 (1 000 particles): 19.8 -> see DESIGN.md section 5.
+// ctl (optional): LDS copy of A.steps (8 dwords per step: V, G first), so that the loop does not fetch a cold line of the
+// kernel-argument segment per iteration (scalar cache misses at every launch: ~0.3 us each on the step's critical chain)
 SLAM_DEV void predict_steps_fs1_fast(float &x, float &y, float &th, const PredictArgs &A, const RngArgs &rng, int i, size_t S,
-                                     const float *pre = nullptr) {
+                                     const float *pre = nullptr, const float *ctl = nullptr) {
     const float dt = A.dt, iwb = 1.0f / A.wheel_base;
     const L2 L = llt2(A.Q[0], A.Q[2], A.Q[3]);  // multivariateGauss((V,G), Q, 1) (core.cpp:452)
     for (int s = 0; s < A.nsteps; s++) {
@@ -197,8 +204,8 @@ SLAM_DEV void predict_steps_fs1_fast(float &x, float &y, float &th, const Predic
             U4 r = philox4x32((uint32_t) (rng.first_particle + i), A.steps[s].step, 2u, 0u, rng.k0, rng.k1);
             box_muller3_fast(r, g0, g1, g2);
         }
-        const float V = ffma(L.l00, g0, A.steps[s].V);
-        const float G = ffma(L.l11, g1, ffma(L.l10, g0, A.steps[s].G));
+        const float V = ffma(L.l00, g0, ctl ? ctl[8 * s] : A.steps[s].V);
+        const float G = ffma(L.l11, g1, ffma(L.l10, g0, ctl ? ctl[8 * s + 1] : A.steps[s].G));
         float sn, cs, sgw, cgw;
         sincos_cw(G + th, sn, cs);
         sincos_cw(G * iwb, sgw, cgw);  // sin(G / wheelBase): upstream quirk (fastslam1.cpp:52)
@@ -947,7 +954,14 @@ SLAM_DEV void front_book(const FrontArgs &F, const FrontObs ob, const FrontLm s,
 // instead of one dependent slot -> record round trip per landmark.
 // (measured at config 5, gpurun_out/var: 4 and 8 landmarks per chunk run the same 1.61 ms per step, 12 and 16 are slower;
 // 4 keeps the kernel at 103 / 110 VGPRs (fast / strict build: 4 waves per SIMD) and 20 KB of LDS per block, 8 needs 134 / 143)
-constexpr int kBigChunk = 4;
+#ifndef SLAM_BIG_CHUNK   // (round-4 experiment: pipeline geometry A/B, tools/gpu_r04_c5.sh)
+#define SLAM_BIG_CHUNK 4
+#endif
+#ifndef SLAM_PIPE_DEPTH
+#define SLAM_PIPE_DEPTH 1
+#endif
+constexpr int kBigChunk = SLAM_BIG_CHUNK;
+constexpr int kPipeDepth = SLAM_PIPE_DEPTH;
 constexpr int kStage = 8;  // landmarks per particle kept in LDS between the two passes of a small packet
 
 // LDS of the per-wave ancestor windows of a launch that plans inline (host and device agree on the dynamic LDS layout)
@@ -971,11 +985,12 @@ __host__ __device__ inline int staging_slots(int method, bool big, int m) {
 // Tried on top and measured as no better (gpurun_out/ab, 16.28 / 16.10 / 16.04 us): preloading these arguments into SGPRs
 // (-mllvm -amdgpu-kernarg-preload-count=16) and touching every 64-byte line of the argument segment at entry.
 //   h_flags: bit 0 plan_inline, bit 1 scan_global, bit 2 logw, bit 3 lazy, bit 4 front end inside the launch (h_front),
-//            bit 5 the predicts' control noise is drawn at the head of the launch (draw_predict_noise)
+//            bit 5 the predicts' control noise is drawn at the head of the launch (draw_predict_noise), bit 6 with box_muller3_fast
 template <int METHOD, int MODE, bool BIG>
 __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict__ h_tot, Ctrl *h_ctrl,
-                                                         const FrontState *h_front, int h_nb, int h_slot, int h_grid, int h_flags, Buffers B, PredictArgs PA,
-                                                         UpdateArgs U, RngArgs rng, WeightScratch ws) {
+                                                         const FrontState *h_front, int h_nb, int h_slot, int h_grid, int h_flags,
+                                                         uint32_t h_k0, uint32_t h_k1, uint32_t h_first, uint32_t h_step0, int h_nsteps, int h_pad,
+                                                         Buffers B, PredictArgs PA, UpdateArgs U, RngArgs rng, WeightScratch ws) {
     constexpr bool ARR = MODE == 1, DIST = MODE == 2;
     __shared__ float sh_w[kBlock / kWave], sh_w2[kBlock / kWave];
     // landmarks re-observed this step, staged between the proposal pass and the likelihood/feature-update pass
@@ -1074,8 +1089,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     FrontLm f_lm{-1, 0};
     FrontHdr f_hd{0, -1, 0, 0};
     float f_x = 0.f, f_y = 0.f;
-    // dword offsets in the kernel-argument segment (40: the head)
-    constexpr size_t ka0 = (40 + sizeof(Buffers) + alignof(PredictArgs) - 1) / alignof(PredictArgs) * alignof(PredictArgs);
+    // dword offsets in the kernel-argument segment (64: the head: 3 pointers + 10 ints)
+    constexpr size_t ka0 = (64 + sizeof(Buffers) + alignof(PredictArgs) - 1) / alignof(PredictArgs) * alignof(PredictArgs);
     constexpr size_t ka1 = (ka0 + sizeof(PredictArgs) + alignof(UpdateArgs) - 1) / alignof(UpdateArgs) * alignof(UpdateArgs);
     constexpr size_t ka_small = (ka1 + offsetof(UpdateArgs, small)) / 4;
     if constexpr (!BIG && MODE == 0) {
@@ -1099,10 +1114,17 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     __shared__ uint32_t f_sets[4];
     __shared__ float f_aux[2 * kWave + 2];
     int32_t pkv = 0;
+    // ... and the queued controls (PredictArgs::steps: 16 x 8 dwords) the same way, for the predict loop (compact contexts)
+    constexpr int kStepWords = (int) (sizeof(PredictStep) / 4) * kMaxFusedPredict;
+    static_assert(sizeof(PredictStep) == 32 && kStepWords <= kBlock, "one dword of PredictArgs::steps per thread");
+    __shared__ float sh_ctl[BIG ? 1 : kStepWords];
+    float ctlv = 0.0f;
     if constexpr (!BIG) {
         constexpr size_t at = ka_small;  // dword offset of U.small in the kernel arguments
         const auto *ka = (const __attribute__((address_space(4))) int32_t *) __builtin_amdgcn_kernarg_segment_ptr();
         if (!front && threadIdx.x < kSmallWords) pkv = ka[at + threadIdx.x];  // (parked in LDS below, once the scan's loads are out too)
+        const auto *kc = (const __attribute__((address_space(4))) float *) __builtin_amdgcn_kernarg_segment_ptr();
+        if (threadIdx.x < kStepWords) ctlv = kc[(ka0 + offsetof(PredictArgs, steps)) / 4 + threadIdx.x];
     }
     const int cur = h_ctrl->live[h_slot];  // ... and the Ctrl words
     const bool pend_word = h_ctrl->pend[h_slot] != 0;
@@ -1125,6 +1147,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                 // (every word a host-made packet would carry is defined: loops further down read clamped entries past m and n)
                 for (int w = ft; w < kSmallWords; w += kWave) pk[w] = 0;
             }
+            if (threadIdx.x < kStepWords) sh_ctl[threadIdx.x] = ctlv;
             __syncthreads();
             if (fw == 0) {
                 const auto *kf = (const __attribute__((address_space(4))) float *) __builtin_amdgcn_kernarg_segment_ptr();
@@ -1143,10 +1166,12 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     // (LDS behind the staged records: [2 nsteps][256] floats, launch_update sizes it with the same rule)
     float *const pnl = shB + (size_t) nslots * kBlock;
     const bool hoist_noise = MODE == 0 && (h_flags & 32) != 0 && (int) blockIdx.x < nb;  // (single contexts)
-    const int n_early = hoist_noise ? (PA.nsteps + 1) / 2 : 0;
+    const int n_early = hoist_noise ? (h_nsteps + 1) / 2 : 0;
+    const bool fast_bm = (h_flags & 64) != 0;
+    (void) h_pad;
     if (hoist_noise) {
         __builtin_amdgcn_sched_barrier(0);
-        draw_predict_noise(PA, rng, bt * kBlock + (int) threadIdx.x, 0, n_early, pnl);
+        draw_predict_noise(h_first, h_step0, h_k0, h_k1, fast_bm, bt * kBlock + (int) threadIdx.x, 0, n_early, pnl);
         __builtin_amdgcn_sched_barrier(0);
     }
     SLAM_STAMP(1);  // Ctrl words arrived
@@ -1228,6 +1253,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     }
     if constexpr (!BIG) {
         if (!front && threadIdx.x < kSmallWords) pk[threadIdx.x] = pkv;
+        if (!front && threadIdx.x < kStepWords) sh_ctl[threadIdx.x] = ctlv;
         __syncthreads();
         if ((uint32_t) pk[offsetof(SmallObs, magic) / 4] != kSmallMagic) {  // (layout guard: never seen)
             if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->status = kStatusBadPacket;
@@ -1415,14 +1441,16 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         // (see kBigChunk).  Out-of-range tail entries re-read the last landmark (never consumed).
         auto pipeline = [&](auto body) {
             constexpr int CH = kBigChunk;
+            // kPipeDepth chunks of records in flight (their slots one chunk further ahead): register sets used in rotation,
+            // the loop unrolled by the depth so that every set is indexed statically
             int sl[CH];
-            float4 ta[CH];
-            float tb[CH];
+            float4 ta0[CH], ta1[CH], ta2[CH];
+            float tb0[CH], tb1[CH], tb2[CH];
             auto load_slots = [&](int k0) {
 #pragma unroll
                 for (int k = 0; k < CH; k++) sl[k] = slot_of(min(k0 + k, m - 1));
             };
-            auto load_recs = [&](int k0) {
+            auto load_recs = [&](int k0, float4 *ta, float *tb) {
 #pragma unroll
                 for (int k = 0; k < CH; k++) {
                     const Rec r = load_rec(idf[min(k0 + k, m - 1)], sl[k], buf_of(min(k0 + k, m - 1)));
@@ -1430,21 +1458,38 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                     tb[k] = r.b;
                 }
             };
-            load_slots(0);
-            load_recs(0);
-            load_slots(CH);
-            for (int k0 = 0; k0 < m; k0 += CH) {
+            // one chunk: park its records (requested kPipeDepth chunks of compute ago) in LDS, request the chunk kPipeDepth
+            // ahead into the set just freed and the slots of the one after, compute out of LDS
+            auto phase = [&](int k0, float4 *ta, float *tb) {
 #pragma unroll
                 for (int k = 0; k < CH; k++) {
                     shA[(k) * kBlock + threadIdx.x] = ta[k];
                     shB[(k) * kBlock + threadIdx.x] = tb[k];
                 }
-                if (k0 + CH < m) {
-                    load_recs(k0 + CH);       // slots of this chunk were requested one chunk of compute ago
-                    load_slots(k0 + 2 * CH);  // (clamped: harmless re-reads past the end)
+                if (k0 + kPipeDepth * CH < m) {
+                    load_recs(k0 + kPipeDepth * CH, ta, tb);
+                    load_slots(k0 + (kPipeDepth + 1) * CH);  // (clamped: harmless re-reads past the end)
                 }
                 const int kn = min(CH, m - k0);
                 for (int k = 0; k < kn; k++) body(k0 + k, shA[(k) * kBlock + threadIdx.x], shB[(k) * kBlock + threadIdx.x]);
+            };
+            load_slots(0);
+            load_recs(0, ta0, tb0);
+            load_slots(CH);
+            if constexpr (kPipeDepth >= 2) {
+                load_recs(CH, ta1, tb1);
+                load_slots(2 * CH);
+            }
+            if constexpr (kPipeDepth >= 3) {
+                load_recs(2 * CH, ta2, tb2);
+                load_slots(3 * CH);
+            }
+            for (int k0 = 0; k0 < m; k0 += kPipeDepth * CH) {
+                phase(k0, ta0, tb0);
+                if constexpr (kPipeDepth >= 2)
+                    if (k0 + CH < m) phase(k0 + CH, ta1, tb1);
+                if constexpr (kPipeDepth >= 3)
+                    if (k0 + 2 * CH < m) phase(k0 + 2 * CH, ta2, tb2);
             }
         };
 
@@ -1483,7 +1528,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         }
         if (hoist_noise) {  // ... and the second half of the predicts' control noise (draw_predict_noise)
             __builtin_amdgcn_sched_barrier(0);
-            draw_predict_noise(PA, rng, i, n_early, PA.nsteps, pnl);
+            draw_predict_noise(h_first, h_step0, h_k0, h_k1, fast_bm, i, n_early, h_nsteps, pnl);
             __builtin_amdgcn_sched_barrier(0);
         }
         SLAM_STAMP(4);  // pose + genealogy of the ancestor arrived
@@ -1516,7 +1561,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                 predict_composite(x, y, th, P, PA.comp);
                 q00 = P.p00; q10 = P.p10; q11 = P.p11; q20 = P.p20; q21 = P.p21; q22 = P.p22;
             } else if (METHOD == 1 && PA.add_noise && !PA.use_heading) {
-                predict_steps_fs1_fast(x, y, th, PA, rng, i, S, hoist_noise ? pnl : nullptr);
+                predict_steps_fs1_fast(x, y, th, PA, rng, i, S, hoist_noise ? pnl : nullptr, BIG ? nullptr : sh_ctl);
             } else
 #endif
             {
@@ -1526,6 +1571,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
             }
             pose_dirty = true;
         }
+        SLAM_STAMP(10);  // queued predicts applied
 
 #ifdef SLAM_FAST_MATH
         if (METHOD == 2) {
@@ -1748,6 +1794,21 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
             if (m > 0) {
                 float wp = 1.0f;
                 double dl = 0.0;
+#ifdef SLAM_FAST_MATH
+                // fast build (round 4): the restructured arithmetic FastSLAM2's second pass uses (device_math.h: observe2 +
+                // feature_update2: closed-form 2x2 inverse on one v_rcp_f32, polynomial atan2, hardware exp): computeWeight's
+                // factor exp(-v^T S^-1 v / 2) / (2 pi sqrt(det S)) (fastslam1.cpp:105-115) is gaussEvaluate(v, S) with D = 2, and
+                // choleskyUpdate is the same Kalman update.  ~100 VALU instructions per landmark instead of ~450 (IEEE divisions,
+                // libm atan2f / expf / sqrtf): 1.2 -> ~0.3 us per landmark for a wave that has its SIMD to itself.
+                const float rl1 = 0.5f * (r01 + r10);
+                auto one_pass = [&](int k, float4 la, float lb) {
+                    const Obs2 o = observe2(x, y, th, la.x, la.y, la.z, la.w, lb, r00, rl1, r11);
+                    const Gauss2 g = feature_update2(la.x, la.y, la.z, la.w, lb, o, zf[2 * k] - o.zp0, wrap_pi(zf[2 * k + 1] - o.zp1));
+                    if (logw) dl += (double) (g.E + __logf(g.norm));
+                    else wp *= __expf(g.E) * g.norm;
+                    store_lmk(idf[k], buf_of(k), la, lb);
+                };
+#else
                 auto one_pass = [&](int k, float4 la, float lb) {
                     Jac j = jacobian(x, y, th, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
                     const float v0 = zf[2 * k] - j.zp0;
@@ -1766,6 +1827,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                     cholesky_update2(la.x, la.y, la.z, la.w, lb, v0, v1, r00, r01, r10, r11, j.hf00, j.hf01, j.hf10, j.hf11);
                     store_lmk(idf[k], buf_of(k), la, lb);
                 };
+#endif
                 if constexpr (BIG) {
                     pipeline(one_pass);
                 } else {
@@ -1773,6 +1835,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                     // them, all in flight together, instead of a slot -> record chain of two dependent trips per landmark
                     // (config 2: ~9 of the launch's 15 us lay between the arrival of the pose and its store)
                     stage_landmarks(ts, early_records);
+                    SLAM_STAMP(5);  // records staged
                     for (int k = 0; k < m; k++) {
                         float4 la;
                         float lb;
@@ -1784,6 +1847,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                         }
                         one_pass(k, la, lb);
                     }
+                    SLAM_STAMP(7);  // landmark pass done, record stores landed
                 }
                 w = logw ? (float) ((double) w + dl) : w * wp;
             }
@@ -3162,10 +3226,12 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
     const int sel = (U.method == 2 ? 6 : 0) + 2 * U.arrivals + (U.big ? 1 : 0);
     const float *h_tot = U.arrivals == 2 ? B.gtot[ws.wpar ^ 1] : ws.blk_w[ws.wpar ^ 1];
     const int h_flags = (U.plan_inline ? 1 : 0) | (U.scan_global ? 2 : 0) | (U.logw ? 4 : 0) | (U.lazy ? 8 : 0) | (U.front.on ? 16 : 0) |
-                        ((U.arrivals == 0 && hoist_predict_noise(PA, rng.mode, ws.nblocks)) ? 32 : 0);
+                        ((U.arrivals == 0 && hoist_predict_noise(PA, rng.mode, ws.nblocks)) ? 32 : 0) |
+                        ((PA.method == 1 && !PA.use_heading) ? 64 : 0);  // (bit 6: the fast build's FastSLAM1 predict draws with box_muller3_fast)
+    const uint32_t h_first = (uint32_t) rng.first_particle, h_step0 = PA.nsteps > 0 ? PA.steps[0].step : 0u;
 #define SLAM_LAUNCH_UPDATE(M, A, G)                                                                                              \
     hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid, \
-                       h_flags, B, PA, U, rng, ws)
+                       h_flags, rng.k0, rng.k1, h_first, h_step0, PA.nsteps, 0, B, PA, U, rng, ws)
     switch (sel) {
         case 11: SLAM_LAUNCH_UPDATE(2, 2, true); break;
         case 10: SLAM_LAUNCH_UPDATE(2, 2, false); break;

@@ -78,7 +78,7 @@ def _mk(sg, o, N, method, rng_mode, math_mode, seed, log_weights=False):
 
 
 def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None, threads=1, mapname="example_webmap", args=None,
-               log_weights=False, full_at=None, w_tol=None, on_step=None, weights_comparable=True, anchor_at=None, pose_atol=None, lmk_atol=None):
+               log_weights=False, full_at=None, w_tol=None, on_step=None, weights_comparable=True, anchor_at=None, pose_atol=None, lmk_atol=None, yardstick64=None):
     """Drive oracle + GPU as described in the module docstring.  window = (lo, hi): observation steps (1-based) whose full
     state is compared; None = every step.  full_at(k) (optional): on steps inside the window where it is false only the poses
     and the weights are read and compared (big maps: the landmark records of a step are tens of MB).  args: the simulation's
@@ -88,7 +88,8 @@ def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None
     test_config5_map_*); anchor_at(k): step k is ALSO checked teacher-forced from the GPU's OWN free-running state: the GPU's
     full state after step k - 1 (read through its genealogy) goes into a scratch oracle set, which takes the same predicts,
     packet and normals, and must land on the GPU's state after step k within the per-step tolerances of
-    tests/test_gpu_parity.py (st["anchored"] counts them).  Returns the per-run statistics, the inputs (for the undisturbed
+    tests/test_gpu_parity.py (st["anchored"] counts them); yardstick64 = f: the anchored weights are judged against a float64
+    evaluation instead: the GPU's error may be at most f x the float32 oracle's own.  Returns the per-run statistics, the inputs (for the undisturbed
     replay) and the GPU's final state / history."""
     fs2 = method == "FASTSLAM2"
     oracle.set_threads(threads)
@@ -184,6 +185,7 @@ def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None
             for (V, G, phi, n2) in inputs[-1]["ctl"]:
                 P2.predict(algo, V, G, Q, float(dt), phi, n2)
             nm = o.last_tape()[0]
+            pre2 = P2.get() if yardstick64 else None   # the predicted set both float32 updates and the float64 yardstick start from
             P2.update_local(algo, ob["zf"], ob["idf"], ob["zn"], R, np.ascontiguousarray(nm))
             e2 = P2.get()
             src = keep if did_g else np.arange(N)
@@ -206,8 +208,21 @@ def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None
                 st["anch_w_p99"] = max(st.get("anch_w_p99", 0.0), float(np.quantile(rel, 0.99)))
                 st["anch_w_max"] = max(st.get("anch_w_max", 0.0), float(rel.max()))
                 t2 = W_TOL[math_mode]
-                ensure(np.median(rel) <= t2["median"] and np.quantile(rel, 0.99) <= t2["p99"] and rel.max() <= t2["max"],
-                       (tag, "anchored weights", np.median(rel), np.quantile(rel, 0.99), rel.max()))
+                if yardstick64:
+                    # hundreds of likelihood factors per weight: neither float32 evaluation is privileged -- both against a float64
+                    # evaluation of the same update from the same (float32) predicted set (tests/fs2_float64.py)
+                    import fs2_float64
+                    _, l64 = fs2_float64.update_log_weights(pre2, ob["zf"], ob["idf"], R, nm)
+                    w64 = np.exp(l64 - l64.max())
+                    w64 /= w64.sum()
+                    eg, er = np.abs(lg / w64 - 1.0), np.abs(le / w64 - 1.0)
+                    st.setdefault("y64", []).append((int(ob["zf"].shape[0]), float(np.median(eg)), float(np.median(er)), float(np.quantile(eg, 0.99)),
+                                                     float(np.quantile(er, 0.99))))
+                    ensure(np.median(eg) <= yardstick64 * np.median(er) + 1e-3 and np.quantile(eg, 0.99) <= yardstick64 * np.quantile(er, 0.99) + 1e-2,
+                           (tag, "anchored weights vs float64", np.median(eg), np.median(er), np.quantile(eg, 0.99), np.quantile(er, 0.99)))
+                else:
+                    ensure(np.median(rel) <= t2["median"] and np.quantile(rel, 0.99) <= t2["p99"] and rel.max() <= t2["max"],
+                           (tag, "anchored weights", np.median(rel), np.quantile(rel, 0.99), rel.max()))
         anchor = got if want_anchor else None
         exp = o.particles(landmarks=full)
         assert got["nf"] == exp["nf"], tag
@@ -440,7 +455,9 @@ def test_config5_map_whole_run_ancestor_forced_log_weights(sg_mod, oracle, synma
     anchor_at = lambda k: k % 32 == 1 and k > 1
     st, inputs, QRdt, hist, final, final_exp = forced_run(sg_mod, oracle, "FASTSLAM2", N, seed, 100000, math_mode, True, threads=threads, args=args,
                                                           log_weights=True, full_at=full_at, on_step=on_step, weights_comparable=False,
-                                                          anchor_at=anchor_at, pose_atol=(1.5e-3, 4e-3)[math_mode], lmk_atol=(2e-3, 7.5e-3)[math_mode])
+                                                          anchor_at=anchor_at, pose_atol=(1.5e-3, 4e-3)[math_mode], lmk_atol=(2e-3, 7.5e-3)[math_mode],
+                                                          yardstick64=3.0)
+    print("anchored steps vs float64 (m, median GPU, median oracle, p99 GPU, p99 oracle):", st.pop("y64", None))
     print("free-running FASTSLAM2 philox 10k-landmark map N=256 log-weights %s: %s; rows in use: max %d, final %d, target first reached at step %s"
           % (["strict", "fast"][math_mode], st, max(rows), rows[-1], crossed[:1]))
     assert st["steps"] == 2172 and st["resamples"] > 1000, st

@@ -14,8 +14,9 @@ The device sums the UN-normalised weights in double (block totals + in-block pre
 prefix; the reference normalises in float32 (w / sum, serial float sum, core.cpp:726-729) and compares the stratum with a
 float32 cumulative sum that restarts from zero for every prefix (core.cpp:813-824).  The two can only differ where a stratum
 lies within the float32 rounding of a cumulative-sum boundary; every mismatch below is checked to be exactly that (one
-neighbour, stratum within 4 float32 ulps of the float64 boundary).  Measured on MI355X (both builds, both paths):
-identical ancestor lists for every N -- the bound in the test is 0 mismatches for N <= 1000 and <= 2 for N = 5000."""
+neighbour, stratum within 4 float32 ulps of the float64 boundary; 16 at N = 5000).  Measured on MI355X (both builds, both
+paths): identical ancestor lists for N <= 1000, ONE differing ancestor of 5 000 at N = 5000 (stratum 4.07 ulps from the
+boundary, where the device's double sum is the more accurate of the two) -- the bounds in the test: 0 and <= 2."""
 import ctypes
 
 import numpy as np
@@ -42,7 +43,7 @@ def reference_strata(N):
     return sel
 
 
-def explain(w, sel, keep_gpu, keep_ref):
+def explain(w, sel, keep_gpu, keep_ref, ulps=4):
     """every differing ancestor: a neighbour, and its stratum sits on a cumulative-sum boundary to float32 rounding"""
     bad = np.nonzero(keep_gpu != keep_ref)[0]
     if bad.size == 0:
@@ -53,7 +54,7 @@ def explain(w, sel, keep_gpu, keep_ref):
         a, b = int(keep_gpu[i]), int(keep_ref[i])
         assert abs(a - b) == 1, (i, a, b)
         boundary = c[min(a, b)]
-        assert abs(float(sel[i]) - boundary) <= 4 * np.spacing(f32(boundary)), (i, a, b, float(sel[i]), boundary)
+        assert abs(float(sel[i]) - boundary) <= ulps * np.spacing(f32(boundary)), (i, a, b, float(sel[i]), boundary)
     return int(bad.size)
 
 
@@ -91,7 +92,9 @@ def test_resample_stage_vs_reference_vectors(sg, kat, N, math_mode):
             np.testing.assert_allclose(neff, neff_ref, rtol=2e-6)   # (double sums on the device, float32 in the reference)
             np.testing.assert_allclose(wsum, w.astype(np.float64).sum(), rtol=2e-7)   # (float32 prefixes inside a block of 256, double across blocks)
         assert np.all(np.diff(keep) >= 0) and keep.min() >= 0 and keep.max() < N
-        nbad = explain(w, sel, keep, keep_ref)
+        # (the reference's float32 prefix of i terms, restarted from zero for every i (core.cpp:813-824), carries ~sqrt(i) roundings:
+        # at N = 5 000 a stratum four ulps from the float64 boundary falls on the other side)
+        nbad = explain(w, sel, keep, keep_ref, ulps=4 if N <= 1000 else 16)
         worst = max(worst, nbad)
         print("resample KAT N=%d %s %s: %d of %d ancestors differ from the reference's" % (N, ("strict", "fast")[math_mode], path, nbad, N))
         s.close()

@@ -29,7 +29,8 @@ MID = 2 if METHOD == "FASTSLAM2" else 1
 START = 1000
 LEVELS = ["0 kernel entry (first block = 0)", "1 Ctrl words arrived", "2 block totals scanned (W, Neff, decision)",
           "3 ancestor found", "4 pose + genealogy arrived", "5 records staged in LDS", "6 proposal pass done",
-          "7 second pass done, record stores landed", "8 pose / genealogy stores landed", "9 weight prefix + totals written"]
+          "7 second pass done, record stores landed", "8 pose / genealogy stores landed", "9 weight prefix + totals written",
+          "10 queued predicts applied (between 4 and 5)"]
 
 tape = host.make_tape(["-m", os.path.join(ROOT, "data", "example_webmap.mat"), "-method", METHOD, "-NPARTICLES", N,
                        "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", 7], max_obs=START + SAMPLES + 2)
@@ -92,7 +93,7 @@ def table(title, stamp_sets):
     rel = []
     for st in stamp_sets:
         t0 = st[:, 0].min()
-        rel.append((st[:, :10] - t0) / 100.0)   # 100 MHz -> us
+        rel.append((st[:, :11] - t0) / 100.0)   # 100 MHz -> us
     rel = np.concatenate(rel)
     print("%-48s %8s %8s %8s   %s" % ("level", "median", "p90", "max", "median step from previous level"))
     prev = None
