@@ -329,6 +329,13 @@ int slamgpu_dist_comm_id(void *id, int32_t bytes);
 int slamgpu_dist_comm_init(slamgpu_ctx *ctx, const void *id, int32_t n_ranks, int32_t rank);
 /* the all-gather of the last step's totals once more (collective, idempotent): lets a harness time the collective alone */
 int slamgpu_dist_gather(slamgpu_ctx *ctx);
+/* what the communicator inside the library says about itself (ncclCommCount / ncclCommUserRank): a harness that claims an
+ * N-GPU run checks n_ranks == N here instead of trusting its launcher's environment */
+int slamgpu_dist_comm_info(slamgpu_ctx *ctx, int32_t *n_ranks, int32_t *rank);
+/* particles of this shard, since the context was created, whose ancestor at a resample lived on ANOTHER shard: their pose and
+ * genealogy were read in place out of that GPU's memory (over xGMI between physical GPUs).  Does not run outstanding stages;
+ * synchronises the stream. */
+int slamgpu_dist_remote_reads(slamgpu_ctx *ctx, uint64_t *particles);
 
 
 /* All shards in ONE process (the reference's single backend process driving k GPUs; or k logical shards on one GPU, which

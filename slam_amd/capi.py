@@ -25,7 +25,7 @@ DECLARED_SYMBOLS = [
     "slamgpu_dist_history_fetch", "slamgpu_dist_gather", "slamgpu_dist_set_collective", "slamgpu_dist_handshake_test",
     "slamgpu_dist_collective_status", "slamgpu_dist_comm_id", "slamgpu_dist_comm_init", "slamgpu_dist_group_create", "slamgpu_dist_group_destroy",
     "slamgpu_dist_group_step", "slamgpu_dist_group_settle", "slamgpu_dist_group_history", "slamgpu_dist_group_download",
-    "slamgpu_peek", "slamgpu_step_observe", "slamgpu_observe_fetch", "slamgpu_associate_ex",
+    "slamgpu_peek", "slamgpu_step_observe", "slamgpu_observe_fetch", "slamgpu_associate_ex", "slamgpu_dist_comm_info", "slamgpu_dist_remote_reads",
 ]
 ASSOC_AUTO, ASSOC_EXHAUSTIVE, ASSOC_GRID = 0, 1, 2
 FLAG_DEVICE_OBSERVE = 1
@@ -581,6 +581,18 @@ class SlamGpu:
 
     def dist_gather(self):
         _chk(self.L.slamgpu_dist_gather(self.h))
+
+    def dist_comm_info(self):
+        """(ranks, this rank) of the RCCL communicator inside the library, as RCCL itself reports them"""
+        n, r = C.c_int32(), C.c_int32()
+        _chk(self.L.slamgpu_dist_comm_info(self.h, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def dist_remote_reads(self):
+        """particles so far whose ancestor at a resample lived on another shard (read in place over xGMI)"""
+        v = C.c_uint64()
+        _chk(self.L.slamgpu_dist_remote_reads(self.h, C.byref(v)))
+        return v.value
 
     def dist_settle(self):
         _chk(self.L.slamgpu_dist_settle(self.h))

@@ -71,6 +71,8 @@ struct Ctrl {
     double wsq;           // sum of squared raw weights (global)
     double wmax;          // log-weight contexts: the largest log-weight M; wsum / wsq are sums of exp(l - M) and its square
     double est[4];        // sum x, sum y, heading of max-w particle, max w
+    unsigned long long remote_reads;  // distributed contexts: particles, so far, whose ancestor lived on ANOTHER shard (its pose and
+                                      // genealogy were read out of that GPU's memory over xGMI): one atomic per wave and resample
 };
 
 // Distributed operation (one context per GPU, particles sharded in contiguous blocks): the state arrays of every shard as

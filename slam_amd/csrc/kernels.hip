@@ -39,39 +39,8 @@ SLAM_DEV void nt_store(float *p, float v) { __builtin_nontemporal_store(v, p); }
 // FastSLAM1::predictState (fastslam1.cpp:37-54).  P is the full 3x3 (the reference's Pv is not kept
 // symmetric by its own float arithmetic; only the stored form is packed).
 // ---------------------------------------------------------------------------------------------------
-// Per-particle control noise of the queued predicts (multivariateGauss((V, G), Q): fastslam1.cpp:44, fastslam2.cpp:91), device
-// draws: Philox + Box-Muller per (particle, control step) depend on NOTHING the launch has to wait for, and they are most of a
-// FastSLAM1 step's arithmetic (two 32-bit multiply pairs per Philox round at quarter rate: ~0.3 us per draw for a wave that has
-// its SIMD to itself).  In small contexts (at most one block per CU: the launch is a latency chain, BASELINE config 2)
-// update_kernel draws them while the head of its dependent-load chain is in flight -- half behind the block totals, half
-// behind the pose -- into LDS ([2 nsteps][256] floats: column = thread, so no barrier and no bank conflict) instead of inside the
-// predict loop after the pose has arrived.  Same function, same counter, same values: results are bit for bit those of
-// drawing in the loop.  (Registers were tried first: a 16-wide vector indexed by the loop counter is demoted to scratch.)
-constexpr int kHoistNoiseMaxBlocks = 256;  // (larger contexts have other waves to issue while one waits, and need their LDS)
-static bool hoist_predict_noise(const PredictArgs &A, int rng_mode, int nblocks) {
-    static const bool off = getenv("SLAMGPU_NO_HOIST") != nullptr;  // (experiment switch, round 4)
-    return !off && A.nsteps > 0 && A.add_noise != 0 && rng_mode != 0 && nblocks <= kHoistNoiseMaxBlocks;
-}
-// (everything it needs rides in the kernel's LEADING scalar arguments -- Philox key, first particle, counter of the first
-// queued predict (the counters of one launch are consecutive: slamgpu_predict) -- so the draws wait for nothing but the first
-// scalar load of the kernel; taken from the argument structs they would queue behind the cold trip of the Ctrl words, which
-// shares the scalar-load counter)
-SLAM_DEV void draw_predict_noise(uint32_t first, uint32_t step0, uint32_t k0, uint32_t k1, bool fast_bm, int i, int lo, int hi, float *pnl) {
-    for (int s = lo; s < hi; s++) {
-        float g0, g1, g2;
-        U4 r = philox4x32(first + (uint32_t) i, step0 + (uint32_t) s, 2u, 0u, k0, k1);
-#ifdef SLAM_FAST_MATH
-        if (fast_bm) box_muller3_fast(r, g0, g1, g2);  // (what predict_steps_fs1_fast draws)
-        else
-#endif
-            box_muller3(r, g0, g1, g2);
-        pnl[(2 * s) * kBlock + threadIdx.x] = g0;
-        pnl[(2 * s + 1) * kBlock + threadIdx.x] = g1;
-    }
-}
-
 SLAM_DEV void predict_steps(float &x, float &y, float &th, float P[9], const PredictArgs &A, const RngArgs &rng, int i,
-                            size_t S, const float *pre = nullptr) {
+                            size_t S) {
     const bool fs2 = A.method == 2;
     const float dt = A.dt, wb = A.wheel_base;
     const float Q00 = A.Q[0], Q01 = A.Q[1], Q10 = A.Q[2], Q11 = A.Q[3];
@@ -119,9 +88,6 @@ SLAM_DEV void predict_steps(float &x, float &y, float &th, float P[9], const Pre
             if (rng.mode == 0) {
                 g0 = rng.normals[((size_t) s * 2 + 0) * S + i];
                 g1 = rng.normals[((size_t) s * 2 + 1) * S + i];
-            } else if (pre) {
-                g0 = pre[(2 * s) * kBlock + threadIdx.x];
-                g1 = pre[(2 * s + 1) * kBlock + threadIdx.x];
             } else {
                 U4 r = philox4x32((uint32_t) (rng.first_particle + i), A.steps[s].step, 2u, 0u, rng.k0, rng.k1);
                 box_muller3(r, g0, g1, g2);
@@ -189,7 +155,7 @@ SLAM_DEV void predict_steps(float &x, float &y, float &th, float P[9], const Pre
 // ctl (optional): LDS copy of A.steps (8 dwords per step: V, G first), so that the loop does not fetch a cold line of the
 // kernel-argument segment per iteration (scalar cache misses at every launch: ~0.3 us each on the step's critical chain)
 SLAM_DEV void predict_steps_fs1_fast(float &x, float &y, float &th, const PredictArgs &A, const RngArgs &rng, int i, size_t S,
-                                     const float *pre = nullptr, const float *ctl = nullptr) {
+                                     const float *ctl = nullptr) {
     const float dt = A.dt, iwb = 1.0f / A.wheel_base;
     const L2 L = llt2(A.Q[0], A.Q[2], A.Q[3]);  // multivariateGauss((V,G), Q, 1) (core.cpp:452)
     for (int s = 0; s < A.nsteps; s++) {
@@ -197,11 +163,11 @@ SLAM_DEV void predict_steps_fs1_fast(float &x, float &y, float &th, const Predic
         if (rng.mode == 0) {
             g0 = rng.normals[((size_t) s * 2 + 0) * S + i];
             g1 = rng.normals[((size_t) s * 2 + 1) * S + i];
-        } else if (pre) {
-            g0 = pre[(2 * s) * kBlock + threadIdx.x];
-            g1 = pre[(2 * s + 1) * kBlock + threadIdx.x];
         } else {
-            U4 r = philox4x32((uint32_t) (rng.first_particle + i), A.steps[s].step, 2u, 0u, rng.k0, rng.k1);
+            // (drawing these at the head of the launch, behind the loads in flight, was built and measured in round 4: 14.55
+            // against 14.22 us per step at BASELINE config 2 -- the compiler sinks the head's loads below the inserted loop, so
+            // nothing overlaps and the LDS hop is extra; profiles/config2_levels_r04.txt)
+            U4 r = philox4x32((uint32_t) (rng.first_particle + i), ctl ? __float_as_uint(ctl[8 * s + 3]) : A.steps[s].step, 2u, 0u, rng.k0, rng.k1);
             box_muller3_fast(r, g0, g1, g2);
         }
         const float V = ffma(L.l00, g0, ctl ? ctl[8 * s] : A.steps[s].V);
@@ -984,13 +950,11 @@ __host__ __device__ inline int staging_slots(int method, bool big, int m) {
 // stood between kernel entry and the first vector load before; 16.7 -> 16.05 us per step at 10^5 particles).
 // Tried on top and measured as no better (gpurun_out/ab, 16.28 / 16.10 / 16.04 us): preloading these arguments into SGPRs
 // (-mllvm -amdgpu-kernarg-preload-count=16) and touching every 64-byte line of the argument segment at entry.
-//   h_flags: bit 0 plan_inline, bit 1 scan_global, bit 2 logw, bit 3 lazy, bit 4 front end inside the launch (h_front),
-//            bit 5 the predicts' control noise is drawn at the head of the launch (draw_predict_noise), bit 6 with box_muller3_fast
+//   h_flags: bit 0 plan_inline, bit 1 scan_global, bit 2 logw, bit 3 lazy, bit 4 front end inside the launch (h_front)
 template <int METHOD, int MODE, bool BIG>
 __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict__ h_tot, Ctrl *h_ctrl,
-                                                         const FrontState *h_front, int h_nb, int h_slot, int h_grid, int h_flags,
-                                                         uint32_t h_k0, uint32_t h_k1, uint32_t h_first, uint32_t h_step0, int h_nsteps, int h_pad,
-                                                         Buffers B, PredictArgs PA, UpdateArgs U, RngArgs rng, WeightScratch ws) {
+                                                         const FrontState *h_front, int h_nb, int h_slot, int h_grid, int h_flags, Buffers B, PredictArgs PA,
+                                                         UpdateArgs U, RngArgs rng, WeightScratch ws) {
     constexpr bool ARR = MODE == 1, DIST = MODE == 2;
     __shared__ float sh_w[kBlock / kWave], sh_w2[kBlock / kWave];
     // landmarks re-observed this step, staged between the proposal pass and the likelihood/feature-update pass
@@ -1089,8 +1053,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     FrontLm f_lm{-1, 0};
     FrontHdr f_hd{0, -1, 0, 0};
     float f_x = 0.f, f_y = 0.f;
-    // dword offsets in the kernel-argument segment (64: the head: 3 pointers + 10 ints)
-    constexpr size_t ka0 = (64 + sizeof(Buffers) + alignof(PredictArgs) - 1) / alignof(PredictArgs) * alignof(PredictArgs);
+    // dword offsets in the kernel-argument segment (40: the head)
+    constexpr size_t ka0 = (40 + sizeof(Buffers) + alignof(PredictArgs) - 1) / alignof(PredictArgs) * alignof(PredictArgs);
     constexpr size_t ka1 = (ka0 + sizeof(PredictArgs) + alignof(UpdateArgs) - 1) / alignof(UpdateArgs) * alignof(UpdateArgs);
     constexpr size_t ka_small = (ka1 + offsetof(UpdateArgs, small)) / 4;
     if constexpr (!BIG && MODE == 0) {
@@ -1160,19 +1124,6 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     if (bt < nb) {
         const int x = bt & 7, j = bt >> 3, q = nb >> 3, r = nb & 7;
         bt = x < r ? x * (q + 1) + j : r * (q + 1) + (x - r) * q + j;
-    }
-    // control noise of the queued predicts (draw_predict_noise): the first half is drawn here, behind the head's loads (block totals,
-    // packet, Ctrl words: all requested above) and in front of the first wait for them
-    // (LDS behind the staged records: [2 nsteps][256] floats, launch_update sizes it with the same rule)
-    float *const pnl = shB + (size_t) nslots * kBlock;
-    const bool hoist_noise = MODE == 0 && (h_flags & 32) != 0 && (int) blockIdx.x < nb;  // (single contexts)
-    const int n_early = hoist_noise ? (h_nsteps + 1) / 2 : 0;
-    const bool fast_bm = (h_flags & 64) != 0;
-    (void) h_pad;
-    if (hoist_noise) {
-        __builtin_amdgcn_sched_barrier(0);
-        draw_predict_noise(h_first, h_step0, h_k0, h_k1, fast_bm, bt * kBlock + (int) threadIdx.x, 0, n_early, pnl);
-        __builtin_amdgcn_sched_barrier(0);
     }
     SLAM_STAMP(1);  // Ctrl words arrived
     // Where does particle i of the set this update works on come from?
@@ -1318,6 +1269,9 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
             si -= h * B.ncap;
             src_local = h == B.shard;
             rp = B.peers + h;
+            // (bookkeeping for the bench line: how much of a resample crosses xGMI)
+            const unsigned long long rm = __ballot(!src_local);
+            if (rm && lane == (int) __ffsll((long long) __ballot(true)) - 1) atomicAdd(&ctrl->remote_reads, (unsigned long long) __popcll(rm));
         }
         const float4 *__restrict__ poseA = (DIST && !src_local) ? rp->poseA[sb] : (sb ? B.poseA[1] : B.poseA[0]);
         const float4 *__restrict__ poseB = (DIST && !src_local) ? rp->poseB[sb] : (sb ? B.poseB[1] : B.poseB[0]);
@@ -1526,11 +1480,6 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
 #endif
             asm volatile("" : "+v"(hg0), "+v"(hg1), "+v"(hg2));  // (pinned above the wait for the pose)
         }
-        if (hoist_noise) {  // ... and the second half of the predicts' control noise (draw_predict_noise)
-            __builtin_amdgcn_sched_barrier(0);
-            draw_predict_noise(h_first, h_step0, h_k0, h_k1, fast_bm, i, n_early, h_nsteps, pnl);
-            __builtin_amdgcn_sched_barrier(0);
-        }
         SLAM_STAMP(4);  // pose + genealogy of the ancestor arrived
         float x = pa.x, y = pa.y, th = pa.z;
         if (!BIG && copy_inline) {
@@ -1561,12 +1510,12 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                 predict_composite(x, y, th, P, PA.comp);
                 q00 = P.p00; q10 = P.p10; q11 = P.p11; q20 = P.p20; q21 = P.p21; q22 = P.p22;
             } else if (METHOD == 1 && PA.add_noise && !PA.use_heading) {
-                predict_steps_fs1_fast(x, y, th, PA, rng, i, S, hoist_noise ? pnl : nullptr, BIG ? nullptr : sh_ctl);
+                predict_steps_fs1_fast(x, y, th, PA, rng, i, S, BIG ? nullptr : sh_ctl);
             } else
 #endif
             {
                 float P[9] = {q00, q10, q20, q10, q11, q21, q20, q21, q22};
-                predict_steps(x, y, th, P, PA, rng, i, S, hoist_noise ? pnl : nullptr);
+                predict_steps(x, y, th, P, PA, rng, i, S);
                 q00 = P[0]; q10 = P[3]; q11 = P[4]; q20 = P[6]; q21 = P[7]; q22 = P[8];
             }
             pose_dirty = true;
@@ -3221,17 +3170,13 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
     const size_t nbg = (size_t) ws.nblocks * (U.arrivals == 2 ? (size_t) B.n_shards : 1);  // distributed: blocks of all shards
     const size_t lds = (size_t) staging_slots(U.method, U.big != nullptr, U.m) * kBlock * (sizeof(float4) + sizeof(float)) +
                        ((U.plan_inline && !U.scan_global) ? sizeof(double) * ((nbg + 3) & ~(size_t) 1) : 0) +
-                       (U.plan_inline ? update_window_bytes() : 0) +
-                       ((U.arrivals == 0 && hoist_predict_noise(PA, rng.mode, ws.nblocks)) ? sizeof(float) * 2 * (size_t) PA.nsteps * kBlock : 0);
+                       (U.plan_inline ? update_window_bytes() : 0);
     const int sel = (U.method == 2 ? 6 : 0) + 2 * U.arrivals + (U.big ? 1 : 0);
     const float *h_tot = U.arrivals == 2 ? B.gtot[ws.wpar ^ 1] : ws.blk_w[ws.wpar ^ 1];
-    const int h_flags = (U.plan_inline ? 1 : 0) | (U.scan_global ? 2 : 0) | (U.logw ? 4 : 0) | (U.lazy ? 8 : 0) | (U.front.on ? 16 : 0) |
-                        ((U.arrivals == 0 && hoist_predict_noise(PA, rng.mode, ws.nblocks)) ? 32 : 0) |
-                        ((PA.method == 1 && !PA.use_heading) ? 64 : 0);  // (bit 6: the fast build's FastSLAM1 predict draws with box_muller3_fast)
-    const uint32_t h_first = (uint32_t) rng.first_particle, h_step0 = PA.nsteps > 0 ? PA.steps[0].step : 0u;
+    const int h_flags = (U.plan_inline ? 1 : 0) | (U.scan_global ? 2 : 0) | (U.logw ? 4 : 0) | (U.lazy ? 8 : 0) | (U.front.on ? 16 : 0);
 #define SLAM_LAUNCH_UPDATE(M, A, G)                                                                                              \
     hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid, \
-                       h_flags, rng.k0, rng.k1, h_first, h_step0, PA.nsteps, 0, B, PA, U, rng, ws)
+                       h_flags, B, PA, U, rng, ws)
     switch (sel) {
         case 11: SLAM_LAUNCH_UPDATE(2, 2, true); break;
         case 10: SLAM_LAUNCH_UPDATE(2, 2, false); break;

@@ -48,6 +48,8 @@ struct Rccl {
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
     bool ok = false;
 };
 const Rccl *rccl() {
@@ -68,6 +70,8 @@ const Rccl *rccl() {
     SLAM_SYM(GroupStart);
     SLAM_SYM(GroupEnd);
     SLAM_SYM(GetErrorString);
+    SLAM_SYM(CommCount);
+    SLAM_SYM(CommUserRank);
 #undef SLAM_SYM
     R.ok = R.GetUniqueId && R.CommInitRank && R.CommInitAll && R.CommDestroy && R.AllGather && R.GroupStart && R.GroupEnd && R.GetErrorString;
     return R.ok ? &R : nullptr;
@@ -1818,6 +1822,31 @@ int slamgpu_dist_comm_init(slamgpu_ctx *c, const void *id, int32_t n_ranks, int3
     ncclComm_t comm = nullptr;
     RCCL_TRY(rccl()->CommInitRank(&comm, n_ranks, u, rank));
     c->comm = comm;
+    return 0;
+}
+
+int slamgpu_dist_comm_info(slamgpu_ctx *c, int32_t *n_ranks, int32_t *rank) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!c->comm) return fail(SLAMGPU_ERR_INVALID, "no communicator inside the library (slamgpu_dist_comm_init)");
+    if (!rccl() || !rccl()->CommCount || !rccl()->CommUserRank) return fail(SLAMGPU_ERR_HIP, "this librccl has no ncclCommCount / ncclCommUserRank");
+    int n = 0, r = 0;
+    RCCL_TRY(rccl()->CommCount(static_cast<ncclComm_t>(c->comm), &n));
+    RCCL_TRY(rccl()->CommUserRank(static_cast<ncclComm_t>(c->comm), &r));
+    if (n_ranks) *n_ranks = n;
+    if (rank) *rank = r;
+    return 0;
+}
+
+int slamgpu_dist_remote_reads(slamgpu_ctx *c, uint64_t *particles) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!particles) return fail(SLAMGPU_ERR_INVALID, "null output");
+    if (!c->dist) return fail(SLAMGPU_ERR_INVALID, "not a distributed context");
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    // (only this word, and without running any outstanding stage: a distributed context's stages need the other shards)
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, &c->B.ctrl->remote_reads, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *particles = v;
     return 0;
 }
 

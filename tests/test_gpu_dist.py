@@ -44,6 +44,14 @@ def run_dist(sg, tp, Np, G, method, math_mode, seed, check_at=(), push=False):
     d = cat(f.download())
     if push:
         assert f.collective_ok()
+    # ancestors read out of another shard's memory (slamgpu_dist_remote_reads): none with one shard; with several, stratified
+    # ancestors sit next to their offspring, so only the particles around the shard boundaries cross
+    remote = sum(c.dist_remote_reads() for c in f.ctx)
+    resampled = int(np.count_nonzero(hist[2])) * Np
+    if G == 1:
+        assert remote == 0
+    elif resampled:
+        assert 0 < remote <= 0.25 * resampled, (G, remote, resampled)
     f.close()
     return d, hist, mid
 

@@ -450,13 +450,17 @@ def test_config5_map_whole_run_ancestor_forced_log_weights(sg_mod, oracle, synma
     full_at = lambda k: k % 64 == 0 or k >= 2171 or (crossed and k - crossed[0] in (0, 1, 2, 8, 40))
     # Free-running WEIGHTS are not comparable on this map: a weight is a product of ~1.2 k likelihoods with sigma_r = 0.1 m, so two
     # pre-states 1e-3 m apart (what a free run accumulates: measured 5.6e-4 / 2.0e-3 m) already move it by tens of percent
-    # (measured worst-step median 6.5e-2 / 0.41) and Neff with it.  The weights are therefore checked where they are well
-    # defined: every 32nd step teacher-forced from the GPU's OWN free-running state (anchor_at), per-step bounds W_TOL.
+    # (measured worst-step median 6.5e-2 / 0.41) and Neff with it.  The weights are therefore checked every 32nd step
+    # teacher-forced from the GPU's OWN free-running state (anchor_at) -- and even from identical pre-states two float32
+    # evaluations of a 1 000-factor weight differ by percents (the sampled pose to 1e-4 m decides), so the yardstick is a float64
+    # evaluation of the same update (tests/fs2_float64.py): measured over 25 such steps (gpurun_out/r4_free10k.log), median
+    # |w / w64 - 1| of the float32 ORACLE 1.2e-2 .. 0.17, of the strict build the same to 2 digits (ratio 0.9 .. 1.14), of the
+    # fast build 0.5 .. 2.9 times the oracle's.  Bounds: 1.5x / 4x the oracle's own error.
     anchor_at = lambda k: k % 32 == 1 and k > 1
     st, inputs, QRdt, hist, final, final_exp = forced_run(sg_mod, oracle, "FASTSLAM2", N, seed, 100000, math_mode, True, threads=threads, args=args,
                                                           log_weights=True, full_at=full_at, on_step=on_step, weights_comparable=False,
                                                           anchor_at=anchor_at, pose_atol=(1.5e-3, 4e-3)[math_mode], lmk_atol=(2e-3, 7.5e-3)[math_mode],
-                                                          yardstick64=3.0)
+                                                          yardstick64=(1.5, 4.0)[math_mode])
     print("anchored steps vs float64 (m, median GPU, median oracle, p99 GPU, p99 oracle):", st.pop("y64", None))
     print("free-running FASTSLAM2 philox 10k-landmark map N=256 log-weights %s: %s; rows in use: max %d, final %d, target first reached at step %s"
           % (["strict", "fast"][math_mode], st, max(rows), rows[-1], crossed[:1]))

@@ -260,7 +260,9 @@ def test_stepwise_vs_oracle(sg, oracle, method, N, seed, nobs, math_mode):
         if r["did"][0]:
             bad = np.abs(r["got"]["xv"] - r["exp"]["xv"]).max(axis=1) > POSE_ATOL
             # FastSLAM1's weights agree to ~1e-4: identical ancestors at N=100, a boundary stratum or two at N=1000
-            assert bad.mean() <= (W_TOL[math_mode]["ancestors"] if fs2 else (0.0 if N <= 100 else 0.005)), (tag, bad.mean())
+            # (the fast build's FastSLAM1 update runs the restructured arithmetic since round 4 -- hardware exp / rcp, polynomial
+            # atan2: weights to ~1e-5 instead of ~1e-6 -- and one stratum in a few thousand lands on the other side)
+            assert bad.mean() <= (W_TOL[math_mode]["ancestors"] if fs2 else ((0.0 if math_mode == 0 else 0.01) if N <= 100 else 0.005)), (tag, bad.mean())
             anc_bad += int(bad.sum())
             anc_tot += bad.size
         else:
