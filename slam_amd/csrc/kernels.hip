@@ -158,7 +158,7 @@ SLAM_DEV void predict_steps_fs1_fast(float &x, float &y, float &th, const Predic
                                      const float *ctl = nullptr) {
     const float dt = A.dt, iwb = 1.0f / A.wheel_base;
     const L2 L = llt2(A.Q[0], A.Q[2], A.Q[3]);  // multivariateGauss((V,G), Q, 1) (core.cpp:452)
-    auto one = [&](int s, float cV, float cG, uint32_t cstep) {
+    for (int s = 0; s < A.nsteps; s++) {
         float g0, g1, g2;
         if (rng.mode == 0) {
             g0 = rng.normals[((size_t) s * 2 + 0) * S + i];
@@ -167,36 +167,17 @@ SLAM_DEV void predict_steps_fs1_fast(float &x, float &y, float &th, const Predic
             // (drawing these at the head of the launch, behind the loads in flight, was built and measured in round 4: 14.55
             // against 14.22 us per step at BASELINE config 2 -- the compiler sinks the head's loads below the inserted loop, so
             // nothing overlaps and the LDS hop is extra; profiles/config2_levels_r04.txt)
-            U4 r = philox4x32((uint32_t) (rng.first_particle + i), cstep, 2u, 0u, rng.k0, rng.k1);
+            U4 r = philox4x32((uint32_t) (rng.first_particle + i), ctl ? __float_as_uint(ctl[8 * s + 3]) : A.steps[s].step, 2u, 0u, rng.k0, rng.k1);
             box_muller3_fast(r, g0, g1, g2);
         }
-        const float V = ffma(L.l00, g0, cV);
-        const float G = ffma(L.l11, g1, ffma(L.l10, g0, cG));
+        const float V = ffma(L.l00, g0, ctl ? ctl[8 * s] : A.steps[s].V);
+        const float G = ffma(L.l11, g1, ffma(L.l10, g0, ctl ? ctl[8 * s + 1] : A.steps[s].G));
         float sn, cs, sgw, cgw;
         sincos_cw(G + th, sn, cs);
         sincos_cw(G * iwb, sgw, cgw);  // sin(G / wheelBase): upstream quirk (fastslam1.cpp:52)
         x = ffma(V * dt, cs, x);
         y = ffma(V * dt, sn, y);
         th = wrap_pi(ffma(V * dt, sgw, th));
-    };
-    // the first eight steps (the bundled maps queue eight predicts per observation) unrolled: their controls are read from LDS
-    // in one batch -- one wait instead of one per step -- and the draws of different steps, which depend on nothing, interleave
-    constexpr int kUnroll = 8;
-    if (ctl) {
-        float cV[kUnroll], cG[kUnroll];
-        uint32_t cs_[kUnroll];
-#pragma unroll
-        for (int s = 0; s < kUnroll; s++) {
-            cV[s] = ctl[8 * s];
-            cG[s] = ctl[8 * s + 1];
-            cs_[s] = __float_as_uint(ctl[8 * s + 3]);
-        }
-#pragma unroll
-        for (int s = 0; s < kUnroll; s++)
-            if (s < A.nsteps) one(s, cV[s], cG[s], cs_[s]);
-        for (int s = kUnroll; s < A.nsteps; s++) one(s, ctl[8 * s], ctl[8 * s + 1], __float_as_uint(ctl[8 * s + 3]));
-    } else {
-        for (int s = 0; s < A.nsteps; s++) one(s, A.steps[s].V, A.steps[s].G, A.steps[s].step);
     }
 }
 #endif
@@ -362,14 +343,9 @@ struct NoOp {
 // the totals on the in-order return path instead of in front of them.
 // The loads of the scan (contexts of at most 512 blocks: at most two totals per thread), separated from the arithmetic so
 // that a caller can request them before anything else (update_kernel: at kernel entry, from preloaded arguments).
-// A thread's whole segment of the table rides in registers (named through fully unrolled loops: static indices), requested in
-// ONE burst: up to kScanMax totals per thread = 4 096 blocks = 1 048 576 particles in the table.  (Round 4: a thread used to
-// fetch its segment four totals at a time, each batch a dependent trip: with the gathered table of 8 shards of 100 096
-// particles -- 13 totals per thread -- that was four cold trips at the head of EVERY launch of EVERY GPU:
-// profiles/dist_width_r04.txt.)
-constexpr int kScanMax = 16;
+constexpr int kScanBatch = 4;  // totals of a thread's segment requested together by the scan of a wide table (scan_finish)
 struct ScanLoads {
-    float tv[kScanMax], qv[kScanMax], mv[kScanMax];
+    float tv0, tv1, qv0, qv1, mv0, mv1;
 };
 SLAM_DEV int scan_at(int k, int nb, int nbl, bool logw) {
     // (one shard: nbl == nb and the index is k itself; the general form costs two integer divisions per entry)
@@ -379,50 +355,38 @@ SLAM_DEV ScanLoads scan_issue(const float *__restrict__ tot, int nb, int nbl, bo
     const int t = threadIdx.x;
     const int per = (nb + kBlock - 1) / kBlock;
     const int lo = min(nb, t * per), hi = min(nb, lo + per);
-    ScanLoads L;
-#pragma unroll
-    for (int u = 0; u < kScanMax; u++) {
-        L.tv[u] = 0.0f;
-        L.qv[u] = 0.0f;
-        L.mv[u] = -INFINITY;
-    }
-    if (per <= kScanMax) {
-        // gathered tables of several shards: [shard][w(nbl) | q(nbl) (| m(nbl))]: walk the index instead of dividing per entry
-        const int rows = logw ? 3 : 2;
-        int sh = (lo < hi && nbl != nb) ? lo / nbl : 0, r = lo < hi ? lo - sh * nbl : 0;
-#pragma unroll
-        for (int u = 0; u < kScanMax; u++) {
-            if (lo + u < hi) {
-                const int at = sh * rows * nbl + r;
-                L.tv[u] = tot[at];
-                L.qv[u] = tot[at + nbl];
-                if (logw) L.mv[u] = tot[at + 2 * nbl];
-                if (++r == nbl) {
-                    r = 0;
-                    sh++;
-                }
-            }
+    // (named scalars, not arrays: a register array indexed by k - lo would be demoted to scratch)
+    ScanLoads L{0.0f, 0.0f, 0.0f, 0.0f, -INFINITY, -INFINITY};
+    if (per <= 2) {
+        if (lo < hi) {
+            const int at = scan_at(lo, nb, nbl, logw);
+            L.tv0 = tot[at];
+            L.qv0 = tot[at + nbl];
+            if (logw) L.mv0 = tot[at + 2 * nbl];
+        }
+        if (lo + 1 < hi) {
+            const int at = scan_at(lo + 1, nb, nbl, logw);
+            L.tv1 = tot[at];
+            L.qv1 = tot[at + nbl];
+            if (logw) L.mv1 = tot[at + 2 * nbl];
         }
     }
     return L;
 }
 
-SLAM_DEV void scan_finish(const ScanLoads &L, const float *__restrict__ tot, int nb, int nbl, bool logw, double *off, double *sh_a,
+SLAM_DEV void scan_finish(const ScanLoads L, const float *__restrict__ tot, int nb, int nbl, bool logw, double *off, double *sh_a,
                           double *sh_q, double &W, double &Q, double &M) {
     const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
     const int per = (nb + kBlock - 1) / kBlock;
     const int lo = min(nb, t * per), hi = min(nb, lo + per);
-    const bool staged = per <= kScanMax;
+    const bool two = per <= 2;
     auto at_of = [&](int k) { return scan_at(k, nb, nbl, logw); };
     M = 0.0;
     if (logw) {
         float mx = -INFINITY;
-        if (staged) {
-#pragma unroll
-            for (int u = 0; u < kScanMax; u++) mx = fmaxf(mx, L.mv[u]);
-        } else {
+        if (two) mx = fmaxf(L.mv0, L.mv1);
+        else
             for (int k = lo; k < hi; k++) mx = fmaxf(mx, tot[at_of(k) + 2 * nbl]);
-        }
 #pragma unroll
         for (int d = kWave / 2; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d, kWave));
         if (lane == 0) sh_a[wv] = (double) mx;
@@ -438,19 +402,25 @@ SLAM_DEV void scan_finish(const ScanLoads &L, const float *__restrict__ tot, int
         a += tk;
         q += (double) qk_f * (tk * tk);  // second row: sum (w_i / T)^2 of the block (update_kernel's tail)
     };
-    if (staged) {
-#pragma unroll
-        for (int u = 0; u < kScanMax; u++)
-            if (lo + u < hi) acc(lo + u, L.tv[u], L.qv[u], L.mv[u]);  // (k ascending: the association every kernel shares)
+    if (two) {
+        if (lo < hi) acc(lo, L.tv0, L.qv0, L.mv0);
+        if (lo + 1 < hi) acc(lo + 1, L.tv1, L.qv1, L.mv1);
     } else {
-        // (tables beyond 4 096 blocks: four totals at a time)
+        // (gathered tables of several shards: [shard][w(nbl) | q(nbl) (| m(nbl))]: walk the index instead of dividing per
+        // entry, and request kScanBatch totals of the thread's segment before using any of them.  Round 4 priced this loop for
+        // the table of 8 shards x 100 096 particles (13 totals per thread = four dependent trips at the head of every launch:
+        // tools/dist_width.py, profiles/dist_width_r04.txt: ~+4 us per launch against one shard) and tried larger batches and a
+        // burst of the whole segment into registers: the distributed kernels sit at the scalar-register limit and one or two of
+        // their variants then spill (tests/test_host_frontend.py::test_no_kernel_spills_to_scratch), chaotically in the batch
+        // size (6, 7, 8, 16 all do, in different variants).  Left at four; the remedy that needs no registers is LDS-DMA
+        // (global_load_lds) of the table into `off`: DESIGN.md section 10)
         const int rows = logw ? 3 : 2;
         int sh = lo < hi ? lo / nbl : 0, r = lo < hi ? lo - sh * nbl : 0;
-        for (int k0 = lo; k0 < hi; k0 += 4) {
-            float tk[4], qk[4], mk[4];
+        for (int k0 = lo; k0 < hi; k0 += kScanBatch) {
+            float tk[kScanBatch], qk[kScanBatch], mk[kScanBatch];
             int shq = sh, rq = r;
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < kScanBatch; u++) {
                 const bool on = k0 + u < hi;
                 const int at = on ? shq * rows * nbl + rq : 0;
                 tk[u] = on ? tot[at] : 0.0f;
@@ -462,7 +432,7 @@ SLAM_DEV void scan_finish(const ScanLoads &L, const float *__restrict__ tot, int
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+            for (int u = 0; u < kScanBatch; u++)
                 if (k0 + u < hi) acc(k0 + u, tk[u], qk[u], mk[u]);
             sh = shq;
             r = rq;
@@ -573,11 +543,8 @@ SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const f
 // never seen on the bundled maps; possible with degenerate weights) take the per-lane path.  ALL lanes of the wave must call
 // (`valid` = the lane has an output particle); distributed contexts stage peer blocks straight out of the owning GPU's memory.
 constexpr int kWinBlocks = 4;
-// prefilled: the wave's window already holds the prefixes of blocks 0 .. nb - 1 (tiny contexts: nb <= kWinBlocks: staged at the
-// head of the launch, with the first loads, instead of one dependent trip behind the scan: update_kernel).
 SLAM_DEV int64_t find_ancestor_win(double target, bool valid, int guess, const double *off, int nb, float *win, const float *__restrict__ lcum_local,
-                                   int nb_local, int64_t n_global, const float *__restrict__ blk_m, double M, const PeerPtrs *peers, int par,
-                                   bool prefilled = false) {
+                                   int nb_local, int64_t n_global, const float *__restrict__ blk_m, double M, const PeerPtrs *peers, int par) {
     const int lane = threadIdx.x & (kWave - 1);
     // The source block: the first b with off[b + 1] > target (nb: none).  Stratified ancestors sit near their offspring, so
     // the search starts at the block the caller names (the particle's own) and gallops outwards -- two or three dependent LDS
@@ -610,7 +577,7 @@ SLAM_DEV int64_t find_ancestor_win(double target, bool valid, int guess, const d
         b0 = s_lo;
     }
     const bool use = valid && b0 < nb;  // (beyond the last cumulative weight: undefined upstream, clamped below)
-    const int lo = prefilled ? 0 : wave_min_i(use ? b0 : 0x7fffffff), hi = prefilled ? -1 : wave_max_i(use ? b0 : -1);
+    const int lo = wave_min_i(use ? b0 : 0x7fffffff), hi = wave_max_i(use ? b0 : -1);
     auto block_ptr = [&](int b) -> const float * {
         return peers ? peers[b / nb_local].lcum[par] + (size_t) (b % nb_local) * kBlock : lcum_local + (size_t) b * kBlock;
     };
@@ -960,14 +927,9 @@ SLAM_DEV void front_book(const FrontArgs &F, const FrontObs ob, const FrontLm s,
 // instead of one dependent slot -> record round trip per landmark.
 // (measured at config 5, gpurun_out/var: 4 and 8 landmarks per chunk run the same 1.61 ms per step, 12 and 16 are slower;
 // 4 keeps the kernel at 103 / 110 VGPRs (fast / strict build: 4 waves per SIMD) and 20 KB of LDS per block, 8 needs 134 / 143)
-#ifndef SLAM_BIG_CHUNK   // (round-4 experiment: pipeline geometry A/B, tools/gpu_r04_c5.sh)
-#define SLAM_BIG_CHUNK 4
-#endif
-#ifndef SLAM_PIPE_DEPTH
-#define SLAM_PIPE_DEPTH 1
-#endif
-constexpr int kBigChunk = SLAM_BIG_CHUNK;
-constexpr int kPipeDepth = SLAM_PIPE_DEPTH;
+// (round 4, same question again with the scalar packet reads in place, tools/gpu_r04_c5.sh: chunks of 2 / 4 / 8 landmarks with
+// 1 / 2 / 3 chunks of records in flight: 1.155 .. 1.193 ms per step, all within 3 % of each other: not what bounds the launch)
+constexpr int kBigChunk = 4;
 constexpr int kStage = 8;  // landmarks per particle kept in LDS between the two passes of a small packet
 
 // LDS of the per-wave ancestor windows of a launch that plans inline (host and device agree on the dynamic LDS layout)
@@ -993,8 +955,8 @@ __host__ __device__ inline int staging_slots(int method, bool big, int m) {
 //   h_flags: bit 0 plan_inline, bit 1 scan_global, bit 2 logw, bit 3 lazy, bit 4 front end inside the launch (h_front)
 template <int METHOD, int MODE, bool BIG>
 __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict__ h_tot, Ctrl *h_ctrl,
-                                                         const FrontState *h_front, const float *__restrict__ h_lcum, int h_nb, int h_slot, int h_grid,
-                                                         int h_flags, Buffers B, PredictArgs PA, UpdateArgs U, RngArgs rng, WeightScratch ws) {
+                                                         const FrontState *h_front, int h_nb, int h_slot, int h_grid, int h_flags, Buffers B, PredictArgs PA,
+                                                         UpdateArgs U, RngArgs rng, WeightScratch ws) {
     constexpr bool ARR = MODE == 1, DIST = MODE == 2;
     __shared__ float sh_w[kBlock / kWave], sh_w2[kBlock / kWave];
     // landmarks re-observed this step, staged between the proposal pass and the likelihood/feature-update pass
@@ -1093,8 +1055,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     FrontLm f_lm{-1, 0};
     FrontHdr f_hd{0, -1, 0, 0};
     float f_x = 0.f, f_y = 0.f;
-    // dword offsets in the kernel-argument segment (48: the head: four pointers, four ints)
-    constexpr size_t ka0 = (48 + sizeof(Buffers) + alignof(PredictArgs) - 1) / alignof(PredictArgs) * alignof(PredictArgs);
+    // dword offsets in the kernel-argument segment (40: the head)
+    constexpr size_t ka0 = (40 + sizeof(Buffers) + alignof(PredictArgs) - 1) / alignof(PredictArgs) * alignof(PredictArgs);
     constexpr size_t ka1 = (ka0 + sizeof(PredictArgs) + alignof(UpdateArgs) - 1) / alignof(UpdateArgs) * alignof(UpdateArgs);
     constexpr size_t ka_small = (ka1 + offsetof(UpdateArgs, small)) / 4;
     if constexpr (!BIG && MODE == 0) {
@@ -1110,18 +1072,9 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     }
     const bool logw = (h_flags & 4) != 0;
     const bool do_scan = h_plan && !h_scan_global;
-    ScanLoads scl = scan_issue(h_tot, do_scan ? nbg : 0, h_nb, logw);  // (nothing requested when this launch does not scan)
-    // Tiny contexts (at most kWinBlocks blocks: BASELINE config 2): the ancestor search's window is the WHOLE prefix array of the
-    // previous step (h_lcum = ws.lcum[wpar ^ 1], 1 KB per block), so every wave requests it NOW, with the head's loads, instead
-    // of one dependent trip behind the scan (find_ancestor_win, prefilled): ~1.1 us off every launch that applies a resample.
-    const bool win_prefill = !DIST && h_plan && nbg <= kWinBlocks && (int) blockIdx.x < h_nb;
-    float4 wp0 = make_float4(0.f, 0.f, 0.f, 0.f), wp1 = wp0, wp2 = wp0, wp3 = wp0;
-    if (win_prefill) {
-        const float4 *l4 = reinterpret_cast<const float4 *>(h_lcum) + (threadIdx.x & (kWave - 1));
-        wp0 = l4[0];
-        if (nbg > 1) wp1 = l4[kBlock / 4];
-        if (nbg > 2) wp2 = l4[2 * (kBlock / 4)];
-        if (nbg > 3) wp3 = l4[3 * (kBlock / 4)];
+    ScanLoads scl{0.0f, 0.0f, 0.0f, 0.0f, -INFINITY, -INFINITY};
+    if (do_scan) {
+        scl = scan_issue(h_tot, nbg, h_nb, logw);
     }
     __shared__ int32_t pk[kSmallWords];
     __shared__ uint32_t f_sets[4];
@@ -1218,8 +1171,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         const double target = valid ? (double) stratum_prev(rng, gk) * W : 0.0;
         const int64_t ng = DIST ? rng.n_global : (int64_t) B.n;
         return (int) find_ancestor_win(target, valid, (int) (gk >> 8), offp, nbg, win, ws.lcum[ws.wpar ^ 1], nb, ng,
-                                       (!DIST && logw) ? ws.blk_w[ws.wpar ^ 1] + 2 * nb : nullptr, Mx, DIST ? B.peers : nullptr, ws.wpar ^ 1,
-                                       win_prefill);
+                                       (!DIST && logw) ? ws.blk_w[ws.wpar ^ 1] + 2 * nb : nullptr, Mx, DIST ? B.peers : nullptr, ws.wpar ^ 1);
     };
     if ((int) blockIdx.x >= nb) {
         // ---- helper blocks ---------------------------------------------------------------------------------
@@ -1296,13 +1248,6 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     float w = logw ? -INFINITY : 0.0f;  // lanes beyond the particle count carry no weight
 
     EstItem ei_prev{0.0, 0.0, -3.0e38f, 0.0f, 0x7fffffff};  // inline plan: this particle's term of the previous step's estimate
-    if (win_prefill && pend) {  // tiny contexts: the whole prefix array, requested at the head, into this wave's window
-        reinterpret_cast<float4 *>(win)[lane] = wp0;
-        if (nbg > 1) reinterpret_cast<float4 *>(win + kBlock)[lane] = wp1;
-        if (nbg > 2) reinterpret_cast<float4 *>(win + 2 * kBlock)[lane] = wp2;
-        if (nbg > 3) reinterpret_cast<float4 *>(win + 3 * kBlock)[lane] = wp3;
-        __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave execute in order)
-    }
     const int si_plan = pend ? ancestor(i, active) : i;  // (every lane of the block: the windowed search is a wave's joint effort)
     if (active) {
         // where this particle's pose and genealogy are read from: slot i of the live buffers, or its ancestor's slot; or
@@ -1452,16 +1397,14 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         // (see kBigChunk).  Out-of-range tail entries re-read the last landmark (never consumed).
         auto pipeline = [&](auto body) {
             constexpr int CH = kBigChunk;
-            // kPipeDepth chunks of records in flight (their slots one chunk further ahead): register sets used in rotation,
-            // the loop unrolled by the depth so that every set is indexed statically
             int sl[CH];
-            float4 ta0[CH], ta1[CH], ta2[CH];
-            float tb0[CH], tb1[CH], tb2[CH];
+            float4 ta[CH];
+            float tb[CH];
             auto load_slots = [&](int k0) {
 #pragma unroll
                 for (int k = 0; k < CH; k++) sl[k] = slot_of(min(k0 + k, m - 1));
             };
-            auto load_recs = [&](int k0, float4 *ta, float *tb) {
+            auto load_recs = [&](int k0) {
 #pragma unroll
                 for (int k = 0; k < CH; k++) {
                     const Rec r = load_rec(idf[min(k0 + k, m - 1)], sl[k], buf_of(min(k0 + k, m - 1)));
@@ -1469,38 +1412,21 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                     tb[k] = r.b;
                 }
             };
-            // one chunk: park its records (requested kPipeDepth chunks of compute ago) in LDS, request the chunk kPipeDepth
-            // ahead into the set just freed and the slots of the one after, compute out of LDS
-            auto phase = [&](int k0, float4 *ta, float *tb) {
+            load_slots(0);
+            load_recs(0);
+            load_slots(CH);
+            for (int k0 = 0; k0 < m; k0 += CH) {
 #pragma unroll
                 for (int k = 0; k < CH; k++) {
                     shA[(k) * kBlock + threadIdx.x] = ta[k];
                     shB[(k) * kBlock + threadIdx.x] = tb[k];
                 }
-                if (k0 + kPipeDepth * CH < m) {
-                    load_recs(k0 + kPipeDepth * CH, ta, tb);
-                    load_slots(k0 + (kPipeDepth + 1) * CH);  // (clamped: harmless re-reads past the end)
+                if (k0 + CH < m) {
+                    load_recs(k0 + CH);       // slots of this chunk were requested one chunk of compute ago
+                    load_slots(k0 + 2 * CH);  // (clamped: harmless re-reads past the end)
                 }
                 const int kn = min(CH, m - k0);
                 for (int k = 0; k < kn; k++) body(k0 + k, shA[(k) * kBlock + threadIdx.x], shB[(k) * kBlock + threadIdx.x]);
-            };
-            load_slots(0);
-            load_recs(0, ta0, tb0);
-            load_slots(CH);
-            if constexpr (kPipeDepth >= 2) {
-                load_recs(CH, ta1, tb1);
-                load_slots(2 * CH);
-            }
-            if constexpr (kPipeDepth >= 3) {
-                load_recs(2 * CH, ta2, tb2);
-                load_slots(3 * CH);
-            }
-            for (int k0 = 0; k0 < m; k0 += kPipeDepth * CH) {
-                phase(k0, ta0, tb0);
-                if constexpr (kPipeDepth >= 2)
-                    if (k0 + CH < m) phase(k0 + CH, ta1, tb1);
-                if constexpr (kPipeDepth >= 3)
-                    if (k0 + 2 * CH < m) phase(k0 + 2 * CH, ta2, tb2);
             }
         };
 
@@ -3232,8 +3158,8 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
     const float *h_tot = U.arrivals == 2 ? B.gtot[ws.wpar ^ 1] : ws.blk_w[ws.wpar ^ 1];
     const int h_flags = (U.plan_inline ? 1 : 0) | (U.scan_global ? 2 : 0) | (U.logw ? 4 : 0) | (U.lazy ? 8 : 0) | (U.front.on ? 16 : 0);
 #define SLAM_LAUNCH_UPDATE(M, A, G)                                                                                              \
-    hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.lcum[ws.wpar ^ 1], \
-                       ws.nblocks, B.slot, grid, h_flags, B, PA, U, rng, ws)
+    hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid, \
+                       h_flags, B, PA, U, rng, ws)
     switch (sel) {
         case 11: SLAM_LAUNCH_UPDATE(2, 2, true); break;
         case 10: SLAM_LAUNCH_UPDATE(2, 2, false); break;
