@@ -78,7 +78,7 @@ def _mk(sg, o, N, method, rng_mode, math_mode, seed, log_weights=False):
 
 
 def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None, threads=1, mapname="example_webmap", args=None,
-               log_weights=False, full_at=None, w_tol=None, on_step=None, weights_comparable=True, anchor_at=None, pose_atol=None, lmk_atol=None, yardstick64=None):
+               log_weights=False, full_at=None, w_tol=None, on_step=None, weights_comparable=True, anchor_at=None, pose_atol=None, lmk_atol=None, yardstick64=None, anchor_pose_atol=2e-4):
     """Drive oracle + GPU as described in the module docstring.  window = (lo, hi): observation steps (1-based) whose full
     state is compared; None = every step.  full_at(k) (optional): on steps inside the window where it is false only the poses
     and the weights are read and compared (big maps: the landmark records of a step are tens of MB).  args: the simulation's
@@ -194,8 +194,8 @@ def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None
             st["anchored"] = st.get("anchored", 0) + 1
             st["anch_pose"] = max(st.get("anch_pose", 0.0), float(da.max()))
             st["anch_lmk"] = max(st.get("anch_lmk", 0.0), float(np.abs(got["xf"] - e2["xf"][src]).max()))
-            ensure(da.max() <= POSE_ATOL, (tag, "anchored pose", da.max()))
-            ensure(np.abs(got["xf"] - e2["xf"][src]).max() <= 5 * POSE_ATOL, (tag, "anchored landmarks"))
+            ensure(da.max() <= anchor_pose_atol, (tag, "anchored pose", da.max()))
+            ensure(np.abs(got["xf"] - e2["xf"][src]).max() <= 5 * anchor_pose_atol, (tag, "anchored landmarks"))
             ensure(close_cov(got["Pf"], sym(e2["Pf"][src])), (tag, "anchored Pf"))
             if not did_g and ob["zf"].shape[0] > 0:
                 lg, le = got["w"].astype(np.float64), e2["w"].astype(np.float64)
@@ -460,7 +460,9 @@ def test_config5_map_whole_run_ancestor_forced_log_weights(sg_mod, oracle, synma
     st, inputs, QRdt, hist, final, final_exp = forced_run(sg_mod, oracle, "FASTSLAM2", N, seed, 100000, math_mode, True, threads=threads, args=args,
                                                           log_weights=True, full_at=full_at, on_step=on_step, weights_comparable=False,
                                                           anchor_at=anchor_at, pose_atol=(1.5e-3, 4e-3)[math_mode], lmk_atol=(2e-3, 7.5e-3)[math_mode],
-                                                          yardstick64=(1.5, 4.0)[math_mode])
+                                                          yardstick64=(1.5, 4.0)[math_mode],
+                                                          # (one update over ~1 k landmarks from identical pre-states; measured 6.1e-5 / 3.7e-4 m)
+                                                          anchor_pose_atol=(2e-4, 8e-4)[math_mode])
     print("anchored steps vs float64 (m, median GPU, median oracle, p99 GPU, p99 oracle):", st.pop("y64", None))
     print("free-running FASTSLAM2 philox 10k-landmark map N=256 log-weights %s: %s; rows in use: max %d, final %d, target first reached at step %s"
           % (["strict", "fast"][math_mode], st, max(rows), rows[-1], crossed[:1]))
