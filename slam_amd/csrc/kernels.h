@@ -280,8 +280,6 @@ struct UpdateArgs {
                              // every other block waits for the helper's go word before it touches anything
     uint32_t fold_spins;     // bound of the helper's poll (the other blocks wait four times as long)
     int32_t finalize_par;    // parity of the estimate partials the helper block reduces
-    int32_t split_blocks;    // > 0 (big-map single contexts): the launch's compute blocks are this many blocks of ceil(n / blocks)
-                             // particles instead of the 256-slot tiles, and tail_kernel follows (kernels.hip: update_kernel, h_ncomp)
     int32_t finalize;        // 1: the extra block reduces the previous update's pose-estimate partials
     double *finalize_hist;   // history slot of that estimate (kHistStride doubles) or null
     unsigned long long *stamps;  // diagnostic build (-DSLAM_STAMPS, libslamgpu_stamps.so): [compute blocks][kStampSlots] wall-clock stamps
@@ -303,8 +301,6 @@ struct WeightScratch {
     double *scan[2];      // [nblocks + 4] large contexts: exclusive prefix of the block totals, then sum w, sum w^2, max log-weight
                           // (scan_kernel), so that the update launch need not rescan the totals in every block
     int32_t wpar;       // parity of the step this launch belongs to
-    float4 *est_term;   // [ncap] big-map single contexts (UpdateArgs::split_blocks): x, y, heading, weight of every particle of
-                        // the previous step's set, left by the update launch for tail_kernel's tile-wise estimate partials
     int32_t *keep[2];   // [ncap] ancestors of the last resample, double-buffered by Buffers::slot: a launch reads the
                         // pending gather through keep[slot] and writes new ancestors into keep[slot ^ 1]
     int32_t nblocks;

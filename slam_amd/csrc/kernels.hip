@@ -910,64 +910,6 @@ SLAM_DEV void front_book(const FrontArgs &F, const FrontObs ob, const FrontLm s,
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Tail of an update: in-block inclusive prefix of the new weights of one 256-slot tile and the tile's totals (what the next
-// launch's plan scans).  Called by update_kernel for its own tile, or -- big-map single contexts whose tile count is not a
-// multiple of the CU count: update_kernel then runs in a geometry of its own, see tail_kernel -- by tail_kernel.
-// log-weight contexts: the prefix / totals are those of exp(l - M_b), M_b = the tile's largest log-weight, which travels as a
-// third row of the totals (scan_block_totals rescales by exp(M_b - M)).
-// The sum of squares is kept SCALE-FREE, as q = sum (w_i / T)^2 with T the tile total (every partial a ratio <= 1): the
-// reference computes Neff from the normalised weights (core.cpp:784-788) and survives weights whose square overflows float32
-// (w > 1.8e19: a dozen landmarks in one update); scan_block_totals rebuilds sum w^2 = q T^2 in double.
-// Returns the tile's T and q in the block's last thread (others: unspecified).
-// ---------------------------------------------------------------------------------------------------
-SLAM_DEV void weight_tail(float w, int bt, int i, bool logw, const WeightScratch &ws, float *sh_w, float *sh_w2, float &T_out, float &q_out) {
-    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
-    if (logw) {
-        float mb = w;
-#pragma unroll
-        for (int d = kWave / 2; d > 0; d >>= 1) mb = fmaxf(mb, __shfl_xor(mb, d, kWave));
-        if (lane == 0) sh_w[wv] = mb;
-        __syncthreads();
-        mb = fmaxf(fmaxf(sh_w[0], sh_w[1]), fmaxf(sh_w[2], sh_w[3]));
-        __syncthreads();
-        if (threadIdx.x == 0) ws.blk_w[ws.wpar][2 * ws.nblocks + bt] = mb;
-        w = (w == -INFINITY) ? 0.0f : expf(w - mb);  // NaN log-weights stay NaN and are flagged by the plan (status)
-    }
-    // in-block inclusive prefix of w; block totals of w and of w^2 (fixed association: deterministic)
-    const float s = wave_scan_f(w);
-    const float tw = wave_last_f(s);  // this wave's total
-    const float rw = tw > 0.0f ? w / tw : 0.0f;
-    const float s2 = wave_sum_f(rw * rw);
-    if (lane == kWave - 1) {
-        sh_w[wv] = s;
-        sh_w2[wv] = s2;
-    }
-    __syncthreads();
-    float base = 0.0f;
-#pragma unroll
-    for (int k = 0; k < kBlock / kWave; k++)
-        if (k < wv) base += sh_w[k];
-    __builtin_nontemporal_store(base + s, &ws.lcum[ws.wpar][i]);
-    T_out = 0.0f;
-    q_out = 0.0f;
-    if (threadIdx.x == kBlock - 1) {
-        const float T = base + s;
-        float q = 0.0f;
-        if (T > 0.0f) {
-#pragma unroll
-            for (int k = 0; k < kBlock / kWave; k++) {
-                const float f = sh_w[k] / T;
-                q += sh_w2[k] * (f * f);
-            }
-        }
-        ws.blk_w[ws.wpar][bt] = T;
-        ws.blk_w[ws.wpar][ws.nblocks + bt] = q;
-        T_out = T;
-        q_out = q;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // K1: [pending predicts] + per-particle observation update.  FastSLAM2::update body
 // (fastslam2.cpp:26-45): sampleProposal (:290-368) + likelihoodGivenXv (:370-400) fused with
 // featureUpdate (core.cpp:132-175; both evaluate their Jacobians at the same sampled pose) + addFeature
@@ -1011,18 +953,10 @@ __host__ __device__ inline int staging_slots(int method, bool big, int m) {
 // Tried on top and measured as no better (gpurun_out/ab, 16.28 / 16.10 / 16.04 us): preloading these arguments into SGPRs
 // (-mllvm -amdgpu-kernarg-preload-count=16) and touching every 64-byte line of the argument segment at entry.
 //   h_flags: bit 0 plan_inline, bit 1 scan_global, bit 2 logw, bit 3 lazy, bit 4 front end inside the launch (h_front)
-//   h_nb: 256-slot tiles of the particle set (the geometry of the weight scratch: prefixes, totals, estimate partials);
-//   h_ncomp / h_ppb: compute blocks of THIS launch and particles per compute block.  Normally h_ncomp = h_nb, h_ppb = 256: a
-//   compute block is a tile and ends with the tile's weight tail.  Big-map single contexts whose tile count is not a multiple
-//   of the CU count (BASELINE config 5: 391 tiles on 256 CUs: 135 CUs hold two blocks, 121 one, and the launch lasts as long
-//   as the former: 12.0 ns per particle and step against 10.6 ns at 131 072 particles = two blocks on every CU,
-//   profiles/config5_vs_particles_r04.txt) run in a geometry of their own instead -- a multiple of 256 compute blocks of
-//   ceil(n / blocks) particles each (config 5: 512 x 196) -- leave the raw weight and the estimate term of every particle
-//   behind, and tail_kernel, a launch of ~5 us behind a launch of ~1 ms, does the tile-wise tail with the same arithmetic.
 template <int METHOD, int MODE, bool BIG>
 __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict__ h_tot, Ctrl *h_ctrl,
-                                                         const FrontState *h_front, int h_nb, int h_slot, int h_grid, int h_flags, int h_ncomp,
-                                                         int h_ppb, Buffers B, PredictArgs PA, UpdateArgs U, RngArgs rng, WeightScratch ws) {
+                                                         const FrontState *h_front, int h_nb, int h_slot, int h_grid, int h_flags, Buffers B, PredictArgs PA,
+                                                         UpdateArgs U, RngArgs rng, WeightScratch ws) {
     constexpr bool ARR = MODE == 1, DIST = MODE == 2;
     __shared__ float sh_w[kBlock / kWave], sh_w2[kBlock / kWave];
     // landmarks re-observed this step, staged between the proposal pass and the likelihood/feature-update pass
@@ -1051,9 +985,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     const size_t S = (size_t) B.ncap;
     Ctrl *ctrl = h_ctrl;
     const int nb = h_nb;
-    const int ncomp = (BIG && MODE == 0) ? h_ncomp : h_nb, ppb = (BIG && MODE == 0) ? h_ppb : kBlock;
-    const bool split_tail = BIG && MODE == 0 && ppb != kBlock;
-    const bool helper = (int) blockIdx.x == h_grid - 1 && (int) blockIdx.x >= ncomp;
+    const bool helper = (int) blockIdx.x == h_grid - 1 && (int) blockIdx.x >= nb;
     // XCD-aware tile mapping.  Workgroups go round-robin to the 8 XCDs (workgroup b -> XCD b % 8) and every XCD has an L2
     // of its own, so with tile = workgroup the 256 particles next to a tile always belong to another XCD: after a resample
     // the ancestor's pose, genealogy and records -- written one launch ago by a neighbouring tile -- missed this XCD's L2
@@ -1123,8 +1055,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     FrontLm f_lm{-1, 0};
     FrontHdr f_hd{0, -1, 0, 0};
     float f_x = 0.f, f_y = 0.f;
-    // dword offsets in the kernel-argument segment (48: the head: three pointers, six ints)
-    constexpr size_t ka0 = (48 + sizeof(Buffers) + alignof(PredictArgs) - 1) / alignof(PredictArgs) * alignof(PredictArgs);
+    // dword offsets in the kernel-argument segment (40: the head)
+    constexpr size_t ka0 = (40 + sizeof(Buffers) + alignof(PredictArgs) - 1) / alignof(PredictArgs) * alignof(PredictArgs);
     constexpr size_t ka1 = (ka0 + sizeof(PredictArgs) + alignof(UpdateArgs) - 1) / alignof(UpdateArgs) * alignof(UpdateArgs);
     constexpr size_t ka_small = (ka1 + offsetof(UpdateArgs, small)) / 4;
     if constexpr (!BIG && MODE == 0) {
@@ -1191,8 +1123,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         }
     }
     int bt = (int) blockIdx.x;
-    if (bt < ncomp) {
-        const int x = bt & 7, j = bt >> 3, q = ncomp >> 3, r = ncomp & 7;
+    if (bt < nb) {
+        const int x = bt & 7, j = bt >> 3, q = nb >> 3, r = nb & 7;
         bt = x < r ? x * (q + 1) + j : r * (q + 1) + (x - r) * q + j;
     }
     SLAM_STAMP(1);  // Ctrl words arrived
@@ -1241,7 +1173,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         return (int) find_ancestor_win(target, valid, (int) (gk >> 8), offp, nbg, win, ws.lcum[ws.wpar ^ 1], nb, ng,
                                        (!DIST && logw) ? ws.blk_w[ws.wpar ^ 1] + 2 * nb : nullptr, Mx, DIST ? B.peers : nullptr, ws.wpar ^ 1);
     };
-    if ((int) blockIdx.x >= ncomp) {
+    if ((int) blockIdx.x >= nb) {
         // ---- helper blocks ---------------------------------------------------------------------------------
         if (helper) {
             // the set this launch leaves lives in `out` (published in the other Ctrl slot; the host flips after the
@@ -1267,7 +1199,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         if constexpr (BIG) {
             if (pend) {
                 const PacketView V = packet_view(U);
-                copy_genealogy(B, V.rows, V.n_rows, V.rows_per_role, ws, cur, U.copy_lo + (int) blockIdx.x - ncomp, ancestor);
+                copy_genealogy(B, V.rows, V.n_rows, V.rows_per_role, ws, cur, U.copy_lo + (int) blockIdx.x - nb, ancestor);
             }
         }
         return;
@@ -1281,14 +1213,14 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
             return;
         }
     }
-    const int i = bt * ppb + threadIdx.x;
-    const int lane = threadIdx.x & (kWave - 1);
+    const int i = bt * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     // select (not index) the buffers: an indexed read of the pointer table in the kernel-argument segment
     // would be one more dependent scalar load at the head of every wave
     float4 *__restrict__ poseAo = out ? B.poseA[1] : B.poseA[0];
     float4 *__restrict__ poseBo = out ? B.poseB[1] : B.poseB[0];
     float2 *__restrict__ poseCo = out ? B.poseC[1] : B.poseC[0];
-    const bool active = (int) threadIdx.x < ppb && i < B.n;
+    const bool active = i < B.n;
     int m = U.m, n = U.n, nf = U.nf, e_new = U.e_new;
     int live_chunks = U.live_chunks, n_cons = U.n_cons;
     bool all_fresh = U.all_fresh != 0;
@@ -1547,7 +1479,6 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         w = pend ? ctrl->inv_n : (U.plan_inline ? (logw ? pa.w - (float) (Mx + log(W)) : pa.w / (float) W) : pa.w);
         // computeEstimatedPosition of the previous update (ParticleSLAMWrapper.cpp:56-77) sees exactly this set
         ei_prev = EstItem{(double) pa.x, (double) pa.y, w, pa.z, i};
-        if (split_tail && U.plan_inline) nt_store(&ws.est_term[i], make_float4(pa.x, pa.y, pa.z, w));  // (reduced tile-wise by tail_kernel)
         float q00 = 0.f, q10 = 0.f, q11 = 0.f, q20 = 0.f, q21 = 0.f, q22 = 0.f;
         bool pose_dirty = pend;
         if (METHOD == 2) {
@@ -1924,12 +1855,6 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     }
 
     SLAM_STAMP(8);  // pose / genealogy stores landed
-    if (split_tail) {
-        // this launch's geometry is not the weight scratch's: the raw weight stays behind for tail_kernel (in the place the
-        // prefix will take)
-        if (active) __builtin_nontemporal_store(w, &ws.lcum[ws.wpar][i]);
-        return;
-    }
     if (U.plan_inline) {
         ei_prev = block_reduce_est(ei_prev, sh_est);
         if (threadIdx.x == 0) {
@@ -1940,10 +1865,50 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
             p[3] = (double) ei_prev.w;
         }
     }
-    {
-        float T, q;
-        weight_tail(w, bt, i, logw, ws, sh_w, sh_w2, T, q);
-        if (DIST && U.push_totals && threadIdx.x == kBlock - 1) {
+    // log-weight contexts: the prefix / totals below are those of exp(l - M_b), M_b = the block's largest log-weight,
+    // which travels as a third row of the totals (scan_block_totals rescales by exp(M_b - M))
+    if (logw) {
+        float mb = w;
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) mb = fmaxf(mb, __shfl_xor(mb, d, kWave));
+        if (lane == 0) sh_w[wv] = mb;
+        __syncthreads();
+        mb = fmaxf(fmaxf(sh_w[0], sh_w[1]), fmaxf(sh_w[2], sh_w[3]));
+        __syncthreads();
+        if (threadIdx.x == 0) ws.blk_w[ws.wpar][2 * ws.nblocks + bt] = mb;
+        w = (w == -INFINITY) ? 0.0f : expf(w - mb);  // NaN log-weights stay NaN and are flagged by the plan (status)
+    }
+    // in-block inclusive prefix of w; block totals of w and of w^2 (fixed association: deterministic).  The sum of squares
+    // is kept SCALE-FREE, as q = sum (w_i / T)^2 with T the block total (every partial a ratio <= 1): the reference computes
+    // Neff from the normalised weights (core.cpp:784-788) and survives weights whose square overflows float32 (w > 1.8e19:
+    // a dozen landmarks in one update); scan_block_totals rebuilds sum w^2 = q T^2 in double.
+    const float s = wave_scan_f(w);
+    const float tw = wave_last_f(s);  // this wave's total
+    const float rw = tw > 0.0f ? w / tw : 0.0f;
+    const float s2 = wave_sum_f(rw * rw);
+    if (lane == kWave - 1) {
+        sh_w[wv] = s;
+        sh_w2[wv] = s2;
+    }
+    __syncthreads();
+    float base = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kBlock / kWave; k++)
+        if (k < wv) base += sh_w[k];
+    __builtin_nontemporal_store(base + s, &ws.lcum[ws.wpar][i]);
+    if (threadIdx.x == kBlock - 1) {
+        const float T = base + s;
+        float q = 0.0f;
+        if (T > 0.0f) {
+#pragma unroll
+            for (int k = 0; k < kBlock / kWave; k++) {
+                const float f = sh_w[k] / T;
+                q += sh_w2[k] * (f * f);
+            }
+        }
+        ws.blk_w[ws.wpar][bt] = T;
+        ws.blk_w[ws.wpar][ws.nblocks + bt] = q;
+        if (DIST && U.push_totals) {
             // push collective: this block's totals straight into every shard's table, shard-major [shard][w(nb) | q(nb)]
             // (visible to the peers' next launch: the flag handshake that follows this launch orders them)
             const size_t at = (size_t) B.shard * 2 * ws.nblocks + bt;
@@ -1955,36 +1920,6 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         }
     }
     SLAM_STAMP(9);  // weight prefix + totals written: end of the block
-}
-
-// The tile-wise tail of an update whose launch ran in a geometry of its own (update_kernel: h_ncomp / h_ppb): per 256-slot
-// tile, the estimate partial of the previous step from the terms the update left (block_reduce_est, as update_kernel does
-// for its own tile) and the prefix / totals of the new weights (weight_tail).  Same functions on the same values in the same
-// order: bit for bit what the update launch would have written in the tile geometry.
-__global__ void __launch_bounds__(kBlock) tail_kernel(Buffers B, WeightScratch ws, int plan_inline, int logw) {
-    __shared__ float sh_w[kBlock / kWave], sh_w2[kBlock / kWave];
-    __shared__ EstItem sh_est[kBlock / kWave];
-    const int bt = blockIdx.x, i = bt * kBlock + threadIdx.x;
-    const bool active = i < B.n;
-    if (plan_inline) {
-        EstItem ei{0.0, 0.0, -3.0e38f, 0.0f, 0x7fffffff};
-        if (active) {
-            const float4 e = ws.est_term[i];
-            ei = EstItem{(double) e.x, (double) e.y, e.w, e.z, i};
-        }
-        ei = block_reduce_est(ei, sh_est);
-        if (threadIdx.x == 0) {
-            double *p = ws.est_part[ws.wpar ^ 1] + (size_t) bt * 4;
-            p[0] = ei.sx;
-            p[1] = ei.sy;
-            p[2] = (double) ei.th;
-            p[3] = (double) ei.w;
-        }
-    }
-    float w = logw ? -INFINITY : 0.0f;  // slots beyond the particle count carry no weight
-    if (active) w = ws.lcum[ws.wpar][i];
-    float T, q;
-    weight_tail(w, bt, i, logw != 0, ws, sh_w, sh_w2, T, q);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -3212,10 +3147,7 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
                           const RngArgs &rng, const WeightScratch &ws) {
     // compute blocks first (they are the long pole), then -- single-context pipeline only -- the copy blocks of a
     // pending lazy gather (they exit at once when nothing is pending: the host cannot know) and one helper block
-    // compute blocks: the tiles, or the launch's own geometry (UpdateArgs::split_blocks, big-map single contexts)
-    const int ncomp = U.split_blocks > 0 ? U.split_blocks : B.ncap / kBlock;
-    const int ppb = U.split_blocks > 0 ? (B.n + U.split_blocks - 1) / U.split_blocks : kBlock;
-    int grid = ncomp;
+    int grid = B.ncap / kBlock;
     if (U.lazy) grid += (U.copy_hi - U.copy_lo) + 1;
     // inline plan only: prefix of the previous step's block totals (launches that do not plan never touch off[])
     const size_t nbg = (size_t) ws.nblocks * (U.arrivals == 2 ? (size_t) B.n_shards : 1);  // distributed: blocks of all shards
@@ -3227,7 +3159,7 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
     const int h_flags = (U.plan_inline ? 1 : 0) | (U.scan_global ? 2 : 0) | (U.logw ? 4 : 0) | (U.lazy ? 8 : 0) | (U.front.on ? 16 : 0);
 #define SLAM_LAUNCH_UPDATE(M, A, G)                                                                                              \
     hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid, \
-                       h_flags, ncomp, ppb, B, PA, U, rng, ws)
+                       h_flags, B, PA, U, rng, ws)
     switch (sel) {
         case 11: SLAM_LAUNCH_UPDATE(2, 2, true); break;
         case 10: SLAM_LAUNCH_UPDATE(2, 2, false); break;
@@ -3243,8 +3175,6 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
         default: SLAM_LAUNCH_UPDATE(1, 0, false); break;
     }
 #undef SLAM_LAUNCH_UPDATE
-    // the tile-wise tail of a launch that ran in a geometry of its own (kernels.hip: tail_kernel)
-    if (U.split_blocks > 0) hipLaunchKernelGGL(tail_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B, ws, U.plan_inline, U.logw);
 }
 
 static void launch_resample(hipStream_t st, const Buffers &B, const WeightScratch &ws, const RngArgs &rng,

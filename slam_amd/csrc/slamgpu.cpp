@@ -782,10 +782,6 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     for (int b = 0; b < 2; b++) {
         CTX_TRY(hipMalloc((void **) &c->ws.keep[b], sizeof(int32_t) * S));
         CTX_TRY(hipMemsetAsync(c->ws.keep[b], 0, sizeof(int32_t) * S, c->stream));
-        if (b == 0 && !c->B.compact) {  // (big maps: the update launch may run in a geometry of its own, issue_update)
-            CTX_TRY(hipMalloc((void **) &c->ws.est_term, sizeof(float4) * S));
-            CTX_TRY(hipMemsetAsync(c->ws.est_term, 0, sizeof(float4) * S, c->stream));
-        }
     }
     CTX_TRY(hipMalloc((void **) &c->hist_dev, sizeof(double) * kHistStride * (size_t) kHistCap));
     if (want_stamps) {
@@ -843,7 +839,6 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     }
     for (int b = 0; b < 2; b++)
         if (c->ws.keep[b]) (void) hipFree(c->ws.keep[b]);
-    if (c->ws.est_term) (void) hipFree(c->ws.est_term);
     if (c->hist_dev) (void) hipFree(c->hist_dev);
     if (c->stamps_dev) (void) hipFree(c->stamps_dev);
     if (c->peek_dev) (void) hipFree(c->peek_dev);
@@ -1007,19 +1002,6 @@ int issue_update(slamgpu_ctx *c, UpdateArgs &U, int n_new, int n_rows, bool need
     U.n_effective = c->cfg.n_effective;
     U.logw = c->cfg.log_weights;
     U.stamps = c->stamps_dev;
-    // Big-map single contexts whose tiles do not divide evenly over the CUs: the launch runs in a geometry of its own -- the
-    // next multiple of 256 blocks, ceil(n / blocks) particles each -- and a small launch does the tile-wise tail behind it
-    // (kernels.hip: update_kernel h_ncomp / h_ppb, tail_kernel).  256 = the CUs of an MI355X; up to 256 tiles every CU holds at
-    // most one block anyway.
-    U.split_blocks = 0;
-    {
-        const bool off = getenv("SLAMGPU_NO_SPLIT_TAIL") != nullptr;  // (diagnostic / A-B; read per launch: tests toggle it)
-        const int tiles = c->ws.nblocks;
-        if (!off && U.big && !sharded && !c->dist && c->ws.est_term && tiles > 256 && tiles % 256 != 0) {
-            const int blocks = (tiles + 255) / 256 * 256;
-            if ((c->B.n + blocks - 1) / blocks >= 64) U.split_blocks = blocks;  // (never less than a wave of particles per block)
-        }
-    }
     U.finalize = c->unreduced.has ? 1 : 0;  // (sharded: this shard's partials of the previous step, shard_finalize_kernel)
     U.finalize_hist = c->unreduced.hist;
     U.finalize_par = c->unreduced.par;

@@ -790,50 +790,3 @@ def test_plain_row_consolidation_changes_no_bit(sg, tmp_path, monkeypatch):
     for key in ("xv", "Pv", "w", "xf", "Pf"):
         assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), key
         assert np.array_equal(ma[key].view(np.uint32), mb[key].view(np.uint32)), (key, "mid-run")
-
-
-@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
-@pytest.mark.parametrize("log_weights", [False, True], ids=["linear", "logw"])
-def test_split_tail_geometry_changes_no_bit(sg, tmp_path, monkeypatch, math_mode, log_weights):
-    """Big-map single contexts whose 256-slot tiles do not divide evenly over the 256 CUs run their update launch in a
-    geometry of its own (here 70 000 particles: 274 tiles -> 512 blocks of 137 particles) and leave the tile-wise tail --
-    weight prefix, tile totals, estimate partials -- to tail_kernel (kernels.hip).  Same per-particle arithmetic, same
-    tile-wise reductions: histories, final state and a mid-run view must equal the tile geometry's (SLAMGPU_NO_SPLIT_TAIL=1)
-    bit for bit, resampling steps, observer calls (stage launches) and a lazy gather included."""
-    import os
-    from conftest import DATA
-    from slam_amd import host
-    lm = host.synthetic_landmarks(777, 300, -130, 100, -100, 90)
-    _, wp = host.HostSim(sim_args("example_webmap", "FASTSLAM2", 100, 7)).map()
-    mp = str(tmp_path / "syn300.mat")
-    host.write_map(mp, lm, wp)
-    open(str(tmp_path / "syn300.ini"), "w").write(open(os.path.join(DATA, "example_webmap.ini")).read().replace(
-        "MAX_RANGE           = 60.0", "MAX_RANGE           = 25.0"))
-    N = 70000
-    tape = host.make_tape(["-m", mp, "-method", "FASTSLAM2", "-NPARTICLES", N, "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", 3], max_obs=40)
-    out = []
-    for tiles in (False, True):
-        if tiles:
-            monkeypatch.setenv("SLAMGPU_NO_SPLIT_TAIL", "1")
-        else:
-            monkeypatch.delenv("SLAMGPU_NO_SPLIT_TAIL", raising=False)
-        s = sg.SlamGpu(N, tape["nlm"], method=2, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=5, math_mode=math_mode,
-                       log_weights=log_weights)
-        mid = None
-        for k, st in enumerate(tape["steps"]):
-            s.step(np.array(st["controls"], f32).reshape(-1, 3), tape["Q"], float(tape["dt"]), st["zf"], st["idf"], st["zn"], tape["R"])
-            if k == 17:
-                s.stats()                                   # (the stage as launches of its own, then a lazy gather in the next launch)
-            if k == 25:
-                mid = s.peek(first=11, stride=997)
-        h = s.history_fetch()
-        out.append((s.download(first=0, count=4096), s.download(first=N - 4096, count=4096), h, mid))
-        s.close()
-    monkeypatch.delenv("SLAMGPU_NO_SPLIT_TAIL", raising=False)
-    (a0, a1, ha, ma), (b0, b1, hb, mb) = out
-    assert 3 < ha[2].sum() < 40 and np.isfinite(ha[1]).all()
-    for x, y in zip(ha, hb):
-        assert np.array_equal(x, y, equal_nan=True)
-    for key in ("xv", "Pv", "w", "xf", "Pf"):
-        for p, q in ((a0, b0), (a1, b1), (ma, mb)):
-            assert np.array_equal(p[key].view(np.uint32), q[key].view(np.uint32)), key
