@@ -117,8 +117,18 @@ __global__ void __launch_bounds__(256) dma_kernel(const float4 *__restrict__ A, 
         const int slot = c % R;
 #pragma unroll
         for (int k = 0; k < CH; k++) {
-            const float4 a = shA[(slot * CH + k) * 256 + threadIdx.x];
-            const float b = shB[(slot * CH + k) * 256 + threadIdx.x];
+            // read through inline asm: a ds_read the compiler can see makes it wait vmcnt(0) first (LDS read after an LDS-DMA
+            // write that may alias), which drains the chunks in flight and undoes the overlap
+            float4 a;
+            float b;
+            {
+                const unsigned oa = (unsigned) (size_t) (const __attribute__((address_space(3))) void *) (shA + (slot * CH + k) * 256 + threadIdx.x);
+                const unsigned ob = (unsigned) (size_t) (const __attribute__((address_space(3))) void *) (shB + (slot * CH + k) * 256 + threadIdx.x);
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                v4f av;
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(av), "=&v"(b) : "v"(oa), "v"(ob) : "memory");
+                a = make_float4(av.x, av.y, av.z, av.w);
+            }
             const bool on = c * CH + k < m;
             const float nacc = chew(a, b, work, acc);
             acc = on ? nacc : acc;
