@@ -45,3 +45,12 @@ void wrapper_calls(FastSLAM2Gpu *algorithm, vector<Particle> &particles, VectorX
 }
 ''')
     subprocess.check_call(flags + [str(tu)])
+
+
+def test_integration_md_shows_the_compiled_bindings():
+    """The code blocks of INTEGRATION.md are the compiled files, not a paraphrase of them."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    shim = open(os.path.join(HERE, "cabi", "accel_shim.h")).read()
+    adapter = open(os.path.join(HERE, "cabi", "fastslam2gpu_adapter.h")).read()
+    assert shim[shim.index("class AcceleratorHandler {"):shim.index("#endif")].rstrip() in doc
+    assert adapter[adapter.index("template <class Particle, class VectorXf, class MatrixXf>"):adapter.index("#endif")].rstrip() in doc

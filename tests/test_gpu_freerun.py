@@ -78,7 +78,7 @@ def _mk(sg, o, N, method, rng_mode, math_mode, seed, log_weights=False):
 
 
 def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None, threads=1, mapname="example_webmap", args=None,
-               log_weights=False, full_at=None, w_tol=None, on_step=None, weights_comparable=True, anchor_at=None, pose_atol=None, lmk_atol=None, yardstick64=None, anchor_pose_atol=2e-4):
+               log_weights=False, full_at=None, w_tol=None, on_step=None, weights_comparable=True, anchor_at=None, pose_atol=None, lmk_atol=None, yardstick64=None, anchor_pose_atol=2e-4, est_atol=1e-3):
     """Drive oracle + GPU as described in the module docstring.  window = (lo, hi): observation steps (1-based) whose full
     state is compared; None = every step.  full_at(k) (optional): on steps inside the window where it is false only the poses
     and the weights are read and compared (big maps: the landmark records of a step are tens of MB).  args: the simulation's
@@ -267,7 +267,7 @@ def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None
                 ensure(rel.max() <= FREE_W_FS1[math_mode], (tag, rel.max()))
         eg, eo = got["xv"][:, :2].astype(np.float64).mean(axis=0), o.estimate()[:2]
         st["max_est"] = max(st.get("max_est", 0.0), float(np.abs(eg - eo).max()))
-        ensure(np.abs(eg - eo).max() <= 1e-3, (tag, eg, eo))
+        ensure(np.abs(eg - eo).max() <= est_atol, (tag, eg, eo))
     hist_parts.append(s.history_fetch())
     hist = tuple(np.concatenate([h[j] for h in hist_parts]) for j in range(3))
     st["rows_in_use"] = s.live_rows()
@@ -462,7 +462,8 @@ def test_config5_map_whole_run_ancestor_forced_log_weights(sg_mod, oracle, synma
                                                           anchor_at=anchor_at, pose_atol=(1.5e-3, 4e-3)[math_mode], lmk_atol=(2e-3, 7.5e-3)[math_mode],
                                                           yardstick64=(1.5, 4.0)[math_mode],
                                                           # (one update over ~1 k landmarks from identical pre-states; measured 6.1e-5 / 3.7e-4 m)
-                                                          anchor_pose_atol=(2e-4, 8e-4)[math_mode])
+                                                          anchor_pose_atol=(2e-4, 8e-4)[math_mode],
+                                                          est_atol=(1e-3, 3e-3)[math_mode])   # (measured 1.9e-4 / 1.5e-3 m)
     print("anchored steps vs float64 (m, median GPU, median oracle, p99 GPU, p99 oracle):", st.pop("y64", None))
     print("free-running FASTSLAM2 philox 10k-landmark map N=256 log-weights %s: %s; rows in use: max %d, final %d, target first reached at step %s"
           % (["strict", "fast"][math_mode], st, max(rows), rows[-1], crossed[:1]))
