@@ -127,3 +127,57 @@ def test_config5_full_size_properties(sg, synmap):
     if res[-1]:
         assert np.all(d["w"] == d["w"][0]) and abs(float(d["w"][0]) - np.log(1.0 / N)) < 1e-4
     s.close()
+
+
+def test_config5_full_size_whole_run_consolidation_invisible_and_sane(sg, synmap, monkeypatch):
+    """BASELINE configs[4] at FULL size over the WHOLE run (2 172 observation steps, the fast build, log-weights, Philox) -- the
+    window bench.py times (steps ~1 003..1 026) lies inside it.  The oracle cannot follow 10^5 particles x 10^4 landmarks, so at
+    this size the run is held to what does not need it: (1) plain-row consolidation is invisible: the run with the rows held at 512
+    (consolidation engaged for most of the run) and the run that never consolidates (this map levels off at ~1 020 rows, below the
+    default target) give bit-identical histories (Neff, resample decision, estimate of every step) and bit-identical states for
+    three tiles of particles at the end; (2) the filter is healthy all the way: no degenerate step, Neff in range, the estimate
+    within 1 m of the true pose on average and at the end, the landmark count the reference's known association gives."""
+    from slam_amd import host
+    N = 100000
+    tape = host.make_tape(args_for(synmap, N, 60))
+    Q, R, dt = tape["Q"], tape["R"], float(tape["dt"])
+    steps = tape["steps"]
+    assert len(steps) == 2172 and tape["nlm"] == 10000
+
+    def run(target):
+        if target:
+            monkeypatch.setenv("SLAMGPU_PLAIN_ROWS_TARGET", str(target))
+        else:
+            monkeypatch.delenv("SLAMGPU_PLAIN_ROWS_TARGET", raising=False)
+        s = sg.SlamGpu(N, tape["nlm"], method=2, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=7, math_mode=1, log_weights=True)
+        rows_max = 0
+        for k, st in enumerate(steps):
+            s.step(np.array(st["controls"], f32).reshape(-1, 3), Q, dt, st["zf"], st["idf"], st["zn"], R)
+            if k % 256 == 255:
+                rows_max = max(rows_max, s.live_rows())
+        est, neff, res = s.history_fetch()
+        status = s.last_history_status.copy()
+        tiles = [s.download(first=f, count=256) for f in (0, 49920, N - 256)]
+        s.close()
+        return est, neff, res, status, tiles, rows_max
+
+    a = run(512)
+    b = run(0)
+    assert a[5] <= 512 + 64 < b[5], (a[5], b[5])   # consolidation held the rows at the target in one run and never ran in the other
+    for x, y in zip(a[:4], b[:4]):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    for ta, tb in zip(a[4], b[4]):
+        assert ta["nf"] == tb["nf"]
+        for key in ("xv", "Pv", "w", "xf", "Pf"):
+            assert np.array_equal(ta[key].view(np.uint32), tb[key].view(np.uint32)), key
+    est, neff, res, status = a[:4]
+    assert not status.any()
+    assert np.isfinite(est).all() and np.all(neff > 0) and np.all(neff <= N * 1.001)
+    assert 0.3 < res.mean() <= 1.0, res.mean()
+    err = np.array([np.hypot(e[0] - st["true"][0], e[1] - st["true"][1]) for e, st in zip(est, steps)])
+    print("config 5 at full size, whole run: mean / max / final position error %.3f / %.3f / %.3f m, resample rate %.2f, rows in use <= %d (consolidating) / %d (not)"
+          % (err.mean(), err.max(), err[-1], res.mean(), a[5], b[5]))
+    assert err.mean() < 1.0 and err[-1] < 1.0, (err.mean(), err[-1])
+    assert a[4][0]["nf"] > 9000
+    for t in a[4]:
+        assert np.isfinite(t["xf"]).all() and np.isfinite(t["Pf"]).all() and np.isfinite(t["w"]).all()
