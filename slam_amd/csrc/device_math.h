@@ -391,6 +391,40 @@ SLAM_DEV U4 philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint3
     return U4{c0, c1, c2, c3};
 }
 
+// W counters that differ in c1 only (the predict steps of one particle), their rounds interleaved: W x 2 independent multiply
+// chains in one basic block.  A Philox round is two v_mad_u64_u32 (~10 cycles of issue each) feeding each other across
+// the halves: one generator alone runs at ~8 cycles per instruction, four together at ~6.5 (tools/microbench/valu_latency.hip).
+// Same integers as philox4x32() W times.
+template <int W>
+SLAM_DEV void philox4x32_n(U4 (&out)[W], uint32_t c0, const uint32_t (&c1)[W], uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    uint32_t a0[W], a1[W], a2[W], a3[W];
+#pragma unroll
+    for (int q = 0; q < W; q++) {
+        a0[q] = c0;
+        a1[q] = c1[q];
+        a2[q] = c2;
+        a3[q] = c3;
+    }
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+#pragma unroll
+        for (int q = 0; q < W; q++) {
+            const uint64_t p0 = (uint64_t) 0xD2511F53u * a0[q];
+            const uint64_t p1 = (uint64_t) 0xCD9E8D57u * a2[q];
+            const uint32_t n0 = (uint32_t) (p1 >> 32) ^ a1[q] ^ k0;
+            const uint32_t n2 = (uint32_t) (p0 >> 32) ^ a3[q] ^ k1;
+            a1[q] = (uint32_t) p1;
+            a3[q] = (uint32_t) p0;
+            a0[q] = n0;
+            a2[q] = n2;
+        }
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int q = 0; q < W; q++) out[q] = U4{a0[q], a1[q], a2[q], a3[q]};
+}
+
 SLAM_DEV float u01(uint32_t x) { return ((float) (x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
 // Same pairing as nRandMat::randn(3,1) (core.cpp:401-416): (u0,u1) -> g0 (sin), g1 (cos); (u2,u3) -> g2 (sin)

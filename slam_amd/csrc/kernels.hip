@@ -154,30 +154,90 @@ SLAM_DEV void predict_steps(float &x, float &y, float &th, float P[9], const Pre
 // (1.5 ulp, tools/check_fast_math.py).  BASELINE config 2 (1 000 particles): 19.8 -> see DESIGN.md section 5.
 // ctl (optional): LDS copy of A.steps (8 dwords per step: V, G first), so that the loop does not fetch a cold line of the
 // kernel-argument segment per iteration (scalar cache misses at every launch: ~0.3 us each on the step's critical chain)
+// steps s0 .. s0 + nb - 1 (nb <= W) of predict_steps_fs1_fast, their draws made TOGETHER (see there)
+template <int W>
+SLAM_DEV void predict_batch_fs1_fast(float &x, float &y, float &th, const PredictArgs &A, const RngArgs &rng, int i, size_t S, const float *ctl,
+                                     float dt, float iwb, const L2 &L, int s0, int nb) {
+    float g0[W], g1[W];
+    if (rng.mode == 0) {
+#pragma unroll
+        for (int q = 0; q < W; q++) {
+            const int s = s0 + min(q, nb - 1);
+            g0[q] = rng.normals[((size_t) s * 2 + 0) * S + i];
+            g1[q] = rng.normals[((size_t) s * 2 + 1) * S + i];
+        }
+    } else {
+        uint32_t c1[W];
+        U4 r[W];
+#pragma unroll
+        for (int q = 0; q < W; q++) {
+            const int s = s0 + min(q, nb - 1);  // (past the last step: a draw nobody uses)
+            c1[q] = ctl ? __float_as_uint(ctl[8 * s + 3]) : A.steps[s].step;
+        }
+        philox4x32_n<W>(r, (uint32_t) (rng.first_particle + i), c1, 2u, 0u, rng.k0, rng.k1);
+#pragma unroll
+        for (int q = 0; q < W; q++) {
+            float g2;
+            box_muller3_fast(r[q], g0[q], g1[q], g2);
+        }
+    }
+    // a step's heading needs only the headings before it (a chain of one FMA and one wrap per step); its sine and cosine need
+    // only that heading: in a full batch the headings are run first and the W sincos pairs are independent
+    float vd[W], gs[W], th_at[W];
+    auto heading = [&](int q) {
+        const int s = s0 + q;
+        const float V = ffma(L.l00, g0[q], ctl ? ctl[8 * s] : A.steps[s].V);
+        const float G = ffma(L.l11, g1[q], ffma(L.l10, g0[q], ctl ? ctl[8 * s + 1] : A.steps[s].G));
+        float sgw, cgw;
+        sincos_cw(G * iwb, sgw, cgw);  // sin(G / wheelBase): upstream quirk (fastslam1.cpp:52)
+        vd[q] = V * dt;
+        gs[q] = G;
+        th_at[q] = th;
+        th = wrap_pi(ffma(vd[q], sgw, th));
+    };
+    auto position = [&](int q) {
+        float sn, cs;
+        sincos_cw(gs[q] + th_at[q], sn, cs);
+        x = ffma(vd[q], cs, x);
+        y = ffma(vd[q], sn, y);
+    };
+    if (nb == W) {
+#pragma unroll
+        for (int q = 0; q < W; q++) heading(q);
+#pragma unroll
+        for (int q = 0; q < W; q++) position(q);
+    } else {
+#pragma unroll
+        for (int q = 0; q < W; q++)
+            if (q < nb) {
+                heading(q);
+                position(q);
+            }
+    }
+}
+
 SLAM_DEV void predict_steps_fs1_fast(float &x, float &y, float &th, const PredictArgs &A, const RngArgs &rng, int i, size_t S,
                                      const float *ctl = nullptr) {
     const float dt = A.dt, iwb = 1.0f / A.wheel_base;
     const L2 L = llt2(A.Q[0], A.Q[2], A.Q[3]);  // multivariateGauss((V,G), Q, 1) (core.cpp:452)
-    for (int s = 0; s < A.nsteps; s++) {
-        float g0, g1, g2;
-        if (rng.mode == 0) {
-            g0 = rng.normals[((size_t) s * 2 + 0) * S + i];
-            g1 = rng.normals[((size_t) s * 2 + 1) * S + i];
+    // The draws of up to eight steps are made TOGETHER (they depend on counters only), then the steps are applied one after the
+    // other (each needs the heading the one before left): for a wave that has its SIMD to itself -- BASELINE config 2: 16 waves on
+    // 16 SIMDs -- a dependent instruction issues every ~9.6 cycles, four independent chains at ~2.9 each
+    // (tools/microbench/valu_latency.hip), and one Philox4x32-10 + Box-Muller is ~130 instructions of mostly ONE chain.  Same
+    // counters, same integers, same float operations per draw and step: bit-identical to drawing inside the step.
+    // Measured at config 2 (eight steps per update), one box: draws inside the step 13.02-13.10 us per step, batches of four
+    // 12.34, of eight 12.13-12.24.
+    // (Drawing at the HEAD of the launch, behind the loads in flight, was built and measured in round 4 and was slower, 14.55
+    // against 14.22 us per step: the compiler sinks the head's loads below the inserted loop and the values take an LDS hop.)
+    for (int s0 = 0; s0 < A.nsteps;) {
+        const int rem = A.nsteps - s0;
+        if (rem > 4) {
+            predict_batch_fs1_fast<8>(x, y, th, A, rng, i, S, ctl, dt, iwb, L, s0, min(rem, 8));
+            s0 += 8;
         } else {
-            // (drawing these at the head of the launch, behind the loads in flight, was built and measured in round 4: 14.55
-            // against 14.22 us per step at BASELINE config 2 -- the compiler sinks the head's loads below the inserted loop, so
-            // nothing overlaps and the LDS hop is extra; profiles/config2_levels_r04.txt)
-            U4 r = philox4x32((uint32_t) (rng.first_particle + i), ctl ? __float_as_uint(ctl[8 * s + 3]) : A.steps[s].step, 2u, 0u, rng.k0, rng.k1);
-            box_muller3_fast(r, g0, g1, g2);
+            predict_batch_fs1_fast<4>(x, y, th, A, rng, i, S, ctl, dt, iwb, L, s0, rem);
+            s0 += 4;
         }
-        const float V = ffma(L.l00, g0, ctl ? ctl[8 * s] : A.steps[s].V);
-        const float G = ffma(L.l11, g1, ffma(L.l10, g0, ctl ? ctl[8 * s + 1] : A.steps[s].G));
-        float sn, cs, sgw, cgw;
-        sincos_cw(G + th, sn, cs);
-        sincos_cw(G * iwb, sgw, cgw);  // sin(G / wheelBase): upstream quirk (fastslam1.cpp:52)
-        x = ffma(V * dt, cs, x);
-        y = ffma(V * dt, sn, y);
-        th = wrap_pi(ffma(V * dt, sgw, th));
     }
 }
 #endif
@@ -1564,6 +1624,9 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                     pipeline(second_pass);
                 } else {
                     const int ms = min(m, kStage);
+                    // (two landmarks per basic block, as FastSLAM 1's pair_pass below, was measured here in round 4: 14.180
+                    // against 14.184 us per step over 2 000 steps at 10^5 particles -- with ~1.5 waves per SIMD the other wave
+                    // fills the dependent-issue gaps already)
                     for (int k = 0; k < ms; k++) second_pass(k, shA[(k) * kBlock + threadIdx.x], shB[(k) * kBlock + threadIdx.x]);
                     for (int k = ms; k < m; k++) {
                         float4 la;
@@ -1740,6 +1803,25 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                     else wp *= __expf(g.E) * g.norm;
                     store_lmk(idf[k], buf_of(k), la, lb);
                 };
+                // landmarks k and k + 1 in one basic block: the two updates are independent (only the weight product runs
+                // through both, in landmark order), and a wave that has its SIMD to itself issues a DEPENDENT instruction
+                // every ~9.6 cycles but two interleaved chains at 5.6 each (tools/microbench/valu_latency.hip): same
+                // operations on the same values, bit-identical results
+                auto pair_pass = [&](int k, float4 la, float lb, float4 ma, float mb) {
+                    const Obs2 o = observe2(x, y, th, la.x, la.y, la.z, la.w, lb, r00, rl1, r11);
+                    const Obs2 p = observe2(x, y, th, ma.x, ma.y, ma.z, ma.w, mb, r00, rl1, r11);
+                    const Gauss2 g = feature_update2(la.x, la.y, la.z, la.w, lb, o, zf[2 * k] - o.zp0, wrap_pi(zf[2 * k + 1] - o.zp1));
+                    const Gauss2 h = feature_update2(ma.x, ma.y, ma.z, ma.w, mb, p, zf[2 * k + 2] - p.zp0, wrap_pi(zf[2 * k + 3] - p.zp1));
+                    if (logw) {
+                        dl += (double) (g.E + __logf(g.norm));
+                        dl += (double) (h.E + __logf(h.norm));
+                    } else {
+                        wp *= __expf(g.E) * g.norm;
+                        wp *= __expf(h.E) * h.norm;
+                    }
+                    store_lmk(idf[k], buf_of(k), la, lb);
+                    store_lmk(idf[k + 1], buf_of(k + 1), ma, mb);
+                };
 #else
                 auto one_pass = [&](int k, float4 la, float lb) {
                     Jac j = jacobian(x, y, th, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
@@ -1768,7 +1850,13 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                     // (config 2: ~9 of the launch's 15 us lay between the arrival of the pose and its store)
                     stage_landmarks(ts, early_records);
                     SLAM_STAMP(5);  // records staged
-                    for (int k = 0; k < m; k++) {
+                    int k = 0;
+#ifdef SLAM_FAST_MATH
+                    for (; k + 1 < min(m, kStage); k += 2)
+                        pair_pass(k, shA[(k) * kBlock + threadIdx.x], shB[(k) * kBlock + threadIdx.x], shA[(k + 1) * kBlock + threadIdx.x],
+                                  shB[(k + 1) * kBlock + threadIdx.x]);
+#endif
+                    for (; k < m; k++) {
                         float4 la;
                         float lb;
                         if (k < kStage) {
