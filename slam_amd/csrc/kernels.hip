@@ -154,11 +154,10 @@ SLAM_DEV void predict_steps(float &x, float &y, float &th, float P[9], const Pre
 // (1.5 ulp, tools/check_fast_math.py).  BASELINE config 2 (1 000 particles): 19.8 -> see DESIGN.md section 5.
 // ctl (optional): LDS copy of A.steps (8 dwords per step: V, G first), so that the loop does not fetch a cold line of the
 // kernel-argument segment per iteration (scalar cache misses at every launch: ~0.3 us each on the step's critical chain)
-// steps s0 .. s0 + nb - 1 (nb <= W) of predict_steps_fs1_fast, their draws made TOGETHER (see there)
+// the (V, G) normals of steps s0 .. s0 + nb - 1 (nb <= W) of predict_steps_fs1_fast, made TOGETHER (see there)
 template <int W>
-SLAM_DEV void predict_batch_fs1_fast(float &x, float &y, float &th, const PredictArgs &A, const RngArgs &rng, int i, size_t S, const float *ctl,
-                                     float dt, float iwb, const L2 &L, int s0, int nb) {
-    float g0[W], g1[W];
+SLAM_DEV void draw_batch_fs1_fast(float (&g0)[W], float (&g1)[W], const PredictArgs &A, const RngArgs &rng, int i, size_t S, const float *ctl,
+                                  int s0, int nb) {
     if (rng.mode == 0) {
 #pragma unroll
         for (int q = 0; q < W; q++) {
@@ -181,6 +180,12 @@ SLAM_DEV void predict_batch_fs1_fast(float &x, float &y, float &th, const Predic
             box_muller3_fast(r[q], g0[q], g1[q], g2);
         }
     }
+}
+
+// ... and the steps applied, one after the other
+template <int W>
+SLAM_DEV void apply_batch_fs1_fast(float &x, float &y, float &th, const float (&g0)[W], const float (&g1)[W], const PredictArgs &A, const float *ctl,
+                                   float dt, float iwb, const L2 &L, int s0, int nb) {
     // a step's heading needs only the headings before it (a chain of one FMA and one wrap per step); its sine and cosine need
     // only that heading: in a full batch the headings are run first and the W sincos pairs are independent
     float vd[W], gs[W], th_at[W];
@@ -214,6 +219,14 @@ SLAM_DEV void predict_batch_fs1_fast(float &x, float &y, float &th, const Predic
                 position(q);
             }
     }
+}
+
+template <int W>
+SLAM_DEV void predict_batch_fs1_fast(float &x, float &y, float &th, const PredictArgs &A, const RngArgs &rng, int i, size_t S, const float *ctl,
+                                     float dt, float iwb, const L2 &L, int s0, int nb) {
+    float g0[W], g1[W];
+    draw_batch_fs1_fast<W>(g0, g1, A, rng, i, S, ctl, s0, nb);
+    apply_batch_fs1_fast<W>(x, y, th, g0, g1, A, ctl, dt, iwb, L, s0, nb);
 }
 
 SLAM_DEV void predict_steps_fs1_fast(float &x, float &y, float &th, const PredictArgs &A, const RngArgs &rng, int i, size_t S,
@@ -1523,6 +1536,18 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
 #endif
             asm volatile("" : "+v"(hg0), "+v"(hg1), "+v"(hg2));  // (pinned above the wait for the pose)
         }
+#ifdef SLAM_FAST_MATH
+        // FastSLAM 1, the usual five to eight queued predicts: their (V, G) normals depend on counters only and are drawn HERE,
+        // in one batch, while the pose is in flight (~1 us of arithmetic behind a ~0.9 us trip; predict_steps_fs1_fast)
+        constexpr int kEarly = 8;
+        float pg0[kEarly], pg1[kEarly];
+        const bool early_draws = METHOD == 1 && !BIG && PA.nsteps > kEarly / 2 && PA.nsteps <= kEarly && PA.add_noise && !PA.use_heading && !PA.comp.valid;
+        if (early_draws) {
+            draw_batch_fs1_fast<kEarly>(pg0, pg1, PA, rng, i, S, sh_ctl, 0, PA.nsteps);
+#pragma unroll
+            for (int q = 0; q < kEarly; q++) asm volatile("" : "+v"(pg0[q]), "+v"(pg1[q]));  // (pinned above the wait for the pose)
+        }
+#endif
         SLAM_STAMP(4);  // pose + genealogy of the ancestor arrived
         float x = pa.x, y = pa.y, th = pa.z;
         if (!BIG && copy_inline) {
@@ -1553,7 +1578,12 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                 predict_composite(x, y, th, P, PA.comp);
                 q00 = P.p00; q10 = P.p10; q11 = P.p11; q20 = P.p20; q21 = P.p21; q22 = P.p22;
             } else if (METHOD == 1 && PA.add_noise && !PA.use_heading) {
-                predict_steps_fs1_fast(x, y, th, PA, rng, i, S, BIG ? nullptr : sh_ctl);
+                if (early_draws) {
+                    const L2 Lq = llt2(PA.Q[0], PA.Q[2], PA.Q[3]);
+                    apply_batch_fs1_fast<kEarly>(x, y, th, pg0, pg1, PA, sh_ctl, PA.dt, 1.0f / PA.wheel_base, Lq, 0, PA.nsteps);
+                } else {
+                    predict_steps_fs1_fast(x, y, th, PA, rng, i, S, BIG ? nullptr : sh_ctl);
+                }
             } else
 #endif
             {
