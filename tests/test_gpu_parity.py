@@ -280,10 +280,13 @@ def test_stepwise_vs_oracle(sg, oracle, method, N, seed, nobs, math_mode):
             assert anc_bad / anc_tot <= agg["ancestors"], ("aggregate ancestors", anc_bad / anc_tot)
 
 
-def test_fast_build_vs_float64_yardstick(sg, oracle):
+@pytest.mark.parametrize("mapname,seed,nobs", [("example_webmap", 7, 200), ("example_loop2", 7, 200), ("example_loop902", 3, 200)])
+def test_fast_build_vs_float64_yardstick(sg, oracle, mapname, seed, nobs):
     """Where the fast build and the float32 reference disagree about a weight, neither is privileged: compare both
     with a float64 evaluation of the same update from the same (float32) predicted particle set.  The fast build's
-    error must stay within 2x the reference's own (measured 1.3x), over all non-resampling steps of the run."""
+    error must stay within 2x the reference's own, over all non-resampling steps of the run's first 200 observations, on
+    three bundled maps (measured, median / p99 of the fast build's error over the reference's: webmap 1.30 / 1.54, loop2
+    1.13 / 1.44, loop902 -- up to ~40 re-observed landmarks per step -- 1.36 / 1.47)."""
     import fs2_float64
     e_gpu, e_ref = [], []
 
@@ -295,12 +298,16 @@ def test_fast_build_vs_float64_yardstick(sg, oracle):
         for dst, w in ((e_gpu, r["got"]["w"]), (e_ref, r["exp"]["w"])):
             w = w.astype(np.float64)
             dst.append(np.abs(w / w.sum() / wt - 1.0))
-    drive_pair(sg, oracle, "example_webmap", "FASTSLAM2", 100, 7, 200, math_mode=1, per_step=collect, want_pre=True)
+    drive_pair(sg, oracle, mapname, "FASTSLAM2", 100, seed, nobs, math_mode=1, per_step=collect, want_pre=True)
     e_gpu, e_ref = np.concatenate(e_gpu), np.concatenate(e_ref)
+    print("float64 yardstick %s: fast build median %.3g p99 %.3g; float32 reference median %.3g p99 %.3g; ratios %.2f / %.2f over %d weights"
+          % (mapname, np.median(e_gpu), np.quantile(e_gpu, 0.99), np.median(e_ref), np.quantile(e_ref, 0.99),
+             np.median(e_gpu) / np.median(e_ref), np.quantile(e_gpu, 0.99) / np.quantile(e_ref, 0.99), e_gpu.size))
     assert e_gpu.size >= 2000
     assert np.median(e_gpu) <= 2.0 * np.median(e_ref), (np.median(e_gpu), np.median(e_ref))
     assert np.quantile(e_gpu, 0.99) <= 2.0 * np.quantile(e_ref, 0.99), (np.quantile(e_gpu, 0.99), np.quantile(e_ref, 0.99))
-    assert np.median(e_ref) >= 3e-4  # the yardstick really is this coarse: float32 FastSLAM2 weights carry ~1e-3 noise
+    if mapname == "example_webmap":
+        assert np.median(e_ref) >= 3e-4  # the yardstick really is this coarse there: float32 FastSLAM2 weights carry ~1e-3 noise
 
 
 @pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
