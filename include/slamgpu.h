@@ -227,6 +227,15 @@ int slamgpu_observe(slamgpu_ctx *ctx, const float xtrue[3], float max_range, con
 int slamgpu_step_observe(slamgpu_ctx *ctx, const float *controls, int32_t n_controls, const float Q[4], float dt, const float xtrue[3],
                          float max_range, const float R[4], int32_t noise, const float *r1, const float *r2, const float *normals,
                          const float *strata, int32_t record_estimate);
+/* K iterations of the wrapper's loop in ONE call (FastSLAM2Wrapper::run's loop body K times, fastslam2wrapper.cpp:51-117), the
+ * observations made on the device: iteration k applies n_controls[k] control steps -- rows (V, G, phi_true) of `controls`, the
+ * iterations' rows one after the other -- and observes from the true pose xtrue[3 k .. 3 k + 2]; the pose estimate of every
+ * iteration is recorded (slamgpu_estimate_fetch / slamgpu_history_fetch: their capacity, 4 096 iterations, bounds K between two
+ * fetches).  noise: 0 none or 2 Philox on the device (a caller's tape is per iteration: use slamgpu_step_observe).  Enqueues the
+ * K update launches and returns without waiting for the GPU; the results are bit-identical to K calls of slamgpu_step_observe
+ * with record_estimate = 1.  On an error the iterations before the failing one stay applied; slamgpu_last_error names it. */
+int slamgpu_run_observe(slamgpu_ctx *ctx, int32_t K, const int32_t *n_controls, const float *controls, const float Q[4], float dt,
+                        const float *xtrue, float max_range, const float R[4], int32_t noise);
 /* The observation packet of the last slamgpu_step_observe, copied back for logging / tests (any pointer may be NULL;
  * arrays sized for the map): raw observations z[2 nz] and visible landmark ids vis[nz], re-observed zf[2 m] / idf[m],
  * new zn[2 n].  Synchronises. */

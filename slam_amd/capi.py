@@ -25,7 +25,7 @@ DECLARED_SYMBOLS = [
     "slamgpu_dist_history_fetch", "slamgpu_dist_gather", "slamgpu_dist_set_collective", "slamgpu_dist_handshake_test",
     "slamgpu_dist_collective_status", "slamgpu_dist_comm_id", "slamgpu_dist_comm_init", "slamgpu_dist_group_create", "slamgpu_dist_group_destroy",
     "slamgpu_dist_group_step", "slamgpu_dist_group_settle", "slamgpu_dist_group_history", "slamgpu_dist_group_download",
-    "slamgpu_peek", "slamgpu_step_observe", "slamgpu_observe_fetch", "slamgpu_associate_ex", "slamgpu_dist_comm_info", "slamgpu_dist_remote_reads",
+    "slamgpu_peek", "slamgpu_step_observe", "slamgpu_run_observe", "slamgpu_observe_fetch", "slamgpu_associate_ex", "slamgpu_dist_comm_info", "slamgpu_dist_remote_reads",
 ]
 ASSOC_AUTO, ASSOC_EXHAUSTIVE, ASSOC_GRID = 0, 1, 2
 FLAG_DEVICE_OBSERVE = 1
@@ -94,6 +94,7 @@ def load_library():
     L.slamgpu_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int32] + [C.c_void_p] * 2 + [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32)]
     L.slamgpu_step_observe.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    L.slamgpu_run_observe.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p, C.c_int32]
     L.slamgpu_observe_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.POINTER(C.c_int32),
                                         C.c_void_p, C.POINTER(C.c_int32)]
     L.slamgpu_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
@@ -656,6 +657,17 @@ class SlamGpu:
 
     def step_observe(self, controls, Q, dt, xtrue, max_range, R, **kw):
         self.prepare_step_observe(controls, Q, dt, xtrue, max_range, R, **kw)()
+
+    def run_observe(self, controls_per_step, Q, dt, xtrue_per_step, max_range, R, noise=2):
+        """slamgpu_run_observe: K iterations (k predicts + device-made observation + update + estimate each) in one C call;
+        controls_per_step: K arrays of (V, G, phi_true) rows; xtrue_per_step: K poses"""
+        K = len(controls_per_step)
+        counts = np.ascontiguousarray([np.asarray(c, np.float32).reshape(-1, 3).shape[0] for c in controls_per_step], np.int32)
+        rows = [np.asarray(c, np.float32).reshape(-1, 3) for c in controls_per_step if np.asarray(c).size]
+        ctl = _f32(np.concatenate(rows) if rows else np.zeros((0, 3), np.float32))
+        xt = _f32(np.asarray(xtrue_per_step, np.float32).reshape(K, 3))
+        _chk(self.L.slamgpu_run_observe(self.h, K, _ptr(counts), _ptr(ctl), _ptr(_f32(Q, 4)), C.c_float(dt), _ptr(xt), C.c_float(max_range),
+                                        _ptr(_f32(R, 4)), int(noise)))
 
     def observe_fetch(self):
         """the observation packet of the last step_observe: dict(z, vis, zf, idf, zn)"""

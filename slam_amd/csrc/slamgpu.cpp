@@ -1385,6 +1385,26 @@ int slamgpu_step_observe(slamgpu_ctx *c, const float *controls, int32_t n_contro
     return 0;
 }
 
+int slamgpu_run_observe(slamgpu_ctx *c, int32_t K, const int32_t *n_controls, const float *controls, const float Q[4], float dt,
+                        const float *xtrue, float max_range, const float R[4], int32_t noise) {
+    if (int rc = check_ctx(c)) return rc;
+    if (K < 0 || (K > 0 && (!n_controls || !xtrue))) return fail(SLAMGPU_ERR_INVALID, "slamgpu_run_observe: bad arguments");
+    if (noise != 0 && noise != 2) return fail(SLAMGPU_ERR_INVALID, "slamgpu_run_observe: noise must be 0 or 2 (a tape is per iteration: slamgpu_step_observe)");
+    if (c->cfg.rng_mode == SLAMGPU_RNG_TAPE) return fail(SLAMGPU_ERR_INVALID, "slamgpu_run_observe: TAPE-mode contexts take their draws per iteration (slamgpu_step_observe)");
+    size_t row = 0;
+    for (int32_t k = 0; k < K; k++) {
+        const int32_t nc = n_controls[k];
+        if (nc < 0) return fail(SLAMGPU_ERR_INVALID, "slamgpu_run_observe: iteration %d has a negative control count", (int) k);
+        if (int rc = slamgpu_step_observe(c, nc ? controls + 3 * row : nullptr, nc, Q, dt, xtrue + 3 * (size_t) k, max_range, R, noise, nullptr, nullptr,
+                                          nullptr, nullptr, 1)) {
+            std::string why = slamgpu_last_error();
+            return fail(rc, "slamgpu_run_observe: iteration %d of %d: %s", (int) k, (int) K, why.c_str());
+        }
+        row += (size_t) nc;
+    }
+    return 0;
+}
+
 int slamgpu_observe_fetch(slamgpu_ctx *c, float *z, int32_t *vis, int32_t *nz, float *zf, int32_t *idf, int32_t *m, float *zn, int32_t *n) {
     if (int rc = check_ctx(c)) return rc;
     if (!c->last_pkt_dev) return fail(SLAMGPU_ERR_INVALID, "no device-made observation yet (slamgpu_step_observe)");

@@ -296,3 +296,45 @@ def test_c_download_straight_after_device_steps(sg, monkeypatch, plain):
     for key in ("xv", "w", "xf", "Pf"):
         assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), key
     assert np.isfinite(a["xf"]).all()
+
+
+@pytest.mark.parametrize("method,N", [("FASTSLAM2", 1024), ("FASTSLAM1", 1000)])
+def test_run_observe_equals_step_by_step(sg, method, N):
+    """slamgpu_run_observe (K iterations of the wrapper's loop in one C call, observation made on the device) against K calls of
+    slamgpu_step_observe: the histories of all iterations (estimate, Neff, decision, status) and the final state bit for bit, the
+    call split in uneven pieces; bad arguments are refused."""
+    from slam_amd import host
+    args = sim_args("example_webmap", method, 100, 7)
+    tape = host.make_tape(args, max_obs=160)
+    sim = host.HostSim(args)
+    lm, _ = sim.map()
+    max_range = float(sim.conf.MAX_RANGE)
+    sim.close()
+    steps = tape["steps"]
+    ctl = [np.array(st["controls"], f32).reshape(-1, 3) for st in steps]
+    xt = [np.asarray(st["true"], f32) for st in steps]
+    out = []
+    for whole in (False, True):
+        s = sg.SlamGpu(N, tape["nlm"], method=2 if method == "FASTSLAM2" else 1, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=5,
+                       math_mode=1, device_observe=True)
+        s.set_map(lm)
+        if whole:
+            for a, b in ((0, 1), (1, 64), (64, 64), (64, len(steps))):   # (an empty call in the middle)
+                s.run_observe(ctl[a:b], tape["Q"], float(tape["dt"]), xt[a:b], max_range, tape["R"], noise=2)
+        else:
+            for c, x in zip(ctl, xt):
+                s.step_observe(c, tape["Q"], float(tape["dt"]), x, max_range, tape["R"], noise=2)
+        hist = s.history_fetch()
+        out.append((hist, s.last_history_status.copy(), s.download()))
+        if whole:
+            with pytest.raises(sg.SlamGpuError):
+                s.run_observe(ctl[:2], tape["Q"], float(tape["dt"]), xt[:2], max_range, tape["R"], noise=1)
+        s.close()
+    (ha, sa, da), (hb, sb, db) = out
+    assert len(ha[0]) == len(steps)
+    for x, y in zip(ha, hb):
+        assert np.array_equal(np.asarray(x), np.asarray(y))
+    assert np.array_equal(sa, sb) and not sa.any()
+    assert da["nf"] == db["nf"] and da["nf"] > 10
+    for key in ("xv", "Pv", "w", "xf", "Pf"):
+        assert np.array_equal(da[key].view(np.uint32), db[key].view(np.uint32)), key
