@@ -7,6 +7,9 @@
  *           -DJACOBIAN_ACCELERATOR=on: class AcceleratorHandler { getMemoryPointer(); setN(n);
  *           start(); isDone(); } (src/backend/AcceleratorHandler.h:10-23) with the packed float32
  *           window written/read at src/backend/core.cpp:586-664.  => slamgpu_jacobians().
+ *           Built with -DMULTIPARTICLE_ACCELERATOR=on the object has setParticlesCount(count) in the place of setN
+ *           (AcceleratorHandler.h:17-21) and the window holds `count` self-describing records
+ *           (src/backend/algorithms/fastslam2.cpp:172-286).  => slamgpu_jacobians_multi().
  *
  *  Seam 2 — the algorithm objects the wrappers drive:
  *           FastSLAM2::predict / FastSLAM2::update (src/backend/algorithms/fastslam2.h:20-24, called at
@@ -31,7 +34,7 @@
 extern "C" {
 #endif
 
-/* 3 (round 4): SLAMGPU_STATUS_CAPACITY; slamgpu_run_observe; the round-1 exchange path, the push / fold collectives, the raw
+/* 3 (round 4): SLAMGPU_STATUS_CAPACITY; slamgpu_run_observe; slamgpu_jacobians_multi; the round-1 exchange path, the push / fold collectives, the raw
  *    device-buffer helpers and slamgpu_debug_stamps moved behind SLAMGPU_EXPERIMENTAL (still exported, no longer stable).
  * Everything declared outside the SLAMGPU_EXPERIMENTAL block at the end of this file is STABLE: same name, same argument
  * meaning and same error behaviour for a given SLAMGPU_ABI_VERSION. */
@@ -128,6 +131,14 @@ int slamgpu_device_count(void);
  *                                                                              => 16n floats
  * Host pointers; synchronous (this is the start()/isDone() spin of core.cpp:619-622). */
 int slamgpu_jacobians(const float *in, uint32_t n, float *out);
+/* The same for the MULTIPARTICLE_ACCELERATOR form of the window (AcceleratorHandler.h:17-21: setParticlesCount + start;
+ * written and read back at algorithms/fastslam2.cpp:172-286): `records` self-describing records back to back in ONE host
+ * buffer, each  n, xv[3], R[4], n x (xf[2], Pf[4]), then n x 16 output floats (zp, Hf, Hv, Sf as above)  = 8 + 22 n floats
+ * (the reference writes one record per particle and re-observed landmark, n = 1); the outputs are written IN PLACE, as the
+ * accelerator wrote them into its memory block.  window_floats = size of the buffer (a record running beyond it is refused).
+ * Synchronous.  (Upstream's caller of this form is unfinished -- it loops over copies of the particles and indexes Sf by the
+ * observation -- so only the window itself is the contract here.) */
+int slamgpu_jacobians_multi(float *window, uint32_t records, uint64_t window_floats);
 
 /* Known-answer entry point for the scalar device functions the update kernels are built from, in the arithmetic of the
  * chosen build (SLAMGPU_MATH_*): op 0 = trigonometricOffset (core.cpp:460-477), in[n] -> out[n];

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 # every symbol include/slamgpu.h declares (tests check the built library exports each one)
 DECLARED_SYMBOLS = [
-    "slamgpu_last_error", "slamgpu_abi_version", "slamgpu_device_count", "slamgpu_jacobians", "slamgpu_create",
+    "slamgpu_last_error", "slamgpu_abi_version", "slamgpu_device_count", "slamgpu_jacobians", "slamgpu_jacobians_multi", "slamgpu_create",
     "slamgpu_destroy", "slamgpu_predict", "slamgpu_update", "slamgpu_estimate", "slamgpu_estimate_async", "slamgpu_estimate_fetch", "slamgpu_stats", "slamgpu_ancestors",
     "slamgpu_num_landmarks", "slamgpu_genealogy_rows", "slamgpu_download", "slamgpu_upload", "slamgpu_sync", "slamgpu_step", "slamgpu_history_fetch", "slamgpu_shard_set_totals_buffer", "slamgpu_shard_step", "slamgpu_timer_start", "slamgpu_timer_stop", "slamgpu_stream", "slamgpu_profile",
     "slamgpu_kernel_time", "slamgpu_algorithmic_bytes", "slamgpu_shard_update", "slamgpu_shard_block_totals", "slamgpu_shard_plan",
@@ -75,6 +75,7 @@ def load_library():
     L.slamgpu_destroy.argtypes = [C.c_void_p]
     L.slamgpu_destroy.restype = None
     L.slamgpu_jacobians.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.slamgpu_jacobians_multi.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
     L.slamgpu_predict.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
     L.slamgpu_update.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p]

@@ -507,6 +507,8 @@ struct KernelTable {
     // (particle, observation)
     void (*associate_grid)(hipStream_t, const Buffers &, const AssocGridArgs &, const float *R4, float gate_reject, float gate_augment,
                            int32_t *labels_dev);
+    // seam 1, MULTIPARTICLE_ACCELERATOR form: self-describing records back to back, outputs in place; tab: 3 words per feature
+    void (*jacobians_multi)(hipStream_t, float *win_dev, const uint32_t *tab_dev, uint32_t nfeat);
 };
 
 const KernelTable *kernels_strict();

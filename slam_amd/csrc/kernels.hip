@@ -2256,6 +2256,25 @@ __global__ void __launch_bounds__(kBlock) jacobians_kernel(const float *__restri
     o[12] = j.s00; o[13] = j.s01; o[14] = j.s10; o[15] = j.s11;
 }
 
+// The MULTIPARTICLE_ACCELERATOR form of the window (fastslam2.cpp:172-286; AcceleratorHandler.h:17-21): `records` records back to
+// back, each self-describing: [n][xv 3][R 4][n x (xf 2, Pf 4)][n x 16 output floats].  One thread per feature; tab[f] = (offset
+// of the record's first float, feature index inside the record, the record's n).  Outputs in place, as the FPGA wrote them.
+__global__ void __launch_bounds__(kBlock) jacobians_multi_kernel(float *__restrict__ win, const uint32_t *__restrict__ tab, uint32_t nfeat) {
+    const uint32_t f = blockIdx.x * kBlock + threadIdx.x;
+    if (f >= nfeat) return;
+    const uint32_t base = tab[3 * (size_t) f], k = tab[3 * (size_t) f + 1], n = tab[3 * (size_t) f + 2];
+    const float *h = win + base + 1;
+    const float x = h[0], y = h[1], th = h[2];
+    const float r00 = h[3], r10 = h[4], r01 = h[5], r11 = h[6];
+    const float *p = h + 7 + 6 * (size_t) k;
+    Jac j = jacobian(x, y, th, p[0], p[1], p[2], p[3], p[5], r00, r01, r10, r11);
+    float *o = win + base + 8 + 6 * (size_t) n + 16 * (size_t) k;
+    o[0] = j.zp0; o[1] = j.zp1;
+    o[2] = j.hf00; o[3] = j.hf01; o[4] = j.hf10; o[5] = j.hf11;
+    o[6] = j.hv00; o[7] = j.hv01; o[8] = 0.0f; o[9] = j.hv10; o[10] = j.hv11; o[11] = -1.0f;
+    o[12] = j.s00; o[13] = j.s01; o[14] = j.s10; o[15] = j.s11;
+}
+
 // Known-answer entry point (slamgpu_kat): the scalar device functions of THIS build against the reference's edge-case
 // vectors (tests/golden/kat_functions.npz): op 0 trigonometricOffset (core.cpp:460-477; the fast build's wrap_pi),
 // op 1 / 2 gaussEvaluate for D = 2 / 3 (fastslam2.cpp:127-163) in the form the update kernel evaluates it.
@@ -3345,6 +3364,10 @@ static void launch_jacobians(hipStream_t st, const float *in, uint32_t n, float 
     hipLaunchKernelGGL(jacobians_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, in, n, out);
 }
 
+static void launch_jacobians_multi(hipStream_t st, float *win, const uint32_t *tab, uint32_t nfeat) {
+    hipLaunchKernelGGL(jacobians_multi_kernel, dim3((nfeat + kBlock - 1) / kBlock), dim3(kBlock), 0, st, win, tab, nfeat);
+}
+
 static void launch_observe(hipStream_t st, const ObserveArgs &A) { hipLaunchKernelGGL(observe_kernel, dim3(1), dim3(kBlock), 0, st, A); }
 static void launch_observe_book(hipStream_t st, const ObserveArgs &A) {
     hipLaunchKernelGGL(observe_book_kernel, dim3(1), dim3(kObsThreads), 0, st, A);
@@ -3443,7 +3466,7 @@ static void launch_associate_grid(hipStream_t st, const Buffers &B, const AssocG
 
 static const KernelTable kTable = {launch_update, launch_resample, launch_scan, launch_gather, launch_flatten, launch_identity, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat, launch_observe, launch_observe_book, launch_associate,
                                    launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish, launch_dist_gather, launch_dist_flags, launch_peek, launch_lmk_box, launch_assoc_grid,
-                                   launch_associate_grid};
+                                   launch_associate_grid, launch_jacobians_multi};
 
 }  // namespace SLAM_KNS
 

@@ -2990,6 +2990,52 @@ int slamgpu_jacobians(const float *in, uint32_t n, float *out) {
     return rc;
 }
 
+int slamgpu_jacobians_multi(float *window, uint32_t records, uint64_t window_floats) {
+    if (!window && records > 0) return fail(SLAMGPU_ERR_INVALID, "null window");
+    if (records == 0) return 0;
+    // walk the self-describing records: [n][xv 3][R 4][n x 6 in][n x 16 out]
+    std::vector<uint32_t> tab;
+    uint64_t pos = 0;
+    for (uint32_t r = 0; r < records; r++) {
+        if (pos + 8 > window_floats) return fail(SLAMGPU_ERR_INVALID, "record %u starts beyond the window (%llu floats)", r, (unsigned long long) window_floats);
+        const float nf = window[pos];
+        if (!(nf >= 0.0f) || nf > 65536.0f || nf != (float) (uint32_t) nf) return fail(SLAMGPU_ERR_INVALID, "record %u: feature count %g", r, (double) nf);
+        const uint32_t n = (uint32_t) nf;
+        const uint64_t len = 8 + 22 * (uint64_t) n;
+        if (pos + len > window_floats || pos + len > 0xffffffffull) return fail(SLAMGPU_ERR_INVALID, "record %u (%u features) runs beyond the window", r, n);
+        for (uint32_t k = 0; k < n; k++) {
+            tab.push_back((uint32_t) pos);
+            tab.push_back(k);
+            tab.push_back(n);
+        }
+        pos += len;
+    }
+    const uint32_t nfeat = (uint32_t) (tab.size() / 3);
+    if (nfeat == 0) return 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SLAMGPU_ERR_NO_DEVICE, "no HIP device: libslamgpu has no CPU fallback");
+    float *dwin = nullptr;
+    uint32_t *dtab = nullptr;
+    HIP_TRY(hipMalloc((void **) &dwin, sizeof(float) * pos));
+    hipError_t e = hipMalloc((void **) &dtab, sizeof(uint32_t) * tab.size());
+    if (e != hipSuccess) {
+        (void) hipFree(dwin);
+        return fail(SLAMGPU_ERR_ALLOC, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    int rc = 0;
+    if ((e = hipMemcpy(dwin, window, sizeof(float) * pos, hipMemcpyHostToDevice)) != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "H2D: %s", hipGetErrorString(e));
+    if (!rc && (e = hipMemcpy(dtab, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice)) != hipSuccess)
+        rc = fail(SLAMGPU_ERR_HIP, "H2D: %s", hipGetErrorString(e));
+    if (!rc) {
+        kernels_strict()->jacobians_multi(nullptr, dwin, dtab, nfeat);
+        if ((e = hipGetLastError()) != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "launch: %s", hipGetErrorString(e));
+    }
+    if (!rc && (e = hipMemcpy(window, dwin, sizeof(float) * pos, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "D2H: %s", hipGetErrorString(e));
+    (void) hipFree(dwin);
+    (void) hipFree(dtab);
+    return rc;
+}
+
 int slamgpu_debug_stamps(slamgpu_ctx *c, uint64_t *out, int32_t max_blocks, int32_t *nblocks) {
     if (int rc = check_ctx(c)) return rc;
     if (!nblocks) return fail(SLAMGPU_ERR_INVALID, "null output");

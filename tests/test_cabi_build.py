@@ -52,5 +52,5 @@ def test_integration_md_shows_the_compiled_bindings():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     shim = open(os.path.join(HERE, "cabi", "accel_shim.h")).read()
     adapter = open(os.path.join(HERE, "cabi", "fastslam2gpu_adapter.h")).read()
-    assert shim[shim.index("class AcceleratorHandler {"):shim.index("#endif")].rstrip() in doc
+    assert shim[shim.index("class AcceleratorHandler {"):shim.rindex("#endif")].rstrip() in doc
     assert adapter[adapter.index("template <class Particle, class VectorXf, class MatrixXf>"):adapter.index("#endif")].rstrip() in doc

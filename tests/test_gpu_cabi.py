@@ -178,3 +178,51 @@ def test_reference_filter_with_jacobians_on_the_gpu(ref_accel, name, mapname, me
         else:
             assert np.hypot(*(est[:2] - g["true"][k - 1, :2])) <= np.hypot(*(g["est"][k - 1, :2] - g["true"][k - 1, :2])) + 0.5, k
     r.close()
+
+
+def test_multiparticle_form_of_the_accelerator_window(kat):
+    """The MULTIPARTICLE_ACCELERATOR form of seam 1 (AcceleratorHandler.h:17-21: setParticlesCount + start): the drop-in compiled
+    with that macro, its window written and read back as FastSLAM2::precomputeAllLikelihoodGivenXv does (fastslam2.cpp:172-286:
+    one self-describing record per particle and re-observed landmark).  Every record must carry exactly what the single-particle
+    window gives for that particle and landmark (bit for bit: the same device function), and the reference-held Jacobian vectors
+    within the seam's bound; a record that runs beyond the buffer is refused."""
+    from slam_amd import capi
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "cabi")])
+    L = C.CDLL(os.path.join(HERE, "cabi", "libcabi_multi.so"))
+    L.cabi_multi_last_error.restype = C.c_char_p
+    L.cabi_multi_window.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 4
+    n = kat["jac_xv"].shape[0]
+    P, nf = 24, n
+    rng = np.random.default_rng(3)
+    xv = np.ascontiguousarray(kat["jac_xv"][rng.integers(0, n, P)], f32)
+    xv[:, :2] += rng.normal(0, 0.05, (P, 2)).astype(f32)
+    xf = np.ascontiguousarray(np.broadcast_to(kat["jac_xf"], (P, nf, 2)), f32)
+    Pf = np.ascontiguousarray(np.broadcast_to(kat["jac_Pf"], (P, nf, 2, 2)), f32)
+    idf = np.array([5, 0, 17, 3, 95, 40, 41], np.int32)
+    k = idf.size
+    zp, Hv, Hf, Sf = np.zeros((P, k, 2), f32), np.zeros((P, k, 6), f32), np.zeros((P, k, 4), f32), np.zeros((P, k, 4), f32)
+    rc = L.cabi_multi_window(_p(xv), _p(RM), _p(xf), _p(Pf), P, nf, _p(idf), k, _p(zp), _p(Hv), _p(Hf), _p(Sf))
+    assert rc == 0, L.cabi_multi_last_error()
+    for p in range(P):
+        z1, hv1, hf1, sf1 = capi.jacobians(xv[p], RM, xf[p][idf], Pf[p][idf])
+        assert np.array_equal(zp[p], z1) and np.array_equal(Hv[p].reshape(k, 2, 3), hv1)
+        assert np.array_equal(Hf[p].reshape(k, 2, 2), hf1) and np.array_equal(Sf[p].reshape(k, 2, 2), sf1)
+    # the reference-held vectors themselves, one record each (pose i, landmark i)
+    xv2 = np.ascontiguousarray(kat["jac_xv"], f32)
+    for i in range(0, n, 7):
+        out = [np.zeros((1, 1, 2), f32), np.zeros((1, 1, 6), f32), np.zeros((1, 1, 4), f32), np.zeros((1, 1, 4), f32)]
+        rc = L.cabi_multi_window(_p(xv2[i:i + 1]), _p(RM), _p(np.ascontiguousarray(kat["jac_xf"][i:i + 1])), _p(np.ascontiguousarray(kat["jac_Pf"][i:i + 1])),
+                                 1, 1, _p(np.array([0], np.int32)), 1, *[_p(a) for a in out])
+        assert rc == 0, L.cabi_multi_last_error()
+        np.testing.assert_allclose(out[0].ravel(), kat["jac_zp"][i], rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(out[1].reshape(2, 3), kat["jac_Hv"][i], rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(out[2].reshape(2, 2), kat["jac_Hf"][i], rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(out[3].reshape(2, 2), kat["jac_Sf"][i], rtol=1e-5, atol=1e-9)
+    # the C entry on its own: a window whose last record claims more features than the buffer holds is refused
+    lib = capi.load_library()
+    win = np.zeros(30, f32)
+    win[0] = 2.0
+    assert lib.slamgpu_jacobians_multi(_p(win), 1, win.size) < 0 and b"beyond the window" in lib.slamgpu_last_error()
+    win[0] = 1.0
+    assert lib.slamgpu_jacobians_multi(_p(win), 1, win.size) == 0
+    assert lib.slamgpu_jacobians_multi(_p(win), 0, 0) == 0
