@@ -447,8 +447,34 @@ SLAM_DEV ScanLoads scan_issue(const float *__restrict__ tot, int nb, int nbl, bo
     return L;
 }
 
+// Wide tables (the gathered totals of several shards: more than two per thread), linear weights: the whole table by LDS-DMA
+// (global_load_lds: memory -> LDS, no registers) into `stab` -- w[nb] then, kScanPad further, q[nb] -- every request of the block
+// in flight at once, where scan_finish's batches of kScanBatch are ceil(per / kScanBatch) dependent trips at the head of every
+// launch (profiles/dist_width_r04.txt: ~+4 us at 8 shards).  Lane l of a wave lands at base + l: instruction u of thread t
+// carries entry k = t + 256 u, so the table arrives in index order.
+SLAM_DEV int scan_pad(int nb) { return (nb + 255) & ~255; }
+SLAM_DEV void scan_issue_dma(const float *__restrict__ tot, int nb, int nbl, float *stab) {
+    const int t = threadIdx.x, wbase = (t / kWave) * kWave;
+    float *const qtab = stab + scan_pad(nb);
+    int sh = t / nbl, r = t - sh * nbl;  // entry k = t + 256 u lives at [shard sh][row][r]
+    for (int k0 = 0; k0 < nb; k0 += kBlock) {
+        if (k0 + t < nb) {
+            const float *src = tot + (size_t) sh * 2 * nbl + r;
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *) src,
+                                             (void __attribute__((address_space(3))) *) (stab + k0 + wbase), 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *) (src + nbl),
+                                             (void __attribute__((address_space(3))) *) (qtab + k0 + wbase), 4, 0, 0);
+        }
+        r += kBlock;
+        while (r >= nbl) {
+            r -= nbl;
+            sh++;
+        }
+    }
+}
+
 SLAM_DEV void scan_finish(const ScanLoads L, const float *__restrict__ tot, int nb, int nbl, bool logw, double *off, double *sh_a,
-                          double *sh_q, double &W, double &Q, double &M) {
+                          double *sh_q, double &W, double &Q, double &M, const float *stab = nullptr) {
     const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
     const int per = (nb + kBlock - 1) / kBlock;
     const int lo = min(nb, t * per), hi = min(nb, lo + per);
@@ -478,6 +504,12 @@ SLAM_DEV void scan_finish(const ScanLoads L, const float *__restrict__ tot, int 
     if (two) {
         if (lo < hi) acc(lo, L.tv0, L.qv0, L.mv0);
         if (lo + 1 < hi) acc(lo + 1, L.tv1, L.qv1, L.mv1);
+    } else if (stab) {
+        // the table is in LDS (scan_issue_dma): every wave's requests must have landed before anybody reads
+        __syncthreads();
+        const float *qtab = stab + scan_pad(nb);
+        for (int k = lo; k < hi; k++) acc(k, stab[k], qtab[k], 0.0f);
+        // (stab is the memory of the ancestor windows: the barriers below stand between these reads and the first window)
     } else {
         // (gathered tables of several shards: [shard][w(nbl) | q(nbl) (| m(nbl))]: walk the index instead of dividing per
         // entry, and request kScanBatch totals of the thread's segment before using any of them.  Round 4 priced this loop for
@@ -1025,7 +1057,8 @@ __host__ __device__ inline int staging_slots(int method, bool big, int m) {
 // stood between kernel entry and the first vector load before; 16.7 -> 16.05 us per step at 10^5 particles).
 // Tried on top and measured as no better (gpurun_out/ab, 16.28 / 16.10 / 16.04 us): preloading these arguments into SGPRs
 // (-mllvm -amdgpu-kernarg-preload-count=16) and touching every 64-byte line of the argument segment at entry.
-//   h_flags: bit 0 plan_inline, bit 1 scan_global, bit 2 logw, bit 3 lazy, bit 4 front end inside the launch (h_front)
+//   h_flags: bit 0 plan_inline, bit 1 scan_global, bit 2 logw, bit 3 lazy, bit 4 front end inside the launch (h_front),
+//            bit 5 the gathered totals table travels by LDS-DMA (scan_issue_dma)
 template <int METHOD, int MODE, bool BIG>
 __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict__ h_tot, Ctrl *h_ctrl,
                                                          const FrontState *h_front, int h_nb, int h_slot, int h_grid, int h_flags, Buffers B, PredictArgs PA,
@@ -1146,8 +1179,16 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     const bool logw = (h_flags & 4) != 0;
     const bool do_scan = h_plan && !h_scan_global;
     ScanLoads scl{0.0f, 0.0f, 0.0f, 0.0f, -INFINITY, -INFINITY};
+    // distributed contexts, table wider than two totals per thread: by LDS-DMA into the memory of the ancestor windows and the
+    // landmark staging (both used only after the scan), when the table fits there
+    // (the launcher knows whether it fits: h_flags bit 5 -- a head argument, like everything the scan's requests depend on)
+    float *scan_tab = nullptr;
+    if constexpr (DIST) {
+        if (do_scan && (h_flags & 32) != 0) scan_tab = wins;
+    }
     if (do_scan) {
-        scl = scan_issue(h_tot, nbg, h_nb, logw);
+        if (scan_tab) scan_issue_dma(h_tot, nbg, h_nb, scan_tab);
+        else scl = scan_issue(h_tot, nbg, h_nb, logw);
     }
     __shared__ int32_t pk[kSmallWords];
     __shared__ uint32_t f_sets[4];
@@ -1219,7 +1260,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
             Q = offp[nb + 2];
             Mx = offp[nb + 3];
         } else {
-            scan_finish(scl, h_tot, nbg, nb, logw, off, sh_a, sh_q, W, Q, Mx);
+            scan_finish(scl, h_tot, nbg, nb, logw, off, sh_a, sh_q, W, Q, Mx, scan_tab);
         }
         const float neff = neff_of(W, Q);  // Neff = 1 / sum((w/W)^2)  (core.cpp:784-788)
         pend = U.do_resample && (neff < (float) U.n_effective);
@@ -1258,7 +1299,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                     W = offp[nb + 1];
                     Q = offp[nb + 2];
                 } else {
-                    scan_finish(scl, h_tot, nbg, nb, logw, off, sh_a, sh_q, W, Q, Mx);
+                    scan_finish(scl, h_tot, nbg, nb, logw, off, sh_a, sh_q, W, Q, Mx, scan_tab);
                 }
                 pend = U.do_resample && (neff_of(W, Q) < (float) U.n_effective);
             }
@@ -3293,7 +3334,12 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
                        (U.plan_inline ? update_window_bytes() : 0);
     const int sel = (U.method == 2 ? 6 : 0) + 2 * U.arrivals + (U.big ? 1 : 0);
     const float *h_tot = U.arrivals == 2 ? B.gtot[ws.wpar ^ 1] : ws.blk_w[ws.wpar ^ 1];
-    const int h_flags = (U.plan_inline ? 1 : 0) | (U.scan_global ? 2 : 0) | (U.logw ? 4 : 0) | (U.lazy ? 8 : 0) | (U.front.on ? 16 : 0);
+    // bit 5: distributed contexts: the gathered table is wider than two totals per thread and fits the LDS behind the block prefix
+    // (ancestor windows + landmark staging): the scan fetches it by LDS-DMA (scan_issue_dma)
+    const size_t stage_bytes = (size_t) staging_slots(U.method, U.big != nullptr, U.m) * kBlock * (sizeof(float4) + sizeof(float));
+    const bool scan_dma = U.arrivals == 2 && U.plan_inline && !U.scan_global && !U.logw && nbg > 2 * (size_t) kBlock &&
+                          2 * sizeof(float) * (((nbg + 255) / 256) * 256) <= update_window_bytes() + stage_bytes;
+    const int h_flags = (U.plan_inline ? 1 : 0) | (U.scan_global ? 2 : 0) | (U.logw ? 4 : 0) | (U.lazy ? 8 : 0) | (U.front.on ? 16 : 0) | (scan_dma ? 32 : 0);
 #define SLAM_LAUNCH_UPDATE(M, A, G)                                                                                              \
     hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid, \
                        h_flags, B, PA, U, rng, ws)

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """GPU box: what the width of the gathered totals table costs a distributed launch.  G logical shards of 100 096 particles
 on ONE GPU and one stream run their launches back to back, so (time per step) / G is the launch time of one shard when
-the particle set spans G GPUs (remote reads excepted: everything is local here).  usage: python tools/dist_width.py"""
+the particle set spans G GPUs (remote reads excepted: everything is local here).
+usage: python tools/dist_width.py [particles per shard] [G,G,...]   (under rocprofv3 --kernel-trace --stats with ONE G: the average
+duration of update_kernel<2, 2, false> is the cleaner number: the wall time includes G host loops)"""
 import os
 import sys
 import time
@@ -13,7 +15,7 @@ import slam_amd as sg  # noqa: E402
 from slam_amd import host  # noqa: E402
 
 n, start, steps = (int(sys.argv[1]) if len(sys.argv) > 1 else 100096), 600, 400
-for G in (1, 2, 4, 8):
+for G in ([int(x) for x in sys.argv[2].split(',')] if len(sys.argv) > 2 else (1, 2, 4, 8)):
     Np = G * n
     tp = host.make_tape(["-m", os.path.join(ROOT, "data", "example_webmap.mat"), "-method", "FASTSLAM2", "-NPARTICLES", Np, "-NEFFECTIVE",
                          int(0.75 * Np), "-SWITCH_SEED_RANDOM", 7], max_obs=start + steps)
