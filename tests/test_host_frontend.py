@@ -42,6 +42,26 @@ def test_no_gpu_fails_loudly():
     assert e.value.code == -4 and "no CPU fallback" in str(e.value)
 
 
+def test_multi_window_is_validated_before_any_device_call():
+    """slamgpu_jacobians_multi walks the self-describing records on the host first: a malformed window is refused as such with or
+    without a GPU, a well-formed one reaches the device (and without a GPU fails loudly there: no CPU fallback)."""
+    import ctypes as C
+    import slam_amd
+    from slam_amd import capi
+    L = capi.load_library()
+    win = np.zeros(30, np.float32)
+    p = win.ctypes.data_as(C.c_void_p)
+    for bad in (2.0, -1.0, 0.5, float("nan")):      # more features than the buffer holds; no count at all
+        win[0] = bad
+        assert L.slamgpu_jacobians_multi(p, 1, win.size) == -1, bad
+    win[0] = 1.0
+    assert L.slamgpu_jacobians_multi(p, 2, win.size) == -1            # the second record starts beyond the window
+    assert L.slamgpu_jacobians_multi(None, 1, 0) == -1
+    assert L.slamgpu_jacobians_multi(p, 0, win.size) == 0
+    if slam_amd.device_count() == 0:
+        assert L.slamgpu_jacobians_multi(p, 1, win.size) == -4 and b"no CPU fallback" in L.slamgpu_last_error()
+
+
 def test_conf_defaults_and_overrides():
     from slam_amd import host
     s = host.HostSim(sim_args("example_webmap", "FASTSLAM2", 1234, 9))
