@@ -342,7 +342,9 @@ SLAM_DEV void est_combine(EstItem &a, const EstItem &b) {
 
 // reduce over the 256 threads of a block; result valid in thread 0.  Sums on the DPP path (device_math.h); the first
 // strictly greatest weight of a wave = the lowest lane holding the wave's maximum (indices ascend with the lane).
-SLAM_DEV EstItem block_reduce_est(EstItem v, EstItem *sh) {
+// ... in two halves, so that a caller with a barrier of its own can put it between them: the wave's part (every lane returns the
+// wave's result; lane 0 parks it in sh[wave]) ...
+SLAM_DEV EstItem wave_reduce_est(EstItem v, EstItem *sh) {
     v.sx = wave_sum_d(v.sx);
     v.sy = wave_sum_d(v.sy);
     float wm = v.w;
@@ -357,11 +359,18 @@ SLAM_DEV EstItem block_reduce_est(EstItem v, EstItem *sh) {
     }
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     if (lane == 0) sh[wv] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    return v;
+}
+// ... and, behind a barrier, thread 0's combination of the waves' results (v: what wave_reduce_est returned to it)
+SLAM_DEV EstItem combine_waves_est(EstItem v, const EstItem *sh) {
 #pragma unroll
-        for (int k = 1; k < kBlock / kWave; k++) est_combine(v, sh[k]);
-    }
+    for (int k = 1; k < kBlock / kWave; k++) est_combine(v, sh[k]);
+    return v;
+}
+SLAM_DEV EstItem block_reduce_est(EstItem v, EstItem *sh) {
+    v = wave_reduce_est(v, sh);
+    __syncthreads();
+    if (threadIdx.x == 0) v = combine_waves_est(v, sh);
     return v;
 }
 
@@ -1319,6 +1328,8 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         return;
     }
     if constexpr (!BIG) {
+        // (parking these in front of the scan's last barrier, to save this one, was measured in round 4: config 2 +-0, config 3
+        // 14.86 against 14.35 us per step -- the scan would then wait for the packet's loads as well)
         if (!front && threadIdx.x < kSmallWords) pk[threadIdx.x] = pkv;
         if (!front && threadIdx.x < kStepWords) sh_ctl[threadIdx.x] = ctlv;
         __syncthreads();
@@ -2014,16 +2025,19 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
     }
 
     SLAM_STAMP(8);  // pose / genealogy stores landed
-    if (U.plan_inline) {
-        ei_prev = block_reduce_est(ei_prev, sh_est);
-        if (threadIdx.x == 0) {
+    // the block's term of the previous step's estimate: the waves' parts now, thread 0's combination behind the barrier the
+    // weight prefix needs anyway (linear weights: one barrier at the end of the launch instead of two)
+    if (U.plan_inline) ei_prev = wave_reduce_est(ei_prev, sh_est);
+    auto est_out = [&]() {
+        if (U.plan_inline && threadIdx.x == 0) {
+            const EstItem e = combine_waves_est(ei_prev, sh_est);
             double *p = ws.est_part[ws.wpar ^ 1] + (size_t) bt * 4;
-            p[0] = ei_prev.sx;
-            p[1] = ei_prev.sy;
-            p[2] = (double) ei_prev.th;
-            p[3] = (double) ei_prev.w;
+            p[0] = e.sx;
+            p[1] = e.sy;
+            p[2] = (double) e.th;
+            p[3] = (double) e.w;
         }
-    }
+    };
     // log-weight contexts: the prefix / totals below are those of exp(l - M_b), M_b = the block's largest log-weight,
     // which travels as a third row of the totals (scan_block_totals rescales by exp(M_b - M))
     if (logw) {
@@ -2050,6 +2064,7 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
         sh_w2[wv] = s2;
     }
     __syncthreads();
+    est_out();
     float base = 0.0f;
 #pragma unroll
     for (int k = 0; k < kBlock / kWave; k++)
