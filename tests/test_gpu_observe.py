@@ -298,13 +298,14 @@ def test_c_download_straight_after_device_steps(sg, monkeypatch, plain):
     assert np.isfinite(a["xf"]).all()
 
 
-@pytest.mark.parametrize("method,N", [("FASTSLAM2", 1024), ("FASTSLAM1", 1000)])
-def test_run_observe_equals_step_by_step(sg, method, N):
+@pytest.mark.parametrize("method,N,mapname", [("FASTSLAM2", 1024, "example_webmap"), ("FASTSLAM1", 1000, "example_webmap"),
+                                              ("FASTSLAM2", 512, "example_loop902")])   # (117 landmarks: the front-end kernel on its own stream)
+def test_run_observe_equals_step_by_step(sg, method, N, mapname):
     """slamgpu_run_observe (K iterations of the wrapper's loop in one C call, observation made on the device) against K calls of
     slamgpu_step_observe: the histories of all iterations (estimate, Neff, decision, status) and the final state bit for bit, the
     call split in uneven pieces; bad arguments are refused."""
     from slam_amd import host
-    args = sim_args("example_webmap", method, 100, 7)
+    args = sim_args(mapname, method, 100, 7)
     tape = host.make_tape(args, max_obs=160)
     sim = host.HostSim(args)
     lm, _ = sim.map()
@@ -315,8 +316,10 @@ def test_run_observe_equals_step_by_step(sg, method, N):
     xt = [np.asarray(st["true"], f32) for st in steps]
     out = []
     for whole in (False, True):
+        conf = tape["conf"]
         s = sg.SlamGpu(N, tape["nlm"], method=2 if method == "FASTSLAM2" else 1, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=5,
-                       math_mode=1, device_observe=True)
+                       math_mode=1, device_observe=True, use_heading=bool(conf.SWITCH_HEADING_KNOWN), wheel_base=float(conf.WHEELBASE),
+                       sigma_phi=float(conf.sigmaT))
         s.set_map(lm)
         if whole:
             for a, b in ((0, 1), (1, 64), (64, 64), (64, len(steps))):   # (an empty call in the middle)
@@ -333,8 +336,11 @@ def test_run_observe_equals_step_by_step(sg, method, N):
     (ha, sa, da), (hb, sb, db) = out
     assert len(ha[0]) == len(steps)
     for x, y in zip(ha, hb):
-        assert np.array_equal(np.asarray(x), np.asarray(y))
-    assert np.array_equal(sa, sb) and not sa.any()
+        assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)
+    assert np.array_equal(sa, sb)
+    # (example_loop902: up to ~40 re-observed landmarks per step in LINEAR weights -- the reference's own arithmetic -- collapse the
+    # weights of a 512-particle set now and then: a degenerate step is reported as such by both paths alike)
+    assert not sa.any() or mapname == "example_loop902"
     assert da["nf"] == db["nf"] and da["nf"] > 10
     for key in ("xv", "Pv", "w", "xf", "Pf"):
         assert np.array_equal(da[key].view(np.uint32), db[key].view(np.uint32)), key
