@@ -209,6 +209,7 @@ static int run_batched(Simulator &sim, slamgpu_ctx *ctx, bool observe_dev, long 
     long iter = 0, nobs = 0;
     double sq_err = 0, est[3] = {0, 0, 0};
     int rc = 0;
+    size_t run_first = 0;  // -observe device: first row of `rows` that belongs to the chunk not yet handed over
     if (observe_dev) rc = slamgpu_set_map(ctx, sim.map.lm.data(), sim.map.nlm);
     if (!rc && gpubusy) rc = slamgpu_profile(ctx, 1);
     auto fetch = [&]() -> int {
@@ -221,10 +222,30 @@ static int run_batched(Simulator &sim, slamgpu_ctx *ctx, bool observe_dev, long 
             if (log) fprintf(log, "%ld,%.6f,%.6f,%.6f,%.6f,%.6f,%.6f,%.1f\n", o.iter, o.xt[0], o.xt[1], o.xt[2], est[0], est[1], est[2], o.us);
         }
         rows.clear();
+        run_first = 0;
         return 0;
     };
     const auto t_begin = std::chrono::steady_clock::now();
     auto t_obs = t_begin;
+    constexpr int kRunChunk = 256;
+    std::vector<int32_t> run_counts;
+    std::vector<float> run_xt;
+    size_t run_rows = 0;
+    auto flush_run = [&]() -> int {
+        if (run_counts.empty()) return 0;
+        const int r = slamgpu_run_observe(ctx, (int32_t) run_counts.size(), run_counts.data(), controls.data(), sim.Qe, sim.dt, run_xt.data(), c.MAX_RANGE,
+                                          sim.Re, c.SWITCH_SENSOR_NOISE ? 2 : 0);
+        const auto now = std::chrono::steady_clock::now();
+        const double us = std::chrono::duration<double, std::micro>(now - t_obs).count() / (double) run_counts.size();
+        for (size_t t = run_first; t < rows.size(); t++) rows[t].us = us;  // (per iteration: the chunk's enqueue time, evenly)
+        t_obs = now;
+        run_first = rows.size();
+        run_counts.clear();
+        run_xt.clear();
+        controls.clear();
+        run_rows = 0;
+        return r;
+    };
     while ((maxsteps < 0 || iter < maxsteps) && !rc) {
         const int r = sim.control();
         if (r < 0) break;
@@ -234,8 +255,18 @@ static int run_batched(Simulator &sim, slamgpu_ctx *ctx, bool observe_dev, long 
         iter++;
         if (r != 1) continue;
         if (observe_dev) {
-            rc = slamgpu_step_observe(ctx, controls.data(), (int) (controls.size() / 3), sim.Qe, sim.dt, sim.xTrue, c.MAX_RANGE, sim.Re,
-                                      c.SWITCH_SENSOR_NOISE ? 2 : 0, nullptr, nullptr, nullptr, nullptr, 1);
+            // the true poses and controls do not depend on the filter: kRunChunk iterations are collected and handed over in ONE
+            // call (slamgpu_run_observe: the same launches as one slamgpu_step_observe per iteration, bit-identical results)
+            run_counts.push_back((int32_t) (controls.size() / 3 - run_rows));
+            run_rows = controls.size() / 3;
+            for (int q = 0; q < 3; q++) run_xt.push_back(sim.xTrue[q]);
+            nobs++;
+            rows.push_back(ObsRow{iter, {sim.xTrue[0], sim.xTrue[1], sim.xTrue[2]}, 0.0});
+            if ((int) run_counts.size() == kRunChunk || rows.size() == 4096) {
+                rc = flush_run();
+                if (!rc && rows.size() == 4096) rc = fetch();
+            }
+            continue;
         } else {
             sim.observe();
             const int nf_now = landmark_count(ctx, rc);
@@ -251,6 +282,7 @@ static int run_batched(Simulator &sim, slamgpu_ctx *ctx, bool observe_dev, long 
         t_obs = now;
         if (!rc && rows.size() == 4096) rc = fetch();
     }
+    if (!rc && observe_dev) rc = flush_run();
     if (!rc) rc = fetch();  // (synchronises: everything enqueued has finished)
     const double wall_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
     if (rc) fprintf(stderr, "slamgpu: %s\n", slamgpu_last_error());
