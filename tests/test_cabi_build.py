@@ -54,3 +54,15 @@ def test_integration_md_shows_the_compiled_bindings():
     adapter = open(os.path.join(HERE, "cabi", "fastslam2gpu_adapter.h")).read()
     assert shim[shim.index("class AcceleratorHandler {"):shim.rindex("#endif")].rstrip() in doc
     assert adapter[adapter.index("template <class Particle, class VectorXf, class MatrixXf>"):adapter.index("#endif")].rstrip() in doc
+
+
+def test_headers_are_plain_c(tmp_path):
+    """The boundary is a C ABI: include/slamgpu.h (stable part and experimental block) and include/slamhost.h compile as C99 with
+    -pedantic, and a C program links against the library's version symbol."""
+    src = tmp_path / "abi.c"
+    src.write_text("#define SLAMGPU_EXPERIMENTAL 1\n#include <slamgpu.h>\n#include <slamhost.h>\n"
+                   "int main(void) { return slamgpu_abi_version() == SLAMGPU_ABI_VERSION ? 0 : 1; }\n")
+    exe = tmp_path / "abi"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L" + os.path.join(ROOT, "slam_amd"), "-lslamgpu", "-Wl,-rpath," + os.path.join(ROOT, "slam_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    assert subprocess.call([str(exe)]) == 0
