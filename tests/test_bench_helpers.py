@@ -20,6 +20,31 @@ def test_window_does_not_depend_on_steps_and_warmup():
         bench.pick_start(100, 50, 200, None)
 
 
+def test_default_window_looks_like_the_run():
+    # (round 5) the default window is the first one after step 1 000 whose mean m / n / resample rate are the run's to 10 %:
+    # steps 1005..1025 re-observe 1.65 landmarks per step, the run 3.53
+    import numpy as np
+    from slam_amd import host
+    N = 1000
+    tape = host.make_tape(["-m", os.path.join(ROOT, "data", "example_webmap.mat"), "-method", "FASTSLAM1", "-NPARTICLES", N, "-NEFFECTIVE",
+                           int(0.75 * N), "-SWITCH_SEED_RANDOM", 7])
+    obs = tape["steps"]
+    mbar = np.mean([st["zf"].shape[0] for st in obs])
+    for warmup, steps in ((5, 20), (20, 200), (100, 2000)):
+        s, info = bench.pick_window(obs, warmup, steps, None)
+        m = np.mean([st["zf"].shape[0] for st in obs[s + warmup:s + warmup + steps]])
+        assert abs(m / mbar - 1) <= 0.1 and abs(info["mean_m"] - m) < 1e-12, (warmup, steps, s, m)
+        assert s == bench.pick_window(obs, warmup, steps, None)[0]  # deterministic
+        json.dumps(info)
+    assert bench.pick_window(obs, 5, 20, None)[0] >= 1000
+    # a resample history that never fires in the first candidates pushes the window on; an explicit start is taken as given
+    res = np.arange(len(obs) - 100) % 5 < 3   # rate 0.6 ...
+    res[1000 - 100:1100 - 100] = False          # ... but for steps 1000..1100
+    s_r, info_r = bench.pick_window(obs, 5, 20, None, res, 100)
+    assert s_r + 5 >= 1090 and abs(info_r["resample_rate"] / info_r["run_resample_rate"] - 1) <= 0.1
+    assert bench.pick_window(obs, 5, 20, 1000)[0] == 1000 and bench.pick_window(obs, 5, 20, 1000)[1]["mean_m"] < 2.0
+
+
 def test_algorithmic_and_design_bytes():
     # B_t = 80 + 40 m + 20 n + r (2 (40 + 20 Nf) + 12)
     assert bench.step_bytes(3, 1, 30, False) == 80 + 120 + 20
@@ -38,6 +63,8 @@ def test_traffic_file_of_the_matching_build_is_quoted():
     assert exact and tj["config"] == 3 and "_final_c3.json" in note and 10.0 < tj["bench_avg_launch_us"] < 20.0, note
     tj5, exact5, _ = bench.load_traffic(5, "fast", 100000, 1650.0)
     assert exact5 and tj5["config"] == 5 and tj5["kernels"]["fs2_update"]["hbm_bytes_per_launch"] > 1e9
+    tj4, exact4, note4 = bench.load_traffic(4, "fast", 8 * bench.CONFIGS[4]["particles"], 95.0)  # (what --config 4 --gpus 1 asks for)
+    assert exact4 and tj4["config"] == 4, note4
     _, exact_other, note_other = bench.load_traffic(3, "fast", 12345, 16.1)
     assert not exact_other and "NOT this workload" in note_other
 
