@@ -49,7 +49,9 @@ typedef enum {
     SLAMGPU_ERR_ALLOC = -5,
     SLAMGPU_ERR_BARRIER = -6    /* distributed contexts, push / fold collective: a peer did not arrive at a flag barrier in
                                    time; every step since then ran unsynchronised and its results are void.  Sticky: destroy
-                                   the contexts (or switch to SLAMGPU_DIST_GATHER and start the run again) */
+                                   the contexts (or switch to SLAMGPU_DIST_GATHER and start the run again).  Also: the
+                                   persistent step loop of slamgpu_run_observe abandoned a launch (a workgroup waited too long
+                                   at the in-launch barrier); sticky, the steps of that launch are void */
 } slamgpu_status;
 
 enum { SLAMGPU_FASTSLAM1 = 1, SLAMGPU_FASTSLAM2 = 2 };
@@ -242,9 +244,17 @@ int slamgpu_step_observe(slamgpu_ctx *ctx, const float *controls, int32_t n_cont
  * observations made on the device: iteration k applies n_controls[k] control steps -- rows (V, G, phi_true) of `controls`, the
  * iterations' rows one after the other -- and observes from the true pose xtrue[3 k .. 3 k + 2]; the pose estimate of every
  * iteration is recorded (slamgpu_estimate_fetch / slamgpu_history_fetch: their capacity, 4 096 iterations, bounds K between two
- * fetches).  noise: 0 none or 2 Philox on the device (a caller's tape is per iteration: use slamgpu_step_observe).  Enqueues the
- * K update launches and returns without waiting for the GPU; the results are bit-identical to K calls of slamgpu_step_observe
- * with record_estimate = 1.  On an error the iterations before the failing one stay applied; slamgpu_last_error names it. */
+ * fetches).  noise: 0 none or 2 Philox on the device (a caller's tape is per iteration: use slamgpu_step_observe).  Returns
+ * without waiting for the GPU; the results are bit-identical to K calls of slamgpu_step_observe with record_estimate = 1.
+ * Contexts of at most 39 landmarks and at most 2 048 particles (K >= 2, at most 16 controls per iteration) run the K
+ * iterations as ONE launch: a persistent step loop whose workgroups sit on one XCD and meet at a counter in its L2 between two
+ * iterations instead of at a kernel boundary (round 5; every wait is bounded: a workgroup that waits too long abandons the
+ * launch, and whatever synchronises next -- slamgpu_sync, _history_fetch, _estimate, _stats, the next slamgpu_run_observe --
+ * returns SLAMGPU_ERR_BARRIER); everything else enqueues K update launches.  SLAMGPU_NO_PERSIST=1 in the environment selects
+ * the K launches everywhere (diagnostic).
+ * Arguments are validated before anything is enqueued: a call that is refused (bad pointers or counts, no map, a history that
+ * K more estimates would overflow: SLAMGPU_ERR_CAPACITY) applies NO iteration.  Should an iteration fail later all the same,
+ * the iterations before it stay applied and slamgpu_last_error names it. */
 int slamgpu_run_observe(slamgpu_ctx *ctx, int32_t K, const int32_t *n_controls, const float *controls, const float Q[4], float dt,
                         const float *xtrue, float max_range, const float R[4], int32_t noise);
 /* The observation packet of the last slamgpu_step_observe, copied back for logging / tests (any pointer may be NULL;
@@ -282,6 +292,10 @@ int slamgpu_num_landmarks(slamgpu_ctx *ctx);
  * No counterpart in the reference (its resample copies whole particles, core.cpp:735-749).  Synchronises after
  * slamgpu_step_observe steps. */
 int slamgpu_genealogy_rows(slamgpu_ctx *ctx, int32_t *in_use, int32_t *capacity);
+/* How slamgpu_run_observe has run on this context so far: launches of the persistent step loop and the iterations they carried
+ * (0 / 0: every iteration was a launch of its own); cross_xcd (may be NULL; synchronises): 1 if the last such launch found its
+ * workgroups on more than one XCD and took the memory model's agent-scope release / acquire between iterations. */
+int slamgpu_persist_info(slamgpu_ctx *ctx, int64_t *launches, int64_t *iterations, int32_t *cross_xcd);
 /* Particle-major host copies (any pointer may be NULL): xv[3N], Pv[9N] row-major, w[N],
  * xf[2*Nf*N], Pf[4*Nf*N] row-major — the layout of vector<Particle> flattened. Synchronises. */
 int slamgpu_download(slamgpu_ctx *ctx, float *xv, float *Pv9, float *w, float *xf, float *Pf4);

@@ -244,6 +244,43 @@ struct PredictArgs {
     PredictComposite comp;
 };
 
+// Persistent small-N step loop (slamgpu_run_observe on compact single contexts of at most kPersistMaxBlocks tiles; reference:
+// the wrapper's loop, fastslam1wrapper.cpp:51-113 / fastslam2wrapper.cpp:51-117, one iteration = predicts + observe + update +
+// estimate).  At 1 000 particles a step is one dependent chain on four workgroups, and a third of it is the kernel boundary
+// (3.07 us per launch against 0.73-1.2 us for an exchange between four workgroups of one XCD: profiles/xcd_exchange_r04.txt).
+// ONE launch runs K iterations: grid of 8 x (tiles + 1) workgroups of which those with blockIdx % 8 == 0 stay (the dispatcher
+// deals workgroups round-robin to the 8 XCDs: the ones that stay share an L2; verified at run time through HW_REG_XCC_ID, a
+// placement on several XCDs takes the agent-scope release / acquire of the memory model instead), the tiles' workgroups + one
+// helper (Ctrl words, estimate reductions); between two iterations they meet at a counter in L2.  Every spin is bounded; a
+// workgroup that waits too long sets the abort word, everybody leaves, and the call returns SLAMGPU_ERR_BARRIER.
+// What an iteration needs from the host rides in a queue in device memory, written before the launch and never during it.
+constexpr int kPersistMaxBlocks = 8;
+constexpr int kPersistStride = 8;       // workgroups that stay: blockIdx % kPersistStride == 0
+struct PersistStep {
+    PredictArgs PA;                     // the iteration's queued predicts (composed, compose_predicts)
+    float fx, fy, fphi;                 // true pose: FrontArgs::x / y / phi
+    uint32_t fstep;                     // FrontArgs::step
+    uint32_t rng_step, rng_prev_step;   // RngArgs::step / prev_step
+    int32_t wpar;                       // WeightScratch::wpar
+    int32_t plan_inline;                // UpdateArgs::plan_inline (0 only in a first iteration whose predecessor's plan already ran)
+    int32_t finalize, finalize_par;     // UpdateArgs::finalize / finalize_par
+    double *finalize_hist;              // UpdateArgs::finalize_hist
+};
+constexpr int kPersistStepWords = (int) (sizeof(PersistStep) / 4);
+// words of PersistArgs::sync, on lines of their own: [0, kPersistSyncWords) zeroed before every launch; the abort word behind
+// them is sticky (a launch that finds it set leaves at once)
+enum { kPersistSyncCounter = 0, kPersistSyncXcc = 64, kPersistSyncDone = 96, kPersistSyncCross = 97, kPersistSyncWords = 128, kPersistSyncAbort = 128,
+       kPersistSyncAlloc = 192 };
+struct PersistArgs {
+    const PersistStep *queue;           // [K]
+    int32_t K;
+    uint32_t max_spins;                 // bound of one wait at the counter
+    uint32_t *sync;                     // [kPersistSyncAlloc]
+    uint32_t *host_status;              // pinned host word: set to 1 by a workgroup that abandons the loop (the host reads it behind
+                                        // any synchronisation, without a copy of its own)
+    FrontState *state_final;            // where the front end's state is left for the next launch
+};
+
 struct UpdateArgs {
     int32_t method, m, n, nf;
     float R[4];
@@ -283,6 +320,7 @@ struct UpdateArgs {
     int32_t finalize;        // 1: the extra block reduces the previous update's pose-estimate partials
     double *finalize_hist;   // history slot of that estimate (kHistStride doubles) or null
     unsigned long long *stamps;  // diagnostic build (-DSLAM_STAMPS, libslamgpu_stamps.so): [compute blocks][kStampSlots] wall-clock stamps
+    PersistArgs persist;         // update_persist only
 };
 constexpr int kStampSlots = 16;
 constexpr int kAssocNew = -1, kAssocDiscard = -2;
@@ -460,6 +498,8 @@ struct KernelTable {
     // update + in-block weight prefix / totals  (+ helper blocks: genealogy copy, Ctrl words, estimate reduction)
     void (*update)(hipStream_t, const Buffers &, const PredictArgs &, const UpdateArgs &, const RngArgs &,
                    const WeightScratch &);
+    // K steps of a compact single context in ONE launch (PersistArgs): U = what every iteration shares (front end on: the map, R)
+    void (*update_persist)(hipStream_t, const Buffers &, const PredictArgs &, const UpdateArgs &, const RngArgs &, const WeightScratch &);
     // the resampling stage as a launch of its own (on demand): Neff + decision; normalise, or the ancestors of a
     // stratified resample into keep[] (nothing is moved); estimate partials
     void (*resample)(hipStream_t, const Buffers &, const WeightScratch &, const RngArgs &, const ResampleArgs &,

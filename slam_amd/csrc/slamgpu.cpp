@@ -232,6 +232,22 @@ struct slamgpu_ctx {
     char *peek_dev = nullptr;        // staging of slamgpu_peek, grown on demand
     size_t peek_bytes = 0;
     unsigned long long *stamps_dev = nullptr;  // diagnostic (SLAMGPU_STAMPS=1 + libslamgpu_stamps.so): UpdateArgs::stamps
+    // persistent small-N step loop (slamgpu_run_observe, kernels.h: PersistArgs)
+    bool persist_ok = true;              // SLAMGPU_NO_PERSIST=1 turns it off (diagnostic / tests: the per-step loop)
+    struct PersistCollect {              // while set, issue_update queues its launch instead of making it
+        std::vector<PersistStep> steps;
+        bool have_first = false;
+        Buffers B{};
+        UpdateArgs U{};
+        RngArgs rng{};
+        WeightScratch ws{};
+    } *collect = nullptr;
+    PersistStep *pq_dev = nullptr, *pq_host = nullptr;  // the queue in device memory and its pinned staging
+    size_t pq_cap = 0;
+    hipEvent_t pq_ev = nullptr;          // the staging buffer's last upload has finished
+    bool pq_ev_used = false;
+    uint32_t *psync_dev = nullptr, *pstatus_host = nullptr;
+    int64_t persist_launches = 0, persist_steps = 0;
     EstStage unplanned;           // the last update: resampling stage not run yet
     EstStage unreduced;           // an update whose partials exist (est_part[par]) but are not reduced yet
 };
@@ -654,6 +670,15 @@ int keep_history_tail(slamgpu_ctx *c, const std::vector<double> &h, int taken) {
     return 0;
 }
 
+// The abort word of the persistent step loop is sticky, like the barrier error of the push collective: whoever synchronises with
+// the device reports it (the kernel stores it into pinned host memory: no copy needed here).
+int persist_check(slamgpu_ctx *c) {
+    if (c->pstatus_host && *(volatile uint32_t *) c->pstatus_host != 0)
+        return fail(SLAMGPU_ERR_BARRIER, "persistent step loop (slamgpu_run_observe): a workgroup waited too long at the in-launch barrier and the launch "
+                                         "was abandoned; the steps since then are void (recreate the context; SLAMGPU_NO_PERSIST=1 selects the per-step loop)");
+    return 0;
+}
+
 int check_ctx(slamgpu_ctx *c) {
     if (!c) return fail(SLAMGPU_ERR_INVALID, "null context");
     return 0;
@@ -668,7 +693,7 @@ int read_ctrl(slamgpu_ctx *c, bool need_set = false) {
     if (int rc = flush_stages(c)) return rc;
     HIP_TRY(hipMemcpyAsync(c->ctrl_host, c->B.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return 0;
+    return persist_check(c);
 }
 
 }  // namespace
@@ -710,6 +735,7 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     c->k = cfg->math_mode == SLAMGPU_MATH_FAST ? kernels_fast() : kernels_strict();
     if (const char *e = getenv("SLAMGPU_SCAN_MIN_BLOCKS")) c->scan_min_blocks = atoi(e);  // diagnostic
     c->consolidate = getenv("SLAMGPU_NO_CONSOLIDATE") == nullptr;                          // diagnostic / tests
+    c->persist_ok = getenv("SLAMGPU_NO_PERSIST") == nullptr;                               // diagnostic / tests: slamgpu_run_observe as a loop of launches
     if (const char *e = getenv("SLAMGPU_CONSOLIDATE_ABOVE")) c->consolidate_above = atoi(e);
     if (const char *e = getenv("SLAMGPU_PLAIN_ROWS_TARGET")) c->plain_rows_target = atoi(e);
     const bool want_stamps = getenv("SLAMGPU_STAMPS") != nullptr;                         // diagnostic
@@ -845,6 +871,11 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     for (void *p_ : {(void *) c->box_dev, (void *) c->assoc_ids_dev, (void *) c->cell_start_dev, (void *) c->cell_fill_dev, (void *) c->items_dev,
                      (void *) c->geom_dev})
         if (p_) (void) hipFree(p_);
+    if (c->pq_dev) (void) hipFree(c->pq_dev);
+    if (c->pq_host) (void) hipHostFree(c->pq_host);
+    if (c->pq_ev) (void) hipEventDestroy(c->pq_ev);
+    if (c->psync_dev) (void) hipFree(c->psync_dev);
+    if (c->pstatus_host) (void) hipHostFree(c->pstatus_host);
     if (c->book_dev) (void) hipFree(c->book_dev);
     if (c->refcnt_dev) (void) hipFree(c->refcnt_dev);
     if (c->take_dev) (void) hipFree(c->take_dev);
@@ -1005,7 +1036,31 @@ int issue_update(slamgpu_ctx *c, UpdateArgs &U, int n_new, int n_rows, bool need
     U.finalize = c->unreduced.has ? 1 : 0;  // (sharded: this shard's partials of the previous step, shard_finalize_kernel)
     U.finalize_hist = c->unreduced.hist;
     U.finalize_par = c->unreduced.par;
-    {
+    if (c->collect) {
+        // persistent loop: this iteration rides in the queue of ONE launch (slamgpu_run_observe); everything the host keeps
+        // track of moves on exactly as if the launch had been made
+        PersistStep q{};
+        q.PA = PA;
+        q.fx = U.front.x;
+        q.fy = U.front.y;
+        q.fphi = U.front.phi;
+        q.fstep = U.front.step;
+        q.rng_step = rng.step;
+        q.rng_prev_step = rng.prev_step;
+        q.wpar = c->ws.wpar;
+        q.plan_inline = U.plan_inline;
+        q.finalize = U.finalize;
+        q.finalize_par = U.finalize_par;
+        q.finalize_hist = U.finalize_hist;
+        if (!c->collect->have_first) {
+            c->collect->have_first = true;
+            c->collect->B = c->B;
+            c->collect->U = U;
+            c->collect->rng = rng;
+            c->collect->ws = c->ws;
+        }
+        c->collect->steps.push_back(q);
+    } else {
         Timed t(c, c->cfg.method == SLAMGPU_FASTSLAM2 ? "fs2_update" : "fs1_update");
         c->k->update(c->stream, c->B, PA, U, rng, c->ws);
     }
@@ -1385,16 +1440,110 @@ int slamgpu_step_observe(slamgpu_ctx *c, const float *controls, int32_t n_contro
     return 0;
 }
 
+// K iterations of the wrapper's loop as ONE launch (kernels.h: PersistArgs): the K calls of slamgpu_step_observe are made with
+// the context in collect mode -- every piece of host bookkeeping moves on as usual, the update launches are queued instead of
+// made -- then the queue is uploaded and update_persist runs it.
+static int run_observe_persist(slamgpu_ctx *c, int32_t K, const int32_t *n_controls, const float *controls, const float Q[4], float dt,
+                               const float *xtrue, float max_range, const float R[4], int32_t noise) {
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (!c->psync_dev) {
+        HIP_TRY(hipMalloc((void **) &c->psync_dev, sizeof(uint32_t) * kPersistSyncAlloc));
+        HIP_TRY(hipMemsetAsync(c->psync_dev, 0, sizeof(uint32_t) * kPersistSyncAlloc, c->stream));
+        HIP_TRY(hipHostMalloc((void **) &c->pstatus_host, 2 * sizeof(uint32_t), hipHostMallocDefault));
+        c->pstatus_host[0] = c->pstatus_host[1] = 0;
+        HIP_TRY(hipEventCreateWithFlags(&c->pq_ev, hipEventDisableTiming));
+    }
+    if ((size_t) K > c->pq_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));  // (a launch in flight may still read the old queue)
+        if (c->pq_dev) (void) hipFree(c->pq_dev);
+        if (c->pq_host) (void) hipHostFree(c->pq_host);
+        c->pq_dev = c->pq_host = nullptr;
+        c->pq_cap = 0;
+        const size_t cap = std::max<size_t>((size_t) K, 256);
+        HIP_TRY(hipMalloc((void **) &c->pq_dev, sizeof(PersistStep) * cap));
+        HIP_TRY(hipHostMalloc((void **) &c->pq_host, sizeof(PersistStep) * cap, hipHostMallocDefault));
+        c->pq_cap = cap;
+        c->pq_ev_used = false;
+    }
+    slamgpu_ctx::PersistCollect col;
+    col.steps.reserve((size_t) K);
+    c->collect = &col;
+    int rc = 0;
+    std::string why;
+    size_t row = 0;
+    int32_t k = 0;
+    for (; k < K; k++) {
+        const int32_t nc = n_controls[k];
+        rc = slamgpu_step_observe(c, nc ? controls + 3 * row : nullptr, nc, Q, dt, xtrue + 3 * (size_t) k, max_range, R, noise, nullptr, nullptr, nullptr,
+                                  nullptr, 1);
+        if (rc) {
+            why = slamgpu_last_error();
+            break;
+        }
+        row += (size_t) nc;
+    }
+    c->collect = nullptr;
+    if (!col.steps.empty()) {  // (after a failure: the iterations before the failing one are applied, as the header promises)
+        const size_t n = col.steps.size();
+        if (c->pq_ev_used) HIP_TRY(hipEventSynchronize(c->pq_ev));  // the staging buffer's previous upload has finished
+        memcpy(c->pq_host, col.steps.data(), sizeof(PersistStep) * n);
+        HIP_TRY(hipMemcpyAsync(c->pq_dev, c->pq_host, sizeof(PersistStep) * n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->pq_ev, c->stream));
+        c->pq_ev_used = true;
+        HIP_TRY(hipMemsetAsync(c->psync_dev, 0, sizeof(uint32_t) * kPersistSyncWords, c->stream));
+        UpdateArgs U = col.U;
+        U.persist.queue = c->pq_dev;
+        U.persist.K = (int32_t) n;
+        U.persist.max_spins = 1u << 20;
+        U.persist.sync = c->psync_dev;
+        U.persist.host_status = c->pstatus_host;
+        U.persist.state_final = c->front_dev + c->front_par;  // (the copy the next launch reads)
+        {
+            Timed t(c, "persist_loop");
+            c->k->update_persist(c->stream, col.B, PredictArgs{}, U, col.rng, col.ws);
+        }
+        HIP_TRY(hipGetLastError());
+        c->persist_launches++;
+        c->persist_steps += (int64_t) n;
+    }
+    if (rc) return fail(rc, "slamgpu_run_observe: iteration %d of %d: %s", (int) k, (int) K, why.c_str());
+    return 0;
+}
+
 int slamgpu_run_observe(slamgpu_ctx *c, int32_t K, const int32_t *n_controls, const float *controls, const float Q[4], float dt,
                         const float *xtrue, float max_range, const float R[4], int32_t noise) {
     if (int rc = check_ctx(c)) return rc;
-    if (K < 0 || (K > 0 && (!n_controls || !xtrue))) return fail(SLAMGPU_ERR_INVALID, "slamgpu_run_observe: bad arguments");
+    // everything that can be refused is refused BEFORE the first device call: a failing call applies no iteration at all
+    if (K < 0 || (K > 0 && (!n_controls || !xtrue || !R))) return fail(SLAMGPU_ERR_INVALID, "slamgpu_run_observe: bad arguments");
     if (noise != 0 && noise != 2) return fail(SLAMGPU_ERR_INVALID, "slamgpu_run_observe: noise must be 0 or 2 (a tape is per iteration: slamgpu_step_observe)");
     if (c->cfg.rng_mode == SLAMGPU_RNG_TAPE) return fail(SLAMGPU_ERR_INVALID, "slamgpu_run_observe: TAPE-mode contexts take their draws per iteration (slamgpu_step_observe)");
+    if (K == 0) return 0;
+    if (!c->map_dev) return fail(SLAMGPU_ERR_INVALID, "slamgpu_run_observe: no map: call slamgpu_set_map first");
+    if (!c->B.compact && !(c->cfg.flags & SLAMGPU_FLAG_DEVICE_OBSERVE))
+        return fail(SLAMGPU_ERR_INVALID, "slamgpu_run_observe: create the context with SLAMGPU_FLAG_DEVICE_OBSERVE (its observation packets live in device memory)");
+    if (c->dist || c->cfg.n_particles_global != c->cfg.n_particles) return fail(SLAMGPU_ERR_INVALID, "slamgpu_run_observe: single contexts only");
+    if (c->map_n > c->B.cap_nf) return fail(SLAMGPU_ERR_CAPACITY, "slamgpu_run_observe: map of %d landmarks, capacity %d", c->map_n, c->B.cap_nf);
+    size_t total = 0;
+    int32_t max_nc = 0;
+    for (int32_t k = 0; k < K; k++) {
+        if (n_controls[k] < 0) return fail(SLAMGPU_ERR_INVALID, "slamgpu_run_observe: iteration %d has a negative control count", (int) k);
+        total += (size_t) n_controls[k];
+        max_nc = std::max(max_nc, n_controls[k]);
+    }
+    if (total > 0 && (!controls || !Q)) return fail(SLAMGPU_ERR_INVALID, "slamgpu_run_observe: %zu controls but no control list / Q", total);
+    if (total > 0 && c->cfg.add_predict_noise && c->cfg.rng_mode == SLAMGPU_RNG_TAPE)
+        return fail(SLAMGPU_ERR_INVALID, "slamgpu_run_observe cannot carry TAPE-mode predict noise");
+    if ((int64_t) c->hist_n + K > kHistCap)
+        return fail(SLAMGPU_ERR_CAPACITY, "slamgpu_run_observe: %d iterations would overflow the estimate history (%d of %d entries in use): call "
+                                          "slamgpu_history_fetch first, or hand over fewer iterations", (int) K, c->hist_n, kHistCap);
+    if (int rc = persist_check(c)) return rc;
+    // small compact contexts: ONE launch for all K iterations (kernels.h: PersistArgs)
+    if (c->persist_ok && K >= 2 && c->B.compact && c->ws.nblocks <= kPersistMaxBlocks && c->ws.nblocks <= c->scan_min_blocks && max_nc <= kMaxFusedPredict &&
+        !c->stamps_dev)
+        return run_observe_persist(c, K, n_controls, controls, Q, dt, xtrue, max_range, R, noise);
     size_t row = 0;
     for (int32_t k = 0; k < K; k++) {
         const int32_t nc = n_controls[k];
-        if (nc < 0) return fail(SLAMGPU_ERR_INVALID, "slamgpu_run_observe: iteration %d has a negative control count", (int) k);
         if (int rc = slamgpu_step_observe(c, nc ? controls + 3 * row : nullptr, nc, Q, dt, xtrue + 3 * (size_t) k, max_range, R, noise, nullptr, nullptr,
                                           nullptr, nullptr, 1)) {
             std::string why = slamgpu_last_error();
@@ -2282,6 +2431,7 @@ int slamgpu_history_fetch(slamgpu_ctx *c, double *xyt, float *neff, int32_t *res
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = flush_stages(c)) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (int rc = persist_check(c)) return rc;
     const int n = c->hist_n < std::max(max_count, 0) ? c->hist_n : std::max(max_count, 0);
     std::vector<double> h((size_t) kHistStride * (c->hist_n > 0 ? c->hist_n : 1));
     if (c->hist_n > 0) HIP_TRY(hipMemcpy(h.data(), c->hist_dev, sizeof(double) * kHistStride * (size_t) c->hist_n, hipMemcpyDeviceToHost));
@@ -2687,6 +2837,24 @@ int slamgpu_genealogy_rows(slamgpu_ctx *c, int32_t *in_use, int32_t *capacity) {
     return 0;
 }
 
+int slamgpu_persist_info(slamgpu_ctx *c, int64_t *launches, int64_t *iterations, int32_t *cross_xcd) {
+    if (int rc = check_ctx(c)) return rc;
+    if (launches) *launches = c->persist_launches;
+    if (iterations) *iterations = c->persist_steps;
+    if (cross_xcd) {
+        *cross_xcd = 0;
+        if (c->psync_dev) {
+            HIP_TRY(hipSetDevice(c->cfg.device));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            uint32_t v = 0;
+            HIP_TRY(hipMemcpy(&v, c->psync_dev + kPersistSyncCross, sizeof v, hipMemcpyDeviceToHost));
+            *cross_xcd = (int32_t) v;
+            return persist_check(c);
+        }
+    }
+    return 0;
+}
+
 int slamgpu_sync(slamgpu_ctx *c) {
     if (int rc = check_ctx(c)) return rc;
     HIP_TRY(hipSetDevice(c->cfg.device));
@@ -2695,7 +2863,7 @@ int slamgpu_sync(slamgpu_ctx *c) {
         if (int rc = flush_stages(c)) return rc;
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return 0;
+    return persist_check(c);
 }
 
 int slamgpu_download_range(slamgpu_ctx *c, int32_t first, int32_t count, float *xv, float *Pv9, float *w, float *xf, float *Pf4) {

@@ -298,12 +298,18 @@ def test_c_download_straight_after_device_steps(sg, monkeypatch, plain):
     assert np.isfinite(a["xf"]).all()
 
 
-@pytest.mark.parametrize("method,N,mapname", [("FASTSLAM2", 1024, "example_webmap"), ("FASTSLAM1", 1000, "example_webmap"),
-                                              ("FASTSLAM2", 512, "example_loop902")])   # (117 landmarks: the front-end kernel on its own stream)
-def test_run_observe_equals_step_by_step(sg, method, N, mapname):
+@pytest.mark.parametrize("method,N,mapname,math", [("FASTSLAM2", 1024, "example_webmap", 1), ("FASTSLAM1", 1000, "example_webmap", 1),
+                                                   ("FASTSLAM2", 1000, "example_webmap", 0), ("FASTSLAM1", 1024, "example_webmap", 0),
+                                                   ("FASTSLAM1", 200, "example_webmap", 1), ("FASTSLAM2", 2048, "example_webmap", 1),
+                                                   ("FASTSLAM2", 1000, "example_loop2", 1),   # (heading known: sequential predicts)
+                                                   ("FASTSLAM2", 4096, "example_webmap", 1),  # (16 tiles: beyond the persistent loop)
+                                                   ("FASTSLAM2", 512, "example_loop902", 1)])   # (117 landmarks: the front-end kernel on its own stream)
+def test_run_observe_equals_step_by_step(sg, method, N, mapname, math):
     """slamgpu_run_observe (K iterations of the wrapper's loop in one C call, observation made on the device) against K calls of
     slamgpu_step_observe: the histories of all iterations (estimate, Neff, decision, status) and the final state bit for bit, the
-    call split in uneven pieces; bad arguments are refused."""
+    call split in uneven pieces; bad arguments are refused.  Round 5: small compact contexts run a call's iterations as ONE launch
+    (the persistent step loop: four workgroups + a helper on one XCD meeting at a counter in L2; fastslam1wrapper.cpp:51-113,
+    fastslam2wrapper.cpp:51-117): same histories, same final state, whatever the split."""
     from slam_amd import host
     args = sim_args(mapname, method, 100, 7)
     tape = host.make_tape(args, max_obs=160)
@@ -318,15 +324,24 @@ def test_run_observe_equals_step_by_step(sg, method, N, mapname):
     for whole in (False, True):
         conf = tape["conf"]
         s = sg.SlamGpu(N, tape["nlm"], method=2 if method == "FASTSLAM2" else 1, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=5,
-                       math_mode=1, device_observe=True, use_heading=bool(conf.SWITCH_HEADING_KNOWN), wheel_base=float(conf.WHEELBASE),
+                       math_mode=math, device_observe=True, use_heading=bool(conf.SWITCH_HEADING_KNOWN), wheel_base=float(conf.WHEELBASE),
                        sigma_phi=float(conf.sigmaT))
         s.set_map(lm)
         if whole:
-            for a, b in ((0, 1), (1, 64), (64, 64), (64, len(steps))):   # (an empty call in the middle)
+            for a, b in ((0, 1), (1, 64), (64, 64), (64, 67), (67, len(steps))):   # (an empty call in the middle)
                 s.run_observe(ctl[a:b], tape["Q"], float(tape["dt"]), xt[a:b], max_range, tape["R"], noise=2)
+                if b == 67:
+                    s.peek(True, 0, 7, 5)   # (an observer between two launches of the loop: the outstanding stages run as launches of their own)
+            launches, iters, cross = s.persist_info(cross=True)
+            small = mapname != "example_loop902" and N <= 2048
+            # (a one-iteration call stays a per-step launch; the others are ONE launch each)
+            assert (launches, iters) == ((3, len(steps) - 1) if small else (0, 0)), (launches, iters)
+            assert cross == 0   # (blockIdx % 8 == 0: one XCD; a placement across XCDs is handled, but has never been seen)
         else:
-            for c, x in zip(ctl, xt):
+            for k, (c, x) in enumerate(zip(ctl, xt)):
                 s.step_observe(c, tape["Q"], float(tape["dt"]), x, max_range, tape["R"], noise=2)
+                if k == 66:
+                    s.peek(True, 0, 7, 5)
         hist = s.history_fetch()
         out.append((hist, s.last_history_status.copy(), s.download()))
         if whole:
