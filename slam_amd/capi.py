@@ -666,6 +666,23 @@ class SlamGpu:
     def step_observe(self, controls, Q, dt, xtrue, max_range, R, **kw):
         self.prepare_step_observe(controls, Q, dt, xtrue, max_range, R, **kw)()
 
+    def prepare_run_observe(self, controls_per_step, Q, dt, xtrue_per_step, max_range, R, noise=2):
+        """slamgpu_run_observe marshalled once: returns a closure that makes the C call (a C++ host holds plain arrays already)"""
+        K = len(controls_per_step)
+        counts = np.ascontiguousarray([np.asarray(c, np.float32).reshape(-1, 3).shape[0] for c in controls_per_step], np.int32)
+        rows = [np.asarray(c, np.float32).reshape(-1, 3) for c in controls_per_step if np.asarray(c).size]
+        ctl = _f32(np.concatenate(rows) if rows else np.zeros((0, 3), np.float32))
+        xt = _f32(np.asarray(xtrue_per_step, np.float32).reshape(K, 3))
+        Q = _f32(Q, 4)
+        R = _f32(R, 4)
+        keep = (counts, ctl, xt, Q, R)
+        args = (self.h, K, _ptr(counts), _ptr(ctl), _ptr(Q), C.c_float(dt), _ptr(xt), C.c_float(max_range), _ptr(R), int(noise))
+        fn = self.L.slamgpu_run_observe
+
+        def call(_keep=keep):
+            _chk(fn(*args))
+        return call
+
     def run_observe(self, controls_per_step, Q, dt, xtrue_per_step, max_range, R, noise=2):
         """slamgpu_run_observe: K iterations (k predicts + device-made observation + update + estimate each) in one C call;
         controls_per_step: K arrays of (V, G, phi_true) rows; xtrue_per_step: K poses"""

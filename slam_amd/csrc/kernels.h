@@ -279,6 +279,7 @@ struct PersistArgs {
     uint32_t *host_status;              // pinned host word: set to 1 by a workgroup that abandons the loop (the host reads it behind
                                         // any synchronisation, without a copy of its own)
     FrontState *state_final;            // where the front end's state is left for the next launch
+    int32_t *packets;                   // [2][kSmallWords]: the observation packets the helper workgroup makes, an iteration ahead
 };
 
 struct UpdateArgs {

@@ -15,9 +15,9 @@ using namespace slamgpu;
 #ifdef SLAM_STAMPS
 #define SLAM_STAMP(k)                                                                                      \
     do {                                                                                                   \
-        if (U.stamps && threadIdx.x == 0 && (int) blockIdx.x < ws.nblocks) {                               \
+        if (U.stamps && threadIdx.x == 0 && bid < ws.nblocks) {                                            \
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                    \
-            U.stamps[(size_t) blockIdx.x * kStampSlots + (k)] = wall_clock64();                            \
+            U.stamps[(size_t) bid * kStampSlots + (k)] = wall_clock64();                                   \
         }                                                                                                  \
     } while (0)
 #else
@@ -580,6 +580,37 @@ SLAM_DEV void scan_block_totals(const float *__restrict__ tot, int nb, int nbl, 
     scan_finish(L, tot, nb, nbl, logw, off, sh_a, sh_q, W, Q, M);
 }
 
+// scan_finish for a table of at most 64 totals (one per lane of ONE wave: at most 16 384 particles), linear weights, by every wave
+// for itself: no barrier.  In scan_finish the first wave holds all the totals and the other waves hold zeros, so W is the first
+// wave's sum plus three zeros and the exclusive prefix is that wave's; here every wave redoes exactly those operations on those
+// values (identical bits) and all of them store the same prefix into `off` (LDS: a wave reads back what it wrote itself).
+SLAM_DEV ScanLoads scan_issue_small(const float *__restrict__ tot, int nb) {  // (lane l of EVERY wave: total l)
+    const int lane = threadIdx.x & (kWave - 1);
+    ScanLoads L{0.0f, 0.0f, 0.0f, 0.0f, -INFINITY, -INFINITY};
+    if (lane < nb) {
+        L.tv0 = tot[lane];
+        L.qv0 = tot[nb + lane];
+    }
+    return L;
+}
+SLAM_DEV void scan_small(const ScanLoads L, int nb, double *off, double &W, double &Q) {
+    const int lane = threadIdx.x & (kWave - 1);
+    double a = 0.0, q = 0.0;
+    if (lane < nb) {
+        const double tk = (double) L.tv0 * 1.0;
+        a += tk;
+        q += (double) L.qv0 * (tk * tk);
+    }
+    const double sa = wave_scan_d(a);
+    const double sq = wave_sum_d(q);
+    const double s0 = wave_last_d(sa);
+    W = ((s0 + 0.0) + 0.0) + 0.0;
+    Q = ((sq + 0.0) + 0.0) + 0.0;
+    if (lane < nb) off[lane] = (0.0 + sa) - a;
+    if (lane == 0) off[nb] = W;
+    __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave execute in order)
+}
+
 // Neff = W^2 / Q, the same expression in every kernel, block and shard (the decision must be identical everywhere): one
 // v_rcp_f64 + a Newton step instead of the ~40-instruction IEEE double division on the step's critical path
 SLAM_DEV float neff_of(double W, double Q) {
@@ -1079,10 +1110,13 @@ __host__ __device__ inline int staging_slots(int method, bool big, int m) {
 // another one wrote), the helper's role from workgroup nb, tile = workgroup.  Same operations on the same values: bit-identical
 // to K launches (tests/test_gpu_observe.py).
 struct StepCarry {
-    int cur;          // live pose / genealogy buffer
-    bool pend_word;   // first iteration only: Ctrl.pend as the launch found it
-    FrontLm lm;       // front end's state (first wave: lane t = landmark t of the map)
-    FrontHdr hd;
+    int cur;                  // live pose / genealogy buffer
+    bool pend_word;           // first iteration only: Ctrl.pend as the launch found it
+    const int32_t *pk_src;    // the iteration's observation packet (SmallObs words), made by the helper workgroup
+    // drawn while the workgroups were meeting (persist_predraw): this particle's resampling stratum, its FastSLAM 2 normals, the
+    // (V, G) normals of its FastSLAM 1 predicts -- counters only, nothing another workgroup wrote
+    float strat, hg0, hg1, hg2;
+    float pg0[8], pg1[8];
 };
 
 template <int METHOD, int MODE, bool BIG>
@@ -1130,13 +1164,22 @@ SLAM_DEV void persist_step(const float *__restrict__ h_tot, Ctrl *h_ctrl, const 
 
 // ---------------------------------------------------------------------------------------------------
 // The persistent small-N step loop (kernels.h: PersistArgs).  Same leading arguments and argument layout as update_kernel (the
-// step's code reads the map out of the kernel-argument segment at update_kernel's offsets).
+// front end reads the map out of the kernel-argument segment at update_kernel's offsets).
+//
+// One iteration, tile workgroups:   [packet + block totals of the previous iteration arrive from L2] -> plan (scan, Neff,
+//   decision, ancestor) -> pose / records -> predicts -> landmark pass -> stores -> weight prefix + totals -> ARRIVE at the
+//   counter -> (while the others arrive) the next iteration's queue entry into LDS and everything of it that needs nobody
+//   else's data: the resampling stratum and the particle's normals (Philox + Box-Muller: ~1 us of arithmetic) -> PASS.
+// helper workgroup:  the decision again (for the Ctrl words), the estimate reduction of two iterations ago, and the observation
+//   packet of the NEXT iteration (get_observations + dataAssociationKnown + the genealogy book: the front end's state lives in
+//   its first wave's registers), stored for the tiles to pick up behind the barrier -> ARRIVE -> PASS.
 // ---------------------------------------------------------------------------------------------------
-// All workgroups of the loop meet: stores drained, one arrival each at the counter, a bounded poll, then this CU's vector cache
-// is invalidated (the other workgroups' stores are in the XCD's L2; a workgroup on another XCD -- never seen, checked at the
-// start of the launch -- also writes its L2 back first: the release of the memory model).  Returns false when the launch is
-// being abandoned (somebody waited longer than `max_spins` polls: the abort word is set and everybody leaves).
-SLAM_DEV bool persist_barrier(uint32_t *sync, uint32_t target, uint32_t max_spins, bool cross_xcd, int *sh_ok) {
+// All workgroups of the loop meet, in two halves.  arrive: stores drained, one arrival each at the counter.  pass: a bounded
+// poll, then this CU's vector cache is invalidated (the other workgroups' stores are in the XCD's L2; a workgroup on another
+// XCD -- never seen, checked at the start of the launch -- also writes its L2 back before it arrives: the release of the
+// memory model).  pass returns false when the launch is being abandoned (somebody waited longer than `max_spins` polls: the
+// abort word is set and everybody leaves).
+SLAM_DEV void persist_arrive(uint32_t *sync, bool cross_xcd) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have reached the L2
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1145,6 +1188,10 @@ SLAM_DEV bool persist_barrier(uint32_t *sync, uint32_t target, uint32_t max_spin
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __hip_atomic_fetch_add(sync + kPersistSyncCounter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+SLAM_DEV bool persist_pass(uint32_t *sync, uint32_t target, uint32_t max_spins, int *sh_ok) {
+    if (threadIdx.x == 0) {
         int ok = 1;
         uint32_t spins = 0;
         while ((int32_t) (__hip_atomic_load(sync + kPersistSyncCounter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
@@ -1164,12 +1211,71 @@ SLAM_DEV bool persist_barrier(uint32_t *sync, uint32_t target, uint32_t max_spin
     return *sh_ok != 0;
 }
 
+// what an iteration can work out before it has seen anybody else's data (StepCarry): the draws update_step would make at the
+// places named there, from the same counters, with the same functions
+template <int METHOD>
+SLAM_DEV void persist_predraw(const PersistStep *qe, const RngArgs &rng_k, const Buffers &B, int i, StepCarry &carry) {
+    RngArgs rng = rng_k;
+    rng.step = (uint32_t) __builtin_amdgcn_readfirstlane((int) qe->rng_step);
+    rng.prev_step = (uint32_t) __builtin_amdgcn_readfirstlane((int) qe->rng_prev_step);
+    carry.strat = stratum_prev(rng, (int64_t) i);
+    carry.hg0 = carry.hg1 = carry.hg2 = 0.f;
+    if (METHOD == 2 && rng.mode != 0) {
+        U4 r = philox4x32((uint32_t) (rng.first_particle + i), rng.step, 0u, 0u, rng.k0, rng.k1);
+#ifdef SLAM_FAST_MATH
+        box_muller3_fast(r, carry.hg0, carry.hg1, carry.hg2);
+#else
+        box_muller3(r, carry.hg0, carry.hg1, carry.hg2);
+#endif
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) carry.pg0[q] = carry.pg1[q] = 0.f;
+#ifdef SLAM_FAST_MATH
+    const PredictArgs &PA = qe->PA;
+    if (METHOD == 1 && PA.nsteps > 4 && PA.nsteps <= 8 && PA.add_noise && !PA.use_heading && !PA.comp.valid)  // (update_step: early_draws)
+        draw_batch_fs1_fast<8>(carry.pg0, carry.pg1, PA, rng, i, (size_t) B.ncap, reinterpret_cast<const float *>(qe->PA.steps), 0, PA.nsteps);
+#endif
+}
+
+// the observation packet of one iteration, by the helper workgroup (the front end of update_step, same functions in the same
+// roles): SmallObs words into `pk` (LDS), then into `dst`; the front end's state moves on in the first wave's registers
+SLAM_DEV void persist_front(const FrontArgs &F, float f_x, float f_y, FrontLm &lm, FrontHdr &hd, const __attribute__((address_space(4))) float *tape,
+                            int32_t *pk, uint32_t *f_sets, float *f_aux, int32_t *dst) {
+    const int fw = threadIdx.x / kWave, ft = threadIdx.x & (kWave - 1);
+    FrontGeom fg{};
+    if (fw == 0) {
+        fg = front_geometry(F, f_x, f_y);
+    } else if (fw == 1) {
+        front_draw(F, ft, f_aux);
+    } else if (fw == 2) {
+        const float cph = cosf(F.phi), sph = sinf(F.phi);
+        if (ft == 0) {
+            f_aux[2 * kWave] = cph;
+            f_aux[2 * kWave + 1] = sph;
+        }
+    } else {
+        for (int w = ft; w < kSmallWords; w += kWave) pk[w] = 0;
+    }
+    __syncthreads();
+    if (fw == 0) {
+        const FrontObs ob = front_observe(F, fg, f_aux, tape);
+        FrontLm nl;
+        FrontHdr nh;
+        front_book(F, ob, lm, hd, pk, f_sets, true, &nl, &nh);
+        lm = nl;
+        hd = nh;
+    }
+    __syncthreads();
+    if (threadIdx.x < kSmallWords) dst[threadIdx.x] = pk[threadIdx.x];
+}
+
 template <int METHOD>
 __global__ void __launch_bounds__(kBlock) update_persist_kernel(const float *__restrict__ h_tot, Ctrl *h_ctrl,
                                                                  const FrontState *h_front, int h_nb, int h_slot, int h_grid, int h_flags, Buffers B,
                                                                  PredictArgs PA, UpdateArgs U, RngArgs rng, WeightScratch ws) {
     if (blockIdx.x % kPersistStride != 0) return;  // (the workgroups that stay were dealt to ONE XCD)
     const int bid = (int) blockIdx.x / kPersistStride, nb = h_nb;
+    const bool helper = bid == nb;
     const PersistArgs &P = U.persist;
     __shared__ PersistStep qe;
     __shared__ int sh_ok;
@@ -1182,45 +1288,111 @@ __global__ void __launch_bounds__(kBlock) update_persist_kernel(const float *__r
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         __hip_atomic_store(sync + kPersistSyncXcc + bid, (xcc & 15u) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const uint32_t *__restrict__ q0 = reinterpret_cast<const uint32_t *>(P.queue);
-    uint32_t qv = (P.K > 0 && threadIdx.x < kPersistStepWords) ? q0[threadIdx.x] : 0u;  // (the queue is never written during the launch)
+    const uint32_t *__restrict__ q0 = reinterpret_cast<const uint32_t *>(P.queue);  // (the queue is never written during the launch)
+    if (P.K > 0 && threadIdx.x < kPersistStepWords) reinterpret_cast<uint32_t *>(&qe)[threadIdx.x] = q0[threadIdx.x];
+    __syncthreads();
     StepCarry carry;
     carry.cur = h_ctrl->live[h_slot];
     carry.pend_word = h_ctrl->pend[h_slot] != 0;
-    carry.hd = FrontHdr{0, -1, 0, 0};
-    carry.lm = FrontLm{-1, 0};
-    if (threadIdx.x < kWave) {
-        carry.hd = h_front->hdr;
-        carry.lm = h_front->lm[threadIdx.x];
+    carry.pk_src = P.packets;
+    const int i = bid * kBlock + (int) threadIdx.x;  // (tile = workgroup)
+    // helper: the front end's state, the map (kernel arguments, update_kernel's layout) and the first packet
+    FrontLm f_lm{-1, 0};
+    FrontHdr f_hd{0, -1, 0, 0};
+    float f_x = 0.f, f_y = 0.f;
+    constexpr size_t ka0 = (40 + sizeof(Buffers) + alignof(PredictArgs) - 1) / alignof(PredictArgs) * alignof(PredictArgs);
+    constexpr size_t ka1 = (ka0 + sizeof(PredictArgs) + alignof(UpdateArgs) - 1) / alignof(UpdateArgs) * alignof(UpdateArgs);
+    constexpr size_t ka_small = (ka1 + offsetof(UpdateArgs, small)) / 4;
+    const auto *kf = (const __attribute__((address_space(4))) float *) __builtin_amdgcn_kernarg_segment_ptr();
+    __shared__ int32_t h_pk[kSmallWords];
+    __shared__ uint32_t h_sets[4];
+    __shared__ float h_aux[2 * kWave + 2];
+    __shared__ double hs_a[kBlock / kWave], hs_q[kBlock / kWave];
+    __shared__ EstItem hs_est[kBlock / kWave];
+    extern __shared__ __align__(16) unsigned char dyn_lds[];  // (helper: the prefix of the block totals, as in update_step)
+    auto front_args = [&](const PersistStep *q) {
+        FrontArgs F = U.front;
+        F.x = q->fx;
+        F.y = q->fy;
+        F.phi = q->fphi;
+        F.step = (uint32_t) __builtin_amdgcn_readfirstlane((int) q->fstep);
+        return F;
+    };
+    if (helper) {
+        if (threadIdx.x < kWave) {
+            const int t = min((int) threadIdx.x, kSmallObs - 1);
+            f_x = kf[ka_small + offsetof(SmallObs, zn) / 4 + t];
+            f_y = kf[ka_small + offsetof(SmallObs, zn) / 4 + kSmallObs + t];
+            f_hd = h_front->hdr;
+            f_lm = h_front->lm[threadIdx.x];
+        }
+        if (P.K > 0) persist_front(front_args(&qe), f_x, f_y, f_lm, f_hd, kf + ka_small + offsetof(SmallObs, zf) / 4, h_pk, h_sets, h_aux, P.packets);
     }
-    bool alive = persist_barrier(sync, members, P.max_spins, true, &sh_ok);
+    persist_arrive(sync, true);
+    if (!helper && P.K > 0) persist_predraw<METHOD>(&qe, rng, B, i, carry);
+    bool alive = persist_pass(sync, members, P.max_spins, &sh_ok);
     bool cross = false;
     {
         const uint32_t mine = __hip_atomic_load(sync + kPersistSyncXcc + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int b = 0; b <= nb; b++) cross |= __hip_atomic_load(sync + kPersistSyncXcc + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mine;
     }
+    const bool logw = (h_flags & 4) != 0;
     int it = 0;
     for (; alive && it < P.K; it++) {
-        if (threadIdx.x < kPersistStepWords) reinterpret_cast<uint32_t *>(&qe)[threadIdx.x] = qv;
-        __syncthreads();
-        // the next iteration's entry: requested now, parked in LDS behind the barrier
-        if (it + 1 < P.K && threadIdx.x < kPersistStepWords) qv = q0[(size_t) (it + 1) * kPersistStepWords + threadIdx.x];
-        persist_step<METHOD>(h_tot, h_ctrl, h_front, h_nb, h_slot, h_grid, h_flags, B, U, rng, ws, &qe, carry);
+        SLAM_STAMP(12);  // (diagnostic build) this iteration begins: the previous barrier has been passed
+        const bool more = it + 1 < P.K;
+        // the next iteration's entry: requested now, parked in LDS once everybody is done with this one
+        uint32_t qv = 0;
+        if (more && threadIdx.x < kPersistStepWords) qv = q0[(size_t) (it + 1) * kPersistStepWords + threadIdx.x];
+        if (!helper) {
+            carry.pk_src = P.packets + (size_t) (it & 1) * kSmallWords;
+            persist_step<METHOD>(h_tot, h_ctrl, h_front, h_nb, h_slot, h_grid, h_flags, B, U, rng, ws, &qe, carry);
+        } else {
+            // the decision (for the live buffer the launch leaves), as update_step's helper block works it out
+            const int wpar = __builtin_amdgcn_readfirstlane(qe.wpar);
+            bool pend = (h_flags & 8) && carry.pend_word;
+            if (__builtin_amdgcn_readfirstlane(qe.plan_inline)) {
+                const float *__restrict__ tot = wpar ? ws.blk_w[0] : ws.blk_w[1];
+                const ScanLoads scl = scan_issue(tot, nb, nb, logw);
+                double W, Q, Mx;
+                scan_finish(scl, tot, nb, nb, logw, reinterpret_cast<double *>(dyn_lds), hs_a, hs_q, W, Q, Mx);
+                pend = U.do_resample && (neff_of(W, Q) < (float) U.n_effective);
+            }
+            carry.cur = pend ? carry.cur ^ 1 : carry.cur;
+            if (__builtin_amdgcn_readfirstlane(qe.finalize)) finish_estimate(B, ws, __builtin_amdgcn_readfirstlane(qe.finalize_par), qe.finalize_hist, hs_est);
+            // ... and the NEXT iteration's observation packet, in place before this iteration's barrier
+            if (more) {
+                __syncthreads();  // (everybody is done with this iteration's queue entry)
+                if (threadIdx.x < kPersistStepWords) reinterpret_cast<uint32_t *>(&qe)[threadIdx.x] = qv;
+                __syncthreads();
+                persist_front(front_args(&qe), f_x, f_y, f_lm, f_hd, kf + ka_small + offsetof(SmallObs, zf) / 4, h_pk, h_sets, h_aux,
+                              P.packets + (size_t) ((it + 1) & 1) * kSmallWords);
+            }
+        }
         carry.pend_word = false;
-        alive = persist_barrier(sync, members * (uint32_t) (it + 2), P.max_spins, cross, &sh_ok);
+        SLAM_STAMP(11);  // the step's code is done
+        persist_arrive(sync, cross);
+        // (everybody of this workgroup is done with the queue entry: arrive's barrier)
+        if (more && !helper) {
+            if (threadIdx.x < kPersistStepWords) reinterpret_cast<uint32_t *>(&qe)[threadIdx.x] = qv;
+            __syncthreads();
+            persist_predraw<METHOD>(&qe, rng, B, i, carry);
+        }
+        alive = persist_pass(sync, members * (uint32_t) (it + 2), P.max_spins, &sh_ok);
+        SLAM_STAMP(13);  // barrier passed
     }
     // where the launch leaves things, for the host and the next launch: the Ctrl words (both slots: the set is plain, in
     // `cur`) and the front end's state
-    if (bid == nb && threadIdx.x == 0) {
+    if (helper && threadIdx.x == 0) {
         h_ctrl->live[0] = h_ctrl->live[1] = carry.cur;
         h_ctrl->pend[0] = h_ctrl->pend[1] = 0;
         sync[kPersistSyncDone] = (uint32_t) it;        // iterations completed
         sync[kPersistSyncCross] = cross ? 1u : 0u;     // (diagnostic: the placement was not one XCD)
     }
     if (!alive && threadIdx.x == 0) __hip_atomic_store(P.host_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (bid == 0 && threadIdx.x < kWave) {
-        if ((int) threadIdx.x < U.front.nlm) P.state_final->lm[threadIdx.x] = carry.lm;
-        if (threadIdx.x == 0) P.state_final->hdr = carry.hd;
+    if (helper && threadIdx.x < kWave) {
+        if ((int) threadIdx.x < U.front.nlm) P.state_final->lm[threadIdx.x] = f_lm;
+        if (threadIdx.x == 0) P.state_final->hdr = f_hd;
     }
 }
 

@@ -247,6 +247,7 @@ struct slamgpu_ctx {
     hipEvent_t pq_ev = nullptr;          // the staging buffer's last upload has finished
     bool pq_ev_used = false;
     uint32_t *psync_dev = nullptr, *pstatus_host = nullptr;
+    int32_t *ppk_dev = nullptr;          // [2][kSmallWords] observation packets of the loop's helper workgroup
     int64_t persist_launches = 0, persist_steps = 0;
     EstStage unplanned;           // the last update: resampling stage not run yet
     EstStage unreduced;           // an update whose partials exist (est_part[par]) but are not reduced yet
@@ -875,6 +876,7 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     if (c->pq_host) (void) hipHostFree(c->pq_host);
     if (c->pq_ev) (void) hipEventDestroy(c->pq_ev);
     if (c->psync_dev) (void) hipFree(c->psync_dev);
+    if (c->ppk_dev) (void) hipFree(c->ppk_dev);
     if (c->pstatus_host) (void) hipHostFree(c->pstatus_host);
     if (c->book_dev) (void) hipFree(c->book_dev);
     if (c->refcnt_dev) (void) hipFree(c->refcnt_dev);
@@ -1449,6 +1451,7 @@ static int run_observe_persist(slamgpu_ctx *c, int32_t K, const int32_t *n_contr
     if (!c->psync_dev) {
         HIP_TRY(hipMalloc((void **) &c->psync_dev, sizeof(uint32_t) * kPersistSyncAlloc));
         HIP_TRY(hipMemsetAsync(c->psync_dev, 0, sizeof(uint32_t) * kPersistSyncAlloc, c->stream));
+        HIP_TRY(hipMalloc((void **) &c->ppk_dev, sizeof(int32_t) * 2 * kSmallWords));
         HIP_TRY(hipHostMalloc((void **) &c->pstatus_host, 2 * sizeof(uint32_t), hipHostMallocDefault));
         c->pstatus_host[0] = c->pstatus_host[1] = 0;
         HIP_TRY(hipEventCreateWithFlags(&c->pq_ev, hipEventDisableTiming));
@@ -1498,6 +1501,7 @@ static int run_observe_persist(slamgpu_ctx *c, int32_t K, const int32_t *n_contr
         U.persist.sync = c->psync_dev;
         U.persist.host_status = c->pstatus_host;
         U.persist.state_final = c->front_dev + c->front_par;  // (the copy the next launch reads)
+        U.persist.packets = c->ppk_dev;
         {
             Timed t(c, "persist_loop");
             c->k->update_persist(c->stream, col.B, PredictArgs{}, U, col.rng, col.ws);
@@ -1538,8 +1542,7 @@ int slamgpu_run_observe(slamgpu_ctx *c, int32_t K, const int32_t *n_controls, co
                                           "slamgpu_history_fetch first, or hand over fewer iterations", (int) K, c->hist_n, kHistCap);
     if (int rc = persist_check(c)) return rc;
     // small compact contexts: ONE launch for all K iterations (kernels.h: PersistArgs)
-    if (c->persist_ok && K >= 2 && c->B.compact && c->ws.nblocks <= kPersistMaxBlocks && c->ws.nblocks <= c->scan_min_blocks && max_nc <= kMaxFusedPredict &&
-        !c->stamps_dev)
+    if (c->persist_ok && K >= 2 && c->B.compact && c->ws.nblocks <= kPersistMaxBlocks && c->ws.nblocks <= c->scan_min_blocks && max_nc <= kMaxFusedPredict)
         return run_observe_persist(c, K, n_controls, controls, Q, dt, xtrue, max_range, R, noise);
     size_t row = 0;
     for (int32_t k = 0; k < K; k++) {

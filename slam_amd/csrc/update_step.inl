@@ -36,7 +36,7 @@
     const size_t S = (size_t) B.ncap;
     Ctrl *ctrl = h_ctrl;
     const int nb = h_nb;
-    const bool helper = PERSIST ? bid == nb : ((int) blockIdx.x == h_grid - 1 && (int) blockIdx.x >= nb);
+    const bool helper = !PERSIST && (int) blockIdx.x == h_grid - 1 && (int) blockIdx.x >= nb;  // (persistent loop: persist_helper)
     // XCD-aware tile mapping.  Workgroups go round-robin to the 8 XCDs (workgroup b -> XCD b % 8) and every XCD has an L2
     // of its own, so with tile = workgroup the 256 particles next to a tile always belong to another XCD: after a resample
     // the ancestor's pose, genealogy and records -- written one launch ago by a neighbouring tile -- missed this XCD's L2
@@ -110,20 +110,15 @@
     constexpr size_t ka0 = (40 + sizeof(Buffers) + alignof(PredictArgs) - 1) / alignof(PredictArgs) * alignof(PredictArgs);
     constexpr size_t ka1 = (ka0 + sizeof(PredictArgs) + alignof(UpdateArgs) - 1) / alignof(UpdateArgs) * alignof(UpdateArgs);
     constexpr size_t ka_small = (ka1 + offsetof(UpdateArgs, small)) / 4;
-    if constexpr (!BIG && MODE == 0) {
+    if constexpr (!BIG && MODE == 0 && !PERSIST) {  // (persistent loop: the helper workgroup makes the packets, an iteration ahead)
         if (front && threadIdx.x < kWave) {
             // front-end launches: this wave's oldest loads: the map (kernel arguments), then the state the previous launch left
             const auto *kf = (const __attribute__((address_space(4))) float *) __builtin_amdgcn_kernarg_segment_ptr();
             const int t = min((int) threadIdx.x, kSmallObs - 1);
             f_x = kf[ka_small + offsetof(SmallObs, zn) / 4 + t];
             f_y = kf[ka_small + offsetof(SmallObs, zn) / 4 + kSmallObs + t];
-            if constexpr (PERSIST) {
-                f_hd = carry.hd;
-                f_lm = carry.lm;
-            } else {
-                f_hd = h_front->hdr;
-                f_lm = h_front->lm[threadIdx.x];
-            }
+            f_hd = h_front->hdr;
+            f_lm = h_front->lm[threadIdx.x];
         }
     }
     const bool logw = (h_flags & 4) != 0;
@@ -140,6 +135,7 @@
     const float *__restrict__ tot = PERSIST ? (STEP_WPAR ? ws.blk_w[0] : ws.blk_w[1]) : h_tot;
     if (do_scan) {
         if (scan_tab) scan_issue_dma(tot, nbg, h_nb, scan_tab);
+        else if (PERSIST && !logw) scl = scan_issue_small(tot, nbg);
         else scl = scan_issue(tot, nbg, h_nb, logw);
     }
     __shared__ int32_t pk[kSmallWords];
@@ -158,12 +154,16 @@
         const auto *kc = (const __attribute__((address_space(4))) float *) __builtin_amdgcn_kernarg_segment_ptr();
         if (threadIdx.x < kStepWords) ctlv = kc[(ka0 + offsetof(PredictArgs, steps)) / 4 + threadIdx.x];
     }
+    if constexpr (PERSIST) {
+        // the iteration's packet: made by the helper workgroup during the previous iteration, in the XCD's L2
+        if (threadIdx.x < kSmallWords) pkv = carry.pk_src[threadIdx.x];
+    }
     // (persistent loop: the queued controls are already in LDS, in the iteration's queue entry)
     const float *const ctl = PERSIST ? reinterpret_cast<const float *>(qe->PA.steps) : sh_ctl;
     (void) ctl;  // (strict build: the predict loop reads PredictArgs itself)
     const int cur = PERSIST ? carry.cur : h_ctrl->live[h_slot];  // ... and the Ctrl words
     const bool pend_word = PERSIST ? carry.pend_word : h_ctrl->pend[h_slot] != 0;
-    if constexpr (!BIG && MODE == 0) {
+    if constexpr (!BIG && MODE == 0 && !PERSIST) {
         // front-end launches: the packet is worked out here, while the scan's loads and the Ctrl words are in flight
         if (front && bid < h_nb) {
             const int fw = threadIdx.x / kWave, ft = threadIdx.x & (kWave - 1);
@@ -182,13 +182,12 @@
                 // (every word a host-made packet would carry is defined: loops further down read clamped entries past m and n)
                 for (int w = ft; w < kSmallWords; w += kWave) pk[w] = 0;
             }
-            if (!PERSIST && threadIdx.x < kStepWords) sh_ctl[threadIdx.x] = ctlv;
+            if (threadIdx.x < kStepWords) sh_ctl[threadIdx.x] = ctlv;
             __syncthreads();
             if (fw == 0) {
                 const auto *kf = (const __attribute__((address_space(4))) float *) __builtin_amdgcn_kernarg_segment_ptr();
                 const FrontObs ob = front_observe(STEP_FRONT, fg, f_aux, kf + ka_small + offsetof(SmallObs, zf) / 4);
-                if constexpr (PERSIST) front_book(STEP_FRONT, ob, f_lm, f_hd, pk, f_sets, bid == 0, &carry.lm, &carry.hd);
-                else front_book(STEP_FRONT, ob, f_lm, f_hd, pk, f_sets, blockIdx.x == 0);
+                front_book(STEP_FRONT, ob, f_lm, f_hd, pk, f_sets, blockIdx.x == 0);
             }
         }
     }
@@ -215,6 +214,8 @@
             W = offp[nb + 1];
             Q = offp[nb + 2];
             Mx = offp[nb + 3];
+        } else if (PERSIST && !logw) {
+            scan_small(scl, nb, off, W, Q);  // (every wave for itself: no barrier)
         } else {
             scan_finish(scl, tot, nbg, nb, logw, off, sh_a, sh_q, W, Q, Mx, scan_tab);
         }
@@ -230,16 +231,17 @@
             ws.est_part[STEP_WPAR ^ 1][4 * (size_t) nb] = (double) neff;  // travels with the partials into the history
             ws.est_part[STEP_WPAR ^ 1][4 * (size_t) nb + 1] = (double) ((pend ? 1 : 0) | (weight_status(W, Q) << 1));
         }
-        __syncthreads();
+        if (!(PERSIST && !logw)) __syncthreads();
     }
     SLAM_STAMP(2);  // block totals scanned: W, Neff, decision known
     const int out = pend ? cur ^ 1 : cur;
-    if constexpr (PERSIST) carry.cur = out;  // (the helper corrects its copy below)
+    if constexpr (PERSIST) carry.cur = out;
     // (DIST: the GLOBAL index of the ancestor of local particle k; global particle ids key the strata)
     auto ancestor = [&](int k, bool valid) -> int {
         if (!STEP_PLAN) return valid ? ws.keep[B.slot][k] : 0;
         const int64_t gk = (int64_t) (DIST ? B.first : 0) + k;
-        const double target = valid ? (double) stratum_prev(rng, gk) * W : 0.0;
+        // (persistent loop: this thread's stratum was drawn while the workgroups were meeting: persist_predraw)
+        const double target = valid ? (double) (PERSIST ? carry.strat : stratum_prev(rng, gk)) * W : 0.0;
         const int64_t ng = DIST ? rng.n_global : (int64_t) B.n;
         return (int) find_ancestor_win(target, valid, (int) (gk >> 8), offp, nbg, win, ws.lcum[STEP_WPAR ^ 1], nb, ng,
                                        (!DIST && logw) ? ws.blk_w[STEP_WPAR ^ 1] + 2 * nb : nullptr, Mx, DIST ? B.peers : nullptr, STEP_WPAR ^ 1);
@@ -252,19 +254,13 @@
             // whose partials are complete: this block runs beside the compute blocks instead of as launches of its own
             if (STEP_PLAN) {  // the decision is needed for `out`: recompute it from the two totals, cheaply
                 double Q;
-                if (!PERSIST && U.scan_global) {
+                if (U.scan_global) {
                     W = offp[nb + 1];
                     Q = offp[nb + 2];
                 } else {
                     scan_finish(scl, tot, nbg, nb, logw, off, sh_a, sh_q, W, Q, Mx, scan_tab);
                 }
                 pend = U.do_resample && (neff_of(W, Q) < (float) U.n_effective);
-            }
-            if constexpr (PERSIST) {
-                // (the Ctrl words are published once, behind the last iteration: update_persist_kernel)
-                carry.cur = pend ? cur ^ 1 : cur;
-                if (__builtin_amdgcn_readfirstlane(qe->finalize)) finish_estimate(B, ws, __builtin_amdgcn_readfirstlane(qe->finalize_par), qe->finalize_hist, sh_est);
-                return;
             }
             if (threadIdx.x == 0) {
                 ctrl->live[B.slot ^ 1] = pend ? cur ^ 1 : cur;
@@ -284,7 +280,7 @@
     if constexpr (!BIG) {
         // (parking these in front of the scan's last barrier, to save this one, was measured in round 4: config 2 +-0, config 3
         // 14.86 against 14.35 us per step -- the scan would then wait for the packet's loads as well)
-        if (!front && threadIdx.x < kSmallWords) pk[threadIdx.x] = pkv;
+        if ((PERSIST || !front) && threadIdx.x < kSmallWords) pk[threadIdx.x] = pkv;
         if (!front && threadIdx.x < kStepWords) sh_ctl[threadIdx.x] = ctlv;
         __syncthreads();
         if (!PERSIST && (uint32_t) pk[offsetof(SmallObs, magic) / 4] != kSmallMagic) {  // (layout guard: never seen)
@@ -533,7 +529,11 @@
         // the particle's normals (device draws) are worked out HERE, while the pose is in flight: ~150 instructions that need
         // nothing from memory and used to run after the pose had arrived (15.17 -> 14.62 us per step, measured)
         float hg0 = 0.f, hg1 = 0.f, hg2 = 0.f;
-        if (METHOD == 2 && rng.mode != 0 && (m > 0 || n > 0)) {
+        if constexpr (PERSIST) {  // (drawn while the workgroups were meeting: persist_predraw)
+            hg0 = carry.hg0;
+            hg1 = carry.hg1;
+            hg2 = carry.hg2;
+        } else if (METHOD == 2 && rng.mode != 0 && (m > 0 || n > 0)) {
             U4 r = philox4x32((uint32_t) (rng.first_particle + i), rng.step, 0u, 0u, rng.k0, rng.k1);
 #ifdef SLAM_FAST_MATH
             box_muller3_fast(r, hg0, hg1, hg2);
@@ -548,7 +548,13 @@
         constexpr int kEarly = 8;
         float pg0[kEarly], pg1[kEarly];
         const bool early_draws = METHOD == 1 && !BIG && PA.nsteps > kEarly / 2 && PA.nsteps <= kEarly && PA.add_noise && !PA.use_heading && !PA.comp.valid;
-        if (early_draws) {
+        if constexpr (PERSIST) {
+#pragma unroll
+            for (int q = 0; q < kEarly; q++) {
+                pg0[q] = carry.pg0[q];
+                pg1[q] = carry.pg1[q];
+            }
+        } else if (early_draws) {
             draw_batch_fs1_fast<kEarly>(pg0, pg1, PA, rng, i, S, ctl, 0, PA.nsteps);
 #pragma unroll
             for (int q = 0; q < kEarly; q++) asm volatile("" : "+v"(pg0[q]), "+v"(pg1[q]));  // (pinned above the wait for the pose)
