@@ -367,6 +367,74 @@ SLAM_DEV int wave_max_i(int v) {
     v = max(v, dpp_i_or<0x143, 0xc>(v, id));
     return __builtin_amdgcn_readlane(v, 63);
 }
+// Loads of what ANOTHER workgroup of the running launch has stored (the persistent step loop): BYP = true reads past this CU's
+// vector cache (agent-scope relaxed atomic loads = global_load ... sc1, served by the XCD's L2 where the producer's drained
+// stores are; 16-byte values as two 8-byte halves: these are single latency-bound requests), so that no cache invalidate -- an
+// acquire fence is 1.2-1.7 us per workgroup and iteration here -- stands between the workgroups' meeting and the first load.
+// BYP = false: a plain load.
+template <bool BYP>
+SLAM_DEV uint32_t ldg_u32(const void *p) {
+    if constexpr (BYP) return __hip_atomic_load(reinterpret_cast<const uint32_t *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *reinterpret_cast<const uint32_t *>(p);
+}
+template <bool BYP>
+SLAM_DEV unsigned long long ldg_u64(const void *p) {
+    if constexpr (BYP) return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *reinterpret_cast<const unsigned long long *>(p);
+}
+template <bool BYP>
+SLAM_DEV float ldg(const float *p) {
+    if constexpr (BYP) return __uint_as_float(ldg_u32<true>(p));
+    else return *p;
+}
+template <bool BYP>
+SLAM_DEV int32_t ldg(const int32_t *p) {
+    if constexpr (BYP) return (int32_t) ldg_u32<true>(p);
+    else return *p;
+}
+template <bool BYP>
+SLAM_DEV float2 ldg(const float2 *p) {
+    if constexpr (BYP) {
+        const unsigned long long a = ldg_u64<true>(p);
+        return make_float2(__uint_as_float((uint32_t) a), __uint_as_float((uint32_t) (a >> 32)));
+    } else {
+        return *p;
+    }
+}
+template <bool BYP>
+SLAM_DEV float4 ldg(const float4 *p) {
+    if constexpr (BYP) {
+        const unsigned long long a = ldg_u64<true>(p), b = ldg_u64<true>(reinterpret_cast<const char *>(p) + 8);
+        return make_float4(__uint_as_float((uint32_t) a), __uint_as_float((uint32_t) (a >> 32)), __uint_as_float((uint32_t) b),
+                           __uint_as_float((uint32_t) (b >> 32)));
+    } else {
+        return *p;
+    }
+}
+template <bool BYP>
+SLAM_DEV int4 ldg(const int4 *p) {
+    if constexpr (BYP) {
+        const unsigned long long a = ldg_u64<true>(p), b = ldg_u64<true>(reinterpret_cast<const char *>(p) + 8);
+        return make_int4((int) (uint32_t) a, (int) (uint32_t) (a >> 32), (int) (uint32_t) b, (int) (uint32_t) (b >> 32));
+    } else {
+        return *p;
+    }
+}
+
+template <int CTRL, int ROW_MASK>
+SLAM_DEV float dpp_f_or(float v, float otherwise) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(otherwise), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+SLAM_DEV float wave_max_f(float v) {  // maximum over the 64 lanes (fmaxf semantics), uniform
+    const float id = -INFINITY;
+    v = fmaxf(v, dpp_f_or<0x111, 0xf>(v, id));
+    v = fmaxf(v, dpp_f_or<0x112, 0xf>(v, id));
+    v = fmaxf(v, dpp_f_or<0x114, 0xf>(v, id));
+    v = fmaxf(v, dpp_f_or<0x118, 0xf>(v, id));
+    v = fmaxf(v, dpp_f_or<0x142, 0xa>(v, id));
+    v = fmaxf(v, dpp_f_or<0x143, 0xc>(v, id));
+    return wave_last_f(v);
+}
 SLAM_DEV float wave_sum_f(float v) { return wave_last_f(wave_scan_f(v)); }
 SLAM_DEV double wave_sum_d(double v) { return wave_last_d(wave_scan_d(v)); }
 

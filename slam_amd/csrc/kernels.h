@@ -280,6 +280,10 @@ struct PersistArgs {
                                         // any synchronisation, without a copy of its own)
     FrontState *state_final;            // where the front end's state is left for the next launch
     int32_t *packets;                   // [2][kSmallWords]: the observation packets the helper workgroup makes, an iteration ahead
+    float4 *draws;                      // [2][4][ncap]: FastSLAM 1 (fast build): the (V, G) normals of a particle's eight predicts, made an
+                                        // iteration ahead by the drawer workgroups (component c of particle i at [c][i]: g0 of steps 0-3,
+                                        // g0 of steps 4-7, g1 of steps 0-3, g1 of steps 4-7)
+    int32_t drawers, pad;               // drawer workgroups: one per tile, or none
 };
 
 struct UpdateArgs {

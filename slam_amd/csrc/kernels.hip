@@ -347,9 +347,9 @@ SLAM_DEV void est_combine(EstItem &a, const EstItem &b) {
 SLAM_DEV EstItem wave_reduce_est(EstItem v, EstItem *sh) {
     v.sx = wave_sum_d(v.sx);
     v.sy = wave_sum_d(v.sy);
-    float wm = v.w;
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) wm = fmaxf(wm, __shfl_xor(wm, d, kWave));
+    // (the maximum by DPP moves inside the VALU, as wave_max_i: six LDS-crossbar shuffles were ~0.2 us of the launch's tail for a
+    // wave that has its SIMD to itself; a maximum is exact whatever the pairing: same value)
+    const float wm = wave_max_f(v.w);
     const unsigned long long holders = __ballot(v.w == wm);
     if (holders) {
         const int src = __ffsll((long long) holders) - 1;
@@ -588,8 +588,8 @@ SLAM_DEV ScanLoads scan_issue_small(const float *__restrict__ tot, int nb) {  //
     const int lane = threadIdx.x & (kWave - 1);
     ScanLoads L{0.0f, 0.0f, 0.0f, 0.0f, -INFINITY, -INFINITY};
     if (lane < nb) {
-        L.tv0 = tot[lane];
-        L.qv0 = tot[nb + lane];
+        L.tv0 = ldg<true>(tot + lane);  // (another workgroup's stores of this launch: past the vector cache, device_math.h: ldg)
+        L.qv0 = ldg<true>(tot + nb + lane);
     }
     return L;
 }
@@ -688,6 +688,10 @@ SLAM_DEV int64_t find_ancestor(double target, const double *off, int nb, const f
 // never seen on the bundled maps; possible with degenerate weights) take the per-lane path.  ALL lanes of the wave must call
 // (`valid` = the lane has an output particle); distributed contexts stage peer blocks straight out of the owning GPU's memory.
 constexpr int kWinBlocks = 4;
+// PRE: the caller has already staged blocks 0 .. nb - 1 (nb <= kWinBlocks) in `win` (persistent loop: requested at the head of the
+// iteration, with the block totals: one trip less between the decision and the ancestor)
+// BYP: the prefixes were stored by other workgroups of the running launch: read them past the vector cache (device_math.h: ldg)
+template <bool PRE = false, bool BYP = false>
 SLAM_DEV int64_t find_ancestor_win(double target, bool valid, int guess, const double *off, int nb, float *win, const float *__restrict__ lcum_local,
                                    int nb_local, int64_t n_global, const float *__restrict__ blk_m, double M, const PeerPtrs *peers, int par) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -722,7 +726,7 @@ SLAM_DEV int64_t find_ancestor_win(double target, bool valid, int guess, const d
         b0 = s_lo;
     }
     const bool use = valid && b0 < nb;  // (beyond the last cumulative weight: undefined upstream, clamped below)
-    const int lo = wave_min_i(use ? b0 : 0x7fffffff), hi = wave_max_i(use ? b0 : -1);
+    const int lo = PRE ? 0 : wave_min_i(use ? b0 : 0x7fffffff), hi = PRE ? -1 : wave_max_i(use ? b0 : -1);
     auto block_ptr = [&](int b) -> const float * {
         return peers ? peers[b / nb_local].lcum[par] + (size_t) (b % nb_local) * kBlock : lcum_local + (size_t) b * kBlock;
     };
@@ -730,16 +734,17 @@ SLAM_DEV int64_t find_ancestor_win(double target, bool valid, int guess, const d
     static_assert(kWinBlocks == 4, "four named staging registers below");
     float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, v2 = v0, v3 = v0;
     const int nw = hi < 0 ? 0 : hi - lo + 1;  // source blocks this wave's outputs draw from (0: no lane has an output)
-    if (nw > 0) v0 = reinterpret_cast<const float4 *>(block_ptr(lo))[lane];
-    if (nw > 1) v1 = reinterpret_cast<const float4 *>(block_ptr(lo + 1))[lane];
-    if (nw > 2) v2 = reinterpret_cast<const float4 *>(block_ptr(lo + 2))[lane];
-    if (nw > 3) v3 = reinterpret_cast<const float4 *>(block_ptr(lo + 3))[lane];
+    if (nw > 0) v0 = ldg<BYP>(reinterpret_cast<const float4 *>(block_ptr(lo)) + lane);
+    if (nw > 1) v1 = ldg<BYP>(reinterpret_cast<const float4 *>(block_ptr(lo + 1)) + lane);
+    if (nw > 2) v2 = ldg<BYP>(reinterpret_cast<const float4 *>(block_ptr(lo + 2)) + lane);
+    if (nw > 3) v3 = ldg<BYP>(reinterpret_cast<const float4 *>(block_ptr(lo + 3)) + lane);
     if (nw > 0) reinterpret_cast<float4 *>(win)[lane] = v0;
     if (nw > 1) reinterpret_cast<float4 *>(win + kBlock)[lane] = v1;
     if (nw > 2) reinterpret_cast<float4 *>(win + 2 * kBlock)[lane] = v2;
     if (nw > 3) reinterpret_cast<float4 *>(win + 3 * kBlock)[lane] = v3;
     __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave execute in order: the reads below see the stores above)
     if (!use) return n_global - 1;
+    (void) block_ptr;
     const double o = off[b0];
     const double sc = blk_m ? block_scale(blk_m[b0], M) : 1.0;
     float pv[16], ev[16];
@@ -758,12 +763,12 @@ SLAM_DEV int64_t find_ancestor_win(double target, bool valid, int guess, const d
     } else {
         const float *lc = block_ptr(b0);
 #pragma unroll
-        for (int q = 0; q < 16; q++) pv[q] = lc[16 * q + 15];
+        for (int q = 0; q < 16; q++) pv[q] = ldg<BYP>(lc + 16 * q + 15);
 #pragma unroll
         for (int q = 14; q >= 0; q--)
             if (o + (double) pv[q] * sc > target) seg = q;
         const float4 *l4 = reinterpret_cast<const float4 *>(lc + 16 * seg);
-        const float4 e0 = l4[0], e1 = l4[1], e2 = l4[2], e3 = l4[3];
+        const float4 e0 = ldg<BYP>(l4), e1 = ldg<BYP>(l4 + 1), e2 = ldg<BYP>(l4 + 2), e3 = ldg<BYP>(l4 + 3);
         ev[0] = e0.x; ev[1] = e0.y; ev[2] = e0.z; ev[3] = e0.w; ev[4] = e1.x; ev[5] = e1.y; ev[6] = e1.z; ev[7] = e1.w;
         ev[8] = e2.x; ev[9] = e2.y; ev[10] = e2.z; ev[11] = e2.w; ev[12] = e3.x; ev[13] = e3.y; ev[14] = e3.z; ev[15] = e3.w;
     }
@@ -1104,6 +1109,15 @@ __host__ __device__ inline int staging_slots(int method, bool big, int m) {
 // (-mllvm -amdgpu-kernarg-preload-count=16) and touching every 64-byte line of the argument segment at entry.
 //   h_flags: bit 0 plan_inline, bit 1 scan_global, bit 2 logw, bit 3 lazy, bit 4 front end inside the launch (h_front),
 //            bit 5 the gathered totals table travels by LDS-DMA (scan_issue_dma)
+// FastSLAM 1, fast build: do the (V, G) normals of this iteration's predicts come in one batch of eight (update_step: early_draws)?
+SLAM_DEV bool persist_batch_draws(int method, const PredictArgs &PA) {
+#ifdef SLAM_FAST_MATH
+    return method == 1 && PA.nsteps > 4 && PA.nsteps <= 8 && PA.add_noise && !PA.use_heading && !PA.comp.valid;
+#else
+    return false;
+#endif
+}
+
 // PERSIST (update_persist_kernel, kernels.h: PersistArgs): the same step as ONE ITERATION of a launch that runs K of them.  What
 // the launch boundary gives a per-step launch comes from elsewhere: the iteration's arguments from `qe` (an LDS copy of its queue
 // entry), the live buffer and the front end's state from `carry` (registers; no workgroup re-reads a Ctrl word or the state
@@ -1113,10 +1127,10 @@ struct StepCarry {
     int cur;                  // live pose / genealogy buffer
     bool pend_word;           // first iteration only: Ctrl.pend as the launch found it
     const int32_t *pk_src;    // the iteration's observation packet (SmallObs words), made by the helper workgroup
-    // drawn while the workgroups were meeting (persist_predraw): this particle's resampling stratum, its FastSLAM 2 normals, the
-    // (V, G) normals of its FastSLAM 1 predicts -- counters only, nothing another workgroup wrote
+    // drawn while the workgroups were meeting (persist_predraw): this particle's resampling stratum and its FastSLAM 2 normals --
+    // counters only, nothing another workgroup wrote
     float strat, hg0, hg1, hg2;
-    float pg0[8], pg1[8];
+    const float4 *draw_src;   // FastSLAM 1, fast build: this iteration's (V, G) normals, made by the drawer workgroups (or null)
 };
 
 template <int METHOD, int MODE, bool BIG>
@@ -1190,7 +1204,9 @@ SLAM_DEV void persist_arrive(uint32_t *sync, bool cross_xcd) {
         __hip_atomic_fetch_add(sync + kPersistSyncCounter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
-SLAM_DEV bool persist_pass(uint32_t *sync, uint32_t target, uint32_t max_spins, int *sh_ok) {
+// invalidate: the workgroup goes on to read other workgroups' stores with plain loads (the helper; everybody when the placement
+// spans XCDs); the tiles read them with ldg<true> (device_math.h) and need no invalidate -- 1.2-1.7 us per iteration otherwise
+SLAM_DEV bool persist_pass(uint32_t *sync, uint32_t target, uint32_t max_spins, int *sh_ok, bool invalidate) {
     if (threadIdx.x == 0) {
         int ok = 1;
         uint32_t spins = 0;
@@ -1203,8 +1219,10 @@ SLAM_DEV bool persist_pass(uint32_t *sync, uint32_t target, uint32_t max_spins, 
             __builtin_amdgcn_s_sleep(1);
         }
         if (ok && __hip_atomic_load(sync + kPersistSyncAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ok = 0;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (holds the barrier below until the invalidate has completed)
+        if (invalidate) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (holds the barrier below until the invalidate has completed)
+        }
         *sh_ok = ok;
     }
     __syncthreads();
@@ -1228,14 +1246,30 @@ SLAM_DEV void persist_predraw(const PersistStep *qe, const RngArgs &rng_k, const
         box_muller3(r, carry.hg0, carry.hg1, carry.hg2);
 #endif
     }
-#pragma unroll
-    for (int q = 0; q < 8; q++) carry.pg0[q] = carry.pg1[q] = 0.f;
+}
+
+// A drawer workgroup: the (V, G) normals of tile `tile`'s particles for the iteration whose queue entry is `qe`: ~1.9 us of Philox +
+// Box-Muller per iteration that need nothing but counters, made on a CU that would otherwise idle, an iteration ahead; the tile
+// picks them up with the block totals (update_step.inl).  The same function on the same counters as the tile would call.
+SLAM_DEV void persist_draw(const PersistStep *qe, const RngArgs &rng, const Buffers &B, int tile, float4 *dst) {
 #ifdef SLAM_FAST_MATH
     const PredictArgs &PA = qe->PA;
-    if (METHOD == 1 && PA.nsteps > 4 && PA.nsteps <= 8 && PA.add_noise && !PA.use_heading && !PA.comp.valid)  // (update_step: early_draws)
-        draw_batch_fs1_fast<8>(carry.pg0, carry.pg1, PA, rng, i, (size_t) B.ncap, reinterpret_cast<const float *>(qe->PA.steps), 0, PA.nsteps);
+    if (!persist_batch_draws(1, PA)) return;
+    const int i = tile * kBlock + (int) threadIdx.x;
+    const size_t S = (size_t) B.ncap;
+    float g0[8], g1[8];
+    draw_batch_fs1_fast<8>(g0, g1, PA, rng, i, S, reinterpret_cast<const float *>(qe->PA.steps), 0, PA.nsteps);
+    dst[i] = make_float4(g0[0], g0[1], g0[2], g0[3]);
+    dst[S + i] = make_float4(g0[4], g0[5], g0[6], g0[7]);
+    dst[2 * S + i] = make_float4(g1[0], g1[1], g1[2], g1[3]);
+    dst[3 * S + i] = make_float4(g1[4], g1[5], g1[6], g1[7]);
 #endif
 }
+
+// (The (V, G) normals of FastSLAM 1's predicts stay where update_step draws them, all eight in one interleaved batch behind the pose
+// request.  Drawing the first four between an iteration's last stores and the wait for them was built and measured in round 5:
+// 10.39 against 9.72 us per step -- two batches of four lose the instruction-level parallelism of one batch of eight, and the
+// compiler is free to sink arithmetic whose results are needed an iteration later below the wait it was meant to fill.)
 
 // the observation packet of one iteration, by the helper workgroup (the front end of update_step, same functions in the same
 // roles): SmallObs words into `pk` (LDS), then into `dst`; the front end's state moves on in the first wave's registers
@@ -1277,10 +1311,12 @@ __global__ void __launch_bounds__(kBlock) update_persist_kernel(const float *__r
     const int bid = (int) blockIdx.x / kPersistStride, nb = h_nb;
     const bool helper = bid == nb;
     const PersistArgs &P = U.persist;
-    __shared__ PersistStep qe;
+    const bool drawer = bid > nb;          // (P.drawers of them: drawer nb + 1 + t serves tile t)
+    const int dtile = bid - nb - 1;
+    __shared__ PersistStep qes[2];  // the queue entries of this iteration and the next
     __shared__ int sh_ok;
     static_assert(kPersistStepWords <= kBlock, "one dword of a queue entry per thread");
-    const uint32_t members = (uint32_t) nb + 1u;  // the tiles' workgroups + the helper
+    const uint32_t members = (uint32_t) (nb + 1 + P.drawers);  // the tiles' workgroups + the helper + the drawers
     uint32_t *sync = P.sync;
     // which XCD is this?  All members say; one barrier with the memory model's full protocol; all read
     if (threadIdx.x == 0) {
@@ -1289,7 +1325,7 @@ __global__ void __launch_bounds__(kBlock) update_persist_kernel(const float *__r
         __hip_atomic_store(sync + kPersistSyncXcc + bid, (xcc & 15u) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const uint32_t *__restrict__ q0 = reinterpret_cast<const uint32_t *>(P.queue);  // (the queue is never written during the launch)
-    if (P.K > 0 && threadIdx.x < kPersistStepWords) reinterpret_cast<uint32_t *>(&qe)[threadIdx.x] = q0[threadIdx.x];
+    if (P.K > 0 && threadIdx.x < kPersistStepWords) reinterpret_cast<uint32_t *>(&qes[0])[threadIdx.x] = q0[threadIdx.x];
     __syncthreads();
     StepCarry carry;
     carry.cur = h_ctrl->live[h_slot];
@@ -1326,26 +1362,33 @@ __global__ void __launch_bounds__(kBlock) update_persist_kernel(const float *__r
             f_hd = h_front->hdr;
             f_lm = h_front->lm[threadIdx.x];
         }
-        if (P.K > 0) persist_front(front_args(&qe), f_x, f_y, f_lm, f_hd, kf + ka_small + offsetof(SmallObs, zf) / 4, h_pk, h_sets, h_aux, P.packets);
+        if (P.K > 0) persist_front(front_args(&qes[0]), f_x, f_y, f_lm, f_hd, kf + ka_small + offsetof(SmallObs, zf) / 4, h_pk, h_sets, h_aux, P.packets);
     }
+    const size_t draw_words = 4 * (size_t) B.ncap;  // float4s per buffer of PersistArgs::draws
+    if (drawer && P.K > 0) persist_draw(&qes[0], rng, B, dtile, P.draws);
     persist_arrive(sync, true);
-    if (!helper && P.K > 0) persist_predraw<METHOD>(&qe, rng, B, i, carry);
-    bool alive = persist_pass(sync, members, P.max_spins, &sh_ok);
+    if (!helper && !drawer && P.K > 0) persist_predraw<METHOD>(&qes[0], rng, B, i, carry);
+    bool alive = persist_pass(sync, members, P.max_spins, &sh_ok, true);
     bool cross = false;
     {
         const uint32_t mine = __hip_atomic_load(sync + kPersistSyncXcc + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int b = 0; b <= nb; b++) cross |= __hip_atomic_load(sync + kPersistSyncXcc + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mine;
+        for (int b = 0; b < (int) members; b++) cross |= __hip_atomic_load(sync + kPersistSyncXcc + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mine;
     }
     const bool logw = (h_flags & 4) != 0;
     int it = 0;
     for (; alive && it < P.K; it++) {
         SLAM_STAMP(12);  // (diagnostic build) this iteration begins: the previous barrier has been passed
         const bool more = it + 1 < P.K;
-        // the next iteration's entry: requested now, parked in LDS once everybody is done with this one
+        const PersistStep &qe = qes[it & 1];
+        PersistStep *const qn = &qes[(it + 1) & 1];  // (free since the previous barrier)
+        // the next iteration's entry: requested now, parked in LDS behind the step's code
         uint32_t qv = 0;
         if (more && threadIdx.x < kPersistStepWords) qv = q0[(size_t) (it + 1) * kPersistStepWords + threadIdx.x];
-        if (!helper) {
+        if (drawer) {
+            // (nothing of this iteration: the next one's draws, below)
+        } else if (!helper) {
             carry.pk_src = P.packets + (size_t) (it & 1) * kSmallWords;
+            carry.draw_src = P.drawers ? P.draws + (size_t) (it & 1) * draw_words : nullptr;
             persist_step<METHOD>(h_tot, h_ctrl, h_front, h_nb, h_slot, h_grid, h_flags, B, U, rng, ws, &qe, carry);
         } else {
             // the decision (for the live buffer the launch leaves), as update_step's helper block works it out
@@ -1360,25 +1403,22 @@ __global__ void __launch_bounds__(kBlock) update_persist_kernel(const float *__r
             }
             carry.cur = pend ? carry.cur ^ 1 : carry.cur;
             if (__builtin_amdgcn_readfirstlane(qe.finalize)) finish_estimate(B, ws, __builtin_amdgcn_readfirstlane(qe.finalize_par), qe.finalize_hist, hs_est);
-            // ... and the NEXT iteration's observation packet, in place before this iteration's barrier
-            if (more) {
-                __syncthreads();  // (everybody is done with this iteration's queue entry)
-                if (threadIdx.x < kPersistStepWords) reinterpret_cast<uint32_t *>(&qe)[threadIdx.x] = qv;
-                __syncthreads();
-                persist_front(front_args(&qe), f_x, f_y, f_lm, f_hd, kf + ka_small + offsetof(SmallObs, zf) / 4, h_pk, h_sets, h_aux,
-                              P.packets + (size_t) ((it + 1) & 1) * kSmallWords);
-            }
         }
         carry.pend_word = false;
         SLAM_STAMP(11);  // the step's code is done
-        persist_arrive(sync, cross);
-        // (everybody of this workgroup is done with the queue entry: arrive's barrier)
-        if (more && !helper) {
-            if (threadIdx.x < kPersistStepWords) reinterpret_cast<uint32_t *>(&qe)[threadIdx.x] = qv;
+        if (more) {
+            if (threadIdx.x < kPersistStepWords) reinterpret_cast<uint32_t *>(qn)[threadIdx.x] = qv;
             __syncthreads();
-            persist_predraw<METHOD>(&qe, rng, B, i, carry);
+            // helper: the NEXT iteration's observation packet, in place before this iteration's barrier; drawers: its draws
+            if (helper)
+                persist_front(front_args(qn), f_x, f_y, f_lm, f_hd, kf + ka_small + offsetof(SmallObs, zf) / 4, h_pk, h_sets, h_aux,
+                              P.packets + (size_t) ((it + 1) & 1) * kSmallWords);
+            else if (drawer)
+                persist_draw(qn, rng, B, dtile, P.draws + (size_t) ((it + 1) & 1) * draw_words);
         }
-        alive = persist_pass(sync, members * (uint32_t) (it + 2), P.max_spins, &sh_ok);
+        persist_arrive(sync, cross);
+        if (more && !helper && !drawer) persist_predraw<METHOD>(qn, rng, B, i, carry);  // (while the arrival travels)
+        alive = persist_pass(sync, members * (uint32_t) (it + 2), P.max_spins, &sh_ok, helper || cross);
         SLAM_STAMP(13);  // barrier passed
     }
     // where the launch leaves things, for the host and the next launch: the Ctrl words (both slots: the set is plain, in
@@ -2679,7 +2719,7 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
 // kPersistStride-th stays; LDS as for a per-step launch that plans inline with the front end on
 static void launch_update_persist(hipStream_t st, const Buffers &B, const PredictArgs &PA, const UpdateArgs &U, const RngArgs &rng,
                                   const WeightScratch &ws) {
-    const int grid = kPersistStride * (ws.nblocks + 1);
+    const int grid = kPersistStride * (ws.nblocks + 1 + U.persist.drawers);
     const size_t lds = (size_t) staging_slots(U.method, false, U.m) * kBlock * (sizeof(float4) + sizeof(float)) +
                        sizeof(double) * (((size_t) ws.nblocks + 3) & ~(size_t) 1) + update_window_bytes();
     const int h_flags = 1 | (U.logw ? 4 : 0) | 8 | 16;

@@ -248,6 +248,7 @@ struct slamgpu_ctx {
     bool pq_ev_used = false;
     uint32_t *psync_dev = nullptr, *pstatus_host = nullptr;
     int32_t *ppk_dev = nullptr;          // [2][kSmallWords] observation packets of the loop's helper workgroup
+    float4 *pdraw_dev = nullptr;         // [2][4][ncap] draws of the loop's drawer workgroups (FastSLAM 1, fast build)
     int64_t persist_launches = 0, persist_steps = 0;
     EstStage unplanned;           // the last update: resampling stage not run yet
     EstStage unreduced;           // an update whose partials exist (est_part[par]) but are not reduced yet
@@ -877,6 +878,7 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     if (c->pq_ev) (void) hipEventDestroy(c->pq_ev);
     if (c->psync_dev) (void) hipFree(c->psync_dev);
     if (c->ppk_dev) (void) hipFree(c->ppk_dev);
+    if (c->pdraw_dev) (void) hipFree(c->pdraw_dev);
     if (c->pstatus_host) (void) hipHostFree(c->pstatus_host);
     if (c->book_dev) (void) hipFree(c->book_dev);
     if (c->refcnt_dev) (void) hipFree(c->refcnt_dev);
@@ -1452,6 +1454,7 @@ static int run_observe_persist(slamgpu_ctx *c, int32_t K, const int32_t *n_contr
         HIP_TRY(hipMalloc((void **) &c->psync_dev, sizeof(uint32_t) * kPersistSyncAlloc));
         HIP_TRY(hipMemsetAsync(c->psync_dev, 0, sizeof(uint32_t) * kPersistSyncAlloc, c->stream));
         HIP_TRY(hipMalloc((void **) &c->ppk_dev, sizeof(int32_t) * 2 * kSmallWords));
+        HIP_TRY(hipMalloc((void **) &c->pdraw_dev, sizeof(float4) * 2 * 4 * (size_t) c->B.ncap));
         HIP_TRY(hipHostMalloc((void **) &c->pstatus_host, 2 * sizeof(uint32_t), hipHostMallocDefault));
         c->pstatus_host[0] = c->pstatus_host[1] = 0;
         HIP_TRY(hipEventCreateWithFlags(&c->pq_ev, hipEventDisableTiming));
@@ -1502,6 +1505,10 @@ static int run_observe_persist(slamgpu_ctx *c, int32_t K, const int32_t *n_contr
         U.persist.host_status = c->pstatus_host;
         U.persist.state_final = c->front_dev + c->front_par;  // (the copy the next launch reads)
         U.persist.packets = c->ppk_dev;
+        U.persist.draws = c->pdraw_dev;
+        // drawer workgroups (one per tile): FastSLAM 1 in the fast build, whose predicts draw eight Philox blocks per particle and step
+        U.persist.drawers = (c->cfg.method == SLAMGPU_FASTSLAM1 && c->cfg.math_mode == SLAMGPU_MATH_FAST && c->cfg.add_predict_noise &&
+                             !c->cfg.use_heading && getenv("SLAMGPU_NO_DRAWERS") == nullptr) ? c->ws.nblocks : 0;
         {
             Timed t(c, "persist_loop");
             c->k->update_persist(c->stream, col.B, PredictArgs{}, U, col.rng, col.ws);

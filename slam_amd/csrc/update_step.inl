@@ -138,6 +138,36 @@
         else if (PERSIST && !logw) scl = scan_issue_small(tot, nbg);
         else scl = scan_issue(tot, nbg, h_nb, logw);
     }
+    // persistent loop, at most kWinBlocks tiles: every wave requests ALL in-block prefixes of the previous iteration now (1 KB per
+    // tile, one 16-byte load per lane and tile) and parks them in its ancestor window behind the scan: a resampling iteration
+    // finds its ancestors without another trip (the per-step launch tried the same and lost: its rows are the last thing the
+    // PREVIOUS LAUNCH wrote, several microseconds away at the head of a launch; here they are L2 hits)
+    const bool pre_win = PERSIST && do_scan && nbg <= kWinBlocks;
+    float4 pw0 = make_float4(0.f, 0.f, 0.f, 0.f), pw1 = pw0, pw2 = pw0, pw3 = pw0;
+    if constexpr (PERSIST) {
+        if (pre_win) {
+            const float *__restrict__ lc = STEP_WPAR ? ws.lcum[0] : ws.lcum[1];
+            const int ln = threadIdx.x & (kWave - 1);
+            pw0 = ldg<true>(reinterpret_cast<const float4 *>(lc) + ln);
+            if (nbg > 1) pw1 = ldg<true>(reinterpret_cast<const float4 *>(lc + kBlock) + ln);
+            if (nbg > 2) pw2 = ldg<true>(reinterpret_cast<const float4 *>(lc + 2 * kBlock) + ln);
+            if (nbg > 3) pw3 = ldg<true>(reinterpret_cast<const float4 *>(lc + 3 * kBlock) + ln);
+        }
+    }
+    // ... and, FastSLAM 1 in the fast build: the (V, G) normals of this particle's eight predicts, made an iteration ahead by a
+    // drawer workgroup (persist_draw): four 16-byte loads in flight with the totals instead of ~1.9 us of Philox + Box-Muller
+    float4 dq0 = make_float4(0.f, 0.f, 0.f, 0.f), dq1 = dq0, dq2 = dq0, dq3 = dq0;
+    bool drawn = false;
+    if constexpr (PERSIST) {
+        drawn = carry.draw_src != nullptr && persist_batch_draws(METHOD, PA) && bid < nb;
+        if (drawn) {
+            const size_t Sd = (size_t) B.ncap, at = (size_t) bid * kBlock + threadIdx.x;
+            dq0 = ldg<true>(carry.draw_src + at);
+            dq1 = ldg<true>(carry.draw_src + Sd + at);
+            dq2 = ldg<true>(carry.draw_src + 2 * Sd + at);
+            dq3 = ldg<true>(carry.draw_src + 3 * Sd + at);
+        }
+    }
     __shared__ int32_t pk[kSmallWords];
     __shared__ uint32_t f_sets[4];
     __shared__ float f_aux[2 * kWave + 2];
@@ -156,7 +186,7 @@
     }
     if constexpr (PERSIST) {
         // the iteration's packet: made by the helper workgroup during the previous iteration, in the XCD's L2
-        if (threadIdx.x < kSmallWords) pkv = carry.pk_src[threadIdx.x];
+        if (threadIdx.x < kSmallWords) pkv = ldg<true>(carry.pk_src + threadIdx.x);
     }
     // (persistent loop: the queued controls are already in LDS, in the iteration's queue entry)
     const float *const ctl = PERSIST ? reinterpret_cast<const float *>(qe->PA.steps) : sh_ctl;
@@ -235,7 +265,17 @@
     }
     SLAM_STAMP(2);  // block totals scanned: W, Neff, decision known
     const int out = pend ? cur ^ 1 : cur;
-    if constexpr (PERSIST) carry.cur = out;
+    if constexpr (PERSIST) {
+        carry.cur = out;
+        if (pre_win && pend) {  // (uniform)
+            const int ln = threadIdx.x & (kWave - 1);
+            reinterpret_cast<float4 *>(win)[ln] = pw0;
+            reinterpret_cast<float4 *>(win + kBlock)[ln] = pw1;
+            reinterpret_cast<float4 *>(win + 2 * kBlock)[ln] = pw2;
+            reinterpret_cast<float4 *>(win + 3 * kBlock)[ln] = pw3;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
     // (DIST: the GLOBAL index of the ancestor of local particle k; global particle ids key the strata)
     auto ancestor = [&](int k, bool valid) -> int {
         if (!STEP_PLAN) return valid ? ws.keep[B.slot][k] : 0;
@@ -243,8 +283,11 @@
         // (persistent loop: this thread's stratum was drawn while the workgroups were meeting: persist_predraw)
         const double target = valid ? (double) (PERSIST ? carry.strat : stratum_prev(rng, gk)) * W : 0.0;
         const int64_t ng = DIST ? rng.n_global : (int64_t) B.n;
-        return (int) find_ancestor_win(target, valid, (int) (gk >> 8), offp, nbg, win, ws.lcum[STEP_WPAR ^ 1], nb, ng,
-                                       (!DIST && logw) ? ws.blk_w[STEP_WPAR ^ 1] + 2 * nb : nullptr, Mx, DIST ? B.peers : nullptr, STEP_WPAR ^ 1);
+        if (PERSIST && pre_win)
+            return (int) find_ancestor_win<true, true>(target, valid, (int) (gk >> 8), offp, nbg, win, ws.lcum[STEP_WPAR ^ 1], nb, ng,
+                                                 logw ? ws.blk_w[STEP_WPAR ^ 1] + 2 * nb : nullptr, Mx, nullptr, STEP_WPAR ^ 1);
+        return (int) find_ancestor_win<false, PERSIST>(target, valid, (int) (gk >> 8), offp, nbg, win, ws.lcum[STEP_WPAR ^ 1], nb, ng,
+                                                       (!DIST && logw) ? ws.blk_w[STEP_WPAR ^ 1] + 2 * nb : nullptr, Mx, DIST ? B.peers : nullptr, STEP_WPAR ^ 1);
     };
     if (bid >= nb) {
         // ---- helper blocks ---------------------------------------------------------------------------------
@@ -385,7 +428,7 @@
                     asm volatile("" : "+v"(pA), "+v"(pB));
                 }
             }
-            return Rec{pA[at], pB[at]};  // by value: a reference into the staging arrays would pin them to scratch
+            return Rec{ldg<PERSIST>(pA + at), ldg<PERSIST>(pB + at)};  // by value: a reference into the staging arrays would pin them to scratch
         };
         auto load_lmk = [&](int j, int s, int b, float4 &la, float &lb) {
             const Rec r = load_rec(j, s, b);
@@ -428,7 +471,7 @@
         // (compact contexts = small packets: rows interleaved four to a chunk, kernels.h: Buffers::gen)
         // (DIST: genealogy entries and the values returned here are GLOBAL slot ids)
         auto slot_of = [&](int k) -> int {
-            return (lrow[k] & kRowFreshBit) ? (DIST ? gsrc : si) : genS[gen_index(!BIG, S, lrow[k] & kRowMask, (size_t) si)];
+            return (lrow[k] & kRowFreshBit) ? (DIST ? gsrc : si) : ldg<PERSIST>(genS + gen_index(!BIG, S, lrow[k] & kRowMask, (size_t) si));
         };
         auto buf_of = [&](int k) -> int { return (lrow[k] >> 30) & 1; };
         const float r00 = U.R[0], r01 = U.R[1], r10 = U.R[2], r11 = U.R[3];
@@ -513,7 +556,7 @@
         const bool copy_inline = !BIG && pend && sb == cur;  // (an arrival's genealogy is already in place)
         const int nchunks = live_chunks;  // chunks holding a row in use after this update (incl. the one it opens)
         int4 gq[kChunks];
-        float4 pa = poseA[si];
+        float4 pa = ldg<PERSIST>(poseA + si);
         // the slots of the (first kStage) re-observed landmarks are fetched now, with the pose: they depend on nothing but
         // the source slot, so the records are one round trip behind the pose, not two
         int ts[kStage];
@@ -548,12 +591,9 @@
         constexpr int kEarly = 8;
         float pg0[kEarly], pg1[kEarly];
         const bool early_draws = METHOD == 1 && !BIG && PA.nsteps > kEarly / 2 && PA.nsteps <= kEarly && PA.add_noise && !PA.use_heading && !PA.comp.valid;
-        if constexpr (PERSIST) {
-#pragma unroll
-            for (int q = 0; q < kEarly; q++) {
-                pg0[q] = carry.pg0[q];
-                pg1[q] = carry.pg1[q];
-            }
+        if (PERSIST && drawn) {
+            pg0[0] = dq0.x; pg0[1] = dq0.y; pg0[2] = dq0.z; pg0[3] = dq0.w; pg0[4] = dq1.x; pg0[5] = dq1.y; pg0[6] = dq1.z; pg0[7] = dq1.w;
+            pg1[0] = dq2.x; pg1[1] = dq2.y; pg1[2] = dq2.z; pg1[3] = dq2.w; pg1[4] = dq3.x; pg1[5] = dq3.y; pg1[6] = dq3.z; pg1[7] = dq3.w;
         } else if (early_draws) {
             draw_batch_fs1_fast<kEarly>(pg0, pg1, PA, rng, i, S, ctl, 0, PA.nsteps);
 #pragma unroll
@@ -568,7 +608,7 @@
             const int4 *__restrict__ g4 = reinterpret_cast<const int4 *>(genS);
 #pragma unroll
             for (int c = 0; c < kChunks; c++)
-                if (c < nchunks) gq[c] = g4[(size_t) c * S + si];
+                if (c < nchunks) gq[c] = ldg<PERSIST>(g4 + ((size_t) c * S + si));
         }
         // resampled particles restart at 1/N (core.cpp:744-747); otherwise the weights are normalised (core.cpp:726-729;
         // resample_kernel has already done it unless this launch plans inline)
@@ -579,8 +619,8 @@
         float q00 = 0.f, q10 = 0.f, q11 = 0.f, q20 = 0.f, q21 = 0.f, q22 = 0.f;
         bool pose_dirty = pend;
         if (METHOD == 2) {
-            const float4 pb = poseB[si];
-            const float2 pc = poseC[si];
+            const float4 pb = ldg<PERSIST>(poseB + si);
+            const float2 pc = ldg<PERSIST>(poseC + si);
             q00 = pb.x; q10 = pb.y; q11 = pb.z; q20 = pb.w; q21 = pc.x; q22 = pc.y;
         }
         if (PA.nsteps > 0) {

@@ -71,3 +71,8 @@ for title, sel in (("last iteration applied a RESAMPLE", True), ("last iteration
             continue
         print("%-52s %8.2f %8.2f %8.2f   %s" % (NAMES[j], med, np.quantile(col, 0.9), col.max(), "" if prev is None else "%+.2f" % (med - prev)))
         prev = med
+    # per workgroup: the medians of a few levels (the barrier waits for the slowest)
+    per = np.stack([(st - st[:, 12].min()) / 100.0 for st in grp])   # [launch][workgroup][slot]
+    print("per workgroup, medians:  " + "  ".join("%s" % NAMES[j].split()[0] for j in (12, 2, 3, 4, 10, 7, 8, 9, 11, 13)))
+    for b in range(per.shape[1]):
+        print("  workgroup %d:           " % b + "  ".join("%5.2f" % np.median(per[:, b, j]) for j in (12, 2, 3, 4, 10, 7, 8, 9, 11, 13)))
