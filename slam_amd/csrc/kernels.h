@@ -280,9 +280,9 @@ struct PersistArgs {
                                         // any synchronisation, without a copy of its own)
     FrontState *state_final;            // where the front end's state is left for the next launch
     int32_t *packets;                   // [2][kSmallWords]: the observation packets the helper workgroup makes, an iteration ahead
-    float4 *draws;                      // [2][4][ncap]: FastSLAM 1 (fast build): the (V, G) normals of a particle's eight predicts, made an
-                                        // iteration ahead by the drawer workgroups (component c of particle i at [c][i]: g0 of steps 0-3,
-                                        // g0 of steps 4-7, g1 of steps 0-3, g1 of steps 4-7)
+    float4 *draws;                      // [2][6][ncap]: FastSLAM 1 (fast build): the pose-independent half of a particle's eight predicts,
+                                        // made an iteration ahead by the drawer workgroups (component c of particle i at [c][i]: V dt of
+                                        // steps 0-3, 4-7; the perturbed G of steps 0-3, 4-7; sin(G / wheelBase) of steps 0-3, 4-7)
     int32_t drawers, pad;               // drawer workgroups: one per tile, or none
 };
 

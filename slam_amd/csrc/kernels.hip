@@ -221,6 +221,51 @@ SLAM_DEV void apply_batch_fs1_fast(float &x, float &y, float &th, const float (&
     }
 }
 
+// The same steps in two halves (persistent loop): what needs no pose -- the perturbed controls, V dt, sin(G / wheelBase) -- is made
+// an iteration ahead by a drawer workgroup (controls_batch_fs1_fast); the pose's own chain applies it (apply_controls_fs1_fast).
+// The operations of apply_batch_fs1_fast's `heading` and `position`, each on the same values: identical bits.
+template <int W>
+SLAM_DEV void controls_batch_fs1_fast(float (&vd)[W], float (&gs)[W], float (&sgw)[W], const float (&g0)[W], const float (&g1)[W], const PredictArgs &A,
+                                      const float *ctl, float dt, float iwb, const L2 &L, int nb) {
+#pragma unroll
+    for (int q = 0; q < W; q++) {
+        const int s = min(q, nb - 1);  // (past the last step: values nobody uses)
+        const float V = ffma(L.l00, g0[q], ctl ? ctl[8 * s] : A.steps[s].V);
+        const float G = ffma(L.l11, g1[q], ffma(L.l10, g0[q], ctl ? ctl[8 * s + 1] : A.steps[s].G));
+        float cgw;
+        sincos_cw(G * iwb, sgw[q], cgw);  // sin(G / wheelBase): upstream quirk (fastslam1.cpp:52)
+        vd[q] = V * dt;
+        gs[q] = G;
+    }
+}
+template <int W>
+SLAM_DEV void apply_controls_fs1_fast(float &x, float &y, float &th, const float (&vd)[W], const float (&gs)[W], const float (&sgw)[W], int nb) {
+    float th_at[W];
+    auto heading = [&](int q) {
+        th_at[q] = th;
+        th = wrap_pi(ffma(vd[q], sgw[q], th));
+    };
+    auto position = [&](int q) {
+        float sn, cs;
+        sincos_cw(gs[q] + th_at[q], sn, cs);
+        x = ffma(vd[q], cs, x);
+        y = ffma(vd[q], sn, y);
+    };
+    if (nb == W) {
+#pragma unroll
+        for (int q = 0; q < W; q++) heading(q);
+#pragma unroll
+        for (int q = 0; q < W; q++) position(q);
+    } else {
+#pragma unroll
+        for (int q = 0; q < W; q++)
+            if (q < nb) {
+                heading(q);
+                position(q);
+            }
+    }
+}
+
 template <int W>
 SLAM_DEV void predict_batch_fs1_fast(float &x, float &y, float &th, const PredictArgs &A, const RngArgs &rng, int i, size_t S, const float *ctl,
                                      float dt, float iwb, const L2 &L, int s0, int nb) {
@@ -1206,7 +1251,7 @@ SLAM_DEV void persist_arrive(uint32_t *sync, bool cross_xcd) {
 }
 // invalidate: the workgroup goes on to read other workgroups' stores with plain loads (the helper; everybody when the placement
 // spans XCDs); the tiles read them with ldg<true> (device_math.h) and need no invalidate -- 1.2-1.7 us per iteration otherwise
-SLAM_DEV bool persist_pass(uint32_t *sync, uint32_t target, uint32_t max_spins, int *sh_ok, bool invalidate) {
+SLAM_DEV bool persist_pass(uint32_t *sync, uint32_t target, uint32_t max_spins, int *sh_ok, bool invalidate, bool lazy = false) {
     if (threadIdx.x == 0) {
         int ok = 1;
         uint32_t spins = 0;
@@ -1216,7 +1261,9 @@ SLAM_DEV bool persist_pass(uint32_t *sync, uint32_t target, uint32_t max_spins, 
                 ok = 0;
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            // (the helper and the drawers have microseconds to spare: they poll at leisure and leave the counter's line to the tiles)
+            if (lazy) __builtin_amdgcn_s_sleep(24);
+            else __builtin_amdgcn_s_sleep(1);
         }
         if (ok && __hip_atomic_load(sync + kPersistSyncAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ok = 0;
         if (invalidate) {
@@ -1248,21 +1295,27 @@ SLAM_DEV void persist_predraw(const PersistStep *qe, const RngArgs &rng_k, const
     }
 }
 
-// A drawer workgroup: the (V, G) normals of tile `tile`'s particles for the iteration whose queue entry is `qe`: ~1.9 us of Philox +
-// Box-Muller per iteration that need nothing but counters, made on a CU that would otherwise idle, an iteration ahead; the tile
-// picks them up with the block totals (update_step.inl).  The same function on the same counters as the tile would call.
+// A drawer workgroup: everything of the predicts of tile `tile`'s particles that needs no pose, for the iteration whose queue entry
+// is `qe`: the (V, G) normals (~1.9 us of Philox + Box-Muller per iteration that need nothing but counters), the perturbed
+// controls, V dt and sin(G / wheelBase) of the eight steps -- made on a CU that would otherwise idle, an iteration ahead; the tile
+// picks them up with the block totals (update_step.inl).  The same functions on the same values as the tile would call.
 SLAM_DEV void persist_draw(const PersistStep *qe, const RngArgs &rng, const Buffers &B, int tile, float4 *dst) {
 #ifdef SLAM_FAST_MATH
     const PredictArgs &PA = qe->PA;
     if (!persist_batch_draws(1, PA)) return;
     const int i = tile * kBlock + (int) threadIdx.x;
     const size_t S = (size_t) B.ncap;
-    float g0[8], g1[8];
-    draw_batch_fs1_fast<8>(g0, g1, PA, rng, i, S, reinterpret_cast<const float *>(qe->PA.steps), 0, PA.nsteps);
-    dst[i] = make_float4(g0[0], g0[1], g0[2], g0[3]);
-    dst[S + i] = make_float4(g0[4], g0[5], g0[6], g0[7]);
-    dst[2 * S + i] = make_float4(g1[0], g1[1], g1[2], g1[3]);
-    dst[3 * S + i] = make_float4(g1[4], g1[5], g1[6], g1[7]);
+    float g0[8], g1[8], vd[8], gs[8], sgw[8];
+    const float *ctl = reinterpret_cast<const float *>(qe->PA.steps);
+    draw_batch_fs1_fast<8>(g0, g1, PA, rng, i, S, ctl, 0, PA.nsteps);
+    const L2 Lq = llt2(PA.Q[0], PA.Q[2], PA.Q[3]);
+    controls_batch_fs1_fast<8>(vd, gs, sgw, g0, g1, PA, ctl, PA.dt, 1.0f / PA.wheel_base, Lq, PA.nsteps);
+    dst[i] = make_float4(vd[0], vd[1], vd[2], vd[3]);
+    dst[S + i] = make_float4(vd[4], vd[5], vd[6], vd[7]);
+    dst[2 * S + i] = make_float4(gs[0], gs[1], gs[2], gs[3]);
+    dst[3 * S + i] = make_float4(gs[4], gs[5], gs[6], gs[7]);
+    dst[4 * S + i] = make_float4(sgw[0], sgw[1], sgw[2], sgw[3]);
+    dst[5 * S + i] = make_float4(sgw[4], sgw[5], sgw[6], sgw[7]);
 #endif
 }
 
@@ -1364,7 +1417,7 @@ __global__ void __launch_bounds__(kBlock) update_persist_kernel(const float *__r
         }
         if (P.K > 0) persist_front(front_args(&qes[0]), f_x, f_y, f_lm, f_hd, kf + ka_small + offsetof(SmallObs, zf) / 4, h_pk, h_sets, h_aux, P.packets);
     }
-    const size_t draw_words = 4 * (size_t) B.ncap;  // float4s per buffer of PersistArgs::draws
+    const size_t draw_words = 6 * (size_t) B.ncap;  // float4s per buffer of PersistArgs::draws
     if (drawer && P.K > 0) persist_draw(&qes[0], rng, B, dtile, P.draws);
     persist_arrive(sync, true);
     if (!helper && !drawer && P.K > 0) persist_predraw<METHOD>(&qes[0], rng, B, i, carry);
@@ -1418,7 +1471,7 @@ __global__ void __launch_bounds__(kBlock) update_persist_kernel(const float *__r
         }
         persist_arrive(sync, cross);
         if (more && !helper && !drawer) persist_predraw<METHOD>(qn, rng, B, i, carry);  // (while the arrival travels)
-        alive = persist_pass(sync, members * (uint32_t) (it + 2), P.max_spins, &sh_ok, helper || cross);
+        alive = persist_pass(sync, members * (uint32_t) (it + 2), P.max_spins, &sh_ok, helper || cross, helper || drawer);
         SLAM_STAMP(13);  // barrier passed
     }
     // where the launch leaves things, for the host and the next launch: the Ctrl words (both slots: the set is plain, in

@@ -248,7 +248,7 @@ struct slamgpu_ctx {
     bool pq_ev_used = false;
     uint32_t *psync_dev = nullptr, *pstatus_host = nullptr;
     int32_t *ppk_dev = nullptr;          // [2][kSmallWords] observation packets of the loop's helper workgroup
-    float4 *pdraw_dev = nullptr;         // [2][4][ncap] draws of the loop's drawer workgroups (FastSLAM 1, fast build)
+    float4 *pdraw_dev = nullptr;         // [2][6][ncap] draws of the loop's drawer workgroups (FastSLAM 1, fast build)
     int64_t persist_launches = 0, persist_steps = 0;
     EstStage unplanned;           // the last update: resampling stage not run yet
     EstStage unreduced;           // an update whose partials exist (est_part[par]) but are not reduced yet
@@ -1454,7 +1454,7 @@ static int run_observe_persist(slamgpu_ctx *c, int32_t K, const int32_t *n_contr
         HIP_TRY(hipMalloc((void **) &c->psync_dev, sizeof(uint32_t) * kPersistSyncAlloc));
         HIP_TRY(hipMemsetAsync(c->psync_dev, 0, sizeof(uint32_t) * kPersistSyncAlloc, c->stream));
         HIP_TRY(hipMalloc((void **) &c->ppk_dev, sizeof(int32_t) * 2 * kSmallWords));
-        HIP_TRY(hipMalloc((void **) &c->pdraw_dev, sizeof(float4) * 2 * 4 * (size_t) c->B.ncap));
+        HIP_TRY(hipMalloc((void **) &c->pdraw_dev, sizeof(float4) * 2 * 6 * (size_t) c->B.ncap));
         HIP_TRY(hipHostMalloc((void **) &c->pstatus_host, 2 * sizeof(uint32_t), hipHostMallocDefault));
         c->pstatus_host[0] = c->pstatus_host[1] = 0;
         HIP_TRY(hipEventCreateWithFlags(&c->pq_ev, hipEventDisableTiming));

@@ -156,7 +156,7 @@
     }
     // ... and, FastSLAM 1 in the fast build: the (V, G) normals of this particle's eight predicts, made an iteration ahead by a
     // drawer workgroup (persist_draw): four 16-byte loads in flight with the totals instead of ~1.9 us of Philox + Box-Muller
-    float4 dq0 = make_float4(0.f, 0.f, 0.f, 0.f), dq1 = dq0, dq2 = dq0, dq3 = dq0;
+    float4 dq0 = make_float4(0.f, 0.f, 0.f, 0.f), dq1 = dq0, dq2 = dq0, dq3 = dq0, dq4 = dq0, dq5 = dq0;
     bool drawn = false;
     if constexpr (PERSIST) {
         drawn = carry.draw_src != nullptr && persist_batch_draws(METHOD, PA) && bid < nb;
@@ -166,6 +166,8 @@
             dq1 = ldg<true>(carry.draw_src + Sd + at);
             dq2 = ldg<true>(carry.draw_src + 2 * Sd + at);
             dq3 = ldg<true>(carry.draw_src + 3 * Sd + at);
+            dq4 = ldg<true>(carry.draw_src + 4 * Sd + at);
+            dq5 = ldg<true>(carry.draw_src + 5 * Sd + at);
         }
     }
     __shared__ int32_t pk[kSmallWords];
@@ -592,8 +594,7 @@
         float pg0[kEarly], pg1[kEarly];
         const bool early_draws = METHOD == 1 && !BIG && PA.nsteps > kEarly / 2 && PA.nsteps <= kEarly && PA.add_noise && !PA.use_heading && !PA.comp.valid;
         if (PERSIST && drawn) {
-            pg0[0] = dq0.x; pg0[1] = dq0.y; pg0[2] = dq0.z; pg0[3] = dq0.w; pg0[4] = dq1.x; pg0[5] = dq1.y; pg0[6] = dq1.z; pg0[7] = dq1.w;
-            pg1[0] = dq2.x; pg1[1] = dq2.y; pg1[2] = dq2.z; pg1[3] = dq2.w; pg1[4] = dq3.x; pg1[5] = dq3.y; pg1[6] = dq3.z; pg1[7] = dq3.w;
+            // (the pose-free half of the predicts came ready-made: applied below)
         } else if (early_draws) {
             draw_batch_fs1_fast<kEarly>(pg0, pg1, PA, rng, i, S, ctl, 0, PA.nsteps);
 #pragma unroll
@@ -630,7 +631,12 @@
                 predict_composite(x, y, th, P, PA.comp);
                 q00 = P.p00; q10 = P.p10; q11 = P.p11; q20 = P.p20; q21 = P.p21; q22 = P.p22;
             } else if (METHOD == 1 && PA.add_noise && !PA.use_heading) {
-                if (early_draws) {
+                if (PERSIST && drawn) {
+                    const float vd[kEarly] = {dq0.x, dq0.y, dq0.z, dq0.w, dq1.x, dq1.y, dq1.z, dq1.w};
+                    const float gs[kEarly] = {dq2.x, dq2.y, dq2.z, dq2.w, dq3.x, dq3.y, dq3.z, dq3.w};
+                    const float sgw[kEarly] = {dq4.x, dq4.y, dq4.z, dq4.w, dq5.x, dq5.y, dq5.z, dq5.w};
+                    apply_controls_fs1_fast<kEarly>(x, y, th, vd, gs, sgw, PA.nsteps);
+                } else if (early_draws) {
                     const L2 Lq = llt2(PA.Q[0], PA.Q[2], PA.Q[3]);
                     apply_batch_fs1_fast<kEarly>(x, y, th, pg0, pg1, PA, ctl, PA.dt, 1.0f / PA.wheel_base, Lq, 0, PA.nsteps);
                 } else {
