@@ -354,7 +354,15 @@ struct ResampleArgs {
     int32_t do_resample;    // SWITCH_RESAMPLE
     int32_t n_effective;    // NEFFECTIVE
     int32_t logw;           // log-weight context
+    int32_t planned;        // 1: resample_ref_kernel has planned this stage (decision in Ctrl.resampled, ancestors in keep[], the weights
+                            // normalised): resample_kernel only publishes the state and reduces the estimate partials
 };
+// Reference-order resampling stage (strict build, TAPE draws, at most kRefResampleMax particles): one block replays
+// resampleParticles / stratifiedResample (core.cpp:718-824) operation by operation -- float32 w / sum(w) with Eigen's packet-order
+// sum, Neff = 1 / sum(w^2) the same way, the serial float32 running prefix, `select[ctr] < cum[i]` -- so that Neff, the decision
+// and every ancestor are the reference's bit for bit (a double-precision block scan puts a stratum within a few float32 ulps of a
+// boundary on the other side: 8 of 5 000 ancestors at N = 5 000, rounds 3-4).
+constexpr int kRefResampleMax = 8192;
 
 // ---- sharded resampling (see kernels.hip) ---------------------------------------------------------------
 constexpr int kMaxShards = 64;
@@ -509,6 +517,9 @@ struct KernelTable {
     // stratified resample into keep[] (nothing is moved); estimate partials
     void (*resample)(hipStream_t, const Buffers &, const WeightScratch &, const RngArgs &, const ResampleArgs &,
                      const UpdateArgs &);
+    // the plan of that stage in the reference's own order of operations (kernels.h: kRefResampleMax); followed by `resample` with
+    // ResampleArgs::planned = 1
+    void (*resample_ref)(hipStream_t, const Buffers &, const WeightScratch &, const RngArgs &, const ResampleArgs &);
     // large contexts: prefix of this step's block totals into WeightScratch::scan[wpar] (one block)
     void (*scan)(hipStream_t, const WeightScratch &, int logw);
     // materialise a pending lazy gather (needed before anything but the next update touches the particle set)

@@ -1498,6 +1498,120 @@ __global__ void __launch_bounds__(kBlock) update_persist_kernel(const float *__r
 //   resample   : ancestor of output k = min{ i : select_k < cumsum_i } (core.cpp:800-806) into keep[slot ^ 1]; NOTHING
 //                is moved here: the next update launch (or gather_kernel) gathers through keep[].
 // ---------------------------------------------------------------------------------------------------
+// VectorXf::sum() of Eigen 3.1.3 as the reference's build runs it (Redux.h:200-240, SSE packets of four, unrolled by two, then the
+// SSE2 horizontal add; restated in oracle/slam_oracle.c: orc_eigen_sum and pinned there to the reference objects): v[i], or
+// v[i]^2 (= (float) pow((double) v[i], 2): the double product of two floats is exact, so one rounding either way), i < n.
+template <bool SQ>
+SLAM_DEV float eigen_order_sum(const float *v, int n) {
+    auto at = [&](int i) { return SQ ? v[i] * v[i] : v[i]; };
+    const int aligned2 = (n / 8) * 8, aligned = (n / 4) * 4;
+    float res;
+    if (aligned) {
+        float p00 = at(0), p01 = at(1), p02 = at(2), p03 = at(3);
+        if (aligned > 4) {
+            float p10 = at(4), p11 = at(5), p12 = at(6), p13 = at(7);
+            for (int i = 8; i < aligned2; i += 8) {
+                p00 = p00 + at(i);
+                p01 = p01 + at(i + 1);
+                p02 = p02 + at(i + 2);
+                p03 = p03 + at(i + 3);
+                p10 = p10 + at(i + 4);
+                p11 = p11 + at(i + 5);
+                p12 = p12 + at(i + 6);
+                p13 = p13 + at(i + 7);
+            }
+            p00 = p00 + p10;
+            p01 = p01 + p11;
+            p02 = p02 + p12;
+            p03 = p03 + p13;
+            if (aligned > aligned2) {
+                p00 = p00 + at(aligned2);
+                p01 = p01 + at(aligned2 + 1);
+                p02 = p02 + at(aligned2 + 2);
+                p03 = p03 + at(aligned2 + 3);
+            }
+        }
+        res = (p00 + p02) + (p01 + p03);
+        for (int i = aligned; i < n; i++) res = res + at(i);
+    } else {
+        res = at(0);
+        for (int i = 1; i < n; i++) res = res + at(i);
+    }
+    return res;
+}
+
+// resampleParticles' plan in the reference's order of operations (kernels.h: kRefResampleMax): ONE block.  The sums and the
+// running prefix are the reference's serial chains and run in one thread (eight independent accumulators in the sums); the
+// divisions, the squares, the write-back and the ancestor of every stratum are the block's.  `keep[ctr] = i while select[ctr] <
+// cum[i]` (core.cpp:800-806) assigns stratum ctr the first i with cum[i] > max(select[0..ctr]) -- the loop never moves back --
+// so every thread searches that prefix maximum in the prefix (both in LDS).  Dynamic LDS: two arrays of n floats.
+__global__ void __launch_bounds__(kBlock) resample_ref_kernel(Buffers B, WeightScratch ws, RngArgs rng, ResampleArgs ra) {
+#pragma clang fp contract(off)
+    extern __shared__ float ref_lds[];
+    __shared__ float sh_f[4];
+    __shared__ int sh_i[2];
+    const int n = B.n, t = threadIdx.x;
+    float *w = ref_lds, *sel = ref_lds + n;
+    Ctrl *ctrl = B.ctrl;
+    const int cur = ctrl->live[B.slot];
+    float4 *__restrict__ poseA = B.poseA[cur];
+    for (int i = t; i < n; i += kBlock) w[i] = poseA[i].w;
+    __syncthreads();
+    if (t == 0) sh_f[0] = eigen_order_sum<false>(w, n);  // ws = w.sum() (core.cpp:726; the same value again at :782)
+    __syncthreads();
+    const float wsum = sh_f[0];
+    for (int i = t; i < n; i += kBlock) w[i] = w[i] / wsum;  // (core.cpp:727-729 and :785: the same division)
+    __syncthreads();
+    if (t == 0) {
+        const float neff = 1 / eigen_order_sum<true>(w, n);  // (core.cpp:786-788)
+        const bool resample = ra.do_resample && (neff < (float) ra.n_effective);  // (core.cpp:739: float < int)
+        sh_f[1] = neff;
+        sh_i[0] = resample ? 1 : 0;
+        const double W = (double) wsum, Q = (double) wsum * (double) wsum / (double) neff;
+        ctrl->wsum = W;
+        ctrl->wsq = Q;
+        ctrl->wmax = 0.0;
+        ctrl->neff = neff;
+        ctrl->resampled = resample ? 1 : 0;
+        ctrl->status = weight_status(W, Q);
+        ws.est_part[ws.wpar][4 * (size_t) ws.nblocks] = (double) neff;
+        ws.est_part[ws.wpar][4 * (size_t) ws.nblocks + 1] = (double) ((resample ? 1 : 0) | (weight_status(W, Q) << 1));
+    }
+    __syncthreads();
+    if (!sh_i[0]) {  // Neff >= nMin: the particles keep the normalised weights (core.cpp:727-729)
+        for (int i = t; i < n; i += kBlock) poseA[i].w = w[i];
+        return;
+    }
+    // the strata and their running maximum (a block scan: a maximum is exact whatever the order)
+    for (int i = t; i < n; i += kBlock) sel[i] = rng.strata[i];
+    if (t == 0) {  // cumulativeSum (core.cpp:813-824): the serial float32 running sum, in place
+        float run = 0;
+        for (int i = 0; i < n; i++) {
+            run += w[i];
+            w[i] = run;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {  // (n <= 8 192: ~n compare-and-stores; a parallel scan would save ~10 us of the stage's ~40)
+        float m = sel[0];
+        for (int i = 1; i < n; i++) {
+            m = fmaxf(m, sel[i]);
+            sel[i] = m;
+        }
+    }
+    __syncthreads();
+    int32_t *__restrict__ keep = ws.keep[B.slot ^ 1];
+    for (int c = t; c < n; c += kBlock) {
+        const float s = sel[c];
+        int lo = 0, hi = n;  // first i with s < w[i]
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s < w[mid]) hi = mid; else lo = mid + 1;
+        }
+        keep[c] = lo < n ? lo : n - 1;  // (beyond the last cumulative weight: keep = -1 upstream, undefined when used; clamped as everywhere)
+    }
+}
+
 __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScratch ws, RngArgs rng, ResampleArgs ra,
                                                            UpdateArgs U) {
     extern __shared__ double off[];  // [nblocks + 1] exclusive prefix of the block totals
@@ -1511,6 +1625,30 @@ __global__ void __launch_bounds__(kBlock) resample_kernel(Buffers B, WeightScrat
 
     double W, Q, Mx;
     const bool logw = ra.logw != 0;
+    if (ra.planned) {
+        // resample_ref_kernel has made the plan (reference order of operations): the decision is in Ctrl, the ancestors are in
+        // keep[], the weights are normalised; what is left to this launch: the state for the next one and the estimate partials
+        const bool resample = ctrl->resampled != 0;
+        if (blockIdx.x == 0 && t == 0) {
+            ctrl->live[B.slot ^ 1] = cur;
+            ctrl->pend[B.slot ^ 1] = resample ? 1 : 0;
+        }
+        const int k = blockIdx.x * kBlock + t;
+        EstItem ei{0.0, 0.0, -3.0e38f, 0.0f, 0x7fffffff};
+        if (k < B.n) {
+            const float4 pa = B.poseA[cur][resample ? ws.keep[B.slot ^ 1][k] : k];
+            ei = EstItem{(double) pa.x, (double) pa.y, resample ? ctrl->inv_n : pa.w, pa.z, k};
+        }
+        ei = block_reduce_est(ei, sh_est);
+        if (t == 0) {
+            double *p = ws.est_part[ws.wpar] + (size_t) blockIdx.x * 4;
+            p[0] = ei.sx;
+            p[1] = ei.sy;
+            p[2] = (double) ei.th;
+            p[3] = (double) ei.w;
+        }
+        return;
+    }
     scan_block_totals(ws.blk_w[ws.wpar], nb, nb, logw, off, sh_a, sh_q, W, Q, Mx);  // one shard: [w(nb) | w2(nb)] contiguous
     // Neff = 1 / sum((w/W)^2)  (core.cpp:784-788)
     const float neff = neff_of(W, Q);
@@ -2790,6 +2928,10 @@ static void launch_resample(hipStream_t st, const Buffers &B, const WeightScratc
     hipLaunchKernelGGL(resample_kernel, dim3(ws.nblocks), dim3(kBlock), lds, st, B, ws, rng, ra, U);
 }
 
+static void launch_resample_ref(hipStream_t st, const Buffers &B, const WeightScratch &ws, const RngArgs &rng, const ResampleArgs &ra) {
+    hipLaunchKernelGGL(resample_ref_kernel, dim3(1), dim3(kBlock), sizeof(float) * 2 * (size_t) B.n, st, B, ws, rng, ra);
+}
+
 static void launch_scan(hipStream_t st, const WeightScratch &ws, int logw) {
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, st, ws, logw);
 }
@@ -2934,7 +3076,7 @@ static void launch_associate_grid(hipStream_t st, const Buffers &B, const AssocG
                        R4[0], R4[1], R4[2], R4[3], g1, g2, labels);
 }
 
-static const KernelTable kTable = {launch_update, launch_update_persist, launch_resample, launch_scan, launch_gather, launch_flatten, launch_identity, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat, launch_observe, launch_observe_book, launch_associate,
+static const KernelTable kTable = {launch_update, launch_update_persist, launch_resample, launch_resample_ref, launch_scan, launch_gather, launch_flatten, launch_identity, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat, launch_observe, launch_observe_book, launch_associate,
                                    launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish, launch_dist_gather, launch_dist_flags, launch_peek, launch_lmk_box, launch_assoc_grid,
                                    launch_associate_grid, launch_jacobians_multi};
 

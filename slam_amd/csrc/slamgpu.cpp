@@ -168,6 +168,8 @@ struct slamgpu_ctx {
         double *hist = nullptr;   // history slot its estimate belongs to (or null)
     };
     bool scan_ready = false;      // scan_kernel ran on the last update's block totals (large contexts)
+    bool ref_resample = false;    // the resampling stage replays the reference's order of operations (kernels.h: kRefResampleMax):
+                                  // strict build, the caller's draws (TAPE), a single context of at most 8 192 particles, linear weights
     bool consolidate = true;      // row consolidation of compact contexts (do_update); SLAMGPU_NO_CONSOLIDATE=1 turns it off
     int consolidate_above = kConsolidateAbove;  // (SLAMGPU_CONSOLIDATE_ABOVE: diagnostic)
     int plain_rows_target = kPlainRowsTarget;   // (SLAMGPU_PLAIN_ROWS_TARGET: diagnostic / tests)
@@ -625,6 +627,12 @@ int flush_stages(slamgpu_ctx *c) {
         ra.n_effective = c->cfg.n_effective;
         ra.logw = c->cfg.log_weights;
         c->ws.wpar = c->unplanned.par;
+        if (c->ref_resample) {
+            // the plan in the reference's own order of operations (one block), then the usual stage for what is left of it
+            Timed t(c, "resample_ref");
+            c->k->resample_ref(c->stream, c->B, c->ws, rng_args(c, c->unplanned.step), ra);
+            ra.planned = 1;
+        }
         {
             Timed t(c, "resample");
             c->k->resample(c->stream, c->B, c->ws, rng_args(c, c->unplanned.step), ra, UpdateArgs{});
@@ -737,6 +745,8 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     c->k = cfg->math_mode == SLAMGPU_MATH_FAST ? kernels_fast() : kernels_strict();
     if (const char *e = getenv("SLAMGPU_SCAN_MIN_BLOCKS")) c->scan_min_blocks = atoi(e);  // diagnostic
     c->consolidate = getenv("SLAMGPU_NO_CONSOLIDATE") == nullptr;                          // diagnostic / tests
+    c->ref_resample = cfg->math_mode != SLAMGPU_MATH_FAST && cfg->rng_mode == SLAMGPU_RNG_TAPE && n <= kRefResampleMax && !cfg->log_weights &&
+                      c->cfg.n_particles_global == c->cfg.n_particles && getenv("SLAMGPU_NO_REF_RESAMPLE") == nullptr;
     c->persist_ok = getenv("SLAMGPU_NO_PERSIST") == nullptr;                               // diagnostic / tests: slamgpu_run_observe as a loop of launches
     if (const char *e = getenv("SLAMGPU_CONSOLIDATE_ABOVE")) c->consolidate_above = atoi(e);
     if (const char *e = getenv("SLAMGPU_PLAIN_ROWS_TARGET")) c->plain_rows_target = atoi(e);
@@ -979,6 +989,10 @@ namespace {
 int issue_update(slamgpu_ctx *c, UpdateArgs &U, int n_new, int n_rows, bool need_normals, const float *normals, const float *strata, bool sharded) {
     const bool tape = c->cfg.rng_mode == SLAMGPU_RNG_TAPE;
     const int n = n_new;
+    // reference-order resampling (strict build, TAPE draws, small contexts): the stage of the previous update never rides in this
+    // launch: it runs now, as launches of its own, through resample_ref_kernel
+    if (c->ref_resample && !sharded && !c->dist && c->unplanned.has)
+        if (int rc = flush_stages(c)) return rc;
     // pending predicts ride inside the update launch (state stays in registers) unless their noise is a host tape
     PredictArgs PA{};
     if (c->pending.nsteps > 0) {

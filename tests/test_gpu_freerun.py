@@ -455,12 +455,14 @@ def test_config5_map_whole_run_ancestor_forced_log_weights(sg_mod, oracle, synma
     # evaluations of a 1 000-factor weight differ by percents (the sampled pose to 1e-4 m decides), so the yardstick is a float64
     # evaluation of the same update (tests/fs2_float64.py): measured over 25 such steps (gpurun_out/r4_free10k.log), median
     # |w / w64 - 1| of the float32 ORACLE 1.2e-2 .. 0.17, of the strict build the same to 2 digits (ratio 0.9 .. 1.14), of the
-    # fast build 0.5 .. 2.9 times the oracle's.  Bounds: 1.5x / 4x the oracle's own error.
+    # fast build 0.5 .. 2.9 times the oracle's (round 4, -ffp-contract=fast); round 5 (-ffp-contract=on: products fused with sums
+    # only where the source says so, so that two kernels that must agree bit for bit do): up to 4.8 times at one of the 25 steps
+    # (step 1729, 938 landmarks: GPU 0.167, oracle 0.035).  Bounds: 1.5x / 6x the oracle's own error.
     anchor_at = lambda k: k % 32 == 1 and k > 1
     st, inputs, QRdt, hist, final, final_exp = forced_run(sg_mod, oracle, "FASTSLAM2", N, seed, 100000, math_mode, True, threads=threads, args=args,
                                                           log_weights=True, full_at=full_at, on_step=on_step, weights_comparable=False,
                                                           anchor_at=anchor_at, pose_atol=(1.5e-3, 4e-3)[math_mode], lmk_atol=(2e-3, 7.5e-3)[math_mode],
-                                                          yardstick64=(1.5, 4.0)[math_mode],
+                                                          yardstick64=(1.5, 6.0)[math_mode],
                                                           # (one update over ~1 k landmarks from identical pre-states; measured 6.1e-5 / 3.7e-4 m)
                                                           anchor_pose_atol=(2e-4, 8e-4)[math_mode],
                                                           est_atol=(1e-3, 3e-3)[math_mode])   # (measured 1.9e-4 / 1.5e-3 m)

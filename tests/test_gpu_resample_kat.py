@@ -10,6 +10,12 @@ exists:
   inline  the plan at the head of the NEXT update launch (the product's one-launch-per-step pipeline); the ancestors are then
           read off the particles themselves (every particle carries its index in its pose).
 
+Round 5: the STRICT build with the caller's draws (TAPE) and at most 8 192 particles replays the reference's own order of operations
+(resample_ref_kernel: float32 w / sum(w) with Eigen's packet-order sum, Neff the same way, the serial float32 running prefix,
+`select[ctr] < cum[i]`): every ancestor, Neff and the normalised weights are the reference's BIT FOR BIT, for all five N, both
+ways the stage is reached.  What follows describes the general path, which the fast build (and every Philox / large / sharded
+context) takes:
+
 The device sums the UN-normalised weights in double (block totals + in-block prefixes) and compares `stratum * sum` with that
 prefix; the reference normalises in float32 (w / sum, serial float sum, core.cpp:726-729) and compares the stratum with a
 float32 cumulative sum that restarts from zero for every prefix (core.cpp:813-824).  The two can only differ where a stratum
@@ -86,10 +92,17 @@ def test_resample_stage_vs_reference_vectors(sg, kat, N, math_mode):
             got = s.download(landmarks=False)
             keep = np.rint(got["xv"][:, 0]).astype(np.int32)
             assert np.array_equal(got["xv"][:, 0], keep.astype(f32))
-            assert np.all(got["w"] == f32(1.0) / f32(N))
+            if math_mode == 0:
+                # (the read-out runs the SECOND update's stage: the reference's own normalisation of N weights of 1/N, whose
+                # float32 packet-order sum is 1 only to rounding)
+                np.testing.assert_allclose(got["w"], f32(1.0) / f32(N), rtol=2e-5)   # (7.7e-6 at N = 5000: eight float32 chains of 625 terms)
+            else:
+                assert np.all(got["w"] == f32(1.0) / f32(N))
             neff, did = None, True
         assert did
-        if neff is not None:
+        if neff is not None and math_mode == 0:
+            assert f32(neff) == f32(neff_ref), (neff, neff_ref)   # (the reference's own operations: the same float)
+        elif neff is not None:
             np.testing.assert_allclose(neff, neff_ref, rtol=2e-6)   # (double sums on the device, float32 in the reference)
             np.testing.assert_allclose(wsum, w.astype(np.float64).sum(), rtol=2e-7)   # (float32 prefixes inside a block of 256, double across blocks)
         assert np.all(np.diff(keep) >= 0) and keep.min() >= 0 and keep.max() < N
@@ -99,7 +112,8 @@ def test_resample_stage_vs_reference_vectors(sg, kat, N, math_mode):
         worst = max(worst, nbad)
         print("resample KAT N=%d %s %s: %d of %d ancestors differ from the reference's" % (N, ("strict", "fast")[math_mode], path, nbad, N))
         s.close()
-    assert worst <= (0 if N <= 1000 else 16), worst
+    # strict build: the reference's order of operations: no ancestor differs, at any N; fast build: the documented neighbours at N = 5000
+    assert worst <= (0 if (N <= 1000 or math_mode == 0) else 16), worst
 
 
 @pytest.mark.parametrize("N", [100, 1000])
@@ -112,11 +126,11 @@ def test_no_resample_above_threshold_normalises_like_the_reference(sg, kat, N):
     s.update(np.zeros((0, 2), f32), np.zeros(0, np.int32), np.zeros((0, 2), f32), np.array([[0.01, 0], [0, 3e-4]], f32), None, sel)
     neff, did, _ = s.stats()
     assert not did
-    np.testing.assert_allclose(neff, float(kat["res%d_neff" % N][0]), rtol=2e-6)
     got = s.download(landmarks=False)["w"]
-    ws = f32(0)
-    for x in w:              # the reference's serial float32 sum (core.cpp:726-729)
-        ws = f32(ws + x)
-    # the device divides by its double-precision sum rounded once; the reference's serial float32 sum is a few ulps off that at N = 1 000
-    np.testing.assert_allclose(got, w / ws, rtol=1e-6)
+    # round 5: the strict build divides by the reference's own sum (VectorXf::sum(), Eigen's packet order: core.cpp:726) in float32:
+    # the same weights bit for bit (the oracle's restatement of that sum is pinned to the reference objects)
+    from oracle import orc
+    ws = orc.Oracle().eigen_sum(w)
+    assert np.array_equal(got.view(np.uint32), (w / f32(ws)).astype(f32).view(np.uint32))
+    assert f32(neff) == f32(kat["res%d_neff" % N][0])
     s.close()
