@@ -119,7 +119,14 @@ enum {
      * capacities above 39: such a context keeps its observation packets in device memory (a ring written by the front-end
      * kernel).  Contexts of up to 39 landmarks make the observation inside the update launch and accept slamgpu_step_observe
      * with or without the flag. */
-    SLAMGPU_FLAG_DEVICE_OBSERVE = 1
+    SLAMGPU_FLAG_DEVICE_OBSERVE = 1,
+    /* (round 5) A strict-build context of at most 8 192 particles that takes the caller's draws (SLAMGPU_RNG_TAPE: the parity
+     * configuration) runs its resampling stage in the REFERENCE'S OWN ORDER OF OPERATIONS -- float32 w / sum(w) with Eigen's
+     * packet-order sum, Neff the same way, the serial float32 running prefix, `select < cum` (core.cpp:718-824) -- so that Neff,
+     * the decision and every ancestor are the reference's bit for bit (two extra small launches per step).  This flag turns that
+     * off: the context then scans in double like every other one (what a comparison with a sharded run of the same particles
+     * needs: shards always do). */
+    SLAMGPU_FLAG_NO_REFERENCE_RESAMPLE = 2
 };
 
 const char *slamgpu_last_error(void);

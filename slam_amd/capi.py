@@ -29,6 +29,7 @@ DECLARED_SYMBOLS = [
 ]
 ASSOC_AUTO, ASSOC_EXHAUSTIVE, ASSOC_GRID = 0, 1, 2
 FLAG_DEVICE_OBSERVE = 1
+FLAG_NO_REFERENCE_RESAMPLE = 2
 
 
 class SlamGpuError(RuntimeError):
@@ -295,7 +296,7 @@ class SlamGpu:
     def __init__(self, n_particles, max_landmarks, method=FASTSLAM2, n_effective=None, resample=True, use_heading=False,
                  add_predict_noise=None, wheel_base=4.0, sigma_phi=0.017453292519943, rng_mode=RNG_TAPE, seed=0,
                  math_mode=MATH_STRICT, device=0, first_particle=0, n_particles_global=0, external_stream=0, log_weights=False,
-                 device_observe=False):
+                 device_observe=False, reference_resample=True):
         self.L = load_library()
         cfg = Config()
         cfg.struct_size = C.sizeof(Config)
@@ -317,7 +318,7 @@ class SlamGpu:
         cfg.n_particles_global = ng
         cfg.external_stream = external_stream
         cfg.log_weights = int(log_weights)
-        cfg.flags = FLAG_DEVICE_OBSERVE if device_observe else 0
+        cfg.flags = (FLAG_DEVICE_OBSERVE if device_observe else 0) | (0 if reference_resample else FLAG_NO_REFERENCE_RESAMPLE)
         self.cfg = cfg
         self.N = n_particles
         self.h = C.c_void_p()

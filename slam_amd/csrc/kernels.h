@@ -40,6 +40,11 @@ constexpr int kSmallRows = 40;      // contexts with at most this many genealogy
                                     // resample composes ceil(rows / 4) chunks per particle with one wide load + store each,
                                     // and their observation packets always travel as kernel arguments
 constexpr int kSmallObs = kSmallRows;  // ... so a packet holds up to this many zf / zn
+constexpr int kMidLandmarks = 256;  // (round 5) single contexts of up to this many landmarks are compact too: with row consolidation a map
+                                    // of a few hundred landmarks lives in a handful of genealogy rows (example_loop902: 117 landmarks,
+                                    // <= 6 re-observed per step), and what sizes the compact layout is the ROWS and the packet, not the
+                                    // landmarks.  A step that does not fit the packet (more than kSmallObs re-observed or new landmarks)
+                                    // or the rows moves the context to plain rows for good (slamgpu.cpp: demote_to_plain)
 constexpr int kRowsPerRole = 16;    // genealogy rows composed by one copy role (x 256 particles)
 constexpr int kRowLiveBit = 1 << 30;  // packet row[k]: the landmark's live record buffer rides in bit 30 of its genealogy row
 constexpr int kRowFreshBit = 1 << 29; // packet row[k]: the landmark was written by the PREVIOUS update and nothing has composed its
@@ -528,6 +533,8 @@ struct KernelTable {
     void (*flatten)(hipStream_t, const Buffers &, int nf);
     // identity ("own slot") in genealogy row `row` of gen[which]
     void (*identity)(hipStream_t, const Buffers &, int which, int row);
+    // genealogy rows from the compact layout (src: [ceil(rows / 4)][ncap][4]) into plain rows (dst: [rows][ncap]); src != dst
+    void (*decompact)(hipStream_t, const int32_t *src, int32_t *dst, int ncap, int rows);
     // reduce the estimate partials est_part[par] now (-> Ctrl.est, history slot)
     void (*finish)(hipStream_t, const Buffers &, const WeightScratch &, double *hist, int par);
     void (*predict)(hipStream_t, const Buffers &, const PredictArgs &, const RngArgs &);

@@ -559,7 +559,9 @@ SLAM_DEV void scan_finish(const ScanLoads L, const float *__restrict__ tot, int 
         if (lo < hi) acc(lo, L.tv0, L.qv0, L.mv0);
         if (lo + 1 < hi) acc(lo + 1, L.tv1, L.qv1, L.mv1);
     } else if (stab) {
-        // the table is in LDS (scan_issue_dma): every wave's requests must have landed before anybody reads
+        // the table is in LDS (scan_issue_dma): every wave's requests must have landed before anybody reads.  (The wait is spelt
+        // out: gfx950's barrier does not imply it, and a workgroup-scope fence need not wait on vmcnt: ADVICE r4)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         const float *qtab = stab + scan_pad(nb);
         for (int k = lo; k < hi; k++) acc(k, stab[k], qtab[k], 0.0f);
@@ -1779,11 +1781,27 @@ __global__ void __launch_bounds__(kBlock) flatten_kernel(Buffers B, int nf) {
 
 // One block: the scan every block of a small context does for itself (scan_block_totals: same association, so the
 // results are bit-identical), once, into global memory: [0..nb] exclusive prefix, [nb+1] sum w, [nb+2] sum w^2.
-__global__ void __launch_bounds__(kBlock) scan_kernel(WeightScratch ws, int logw) {
+// Round 5: with the prefix built in global memory every thread re-read its own 16 stores one dependent trip at a time, and its
+// totals came in four dependent batches: 12.9 us for 3 912 totals (11.6 % of a config-4 step).  lds_mode (linear weights, the
+// table fits): the whole table by LDS-DMA, all requests in flight at once (scan_issue_dma), the prefix built in LDS, one coalesced
+// copy out.  Same operations in the same order: the same bits.
+__host__ __device__ inline size_t scan_lds_bytes(int nb) { return sizeof(double) * (((size_t) nb + 2) & ~(size_t) 1) + 2 * sizeof(float) * (((size_t) nb + 255) & ~(size_t) 255); }
+__global__ void __launch_bounds__(kBlock) scan_kernel(WeightScratch ws, int logw, int lds_mode) {
     __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
+    extern __shared__ __align__(16) unsigned char scan_lds[];
     double W, Q, Mx;
     double *out = ws.scan[ws.wpar];
-    scan_block_totals(ws.blk_w[ws.wpar], ws.nblocks, ws.nblocks, logw != 0, out, sh_a, sh_q, W, Q, Mx);
+    if (lds_mode) {
+        const int nb = ws.nblocks;
+        double *off = reinterpret_cast<double *>(scan_lds);
+        float *stab = reinterpret_cast<float *>(scan_lds + sizeof(double) * (((size_t) nb + 2) & ~(size_t) 1));
+        scan_issue_dma(ws.blk_w[ws.wpar], nb, nb, stab);
+        scan_finish(ScanLoads{0.0f, 0.0f, 0.0f, 0.0f, -INFINITY, -INFINITY}, ws.blk_w[ws.wpar], nb, nb, false, off, sh_a, sh_q, W, Q, Mx, stab);
+        __syncthreads();
+        for (int k = threadIdx.x; k <= nb; k += kBlock) out[k] = off[k];
+    } else {
+        scan_block_totals(ws.blk_w[ws.wpar], ws.nblocks, ws.nblocks, logw != 0, out, sh_a, sh_q, W, Q, Mx);
+    }
     if (threadIdx.x == 0) {
         out[ws.nblocks + 1] = W;
         out[ws.nblocks + 2] = Q;
@@ -2933,7 +2951,9 @@ static void launch_resample_ref(hipStream_t st, const Buffers &B, const WeightSc
 }
 
 static void launch_scan(hipStream_t st, const WeightScratch &ws, int logw) {
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, st, ws, logw);
+    const size_t need = scan_lds_bytes(ws.nblocks);
+    const bool lds_mode = !logw && ws.nblocks > 2 * kBlock && need <= 64 * 1024 - 256;
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), lds_mode ? need : 0, st, ws, logw, lds_mode ? 1 : 0);
 }
 
 static void launch_gather(hipStream_t st, const Buffers &B, const WeightScratch &ws) {
@@ -2949,6 +2969,24 @@ __global__ void __launch_bounds__(kBlock) identity_kernel(int32_t *gen, int comp
 
 static void launch_identity(hipStream_t st, const Buffers &B, int which, int row) {
     hipLaunchKernelGGL(identity_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B.gen[which], B.compact, row, B.ncap, B.first);
+}
+
+// compact genealogy rows -> plain rows (slamgpu.cpp: demote_to_plain)
+__global__ void __launch_bounds__(kBlock) decompact_kernel(const int32_t *__restrict__ src, int32_t *__restrict__ dst, int ncap, int rows) {
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= ncap) return;
+    const int4 *__restrict__ s4 = reinterpret_cast<const int4 *>(src);
+    for (int c = 0; c < (rows + 3) / 4; c++) {
+        const int4 q = s4[(size_t) c * ncap + k];
+        const int v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (4 * c + j < rows) dst[(size_t) (4 * c + j) * ncap + k] = v[j];
+    }
+}
+
+static void launch_decompact(hipStream_t st, const int32_t *src, int32_t *dst, int ncap, int rows) {
+    hipLaunchKernelGGL(decompact_kernel, dim3(ncap / kBlock), dim3(kBlock), 0, st, src, dst, ncap, rows);
 }
 
 static void launch_flatten(hipStream_t st, const Buffers &B, int nf) {
@@ -3076,7 +3114,7 @@ static void launch_associate_grid(hipStream_t st, const Buffers &B, const AssocG
                        R4[0], R4[1], R4[2], R4[3], g1, g2, labels);
 }
 
-static const KernelTable kTable = {launch_update, launch_update_persist, launch_resample, launch_resample_ref, launch_scan, launch_gather, launch_flatten, launch_identity, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat, launch_observe, launch_observe_book, launch_associate,
+static const KernelTable kTable = {launch_update, launch_update_persist, launch_resample, launch_resample_ref, launch_scan, launch_gather, launch_flatten, launch_identity, launch_decompact, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat, launch_observe, launch_observe_book, launch_associate,
                                    launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish, launch_dist_gather, launch_dist_flags, launch_peek, launch_lmk_box, launch_assoc_grid,
                                    launch_associate_grid, launch_jacobians_multi};
 

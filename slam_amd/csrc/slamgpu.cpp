@@ -168,6 +168,7 @@ struct slamgpu_ctx {
         double *hist = nullptr;   // history slot its estimate belongs to (or null)
     };
     bool scan_ready = false;      // scan_kernel ran on the last update's block totals (large contexts)
+    bool mid_compact = false;     // compact layout on a map of more than 39 landmarks (kernels.h: kMidLandmarks): host-made packets only
     bool ref_resample = false;    // the resampling stage replays the reference's order of operations (kernels.h: kRefResampleMax):
                                   // strict build, the caller's draws (TAPE), a single context of at most 8 192 particles, linear weights
     bool consolidate = true;      // row consolidation of compact contexts (do_update); SLAMGPU_NO_CONSOLIDATE=1 turns it off
@@ -746,7 +747,8 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     if (const char *e = getenv("SLAMGPU_SCAN_MIN_BLOCKS")) c->scan_min_blocks = atoi(e);  // diagnostic
     c->consolidate = getenv("SLAMGPU_NO_CONSOLIDATE") == nullptr;                          // diagnostic / tests
     c->ref_resample = cfg->math_mode != SLAMGPU_MATH_FAST && cfg->rng_mode == SLAMGPU_RNG_TAPE && n <= kRefResampleMax && !cfg->log_weights &&
-                      c->cfg.n_particles_global == c->cfg.n_particles && getenv("SLAMGPU_NO_REF_RESAMPLE") == nullptr;
+                      c->cfg.n_particles_global == c->cfg.n_particles && !(cfg->flags & SLAMGPU_FLAG_NO_REFERENCE_RESAMPLE) &&
+                      getenv("SLAMGPU_NO_REF_RESAMPLE") == nullptr;
     c->persist_ok = getenv("SLAMGPU_NO_PERSIST") == nullptr;                               // diagnostic / tests: slamgpu_run_observe as a loop of launches
     if (const char *e = getenv("SLAMGPU_CONSOLIDATE_ABOVE")) c->consolidate_above = atoi(e);
     if (const char *e = getenv("SLAMGPU_PLAIN_ROWS_TARGET")) c->plain_rows_target = atoi(e);
@@ -792,7 +794,19 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     c->B.slot = 0;
     c->B.cap_rows = cap_nf + 1;  // at most one row per landmark, plus the one a step opens while the old ones are still read
     c->B.compact = c->B.cap_rows <= kSmallRows ? 1 : 0;
-    if (getenv("SLAMGPU_NO_COMPACT")) c->B.compact = 0;  // diagnostic: plain rows for a small map
+    // maps of 40 .. kMidLandmarks landmarks (round 5): compact as well -- kSmallRows genealogy rows, packets in the kernel
+    // arguments -- unless the context is going to make its observations on the device (that front end writes plain-row packets)
+    if (!c->B.compact && cap_nf <= kMidLandmarks && !(cfg->flags & SLAMGPU_FLAG_DEVICE_OBSERVE) && c->cfg.n_particles_global == c->cfg.n_particles &&
+        getenv("SLAMGPU_NO_MID_COMPACT") == nullptr) {
+        c->B.compact = 1;
+        c->B.cap_rows = kSmallRows;
+        c->mid_compact = true;
+    }
+    if (getenv("SLAMGPU_NO_COMPACT")) {  // diagnostic: plain rows for a small map
+        c->B.compact = 0;
+        c->B.cap_rows = cap_nf + 1;
+        c->mid_compact = false;
+    }
     c->erow.assign((size_t) cap_nf, 0);
     c->live_flag.assign((size_t) cap_nf, 0);
     c->seen_step.assign((size_t) cap_nf, 0);
@@ -1116,6 +1130,40 @@ int issue_update(slamgpu_ctx *c, UpdateArgs &U, int n_new, int n_rows, bool need
     return 0;
 }
 
+// A compact context on a map of more than 39 landmarks (mid_compact) meets a step its layout cannot take -- more re-observed or
+// new landmarks than a kernel-argument packet holds, or no genealogy row left: it becomes a plain-row context for good.  The
+// records stay where they are (both layouts index the same slots); the genealogy rows are rewritten from the interleaved form
+// (four rows to a 16-byte chunk) into whole rows, and the host's row tables grow to one row per landmark.
+int demote_to_plain(slamgpu_ctx *c) {
+    if (!c->mid_compact) return fail(SLAMGPU_ERR_INVALID, "not a compact context of a mid-size map");
+    if (int rc = materialize(c)) return rc;  // (no pending gather: the set is plain in the live buffers)
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const size_t S = (size_t) c->B.ncap, words = S * (size_t) kSmallRows;
+    int32_t *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **) &tmp, sizeof(int32_t) * words));
+    for (int b = 0; b < 2; b++) {
+        HIP_TRY(hipMemcpyAsync(tmp, c->B.gen[b], sizeof(int32_t) * words, hipMemcpyDeviceToDevice, c->stream));
+        c->k->decompact(c->stream, tmp, c->B.gen[b], c->B.ncap, kSmallRows);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void) hipFree(tmp);
+    const int old_rows = c->B.cap_rows, new_rows = c->B.cap_nf + 1;
+    c->B.compact = 0;
+    c->B.cap_rows = new_rows;
+    c->mid_compact = false;
+    c->refcnt.resize((size_t) new_rows, 0);
+    c->live_pos.resize((size_t) new_rows, -1);
+    for (int r = old_rows; r < new_rows; r++) c->free_rows.push_back(r);
+    std::sort(c->free_rows.begin(), c->free_rows.end(), std::greater<int32_t>());  // back() = lowest free row
+    (void) hipFree(c->rows_dev);
+    c->rows_dev = nullptr;
+    HIP_TRY(hipMalloc((void **) &c->rows_dev, sizeof(int32_t) * (size_t) new_rows));
+    c->fresh_row = -1;
+    c->tables_dirty = true;
+    return 0;
+}
+
 int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, const float *zn, int32_t n,
               const float R[4], const float *normals, const float *strata, bool sharded) {
     if (m < 0 || n < 0 || !R || (m > 0 && (!zf || !idf)) || (n > 0 && !zn)) return fail(SLAMGPU_ERR_INVALID, "bad observation packet");
@@ -1128,6 +1176,10 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     const bool need_normals = c->cfg.method == SLAMGPU_FASTSLAM2 && (m > 0 || n > 0);
     if (tape && ((need_normals && !normals) || !strata)) return fail(SLAMGPU_ERR_INVALID, "TAPE mode needs normals[3N] and strata[N]");
     HIP_TRY(hipSetDevice(c->cfg.device));
+    // a compact context's packet rides in the kernel arguments: at most kSmallObs re-observed and kSmallObs new landmarks, and its
+    // genealogy has kSmallRows rows.  Maps of up to 39 landmarks cannot exceed either; a mid-size map that does goes to plain rows
+    if (c->mid_compact && (m > kSmallObs || n > kSmallObs || c->free_rows.size() < 2))
+        if (int rc = demote_to_plain(c)) return rc;
     c->obs_step++;
 
     // genealogy rows: the landmarks this update writes move to a row it opens; the rows they leave may become unused
@@ -1298,7 +1350,7 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
 int do_update_dev(slamgpu_ctx *c, const float xtrue[3], float max_range, const float R[4], int32_t noise, const float *r1,
                   const float *r2, const float *normals, const float *strata) {
     if (!c->map_dev) return fail(SLAMGPU_ERR_INVALID, "no map: call slamgpu_set_map first");
-    if (!c->B.compact && !(c->cfg.flags & SLAMGPU_FLAG_DEVICE_OBSERVE))
+    if ((!c->B.compact || c->mid_compact) && !(c->cfg.flags & SLAMGPU_FLAG_DEVICE_OBSERVE))
         return fail(SLAMGPU_ERR_INVALID, "create the context with SLAMGPU_FLAG_DEVICE_OBSERVE (its observation packets live in device memory)");
     if (c->dist || c->cfg.n_particles_global != c->cfg.n_particles) return fail(SLAMGPU_ERR_INVALID, "slamgpu_step_observe: single contexts only");
     if (c->map_n > c->B.cap_nf) return fail(SLAMGPU_ERR_CAPACITY, "map of %d landmarks, capacity %d", c->map_n, c->B.cap_nf);
@@ -1544,7 +1596,7 @@ int slamgpu_run_observe(slamgpu_ctx *c, int32_t K, const int32_t *n_controls, co
     if (c->cfg.rng_mode == SLAMGPU_RNG_TAPE) return fail(SLAMGPU_ERR_INVALID, "slamgpu_run_observe: TAPE-mode contexts take their draws per iteration (slamgpu_step_observe)");
     if (K == 0) return 0;
     if (!c->map_dev) return fail(SLAMGPU_ERR_INVALID, "slamgpu_run_observe: no map: call slamgpu_set_map first");
-    if (!c->B.compact && !(c->cfg.flags & SLAMGPU_FLAG_DEVICE_OBSERVE))
+    if ((!c->B.compact || c->mid_compact) && !(c->cfg.flags & SLAMGPU_FLAG_DEVICE_OBSERVE))
         return fail(SLAMGPU_ERR_INVALID, "slamgpu_run_observe: create the context with SLAMGPU_FLAG_DEVICE_OBSERVE (its observation packets live in device memory)");
     if (c->dist || c->cfg.n_particles_global != c->cfg.n_particles) return fail(SLAMGPU_ERR_INVALID, "slamgpu_run_observe: single contexts only");
     if (c->map_n > c->B.cap_nf) return fail(SLAMGPU_ERR_CAPACITY, "slamgpu_run_observe: map of %d landmarks, capacity %d", c->map_n, c->B.cap_nf);

@@ -415,17 +415,24 @@ def test_full_size_philox_vs_oracle(sg, oracle, math_mode):
     Q, R, dt = o.noise()
     s = sg.SlamGpu(N, o.nlm, method=2, n_effective=algo.n_effective, wheel_base=algo.wheel_base, rng_mode=sg.RNG_PHILOX, seed=7,
                    math_mode=math_mode)
+    # a shadow context that never resamples (NEFFECTIVE 0), stepped in lockstep from the same teacher-forced states with the same
+    # Philox keys: its download is the real context's PRE-resample set with the device's own normalised weights
+    shadow = sg.SlamGpu(N, o.nlm, method=2, n_effective=0, wheel_base=algo.wheel_base, rng_mode=sg.RNG_PHILOX, seed=7, math_mode=math_mode)
     k = resamples = 0
     while k < 8:   # (the sixth observation step is the first that resamples)
         a = o.control()
         x, vg = o.true_pose()
         s.predict(float(vg[0]), float(vg[1]), Q, float(dt), float(x[2]))
+        shadow.predict(float(vg[0]), float(vg[1]), Q, float(dt), float(x[2]))
         if a == 1:
             o.observe_local()
             pre = o.particles()   # the set the resampling stage draws from
+            sel = o.last_tape()[1].astype(np.float64)   # the strata of this step (Philox stream 1: the device draws the same)
             own_keep = o.resample()
             ob = o.last_obs()
             s.update(ob["zf"], ob["idf"], ob["zn"], R)
+            shadow.update(ob["zf"], ob["idf"], ob["zn"], R)
+            w_dev = shadow.download(landmarks=False)["w"].astype(np.float64)
             k += 1
             got, exp = s.download(), o.particles()
             ne_o, did_o = o.last_resample()
@@ -444,9 +451,25 @@ def test_full_size_philox_vs_oracle(sg, oracle, math_mode):
                 # goes through the GPU's own ancestors: all particles, no share exempted)
                 assert np.abs(got["xv"] - pre["xv"][keep]).max() <= 5e-4, (k, np.abs(got["xv"] - pre["xv"][keep]).max())
                 assert np.abs(got["xf"] - pre["xf"][keep]).max() <= POSE_ATOL * 5, k
-                # ... and the ancestors themselves are the oracle's up to a few neighbours for most strata
+                # ... and the ancestors themselves, EVERY stratum (round 5; before: "at most 10 % of them more than eight particles
+                # from the oracle's").  The oracle's list is drawn from the ORACLE's weights, which differ from the device's by the
+                # weight noise of this file's tables, so it cannot pin an index at 10^5 particles; the device's own weights can: with
+                # C = the float64 cumulative sum of the device's normalised weights (the shadow context) and t_i the stratum,
+                # ancestor a must satisfy C[a-1] <= t_i < C[a] up to what float32 arithmetic can move a cumulative position: the
+                # in-block prefix (a scan of 256: <= 8 roundings), the normalisation (2), some slack: 16 * 2^-24 * C[a] -- a tenth of a
+                # stratum's width at the far end (core.cpp:800-806 on the device's sums).
+                C = np.cumsum(w_dev)
+                assert abs(C[-1] - 1.0) < 1e-4
+                lo = np.where(keep > 0, C[np.maximum(keep - 1, 0)], 0.0)
+                hi = C[keep]
+                tol = 16.0 * 2.0 ** -24 * hi + 1e-12
+                last = keep == N - 1   # (a stratum beyond the last cumulative weight is clamped to the last particle)
+                assert np.all(sel >= lo - tol), (k, int(np.argmax(lo - tol - sel)), float((lo - tol - sel).max()))
+                assert np.all((sel < hi + tol) | last), (k, int(np.argmax(sel - hi - tol)), float((sel - hi - tol)[~last].max()))
+                # (for the record: how far the oracle's own list, drawn from ITS weights, is from the device's)
                 d = np.abs(keep.astype(np.int64) - own_keep.astype(np.int64))
-                assert (d > 8).mean() <= 0.1, (k, (d > 8).mean())
+                print("N=1e5 %s step %d: ancestors vs the oracle's own list: identical %.3f, one off %.3f, more than eight off %.4f"
+                      % (("strict", "fast")[math_mode], k, (d == 0).mean(), (d == 1).mean(), (d > 8).mean()))
             else:
                 # same Philox bits; Box-Muller through device libm (fast build: the hardware v_log / v_sin / v_cos) instead of
                 # glibc: poses agree to ~1e-5
@@ -456,8 +479,10 @@ def test_full_size_philox_vs_oracle(sg, oracle, math_mode):
                     (k, np.median(rel), np.quantile(rel, 0.99))
             np.testing.assert_allclose(s.estimate()[:2], o.estimate()[:2], atol=2e-3)
             s.upload(exp)
+            shadow.upload(exp)
     assert resamples >= 1
     s.close()
+    shadow.close()
     o.close()
 
 

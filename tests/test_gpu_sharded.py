@@ -17,7 +17,9 @@ def tape():
 
 
 def run_single(sg, tape, rng_mode, tapes=None):
-    s = sg.SlamGpu(N, tape["nlm"], method=sg.FASTSLAM2, n_effective=int(0.75 * N), rng_mode=rng_mode, seed=7)
+    # (reference_resample=False: the comparison is with shards, which always scan in double; a small strict TAPE context on its own
+    # would replay the reference's float32 order of operations: include/slamgpu.h: SLAMGPU_FLAG_NO_REFERENCE_RESAMPLE)
+    s = sg.SlamGpu(N, tape["nlm"], method=sg.FASTSLAM2, n_effective=int(0.75 * N), rng_mode=rng_mode, seed=7, reference_resample=False)
     out = []
     for k, st in enumerate(tape["steps"]):
         for (V, G, phi) in st["controls"]:
