@@ -433,6 +433,12 @@ class SlamGpu:
         _chk(self.L.slamgpu_genealogy_rows(self.h, C.byref(a), C.byref(b)))
         return a.value
 
+    def genealogy_rows(self):
+        """(rows in use, row capacity) (slamgpu_genealogy_rows): capacity 40 = the compact layout"""
+        a, b = C.c_int32(), C.c_int32()
+        _chk(self.L.slamgpu_genealogy_rows(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def persist_info(self, cross=False):
         """(launches, iterations[, cross_xcd]) of the persistent step loop behind run_observe (slamgpu_persist_info)"""
         a, b, x = C.c_int64(), C.c_int64(), C.c_int32()

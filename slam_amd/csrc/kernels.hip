@@ -300,6 +300,62 @@ SLAM_DEV void predict_steps_fs1_fast(float &x, float &y, float &th, const Predic
 }
 #endif
 
+// FastSLAM2::predictState + observeHeading -> josephUpdate (fastslam2.cpp:70-125, core.cpp:294-317) x nsteps in the fast build's
+// arithmetic (round 5): three of the four bundled maps observe the heading (SWITCH_HEADING_KNOWN), which makes every step depend
+// on the particle's own heading, so the queued steps cannot be folded into one (predict_composite) -- and predict_steps replays
+// the reference's full 3x3 products, ~190 instructions per step.  Here: symmetric-packed covariance; Gv Pv Gv^T as the rank-one
+// form of predict_composite; Gu Q Gu^T from the host-evaluated sin(G), cos(G); the heading update with H = (0 0 1) in gain form,
+// P - K (H P) (equal to the Joseph form in exact arithmetic for the optimal gain the reference computes; the reference's
+// "+ 2.2204e-16 I" kept): ~60 instructions per step.  Same tolerances as the rest of the fast build (tests/test_gpu_parity.py).
+SLAM_DEV void predict_steps_heading_fast(float &x, float &y, float &th, Sym3 &P, const PredictArgs &A, const float *ctl) {
+    const float dt = A.dt, iwb = 1.0f / A.wheel_base;
+    const float q00 = A.Q[0], q10 = 0.5f * (A.Q[1] + A.Q[2]), q11 = A.Q[3];
+    const float Rphi = A.sigma_phi * A.sigma_phi;
+    const float eps = (float) (2.2204 * 1e-16);
+    for (int s = 0; s < A.nsteps; s++) {
+        const float V = ctl ? ctl[8 * s] : A.steps[s].V, G = ctl ? ctl[8 * s + 1] : A.steps[s].G;
+        const float phi = ctl ? ctl[8 * s + 2] : A.steps[s].phi_true;
+        const float sinG = ctl ? ctl[8 * s + 4] : A.steps[s].sinG, cosG = ctl ? ctl[8 * s + 5] : A.steps[s].cosG;
+        const float sgw = ctl ? ctl[8 * s + 6] : A.steps[s].sinGw;
+        float sn, cs;
+        sincos_cw(G + th, sn, cs);
+        const float vd = V * dt;
+        // Gv Pv Gv^T, Gv = I + (f0, f1, 0)^T e3^T
+        const float f0 = -vd * sn, f1 = vd * cs;
+        const float n20 = ffma(f0, P.p22, P.p20), n21 = ffma(f1, P.p22, P.p21);
+        const float n00 = ffma(f0, P.p20 + n20, P.p00);
+        const float n10 = ffma(f1, P.p20, ffma(f0, n21, P.p10));
+        const float n11 = ffma(f1, P.p21 + n21, P.p11);
+        // Gu Q Gu^T, Gu = [[dt cs, -vd sn], [dt sn, vd cs], [dt sinG / wb, vd cosG / wb]]
+        const float g00 = dt * cs, g01 = f0, g10 = dt * sn, g11 = f1, g20 = dt * sinG * iwb, g21 = vd * cosG * iwb;
+        const float u00 = ffma(g00, q00, g01 * q10), u01 = ffma(g00, q10, g01 * q11);
+        const float u10 = ffma(g10, q00, g11 * q10), u11 = ffma(g10, q10, g11 * q11);
+        const float u20 = ffma(g20, q00, g21 * q10), u21 = ffma(g20, q10, g21 * q11);
+        float p00 = n00 + ffma(u00, g00, u01 * g01);
+        float p10 = n10 + ffma(u10, g00, u11 * g01);
+        float p11 = n11 + ffma(u10, g10, u11 * g11);
+        float p20 = n20 + ffma(u20, g00, u21 * g01);
+        float p21 = n21 + ffma(u20, g10, u21 * g11);
+        float p22 = P.p22 + ffma(u20, g20, u21 * g21);
+        x = ffma(vd, cs, x);
+        y = ffma(vd, sn, y);
+        th = wrap_pi(ffma(vd, sgw, th));  // sin(G / wheelBase): upstream quirk (fastslam2.cpp:103)
+        // observeHeading: v = wrap(phi - th), S = P22 + R, K = P(:, 2) / S
+        const float v = wrap_pi(phi - th);
+        const float si = __builtin_amdgcn_rcpf(p22 + Rphi);
+        const float k0 = p20 * si, k1 = p21 * si, k2 = p22 * si;
+        x = ffma(k0, v, x);
+        y = ffma(k1, v, y);
+        th = ffma(k2, v, th);
+        P.p00 = ffma(-k0, p20, p00) + eps;
+        P.p10 = ffma(-k1, p20, p10);
+        P.p11 = ffma(-k1, p21, p11) + eps;
+        P.p20 = ffma(-k2, p20, p20);
+        P.p21 = ffma(-k2, p21, p21);
+        P.p22 = ffma(-k2, p22, p22) + eps;
+    }
+}
+
 // All queued predicts as one step (PredictComposite, kernels.h): one sincos and ~60 FMAs per particle instead of
 // ~190 instructions per queued predict.
 SLAM_DEV void predict_composite(float &x, float &y, float &th, Sym3 &P, const PredictComposite &C) {
@@ -338,6 +394,16 @@ __global__ void __launch_bounds__(kBlock) predict_kernel(Buffers B, PredictArgs 
         const float2 c = B.poseC[cur][i];
         Sym3 P = {b.x, b.y, b.z, b.w, c.x, c.y};
         predict_composite(a.x, a.y, a.z, P, A.comp);
+        B.poseA[cur][i] = a;
+        B.poseB[cur][i] = make_float4(P.p00, P.p10, P.p11, P.p20);
+        B.poseC[cur][i] = make_float2(P.p21, P.p22);
+        return;
+    }
+    if (A.method == 2 && A.use_heading && !A.add_noise) {  // (the same arithmetic as inside the update launch)
+        const float4 b = B.poseB[cur][i];
+        const float2 c = B.poseC[cur][i];
+        Sym3 P = {b.x, b.y, b.z, b.w, c.x, c.y};
+        predict_steps_heading_fast(a.x, a.y, a.z, P, A, nullptr);
         B.poseA[cur][i] = a;
         B.poseB[cur][i] = make_float4(P.p00, P.p10, P.p11, P.p20);
         B.poseC[cur][i] = make_float2(P.p21, P.p22);

@@ -93,6 +93,7 @@ const Rccl *rccl() {
 constexpr int kRing = 64;       // big-packet staging slots
 constexpr int kPlainRowsTarget = 2048;  // plain-row contexts: genealogy rows in use before updates start consolidating the emptiest ones
 constexpr int kPlainConsBudget = 32;  // ... landmarks moved per update, at least
+constexpr int kMidRowsHigh = 24, kMidRowsLow = 12;  // compact contexts of mid-size maps: consolidate the emptiest rows from ... down to ... rows in use
 constexpr int kStageBound = 8;  // = kStage of kernels.hip: re-observed landmarks whose records an update launch stages in LDS
 constexpr int kConsolidateAbove = 6;  // compact contexts: genealogy rows alive before stale rows are consolidated (3..8 measure alike; profiles/consolidate_sweep_r03.txt)
 constexpr int kHistCap = 4096;  // asynchronous pose-estimate history entries
@@ -1194,7 +1195,7 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     // steps, and a resample composes one 16-byte chunk per particle instead of eight.  Values never change: results are bit
     // for bit those of a run without it (SLAMGPU_NO_CONSOLIDATE=1, tests/test_gpu_parity.py).
     std::vector<int32_t> cons;
-    if (c->B.compact && !sharded && c->consolidate && (int) c->live_rows.size() > c->consolidate_above) {
+    if (c->B.compact && !c->mid_compact && !sharded && c->consolidate && (int) c->live_rows.size() > c->consolidate_above) {
         for (int j = 0; j < c->nf && m + (int) cons.size() < kSmallObs; j++)
             if (c->seen_step[j] != c->obs_step) cons.push_back(j);
         // (only worth a launch's while if it empties rows: every row but the one opened now, or as many landmarks as fit)
@@ -1207,14 +1208,23 @@ int do_update(slamgpu_ctx *c, const float *zf, const int32_t *idf, int32_t m, co
     // the bound is set where the copy would start to show: past kPlainRowsTarget rows in use each update also moves the
     // landmarks of the emptiest rows (at most max(kPlainConsBudget, m / 16), 40 bytes per particle each) into the row it
     // opens, and the rows in use stop growing.
-    if (!c->B.compact && !sharded && !c->dist && c->consolidate && (int) c->live_rows.size() > c->plain_rows_target) {
-        const int budget = std::max(kPlainConsBudget, m / 16);
+    // Compact contexts of mid-size maps (kernels.h: kMidLandmarks) keep far more landmarks than a packet can move at once, most of
+    // them out of view for good (example_loop902: a loop of 117): moving "everything stale" every time seven rows are alive moved
+    // ~34 landmarks on EVERY step (53 us per step at 10^5 particles against 30 with plain rows, round 5).  They take the plain
+    // rows' policy instead, with bounds that fit the layout: past kMidRowsHigh rows in use the emptiest rows are emptied -- one or two
+    // landmarks each on that map -- down to kMidRowsLow, as many as the packet has room for; 40 rows are never exceeded (past
+    // kSmallRows - 2 the context would go to plain rows: do_update's guard).
+    const bool mid_cons = c->mid_compact && !sharded && c->consolidate && (int) c->live_rows.size() > kMidRowsHigh;
+    if (mid_cons || (!c->B.compact && !sharded && !c->dist && c->consolidate && (int) c->live_rows.size() > c->plain_rows_target)) {
+        const int budget = mid_cons ? std::max(0, kSmallObs - m) : std::max(kPlainConsBudget, m / 16);
+        const int target = mid_cons ? kMidRowsLow : c->plain_rows_target;
         std::vector<int32_t> order(c->live_rows);
         std::sort(order.begin(), order.end(), [&](int a, int b) { return c->refcnt[a] != c->refcnt[b] ? c->refcnt[a] < c->refcnt[b] : a < b; });
         std::vector<char> take((size_t) c->B.cap_rows, 0);
         int planned = 0, rows_taken = 0;
         for (int r : order) {
-            if (planned >= budget || (int) c->live_rows.size() - rows_taken <= c->plain_rows_target) break;
+            if (planned >= budget || (int) c->live_rows.size() - rows_taken <= target) break;
+            if (mid_cons && planned + c->refcnt[r] > budget) break;  // (whole rows only: a row half emptied stays in use)
             take[(size_t) r] = 1;
             planned += c->refcnt[r];
             rows_taken++;

@@ -630,6 +630,10 @@
                 Sym3 P = {q00, q10, q11, q20, q21, q22};
                 predict_composite(x, y, th, P, PA.comp);
                 q00 = P.p00; q10 = P.p10; q11 = P.p11; q20 = P.p20; q21 = P.p21; q22 = P.p22;
+            } else if (METHOD == 2 && PA.use_heading && !PA.add_noise) {
+                Sym3 P = {q00, q10, q11, q20, q21, q22};
+                predict_steps_heading_fast(x, y, th, P, PA, BIG ? nullptr : ctl);
+                q00 = P.p00; q10 = P.p10; q11 = P.p11; q20 = P.p20; q21 = P.p21; q22 = P.p22;
             } else if (METHOD == 1 && PA.add_noise && !PA.use_heading) {
                 if (PERSIST && drawn) {
                     const float vd[kEarly] = {dq0.x, dq0.y, dq0.z, dq0.w, dq1.x, dq1.y, dq1.z, dq1.w};

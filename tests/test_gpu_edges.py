@@ -112,3 +112,57 @@ def test_history_capacity_is_reported_not_overrun(sg):
     s.step(ctl, Q, 0.025, zf, idf, zf, R)  # usable again after the fetch
     assert s.history_fetch()[0].shape == (1, 3)
     s.close()
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+def test_mid_size_map_runs_compact_and_falls_back_to_plain_rows(sg, math_mode, monkeypatch):
+    """Round 5: a single context on a map of 40 .. 256 landmarks (example_loop902: 117; fastslam2.cpp:21-48 on that map) uses the
+    COMPACT genealogy layout -- 40 rows, four to a 16-byte chunk, packets in the kernel arguments -- like the 35-landmark maps
+    do; row consolidation keeps a few-hundred-landmark map in a handful of rows.  It must give, bit for bit, what the plain-row
+    layout gives (SLAMGPU_NO_MID_COMPACT=1: the layout of rounds 1-4), over resamples and consolidations; and a step that does
+    not fit a kernel-argument packet (here: 45 new landmarks at once) moves the context to plain rows for good, values unchanged."""
+    from slam_amd import host
+    N = 768
+    tape = host.make_tape(sim_args("example_loop902", "FASTSLAM2", N, 3), max_obs=800)
+    conf = tape["conf"]
+    steps = tape["steps"]
+    cap = tape["nlm"] + 50
+    rng = np.random.default_rng(5)
+    zn_many = np.stack([rng.uniform(5, 20, 45), rng.uniform(-1, 1, 45)], 1).astype(f32)
+    outs = []
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv("SLAMGPU_NO_MID_COMPACT", "1")
+        else:
+            monkeypatch.delenv("SLAMGPU_NO_MID_COMPACT", raising=False)
+        s = sg.SlamGpu(N, cap, method=2, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=11, math_mode=math_mode,
+                       use_heading=bool(conf.SWITCH_HEADING_KNOWN), wheel_base=float(conf.WHEELBASE), sigma_phi=float(conf.sigmaT))
+        in_use0, capacity0 = s.genealogy_rows()
+        assert capacity0 == (cap + 1 if plain else 40)
+        rows_seen = []
+        for k, st in enumerate(steps):
+            s.step(np.array(st["controls"], f32).reshape(-1, 3), tape["Q"], float(tape["dt"]), st["zf"], st["idf"], st["zn"], tape["R"])
+            if k % 16 == 0:
+                rows_seen.append(s.genealogy_rows()[0])
+        mid = s.download()
+        hist_mid = s.history_fetch()
+        # a step no kernel-argument packet holds: 45 new landmarks -> plain rows from here on
+        zf0, idf0 = empty()
+        s.step(np.zeros((0, 3), f32), tape["Q"], float(tape["dt"]), zf0, idf0, zn_many, tape["R"])
+        assert s.genealogy_rows()[1] == cap + 1
+        last = steps[-1]
+        for _ in range(6):
+            s.step(np.array(last["controls"], f32).reshape(-1, 3), tape["Q"], float(tape["dt"]), last["zf"], last["idf"], empty()[0], tape["R"])
+        end = s.download()
+        hist_end = s.history_fetch()
+        outs.append((mid, hist_mid, end, hist_end, max(rows_seen)))
+        s.close()
+    (ma, ha, ea, ka, rows_c), (mb, hb, eb, kb, rows_p) = outs
+    assert ma["nf"] == mb["nf"] and ma["nf"] > 40 and ea["nf"] == eb["nf"] == ma["nf"] + 45
+    assert rows_c <= 30 < rows_p, (rows_c, rows_p)    # (consolidation above 6 rows alive; the plain layout lets them pile up)
+    for a, b in ((ma, mb), (ea, eb)):
+        for key in ("xv", "Pv", "w", "xf", "Pf"):
+            assert np.array_equal(a[key].view(np.uint32), b[key].view(np.uint32)), key
+    for x, y in zip(ha + ka, hb + kb):
+        assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)
+    assert np.asarray(ha[2]).sum() > 20   # resamples happened
