@@ -373,9 +373,10 @@ int slamgpu_dist_gather(slamgpu_ctx *ctx);
 /* what the communicator inside the library says about itself (ncclCommCount / ncclCommUserRank): a harness that claims an
  * N-GPU run checks n_ranks == N here instead of trusting its launcher's environment */
 int slamgpu_dist_comm_info(slamgpu_ctx *ctx, int32_t *n_ranks, int32_t *rank);
-/* particles of this shard, since the context was created, whose ancestor at a resample lived on ANOTHER shard: their pose and
- * genealogy were read in place out of that GPU's memory (over xGMI between physical GPUs).  Does not run outstanding stages;
- * synchronises the stream. */
+/* particles of this shard whose ancestor at a resample lived on ANOTHER shard: their pose and genealogy were read in place out
+ * of that GPU's memory (over xGMI between physical GPUs).  The counter costs the update launches an atomic per wave and resample,
+ * so it is kept only FROM THE FIRST CALL of this function on (round 5): call it once before the steps of interest and take
+ * differences.  Does not run outstanding stages; synchronises the stream. */
 int slamgpu_dist_remote_reads(slamgpu_ctx *ctx, uint64_t *particles);
 
 

@@ -331,6 +331,9 @@ struct UpdateArgs {
     double *finalize_hist;   // history slot of that estimate (kHistStride doubles) or null
     unsigned long long *stamps;  // diagnostic build (-DSLAM_STAMPS, libslamgpu_stamps.so): [compute blocks][kStampSlots] wall-clock stamps
     PersistArgs persist;         // update_persist only
+    int32_t count_remote;        // distributed contexts: count the particles whose ancestor lived on another shard (Ctrl::remote_reads): one
+                                 // atomic per wave and resample on a single address, so only when somebody reads it (slamgpu_dist_remote_reads)
+    int32_t pad_u;
 };
 constexpr int kStampSlots = 16;
 constexpr int kAssocNew = -1, kAssocDiscard = -2;

@@ -455,12 +455,20 @@ SLAM_DEV void est_combine(EstItem &a, const EstItem &b) {
 // strictly greatest weight of a wave = the lowest lane holding the wave's maximum (indices ascend with the lane).
 // ... in two halves, so that a caller with a barrier of its own can put it between them: the wave's part (every lane returns the
 // wave's result; lane 0 parks it in sh[wave]) ...
+// DPP: the maximum by DPP moves inside the VALU (wave_max_f) instead of six LDS-crossbar shuffles (~0.2 us of a launch's tail for a
+// wave that has its SIMD to itself; a maximum is exact whatever the pairing: same value).  Not in the distributed variants of
+// update_kernel: they sit at the register limit, and one of them (FastSLAM 1, compact, strict build) spills 20 bytes with it.
+template <bool DPP = true>
 SLAM_DEV EstItem wave_reduce_est(EstItem v, EstItem *sh) {
     v.sx = wave_sum_d(v.sx);
     v.sy = wave_sum_d(v.sy);
-    // (the maximum by DPP moves inside the VALU, as wave_max_i: six LDS-crossbar shuffles were ~0.2 us of the launch's tail for a
-    // wave that has its SIMD to itself; a maximum is exact whatever the pairing: same value)
-    const float wm = wave_max_f(v.w);
+    float wm = v.w;
+    if constexpr (DPP) {
+        wm = wave_max_f(v.w);
+    } else {
+#pragma unroll
+        for (int d = kWave / 2; d > 0; d >>= 1) wm = fmaxf(wm, __shfl_xor(wm, d, kWave));
+    }
     const unsigned long long holders = __ballot(v.w == wm);
     if (holders) {
         const int src = __ffsll((long long) holders) - 1;
@@ -1221,7 +1229,7 @@ __host__ __device__ inline int staging_slots(int method, bool big, int m) {
 // Tried on top and measured as no better (gpurun_out/ab, 16.28 / 16.10 / 16.04 us): preloading these arguments into SGPRs
 // (-mllvm -amdgpu-kernarg-preload-count=16) and touching every 64-byte line of the argument segment at entry.
 //   h_flags: bit 0 plan_inline, bit 1 scan_global, bit 2 logw, bit 3 lazy, bit 4 front end inside the launch (h_front),
-//            bit 5 the gathered totals table travels by LDS-DMA (scan_issue_dma)
+//            bit 5 the gathered totals table travels by LDS-DMA (scan_issue_dma), bit 6 count the remote ancestors (Ctrl::remote_reads)
 // FastSLAM 1, fast build: do the (V, G) normals of this iteration's predicts come in one batch of eight (update_step: early_draws)?
 SLAM_DEV bool persist_batch_draws(int method, const PredictArgs &PA) {
 #ifdef SLAM_FAST_MATH
@@ -2969,7 +2977,7 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
     const size_t stage_bytes = (size_t) staging_slots(U.method, U.big != nullptr, U.m) * kBlock * (sizeof(float4) + sizeof(float));
     const bool scan_dma = U.arrivals == 2 && U.plan_inline && !U.scan_global && !U.logw && nbg > 2 * (size_t) kBlock &&
                           2 * sizeof(float) * (((nbg + 255) / 256) * 256) <= update_window_bytes() + stage_bytes;
-    const int h_flags = (U.plan_inline ? 1 : 0) | (U.scan_global ? 2 : 0) | (U.logw ? 4 : 0) | (U.lazy ? 8 : 0) | (U.front.on ? 16 : 0) | (scan_dma ? 32 : 0);
+    const int h_flags = (U.plan_inline ? 1 : 0) | (U.scan_global ? 2 : 0) | (U.logw ? 4 : 0) | (U.lazy ? 8 : 0) | (U.front.on ? 16 : 0) | (scan_dma ? 32 : 0) | (U.count_remote ? 64 : 0);
 #define SLAM_LAUNCH_UPDATE(M, A, G)                                                                                              \
     hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid, \
                        h_flags, B, PA, U, rng, ws)

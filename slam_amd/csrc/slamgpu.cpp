@@ -195,6 +195,7 @@ struct slamgpu_ctx {
     void *comm = nullptr;  // ncclComm_t: when set, slamgpu_dist_step / _settle run the all-gather themselves
     // push collective (slamgpu_dist_set_collective): the update launch stores its totals into every shard's table and a
     // one-wave flag kernel is the barrier; flags_dev = [kMaxShards] flag words + the error word, fine-grained memory
+    bool count_remote = false;   // slamgpu_dist_remote_reads has been asked for: the update launches keep the counter from then on
     bool dist_push = false;
     bool dist_fold = false;  // push + the barrier folded into the head of the next update launch (SLAMGPU_DIST_FOLD)
     uint32_t *flags_dev = nullptr;
@@ -1049,6 +1050,7 @@ int issue_update(slamgpu_ctx *c, UpdateArgs &U, int n_new, int n_rows, bool need
         c->B.gtot[1] = c->gtot_dev[1];
         c->dist_clean = false;
         U.push_totals = (c->dist_push || c->dist_fold) ? 1 : 0;
+        U.count_remote = c->count_remote ? 1 : 0;
         U.fold_seq = c->dist_fold ? ++c->flag_seq : 0;
         U.fold_spins = 1u << 20;
     }
@@ -2102,6 +2104,7 @@ int slamgpu_dist_remote_reads(slamgpu_ctx *c, uint64_t *particles) {
     HIP_TRY(hipMemcpyAsync(&v, &c->B.ctrl->remote_reads, sizeof v, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     *particles = v;
+    c->count_remote = true;  // (the counter is kept from the first time it is asked for: ADVICE r4)
     return 0;
 }
 

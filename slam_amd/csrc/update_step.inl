@@ -393,7 +393,7 @@
             rp = B.peers + h;
             // (bookkeeping for the bench line: how much of a resample crosses xGMI)
             const unsigned long long rm = __ballot(!src_local);
-            if (rm && lane == (int) __ffsll((long long) __ballot(true)) - 1) atomicAdd(&ctrl->remote_reads, (unsigned long long) __popcll(rm));
+            if ((h_flags & 64) && rm && lane == (int) __ffsll((long long) __ballot(true)) - 1) atomicAdd(&ctrl->remote_reads, (unsigned long long) __popcll(rm));
         }
         const float4 *__restrict__ poseA = (DIST && !src_local) ? rp->poseA[sb] : (sb ? B.poseA[1] : B.poseA[0]);
         const float4 *__restrict__ poseB = (DIST && !src_local) ? rp->poseB[sb] : (sb ? B.poseB[1] : B.poseB[0]);
@@ -1037,7 +1037,7 @@
     SLAM_STAMP(8);  // pose / genealogy stores landed
     // the block's term of the previous step's estimate: the waves' parts now, thread 0's combination behind the barrier the
     // weight prefix needs anyway (linear weights: one barrier at the end of the launch instead of two)
-    if (STEP_PLAN) ei_prev = wave_reduce_est(ei_prev, sh_est);
+    if (STEP_PLAN) ei_prev = wave_reduce_est<!DIST>(ei_prev, sh_est);
     auto est_out = [&]() {
         if (STEP_PLAN && threadIdx.x == 0) {
             const EstItem e = combine_waves_est(ei_prev, sh_est);

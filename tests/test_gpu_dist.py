@@ -33,6 +33,7 @@ def run_dist(sg, tp, Np, G, method, math_mode, seed, check_at=(), push=False):
     f = DistFilter.local(G, Np // G, tp["nlm"], method=method, n_effective=int(0.75 * Np), seed=seed, math_mode=math_mode)
     if push:
         assert f.use_push(fold=(push == "fold"))
+    assert sum(c.dist_remote_reads() for c in f.ctx) == 0   # (the counter is kept from the first time it is asked for)
     Q, R, dt = tp["Q"], tp["R"], float(tp["dt"])
     mid = {}
     cat = lambda parts: {k: np.concatenate([p[k] for p in parts]) for k in ("xv", "Pv", "w", "xf", "Pf")}

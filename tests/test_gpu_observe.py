@@ -359,3 +359,65 @@ def test_run_observe_equals_step_by_step(sg, method, N, mapname, math):
     assert da["nf"] == db["nf"] and da["nf"] > 10
     for key in ("xv", "Pv", "w", "xf", "Pf"):
         assert np.array_equal(da[key].view(np.uint32), db[key].view(np.uint32)), key
+
+
+def test_run_observe_refuses_before_it_applies_anything(sg):
+    """every precondition of slamgpu_run_observe is checked BEFORE the first device call -- a history that K more
+    estimates would overflow, a missing control list, negative counts, no map -- so that a refused call applies no iteration at all
+    (before: iteration k's predicts and update were enqueued, then the estimate failed, and a caller that fetched and retried from k
+    applied one step twice)."""
+    import ctypes as C
+    from slam_amd import host
+    args = sim_args("example_webmap", "FASTSLAM2", 100, 7)
+    tape = host.make_tape(args, max_obs=40)
+    sim = host.HostSim(args)
+    lm, _ = sim.map()
+    mr = float(sim.conf.MAX_RANGE)
+    sim.close()
+    steps = tape["steps"]
+    ctl = [np.array(st["controls"], f32).reshape(-1, 3) for st in steps]
+    xt = [np.asarray(st["true"], f32) for st in steps]
+    N = 512
+    s = sg.SlamGpu(N, tape["nlm"], method=2, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=5, math_mode=1, device_observe=True)
+    # no map yet
+    with pytest.raises(sg.SlamGpuError):
+        s.run_observe(ctl[:4], tape["Q"], float(tape["dt"]), xt[:4], mr, tape["R"], noise=2)
+    s.set_map(lm)
+    s.run_observe(ctl[:10], tape["Q"], float(tape["dt"]), xt[:10], mr, tape["R"], noise=2)
+    before = s.download()
+    nh = 10
+    # the history holds 4 096 estimates: 10 are in it, 4 090 more do not fit -- refused as a whole, nothing applied
+    K = 4090
+    counts = np.zeros(K, np.int32)
+    xs = np.tile(xt[10], (K, 1)).astype(f32)
+    Q, R4 = np.ascontiguousarray(tape["Q"], f32), np.ascontiguousarray(tape["R"], f32)
+    rc = s.L.slamgpu_run_observe(s.h, K, counts.ctypes.data_as(C.c_void_p), None, Q.ctypes.data_as(C.c_void_p), C.c_float(float(tape["dt"])),
+                                 xs.ctypes.data_as(C.c_void_p), C.c_float(mr), R4.ctypes.data_as(C.c_void_p), 2)
+    assert rc == -3 and b"history" in s.L.slamgpu_last_error()   # SLAMGPU_ERR_CAPACITY
+    # controls announced but no list; a negative count; a null pose list
+    counts2 = np.array([8, 8], np.int32)
+    rc = s.L.slamgpu_run_observe(s.h, 2, counts2.ctypes.data_as(C.c_void_p), None, Q.ctypes.data_as(C.c_void_p), C.c_float(float(tape["dt"])),
+                                 xs.ctypes.data_as(C.c_void_p), C.c_float(mr), R4.ctypes.data_as(C.c_void_p), 2)
+    assert rc == -1
+    counts3 = np.array([8, -1], np.int32)
+    c16 = np.ascontiguousarray(np.concatenate(ctl[10:12]), f32)
+    rc = s.L.slamgpu_run_observe(s.h, 2, counts3.ctypes.data_as(C.c_void_p), c16.ctypes.data_as(C.c_void_p), Q.ctypes.data_as(C.c_void_p),
+                                 C.c_float(float(tape["dt"])), xs.ctypes.data_as(C.c_void_p), C.c_float(mr), R4.ctypes.data_as(C.c_void_p), 2)
+    assert rc == -1
+    rc = s.L.slamgpu_run_observe(s.h, 2, counts2.ctypes.data_as(C.c_void_p), c16.ctypes.data_as(C.c_void_p), Q.ctypes.data_as(C.c_void_p),
+                                 C.c_float(float(tape["dt"])), None, C.c_float(mr), R4.ctypes.data_as(C.c_void_p), 2)
+    assert rc == -1
+    # nothing was applied by any of them: same state, same history length; and the run goes on as if they had not been made
+    after = s.download()
+    for key in ("xv", "Pv", "w", "xf", "Pf"):
+        assert np.array_equal(before[key].view(np.uint32), after[key].view(np.uint32)), key
+    s.run_observe(ctl[10:20], tape["Q"], float(tape["dt"]), xt[10:20], mr, tape["R"], noise=2)
+    est, _, _ = s.history_fetch()
+    assert len(est) == nh + 10
+    ref = sg.SlamGpu(N, tape["nlm"], method=2, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=5, math_mode=1, device_observe=True)
+    ref.set_map(lm)
+    ref.run_observe(ctl[:20], tape["Q"], float(tape["dt"]), xt[:20], mr, tape["R"], noise=2)
+    est_ref, _, _ = ref.history_fetch()
+    assert np.array_equal(np.asarray(est), np.asarray(est_ref))
+    s.close()
+    ref.close()
