@@ -227,15 +227,20 @@ static int run_batched(Simulator &sim, slamgpu_ctx *ctx, bool observe_dev, long 
     };
     const auto t_begin = std::chrono::steady_clock::now();
     auto t_obs = t_begin;
+    // (the hand-over does not wait for the GPU: round 5 found slamgpu_run_observe's queue upload blocking behind the launch before it,
+    // and took the upload out: slamgpu.cpp: run_observe_persist)
     constexpr int kRunChunk = 256;
     std::vector<int32_t> run_counts;
     std::vector<float> run_xt;
     size_t run_rows = 0;
+    double us_handover = 0, us_final = 0;  // where the host's time goes (printed with the result)
     auto flush_run = [&]() -> int {
         if (run_counts.empty()) return 0;
+        const auto t_call = std::chrono::steady_clock::now();
         const int r = slamgpu_run_observe(ctx, (int32_t) run_counts.size(), run_counts.data(), controls.data(), sim.Qe, sim.dt, run_xt.data(), c.MAX_RANGE,
                                           sim.Re, c.SWITCH_SENSOR_NOISE ? 2 : 0);
         const auto now = std::chrono::steady_clock::now();
+        us_handover += std::chrono::duration<double, std::micro>(now - t_call).count();
         const double us = std::chrono::duration<double, std::micro>(now - t_obs).count() / (double) run_counts.size();
         for (size_t t = run_first; t < rows.size(); t++) rows[t].us = us;  // (per iteration: the chunk's enqueue time, evenly)
         t_obs = now;
@@ -283,16 +288,21 @@ static int run_batched(Simulator &sim, slamgpu_ctx *ctx, bool observe_dev, long 
         if (!rc && rows.size() == 4096) rc = fetch();
     }
     if (!rc && observe_dev) rc = flush_run();
+    const auto t_final = std::chrono::steady_clock::now();
     if (!rc) rc = fetch();  // (synchronises: everything enqueued has finished)
+    us_final = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_final).count();
     const double wall_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
     if (rc) fprintf(stderr, "slamgpu: %s\n", slamgpu_last_error());
     printf("control steps %ld, observation steps %ld, wall time per observation step %.2f us (whole loop, host front end included), "
            "rms position error %.4f m, final estimate (%.4f, %.4f, %.4f)\n",
            iter, nobs, nobs ? wall_us / nobs : 0.0, nobs ? std::sqrt(sq_err / nobs) : 0.0, est[0], est[1], est[2]);
+    if (observe_dev && nobs)
+        printf("host side of that, per observation step: %.2f us inside slamgpu_run_observe (hand-over), %.2f us waiting for the GPU at the end "
+               "(the last fetch), the rest simulating the vehicle\n", us_handover / nobs, us_final / nobs);
     if (!rc && gpubusy) {
         double ms = 0, tot = 0;
         int64_t n = 0;
-        for (const char *k : {"fs2_update", "fs1_update", "resample", "scan", "observe", "finish", "gather", "predict", "estimate"})
+        for (const char *k : {"fs2_update", "fs1_update", "persist_loop", "resample", "scan", "observe", "finish", "gather", "predict", "estimate"})
             if (slamgpu_kernel_time(ctx, k, &ms, &n) == 0) tot += ms;
         printf("GPU busy (sum of kernel times between event pairs) %.2f us per observation step = %.0f %% of the wall time\n",
                nobs ? 1e3 * tot / nobs : 0.0, wall_us > 0 ? 100.0 * 1e3 * tot / wall_us : 0.0);

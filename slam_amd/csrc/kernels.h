@@ -277,7 +277,7 @@ constexpr int kPersistStepWords = (int) (sizeof(PersistStep) / 4);
 enum { kPersistSyncCounter = 0, kPersistSyncXcc = 64, kPersistSyncDone = 96, kPersistSyncCross = 97, kPersistSyncWords = 128, kPersistSyncAbort = 128,
        kPersistSyncAlloc = 192 };
 struct PersistArgs {
-    const PersistStep *queue;           // [K]
+    const PersistStep *queue;           // [K], in PINNED HOST memory: every workgroup reads an entry an iteration before it needs it
     int32_t K;
     uint32_t max_spins;                 // bound of one wait at the counter
     uint32_t *sync;                     // [kPersistSyncAlloc]
@@ -289,6 +289,9 @@ struct PersistArgs {
                                         // made an iteration ahead by the drawer workgroups (component c of particle i at [c][i]: V dt of
                                         // steps 0-3, 4-7; the perturbed G of steps 0-3, 4-7; sin(G / wheelBase) of steps 0-3, 4-7)
     int32_t drawers, pad;               // drawer workgroups: one per tile, or none
+    PersistStep *ring;                  // [4] in device memory: the helper workgroup copies entry it + 2 of the (host-resident) queue here
+                                        // during iteration it; everybody else reads its entries from here (an L2 hit), so that no
+                                        // PCIe read sits in front of a tile's loads on the in-order return path
 };
 
 struct UpdateArgs {

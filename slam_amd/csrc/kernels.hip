@@ -1453,8 +1453,12 @@ __global__ void __launch_bounds__(kBlock) update_persist_kernel(const float *__r
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         __hip_atomic_store(sync + kPersistSyncXcc + bid, (xcc & 15u) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const uint32_t *__restrict__ q0 = reinterpret_cast<const uint32_t *>(P.queue);  // (the queue is never written during the launch)
+    // the queue lives in pinned host memory and is never written during the launch.  Entry 0: everybody reads it there, once; the
+    // others reach the tiles and drawers through a ring in device memory that the helper workgroup fills two iterations ahead
+    const uint32_t *__restrict__ q0 = reinterpret_cast<const uint32_t *>(P.queue);
+    uint32_t *const ring = reinterpret_cast<uint32_t *>(P.ring);
     if (P.K > 0 && threadIdx.x < kPersistStepWords) reinterpret_cast<uint32_t *>(&qes[0])[threadIdx.x] = q0[threadIdx.x];
+    if (helper && P.K > 1 && threadIdx.x < kPersistStepWords) ring[kPersistStepWords + threadIdx.x] = q0[kPersistStepWords + threadIdx.x];
     __syncthreads();
     StepCarry carry;
     carry.cur = h_ctrl->live[h_slot];
@@ -1510,9 +1514,12 @@ __global__ void __launch_bounds__(kBlock) update_persist_kernel(const float *__r
         const bool more = it + 1 < P.K;
         const PersistStep &qe = qes[it & 1];
         PersistStep *const qn = &qes[(it + 1) & 1];  // (free since the previous barrier)
-        // the next iteration's entry: requested now, parked in LDS behind the step's code
-        uint32_t qv = 0;
-        if (more && threadIdx.x < kPersistStepWords) qv = q0[(size_t) (it + 1) * kPersistStepWords + threadIdx.x];
+        // the next iteration's entry (from the ring: an L2 hit): requested now, parked in LDS behind the step's code; the helper also
+        // fetches the entry after it from the host (a PCIe trip it has the time for) and puts it into the ring before the barrier
+        uint32_t qv = 0, qv2 = 0;
+        if (more && threadIdx.x < kPersistStepWords) qv = ldg_u32<true>(ring + (size_t) ((it + 1) & 3) * kPersistStepWords + threadIdx.x);
+        const bool more2 = helper && it + 2 < P.K;
+        if (more2 && threadIdx.x < kPersistStepWords) qv2 = q0[(size_t) (it + 2) * kPersistStepWords + threadIdx.x];
         if (drawer) {
             // (nothing of this iteration: the next one's draws, below)
         } else if (!helper) {
@@ -1535,6 +1542,7 @@ __global__ void __launch_bounds__(kBlock) update_persist_kernel(const float *__r
         }
         carry.pend_word = false;
         SLAM_STAMP(11);  // the step's code is done
+        if (more2 && threadIdx.x < kPersistStepWords) ring[(size_t) ((it + 2) & 3) * kPersistStepWords + threadIdx.x] = qv2;
         if (more) {
             if (threadIdx.x < kPersistStepWords) reinterpret_cast<uint32_t *>(qn)[threadIdx.x] = qv;
             __syncthreads();

@@ -136,6 +136,7 @@ struct slamgpu_ctx {
     Ctrl *ctrl_host = nullptr;  // pinned
     // pose-estimate history
     double *hist_dev = nullptr;  // [kHistCap][kHistStride]
+    double *hist_host = nullptr; // pinned mirror of it (history_to_host)
     int hist_n = 0;
     bool est_fresh = false;  // Ctrl.est / hist slot hist_n were written by the last update and nothing changed since
     // profiling
@@ -247,12 +248,17 @@ struct slamgpu_ctx {
         RngArgs rng{};
         WeightScratch ws{};
     } *collect = nullptr;
-    PersistStep *pq_dev = nullptr, *pq_host = nullptr;  // the queue in device memory and its pinned staging
+    // the queue of a launch lives in PINNED HOST memory and the kernel reads it there (an entry an iteration ahead: the PCIe trip is
+    // hidden): kPqBufs buffers of pq_cap entries used in turn; a buffer is rewritten once the launch that read it has finished
+    static constexpr int kPqBufs = 4;
+    PersistStep *pq_host = nullptr;
     size_t pq_cap = 0;
-    hipEvent_t pq_ev = nullptr;          // the staging buffer's last upload has finished
-    bool pq_ev_used = false;
+    hipEvent_t pq_kev[kPqBufs] = {};
+    bool pq_kev_used[kPqBufs] = {};
+    int pq_next = 0;
     uint32_t *psync_dev = nullptr, *pstatus_host = nullptr;
     int32_t *ppk_dev = nullptr;          // [2][kSmallWords] observation packets of the loop's helper workgroup
+    PersistStep *pring_dev = nullptr;    // [4] the loop's ring of queue entries in device memory (kernels.h: PersistArgs::ring)
     float4 *pdraw_dev = nullptr;         // [2][6][ncap] draws of the loop's drawer workgroups (FastSLAM 1, fast build)
     int64_t persist_launches = 0, persist_steps = 0;
     EstStage unplanned;           // the last update: resampling stage not run yet
@@ -672,6 +678,17 @@ int flush_predict(slamgpu_ctx *c) {
     return 0;
 }
 
+// the recorded history entries, behind everything enqueued, through the pinned mirror (a pageable destination cost the FIRST fetch of
+// a process 8.4 ms for 104 KB: 3.9 us per observation step of a whole example_webmap run of the drop-in binary, round 5)
+int history_to_host(slamgpu_ctx *c, std::vector<double> &h) {
+    h.assign((size_t) kHistStride * (c->hist_n > 0 ? c->hist_n : 1), 0.0);
+    if (c->hist_n > 0)
+        HIP_TRY(hipMemcpyAsync(c->hist_host, c->hist_dev, sizeof(double) * kHistStride * (size_t) c->hist_n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->hist_n > 0) memcpy(h.data(), c->hist_host, sizeof(double) * kHistStride * (size_t) c->hist_n);
+    return 0;
+}
+
 // A fetch that took fewer entries than were recorded (max_count < hist_n) keeps the rest: the unfetched tail moves to
 // the front of the device-side history (all stages have been flushed: nothing points into it).
 int keep_history_tail(slamgpu_ctx *c, const std::vector<double> &h, int taken) {
@@ -838,6 +855,7 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
         CTX_TRY(hipMemsetAsync(c->ws.keep[b], 0, sizeof(int32_t) * S, c->stream));
     }
     CTX_TRY(hipMalloc((void **) &c->hist_dev, sizeof(double) * kHistStride * (size_t) kHistCap));
+    CTX_TRY(hipHostMalloc((void **) &c->hist_host, sizeof(double) * kHistStride * (size_t) kHistCap, hipHostMallocDefault));
     if (want_stamps) {
         CTX_TRY(hipMalloc((void **) &c->stamps_dev, sizeof(unsigned long long) * kStampSlots * (size_t) c->ws.nblocks));
         CTX_TRY(hipMemsetAsync(c->stamps_dev, 0, sizeof(unsigned long long) * kStampSlots * (size_t) c->ws.nblocks, c->stream));
@@ -859,6 +877,12 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
         const float uw = cfg->log_weights ? c->ctrl_host->inv_n : (float) (1.0 / (float) n_global(c));
         for (int i = 0; i < n; i++) a[i].w = uw;
         CTX_TRY(hipMemcpyAsync(c->B.poseA[0], a.data(), sizeof(float4) * S, hipMemcpyHostToDevice, c->stream));
+        // one launch out of the library's code object, so that the runtime loads it HERE and not inside the caller's first step
+        // (the first launch of a process pays for the module: ~10 ms, seven microseconds per observation step of a whole
+        // example_webmap run of the drop-in binary, round 5): genealogy row 0 = "own slot", which is what it means before any landmark
+        c->k->identity(c->stream, c->B, 0, 0);
+        c->k->identity(c->stream, c->B, 1, 0);
+        CTX_TRY(hipGetLastError());
         CTX_TRY(hipStreamSynchronize(c->stream));
     }
 #undef CTX_TRY
@@ -894,16 +918,18 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     for (int b = 0; b < 2; b++)
         if (c->ws.keep[b]) (void) hipFree(c->ws.keep[b]);
     if (c->hist_dev) (void) hipFree(c->hist_dev);
+    if (c->hist_host) (void) hipHostFree(c->hist_host);
     if (c->stamps_dev) (void) hipFree(c->stamps_dev);
     if (c->peek_dev) (void) hipFree(c->peek_dev);
     for (void *p_ : {(void *) c->box_dev, (void *) c->assoc_ids_dev, (void *) c->cell_start_dev, (void *) c->cell_fill_dev, (void *) c->items_dev,
                      (void *) c->geom_dev})
         if (p_) (void) hipFree(p_);
-    if (c->pq_dev) (void) hipFree(c->pq_dev);
     if (c->pq_host) (void) hipHostFree(c->pq_host);
-    if (c->pq_ev) (void) hipEventDestroy(c->pq_ev);
+    for (int b = 0; b < slamgpu_ctx::kPqBufs; b++)
+        if (c->pq_kev[b]) (void) hipEventDestroy(c->pq_kev[b]);
     if (c->psync_dev) (void) hipFree(c->psync_dev);
     if (c->ppk_dev) (void) hipFree(c->ppk_dev);
+    if (c->pring_dev) (void) hipFree(c->pring_dev);
     if (c->pdraw_dev) (void) hipFree(c->pdraw_dev);
     if (c->pstatus_host) (void) hipHostFree(c->pstatus_host);
     if (c->book_dev) (void) hipFree(c->book_dev);
@@ -1525,30 +1551,41 @@ int slamgpu_step_observe(slamgpu_ctx *c, const float *controls, int32_t n_contro
 // K iterations of the wrapper's loop as ONE launch (kernels.h: PersistArgs): the K calls of slamgpu_step_observe are made with
 // the context in collect mode -- every piece of host bookkeeping moves on as usual, the update launches are queued instead of
 // made -- then the queue is uploaded and update_persist runs it.
-static int run_observe_persist(slamgpu_ctx *c, int32_t K, const int32_t *n_controls, const float *controls, const float Q[4], float dt,
-                               const float *xtrue, float max_range, const float R[4], int32_t noise) {
+// what the persistent loop needs beside the context's own state (allocated once: at slamgpu_set_map for contexts that qualify, so
+// that a caller's first slamgpu_run_observe does not pay for it; K: entries per queue buffer)
+static int persist_setup(slamgpu_ctx *c, int32_t K) {
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (!c->psync_dev) {
         HIP_TRY(hipMalloc((void **) &c->psync_dev, sizeof(uint32_t) * kPersistSyncAlloc));
         HIP_TRY(hipMemsetAsync(c->psync_dev, 0, sizeof(uint32_t) * kPersistSyncAlloc, c->stream));
         HIP_TRY(hipMalloc((void **) &c->ppk_dev, sizeof(int32_t) * 2 * kSmallWords));
+        HIP_TRY(hipMalloc((void **) &c->pring_dev, sizeof(PersistStep) * 4));
         HIP_TRY(hipMalloc((void **) &c->pdraw_dev, sizeof(float4) * 2 * 6 * (size_t) c->B.ncap));
         HIP_TRY(hipHostMalloc((void **) &c->pstatus_host, 2 * sizeof(uint32_t), hipHostMallocDefault));
         c->pstatus_host[0] = c->pstatus_host[1] = 0;
-        HIP_TRY(hipEventCreateWithFlags(&c->pq_ev, hipEventDisableTiming));
+        for (int b = 0; b < slamgpu_ctx::kPqBufs; b++) HIP_TRY(hipEventCreateWithFlags(&c->pq_kev[b], hipEventDisableTiming));
     }
     if ((size_t) K > c->pq_cap) {
         HIP_TRY(hipStreamSynchronize(c->stream));  // (a launch in flight may still read the old queue)
-        if (c->pq_dev) (void) hipFree(c->pq_dev);
         if (c->pq_host) (void) hipHostFree(c->pq_host);
-        c->pq_dev = c->pq_host = nullptr;
+        c->pq_host = nullptr;
         c->pq_cap = 0;
         const size_t cap = std::max<size_t>((size_t) K, 256);
-        HIP_TRY(hipMalloc((void **) &c->pq_dev, sizeof(PersistStep) * cap));
-        HIP_TRY(hipHostMalloc((void **) &c->pq_host, sizeof(PersistStep) * cap, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **) &c->pq_host, sizeof(PersistStep) * slamgpu_ctx::kPqBufs * cap, hipHostMallocDefault));
         c->pq_cap = cap;
-        c->pq_ev_used = false;
+        for (int b = 0; b < slamgpu_ctx::kPqBufs; b++) c->pq_kev_used[b] = false;
     }
+    return 0;
+}
+
+static bool persist_eligible(const slamgpu_ctx *c) {
+    return c->persist_ok && c->B.compact && !c->mid_compact && !c->dist && c->cfg.n_particles_global == c->cfg.n_particles &&
+           c->cfg.rng_mode == SLAMGPU_RNG_PHILOX && c->ws.nblocks <= kPersistMaxBlocks && c->ws.nblocks <= c->scan_min_blocks;
+}
+
+static int run_observe_persist(slamgpu_ctx *c, int32_t K, const int32_t *n_controls, const float *controls, const float Q[4], float dt,
+                               const float *xtrue, float max_range, const float R[4], int32_t noise) {
+    if (int rc = persist_setup(c, K)) return rc;
     slamgpu_ctx::PersistCollect col;
     col.steps.reserve((size_t) K);
     c->collect = &col;
@@ -1569,20 +1606,25 @@ static int run_observe_persist(slamgpu_ctx *c, int32_t K, const int32_t *n_contr
     c->collect = nullptr;
     if (!col.steps.empty()) {  // (after a failure: the iterations before the failing one are applied, as the header promises)
         const size_t n = col.steps.size();
-        if (c->pq_ev_used) HIP_TRY(hipEventSynchronize(c->pq_ev));  // the staging buffer's previous upload has finished
-        memcpy(c->pq_host, col.steps.data(), sizeof(PersistStep) * n);
-        HIP_TRY(hipMemcpyAsync(c->pq_dev, c->pq_host, sizeof(PersistStep) * n, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipEventRecord(c->pq_ev, c->stream));
-        c->pq_ev_used = true;
+        // The queue is NOT uploaded (round 5, measured with the drop-in binary at 1 000 particles): a hipMemcpyAsync enqueued behind a
+        // running launch made the CALL wait for that launch -- 270-520 us per call of 32 iterations, on the context's stream or on one
+        // of its own -- so the host simulated its next iterations only after the GPU had finished the last ones.  The kernel reads
+        // the entries out of pinned host memory instead, each an iteration before it needs it.
+        const int b = c->pq_next;
+        c->pq_next = (c->pq_next + 1) % slamgpu_ctx::kPqBufs;
+        if (c->pq_kev_used[b]) HIP_TRY(hipEventSynchronize(c->pq_kev[b]));  // (the launch of kPqBufs calls ago: the host's run-ahead is bounded)
+        PersistStep *qh = c->pq_host + (size_t) b * c->pq_cap;
+        memcpy(qh, col.steps.data(), sizeof(PersistStep) * n);
         HIP_TRY(hipMemsetAsync(c->psync_dev, 0, sizeof(uint32_t) * kPersistSyncWords, c->stream));
         UpdateArgs U = col.U;
-        U.persist.queue = c->pq_dev;
+        U.persist.queue = qh;
         U.persist.K = (int32_t) n;
         U.persist.max_spins = 1u << 20;
         U.persist.sync = c->psync_dev;
         U.persist.host_status = c->pstatus_host;
         U.persist.state_final = c->front_dev + c->front_par;  // (the copy the next launch reads)
         U.persist.packets = c->ppk_dev;
+        U.persist.ring = c->pring_dev;
         U.persist.draws = c->pdraw_dev;
         // drawer workgroups (one per tile): FastSLAM 1 in the fast build, whose predicts draw eight Philox blocks per particle and step
         U.persist.drawers = (c->cfg.method == SLAMGPU_FASTSLAM1 && c->cfg.math_mode == SLAMGPU_MATH_FAST && c->cfg.add_predict_noise &&
@@ -1592,6 +1634,8 @@ static int run_observe_persist(slamgpu_ctx *c, int32_t K, const int32_t *n_contr
             c->k->update_persist(c->stream, col.B, PredictArgs{}, U, col.rng, col.ws);
         }
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->pq_kev[b], c->stream));
+        c->pq_kev_used[b] = true;
         c->persist_launches++;
         c->persist_steps += (int64_t) n;
     }
@@ -1627,7 +1671,7 @@ int slamgpu_run_observe(slamgpu_ctx *c, int32_t K, const int32_t *n_controls, co
                                           "slamgpu_history_fetch first, or hand over fewer iterations", (int) K, c->hist_n, kHistCap);
     if (int rc = persist_check(c)) return rc;
     // small compact contexts: ONE launch for all K iterations (kernels.h: PersistArgs)
-    if (c->persist_ok && K >= 2 && c->B.compact && c->ws.nblocks <= kPersistMaxBlocks && c->ws.nblocks <= c->scan_min_blocks && max_nc <= kMaxFusedPredict)
+    if (K >= 2 && persist_eligible(c) && max_nc <= kMaxFusedPredict)
         return run_observe_persist(c, K, n_controls, controls, Q, dt, xtrue, max_range, R, noise);
     size_t row = 0;
     for (int32_t k = 0; k < K; k++) {
@@ -1881,6 +1925,7 @@ int gather_totals(slamgpu_ctx *c) {
     if (c->dist_push) return launch_flags(c);  // the totals are in every table already: only the barrier is left
     if (!c->comm) return 0;
     const int par = (int) (c->obs_step & 1);
+    Timed t(c, "allgather");  // (slamgpu_profile: an event pair around the collective, like around every launch)
     RCCL_TRY(rccl()->AllGather(c->ws.blk_w[par], c->gtot_dev[par], (size_t) 2 * c->ws.nblocks, ncclFloat, (ncclComm_t) c->comm, c->stream));
     return 0;
 }
@@ -2183,6 +2228,7 @@ int slamgpu_dist_gather(slamgpu_ctx *c) {
     if (!c->dist || !c->comm) return fail(SLAMGPU_ERR_INVALID, "no communicator: slamgpu_dist_comm_init first");
     HIP_TRY(hipSetDevice(c->cfg.device));
     const int par = (int) (c->obs_step & 1);
+    Timed t(c, "allgather");  // (slamgpu_profile: an event pair around the collective, like around every launch)
     RCCL_TRY(rccl()->AllGather(c->ws.blk_w[par], c->gtot_dev[par], (size_t) 2 * c->ws.nblocks, ncclFloat, (ncclComm_t) c->comm, c->stream));
     return 0;
 }
@@ -2445,10 +2491,9 @@ int slamgpu_shard_estimate_fetch(slamgpu_ctx *c, double *raw4, int32_t max_count
     if (!count) return fail(SLAMGPU_ERR_INVALID, "null count");
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = flush_stages(c)) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<double> h;
+    if (int rc = history_to_host(c, h)) return rc;
     const int n = c->hist_n < std::max(max_count, 0) ? c->hist_n : std::max(max_count, 0);
-    std::vector<double> h((size_t) kHistStride * (c->hist_n > 0 ? c->hist_n : 1));
-    if (c->hist_n > 0) HIP_TRY(hipMemcpy(h.data(), c->hist_dev, sizeof(double) * kHistStride * (size_t) c->hist_n, hipMemcpyDeviceToHost));
     if (raw4)
         for (int i = 0; i < n; i++)
             for (int k = 0; k < 4; k++) raw4[4 * (size_t) i + k] = h[(size_t) kHistStride * i + k];
@@ -2519,11 +2564,10 @@ int slamgpu_history_fetch(slamgpu_ctx *c, double *xyt, float *neff, int32_t *res
     if (!count) return fail(SLAMGPU_ERR_INVALID, "null count");
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = flush_stages(c)) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<double> h;
+    if (int rc = history_to_host(c, h)) return rc;
     if (int rc = persist_check(c)) return rc;
     const int n = c->hist_n < std::max(max_count, 0) ? c->hist_n : std::max(max_count, 0);
-    std::vector<double> h((size_t) kHistStride * (c->hist_n > 0 ? c->hist_n : 1));
-    if (c->hist_n > 0) HIP_TRY(hipMemcpy(h.data(), c->hist_dev, sizeof(double) * kHistStride * (size_t) c->hist_n, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; i++) {
         const double *e = h.data() + (size_t) kHistStride * i;
         if (xyt) {
@@ -2547,10 +2591,9 @@ int slamgpu_dist_history_fetch(slamgpu_ctx *c, double *raw4, float *neff, int32_
     if (!count) return fail(SLAMGPU_ERR_INVALID, "null count");
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = flush_stages(c)) return rc;
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<double> h;
+    if (int rc = history_to_host(c, h)) return rc;
     const int n = c->hist_n < std::max(max_count, 0) ? c->hist_n : std::max(max_count, 0);
-    std::vector<double> h((size_t) kHistStride * (c->hist_n > 0 ? c->hist_n : 1));
-    if (c->hist_n > 0) HIP_TRY(hipMemcpy(h.data(), c->hist_dev, sizeof(double) * kHistStride * (size_t) c->hist_n, hipMemcpyDeviceToHost));
     for (int i = 0; i < n; i++) {
         const double *e = h.data() + (size_t) kHistStride * i;
         if (raw4)
@@ -2625,6 +2668,9 @@ int slamgpu_set_map(slamgpu_ctx *c, const float *lm, int32_t nlm) {
     c->obs_nf = 0;
     c->map_host.assign(lm, lm + 2 * n);
     c->front_ready = false;  // (a new map starts a new landmark table)
+    // a context that may run slamgpu_run_observe as the persistent loop gets that loop's buffers now, not inside its first call
+    if (persist_eligible(c) && nlm <= kSmallObs - 1)
+        if (int rc = persist_setup(c, 256)) return rc;
     return 0;
 }
 

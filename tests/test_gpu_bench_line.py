@@ -51,7 +51,12 @@ def test_default_line_single_gpu():
     assert r["algorithmic_frac"] > r["frac"]
     # the other driver-timed workloads of the line: strict build, config 2, config 5, each with its own counter file
     also = {(e["config"]["baseline_config"], e["config"]["math"]): e for e in j["also"]}
-    assert set(also) == {(3, "strict"), (2, "fast"), (5, "fast")}
+    assert set(also) == {(3, "strict"), (2, "fast"), (5, "fast"), (6, "fast")}
+    # (round 5) config 2 is the loop handed over in batches: ONE launch for the timed window, the per-step loop's figure beside it
+    c2 = also[(2, "fast")]["config"]
+    assert "ONE launch" in c2["observation_front_end"] and c2["per_step_launches"]["ms_per_step"] > also[(2, "fast")]["ms_per_step"]
+    # ... and the default windows look like the run (mean m within 10 % of the tape's 3.53), with the whole run's figure on the line
+    assert abs(j["config"]["mean_m"] / 3.535 - 1) <= 0.1 and j["whole_run"]["steps"] > 2000 and j["whole_run"]["ms_per_step"] > 0
     for key, e in also.items():
         er = e["roofline"]
         assert er["traffic"], (key, er["traffic_source"])
@@ -74,6 +79,10 @@ def test_multi_gpu_path_with_one_rank():
     check_common(j, 60, 5)
     assert j["config"]["multi_gpu_path"] == "dist" and j["config"]["collective"] == "rccl" and j["config"]["rccl_ranks"] == 1
     assert j["config"]["ranks_agree_on_neff_history"] is True
+    # (round 5) per-phase means of an untimed pass behind the window, and the statement about what bounds weak scaling
+    ph = j["config"]["phases"]
+    assert ph and ph["steps"] >= 8 and 5.0 < ph["update_launch_us"] < 100.0 and 0.5 < ph["allgather_us_in_step"] < 1e3
+    assert "LATENCY-bound" in j["config"]["scaling_note"]
     # both collectives were timed alone before the run, and the line says which one it took and why
     assert 0.5 < j["config"]["allgather_us"] < 1e3 and 0.5 < j["config"]["flag_barrier_us"] < 1e3
     assert j["config"]["collective_choice"].startswith(j["config"]["collective"])

@@ -42,16 +42,23 @@ for f in find("trace/**/*kernel_trace.csv"):
 
 
 def dominant(names):
-    cands = [k for k in names if re.search(r"update_kernel<", k)]
+    cands = [k for k in names if re.search(r"update_kernel<|update_persist_kernel<", k)]
     return max(cands, key=lambda k: sum(dur.get(k, [0])) if dur else 0) if cands else None
 
 
 dom = dominant(dur.keys())
+# the persistent step loop (round 5): the timed window is ONE dispatch of `steps` iterations (the last one of the process): figures
+# per ITERATION = that dispatch's / steps
+persist = bool(dom) and "update_persist_kernel<" in dom
+per_disp = steps if persist else 1
 window_avg_ns = None
 if dom and steps:
-    w = dur[dom][-steps:]
-    window_avg_ns = sum(w) / max(len(w), 1)
-    lines.append("== timed window: last %d dispatches of %s: avg %.1f ns (min %d, max %d)" % (len(w), dom.split("(")[0], window_avg_ns, min(w), max(w)))
+    w = dur[dom][-1:] if persist else dur[dom][-steps:]
+    window_avg_ns = sum(w) / max(len(w), 1) / per_disp
+    if persist:
+        lines.append("== timed window: the LAST dispatch of %s = %d iterations: %.1f ns per iteration (%d ns the dispatch)" % (dom.split("(")[0], steps, window_avg_ns, w[0]))
+    else:
+        lines.append("== timed window: last %d dispatches of %s: avg %.1f ns (min %d, max %d)" % (len(w), dom.split("(")[0], window_avg_ns, min(w), max(w)))
 
 pmc = {}
 for name, pm in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
@@ -69,19 +76,23 @@ for name, pm in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     pmc[name] = per
     lines.append("== %s per dispatch [counter unit: KiB as reported by rocprofv3; gfx950: FETCH_SIZE counts 64 B per 128-B request => x2]" % name)
     for k, v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
-        tail = v[-steps:] if (steps and k == dom) else v
+        tail = (v[-1:] if persist else v[-steps:]) if (steps and k == dom) else v
         lines.append("%-110s dispatches %7d mean(all) %14.2f mean(window) %14.2f" % (k[:110], len(v), sum(v) / max(len(v), 1), sum(tail) / max(len(tail), 1)))
 
 kern = {}
 if dom:
     f_ = pmc["FETCH_SIZE"].get(dom, [])
     w_ = pmc["WRITE_SIZE"].get(dom, [])
-    fk = sum(f_[-steps:]) / max(len(f_[-steps:]), 1) if f_ else 0.0
-    wk = sum(w_[-steps:]) / max(len(w_[-steps:]), 1) if w_ else 0.0
-    short = "fs2_update" if "update_kernel<2" in dom else "fs1_update"
+    if persist:
+        fk = f_[-1] / per_disp if f_ else 0.0
+        wk = w_[-1] / per_disp if w_ else 0.0
+    else:
+        fk = sum(f_[-steps:]) / max(len(f_[-steps:]), 1) if f_ else 0.0
+        wk = sum(w_[-steps:]) / max(len(w_[-steps:]), 1) if w_ else 0.0
+    short = "fs2_update" if ("update_kernel<2" in dom or "update_persist_kernel<2" in dom) else "fs1_update"
     kern[short] = {"rocprof_name": dom.split("(")[0], "fetch_kib_mean": round(fk, 2), "write_kib_mean": round(wk, 2),
                    "hbm_bytes_per_launch": int((2 * fk + wk) * 1024), "avg_ns_rocprof": int(window_avg_ns) if window_avg_ns else None,
-                   "dispatches_in_window": steps}
+                   "dispatches_in_window": 1 if persist else steps, "iterations_per_dispatch": per_disp}
 cfg = bench["config"] if bench else {}
 json.dump({"_comment": "HBM-side traffic per dispatch of the dominant kernel over bench.py's timed window, from rocprofv3 PMC passes "
                        "(tools/profile.sh: separate passes for FETCH_SIZE and WRITE_SIZE, counter unit KiB).  gfx950 correction per "
