@@ -1864,23 +1864,60 @@ __global__ void __launch_bounds__(kBlock) flatten_kernel(Buffers B, int nf) {
 // One block: the scan every block of a small context does for itself (scan_block_totals: same association, so the
 // results are bit-identical), once, into global memory: [0..nb] exclusive prefix, [nb+1] sum w, [nb+2] sum w^2.
 // Round 5: with the prefix built in global memory every thread re-read its own 16 stores one dependent trip at a time, and its
-// totals came in four dependent batches: 12.9 us for 3 912 totals (11.6 % of a config-4 step).  lds_mode (linear weights, the
-// table fits): the whole table by LDS-DMA, all requests in flight at once (scan_issue_dma), the prefix built in LDS, one coalesced
-// copy out.  Same operations in the same order: the same bits.
-__host__ __device__ inline size_t scan_lds_bytes(int nb) { return sizeof(double) * (((size_t) nb + 2) & ~(size_t) 1) + 2 * sizeof(float) * (((size_t) nb + 255) & ~(size_t) 255); }
-__global__ void __launch_bounds__(kBlock) scan_kernel(WeightScratch ws, int logw, int lds_mode) {
+// totals came in four dependent batches: 12.9 us for 3 912 totals (11.6 % of a config-4 step).  reg_mode (linear weights): a
+// thread's segment (at most 32 totals: 8 192 blocks) is read in one burst -- contiguous, 64 bytes per thread at config 4 -- and
+// kept in REGISTERS (a first version staged table and prefix in LDS: 10.2 us, the segments' stride made every access a 32- or
+// 64-way bank conflict); the prefix goes straight out.  The operations of scan_finish in its order (k ascending inside a
+// segment, the wave scan, the waves' sums left to right): the same bits.
+constexpr int kScanMaxPer = kMaxScanBlocks / kBlock;
+__global__ void __launch_bounds__(kBlock) scan_kernel(WeightScratch ws, int logw, int reg_mode) {
     __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
-    extern __shared__ __align__(16) unsigned char scan_lds[];
     double W, Q, Mx;
     double *out = ws.scan[ws.wpar];
-    if (lds_mode) {
-        const int nb = ws.nblocks;
-        double *off = reinterpret_cast<double *>(scan_lds);
-        float *stab = reinterpret_cast<float *>(scan_lds + sizeof(double) * (((size_t) nb + 2) & ~(size_t) 1));
-        scan_issue_dma(ws.blk_w[ws.wpar], nb, nb, stab);
-        scan_finish(ScanLoads{0.0f, 0.0f, 0.0f, 0.0f, -INFINITY, -INFINITY}, ws.blk_w[ws.wpar], nb, nb, false, off, sh_a, sh_q, W, Q, Mx, stab);
+    if (reg_mode) {
+        const int nb = ws.nblocks, t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
+        const int per = (nb + kBlock - 1) / kBlock;
+        const int lo = min(nb, t * per), hi = min(nb, lo + per);
+        const float *__restrict__ tw = ws.blk_w[ws.wpar] + lo, *__restrict__ tq = ws.blk_w[ws.wpar] + nb + lo;
+        float fw[kScanMaxPer], fq[kScanMaxPer];
+#pragma unroll
+        for (int j = 0; j < kScanMaxPer; j++) {
+            const bool on = j < per && lo + j < hi;
+            fw[j] = on ? tw[j] : 0.0f;
+            fq[j] = on ? tq[j] : 0.0f;
+        }
+        double tk[kScanMaxPer];
+        double a = 0.0, q = 0.0;
+#pragma unroll
+        for (int j = 0; j < kScanMaxPer; j++) {
+            if (j < per && lo + j < hi) {
+                tk[j] = (double) fw[j] * 1.0;
+                a += tk[j];
+                q += (double) fq[j] * (tk[j] * tk[j]);
+            } else {
+                tk[j] = 0.0;
+            }
+        }
+        const double sa = wave_scan_d(a);
+        const double sq = wave_sum_d(q);
+        if (lane == kWave - 1) sh_a[wv] = sa;
+        if (lane == 0) sh_q[wv] = sq;
         __syncthreads();
-        for (int k = threadIdx.x; k <= nb; k += kBlock) out[k] = off[k];
+        double base = 0.0;
+#pragma unroll
+        for (int k = 0; k < kBlock / kWave; k++)
+            if (k < wv) base += sh_a[k];
+        double run = base + sa - a;
+#pragma unroll
+        for (int j = 0; j < kScanMaxPer; j++)
+            if (j < per && lo + j < hi) {
+                out[lo + j] = run;
+                run += tk[j];
+            }
+        W = ((sh_a[0] + sh_a[1]) + sh_a[2]) + sh_a[3];
+        Q = ((sh_q[0] + sh_q[1]) + sh_q[2]) + sh_q[3];
+        Mx = 0.0;
+        if (t == 0) out[nb] = W;
     } else {
         scan_block_totals(ws.blk_w[ws.wpar], ws.nblocks, ws.nblocks, logw != 0, out, sh_a, sh_q, W, Q, Mx);
     }
@@ -3033,9 +3070,7 @@ static void launch_resample_ref(hipStream_t st, const Buffers &B, const WeightSc
 }
 
 static void launch_scan(hipStream_t st, const WeightScratch &ws, int logw) {
-    const size_t need = scan_lds_bytes(ws.nblocks);
-    const bool lds_mode = !logw && ws.nblocks > 2 * kBlock && need <= 64 * 1024 - 256;
-    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), lds_mode ? need : 0, st, ws, logw, lds_mode ? 1 : 0);
+    hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(kBlock), 0, st, ws, logw, logw ? 0 : 1);
 }
 
 static void launch_gather(hipStream_t st, const Buffers &B, const WeightScratch &ws) {

@@ -1,7 +1,7 @@
 import os, re, subprocess, sys, tempfile
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-for exe in ("slam_amd/bin/slam-backend", "tools/scratch/r4/slam_amd/bin/slam-backend"):
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for exe in ("slam_amd/bin/slam-backend",):
     for N in (512, 2048):
         for seed in (7, 8, 9, 10, 11):
             for math in ("fast", "strict"):

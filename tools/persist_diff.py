@@ -1,6 +1,6 @@
 """diagnostic: per-step launches vs the persistent loop, first differing step and field (example_loop2, FS2, fast build)"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import slam_amd as sg
