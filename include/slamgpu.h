@@ -138,7 +138,9 @@ int slamgpu_device_count(void);
  *      column-major (core.cpp:608-617)                                        => 7 + 6n floats
  * out: per feature zp[2], Hf[4] row-major, Hv[6] row-major, Sf[4] row-major (core.cpp:631-651)
  *                                                                              => 16n floats
- * Host pointers; synchronous (this is the start()/isDone() spin of core.cpp:619-622). */
+ * Host pointers; synchronous (this is the start()/isDone() spin of core.cpp:619-622).  Both seam-1 calls take no context:
+ * they run on the calling thread's CURRENT HIP device (hipSetDevice; device 0 by default), on its null stream, and keep a
+ * grow-only device scratch per calling thread. */
 int slamgpu_jacobians(const float *in, uint32_t n, float *out);
 /* The same for the MULTIPARTICLE_ACCELERATOR form of the window (AcceleratorHandler.h:17-21: setParticlesCount + start;
  * written and read back at algorithms/fastslam2.cpp:172-286): `records` self-describing records back to back in ONE host

@@ -61,14 +61,16 @@ SLAM_DEV Jac jacobian(float x, float y, float th, float fx, float fy, float p00,
     float d = fsqrt(d2);
     j.zp0 = d;
     j.zp1 = trig_offset(atan2f(dy, dx) - th);
-    j.hv00 = fdiv(-dx, d);
-    j.hv01 = fdiv(-dy, d);
-    j.hv10 = fdiv(dy, d2);
-    j.hv11 = fdiv(-dx, d2);
+    // Hv's entries are Hf's negated (core.cpp:690-697 writes eight quotients); IEEE division is sign-symmetric, (-a) / b ==
+    // -(a / b) bit for bit, so four quotients are computed (the strict build's division is an 11-instruction sequence)
     j.hf00 = fdiv(dx, d);
     j.hf01 = fdiv(dy, d);
     j.hf10 = fdiv(-dy, d2);
     j.hf11 = fdiv(dx, d2);
+    j.hv00 = -j.hf00;
+    j.hv01 = -j.hf01;
+    j.hv10 = -j.hf10;
+    j.hv11 = -j.hf11;
     // T = Hf * Pf ; Sf = T * Hf^T + R  (k-ascending sums, GEMM order)
     float t00 = j.hf00 * p00 + j.hf01 * p10;
     float t01 = j.hf00 * p10 + j.hf01 * p11;
@@ -120,22 +122,28 @@ SLAM_DEV float determinant2(float a00, float a01, float a10, float a11) {
 // On a non-positive pivot at step k the remaining columns keep the input values, as Eigen leaves them.
 struct L3 {
     float l00, l10, l11, l20, l21, l22;
+    // 1 / l00 and 1 / l11 as the factorisation computed them (valid when it got that far: r0 != 0 / r1 != 0); the solve below
+    // needs the same two quotients again
+    float r0, r1;
 };
 
 SLAM_DEV L3 llt3(float a00, float a10, float a11, float a20, float a21, float a22) {
-    L3 L = {a00, a10, a11, a20, a21, a22};
+    L3 L = {a00, a10, a11, a20, a21, a22, 0.0f, 0.0f};
     float x = a00;
     if (x <= 0.0f) return L;
     x = fsqrt(x);
     L.l00 = x;
     float r = frcp(x);
+    L.r0 = r;
     L.l10 = a10 * r;
     L.l20 = a20 * r;
     x = a11 - L.l10 * L.l10;
     if (x <= 0.0f) return L;
     x = fsqrt(x);
     L.l11 = x;
-    L.l21 = (a21 + L.l20 * (-1.0f * L.l10)) * frcp(x);
+    r = frcp(x);
+    L.r1 = r;
+    L.l21 = (a21 + L.l20 * (-1.0f * L.l10)) * r;
     x = a22 - (L.l20 * L.l20 + L.l21 * L.l21);
     if (x <= 0.0f) return L;
     L.l22 = fsqrt(x);
@@ -162,7 +170,8 @@ SLAM_DEV L2 llt2(float a00, float a10, float a11) {
 // A.llt().solve(Identity) for 3x3 (TriangularSolverMatrix.h:109-137): column-oriented forward
 // substitution with reciprocal diagonals, then row-oriented back substitution.  X row-major, full.
 SLAM_DEV void llt_solve_identity3(const L3 &L, float X[9]) {
-    float a0 = frcp(L.l00), a1 = frcp(L.l11), a2 = frcp(L.l22);
+    // (a reciprocal is never 0 for a finite positive pivot: r0 / r1 == 0 means the factorisation stopped before it)
+    float a0 = L.r0 != 0.0f ? L.r0 : frcp(L.l00), a1 = L.r1 != 0.0f ? L.r1 : frcp(L.l11), a2 = frcp(L.l22);
     // Y = L^-1 I
     float y00 = a0;
     float y10 = 0.0f - y00 * L.l10;

@@ -1004,6 +1004,15 @@ int slamgpu_predict(slamgpu_ctx *c, float V, float G, const float Q[4], float dt
     s.cosG = cosf(G);
     s.sinGw = sinf(G / c->cfg.wheel_base);
     s.pad = 0;
+    {  // (this file is compiled with -ffp-contract=off: every operation below rounds to float32 as the strict kernel's did)
+        const float wb = c->cfg.wheel_base;
+        PredictRow3 &r = P.row3[P.nsteps - 1];
+        r.gu20 = dt * s.sinG / wb;
+        r.gu21 = V * dt * s.cosG / wb;
+        r.u20 = r.gu20 * Q[0] + r.gu21 * Q[2];
+        r.u21 = r.gu20 * Q[1] + r.gu21 * Q[3];
+        r.b22 = r.u20 * r.gu20 + r.u21 * r.gu21;
+    }
     c->est_fresh = false;
     c->shard_est_fresh = false;
     if (tape_noise) {
@@ -3268,6 +3277,46 @@ int slamgpu_algorithmic_bytes(slamgpu_ctx *c, double *update_bytes, double *pred
 }
 
 // ---- Seam 1 -----------------------------------------------------------------------------------------
+// Both entry points work on the CALLER's current HIP device and its null stream (they take no context).  Their device
+// buffers are a grow-only scratch per calling thread (the reference's accelerator loop calls once per particle window: a
+// hipMalloc / hipFree pair per call cost more than the 256 KB window's transfer).  The scratch is re-made when the thread's
+// current device changes and is left to the runtime at process exit.
+namespace {
+struct SeamScratch {
+    int device = -1;
+    void *buf[2] = {nullptr, nullptr};
+    size_t bytes[2] = {0, 0};
+};
+thread_local SeamScratch g_seam;
+
+int seam_reserve(int which, size_t bytes, void **out) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    SeamScratch &s = g_seam;
+    if (s.device != dev) {  // buffers of another device: give them back there
+        for (int k = 0; k < 2; k++)
+            if (s.buf[k]) {
+                if (hipSetDevice(s.device) == hipSuccess) (void) hipFree(s.buf[k]);
+                s.buf[k] = nullptr;
+                s.bytes[k] = 0;
+            }
+        HIP_TRY(hipSetDevice(dev));
+        s.device = dev;
+    }
+    if (s.bytes[which] < bytes) {
+        if (s.buf[which]) (void) hipFree(s.buf[which]);
+        s.buf[which] = nullptr;
+        s.bytes[which] = 0;
+        const size_t want = std::max(bytes + bytes / 2, (size_t) 1 << 16);
+        hipError_t e = hipMalloc(&s.buf[which], want);
+        if (e != hipSuccess) return fail(SLAMGPU_ERR_ALLOC, "hipMalloc(%zu): %s", want, hipGetErrorString(e));
+        s.bytes[which] = want;
+    }
+    *out = s.buf[which];
+    return 0;
+}
+}  // namespace
+
 int slamgpu_jacobians(const float *in, uint32_t n, float *out) {
     if (!in || (n > 0 && !out)) return fail(SLAMGPU_ERR_INVALID, "null buffer");
     if (n == 0) return 0;
@@ -3275,29 +3324,22 @@ int slamgpu_jacobians(const float *in, uint32_t n, float *out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SLAMGPU_ERR_NO_DEVICE, "no HIP device: libslamgpu has no CPU fallback");
     float *din = nullptr, *dout = nullptr;
     const size_t nin = 7 + 6 * (size_t) n, nout = 16 * (size_t) n;
-    HIP_TRY(hipMalloc((void **) &din, sizeof(float) * nin));
-    hipError_t e = hipMalloc((void **) &dout, sizeof(float) * nout);
-    if (e != hipSuccess) {
-        (void) hipFree(din);
-        return fail(SLAMGPU_ERR_ALLOC, "hipMalloc: %s", hipGetErrorString(e));
-    }
-    int rc = 0;
-    if ((e = hipMemcpy(din, in, sizeof(float) * nin, hipMemcpyHostToDevice)) != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "H2D: %s", hipGetErrorString(e));
-    if (!rc) {
-        kernels_strict()->jacobians(nullptr, din, n, dout);
-        if ((e = hipGetLastError()) != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "launch: %s", hipGetErrorString(e));
-    }
-    if (!rc && (e = hipMemcpy(out, dout, sizeof(float) * nout, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "D2H: %s", hipGetErrorString(e));
-    (void) hipFree(din);
-    (void) hipFree(dout);
-    return rc;
+    if (int rc = seam_reserve(0, sizeof(float) * nin, (void **) &din)) return rc;
+    if (int rc = seam_reserve(1, sizeof(float) * nout, (void **) &dout)) return rc;
+    hipError_t e;
+    if ((e = hipMemcpy(din, in, sizeof(float) * nin, hipMemcpyHostToDevice)) != hipSuccess) return fail(SLAMGPU_ERR_HIP, "H2D: %s", hipGetErrorString(e));
+    kernels_strict()->jacobians(nullptr, din, n, dout);
+    if ((e = hipGetLastError()) != hipSuccess) return fail(SLAMGPU_ERR_HIP, "launch: %s", hipGetErrorString(e));
+    if ((e = hipMemcpy(out, dout, sizeof(float) * nout, hipMemcpyDeviceToHost)) != hipSuccess) return fail(SLAMGPU_ERR_HIP, "D2H: %s", hipGetErrorString(e));
+    return 0;
 }
 
 int slamgpu_jacobians_multi(float *window, uint32_t records, uint64_t window_floats) {
     if (!window && records > 0) return fail(SLAMGPU_ERR_INVALID, "null window");
     if (records == 0) return 0;
     // walk the self-describing records: [n][xv 3][R 4][n x 6 in][n x 16 out]
-    std::vector<uint32_t> tab;
+    thread_local std::vector<uint32_t> tab;
+    tab.clear();
     uint64_t pos = 0;
     for (uint32_t r = 0; r < records; r++) {
         if (pos + 8 > window_floats) return fail(SLAMGPU_ERR_INVALID, "record %u starts beyond the window (%llu floats)", r, (unsigned long long) window_floats);
@@ -3319,24 +3361,17 @@ int slamgpu_jacobians_multi(float *window, uint32_t records, uint64_t window_flo
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SLAMGPU_ERR_NO_DEVICE, "no HIP device: libslamgpu has no CPU fallback");
     float *dwin = nullptr;
     uint32_t *dtab = nullptr;
-    HIP_TRY(hipMalloc((void **) &dwin, sizeof(float) * pos));
-    hipError_t e = hipMalloc((void **) &dtab, sizeof(uint32_t) * tab.size());
-    if (e != hipSuccess) {
-        (void) hipFree(dwin);
-        return fail(SLAMGPU_ERR_ALLOC, "hipMalloc: %s", hipGetErrorString(e));
-    }
-    int rc = 0;
-    if ((e = hipMemcpy(dwin, window, sizeof(float) * pos, hipMemcpyHostToDevice)) != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "H2D: %s", hipGetErrorString(e));
-    if (!rc && (e = hipMemcpy(dtab, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice)) != hipSuccess)
-        rc = fail(SLAMGPU_ERR_HIP, "H2D: %s", hipGetErrorString(e));
-    if (!rc) {
-        kernels_strict()->jacobians_multi(nullptr, dwin, dtab, nfeat);
-        if ((e = hipGetLastError()) != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "launch: %s", hipGetErrorString(e));
-    }
-    if (!rc && (e = hipMemcpy(window, dwin, sizeof(float) * pos, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail(SLAMGPU_ERR_HIP, "D2H: %s", hipGetErrorString(e));
-    (void) hipFree(dwin);
-    (void) hipFree(dtab);
-    return rc;
+    if (int rc = seam_reserve(0, sizeof(float) * pos, (void **) &dwin)) return rc;
+    if (int rc = seam_reserve(1, sizeof(uint32_t) * tab.size(), (void **) &dtab)) return rc;
+    hipError_t e;
+    if ((e = hipMemcpy(dwin, window, sizeof(float) * pos, hipMemcpyHostToDevice)) != hipSuccess) return fail(SLAMGPU_ERR_HIP, "H2D: %s", hipGetErrorString(e));
+    if ((e = hipMemcpy(dtab, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice)) != hipSuccess) return fail(SLAMGPU_ERR_HIP, "H2D: %s", hipGetErrorString(e));
+    kernels_strict()->jacobians_multi(nullptr, dwin, dtab, nfeat);
+    if ((e = hipGetLastError()) != hipSuccess) return fail(SLAMGPU_ERR_HIP, "launch: %s", hipGetErrorString(e));
+    // the whole window comes back (the outputs are interleaved with the inputs record by record; one copy of 256 KB costs
+    // less than a copy per record)
+    if ((e = hipMemcpy(window, dwin, sizeof(float) * pos, hipMemcpyDeviceToHost)) != hipSuccess) return fail(SLAMGPU_ERR_HIP, "D2H: %s", hipGetErrorString(e));
+    return 0;
 }
 
 int slamgpu_debug_stamps(slamgpu_ctx *c, uint64_t *out, int32_t max_blocks, int32_t *nblocks) {
