@@ -1,5 +1,6 @@
 // Host-visible launch interface of the gfx950 kernels (kernels.hip is compiled twice: slam_strict / slam_fast).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -54,6 +55,13 @@ constexpr int kRowMask = kRowFreshBit - 1;
 constexpr int kPoolBit = (int) 0x80000000;  // genealogy entry: the record lives in the arrival pool (Buffers::poolA/B)
 constexpr int kHistStride = 6;      // doubles per pose-estimate history entry: sum x, sum y, heading, max w, Neff, resampled
 constexpr int kMaxScanBlocks = 8192;
+// single contexts on the compact layout with more tiles than this run update_kernel_wide (kernels.hip)
+constexpr int kWideBlocks = 768;
+inline bool update_wide_off() {  // (diagnostic: SLAMGPU_NO_WIDE=1 keeps update_kernel at every size)
+    static const bool off = getenv("SLAMGPU_NO_WIDE") != nullptr;
+    return off;
+}
+inline bool update_is_wide(int arrivals, bool big, int nblocks) { return arrivals == 0 && !big && nblocks > kWideBlocks && !update_wide_off(); }
 // status bits of an update's resampling stage (slamgpu.h: SLAMGPU_STATUS_*)
 constexpr int kStatusBadPacket = 2;   // the kernel did not find its packet where the kernel-argument layout says (never seen)
 constexpr int kStatusCapacity = 4;    // device front end: more new landmarks than the context has room for (the surplus was dropped)

@@ -1240,6 +1240,69 @@ SLAM_DEV bool persist_batch_draws(int method, const PredictArgs &PA) {
 #endif
 }
 
+// (Doing the scan at the END of the update launch instead -- no launch of its own -- was built three ways in round 5 and removed,
+// 10^6 particles, us per step against 89.8 with scan_kernel: the last tile to arrive at ONE counter scans: 153.8 (3 907 agent-scope
+// atomics on one address serialise at ~17 ns); 64 counters and one above them: 90.8 (every tile then ends with a drain of its
+// stores and a returning atomic, ~3 us it stays resident for); the helper block polls totals the tiles store tagged and written
+// through: 91.2 (rocprofv3: the launch grows by 9.8 us where scan_kernel takes 7.9: a trip to the memory side is 2-3 us, and
+// "store lands, sweep sees it, sums, stores" is three of them -- what a kernel boundary and one HBM trip cost).)
+constexpr int kScanMaxPer = kMaxScanBlocks / kBlock;
+// P = the unrolled segment length (>= the totals per thread).  Every load is unconditional, at a clamped index (a first version
+// guarded each load with `lo + j < hi`: the compiler made a branch, a load and an s_waitcnt vmcnt(0) of every one -- 32 dependent
+// round trips, 9.4 us); a lane's surplus loads re-read the table's last entry and are masked out of the sums.
+template <int P>
+SLAM_DEV void scan_segments_sum(const float (&fw)[P], const float (&fq)[P], int nb, double *__restrict__ out, double *sh_a, double *sh_q, double &W,
+                                double &Q) {
+    const int t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
+    const int per = (nb + kBlock - 1) / kBlock;
+    const int lo = min(nb, t * per), hi = min(nb, lo + per);
+    double tk[P];
+    double a = 0.0, q = 0.0;
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        const bool on = lo + j < hi;
+        tk[j] = on ? (double) fw[j] * 1.0 : 0.0;
+        if (on) {  // (selects: the sums of the lanes' live entries in ascending order, as scan_finish adds them)
+            a += tk[j];
+            q += (double) fq[j] * (tk[j] * tk[j]);
+        }
+    }
+    const double sa = wave_scan_d(a);
+    const double sq = wave_sum_d(q);
+    if (lane == kWave - 1) sh_a[wv] = sa;
+    if (lane == 0) sh_q[wv] = sq;
+    __syncthreads();
+    double base = 0.0;
+#pragma unroll
+    for (int k = 0; k < kBlock / kWave; k++)
+        if (k < wv) base += sh_a[k];
+    double run = base + sa - a;
+#pragma unroll
+    for (int j = 0; j < P; j++)
+        if (lo + j < hi) {
+            out[lo + j] = run;
+            run += tk[j];
+        }
+    W = ((sh_a[0] + sh_a[1]) + sh_a[2]) + sh_a[3];
+    Q = ((sh_q[0] + sh_q[1]) + sh_q[2]) + sh_q[3];
+    if (t == 0) out[nb] = W;
+}
+
+template <int P>
+SLAM_DEV void scan_segments(const float *__restrict__ tw, const float *__restrict__ tq, int nb, double *__restrict__ out, double *sh_a, double *sh_q,
+                            double &W, double &Q) {
+    const int per = (nb + kBlock - 1) / kBlock;
+    const int lo = min(nb, (int) threadIdx.x * per);
+    float fw[P], fq[P];
+#pragma unroll
+    for (int j = 0; j < P; j++) {
+        const int at = min(lo + j, nb - 1);
+        fw[j] = tw[at];
+        fq[j] = tq[at];
+    }
+    scan_segments_sum<P>(fw, fq, nb, out, sh_a, sh_q, W, Q);
+}
+
 // PERSIST (update_persist_kernel, kernels.h: PersistArgs): the same step as ONE ITERATION of a launch that runs K of them.  What
 // the launch boundary gives a per-step launch comes from elsewhere: the iteration's arguments from `qe` (an LDS copy of its queue
 // entry), the live buffer and the front end's state from `carry` (registers; no workgroup re-reads a Ctrl word or the state
@@ -1260,6 +1323,29 @@ __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict_
                                                          const FrontState *h_front, int h_nb, int h_slot, int h_grid, int h_flags, Buffers B, PredictArgs PA,
                                                          UpdateArgs U, RngArgs rng, WeightScratch ws) {
     constexpr bool PERSIST = false;
+    const PersistStep *const qe = nullptr;
+    StepCarry carry;  // (unused by a per-step launch)
+#define STEP_WPAR ws.wpar
+#define STEP_PLAN (U.plan_inline != 0)
+#define STEP_FRONT U.front
+#include "update_step.inl"
+#undef STEP_WPAR
+#undef STEP_PLAN
+#undef STEP_FRONT
+}
+
+// The same step for sets of more than kWideBlocks tiles on one GPU (compact layout, single context), compiled for THREE waves per
+// SIMD (168 vector registers, 4 of them spilled: update_kernel takes 179 and gets two).  At 10^5 particles the launch is a single
+// round of tiles and the registers buy latency; from ~2 x 10^5 on the tiles queue for the CUs and a third resident tile per CU
+// hides more of each tile's dependent chain than the spills cost.  Same box, us per step, update_kernel -> this: 125 000
+// particles 15.0 -> 15.2 (not used there), 250 000: 29.0 -> 28.0, 500 000: 55.1 -> 48.1, 10^6 (BASELINE config 4 on one GPU):
+// 103.0 -> 88.1; four waves per SIMD (128 registers, 30 spilled): 120.9.  Same source text, same contraction rule: bit-identical.
+template <int METHOD>
+__global__ void __launch_bounds__(kBlock, 3) update_kernel_wide(const float *__restrict__ h_tot, Ctrl *h_ctrl, const FrontState *h_front, int h_nb,
+                                                                 int h_slot, int h_grid, int h_flags, Buffers B, PredictArgs PA, UpdateArgs U,
+                                                                 RngArgs rng, WeightScratch ws) {
+    constexpr int MODE = 0;
+    constexpr bool BIG = false, PERSIST = false;
     const PersistStep *const qe = nullptr;
     StepCarry carry;  // (unused by a per-step launch)
 #define STEP_WPAR ws.wpar
@@ -1870,55 +1956,17 @@ __global__ void __launch_bounds__(kBlock) flatten_kernel(Buffers B, int nf) {
 // kept in REGISTERS (a first version staged table and prefix in LDS: 10.2 us, the segments' stride made every access a 32- or
 // 64-way bank conflict); the prefix goes straight out.  The operations of scan_finish in its order (k ascending inside a
 // segment, the wave scan, the waves' sums left to right): the same bits.
-constexpr int kScanMaxPer = kMaxScanBlocks / kBlock;
 __global__ void __launch_bounds__(kBlock) scan_kernel(WeightScratch ws, int logw, int reg_mode) {
     __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
-    double W, Q, Mx;
+    double W, Q, Mx = 0.0;
     double *out = ws.scan[ws.wpar];
-    if (reg_mode) {
-        const int nb = ws.nblocks, t = threadIdx.x, lane = t & (kWave - 1), wv = t / kWave;
-        const int per = (nb + kBlock - 1) / kBlock;
-        const int lo = min(nb, t * per), hi = min(nb, lo + per);
-        const float *__restrict__ tw = ws.blk_w[ws.wpar] + lo, *__restrict__ tq = ws.blk_w[ws.wpar] + nb + lo;
-        float fw[kScanMaxPer], fq[kScanMaxPer];
-#pragma unroll
-        for (int j = 0; j < kScanMaxPer; j++) {
-            const bool on = j < per && lo + j < hi;
-            fw[j] = on ? tw[j] : 0.0f;
-            fq[j] = on ? tq[j] : 0.0f;
-        }
-        double tk[kScanMaxPer];
-        double a = 0.0, q = 0.0;
-#pragma unroll
-        for (int j = 0; j < kScanMaxPer; j++) {
-            if (j < per && lo + j < hi) {
-                tk[j] = (double) fw[j] * 1.0;
-                a += tk[j];
-                q += (double) fq[j] * (tk[j] * tk[j]);
-            } else {
-                tk[j] = 0.0;
-            }
-        }
-        const double sa = wave_scan_d(a);
-        const double sq = wave_sum_d(q);
-        if (lane == kWave - 1) sh_a[wv] = sa;
-        if (lane == 0) sh_q[wv] = sq;
-        __syncthreads();
-        double base = 0.0;
-#pragma unroll
-        for (int k = 0; k < kBlock / kWave; k++)
-            if (k < wv) base += sh_a[k];
-        double run = base + sa - a;
-#pragma unroll
-        for (int j = 0; j < kScanMaxPer; j++)
-            if (j < per && lo + j < hi) {
-                out[lo + j] = run;
-                run += tk[j];
-            }
-        W = ((sh_a[0] + sh_a[1]) + sh_a[2]) + sh_a[3];
-        Q = ((sh_q[0] + sh_q[1]) + sh_q[2]) + sh_q[3];
-        Mx = 0.0;
-        if (t == 0) out[nb] = W;
+    if (reg_mode && ws.nblocks > 0) {
+        const int per = (ws.nblocks + kBlock - 1) / kBlock;
+        const float *tw = ws.blk_w[ws.wpar], *tq = tw + ws.nblocks;
+        if (per <= 4) scan_segments<4>(tw, tq, ws.nblocks, out, sh_a, sh_q, W, Q);
+        else if (per <= 8) scan_segments<8>(tw, tq, ws.nblocks, out, sh_a, sh_q, W, Q);
+        else if (per <= 16) scan_segments<16>(tw, tq, ws.nblocks, out, sh_a, sh_q, W, Q);
+        else scan_segments<kScanMaxPer>(tw, tq, ws.nblocks, out, sh_a, sh_q, W, Q);
     } else {
         scan_block_totals(ws.blk_w[ws.wpar], ws.nblocks, ws.nblocks, logw != 0, out, sh_a, sh_q, W, Q, Mx);
     }
@@ -3027,6 +3075,15 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
 #define SLAM_LAUNCH_UPDATE(M, A, G)                                                                                              \
     hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid, \
                        h_flags, B, PA, U, rng, ws)
+    if (update_is_wide(U.arrivals, U.big != nullptr, ws.nblocks)) {  // (single context, compact layout, more tiles than two rounds of CUs)
+        if (sel == 6)
+            hipLaunchKernelGGL((update_kernel_wide<2>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid,
+                               h_flags, B, PA, U, rng, ws);
+        else
+            hipLaunchKernelGGL((update_kernel_wide<1>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid,
+                               h_flags, B, PA, U, rng, ws);
+        return;
+    }
     switch (sel) {
         case 11: SLAM_LAUNCH_UPDATE(2, 2, true); break;
         case 10: SLAM_LAUNCH_UPDATE(2, 2, false); break;
