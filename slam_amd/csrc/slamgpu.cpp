@@ -1629,6 +1629,7 @@ static int run_observe_persist(slamgpu_ctx *c, int32_t K, const int32_t *n_contr
         U.persist.queue = qh;
         U.persist.K = (int32_t) n;
         U.persist.max_spins = 1u << 20;
+        if (const char *e = getenv("SLAMGPU_PERSIST_MAX_SPINS")) U.persist.max_spins = (uint32_t) std::max(0, atoi(e));  // tests: the abandon path
         U.persist.sync = c->psync_dev;
         U.persist.host_status = c->pstatus_host;
         U.persist.state_final = c->front_dev + c->front_par;  // (the copy the next launch reads)

@@ -421,3 +421,41 @@ def test_run_observe_refuses_before_it_applies_anything(sg):
     assert np.array_equal(np.asarray(est), np.asarray(est_ref))
     s.close()
     ref.close()
+
+
+def test_persistent_loop_that_is_abandoned_says_so(sg, monkeypatch):
+    """The persistent step loop's spins are bounded: a workgroup that waits longer than the bound sets the abort word, every
+    workgroup leaves the launch, and whoever synchronises with the device next gets SLAMGPU_ERR_BARRIER (sticky).  Forced here
+    with a bound of 0 polls (SLAMGPU_PERSIST_MAX_SPINS): the launch ends at its first meeting, the call that waits for the device
+    fails loudly, the context can be destroyed, and the GPU takes the next context as if nothing had happened."""
+    from slam_amd import host
+    args = sim_args("example_webmap", "FASTSLAM1", 100, 7)
+    tape = host.make_tape(args, max_obs=40)
+    sim = host.HostSim(args)
+    lm, _ = sim.map()
+    max_range = float(sim.conf.MAX_RANGE)
+    sim.close()
+    steps = tape["steps"]
+    ctl = [np.array(st["controls"], f32).reshape(-1, 3) for st in steps]
+    xt = [np.asarray(st["true"], f32) for st in steps]
+
+    def make():
+        s = sg.SlamGpu(1000, tape["nlm"], method=1, n_effective=750, rng_mode=sg.RNG_PHILOX, seed=5, math_mode=1, device_observe=True)
+        s.set_map(lm)
+        return s
+
+    monkeypatch.setenv("SLAMGPU_PERSIST_MAX_SPINS", "0")
+    s = make()
+    with pytest.raises(sg.SlamGpuError) as ei:
+        s.run_observe(ctl[:32], tape["Q"], float(tape["dt"]), xt[:32], max_range, tape["R"], noise=2)
+        s.history_fetch()
+    assert ei.value.code == -6, ei.value   # SLAMGPU_ERR_BARRIER (include/slamgpu.h)
+    with pytest.raises(sg.SlamGpuError):   # (sticky)
+        s.sync()
+    s.close()
+    monkeypatch.delenv("SLAMGPU_PERSIST_MAX_SPINS")
+    s = make()
+    s.run_observe(ctl[:32], tape["Q"], float(tape["dt"]), xt[:32], max_range, tape["R"], noise=2)
+    hist = s.history_fetch()
+    assert len(hist[0]) == 32 and s.persist_info() == (1, 32)
+    s.close()
