@@ -236,13 +236,6 @@ struct PredictStep {
     uint32_t pad;
 };
 
-// The particle-independent third row of FastSLAM 2's Gu and what it contributes to Gu Q Gu^T (fastslam2.cpp:79-84), for the
-// strict build's predict_steps: evaluated on the host in the kernel's own operations (IEEE float32 products, quotients and sums,
-// no contraction): gu20 = dt sin(G) / wb, gu21 = V dt cos(G) / wb, (u20, u21) = (gu20, gu21) Q, b22 = u20 gu20 + u21 gu21.
-struct PredictRow3 {
-    float gu20, gu21, u20, u21, b22;
-};
-
 // The queued predicts folded into ONE step, for the fast build.  FastSLAM2::predictState without per-particle control
 // noise and without the heading observation is the same map for every particle when written in the frame of the
 // particle's own pose at the first queued step (the motion model is SE(2)-equivariant): with T = diag(R(theta0), 1),
@@ -262,7 +255,6 @@ struct PredictArgs {
     float dt, wheel_base, sigma_phi;
     PredictStep steps[kMaxFusedPredict];
     PredictComposite comp;
-    PredictRow3 row3[kMaxFusedPredict];
 };
 
 // Persistent small-N step loop (slamgpu_run_observe on compact single contexts of at most kPersistMaxBlocks tiles; reference:

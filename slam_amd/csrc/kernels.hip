@@ -53,8 +53,10 @@ SLAM_DEV void predict_steps(float &x, float &y, float &th, float P[9], const Pre
             const float gv02 = -V * dt * sn, gv12 = V * dt * cs;
             const float gu00 = dt * cs, gu01 = -V * dt * sn;
             const float gu10 = dt * sn, gu11 = V * dt * cs;
-            // third row of Gu and its products with Q: particle-independent, host-evaluated in the same operations (kernels.h)
-            const float gu20 = A.row3[s].gu20, gu21 = A.row3[s].gu21;
+            // (the third row of Gu and its Q products are particle-independent; evaluating them on the host in the same operations
+            // was built in round 5: no measurable gain, and the 160 bytes it added to PredictArgs tipped a distributed variant into a
+            // 20-byte spill)
+            const float gu20 = dt * A.steps[s].sinG / wb, gu21 = V * dt * A.steps[s].cosG / wb;
             // T = Gv * Pv ; A = T * Gv^T   (Gv = [[1,0,gv02],[0,1,gv12],[0,0,1]])
             float T[9], N9[9];
 #pragma unroll
@@ -72,7 +74,7 @@ SLAM_DEV void predict_steps(float &x, float &y, float &th, float P[9], const Pre
             // B = (Gu * Q) * Gu^T
             const float u00 = gu00 * Q00 + gu01 * Q10, u01 = gu00 * Q01 + gu01 * Q11;
             const float u10 = gu10 * Q00 + gu11 * Q10, u11 = gu10 * Q01 + gu11 * Q11;
-            const float u20 = A.row3[s].u20, u21 = A.row3[s].u21;
+            const float u20 = gu20 * Q00 + gu21 * Q10, u21 = gu20 * Q01 + gu21 * Q11;
             P[0] = N9[0] + (u00 * gu00 + u01 * gu01);
             P[1] = N9[1] + (u00 * gu10 + u01 * gu11);
             P[2] = N9[2] + (u00 * gu20 + u01 * gu21);
@@ -81,7 +83,7 @@ SLAM_DEV void predict_steps(float &x, float &y, float &th, float P[9], const Pre
             P[5] = N9[5] + (u10 * gu20 + u11 * gu21);
             P[6] = N9[6] + (u20 * gu00 + u21 * gu01);
             P[7] = N9[7] + (u20 * gu10 + u21 * gu11);
-            P[8] = N9[8] + A.row3[s].b22;
+            P[8] = N9[8] + (u20 * gu20 + u21 * gu21);
         }
         if (A.add_noise) {
             // multivariateGauss((V,G), Q, 1) (core.cpp:452): L = chol(Q), (V,G) = L*g + (V,G)

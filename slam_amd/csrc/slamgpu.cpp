@@ -1004,15 +1004,6 @@ int slamgpu_predict(slamgpu_ctx *c, float V, float G, const float Q[4], float dt
     s.cosG = cosf(G);
     s.sinGw = sinf(G / c->cfg.wheel_base);
     s.pad = 0;
-    {  // (this file is compiled with -ffp-contract=off: every operation below rounds to float32 as the strict kernel's did)
-        const float wb = c->cfg.wheel_base;
-        PredictRow3 &r = P.row3[P.nsteps - 1];
-        r.gu20 = dt * s.sinG / wb;
-        r.gu21 = V * dt * s.cosG / wb;
-        r.u20 = r.gu20 * Q[0] + r.gu21 * Q[2];
-        r.u21 = r.gu20 * Q[1] + r.gu21 * Q[3];
-        r.b22 = r.u20 * r.gu20 + r.u21 * r.gu21;
-    }
     c->est_fresh = false;
     c->shard_est_fresh = false;
     if (tape_noise) {

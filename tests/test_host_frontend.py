@@ -188,7 +188,9 @@ def test_slam_backend_cli_ekf_and_loud_failure_without_gpu():
 def test_no_kernel_spills_to_scratch(tmp_path):
     """Performance guard (no GPU needed: hipcc cross-compiles): an indexed register array that the compiler cannot keep
     in registers lands in the private segment, which cost the update kernel ~5 us per launch twice during development.
-    Every kernel of both builds must report a private segment of 0 bytes."""
+    Every kernel of both builds must report a private segment of 0 bytes -- except update_kernel_wide, which is compiled for three
+    waves per SIMD on purpose (168 registers: a handful of spilled registers buy the third resident tile per CU: 103 -> 88 us per
+    step at 10^6 particles, profiles/wide_kernel_r05.txt): bounded."""
     import re
     import shutil
     import subprocess
@@ -208,4 +210,7 @@ def test_no_kernel_spills_to_scratch(tmp_path):
         assert len(sizes) >= 12
         for kernel, size in sizes.items():
             # (no exemption: the distributed variants of update_kernel used to park four pointers in a 40-byte private array)
+            if "update_kernel_wide" in kernel:
+                assert size <= 128, (name, kernel, size)
+                continue
             assert size == 0, (name, kernel, size)
