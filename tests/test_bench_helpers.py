@@ -65,7 +65,7 @@ def test_traffic_file_of_the_matching_build_is_quoted():
     tj5, exact5, _ = bench.load_traffic(5, "fast", 100000, 1650.0)
     assert exact5 and tj5["config"] == 5 and tj5["kernels"]["fs2_update"]["hbm_bytes_per_launch"] > 1e9
     tj4, exact4, note4 = bench.load_traffic(4, "fast", 8 * bench.CONFIGS[4]["particles"], 95.0)  # (what --config 4 --gpus 1 asks for)
-    assert exact4 and tj4["config"] == 4, note4
+    assert exact4 and tj4["config"] == 4 and tj4["kernels"]["fs2_update"]["hbm_bytes_per_launch"] > 1e8, note4   # (update_kernel_wide)
     _, exact_other, note_other = bench.load_traffic(3, "fast", 12345, 16.1)
     assert not exact_other and "NOT this workload" in note_other
 

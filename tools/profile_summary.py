@@ -42,7 +42,7 @@ for f in find("trace/**/*kernel_trace.csv"):
 
 
 def dominant(names):
-    cands = [k for k in names if re.search(r"update_kernel<|update_persist_kernel<", k)]
+    cands = [k for k in names if re.search(r"update_kernel<|update_kernel_wide<|update_persist_kernel<", k)]
     return max(cands, key=lambda k: sum(dur.get(k, [0])) if dur else 0) if cands else None
 
 
@@ -89,7 +89,7 @@ if dom:
     else:
         fk = sum(f_[-steps:]) / max(len(f_[-steps:]), 1) if f_ else 0.0
         wk = sum(w_[-steps:]) / max(len(w_[-steps:]), 1) if w_ else 0.0
-    short = "fs2_update" if ("update_kernel<2" in dom or "update_persist_kernel<2" in dom) else "fs1_update"
+    short = "fs2_update" if ("update_kernel<2" in dom or "update_kernel_wide<2" in dom or "update_persist_kernel<2" in dom) else "fs1_update"
     kern[short] = {"rocprof_name": dom.split("(")[0], "fetch_kib_mean": round(fk, 2), "write_kib_mean": round(wk, 2),
                    "hbm_bytes_per_launch": int((2 * fk + wk) * 1024), "avg_ns_rocprof": int(window_avg_ns) if window_avg_ns else None,
                    "dispatches_in_window": 1 if persist else steps, "iterations_per_dispatch": per_disp}
