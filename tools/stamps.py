@@ -8,7 +8,8 @@ wave's outstanding memory operations and records the 100 MHz wall clock at ten p
 over blocks and launches of the time since the EARLIEST block entered the kernel, split by whether the launch had to
 perform the previous step's resampling (inline plan fired) or not.
 
-usage: python tools/stamps.py [N] [samples] [host|device] [FASTSLAM2|FASTSLAM1] [fast|strict]  (writes a table to stdout; copy into profiles/)
+usage: python tools/stamps.py [N] [samples] [host|device] [FASTSLAM2|FASTSLAM1] [fast|strict] [map]  (writes a table to stdout; copy into profiles/)
+       map: a bundled map's name (default example_webmap), e.g. example_loop902
        strict: the strict build's kernels (`make -C slam_amd/csrc stamps_strict`)
        device: the steps are slamgpu_step_observe calls (the observation front end inside the update launch)"""
 import os
@@ -17,6 +18,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 STRICT = len(sys.argv) > 5 and sys.argv[5] == "strict"
+MAP = sys.argv[6] if len(sys.argv) > 6 else "example_webmap"
 os.environ["SLAMGPU_LIB"] = os.path.join(ROOT, "slam_amd", "libslamgpu_stamps_strict.so" if STRICT else "libslamgpu_stamps.so")
 os.environ["SLAMGPU_STAMPS"] = "1"
 import numpy as np  # noqa: E402
@@ -35,17 +37,18 @@ LEVELS = ["0 kernel entry (first block = 0)", "1 Ctrl words arrived", "2 block t
           "10 queued predicts applied"]
 ORDER = [0, 1, 2, 3, 4, 10, 5, 6, 7, 8, 9]   # the order the kernel passes them in
 
-tape = host.make_tape(["-m", os.path.join(ROOT, "data", "example_webmap.mat"), "-method", METHOD, "-NPARTICLES", N,
+tape = host.make_tape(["-m", os.path.join(ROOT, "data", MAP + ".mat"), "-method", METHOD, "-NPARTICLES", N,
                        "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", 7], max_obs=START + SAMPLES + 2)
 Q, R, dt = tape["Q"], tape["R"], float(tape["dt"])
-_sim = host.HostSim(["-m", os.path.join(ROOT, "data", "example_webmap.mat"), "-method", "FASTSLAM2"])
+_sim = host.HostSim(["-m", os.path.join(ROOT, "data", MAP + ".mat"), "-method", "FASTSLAM2"])
 LM, _ = _sim.map()
 MAX_RANGE = float(_sim.conf.MAX_RANGE)
 _sim.close()
 
 
 def make():
-    s = slam_amd.SlamGpu(N, tape["nlm"], method=MID, n_effective=int(0.75 * N), rng_mode=slam_amd.RNG_PHILOX, seed=7, math_mode=0 if STRICT else 1, device_observe=DEVICE)
+    s = slam_amd.SlamGpu(N, tape["nlm"], method=MID, n_effective=int(0.75 * N), rng_mode=slam_amd.RNG_PHILOX, seed=7, math_mode=0 if STRICT else 1, device_observe=DEVICE,
+                        use_heading=bool(tape["conf"].SWITCH_HEADING_KNOWN), wheel_base=float(tape["conf"].WHEELBASE), sigma_phi=float(tape["conf"].sigmaT))
     if DEVICE:
         s.set_map(LM)
         calls = [s.prepare_step_observe(np.array(st["controls"], np.float32).reshape(-1, 3), Q, dt, st["true"], MAX_RANGE, R, noise=2) for st in tape["steps"]]
@@ -114,7 +117,7 @@ def table(title, stamp_sets):
 
 print("observation front end: %s" % ("inside the update launch (slamgpu_step_observe)" if DEVICE else "host (slamgpu_step)"))
 print("method %s" % METHOD)
-print("N = %d particles, steps %d..%d of the example_webmap run, %s build, instrumented (thread 0 of each block drains vmcnt/lgkmcnt at each stamp)" % (N, START, START + SAMPLES, "strict" if STRICT else "fast"))
+print("N = %d particles, steps %d..%d of the %s run, %s build, instrumented (thread 0 of each block drains vmcnt/lgkmcnt at each stamp)" % (N, START, START + SAMPLES, MAP, "strict" if STRICT else "fast"))
 table("update launches that do NOT plan inline (previous stage already ran: pose read at slot i or through keep[])", last)
 fired = [st for (kk, st) in pairs if res2[kk - START - 1]]
 quiet = [st for (kk, st) in pairs if not res2[kk - START - 1]]
