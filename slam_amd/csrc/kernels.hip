@@ -8,15 +8,29 @@
 namespace SLAM_KNS {
 using namespace slamgpu;
 
+// The queued controls of a step (PredictArgs::steps as 8 floats per step) where the predict loops read them: ALWAYS in LDS (the
+// per-step launch parks them there, the persistent loop's queue entry lives there) or null (big maps: read from the kernel
+// arguments).  A typed LDS pointer: as a generic `const float *` the loops read them with flat_load + s_waitcnt vmcnt(0) -- every
+// step of a predict loop waited for whatever else was in flight (the genealogy chunks of a resampling launch) and paid a flat
+// load's latency instead of a ds_read's (round 5, found in the ISA of the heading-observed predicts).
+typedef const __attribute__((address_space(3))) float *CtlP;
+
 // Diagnostic build only (make stamps -> libslamgpu_stamps.so, tools/stamps.py): thread 0 of every compute block drains its
 // wave's outstanding memory operations and records the 100 MHz wall clock at the levels of the update kernel's
 // dependent-load chain.  The drain is the point (the stamp is the time the level's data has ARRIVED); it perturbs the
 // overlap a little, so the instrumented kernel is slower than the product's.  Compiled out of the product libraries.
+// SLAM_STAMPS=2 (make stamps_flow): no drain -- the stamp is the time the block's first wave REACHED the point in the product's
+// own schedule (the waits it would have made anyway included): where the time of an undisturbed launch goes.
 #ifdef SLAM_STAMPS
+#if SLAM_STAMPS == 2
+#define SLAM_STAMP_DRAIN() asm volatile("" ::: "memory")
+#else
+#define SLAM_STAMP_DRAIN() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")
+#endif
 #define SLAM_STAMP(k)                                                                                      \
     do {                                                                                                   \
         if (U.stamps && threadIdx.x == 0 && bid < ws.nblocks) {                                            \
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                    \
+            SLAM_STAMP_DRAIN();                                                                            \
             U.stamps[(size_t) bid * kStampSlots + (k)] = wall_clock64();                                   \
         }                                                                                                  \
     } while (0)
@@ -159,7 +173,7 @@ SLAM_DEV void predict_steps(float &x, float &y, float &th, float P[9], const Pre
 // kernel-argument segment per iteration (scalar cache misses at every launch: ~0.3 us each on the step's critical chain)
 // the (V, G) normals of steps s0 .. s0 + nb - 1 (nb <= W) of predict_steps_fs1_fast, made TOGETHER (see there)
 template <int W>
-SLAM_DEV void draw_batch_fs1_fast(float (&g0)[W], float (&g1)[W], const PredictArgs &A, const RngArgs &rng, int i, size_t S, const float *ctl,
+SLAM_DEV void draw_batch_fs1_fast(float (&g0)[W], float (&g1)[W], const PredictArgs &A, const RngArgs &rng, int i, size_t S, CtlP ctl,
                                   int s0, int nb) {
     if (rng.mode == 0) {
 #pragma unroll
@@ -187,7 +201,7 @@ SLAM_DEV void draw_batch_fs1_fast(float (&g0)[W], float (&g1)[W], const PredictA
 
 // ... and the steps applied, one after the other
 template <int W>
-SLAM_DEV void apply_batch_fs1_fast(float &x, float &y, float &th, const float (&g0)[W], const float (&g1)[W], const PredictArgs &A, const float *ctl,
+SLAM_DEV void apply_batch_fs1_fast(float &x, float &y, float &th, const float (&g0)[W], const float (&g1)[W], const PredictArgs &A, CtlP ctl,
                                    float dt, float iwb, const L2 &L, int s0, int nb) {
     // a step's heading needs only the headings before it (a chain of one FMA and one wrap per step); its sine and cosine need
     // only that heading: in a full batch the headings are run first and the W sincos pairs are independent
@@ -229,7 +243,7 @@ SLAM_DEV void apply_batch_fs1_fast(float &x, float &y, float &th, const float (&
 // The operations of apply_batch_fs1_fast's `heading` and `position`, each on the same values: identical bits.
 template <int W>
 SLAM_DEV void controls_batch_fs1_fast(float (&vd)[W], float (&gs)[W], float (&sgw)[W], const float (&g0)[W], const float (&g1)[W], const PredictArgs &A,
-                                      const float *ctl, float dt, float iwb, const L2 &L, int nb) {
+                                      CtlP ctl, float dt, float iwb, const L2 &L, int nb) {
 #pragma unroll
     for (int q = 0; q < W; q++) {
         const int s = min(q, nb - 1);  // (past the last step: values nobody uses)
@@ -270,7 +284,7 @@ SLAM_DEV void apply_controls_fs1_fast(float &x, float &y, float &th, const float
 }
 
 template <int W>
-SLAM_DEV void predict_batch_fs1_fast(float &x, float &y, float &th, const PredictArgs &A, const RngArgs &rng, int i, size_t S, const float *ctl,
+SLAM_DEV void predict_batch_fs1_fast(float &x, float &y, float &th, const PredictArgs &A, const RngArgs &rng, int i, size_t S, CtlP ctl,
                                      float dt, float iwb, const L2 &L, int s0, int nb) {
     float g0[W], g1[W];
     draw_batch_fs1_fast<W>(g0, g1, A, rng, i, S, ctl, s0, nb);
@@ -278,7 +292,7 @@ SLAM_DEV void predict_batch_fs1_fast(float &x, float &y, float &th, const Predic
 }
 
 SLAM_DEV void predict_steps_fs1_fast(float &x, float &y, float &th, const PredictArgs &A, const RngArgs &rng, int i, size_t S,
-                                     const float *ctl = nullptr) {
+                                     CtlP ctl = nullptr) {
     const float dt = A.dt, iwb = 1.0f / A.wheel_base;
     const L2 L = llt2(A.Q[0], A.Q[2], A.Q[3]);  // multivariateGauss((V,G), Q, 1) (core.cpp:452)
     // The draws of up to eight steps are made TOGETHER (they depend on counters only), then the steps are applied one after the
@@ -310,7 +324,7 @@ SLAM_DEV void predict_steps_fs1_fast(float &x, float &y, float &th, const Predic
 // form of predict_composite; Gu Q Gu^T from the host-evaluated sin(G), cos(G); the heading update with H = (0 0 1) in gain form,
 // P - K (H P) (equal to the Joseph form in exact arithmetic for the optimal gain the reference computes; the reference's
 // "+ 2.2204e-16 I" kept): ~60 instructions per step.  Same tolerances as the rest of the fast build (tests/test_gpu_parity.py).
-SLAM_DEV void predict_steps_heading_fast(float &x, float &y, float &th, Sym3 &P, const PredictArgs &A, const float *ctl) {
+SLAM_DEV void predict_steps_heading_fast(float &x, float &y, float &th, Sym3 &P, const PredictArgs &A, CtlP ctl) {
     const float dt = A.dt, iwb = 1.0f / A.wheel_base;
     const float q00 = A.Q[0], q10 = 0.5f * (A.Q[1] + A.Q[2]), q11 = A.Q[3];
     const float Rphi = A.sigma_phi * A.sigma_phi;
@@ -1471,7 +1485,7 @@ SLAM_DEV void persist_draw(const PersistStep *qe, const RngArgs &rng, const Buff
     const int i = tile * kBlock + (int) threadIdx.x;
     const size_t S = (size_t) B.ncap;
     float g0[8], g1[8], vd[8], gs[8], sgw[8];
-    const float *ctl = reinterpret_cast<const float *>(qe->PA.steps);
+    const CtlP ctl = (CtlP) reinterpret_cast<const float *>(qe->PA.steps);  // (the queue entries are LDS copies)
     draw_batch_fs1_fast<8>(g0, g1, PA, rng, i, S, ctl, 0, PA.nsteps);
     const L2 Lq = llt2(PA.Q[0], PA.Q[2], PA.Q[3]);
     controls_batch_fs1_fast<8>(vd, gs, sgw, g0, g1, PA, ctl, PA.dt, 1.0f / PA.wheel_base, Lq, PA.nsteps);

@@ -191,7 +191,7 @@
         if (threadIdx.x < kSmallWords) pkv = ldg<true>(carry.pk_src + threadIdx.x);
     }
     // (persistent loop: the queued controls are already in LDS, in the iteration's queue entry)
-    const float *const ctl = PERSIST ? reinterpret_cast<const float *>(qe->PA.steps) : sh_ctl;
+    const CtlP ctl = PERSIST ? (CtlP) reinterpret_cast<const float *>(qe->PA.steps) : (CtlP) sh_ctl;
     (void) ctl;  // (strict build: the predict loop reads PredictArgs itself)
     const int cur = PERSIST ? carry.cur : h_ctrl->live[h_slot];  // ... and the Ctrl words
     const bool pend_word = PERSIST ? carry.pend_word : h_ctrl->pend[h_slot] != 0;
@@ -559,6 +559,17 @@
         const int nchunks = live_chunks;  // chunks holding a row in use after this update (incl. the one it opens)
         int4 gq[kChunks];
         float4 pa = ldg<PERSIST>(poseA + si);
+        // FastSLAM 2: the pose covariance with the pose, and consumed (below) BEFORE the genealogy chunks of a pending gather are
+        // requested: requested behind them, as the source order had it until round 5, it came back behind them -- loads return in
+        // order -- and the predicts, the first to need it, waited a second trip on every launch and for all the chunks on a
+        // resampling one (undrained level stamps, profiles/update_kernel_flow_r05_*.txt: pose -> predicts +1.47 us on a resampling
+        // launch of config 3 against +0.68 otherwise, +5.8 against +3.0 at config 6, whose 117 landmarks keep five chunks alive).
+        float4 pb = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 pc = make_float2(0.f, 0.f);
+        if (METHOD == 2) {
+            pb = ldg<PERSIST>(poseB + si);
+            pc = ldg<PERSIST>(poseC + si);
+        }
         // the slots of the (first kStage) re-observed landmarks are fetched now, with the pose: they depend on nothing but
         // the source slot, so the records are one round trip behind the pose, not two
         int ts[kStage];
@@ -603,13 +614,24 @@
 #endif
         SLAM_STAMP(4);  // pose + genealogy of the ancestor arrived
         float x = pa.x, y = pa.y, th = pa.z;
+        if (METHOD == 2) asm volatile("" : "+v"(pb.x), "+v"(pb.y), "+v"(pb.z), "+v"(pb.w), "+v"(pc.x), "+v"(pc.y));  // (arrived: see above)
         if (!BIG && copy_inline) {
             // requested only now, behind the pose and the records on the in-order return path (the step's critical chain);
             // they arrive during the compute below and are stored with the pose at the end
+            // UNGUARDED loads, in four sizes (a chunk past the last live one re-reads that one): guarded one by one (`if (c <
+            // nchunks)`, until round 5) every load became a branch, a load and an s_waitcnt vmcnt(0) -- ten dependent round trips of
+            // which a resampling launch of example_webmap paid two or three and one of example_loop902 five (undrained level stamps:
+            // pose -> predicts +6.1 us there against +3.0 on a launch that does not resample)
             const int4 *__restrict__ g4 = reinterpret_cast<const int4 *>(genS);
+            const int last = max(nchunks - 1, 0);
+            auto load_chunks = [&](auto NB) {
 #pragma unroll
-            for (int c = 0; c < kChunks; c++)
-                if (c < nchunks) gq[c] = ldg<PERSIST>(g4 + ((size_t) c * S + si));
+                for (int c = 0; c < decltype(NB)::value; c++) gq[c] = ldg<PERSIST>(g4 + ((size_t) min(c, last) * S + si));
+            };
+            if (nchunks <= 2) load_chunks(std::integral_constant<int, 2>{});
+            else if (nchunks <= 4) load_chunks(std::integral_constant<int, 4>{});
+            else if (nchunks <= 7) load_chunks(std::integral_constant<int, (kChunks < 7 ? kChunks : 7)>{});
+            else load_chunks(std::integral_constant<int, kChunks>{});
         }
         // resampled particles restart at 1/N (core.cpp:744-747); otherwise the weights are normalised (core.cpp:726-729;
         // resample_kernel has already done it unless this launch plans inline)
@@ -620,8 +642,6 @@
         float q00 = 0.f, q10 = 0.f, q11 = 0.f, q20 = 0.f, q21 = 0.f, q22 = 0.f;
         bool pose_dirty = pend;
         if (METHOD == 2) {
-            const float4 pb = ldg<PERSIST>(poseB + si);
-            const float2 pc = ldg<PERSIST>(poseC + si);
             q00 = pb.x; q10 = pb.y; q11 = pb.z; q20 = pb.w; q21 = pc.x; q22 = pc.y;
         }
         if (PA.nsteps > 0) {

@@ -62,7 +62,10 @@ def test_default_line_single_gpu():
         assert er["traffic"], (key, er["traffic_source"])
         assert 0.0 < er["frac"] <= 1.0 and abs(er["frac"] - er["achieved"] / er["peak"]) < 1e-9, key
         assert e["value"] > 0 and abs(e["value"] * e["ms_per_step"] * 1e-3 / e["config"]["particles_total"] - 1.0) < 1e-6
-    assert also[(5, "fast")]["roofline"]["algorithmic_frac"] > 1.0  # the reference's formulation is not a bound for this layout
+    # the reference's formulation is not a bound for this layout: its bytes over the measured time come to about the part's peak
+    # (1.05 of 8 TB/s on the box of profiles/bench_r05_driver_args.json, 0.98 on a slower one) while the counters read ~0.56
+    r5 = also[(5, "fast")]["roofline"]
+    assert r5["algorithmic_frac"] > 0.9 and r5["algorithmic_frac"] > 1.5 * r5["frac"]
     assert also[(3, "strict")]["ms_per_step"] > j["ms_per_step"]
     c = j["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 1e4 and "sample" in c and c["unit"] == j["unit"]

@@ -8,7 +8,7 @@ wave's outstanding memory operations and records the 100 MHz wall clock at ten p
 over blocks and launches of the time since the EARLIEST block entered the kernel, split by whether the launch had to
 perform the previous step's resampling (inline plan fired) or not.
 
-usage: python tools/stamps.py [N] [samples] [host|device] [FASTSLAM2|FASTSLAM1] [fast|strict] [map]  (writes a table to stdout; copy into profiles/)
+usage: python tools/stamps.py [N] [samples] [host|device] [FASTSLAM2|FASTSLAM1] [fast|strict|flow] [map]  (writes a table to stdout; copy into profiles/)
        map: a bundled map's name (default example_webmap), e.g. example_loop902
        strict: the strict build's kernels (`make -C slam_amd/csrc stamps_strict`)
        device: the steps are slamgpu_step_observe calls (the observation front end inside the update launch)"""
@@ -18,8 +18,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 STRICT = len(sys.argv) > 5 and sys.argv[5] == "strict"
+FLOW = len(sys.argv) > 5 and sys.argv[5] == "flow"   # stamps without drains (make stamps_flow): the launch's own schedule
 MAP = sys.argv[6] if len(sys.argv) > 6 else "example_webmap"
-os.environ["SLAMGPU_LIB"] = os.path.join(ROOT, "slam_amd", "libslamgpu_stamps_strict.so" if STRICT else "libslamgpu_stamps.so")
+os.environ["SLAMGPU_LIB"] = os.path.join(ROOT, "slam_amd", "libslamgpu_stamps_strict.so" if STRICT else ("libslamgpu_stamps_flow.so" if FLOW else "libslamgpu_stamps.so"))
 os.environ["SLAMGPU_STAMPS"] = "1"
 import numpy as np  # noqa: E402
 import slam_amd  # noqa: E402
@@ -117,7 +118,7 @@ def table(title, stamp_sets):
 
 print("observation front end: %s" % ("inside the update launch (slamgpu_step_observe)" if DEVICE else "host (slamgpu_step)"))
 print("method %s" % METHOD)
-print("N = %d particles, steps %d..%d of the %s run, %s build, instrumented (thread 0 of each block drains vmcnt/lgkmcnt at each stamp)" % (N, START, START + SAMPLES, MAP, "strict" if STRICT else "fast"))
+print("N = %d particles, steps %d..%d of the %s run, %s build, instrumented (thread 0 of each block drains vmcnt/lgkmcnt at each stamp)" % (N, START, START + SAMPLES, MAP, "strict" if STRICT else ("fast, stamps WITHOUT drains (the time a point was reached, not the time its data had arrived)" if FLOW else "fast")))
 table("update launches that do NOT plan inline (previous stage already ran: pose read at slot i or through keep[])", last)
 fired = [st for (kk, st) in pairs if res2[kk - START - 1]]
 quiet = [st for (kk, st) in pairs if not res2[kk - START - 1]]
