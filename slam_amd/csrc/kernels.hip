@@ -829,9 +829,14 @@ constexpr int kWinBlocks = 4;
 // PRE: the caller has already staged blocks 0 .. nb - 1 (nb <= kWinBlocks) in `win` (persistent loop: requested at the head of the
 // iteration, with the block totals: one trip less between the decision and the ancestor)
 // BYP: the prefixes were stored by other workgroups of the running launch: read them past the vector cache (device_math.h: ldg)
-template <bool PRE = false, bool BYP = false>
-SLAM_DEV int64_t find_ancestor_win(double target, bool valid, int guess, const double *off, int nb, float *win, const float *__restrict__ lcum_local,
+// OFFL: `off_g` points into LDS (the block prefix every block builds for itself: everything but the contexts of more than
+// scan_min_blocks tiles, whose prefix scan_kernel leaves in global memory): read through a typed LDS pointer -- as a generic
+// pointer every probe of the search below was a flat load with a full s_waitcnt (vmcnt and lgkmcnt) behind it.
+template <bool PRE = false, bool BYP = false, bool OFFL = false>
+SLAM_DEV int64_t find_ancestor_win(double target, bool valid, int guess, const double *off_g, int nb, float *win, const float *__restrict__ lcum_local,
                                    int nb_local, int64_t n_global, const float *__restrict__ blk_m, double M, const PeerPtrs *peers, int par) {
+    using OffP = std::conditional_t<OFFL, const __attribute__((address_space(3))) double *, const double *>;
+    const OffP off = (OffP) off_g;
     const int lane = threadIdx.x & (kWave - 1);
     // The source block: the first b with off[b + 1] > target (nb: none).  Stratified ancestors sit near their offspring, so
     // the search starts at the block the caller names (the particle's own) and gallops outwards -- two or three dependent LDS

@@ -286,10 +286,13 @@
         const double target = valid ? (double) (PERSIST ? carry.strat : stratum_prev(rng, gk)) * W : 0.0;
         const int64_t ng = DIST ? rng.n_global : (int64_t) B.n;
         if (PERSIST && pre_win)
-            return (int) find_ancestor_win<true, true>(target, valid, (int) (gk >> 8), offp, nbg, win, ws.lcum[STEP_WPAR ^ 1], nb, ng,
-                                                 logw ? ws.blk_w[STEP_WPAR ^ 1] + 2 * nb : nullptr, Mx, nullptr, STEP_WPAR ^ 1);
-        return (int) find_ancestor_win<false, PERSIST>(target, valid, (int) (gk >> 8), offp, nbg, win, ws.lcum[STEP_WPAR ^ 1], nb, ng,
-                                                       (!DIST && logw) ? ws.blk_w[STEP_WPAR ^ 1] + 2 * nb : nullptr, Mx, DIST ? B.peers : nullptr, STEP_WPAR ^ 1);
+            return (int) find_ancestor_win<true, true, true>(target, valid, (int) (gk >> 8), offp, nbg, win, ws.lcum[STEP_WPAR ^ 1], nb, ng,
+                                                       logw ? ws.blk_w[STEP_WPAR ^ 1] + 2 * nb : nullptr, Mx, nullptr, STEP_WPAR ^ 1);
+        // (the typed LDS pointer for the block prefix -- OFFL -- only in the persistent loop: 8.52 -> 8.29 us per iteration at config
+        // 2; in the per-step kernels, which must keep the global-memory prefix of the largest contexts as well, the two copies of
+        // the search cost more than the flat loads: config 3 14.02 -> 14.14 us per step, 10^6 particles 81.3 -> 85.3, same box)
+        return (int) find_ancestor_win<false, PERSIST, PERSIST>(target, valid, (int) (gk >> 8), offp, nbg, win, ws.lcum[STEP_WPAR ^ 1], nb, ng,
+                                                                (!DIST && logw) ? ws.blk_w[STEP_WPAR ^ 1] + 2 * nb : nullptr, Mx, DIST ? B.peers : nullptr, STEP_WPAR ^ 1);
     };
     if (bid >= nb) {
         // ---- helper blocks ---------------------------------------------------------------------------------

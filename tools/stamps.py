@@ -35,8 +35,9 @@ START = 1000
 LEVELS = ["0 kernel entry (first block = 0)", "1 Ctrl words arrived", "2 block totals scanned (W, Neff, decision)",
           "3 ancestor found", "4 pose + genealogy arrived", "5 records staged in LDS", "6 proposal pass done",
           "7 second pass done, record stores landed", "8 pose / genealogy stores landed", "9 weight prefix + totals written",
-          "10 queued predicts applied"]
-ORDER = [0, 1, 2, 3, 4, 10, 5, 6, 7, 8, 9]   # the order the kernel passes them in
+          "10 queued predicts applied", "11 -", "12 -", "13 -", "14 (free slot: wherever a diagnostic build puts SLAM_STAMP(14))",
+          "15 (free slot: SLAM_STAMP(15))"]
+ORDER = [0, 1, 2, 3, 4, 10, 14, 15, 5, 6, 7, 8, 9]   # the order the kernel passes them in (14, 15: only if stamped)
 
 tape = host.make_tape(["-m", os.path.join(ROOT, "data", MAP + ".mat"), "-method", METHOD, "-NPARTICLES", N,
                        "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", 7], max_obs=START + SAMPLES + 2)
@@ -100,7 +101,7 @@ def table(title, stamp_sets):
     rel = []
     for st in stamp_sets:
         t0 = st[:, 0].min()
-        rel.append((st[:, :11] - t0) / 100.0)   # 100 MHz -> us
+        rel.append((st[:, :16] - t0) / 100.0)   # 100 MHz -> us
     rel = np.concatenate(rel)
     print("%-48s %8s %8s %8s   %s" % ("level", "median", "p90", "max", "median step from previous level"))
     prev = None
