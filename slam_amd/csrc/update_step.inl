@@ -621,20 +621,28 @@
         if (!BIG && copy_inline) {
             // requested only now, behind the pose and the records on the in-order return path (the step's critical chain);
             // they arrive during the compute below and are stored with the pose at the end
-            // UNGUARDED loads, in four sizes (a chunk past the last live one re-reads that one): guarded one by one (`if (c <
-            // nchunks)`, until round 5) every load became a branch, a load and an s_waitcnt vmcnt(0) -- ten dependent round trips of
-            // which a resampling launch of example_webmap paid two or three and one of example_loop902 five (undrained level stamps:
-            // pose -> predicts +6.1 us there against +3.0 on a launch that does not resample)
+            // UNGUARDED loads, in a few sizes behind a uniform branch (a chunk past the last live one re-reads that one: the same 16
+            // bytes again).  Guarded one by one (`if (c < nchunks)`, until round 5) every load became a branch, a load and an
+            // s_waitcnt vmcnt(0) -- dependent round trips, two or three on a resampling launch of example_webmap, five on one of
+            // example_loop902 (undrained level stamps: pose -> predicts +6.1 us there against +3.0 on a launch that does not
+            // resample).  Which sizes: where the sizes' registers meet again the compiler copies some of them, and a copy waits for
+            // its load; measured, one box, us per step: sizes 2 / 4 / 7 / 10 everywhere: config 3 13.9-14.0, config 6 16.7, config 2's
+            // loop 8.51, 10^6 particles 82.8-83.2; all ten always: 14.0, 16.2, 8.81 (its loads pass the vector cache), 83.5-84.2.
             const int4 *__restrict__ g4 = reinterpret_cast<const int4 *>(genS);
             const int last = max(nchunks - 1, 0);
             auto load_chunks = [&](auto NB) {
 #pragma unroll
                 for (int c = 0; c < decltype(NB)::value; c++) gq[c] = ldg<PERSIST>(g4 + ((size_t) min(c, last) * S + si));
             };
-            if (nchunks <= 2) load_chunks(std::integral_constant<int, 2>{});
-            else if (nchunks <= 4) load_chunks(std::integral_constant<int, 4>{});
-            else if (nchunks <= 7) load_chunks(std::integral_constant<int, (kChunks < 7 ? kChunks : 7)>{});
-            else load_chunks(std::integral_constant<int, kChunks>{});
+            if (PERSIST) {
+                if (nchunks <= 2) load_chunks(std::integral_constant<int, 2>{});
+                else if (nchunks <= 4) load_chunks(std::integral_constant<int, 4>{});
+                else if (nchunks <= 7) load_chunks(std::integral_constant<int, (kChunks < 7 ? kChunks : 7)>{});
+                else load_chunks(std::integral_constant<int, kChunks>{});
+            } else {
+                if (nchunks <= 4) load_chunks(std::integral_constant<int, 4>{});
+                else load_chunks(std::integral_constant<int, kChunks>{});
+            }
         }
         // resampled particles restart at 1/N (core.cpp:744-747); otherwise the weights are normalised (core.cpp:726-729;
         // resample_kernel has already done it unless this launch plans inline)
