@@ -37,7 +37,7 @@ LEVELS = ["0 kernel entry (first block = 0)", "1 Ctrl words arrived", "2 block t
           "7 second pass done, record stores landed", "8 pose / genealogy stores landed", "9 weight prefix + totals written",
           "10 queued predicts applied", "11 -", "12 -", "13 -", "14 (free slot: wherever a diagnostic build puts SLAM_STAMP(14))",
           "15 (free slot: SLAM_STAMP(15))"]
-ORDER = [0, 1, 2, 3, 4, 10, 14, 15, 5, 6, 7, 8, 9]   # the order the kernel passes them in (14, 15: only if stamped)
+ORDER = [0, 1, 2, 3, 4, 10, 5, 6, 7, 8, 14, 15, 9]   # the order the kernel passes them in (14, 15: only if stamped)
 
 tape = host.make_tape(["-m", os.path.join(ROOT, "data", MAP + ".mat"), "-method", METHOD, "-NPARTICLES", N,
                        "-NEFFECTIVE", int(0.75 * N), "-SWITCH_SEED_RANDOM", 7], max_obs=START + SAMPLES + 2)

@@ -5,13 +5,15 @@ launch leaves are those of its LAST iteration, so every sample is one call of K 
 Levels 0..10 as in tools/stamps.py (0 = the iteration's code begins), 12 = iteration begins (previous barrier passed), 11 = the
 step's code is done (stores issued), 13 = barrier passed (stores drained, everybody arrived, L1 invalidated).
 
-usage: python tools/stamps_persist.py [N] [samples] [FASTSLAM1|FASTSLAM2] [K]"""
+usage: python tools/stamps_persist.py [N] [samples] [FASTSLAM1|FASTSLAM2] [K] [flow]
+       flow: stamps that do not drain (`make -C slam_amd/csrc stamps_flow`): the iteration's own schedule"""
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["SLAMGPU_LIB"] = os.path.join(ROOT, "slam_amd", "libslamgpu_stamps.so")
+FLOW = len(sys.argv) > 5 and sys.argv[5] == "flow"
+os.environ["SLAMGPU_LIB"] = os.path.join(ROOT, "slam_amd", "libslamgpu_stamps_flow.so" if FLOW else "libslamgpu_stamps.so")
 os.environ["SLAMGPU_STAMPS"] = "1"
 import numpy as np  # noqa: E402
 import slam_amd  # noqa: E402
