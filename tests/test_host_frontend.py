@@ -214,3 +214,19 @@ def test_no_kernel_spills_to_scratch(tmp_path):
                 assert size <= 128, (name, kernel, size)
                 continue
             assert size == 0, (name, kernel, size)
+        # (round 5) no 16-byte load of an update kernel is waited for the instant it is issued: a guarded load in an unrolled loop
+        # (`if (c < n) v[c] = p[...]`) compiles to branch + load + s_waitcnt vmcnt(0) -- ten dependent round trips in the genealogy
+        # composition of a resampling launch until round 5
+        lines = [ln.strip() for ln in asm.split("\n")]
+        code = [ln for ln in lines if ln and not ln.startswith((";", "."))]
+        inside, waited, seen = None, {}, set()
+        for a, b in zip(code, code[1:]):
+            m = re.match(r"^(_ZN\d+slam_(?:strict|fast)\d+update_(?:kernel|persist_kernel|kernel_wide)\w+):", a)
+            if m:
+                inside = m.group(1)
+                seen.add(inside)
+            elif a.startswith("s_endpgm"):
+                inside = None
+            elif inside and a.startswith("global_load_dwordx4") and b.startswith("s_waitcnt") and "vmcnt(0)" in b:
+                waited[inside] = waited.get(inside, 0) + 1
+        assert len(seen) >= 12 and not waited, (name, len(seen), waited)
