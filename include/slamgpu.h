@@ -257,13 +257,16 @@ int slamgpu_step_observe(slamgpu_ctx *ctx, const float *controls, int32_t n_cont
  * without waiting for the GPU; the results are bit-identical to K calls of slamgpu_step_observe with record_estimate = 1.
  * Contexts of at most 39 landmarks and at most 2 048 particles (K >= 2, at most 16 controls per iteration) run the K
  * iterations as ONE launch: a persistent step loop whose workgroups sit on one XCD and meet at a counter in its L2 between two
- * iterations instead of at a kernel boundary (round 5; every wait is bounded: a workgroup that waits too long abandons the
- * launch, and whatever synchronises next -- slamgpu_sync, _history_fetch, _estimate, _stats, the next slamgpu_run_observe --
- * returns SLAMGPU_ERR_BARRIER); everything else enqueues K update launches.  SLAMGPU_NO_PERSIST=1 in the environment selects
- * the K launches everywhere (diagnostic).
+ * iterations instead of at a kernel boundary (round 5; every wait is bounded, in time: a workgroup that waits 2 s -- another
+ * process holding the CUs -- abandons the launch, and whatever synchronises next -- slamgpu_sync, _history_fetch, _estimate,
+ * _stats, the next slamgpu_run_observe -- returns SLAMGPU_ERR_BARRIER, sticky; slamgpu_last_error and slamgpu_persist_status
+ * say which launch it was and how many of its iterations had completed; the state is undefined from there: recreate the
+ * context); everything else enqueues K update launches.  SLAMGPU_NO_PERSIST=1 in the environment selects the K launches
+ * everywhere (diagnostic).
  * Arguments are validated before anything is enqueued: a call that is refused (bad pointers or counts, no map, a history that
- * K more estimates would overflow: SLAMGPU_ERR_CAPACITY) applies NO iteration.  Should an iteration fail later all the same,
- * the iterations before it stay applied and slamgpu_last_error names it. */
+ * K more estimates would overflow: SLAMGPU_ERR_CAPACITY) applies NO iteration.  Should an iteration fail later all the same
+ * ON THE HOST SIDE (a HIP error while iteration k is being prepared), the iterations before it stay applied and
+ * slamgpu_last_error names it; a launch abandoned on the DEVICE is the case above. */
 int slamgpu_run_observe(slamgpu_ctx *ctx, int32_t K, const int32_t *n_controls, const float *controls, const float Q[4], float dt,
                         const float *xtrue, float max_range, const float R[4], int32_t noise);
 /* The observation packet of the last slamgpu_step_observe, copied back for logging / tests (any pointer may be NULL;
@@ -305,6 +308,16 @@ int slamgpu_genealogy_rows(slamgpu_ctx *ctx, int32_t *in_use, int32_t *capacity)
  * (0 / 0: every iteration was a launch of its own); cross_xcd (may be NULL; synchronises): 1 if the last such launch found its
  * workgroups on more than one XCD and took the memory model's agent-scope release / acquire between iterations. */
 int slamgpu_persist_info(slamgpu_ctx *ctx, int64_t *launches, int64_t *iterations, int32_t *cross_xcd);
+/* How far an ABANDONED launch of the persistent step loop got (any pointer may be NULL; does not synchronise: call it after the
+ * call that returned SLAMGPU_ERR_BARRIER).  abandoned: 1 once a launch has been abandoned (sticky), else 0 and the other outputs
+ * are 0; launch: the number of that launch in this context (1 = the first slamgpu_run_observe call that took the loop; the
+ * launches queued behind it did nothing); completed: iterations of THAT launch which every workgroup had completed (all its
+ * barriers passed); handed: the iterations it had been handed.  The iteration
+ * `completed` was in flight and is PARTIALLY applied (poses, records and weights of some tiles only), and the host's bookkeeping
+ * (landmark book, history slots, RNG step) stands at the end of everything handed over: the context's state is undefined.
+ * Recreate it and replay; the counts say from where.  The reference's own wait for its accelerator is an unbounded spin
+ * (core.cpp:619-622): there the process hangs instead. */
+int slamgpu_persist_status(slamgpu_ctx *ctx, int32_t *abandoned, int64_t *launch, int32_t *completed, int32_t *handed);
 /* Particle-major host copies (any pointer may be NULL): xv[3N], Pv[9N] row-major, w[N],
  * xf[2*Nf*N], Pf[4*Nf*N] row-major — the layout of vector<Particle> flattened. Synchronises. */
 int slamgpu_download(slamgpu_ctx *ctx, float *xv, float *Pv9, float *w, float *xf, float *Pf4);

@@ -266,6 +266,19 @@ class Particles:
         self.L.orc_update_local(self.h, C.byref(algo), _p(zf), _p(idf), zf.shape[0], _p(zn), zn.shape[0],
                                 _p(np.ascontiguousarray(R, f32)), _p(normals))
 
+    def resample_forced(self, algo, sel, forced_did=None, forced_keep=None):
+        """resampleParticles alone (orc_resample_forced): forced_did None = the oracle's own decision and ancestors; True / False =
+        that decision with forced_keep as the ancestors.  Returns (the oracle's OWN ancestors, its own Neff, its own decision)."""
+        L = self.L
+        L.orc_resample_forced.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_resample_forced.restype = None
+        own = np.zeros(self.N, np.int32)
+        neff, did = C.c_float(), C.c_int()
+        fk = None if forced_keep is None else np.ascontiguousarray(forced_keep, np.int32)
+        L.orc_resample_forced(self.h, C.byref(algo), _p(np.ascontiguousarray(sel, f32)), -1 if forced_did is None else int(bool(forced_did)),
+                              _p(fk), _p(own), C.byref(neff), C.byref(did))
+        return own, f32(neff.value), bool(did.value)
+
     def close(self):
         if self.owned and self.h:
             self.L.orc_particles_destroy(self.h)

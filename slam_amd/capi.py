@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DECLARED_SYMBOLS = [
     "slamgpu_last_error", "slamgpu_abi_version", "slamgpu_device_count", "slamgpu_jacobians", "slamgpu_jacobians_multi", "slamgpu_create",
     "slamgpu_destroy", "slamgpu_predict", "slamgpu_update", "slamgpu_estimate", "slamgpu_estimate_async", "slamgpu_estimate_fetch", "slamgpu_stats", "slamgpu_ancestors",
-    "slamgpu_num_landmarks", "slamgpu_genealogy_rows", "slamgpu_persist_info", "slamgpu_download", "slamgpu_upload", "slamgpu_sync", "slamgpu_step", "slamgpu_history_fetch", "slamgpu_shard_set_totals_buffer", "slamgpu_shard_step", "slamgpu_timer_start", "slamgpu_timer_stop", "slamgpu_stream", "slamgpu_profile",
+    "slamgpu_num_landmarks", "slamgpu_genealogy_rows", "slamgpu_persist_info", "slamgpu_persist_status", "slamgpu_download", "slamgpu_upload", "slamgpu_sync", "slamgpu_step", "slamgpu_history_fetch", "slamgpu_shard_set_totals_buffer", "slamgpu_shard_step", "slamgpu_timer_start", "slamgpu_timer_stop", "slamgpu_stream", "slamgpu_profile",
     "slamgpu_kernel_time", "slamgpu_algorithmic_bytes", "slamgpu_shard_update", "slamgpu_shard_block_totals", "slamgpu_shard_plan",
     "slamgpu_shard_record_floats", "slamgpu_shard_pack", "slamgpu_shard_unpack", "slamgpu_shard_finish", "slamgpu_shard_estimate",
     "slamgpu_dev_alloc", "slamgpu_dev_free", "slamgpu_dev_copy", "slamgpu_dev_copy_async", "slamgpu_shard_estimate_async",
@@ -105,6 +105,7 @@ def load_library():
     L.slamgpu_num_landmarks.argtypes = [C.c_void_p]
     L.slamgpu_genealogy_rows.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.slamgpu_persist_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    L.slamgpu_persist_status.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.slamgpu_download.argtypes = [C.c_void_p] * 6
     L.slamgpu_download_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 5
     L.slamgpu_peek.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 5
@@ -444,6 +445,12 @@ class SlamGpu:
         a, b, x = C.c_int64(), C.c_int64(), C.c_int32()
         _chk(self.L.slamgpu_persist_info(self.h, C.byref(a), C.byref(b), C.byref(x) if cross else None))
         return (a.value, b.value, x.value) if cross else (a.value, b.value)
+
+    def persist_status(self):
+        """None, or (launch, completed, handed) of the abandoned launch of the persistent step loop (slamgpu_persist_status)"""
+        ab, la, co, ha = C.c_int32(), C.c_int64(), C.c_int32(), C.c_int32()
+        _chk(self.L.slamgpu_persist_status(self.h, C.byref(ab), C.byref(la), C.byref(co), C.byref(ha)))
+        return (la.value, co.value, ha.value) if ab.value else None
 
     def download(self, landmarks=True, first=0, count=None):
         """particles [first, first + count) (default: all); log-weight contexts: w holds log-weights"""

@@ -283,20 +283,24 @@ constexpr int kPersistStepWords = (int) (sizeof(PersistStep) / 4);
 // words of PersistArgs::sync, on lines of their own: [0, kPersistSyncWords) zeroed before every launch; the abort word behind
 // them is sticky (a launch that finds it set leaves at once)
 enum { kPersistSyncCounter = 0, kPersistSyncXcc = 64, kPersistSyncDone = 96, kPersistSyncCross = 97, kPersistSyncWords = 128, kPersistSyncAbort = 128,
-       kPersistSyncAlloc = 192 };
+       kPersistSyncAlloc = 192, kPersistHostWords = 4 };
 struct PersistArgs {
     const PersistStep *queue;           // [K], in PINNED HOST memory: every workgroup reads an entry an iteration before it needs it
     int32_t K;
-    uint32_t max_spins;                 // bound of one wait at the counter
+    uint32_t max_spins;                 // bound of one wait at the counter, in polls (tests: SLAMGPU_PERSIST_MAX_SPINS) ...
     uint32_t *sync;                     // [kPersistSyncAlloc]
-    uint32_t *host_status;              // pinned host word: set to 1 by a workgroup that abandons the loop (the host reads it behind
-                                        // any synchronisation, without a copy of its own)
+    uint32_t *host_status;              // [kPersistHostWords] pinned host words, written by the helper workgroup of the FIRST launch that
+                                        // is abandoned (the host reads them behind any synchronisation, without a copy of its own):
+                                        // [0] 1 = abandoned, [1] iterations of that launch every workgroup had completed (barriers passed),
+                                        // [2] that launch's serial number, [3] the iterations it had been handed
     FrontState *state_final;            // where the front end's state is left for the next launch
     int32_t *packets;                   // [2][kSmallWords]: the observation packets the helper workgroup makes, an iteration ahead
     float4 *draws;                      // [2][6][ncap]: FastSLAM 1 (fast build): the pose-independent half of a particle's eight predicts,
                                         // made an iteration ahead by the drawer workgroups (component c of particle i at [c][i]: V dt of
                                         // steps 0-3, 4-7; the perturbed G of steps 0-3, 4-7; sin(G / wheelBase) of steps 0-3, 4-7)
-    int32_t drawers, pad;               // drawer workgroups: one per tile, or none
+    int32_t drawers, serial;            // drawer workgroups: one per tile, or none; the launch's number (from 1) in this context
+    unsigned long long max_ticks;       // ... and in TIME: ticks of the 100 MHz constant clock (s_memrealtime), looked at every 256 polls
+    int32_t abort_at, pad;              // tests (SLAMGPU_PERSIST_ABORT_AT): the helper workgroup abandons the launch in this iteration (-1: never)
     PersistStep *ring;                  // [4] in device memory: the helper workgroup copies entry it + 2 of the (host-resident) queue here
                                         // during iteration it; everybody else reads its entries from here (an L2 hit), so that no
                                         // PCIe read sits in front of a tile's loads on the in-order return path

@@ -569,6 +569,10 @@ SLAM_DEV int scan_at(int k, int nb, int nbl, bool logw) {
     // (one shard: nbl == nb and the index is k itself; the general form costs two integer divisions per entry)
     return nbl == nb ? k : (k / nbl) * (logw ? 3 : 2) * nbl + (k % nbl);
 }
+// BYP: the totals were stored by other workgroups of the RUNNING launch (the persistent step loop's tiles, log-weight contexts:
+// linear ones take scan_issue_small): read them past the vector cache (device_math.h: ldg) -- a tile skips the cache invalidate
+// at the loop's meeting, so a plain load could be served a line of two iterations ago
+template <bool BYP = false>
 SLAM_DEV ScanLoads scan_issue(const float *__restrict__ tot, int nb, int nbl, bool logw) {
     const int t = threadIdx.x;
     const int per = (nb + kBlock - 1) / kBlock;
@@ -578,15 +582,15 @@ SLAM_DEV ScanLoads scan_issue(const float *__restrict__ tot, int nb, int nbl, bo
     if (per <= 2) {
         if (lo < hi) {
             const int at = scan_at(lo, nb, nbl, logw);
-            L.tv0 = tot[at];
-            L.qv0 = tot[at + nbl];
-            if (logw) L.mv0 = tot[at + 2 * nbl];
+            L.tv0 = ldg<BYP>(tot + at);
+            L.qv0 = ldg<BYP>(tot + at + nbl);
+            if (logw) L.mv0 = ldg<BYP>(tot + at + 2 * nbl);
         }
         if (lo + 1 < hi) {
             const int at = scan_at(lo + 1, nb, nbl, logw);
-            L.tv1 = tot[at];
-            L.qv1 = tot[at + nbl];
-            if (logw) L.mv1 = tot[at + 2 * nbl];
+            L.tv1 = ldg<BYP>(tot + at);
+            L.qv1 = ldg<BYP>(tot + at + nbl);
+            if (logw) L.mv1 = ldg<BYP>(tot + at + 2 * nbl);
         }
     }
     return L;
@@ -889,7 +893,7 @@ SLAM_DEV int64_t find_ancestor_win(double target, bool valid, int guess, const d
     if (!use) return n_global - 1;
     (void) block_ptr;
     const double o = off[b0];
-    const double sc = blk_m ? block_scale(blk_m[b0], M) : 1.0;
+    const double sc = blk_m ? block_scale(ldg<BYP>(blk_m + b0), M) : 1.0;  // (another tile's block maximum: as the prefixes)
     float pv[16], ev[16];
     int seg = 15, r = 15;
     if (b0 - lo < kWinBlocks) {
@@ -1435,12 +1439,23 @@ SLAM_DEV void persist_arrive(uint32_t *sync, bool cross_xcd) {
 }
 // invalidate: the workgroup goes on to read other workgroups' stores with plain loads (the helper; everybody when the placement
 // spans XCDs); the tiles read them with ldg<true> (device_math.h) and need no invalidate -- 1.2-1.7 us per iteration otherwise
-SLAM_DEV bool persist_pass(uint32_t *sync, uint32_t target, uint32_t max_spins, int *sh_ok, bool invalidate, bool lazy = false) {
+// The wait is bounded twice: in polls (max_spins: what the tests force) and in TIME (max_ticks of the 100 MHz constant clock,
+// read every 256 polls so that the clock's scalar-memory trip stays off the path of a wait that ends in a microsecond): a poll
+// count alone is some fraction of a second that depends on the L2's mood.
+SLAM_DEV bool persist_pass(uint32_t *sync, uint32_t target, uint32_t max_spins, unsigned long long max_ticks, int *sh_ok, bool invalidate,
+                           bool lazy = false) {
     if (threadIdx.x == 0) {
         int ok = 1;
         uint32_t spins = 0;
+        unsigned long long t0 = 0;
         while ((int32_t) (__hip_atomic_load(sync + kPersistSyncCounter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            if (__hip_atomic_load(sync + kPersistSyncAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || ++spins > max_spins) {
+            bool late = ++spins > max_spins;
+            if ((spins & 255u) == 0u) {
+                const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                if (t0 == 0) t0 = now;
+                late = late || now - t0 > max_ticks;
+            }
+            if (__hip_atomic_load(sync + kPersistSyncAbort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || late) {
                 __hip_atomic_store(sync + kPersistSyncAbort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
                 break;
@@ -1609,14 +1624,14 @@ __global__ void __launch_bounds__(kBlock) update_persist_kernel(const float *__r
     if (drawer && P.K > 0) persist_draw(&qes[0], rng, B, dtile, P.draws);
     persist_arrive(sync, true);
     if (!helper && !drawer && P.K > 0) persist_predraw<METHOD>(&qes[0], rng, B, i, carry);
-    bool alive = persist_pass(sync, members, P.max_spins, &sh_ok, true);
+    bool alive = persist_pass(sync, members, P.max_spins, P.max_ticks, &sh_ok, true);
     bool cross = false;
     {
         const uint32_t mine = __hip_atomic_load(sync + kPersistSyncXcc + bid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         for (int b = 0; b < (int) members; b++) cross |= __hip_atomic_load(sync + kPersistSyncXcc + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != mine;
     }
     const bool logw = (h_flags & 4) != 0;
-    int it = 0;
+    int it = 0, done = 0;
     for (; alive && it < P.K; it++) {
         SLAM_STAMP(12);  // (diagnostic build) this iteration begins: the previous barrier has been passed
         const bool more = it + 1 < P.K;
@@ -1661,9 +1676,12 @@ __global__ void __launch_bounds__(kBlock) update_persist_kernel(const float *__r
             else if (drawer)
                 persist_draw(qn, rng, B, dtile, P.draws + (size_t) ((it + 1) & 1) * draw_words);
         }
+        // (tests of the abandon path: the helper gives up in iteration abort_at, as a workgroup that waited too long would)
+        if (helper && it == P.abort_at && threadIdx.x == 0) __hip_atomic_store(sync + kPersistSyncAbort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         persist_arrive(sync, cross);
         if (more && !helper && !drawer) persist_predraw<METHOD>(qn, rng, B, i, carry);  // (while the arrival travels)
-        alive = persist_pass(sync, members * (uint32_t) (it + 2), P.max_spins, &sh_ok, helper || cross, helper || drawer);
+        alive = persist_pass(sync, members * (uint32_t) (it + 2), P.max_spins, P.max_ticks, &sh_ok, helper || cross, helper || drawer);
+        if (alive) done = it + 1;  // (this barrier passed: EVERY workgroup has completed iteration `it`)
         SLAM_STAMP(13);  // barrier passed
     }
     // where the launch leaves things, for the host and the next launch: the Ctrl words (both slots: the set is plain, in
@@ -1671,10 +1689,18 @@ __global__ void __launch_bounds__(kBlock) update_persist_kernel(const float *__r
     if (helper && threadIdx.x == 0) {
         h_ctrl->live[0] = h_ctrl->live[1] = carry.cur;
         h_ctrl->pend[0] = h_ctrl->pend[1] = 0;
-        sync[kPersistSyncDone] = (uint32_t) it;        // iterations completed
+        sync[kPersistSyncDone] = (uint32_t) done;      // iterations every workgroup completed (= K unless the launch was abandoned)
         sync[kPersistSyncCross] = cross ? 1u : 0u;     // (diagnostic: the placement was not one XCD)
+        // An abandoned launch says how far it got: the helper workgroup alone writes the host's words, and only for
+        // the FIRST abandoned launch -- the abort word is sticky, the launches queued behind this one leave at their first meeting
+        // with nothing done and must not overwrite the account.  (The helper always gets here: every wait is bounded.)
+        if (!alive && __hip_atomic_load(P.host_status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u) {
+            __hip_atomic_store(P.host_status + 1, (uint32_t) done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(P.host_status + 2, (uint32_t) P.serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(P.host_status + 3, (uint32_t) P.K, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(P.host_status, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
-    if (!alive && threadIdx.x == 0) __hip_atomic_store(P.host_status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (helper && threadIdx.x < kWave) {
         if ((int) threadIdx.x < U.front.nlm) P.state_final->lm[threadIdx.x] = f_lm;
         if (threadIdx.x == 0) P.state_final->hdr = f_hd;

@@ -27,7 +27,7 @@ using namespace slamgpu;
 
 namespace {
 
-thread_local char g_err[512] = "";
+thread_local char g_err[1024] = "";
 
 int fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -703,9 +703,14 @@ int keep_history_tail(slamgpu_ctx *c, const std::vector<double> &h, int taken) {
 // The abort word of the persistent step loop is sticky, like the barrier error of the push collective: whoever synchronises with
 // the device reports it (the kernel stores it into pinned host memory: no copy needed here).
 int persist_check(slamgpu_ctx *c) {
-    if (c->pstatus_host && *(volatile uint32_t *) c->pstatus_host != 0)
-        return fail(SLAMGPU_ERR_BARRIER, "persistent step loop (slamgpu_run_observe): a workgroup waited too long at the in-launch barrier and the launch "
-                                         "was abandoned; the steps since then are void (recreate the context; SLAMGPU_NO_PERSIST=1 selects the per-step loop)");
+    if (c->pstatus_host && __atomic_load_n(c->pstatus_host, __ATOMIC_ACQUIRE) != 0) {
+        const volatile uint32_t *h = c->pstatus_host;
+        return fail(SLAMGPU_ERR_BARRIER, "persistent step loop (slamgpu_run_observe): a workgroup waited too long at the in-launch barrier and launch %u of "
+                                         "this context was abandoned after %u of its %u iterations (every workgroup had completed those; the iteration in "
+                                         "flight is partially applied, so the state is undefined and everything handed over since is void: recreate the "
+                                         "context and replay from there; slamgpu_persist_status returns these counts; SLAMGPU_NO_PERSIST=1 selects the "
+                                         "per-step loop)", (unsigned) h[2], (unsigned) h[1], (unsigned) h[3]);
+    }
     return 0;
 }
 
@@ -1561,8 +1566,8 @@ static int persist_setup(slamgpu_ctx *c, int32_t K) {
         HIP_TRY(hipMalloc((void **) &c->ppk_dev, sizeof(int32_t) * 2 * kSmallWords));
         HIP_TRY(hipMalloc((void **) &c->pring_dev, sizeof(PersistStep) * 4));
         HIP_TRY(hipMalloc((void **) &c->pdraw_dev, sizeof(float4) * 2 * 6 * (size_t) c->B.ncap));
-        HIP_TRY(hipHostMalloc((void **) &c->pstatus_host, 2 * sizeof(uint32_t), hipHostMallocDefault));
-        c->pstatus_host[0] = c->pstatus_host[1] = 0;
+        HIP_TRY(hipHostMalloc((void **) &c->pstatus_host, kPersistHostWords * sizeof(uint32_t), hipHostMallocDefault));
+        for (int w = 0; w < kPersistHostWords; w++) c->pstatus_host[w] = 0;
         for (int b = 0; b < slamgpu_ctx::kPqBufs; b++) HIP_TRY(hipEventCreateWithFlags(&c->pq_kev[b], hipEventDisableTiming));
     }
     if ((size_t) K > c->pq_cap) {
@@ -1586,6 +1591,13 @@ static bool persist_eligible(const slamgpu_ctx *c) {
 static int run_observe_persist(slamgpu_ctx *c, int32_t K, const int32_t *n_controls, const float *controls, const float Q[4], float dt,
                                const float *xtrue, float max_range, const float R[4], int32_t noise) {
     if (int rc = persist_setup(c, K)) return rc;
+    // everything that can fail without a launch having been made comes BEFORE the host's bookkeeping moves on by K iterations
+    // (a failing hipEventSynchronize / hipMemsetAsync behind the collect loop left the host K iterations ahead of the
+    // device).  The queue buffer of kPqBufs calls ago must be free (bounds the host's run-ahead), and the loop's meeting words
+    // are zeroed in stream order behind the previous launch.
+    const int b = c->pq_next;
+    if (c->pq_kev_used[b]) HIP_TRY(hipEventSynchronize(c->pq_kev[b]));
+    HIP_TRY(hipMemsetAsync(c->psync_dev, 0, sizeof(uint32_t) * kPersistSyncWords, c->stream));
     slamgpu_ctx::PersistCollect col;
     col.steps.reserve((size_t) K);
     c->collect = &col;
@@ -1610,17 +1622,21 @@ static int run_observe_persist(slamgpu_ctx *c, int32_t K, const int32_t *n_contr
         // running launch made the CALL wait for that launch -- 270-520 us per call of 32 iterations, on the context's stream or on one
         // of its own -- so the host simulated its next iterations only after the GPU had finished the last ones.  The kernel reads
         // the entries out of pinned host memory instead, each an iteration before it needs it.
-        const int b = c->pq_next;
         c->pq_next = (c->pq_next + 1) % slamgpu_ctx::kPqBufs;
-        if (c->pq_kev_used[b]) HIP_TRY(hipEventSynchronize(c->pq_kev[b]));  // (the launch of kPqBufs calls ago: the host's run-ahead is bounded)
         PersistStep *qh = c->pq_host + (size_t) b * c->pq_cap;
         memcpy(qh, col.steps.data(), sizeof(PersistStep) * n);
-        HIP_TRY(hipMemsetAsync(c->psync_dev, 0, sizeof(uint32_t) * kPersistSyncWords, c->stream));
         UpdateArgs U = col.U;
         U.persist.queue = qh;
         U.persist.K = (int32_t) n;
-        U.persist.max_spins = 1u << 20;
-        if (const char *e = getenv("SLAMGPU_PERSIST_MAX_SPINS")) U.persist.max_spins = (uint32_t) std::max(0, atoi(e));  // tests: the abandon path
+        // one wait is bounded in time (2 s of the 100 MHz constant clock: a member workgroup that is dispatched that late -- another
+        // process holding the CUs -- abandons the launch) and, for the tests of the abandon path, in polls
+        U.persist.max_spins = 0xffffffffu;
+        U.persist.max_ticks = 200000000ull;
+        if (const char *e = getenv("SLAMGPU_PERSIST_MAX_SPINS")) U.persist.max_spins = (uint32_t) std::max(0, atoi(e));
+        if (const char *e = getenv("SLAMGPU_PERSIST_MAX_MS")) U.persist.max_ticks = 100000ull * (unsigned long long) std::max(0, atoi(e));
+        U.persist.serial = (int32_t) (c->persist_launches + 1);
+        U.persist.abort_at = -1;
+        if (const char *e = getenv("SLAMGPU_PERSIST_ABORT_AT")) U.persist.abort_at = atoi(e);
         U.persist.sync = c->psync_dev;
         U.persist.host_status = c->pstatus_host;
         U.persist.state_final = c->front_dev + c->front_par;  // (the copy the next launch reads)
@@ -2988,6 +3004,16 @@ int slamgpu_persist_info(slamgpu_ctx *c, int64_t *launches, int64_t *iterations,
             return persist_check(c);
         }
     }
+    return 0;
+}
+
+int slamgpu_persist_status(slamgpu_ctx *c, int32_t *abandoned, int64_t *launch, int32_t *completed, int32_t *handed) {
+    if (int rc = check_ctx(c)) return rc;
+    const bool ab = c->pstatus_host && __atomic_load_n(c->pstatus_host, __ATOMIC_ACQUIRE) != 0;
+    if (abandoned) *abandoned = ab ? 1 : 0;
+    if (launch) *launch = ab ? (int64_t) c->pstatus_host[2] : 0;
+    if (completed) *completed = ab ? (int32_t) c->pstatus_host[1] : 0;
+    if (handed) *handed = ab ? (int32_t) c->pstatus_host[3] : 0;
     return 0;
 }
 

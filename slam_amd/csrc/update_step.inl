@@ -136,7 +136,7 @@
     if (do_scan) {
         if (scan_tab) scan_issue_dma(tot, nbg, h_nb, scan_tab);
         else if (PERSIST && !logw) scl = scan_issue_small(tot, nbg);
-        else scl = scan_issue(tot, nbg, h_nb, logw);
+        else scl = scan_issue<PERSIST>(tot, nbg, h_nb, logw);
     }
     // persistent loop, at most kWinBlocks tiles: every wave requests ALL in-block prefixes of the previous iteration now (1 KB per
     // tile, one 16-byte load per lane and tile) and parks them in its ancestor window behind the scan: a resampling iteration

@@ -410,6 +410,125 @@ def test_loop902_whole_run_ancestor_forced_plain_rows(sg_mod, oracle, math_mode)
         assert np.array_equal(final[key].view(np.uint32), final_u[key].view(np.uint32)), key
 
 
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+@pytest.mark.parametrize("method", ["FASTSLAM1", "FASTSLAM2"])
+def test_persistent_loop_whole_run_against_the_oracle(sg_mod, oracle, method, math_mode):
+    """The persistent step loop (update_persist_kernel: what `slam-backend -observe device` and bench config 2 run) held to the
+    ORACLE directly, not through the per-step launches: example_webmap, 1 000 particles, ALL 2 172 iterations of the
+    wrapper's loop (fastslam1wrapper.cpp:51-113, fastslam2wrapper.cpp:51-117) handed to slamgpu_run_observe in uneven batches --
+    every batch ONE launch -- and every iteration's estimate, Neff and resampling decision from the loop's history compared with
+    an oracle particle set that takes the same controls, the same observation packets and the same Philox draws; at every batch
+    boundary the loop's full state (read through its genealogy) against the oracle's particles.
+
+    What keeps two float32 filters comparable over a whole run is the module's device: the oracle takes the GPU's resampling
+    decision and ancestors (a stratum a hair across a cumulative-sum boundary picks the neighbour otherwise).  A launch of K
+    iterations cannot be asked for its ancestors in the middle, so they -- and the packets the device front end makes (Philox
+    sensor noise) -- are read from a companion context stepped with slamgpu_step_observe.  The companion supplies INPUTS only;
+    everything asserted here is the loop's own output against the oracle's: were the loop's weights not the companion's, its
+    estimates would leave the oracle's at the first resample."""
+    from slam_amd import host
+    N, seed = 1000, 7
+    fs2 = method == "FASTSLAM2"
+    args = sim_args("example_webmap", method, N, seed)
+    tape = host.make_tape(args)
+    sim = host.HostSim(args)
+    lm, _ = sim.map()
+    max_range = float(sim.conf.MAX_RANGE)
+    sim.close()
+    o = oracle.sim(args)   # (the algorithm constants only)
+    algo0 = o.algo()
+    from oracle.orc import Algo
+    algo = Algo(algo0.method, algo0.use_heading, algo0.add_predict_noise, algo0.resample, algo0.n_effective, algo0.wheel_base, algo0.sigma_phi)
+    o.close()
+    steps = tape["steps"]
+    Q, R, dt = tape["Q"], tape["R"], float(tape["dt"])
+    ctl = [np.array(st["controls"], f32).reshape(-1, 3) for st in steps]
+    xt = [np.asarray(st["true"], f32) for st in steps]
+    T = len(steps)
+    assert T == 2172
+
+    def mk():
+        c = sg_mod.SlamGpu(N, tape["nlm"], method=2 if fs2 else 1, n_effective=algo.n_effective, use_heading=bool(algo.use_heading),
+                           add_predict_noise=bool(algo.add_predict_noise), wheel_base=algo.wheel_base, sigma_phi=algo.sigma_phi,
+                           rng_mode=sg_mod.RNG_PHILOX, seed=seed, math_mode=math_mode, device_observe=True)
+        c.set_map(lm)
+        return c
+    A, B = mk(), mk()
+    P = oracle.particles(N, tape["nlm"])
+    # (orc_particles_create: Particle() then w = 1/N, ParticleSLAMWrapper.cpp:14-25)
+    st = dict(max_est=0.0, max_neff_rel=0.0, decision_diff=0, resamples=0, max_pose=0.0, max_lmk=0.0, boundaries=0, heading_checked=0)
+    sizes = [64, 37, 2, 128, 200, 3, 96, 255]
+    k, bi, ctl_step, launches, carried = 0, 0, 0, 0, 0
+    while k < T:
+        K = min(sizes[bi % len(sizes)], T - k)
+        bi += 1
+        A.run_observe(ctl[k:k + K], Q, dt, xt[k:k + K], max_range, R, noise=2)
+        launches += 1 if K >= 2 else 0
+        carried += K if K >= 2 else 0
+        exp = []
+        for j in range(k, k + K):
+            B.step_observe(ctl[j], Q, dt, xt[j], max_range, R, noise=2)
+            pk = B.observe_fetch()
+            ne_b, did_b, _ = B.stats()
+            keep = B.ancestors() if did_b else None
+            for (V, G, phi) in ctl[j]:
+                ctl_step += 1
+                n2 = oracle.philox_predict_tape(seed, ctl_step, 0, N) if algo.add_predict_noise else None
+                P.predict(algo, float(V), float(G), Q, dt, float(phi), n2)
+            need = fs2 and (pk["zf"].shape[0] > 0 or pk["zn"].shape[0] > 0)
+            normals, sel = oracle.philox_update_tape(seed, j + 1, 0, N, N, want_normals=True)
+            P.update_local(algo, pk["zf"], pk["idf"], pk["zn"], R, np.ascontiguousarray(normals) if need else None)
+            _, ne_o, did_o = P.resample_forced(algo, sel, did_b, keep)
+            exp.append((P.estimate(), float(ne_o), did_o, did_b, float(ne_b), P.get(landmarks=False)["xv"][0, 2] if did_b else None))
+        est, neff, res = A.history_fetch()
+        assert len(est) == K
+        for j, (e_o, ne_o, did_o, did_b, ne_b, th0) in enumerate(exp):
+            tag = "%s %s iteration %d (batch of %d from %d)" % (method, ["strict", "fast"][math_mode], k + j + 1, K, k)
+            # the loop's own history against the oracle: estimate (ParticleSLAMWrapper.cpp:56-77), Neff and decision (core.cpp:718-749)
+            d = float(np.abs(np.asarray(est[j][:2], np.float64) - e_o[:2]).max())
+            st["max_est"] = max(st["max_est"], d)
+            ensure(d <= 1e-3, (tag, "estimate", est[j], e_o))
+            rel = abs(float(neff[j]) / ne_o - 1.0)
+            st["max_neff_rel"] = max(st["max_neff_rel"], rel)
+            ensure(rel <= FREE_NEFF[fs2][math_mode], (tag, "Neff", neff[j], ne_o))
+            assert bool(res[j]) == did_b and float(neff[j]) == ne_b, tag   # (the decision the oracle was handed IS the loop's)
+            st["resamples"] += int(did_b)
+            if bool(res[j]) != did_o:   # only next to the threshold
+                st["decision_diff"] += 1
+                ensure(abs(ne_o / algo.n_effective - 1.0) <= FREE_NEFF[fs2][math_mode], (tag, "decision", neff[j], ne_o))
+            if th0 is not None:   # after a resample every weight is 1/N: the heading is particle 0's (first-max rule)
+                dth = abs(float(est[j][2]) - float(th0))
+                ensure(min(dth, abs(dth - 2 * np.pi)) <= FREE_POSE_ATOL[math_mode], (tag, "heading", est[j][2], th0))
+                st["heading_checked"] += 1
+        k += K
+        # batch boundary: an observer between two launches of the loop reads its state through the genealogy
+        got, want = A.peek(), P.get()
+        assert got["nf"] == want["nf"], k
+        dxv = np.abs(got["xv"].astype(np.float64) - want["xv"])
+        dxv[:, 2] = np.minimum(dxv[:, 2], np.abs(dxv[:, 2] - 2 * np.pi))
+        st["max_pose"] = max(st["max_pose"], float(dxv.max()))
+        ensure(dxv.max() <= FREE_POSE_ATOL[math_mode], (k, "pose", dxv.max()))
+        ensure(close_cov(got["Pv"], sym(want["Pv"]), 5e-3), (k, "Pv"))
+        if got["nf"]:
+            dl = float(np.abs(got["xf"] - want["xf"]).max())
+            st["max_lmk"] = max(st["max_lmk"], dl)
+            ensure(dl <= FREE_LMK_ATOL[math_mode], (k, "landmarks", dl))
+            ensure(close_cov(got["Pf"], sym(want["Pf"]), 5e-3), (k, "Pf"))
+        st["boundaries"] += 1
+        pa = A.observe_fetch()   # the last packet of the launch is the companion's
+        for key in ("zf", "idf", "zn"):
+            assert np.array_equal(pa[key], pk[key]), (k, key)
+    print("persistent loop vs oracle, %s %s: %s" % (method, ["strict", "fast"][math_mode], st))
+    # the iterations DID go through update_persist_kernel: one launch per batch of two or more, no XCD-crossing placement
+    assert A.persist_info(cross=True) == (launches, carried, 0) and launches >= 15 and carried >= T - 4
+    assert B.persist_info() == (0, 0)
+    assert st["resamples"] > 800 and st["heading_checked"] == st["resamples"] and A.nf() == 35
+    ensure(st["decision_diff"] <= 8, st)
+    A.close()
+    B.close()
+    P.close()
+
+
 @pytest.fixture(scope="module")
 def synmap10k(tmp_path_factory):
     from conftest import DATA

@@ -298,13 +298,18 @@ def test_c_download_straight_after_device_steps(sg, monkeypatch, plain):
     assert np.isfinite(a["xf"]).all()
 
 
-@pytest.mark.parametrize("method,N,mapname,math", [("FASTSLAM2", 1024, "example_webmap", 1), ("FASTSLAM1", 1000, "example_webmap", 1),
-                                                   ("FASTSLAM2", 1000, "example_webmap", 0), ("FASTSLAM1", 1024, "example_webmap", 0),
-                                                   ("FASTSLAM1", 200, "example_webmap", 1), ("FASTSLAM2", 2048, "example_webmap", 1),
-                                                   ("FASTSLAM2", 1000, "example_loop2", 1),   # (heading known: sequential predicts)
-                                                   ("FASTSLAM2", 4096, "example_webmap", 1),  # (16 tiles: beyond the persistent loop)
-                                                   ("FASTSLAM2", 512, "example_loop902", 1)])   # (117 landmarks: the front-end kernel on its own stream)
-def test_run_observe_equals_step_by_step(sg, method, N, mapname, math):
+@pytest.mark.parametrize("method,N,mapname,math,logw", [("FASTSLAM2", 1024, "example_webmap", 1, False), ("FASTSLAM1", 1000, "example_webmap", 1, False),
+                                                        ("FASTSLAM2", 1000, "example_webmap", 0, False), ("FASTSLAM1", 1024, "example_webmap", 0, False),
+                                                        ("FASTSLAM1", 200, "example_webmap", 1, False), ("FASTSLAM2", 2048, "example_webmap", 1, False),
+                                                        ("FASTSLAM2", 1000, "example_loop2", 1, False),   # (heading known: sequential predicts)
+                                                        ("FASTSLAM2", 4096, "example_webmap", 1, False),  # (16 tiles: beyond the persistent loop)
+                                                        ("FASTSLAM2", 512, "example_loop902", 1, False),  # (117 landmarks: the front-end kernel on its own stream)
+                                                        # log-weight contexts in the loop (their block totals and maxima are other
+                                                        # tiles' stores of the running launch and must be read past the vector cache, like the
+                                                        # linear ones): 8 tiles, 4 tiles and an uneven last tile, both methods, both builds
+                                                        ("FASTSLAM2", 2048, "example_webmap", 1, True), ("FASTSLAM1", 1000, "example_webmap", 1, True),
+                                                        ("FASTSLAM2", 1000, "example_webmap", 0, True), ("FASTSLAM1", 2048, "example_webmap", 0, True)])
+def test_run_observe_equals_step_by_step(sg, method, N, mapname, math, logw):
     """slamgpu_run_observe (K iterations of the wrapper's loop in one C call, observation made on the device) against K calls of
     slamgpu_step_observe: the histories of all iterations (estimate, Neff, decision, status) and the final state bit for bit, the
     call split in uneven pieces; bad arguments are refused.  Round 5: small compact contexts run a call's iterations as ONE launch
@@ -325,7 +330,7 @@ def test_run_observe_equals_step_by_step(sg, method, N, mapname, math):
         conf = tape["conf"]
         s = sg.SlamGpu(N, tape["nlm"], method=2 if method == "FASTSLAM2" else 1, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=5,
                        math_mode=math, device_observe=True, use_heading=bool(conf.SWITCH_HEADING_KNOWN), wheel_base=float(conf.WHEELBASE),
-                       sigma_phi=float(conf.sigmaT))
+                       sigma_phi=float(conf.sigmaT), log_weights=logw)
         s.set_map(lm)
         if whole:
             for a, b in ((0, 1), (1, 64), (64, 64), (64, 67), (67, len(steps))):   # (an empty call in the middle)
@@ -444,16 +449,36 @@ def test_persistent_loop_that_is_abandoned_says_so(sg, monkeypatch):
         s.set_map(lm)
         return s
 
-    monkeypatch.setenv("SLAMGPU_PERSIST_MAX_SPINS", "0")
+    # a healthy launch first (launch 1: 8 iterations), then the bound of 0 polls: launch 2 is abandoned at its FIRST meeting, before
+    # any of its 24 iterations; the launch queued behind it (3) leaves at once and must not overwrite the account
     s = make()
+    s.run_observe(ctl[:8], tape["Q"], float(tape["dt"]), xt[:8], max_range, tape["R"], noise=2)
+    assert s.persist_status() is None
+    monkeypatch.setenv("SLAMGPU_PERSIST_MAX_SPINS", "0")
     with pytest.raises(sg.SlamGpuError) as ei:
-        s.run_observe(ctl[:32], tape["Q"], float(tape["dt"]), xt[:32], max_range, tape["R"], noise=2)
+        s.run_observe(ctl[8:32], tape["Q"], float(tape["dt"]), xt[8:32], max_range, tape["R"], noise=2)
+        s.run_observe(ctl[32:36], tape["Q"], float(tape["dt"]), xt[32:36], max_range, tape["R"], noise=2)
         s.history_fetch()
     assert ei.value.code == -6, ei.value   # SLAMGPU_ERR_BARRIER (include/slamgpu.h)
+    # ... and says how far it got: which launch, how many of its iterations every workgroup had completed
+    assert "launch 2 of this context was abandoned after 0 of its 24 iterations" in str(ei.value), ei.value
+    assert s.persist_status() == (2, 0, 24)
     with pytest.raises(sg.SlamGpuError):   # (sticky)
         s.sync()
+    assert s.persist_status() == (2, 0, 24)
     s.close()
     monkeypatch.delenv("SLAMGPU_PERSIST_MAX_SPINS")
+    # abandoned in the MIDDLE of a launch (test hook: the helper workgroup gives up in iteration 5 of 24, as one that had waited too
+    # long would): every workgroup has completed iterations 0..4, and the account says exactly that
+    monkeypatch.setenv("SLAMGPU_PERSIST_ABORT_AT", "5")
+    s = make()
+    with pytest.raises(sg.SlamGpuError) as ei:
+        s.run_observe(ctl[:24], tape["Q"], float(tape["dt"]), xt[:24], max_range, tape["R"], noise=2)
+        s.sync()
+    assert ei.value.code == -6 and "launch 1 of this context was abandoned after 5 of its 24 iterations" in str(ei.value), ei.value
+    assert s.persist_status() == (1, 5, 24)
+    s.close()
+    monkeypatch.delenv("SLAMGPU_PERSIST_ABORT_AT")
     s = make()
     s.run_observe(ctl[:32], tape["Q"], float(tape["dt"]), xt[:32], max_range, tape["R"], noise=2)
     hist = s.history_fetch()
