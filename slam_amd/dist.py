@@ -124,23 +124,29 @@ class DistFilter:
     `contexts`: the shards living in this process (all of them with LocalGather, one with TorchGather), created with
     first_particle = shard * n, n_particles_global = n_shards * n, rng_mode = RNG_PHILOX."""
 
-    def __init__(self, contexts, gather):
+    def __init__(self, contexts, gather, on_stage=None):
+        """on_stage(name): called as each collective step of the set-up BEGINS (bench.py's breadcrumbs: a rank that blocks in
+        hipIpcOpenMemHandle or ncclCommInitRank is then named with the step it blocks in)"""
         self.ctx, self.g = list(contexts), gather
         self.push = False
+        stage = on_stage or (lambda name: None)
         self.G = gather.world
         self.n = getattr(self.ctx[0], "n_local", None) or self.ctx[0].N  # particles per shard
         # every step of the set-up is collective: a rank that fails must still take part in the exchange, and all ranks
         # leave together (an exception on one rank alone would leave the others waiting in a collective forever)
         mine, err = [], None
+        stage("ipc_export")
         for c in self.ctx:
             try:
                 mine.append(c.dist_export())
             except Exception as e:  # noqa: BLE001
                 mine.append(None)
                 err = err or e
+        stage("ipc_exchange")
         blobs = gather.exchange_blobs(mine)
         if any(b is None for b in blobs):
             raise RuntimeError("distributed set-up: a shard could not export its state arrays (%s)" % (err or "on another rank"))
+        stage("peer_mappings")
         for c, s in zip(self.ctx, gather.shards):
             try:
                 c.dist_connect(self.G, s, blobs)
@@ -149,7 +155,9 @@ class DistFilter:
         if not self._agree(err is None):
             raise RuntimeError("distributed set-up: a shard could not map its peers (%s)" % (err or "on another rank"))
         if hasattr(gather, "connect_comm"):
+            stage("communicator")
             gather.connect_comm()
+        stage("setup_barrier")
         gather.barrier()
 
     def use_push(self, iters=20, fold=False):

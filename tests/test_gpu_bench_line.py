@@ -70,6 +70,13 @@ def test_default_line_single_gpu():
     c = j["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 1e4 and "sample" in c and c["unit"] == j["unit"]
     assert j["config"]["degenerate_steps"] == 0
+    # (round 6) the like-for-like base of a scaling curve: the DISTRIBUTED path at world size 1 on the same window -- its own rank
+    # process, the library's RCCL communicator, the all-gather in every step -- beside the single context's `value`
+    d = j["dist_path_n1"]
+    assert "error" not in d, d
+    assert d["window_start"] == j["config"]["window_start"] and d["steps"] == 60 and d["rccl_ranks"] == 1 and d["particles"] == 100096
+    assert 1e9 < d["value"] < 2e10 and 0.9 < d["ratio_to_single_context"] < 2.5, d
+    assert 5.0 < d["update_launch_us"] < 100.0 and 0.5 < d["allgather_us_in_step"] < 1e3 and d["preflight"]["hipipc_ok"] is True
 
 
 def test_multi_gpu_path_with_one_rank():
@@ -92,6 +99,12 @@ def test_multi_gpu_path_with_one_rank():
     chk = j["config"]["check_vs_single_context"]
     assert chk["max_abs_diff"] <= 1e-9 and chk["steps"] >= 1065, chk  # ... over every step, the timed window included
     assert "cpu_baseline" not in j
+    # (round 6) what the set-up found, on the line: peer access between the visible GPUs, the mappings across processes, the RCCL
+    # the library bound and the size of its communicator, and what the first and the steady all-gather of the step's size cost
+    pf = j["config"]["preflight"]
+    assert pf["devices_visible"] >= 1 and pf["peer_access"][0][0] == 1 and pf["hipipc_ok"] is True
+    assert pf["rccl_ranks"] == 1 and pf["rccl_version"][0].isdigit() and pf["allgather_bytes_per_rank"] == 8 * (100096 // 256)
+    assert 0.0 < pf["first_allgather_ms"] < 5e3 and pf["allgather_us"] == j["config"]["allgather_us"] and pf["setup_s"] > 0.0
     # BASELINE configs[3] as a strong-scaling run in the same line
     (s4,) = j["also"]
     assert s4["scaling"] == "strong" and s4["config"]["particles_total"] == 1001472 and s4["config"]["baseline_config"] == 4
