@@ -296,6 +296,14 @@ enum { SLAMGPU_ASSOC_AUTO = 0, SLAMGPU_ASSOC_EXHAUSTIVE = 1, SLAMGPU_ASSOC_GRID 
 int slamgpu_associate_ex(slamgpu_ctx *ctx, const float *z, int32_t nz, const float R[4], float gate_reject, float gate_augment, int32_t mode,
                          int32_t *labels, int32_t *consensus, float *support, double stats[4]);
 
+/* Retire landmarks from the gated association (round 6): landmarks ids[0 .. count) take no part in slamgpu_associate /
+ * _associate_ex from now on -- no particle gates an observation against them, nothing votes for them -- and, never being
+ * re-observed, they are never written again.  They stay in the particles' maps (slamgpu_num_landmarks, slamgpu_download and the
+ * landmark capacity count them): what the reference's Particle would allow -- dropping an entry of landmarkXs / landmarkPs,
+ * Particle.cpp:61-73 -- is a renumbering of every later landmark, which a per-step association shared by all particles cannot do
+ * in the middle of a run.  For a caller whose policy has given a landmark up (a duplicate opened by a wrong vote:
+ * slam-backend -assoc gated, host/gated.h).  Single contexts.  Synchronises. */
+int slamgpu_retire_landmarks(slamgpu_ctx *ctx, const int32_t *ids, int32_t count);
 int slamgpu_num_landmarks(slamgpu_ctx *ctx);
 
 /* Introspection: genealogy rows in use (what a resample composes per particle: 4 bytes each) and the context's row capacity.

@@ -60,6 +60,23 @@ int slamhost_ekf_step(slamhost_ekf *e, slamhost_sim *s); /* -1 finished, 0 contr
 int slamhost_ekf_state(const slamhost_ekf *e, float *x, float *P, int32_t cap); /* returns dim; P row-major, ld = cap */
 
 /* libc rand() tape in the reference's draw order */
+/* The policy that turns the vote of the gated per-particle association (slamgpu_associate: labels by EKFSLAM::dataAssociate,
+ * ekfslam.cpp:151-189, per particle) into ONE association per step, as slam-backend -assoc gated applies it (slam_amd/csrc/host/
+ * gated.h: supermajority to open, the second stage in world coordinates, landmark credits).  set: tunables by name -- "enabled",
+ * "new_share", "match_share", "credit_start", "credit_max", "retire_below", "rescue", "rescue_base", "rescue_per_m",
+ * "unique_ratio", "new_factor" (returns -1 for an unknown name).  step: z[2 nz], consensus / support of slamgpu_associate, the
+ * pose xv[3] and landmark means xf[2 nf] of ONE particle (slamgpu_peek), MAX_RANGE, room = landmarks that may still be opened;
+ * out (sized for nz / nz / nf): the packet of slamgpu_update and the landmarks to hand to slamgpu_retire_landmarks.
+ * counts[6]: opened, retired, matched by the second stage, observations left unused, refused as new, landmarks in use. */
+typedef struct slamhost_gated slamhost_gated;
+slamhost_gated *slamhost_gated_create(void);
+void slamhost_gated_destroy(slamhost_gated *g);
+int slamhost_gated_set(slamhost_gated *g, const char *name, double value);
+int slamhost_gated_step(slamhost_gated *g, const float *z, int32_t nz, const int32_t *consensus, const float *support, const float xv[3],
+                        const float *xf, int32_t nf, float max_range, int32_t room, float *zf, int32_t *idf, int32_t *m, float *zn, int32_t *n,
+                        int32_t *retire, int32_t *n_retire);
+void slamhost_gated_counts(const slamhost_gated *g, int32_t counts[6]);
+
 void slamhost_draw_normals(int32_t count, int32_t dim, float *out); /* count x randn(dim,1): dim+1 rand() each */
 int32_t slamhost_draw_strata(int32_t N, float *out);                /* returns the reference's strata count (== N when supported) */
 double slamhost_unif_rand(void);                                    /* unifRand (core.cpp:775) */

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DECLARED_SYMBOLS = [
     "slamgpu_last_error", "slamgpu_abi_version", "slamgpu_device_count", "slamgpu_jacobians", "slamgpu_jacobians_multi", "slamgpu_create",
     "slamgpu_destroy", "slamgpu_predict", "slamgpu_update", "slamgpu_estimate", "slamgpu_estimate_async", "slamgpu_estimate_fetch", "slamgpu_stats", "slamgpu_ancestors",
-    "slamgpu_num_landmarks", "slamgpu_genealogy_rows", "slamgpu_persist_info", "slamgpu_persist_status", "slamgpu_download", "slamgpu_upload", "slamgpu_sync", "slamgpu_step", "slamgpu_history_fetch", "slamgpu_shard_set_totals_buffer", "slamgpu_shard_step", "slamgpu_timer_start", "slamgpu_timer_stop", "slamgpu_stream", "slamgpu_profile",
+    "slamgpu_num_landmarks", "slamgpu_retire_landmarks", "slamgpu_genealogy_rows", "slamgpu_persist_info", "slamgpu_persist_status", "slamgpu_download", "slamgpu_upload", "slamgpu_sync", "slamgpu_step", "slamgpu_history_fetch", "slamgpu_shard_set_totals_buffer", "slamgpu_shard_step", "slamgpu_timer_start", "slamgpu_timer_stop", "slamgpu_stream", "slamgpu_profile",
     "slamgpu_kernel_time", "slamgpu_algorithmic_bytes", "slamgpu_shard_update", "slamgpu_shard_block_totals", "slamgpu_shard_plan",
     "slamgpu_shard_record_floats", "slamgpu_shard_pack", "slamgpu_shard_unpack", "slamgpu_shard_finish", "slamgpu_shard_estimate",
     "slamgpu_dev_alloc", "slamgpu_dev_free", "slamgpu_dev_copy", "slamgpu_dev_copy_async", "slamgpu_shard_estimate_async",
@@ -103,6 +103,7 @@ def load_library():
     L.slamgpu_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.slamgpu_ancestors.argtypes = [C.c_void_p, C.c_void_p]
     L.slamgpu_num_landmarks.argtypes = [C.c_void_p]
+    L.slamgpu_retire_landmarks.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     L.slamgpu_genealogy_rows.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.slamgpu_persist_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     L.slamgpu_persist_status.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -427,6 +428,11 @@ class SlamGpu:
         if n < 0:  # a negative slamgpu_status (e.g. SLAMGPU_ERR_CAPACITY from the device front end), never a count
             _chk(n)
         return n
+
+    def retire_landmarks(self, ids):
+        """landmarks that take no further part in the gated association (slamgpu_retire_landmarks)"""
+        ids = np.ascontiguousarray(ids, np.int32)
+        _chk(self.L.slamgpu_retire_landmarks(self.h, _ptr(ids), int(ids.size)))
 
     def live_rows(self):
         """genealogy rows in use (slamgpu_genealogy_rows)"""

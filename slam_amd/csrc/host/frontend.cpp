@@ -449,6 +449,52 @@ slamhost_sim *slamhost_sim_create(int argc, char **argv) {
 
 void slamhost_sim_destroy(slamhost_sim *s) { delete s; }
 
+slamhost_gated *slamhost_gated_create(void) { return new slamhost_gated(); }
+void slamhost_gated_destroy(slamhost_gated *g) { delete g; }
+int slamhost_gated_set(slamhost_gated *g, const char *name, double v) {
+    if (!g || !name) return -1;
+    slamhost::GatedPolicy &p = g->policy;
+    const std::string k = name;
+    if (k == "enabled") p.enabled = v != 0;
+    else if (k == "new_share") p.new_share = (float) v;
+    else if (k == "match_share") p.match_share = (float) v;
+    else if (k == "credit_start") p.credit_start = (int) v;
+    else if (k == "credit_max") p.credit_max = (int) v;
+    else if (k == "retire_below") p.retire_below = (int) v;
+    else if (k == "rescue") p.rescue = v != 0;
+    else if (k == "rescue_base") p.rescue_base = (float) v;
+    else if (k == "rescue_per_m") p.rescue_per_m = (float) v;
+    else if (k == "unique_ratio") p.unique_ratio = (float) v;
+    else if (k == "new_factor") p.new_factor = (float) v;
+    else return -1;
+    return 0;
+}
+int slamhost_gated_step(slamhost_gated *g, const float *z, int32_t nz, const int32_t *consensus, const float *support, const float xv[3],
+                        const float *xf, int32_t nf, float max_range, int32_t room, float *zf, int32_t *idf, int32_t *m, float *zn, int32_t *n,
+                        int32_t *retire, int32_t *n_retire) {
+    if (!g || nz < 0 || nf < 0 || (nz > 0 && (!z || !consensus)) || !xv || (nf > 0 && !xf) || !m || !n) return -1;
+    std::vector<float> vzf, vzn;
+    std::vector<int32_t> vidf, vret;
+    g->policy.step(z, nz, consensus, support, xv, xf, nf, max_range, room, vzf, vidf, vzn, vret);
+    if (zf) memcpy(zf, vzf.data(), sizeof(float) * vzf.size());
+    if (idf) memcpy(idf, vidf.data(), sizeof(int32_t) * vidf.size());
+    if (zn) memcpy(zn, vzn.data(), sizeof(float) * vzn.size());
+    *m = (int32_t) vidf.size();
+    *n = (int32_t) (vzn.size() / 2);
+    if (retire) memcpy(retire, vret.data(), sizeof(int32_t) * vret.size());
+    if (n_retire) *n_retire = (int32_t) vret.size();
+    return 0;
+}
+void slamhost_gated_counts(const slamhost_gated *g, int32_t c[6]) {
+    const slamhost::GatedPolicy &p = g->policy;
+    c[0] = p.n_opened;
+    c[1] = p.n_retired;
+    c[2] = p.n_rescued;
+    c[3] = p.n_discarded_votes;
+    c[4] = p.n_new_refused;
+    c[5] = p.active();
+}
+
 int slamhost_sim_conf(const slamhost_sim *s, slamhost_conf *out) {
     if (!s || !out) return -1;
     *out = static_cast<const slamhost_conf &>(s->sim.conf);

@@ -63,3 +63,8 @@ class Simulator {
 struct slamhost_sim {
     slamhost::Simulator sim;
 };
+
+#include "gated.h"
+struct slamhost_gated {
+    slamhost::GatedPolicy policy;
+};

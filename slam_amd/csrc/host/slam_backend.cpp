@@ -34,6 +34,7 @@
 #include "../../../include/slamgpu.h"
 #include "ekfslam.h"
 #include "frontend.h"
+#include "gated.h"
 #include "plotwire.h"
 
 using namespace slamhost;
@@ -459,8 +460,25 @@ int main(int argc, char **argv) {
         }
     };
 
-    std::vector<float> zf, zn, normals, strata, noise2;
+    std::vector<float> zf, zn, normals, strata, noise2, g_xf;
     std::vector<int32_t> idf;
+    slamhost::GatedPolicy policy;
+    FILE *alog = (gated && !c.s("assoclog").empty()) ? fopen(c.s("assoclog").c_str(), "w") : nullptr;
+    std::vector<int> truth_of;
+    {
+        auto num = [&](const char *key, double dflt) { return c.s(key).empty() ? dflt : atof(c.s(key).c_str()); };
+        policy.enabled = num("ASSOC_POLICY", 1) != 0;
+        policy.new_share = (float) num("ASSOC_NEW_SHARE", policy.new_share);
+        policy.match_share = (float) num("ASSOC_MATCH_SHARE", policy.match_share);
+        policy.credit_start = (int) num("ASSOC_CREDIT_START", policy.credit_start);
+        policy.credit_max = (int) num("ASSOC_CREDIT_MAX", policy.credit_max);
+        policy.retire_below = (int) num("ASSOC_RETIRE_BELOW", policy.retire_below);
+        policy.rescue = num("ASSOC_RESCUE", 1) != 0;
+        policy.rescue_base = (float) num("ASSOC_RESCUE_BASE", policy.rescue_base);
+        policy.rescue_per_m = (float) num("ASSOC_RESCUE_PER_M", policy.rescue_per_m);
+        policy.unique_ratio = (float) num("ASSOC_UNIQUE_RATIO", policy.unique_ratio);
+        policy.new_factor = (float) num("ASSOC_NEW_FACTOR", policy.new_factor);
+    }
     long iter = 0, nobs = 0;
     double sum_us = 0, sq_err = 0;
     double est[3] = {0, 0, 0};
@@ -483,20 +501,43 @@ int main(int argc, char **argv) {
                 if (gated) {
                     // unknown association: every particle gates the observations against its own map; the weighted vote
                     // becomes this step's association (slamgpu_update's association is per step)
+                    // (the policy that turns the vote into the step's packet: host/gated.h)
                     const int nz = (int) (sim.z.size() / 2);
                     std::vector<int32_t> cons((size_t) std::max(nz, 1));
-                    zf.clear();
-                    idf.clear();
-                    zn.clear();
-                    if (nz > 0) rc = slamgpu_associate(ctx, sim.z.data(), nz, sim.Re, c.GATE_REJECT, c.GATE_AUGMENT, nullptr, cons.data(), nullptr);
-                    for (int q = 0; q < nz && !rc; q++) {
-                        if (cons[q] >= 0) {
-                            zf.push_back(sim.z[2 * q]);
-                            zf.push_back(sim.z[2 * q + 1]);
-                            idf.push_back(cons[q]);
-                        } else if (cons[q] == SLAMGPU_ASSOC_NEW && slamgpu_num_landmarks(ctx) + (int) (zn.size() / 2) < sim.map.nlm * 2) {
-                            zn.push_back(sim.z[2 * q]);
-                            zn.push_back(sim.z[2 * q + 1]);
+                    std::vector<float> supp((size_t) std::max(nz, 1));
+                    if (nz > 0) rc = slamgpu_associate(ctx, sim.z.data(), nz, sim.Re, c.GATE_REJECT, c.GATE_AUGMENT, nullptr, cons.data(), supp.data());
+                    const int nf_now = rc ? 0 : slamgpu_num_landmarks(ctx);
+                    if (!rc && nf_now < 0) rc = nf_now;
+                    float xv0[3] = {0, 0, 0};
+                    g_xf.resize(2 * (size_t) std::max(nf_now, 1));
+                    // the map the credits are kept against: particle 0's (one strided read, nothing rewritten)
+                    if (!rc && policy.enabled) rc = slamgpu_peek(ctx, 0, 1, 1, xv0, nullptr, nullptr, nf_now ? g_xf.data() : nullptr, nullptr);
+                    std::vector<int32_t> retire;
+                    if (!rc) {
+                        policy.step(sim.z.data(), nz, cons.data(), supp.data(), xv0, g_xf.data(), nf_now, c.MAX_RANGE, sim.map.nlm * 2 - nf_now, zf, idf, zn, retire);
+                        if (!retire.empty()) rc = slamgpu_retire_landmarks(ctx, retire.data(), (int32_t) retire.size());
+                        if (alog) {
+                            // diagnostic (-assoclog file): every decision beside the truth the simulator knows (sim.vis: the TRUE landmark
+                            // of each observation; truth_of[k]: the true landmark map entry k was opened for)
+                            for (int q = 0; q < nz; q++) {
+                                const int t = sim.vis[(size_t) q];
+                                const int dcs = policy.decision[(size_t) q];
+                                const char *what = "unused";
+                                int k = -1;
+                                if (dcs >= 0) {
+                                    k = dcs % 1000000;
+                                    what = truth_of[(size_t) k] == t ? (dcs >= 1000000 ? "match2" : "match") : (dcs >= 1000000 ? "MISMATCH2" : "MISMATCH");
+                                } else if (dcs == -1) {
+                                    bool dup = false;
+                                    for (int e = 0; e < (int) truth_of.size(); e++) dup = dup || (truth_of[(size_t) e] == t && !policy.retired[(size_t) e]);
+                                    what = dup ? "DUPLICATE" : "new";
+                                    truth_of.push_back(t);
+                                }
+                                const float ex = sim.xTrue[0] - (float) est[0], ey = sim.xTrue[1] - (float) est[1];
+                                fprintf(alog, "%ld obs %d true %d label %d share %.3f -> %s %d  (range %.2f, pose error %.3f m)\n", nobs, q, t, cons[q], supp[q], what, k,
+                                        sim.z[2 * q], std::sqrt(ex * ex + ey * ey));
+                            }
+                            for (int j : retire) fprintf(alog, "%ld retire %d (true %d)\n", nobs, j, truth_of[(size_t) j]);
                         }
                     }
                     if (rc) {
@@ -586,13 +627,19 @@ int main(int argc, char **argv) {
     }
     printf("control steps %ld, observation steps %ld, mean loop time %.1f us, rms position error %.4f m, final estimate (%.4f, %.4f, %.4f)\n",
            iter, nobs, iter ? sum_us / iter : 0.0, iter ? std::sqrt(sq_err / iter) : 0.0, est[0], est[1], est[2]);
-    if (ctx) printf("landmarks in map: %d\n", slamgpu_num_landmarks(ctx));
+    if (ctx && gated) {
+        const int nfl = slamgpu_num_landmarks(ctx);
+        printf("landmarks in map: %d (%d opened, %d retired by the association policy, %d in use; %d observations matched by the second stage, %d "
+               "left unused, %d refused as new next to a mapped landmark)\n",
+               nfl - policy.n_retired, policy.n_opened, policy.n_retired, nfl - policy.n_retired, policy.n_rescued, policy.n_discarded_votes, policy.n_new_refused);
+    } else if (ctx) printf("landmarks in map: %d\n", slamgpu_num_landmarks(ctx));
     else printf("landmarks in map: %d\n", ekf.num_features());
     if (plot.active()) {
         plot.endPlot();
         plot.close();
     }
     if (log) fclose(log);
+    if (alog) fclose(alog);
     if (ctx) slamgpu_destroy(ctx);
     return rc ? EXIT_FAILURE : 0;
 }

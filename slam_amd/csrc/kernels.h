@@ -569,8 +569,9 @@ struct KernelTable {
     void (*observe_book)(hipStream_t, const ObserveArgs &);
     // per-particle gated nearest-neighbour association of nz observations against every landmark of every particle
     // (slamgpu_associate): labels [n][nz] = landmark index, kAssocNew or kAssocDiscard.  Plain set required (no pending gather).
+    // retired (may be null): bit j set = landmark j takes no part (slamgpu_retire_landmarks)
     void (*associate)(hipStream_t, const Buffers &, int nf, const float *z_dev, int nz, const float *R4, float gate_reject,
-                      float gate_augment, int32_t *labels_dev);
+                      float gate_augment, const uint32_t *retired_dev, int32_t *labels_dev);
     // seq_out != null: `out` and `seq_out` are pinned host memory; the kernel stores `seq` there last (system-scope fence)
     void (*shard_plan)(hipStream_t, const ShardPlanArgs &, const RngArgs &, ShardPlan *out, uint32_t *seq_out, uint32_t seq);
     void (*shard_pack)(hipStream_t, const Buffers &, const WeightScratch &, const ShardPackArgs &, const RngArgs &);
@@ -581,7 +582,8 @@ struct KernelTable {
     void (*dist_flags)(hipStream_t, const DistFlagArgs &);
     void (*peek)(hipStream_t, const Buffers &, const WeightScratch &, const PeekArgs &);
     // bounding boxes of the listed landmarks (ids on the device) over all particle slots of their live record buffer
-    void (*lmk_box)(hipStream_t, const Buffers &, const int32_t *ids_dev, int count, LmkBox *box_dev);
+    // (a retired landmark gets the EMPTY box: it enters no grid cell and is never evaluated)
+    void (*lmk_box)(hipStream_t, const Buffers &, const int32_t *ids_dev, int count, const uint32_t *retired_dev, LmkBox *box_dev);
     // geometry + grid of the landmark boxes for one association call (four small launches)
     void (*assoc_grid)(hipStream_t, const Buffers &, const AssocGridArgs &);
     // slamgpu_associate through the grid: the same labels as `associate`, evaluating only the landmarks of one cell per

@@ -2481,9 +2481,52 @@ __global__ void __launch_bounds__(kObsThreads) observe_book_kernel(ObserveArgs A
 SLAM_DEV void read_through_genealogy(const Buffers &B, const int32_t *__restrict__ live, int cur, size_t S, int l, int anc,
                                      float4 &la, float &lb);
 
+// What one particle's estimate of one landmark contributes to the gates of EKFSLAM::dataAssociate (ekfslam.cpp:160-176): the
+// predicted observation, S^-1 and log det S with S = Hf Pf Hf^T + R; then per observation nis = v^T S^-1 v and nd = nis + log det S.
+// strict build: the reference's operations (computeJacobians, the LU inverse and determinant of the dynamic 2x2, core.cpp:579-715).
+// fast build (round 6): the restructured arithmetic of the update's second pass (device_math.h: observe2 -- rsq, the polynomial
+// atan2, FMAs; the closed-form inverse on one v_rcp_f32; v_log_f32; wrap_pi): ~110 instead of ~435 VALU instructions per
+// evaluated triple on the 10 000-landmark map (SQ counters: profiles/gated_association_r06.txt), the same decisions wherever a gate
+// is not within rounding of its bound (tests/test_association.py holds both builds to the reference's decision vectors).
+struct AssocLm {
+    float zp0, zp1, i00, i01, i10, i11, ldet;
+};
+SLAM_DEV AssocLm assoc_landmark(const float4 &pa, const float4 &la, float lb, float r00, float r01, float r10, float r11) {
+    AssocLm A;
+#ifdef SLAM_FAST_MATH
+    const Obs2 o = observe2(pa.x, pa.y, pa.z, la.x, la.y, la.z, la.w, lb, r00, 0.5f * (r01 + r10), r11);
+    const float det = ffma(o.s00, o.s11, -o.s10 * o.s10);
+    const float rdet = __builtin_amdgcn_rcpf(det);
+    A.zp0 = o.zp0;
+    A.zp1 = o.zp1;  // (not wrapped: assoc_gate wraps the residual, which is the same angle modulo 2 pi)
+    A.i00 = o.s11 * rdet;
+    A.i01 = A.i10 = -o.s10 * rdet;
+    A.i11 = o.s00 * rdet;
+    A.ldet = 0.69314718055994531f * __builtin_amdgcn_logf(det);  // v_log_f32 is log2
+#else
+    const Jac jc = jacobian(pa.x, pa.y, pa.z, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
+    inverse2(jc.s00, jc.s01, jc.s10, jc.s11, A.i00, A.i01, A.i10, A.i11);
+    A.ldet = logf(determinant2(jc.s00, jc.s01, jc.s10, jc.s11));
+    A.zp0 = jc.zp0;
+    A.zp1 = jc.zp1;
+#endif
+    return A;
+}
+SLAM_DEV void assoc_gate(const AssocLm &A, float zr, float zb, float &nis, float &nd) {
+    const float v0 = zr - A.zp0;
+#ifdef SLAM_FAST_MATH
+    const float v1 = wrap_pi(zb - A.zp1);
+#else
+    const float v1 = trig_offset(zb - A.zp1);
+#endif
+    const float t0 = v0 * A.i00 + v1 * A.i10, t1 = v0 * A.i01 + v1 * A.i11;  // v^T S^-1
+    nis = t0 * v0 + t1 * v1;
+    nd = nis + A.ldet;
+}
+
 __global__ void __launch_bounds__(kBlock) associate_kernel(Buffers B, int nf, const float *__restrict__ z, int nz, float r00, float r01,
                                                             float r10, float r11, float gate1, float gate2,
-                                                            int32_t *__restrict__ labels) {
+                                                            const uint32_t *__restrict__ retired, int32_t *__restrict__ labels) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= B.n) return;
     const int cur = B.ctrl->live[B.slot];
@@ -2499,21 +2542,17 @@ __global__ void __launch_bounds__(kBlock) associate_kernel(Buffers B, int nf, co
             jbest[q] = -1;
         }
         for (int j = 0; j < nf; j++) {
+            // (a retired landmark -- slamgpu_retire_landmarks: a duplicate the caller's policy has given up -- takes no part; uniform)
+            if (retired && ((retired[j >> 5] >> (j & 31)) & 1u)) continue;
             float4 la;
             float lb;
             read_through_genealogy(B, B.lmk_live, cur, S, j, i, la, lb);
-            const Jac jc = jacobian(pa.x, pa.y, pa.z, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
-            float i00, i01, i10, i11;
-            inverse2(jc.s00, jc.s01, jc.s10, jc.s11, i00, i01, i10, i11);
-            const float ldet = logf(determinant2(jc.s00, jc.s01, jc.s10, jc.s11));
+            const AssocLm A = assoc_landmark(pa, la, lb, r00, r01, r10, r11);
 #pragma unroll
             for (int q = 0; q < kAssocBatch; q++) {
                 if (q0 + q < nz) {
-                    const float v0 = z[2 * (q0 + q)] - jc.zp0;
-                    const float v1 = trig_offset(z[2 * (q0 + q) + 1] - jc.zp1);
-                    const float t0 = v0 * i00 + v1 * i10, t1 = v0 * i01 + v1 * i11;  // v^T S^-1
-                    const float nis = t0 * v0 + t1 * v1;
-                    const float nd = nis + ldet;
+                    float nis, nd;
+                    assoc_gate(A, z[2 * (q0 + q)], z[2 * (q0 + q) + 1], nis, nd);
                     if (nis < gate1 && nd < nbest[q]) {
                         nbest[q] = nd;
                         jbest[q] = j;
@@ -2536,9 +2575,14 @@ __global__ void __launch_bounds__(kBlock) associate_kernel(Buffers B, int nf, co
 // ---------------------------------------------------------------------------------------------------
 // one block per listed landmark: box of its estimates and largest covariance trace over all particle slots of the live buffer
 // (a resample only removes particles from that set: the box stays valid until the landmark is written again)
-__global__ void __launch_bounds__(kBlock) lmk_box_kernel(Buffers B, const int32_t *__restrict__ ids, int count, LmkBox *__restrict__ box) {
+__global__ void __launch_bounds__(kBlock) lmk_box_kernel(Buffers B, const int32_t *__restrict__ ids, int count, const uint32_t *__restrict__ retired,
+                                                          LmkBox *__restrict__ box) {
     __shared__ float sh[5][kBlock / kWave];
     const int j = ids[blockIdx.x];
+    if (retired && ((retired[j >> 5] >> (j & 31)) & 1u)) {  // the empty box: no cell (assoc_cells), so the landmark is never evaluated
+        if (threadIdx.x == 0) box[j] = LmkBox{INFINITY, -INFINITY, INFINITY, -INFINITY, 0.0f, {0.0f, 0.0f, 0.0f}};
+        return;
+    }
     const int b = B.lmk_live[j];
     const float4 *__restrict__ a = B.lmkA[b] + (size_t) j * B.ncap;
     const float *__restrict__ c = B.lmkB[b] + (size_t) j * B.ncap;
@@ -2754,7 +2798,11 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
         if (on) {
             const float zr = A.z[2 * q], zb = A.z[2 * q + 1];
             float sn, cs;
+#ifdef SLAM_FAST_MATH
+            sincos_cw(pa.z + zb, sn, cs);  // (a bounded angle; the cell the point falls in has a cell of slack on every side)
+#else
             sincosf(pa.z + zb, &sn, &cs);
+#endif
             const float px = pa.x + zr * cs, py = pa.y + zr * sn;
             const int cx = min(max((int) floorf((px - g.x0) * g.inv_cs), 0), g.nx - 1);
             const int cy = min(max((int) floorf((py - g.y0) * g.inv_cs), 0), g.ny - 1);
@@ -2777,15 +2825,9 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
                 float4 la;
                 float lb;
                 read_through_genealogy(B, B.lmk_live, cur, S, j, i, la, lb);
-                const Jac jc = jacobian(pa.x, pa.y, pa.z, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
-                float i00, i01, i10, i11;
-                inverse2(jc.s00, jc.s01, jc.s10, jc.s11, i00, i01, i10, i11);
-                const float ldet = logf(determinant2(jc.s00, jc.s01, jc.s10, jc.s11));
-                const float v0 = zr - jc.zp0;
-                const float v1 = trig_offset(zb - jc.zp1);
-                const float t0 = v0 * i00 + v1 * i10, t1 = v0 * i01 + v1 * i11;
-                const float nis = t0 * v0 + t1 * v1;
-                const float nd = nis + ldet;
+                const AssocLm A = assoc_landmark(pa, la, lb, r00, r01, r10, r11);
+                float nis, nd;
+                assoc_gate(A, zr, zb, nis, nd);
                 pairs++;
                 // (the cell's landmarks come in no particular order: ties go to the lower index, as in the ascending scan)
                 if (nis < gate1 && (nd < nbest || (nd == nbest && j < jbest))) {
@@ -3246,9 +3288,9 @@ static void launch_observe_book(hipStream_t st, const ObserveArgs &A) {
 }
 
 static void launch_associate(hipStream_t st, const Buffers &B, int nf, const float *z, int nz, const float *R4, float g1, float g2,
-                             int32_t *labels) {
+                             const uint32_t *retired, int32_t *labels) {
     hipLaunchKernelGGL(associate_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B, nf, z, nz, R4[0], R4[1], R4[2], R4[3], g1, g2,
-                       labels);
+                       retired, labels);
 }
 
 static void launch_kat(hipStream_t st, int op, const float *in, int n, float *out) {
@@ -3319,8 +3361,8 @@ static void launch_peek(hipStream_t st, const Buffers &B, const WeightScratch &w
     hipLaunchKernelGGL(peek_kernel, dim3((A.count + kBlock - 1) / kBlock, gy), dim3(kBlock), 0, st, B, ws, A);
 }
 
-static void launch_lmk_box(hipStream_t st, const Buffers &B, const int32_t *ids, int count, LmkBox *box) {
-    if (count > 0) hipLaunchKernelGGL(lmk_box_kernel, dim3(count), dim3(kBlock), 0, st, B, ids, count, box);
+static void launch_lmk_box(hipStream_t st, const Buffers &B, const int32_t *ids, int count, const uint32_t *retired, LmkBox *box) {
+    if (count > 0) hipLaunchKernelGGL(lmk_box_kernel, dim3(count), dim3(kBlock), 0, st, B, ids, count, retired, box);
 }
 
 static void launch_assoc_grid(hipStream_t st, const Buffers &B, const AssocGridArgs &A) {

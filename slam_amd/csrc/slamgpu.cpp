@@ -232,6 +232,10 @@ struct slamgpu_ctx {
     // for the landmarks written since (box_dirty), and the grid buffers
     LmkBox *box_dev = nullptr;
     std::vector<char> box_dirty;
+    // landmarks the caller has retired from the gated association (slamgpu_retire_landmarks): host flags + the device's bit mask
+    std::vector<char> retired;
+    uint32_t *retired_dev = nullptr;
+    int n_retired = 0;
     int32_t *assoc_ids_dev = nullptr, *cell_start_dev = nullptr, *cell_fill_dev = nullptr, *items_dev = nullptr;
     AssocGeom *geom_dev = nullptr;
     int32_t cap_items = 0;
@@ -926,6 +930,7 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     if (c->hist_host) (void) hipHostFree(c->hist_host);
     if (c->stamps_dev) (void) hipFree(c->stamps_dev);
     if (c->peek_dev) (void) hipFree(c->peek_dev);
+    if (c->retired_dev) (void) hipFree(c->retired_dev);
     for (void *p_ : {(void *) c->box_dev, (void *) c->assoc_ids_dev, (void *) c->cell_start_dev, (void *) c->cell_fill_dev, (void *) c->items_dev,
                      (void *) c->geom_dev})
         if (p_) (void) hipFree(p_);
@@ -2862,7 +2867,7 @@ int slamgpu_associate_ex(slamgpu_ctx *c, const float *z, int32_t nz, const float
         if (!rc) {
             if (ev0) step(hipEventRecord(ev0, c->stream), "event");
             Timed t(c, "associate");
-            if (!ids.empty()) c->k->lmk_box(c->stream, c->B, c->assoc_ids_dev, (int) ids.size(), c->box_dev);
+            if (!ids.empty()) c->k->lmk_box(c->stream, c->B, c->assoc_ids_dev, (int) ids.size(), c->retired_dev, c->box_dev);
             c->k->assoc_grid(c->stream, c->B, G);
             c->k->associate_grid(c->stream, c->B, G, R, gate_reject, gate_augment, lab_dev);
         }
@@ -2920,7 +2925,7 @@ int slamgpu_associate_ex(slamgpu_ctx *c, const float *z, int32_t nz, const float
             if (ev0) step(hipEventRecord(ev0, c->stream), "event");
             {
                 Timed t(c, "associate");
-                c->k->associate(c->stream, c->B, c->nf, z_dev, nz, R, gate_reject, gate_augment, lab_dev);
+                c->k->associate(c->stream, c->B, c->nf, z_dev, nz, R, gate_reject, gate_augment, c->retired_dev, lab_dev);
             }
             if (ev1) step(hipEventRecord(ev1, c->stream), "event");
             if (stats) stats[0] = (double) N * (double) nz * (double) c->nf;
@@ -2972,6 +2977,31 @@ int slamgpu_associate_ex(slamgpu_ctx *c, const float *z, int32_t nz, const float
         }
     }
     if (want_vote) assoc_resolve(nz, best, share, consensus, support);
+    return 0;
+}
+
+int slamgpu_retire_landmarks(slamgpu_ctx *c, const int32_t *ids, int32_t count) {
+    if (int rc = check_ctx(c)) return rc;
+    if (count < 0 || (count > 0 && !ids)) return fail(SLAMGPU_ERR_INVALID, "slamgpu_retire_landmarks: bad list");
+    if (c->dist || c->cfg.n_particles_global != c->cfg.n_particles) return fail(SLAMGPU_ERR_INVALID, "slamgpu_retire_landmarks: single contexts only");
+    if (int rc = book_pull(c)) return rc;
+    for (int32_t k = 0; k < count; k++)
+        if (ids[k] < 0 || ids[k] >= c->nf) return fail(SLAMGPU_ERR_INVALID, "slamgpu_retire_landmarks: landmark %d of %d", (int) ids[k], c->nf);
+    if (count == 0) return 0;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    const size_t words = ((size_t) c->B.cap_nf + 31) / 32;
+    if (c->retired.empty()) c->retired.assign((size_t) c->B.cap_nf, 0);
+    if (!c->retired_dev) HIP_TRY(hipMalloc((void **) &c->retired_dev, sizeof(uint32_t) * words));
+    for (int32_t k = 0; k < count; k++) {
+        if (!c->retired[(size_t) ids[k]]) c->n_retired++;
+        c->retired[(size_t) ids[k]] = 1;
+        c->box_dirty[(size_t) ids[k]] = 1;  // (its box becomes the empty one at the next grid call)
+    }
+    std::vector<uint32_t> mask(words, 0u);
+    for (int j = 0; j < c->B.cap_nf; j++)
+        if (c->retired[(size_t) j]) mask[(size_t) j >> 5] |= 1u << (j & 31);
+    HIP_TRY(hipStreamSynchronize(c->stream));  // (an association in flight may still read the old mask)
+    HIP_TRY(hipMemcpy(c->retired_dev, mask.data(), sizeof(uint32_t) * words, hipMemcpyHostToDevice));
     return 0;
 }
 

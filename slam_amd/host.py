@@ -10,7 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DECLARED_SYMBOLS = [
     "slamhost_last_error", "slamhost_sim_create", "slamhost_sim_destroy", "slamhost_sim_conf", "slamhost_sim_map",
     "slamhost_sim_control", "slamhost_sim_observe", "slamhost_sim_last_z", "slamhost_sim_true",
-    "slamhost_sim_control_steps", "slamhost_draw_normals", "slamhost_draw_strata", "slamhost_unif_rand",
+    "slamhost_sim_control_steps", "slamhost_gated_create", "slamhost_gated_destroy", "slamhost_gated_set", "slamhost_gated_step",
+    "slamhost_gated_counts", "slamhost_draw_normals", "slamhost_draw_strata", "slamhost_unif_rand",
     "slamhost_synthetic_landmarks", "slamhost_write_map", "slamhost_ekf_create", "slamhost_ekf_destroy", "slamhost_ekf_step",
     "slamhost_ekf_state", "slamhost_plot_open", "slamhost_plot_close", "slamhost_plot_xy", "slamhost_plot_matrix",
     "slamhost_plot_doubles", "slamhost_plot_car_size", "slamhost_plot_u32", "slamhost_plot_cmd", "slamhost_plot_name",
@@ -168,6 +169,52 @@ class HostSim:
     def noise(self):
         f = lambda a: np.array(list(a), np.float32).reshape(2, 2)
         return f(self.conf.Qe), f(self.conf.Re), np.float32(self.conf.DT_CONTROLS)
+
+
+class GatedPolicy:
+    """the policy between the gated association's vote and the update's packet (include/slamhost.h: slamhost_gated_*;
+    slam_amd/csrc/host/gated.h): what slam-backend -assoc gated applies every step"""
+
+    def __init__(self, **tunables):
+        self.L = load_library()
+        L = self.L
+        L.slamhost_gated_create.restype = C.c_void_p
+        L.slamhost_gated_destroy.argtypes = [C.c_void_p]
+        L.slamhost_gated_set.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        L.slamhost_gated_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32,
+                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32)]
+        L.slamhost_gated_counts.argtypes = [C.c_void_p, C.c_void_p]
+        self.h = C.c_void_p(L.slamhost_gated_create())
+        for k, v in tunables.items():
+            if L.slamhost_gated_set(self.h, k.encode(), float(v)) != 0:
+                raise ValueError("unknown association-policy tunable %r" % k)
+
+    def step(self, z, consensus, support, xv, xf, max_range, room):
+        """-> (zf [m, 2], idf [m], zn [n, 2], retire [r]) for slamgpu_update / slamgpu_retire_landmarks"""
+        z = np.ascontiguousarray(z, np.float32).reshape(-1, 2)
+        nz = z.shape[0]
+        xf = np.ascontiguousarray(xf, np.float32).reshape(-1, 2)
+        nf = xf.shape[0]
+        cons = np.ascontiguousarray(consensus, np.int32)
+        sup = np.ascontiguousarray(support, np.float32)
+        xv = np.ascontiguousarray(xv, np.float32)
+        zf, idf, zn, ret = np.zeros((max(nz, 1), 2), np.float32), np.zeros(max(nz, 1), np.int32), np.zeros((max(nz, 1), 2), np.float32), np.zeros(max(nf, 1), np.int32)
+        m, n, r = C.c_int32(), C.c_int32(), C.c_int32()
+        rc = self.L.slamhost_gated_step(self.h, _p(z), nz, _p(cons), _p(sup), _p(xv), _p(xf), nf, float(max_range), int(room), _p(zf), _p(idf), C.byref(m), _p(zn),
+                                        C.byref(n), _p(ret), C.byref(r))
+        if rc != 0:
+            raise RuntimeError("slamhost_gated_step: bad arguments")
+        return zf[:m.value].copy(), idf[:m.value].copy(), zn[:n.value].copy(), ret[:r.value].copy()
+
+    def counts(self):
+        c = np.zeros(6, np.int32)
+        self.L.slamhost_gated_counts(self.h, _p(c))
+        return dict(zip(("opened", "retired", "second_stage_matches", "unused", "refused_new", "in_use"), (int(x) for x in c)))
+
+    def close(self):
+        if self.h:
+            self.L.slamhost_gated_destroy(self.h)
+            self.h = None
 
 
 class HostEkf:

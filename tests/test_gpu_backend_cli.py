@@ -139,33 +139,77 @@ def test_slam_backend_plot_stream_with_particles(tmp_path):
     assert all(np.isfinite(xs)) and 0.5 < np.mean(xs) < 10.0
 
 
-@pytest.mark.parametrize("seed,math,tight", [(8, "strict", True), (7, "fast", False)])
-def test_slam_backend_gated_association_builds_the_same_map(tmp_path, seed, math, tight):
-    """-assoc gated: no association table, every particle gates the observations against its own landmark estimates
-    (slamgpu_associate), weighted vote per step.  On example_webmap (well separated landmarks) a run that goes well finds the 35
-    landmarks plus a few spurious ones and tracks the true path (seed 8, strict build: 39 landmarks, 0.23 m mean error).
-    The whole-run outcome is NOT robust, though, and the test says so instead of picking the lucky case: gated nearest neighbour
-    + vote opens a spurious landmark whenever an observation falls between the gates, and once a few exist next to real ones the
-    map can run to its capacity (2 x 35) -- measured in round 5 over seeds 7..11, both builds, 512 and 2 048 particles, this tree
-    and round 4's: 22 of 40 runs end at 68-70 landmarks with 1-4 m mean error, whatever the rounding (round 4's fast build at
-    seed 7, which this test used to pin, was one of the 18 that do not; profiles/gated_association_whole_runs_r05.txt).  The
-    reference has no FastSLAM version of this association (parity unpinned by nature); what IS pinned is every
-    single decision against the reference's EKF gating (tests/test_association.py)."""
-    log = str(tmp_path / "gated.csv")
-    r = subprocess.run([EXE, "-m", os.path.join(DATA, "example_webmap.mat"), "-method", "FASTSLAM2", "-NPARTICLES", "512", "-NEFFECTIVE", "384",
-                        "-SWITCH_SEED_RANDOM", str(seed), "-math", math, "-assoc", "gated", "-log", log], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+@pytest.mark.parametrize("seed,math", [(8, "strict"), (7, "fast"), (9, "fast"), (11, "strict")])
+def test_slam_backend_gated_association_builds_the_same_map(tmp_path, seed, math):
+    """-assoc gated: no association table: every particle gates the observations against its own landmark estimates
+    (slamgpu_associate: EKFSLAM::dataAssociate per particle, ekfslam.cpp:151-189), the weighted vote gives the step's labels, and
+    the policy of host/gated.h turns them into the update's packet.  Round 5's policy (plurality vote, open on "new") was right
+    decision by decision and wrong run by run: 22 of 40 whole runs ended at the map's capacity.  The cause was not the split votes
+    the review suspected but UNANIMOUS ones (profiles/gated_association_whole_runs_r06.txt): closing the loop of example_webmap the
+    landmarks of the first lap come back into view at 60 m with every particle ~1 m off along the line of sight -- ten standard
+    deviations of the range sensor for a chi-square gate that knows only the particle's own landmark covariance -- so every
+    particle says "new" and the first lap's map is duplicated; before that, the gates drop exactly the observations that contradict
+    the estimate.  Round 6's second stage (a unique nearest mapped landmark in world coordinates explains what the gates leave
+    unexplained; nothing is opened next to a mapped landmark) ends all 40 probed runs (seeds 7..16, both builds, 512 and 2 048
+    particles) with EXACTLY the map's 35 landmarks, none retired, every decision the true one, and the mean position error of the
+    same run with the reference's known association (0.49 against 0.54 m averaged over the 40; 35 of them under 1 m, the other five
+    1.03-1.16 m with the known-association twin at 0.7-1.1 m: 512 particles and that seed's noise, not the association).
+    Pinned here: seeds 7 and 9 in the fast build and 11 in the strict one -- three of round 5's runaways -- and round 5's good case;
+    the map must come out exact and the error must be that of the known-association twin.  The reference has no FastSLAM version of
+    this association (parity unpinned by nature); every single kernel decision is pinned to the reference's EKF gating
+    (tests/test_association.py)."""
     import re
-    nl = int(re.search(r"landmarks in map: (\d+)", r.stdout).group(1))
-    rows = np.loadtxt(log, delimiter=",", skiprows=1)
-    err = np.hypot(rows[:, 4] - rows[:, 1], rows[:, 5] - rows[:, 2])
-    assert np.isfinite(err).all()
-    if tight:
-        assert 35 <= nl <= 48, nl
-        assert err.mean() < 1.0, err.mean()
-    else:
-        assert 35 <= nl <= 70, nl           # (never beyond the capacity the binary gives an unknown association: 2 x the map)
-        assert err.mean() < 10.0, err.mean()  # (the filter stays on the map)
+
+    def run(extra, name):
+        log = str(tmp_path / name)
+        r = subprocess.run([EXE, "-m", os.path.join(DATA, "example_webmap.mat"), "-method", "FASTSLAM2", "-NPARTICLES", "512", "-NEFFECTIVE", "384",
+                            "-SWITCH_SEED_RANDOM", str(seed), "-math", math, "-log", log] + extra, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+        rows = np.loadtxt(log, delimiter=",", skiprows=1)
+        err = np.hypot(rows[:, 4] - rows[:, 1], rows[:, 5] - rows[:, 2])
+        assert np.isfinite(err).all()
+        return r.stdout, err
+    out, err = run(["-assoc", "gated"], "gated.csv")
+    m = re.search(r"landmarks in map: (\d+) \((\d+) opened, (\d+) retired", out)
+    nl, opened, retired = int(m.group(1)), int(m.group(2)), int(m.group(3))
+    assert (nl, opened, retired) == (35, 35, 0), out[-400:]          # the map, no duplicate ever opened, nothing to retire
+    _, err_known = run(["-loop", "step"], "known.csv")              # dataAssociationKnown (core.cpp:91-120), same seed, same particles
+    # (the twin differs by which observations the gates let through early on: individual runs land on either side of it -- over the 40
+    # probed runs the gated mean is the smaller one)
+    assert err.mean() < 1.0 and err.mean() <= 2.0 * err_known.mean() + 0.25, (err.mean(), err_known.mean())
+    assert err.max() < 2.5, err.max()
+
+
+def test_retired_landmarks_take_no_part_in_the_association():
+    """slamgpu_retire_landmarks (round 6): a retired landmark is never a label again -- in the exhaustive scan and through the grid
+    -- and the decisions about every other landmark are what they were."""
+    import slam_amd as sg
+    from slam_amd import host
+    from conftest import sim_args
+    tape = host.make_tape(sim_args("example_webmap", "FASTSLAM2", 1024, 7), max_obs=120)
+    s = sg.SlamGpu(1024, tape["nlm"], method=2, n_effective=768, rng_mode=sg.RNG_PHILOX, seed=3, math_mode=1)
+    for st in tape["steps"]:
+        s.step(np.array(st["controls"], np.float32).reshape(-1, 3), tape["Q"], float(tape["dt"]), st["zf"], st["idf"], st["zn"], tape["R"])
+    st = tape["steps"][-1]
+    z = np.concatenate([st["zf"], st["zn"]]).reshape(-1, 2)
+    assert len(st["idf"]) >= 3
+    g1, g2 = float(tape["conf"].GATE_REJECT), float(tape["conf"].GATE_AUGMENT)
+    for mode in (sg.capi.ASSOC_EXHAUSTIVE, sg.capi.ASSOC_GRID):
+        lab0, cons0, _ = s.associate(z, tape["R"], g1, g2, mode=mode)[:3]
+        found = [int(j) for j in st["idf"] if int(j) in set(int(c) for c in cons0)]
+        assert len(found) >= 2   # (re-observed landmarks are found again)
+    victim = found[0]
+    s.retire_landmarks([victim])
+    for mode in (sg.capi.ASSOC_EXHAUSTIVE, sg.capi.ASSOC_GRID):
+        lab, cons, _ = s.associate(z, tape["R"], g1, g2, mode=mode)[:3]
+        assert victim not in set(int(c) for c in cons) and not (np.asarray(lab) == victim).any()
+        # the labels of every OTHER observation are untouched (the victim's own observation changes for everybody: particles it was
+        # the nearest neighbour of, and particles for which it was the reason to discard rather than open -- `outer`, ekfslam.cpp:176)
+        cols = np.asarray(cons0) != victim
+        assert cols.sum() >= 2 and np.array_equal(np.asarray(lab)[:, cols], np.asarray(lab0)[:, cols])
+    with pytest.raises(sg.SlamGpuError):
+        s.retire_landmarks([s.nf()])
+    s.close()
 
 
 def test_slam_backend_gpus_k_is_independent_of_k(tmp_path):

@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: SQ counters of the update kernel (dynamic instruction mix / stall split), own PMC passes.
-# usage: tools/profile_sq.sh <tag> [bench args...]
+# usage: [KERNEL_FILTER=associate] tools/profile_sq.sh <tag> [bench args...]      (KERNEL_FILTER: substring of the kernel names to report; default update_kernel)
 set -o pipefail
 TAG=${1:-r02}; shift
 ARGS=${@:---no-cpu-baseline}
@@ -25,7 +25,7 @@ for d in ("pmc_sq", "pmc_sq2"):
             dsp = int(r["Dispatch_Id"])
             per[k][r["Counter_Name"]][dsp] = per[k][r["Counter_Name"]].get(dsp, 0.0) + float(r["Counter_Value"])
         for k, cs in per.items():
-            if "update_kernel" not in k:
+            if "${KERNEL_FILTER:-update_kernel}" not in k:
                 continue
             parts = []
             for c, dv in sorted(cs.items()):
