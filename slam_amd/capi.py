@@ -103,10 +103,12 @@ def load_library():
     L.slamgpu_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.slamgpu_ancestors.argtypes = [C.c_void_p, C.c_void_p]
     L.slamgpu_num_landmarks.argtypes = [C.c_void_p]
-    L.slamgpu_retire_landmarks.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    if hasattr(L, "slamgpu_retire_landmarks"):
+        L.slamgpu_retire_landmarks.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     L.slamgpu_genealogy_rows.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.slamgpu_persist_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
-    L.slamgpu_persist_status.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    if hasattr(L, "slamgpu_persist_status"):  # (an older build loaded through SLAMGPU_LIB for an A/B lacks the round-6 entries)
+        L.slamgpu_persist_status.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.slamgpu_download.argtypes = [C.c_void_p] * 6
     L.slamgpu_download_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 5
     L.slamgpu_peek.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 5

@@ -61,7 +61,13 @@ inline bool update_wide_off() {  // (diagnostic: SLAMGPU_NO_WIDE=1 keeps update_
     static const bool off = getenv("SLAMGPU_NO_WIDE") != nullptr;
     return off;
 }
-inline bool update_is_wide(int arrivals, bool big, int nblocks) { return arrivals == 0 && !big && nblocks > kWideBlocks && !update_wide_off(); }
+// (round 6: FastSLAM 1 only.  Without the SLP vectoriser update_kernel<2, 0, false> needs 154 registers and holds three waves per
+// SIMD by itself; the wide kernel, squeezed under __launch_bounds__(256, 3), then LOSES to it: 10^6 particles 88.0 against 84.3 us per
+// step, same box -- and 84.4 for round 5's build, where the SLP vectoriser had update_kernel at 171 registers and the wide kernel won
+// 84.8 against 97.0.  tests/test_host_frontend.py holds update_kernel<2, 0, false> to 168 registers, the most that leaves three waves.)
+inline bool update_is_wide(int method, int arrivals, bool big, int nblocks) {
+    return method == 1 && arrivals == 0 && !big && nblocks > kWideBlocks && !update_wide_off();
+}
 // status bits of an update's resampling stage (slamgpu.h: SLAMGPU_STATUS_*)
 constexpr int kStatusBadPacket = 2;   // the kernel did not find its packet where the kernel-argument layout says (never seen)
 constexpr int kStatusCapacity = 4;    // device front end: more new landmarks than the context has room for (the surplus was dropped)

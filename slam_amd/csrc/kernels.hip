@@ -3164,13 +3164,9 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
 #define SLAM_LAUNCH_UPDATE(M, A, G)                                                                                              \
     hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid, \
                        h_flags, B, PA, U, rng, ws)
-    if (update_is_wide(U.arrivals, U.big != nullptr, ws.nblocks)) {  // (single context, compact layout, more tiles than two rounds of CUs)
-        if (sel == 6)
-            hipLaunchKernelGGL((update_kernel_wide<2>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid,
-                               h_flags, B, PA, U, rng, ws);
-        else
-            hipLaunchKernelGGL((update_kernel_wide<1>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid,
-                               h_flags, B, PA, U, rng, ws);
+    if (update_is_wide(U.method, U.arrivals, U.big != nullptr, ws.nblocks)) {  // (FastSLAM 1, single context, compact layout, more tiles than two rounds of CUs)
+        hipLaunchKernelGGL((update_kernel_wide<1>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid,
+                           h_flags, B, PA, U, rng, ws);
         return;
     }
     switch (sel) {

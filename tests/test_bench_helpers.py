@@ -21,8 +21,9 @@ def test_window_does_not_depend_on_steps_and_warmup():
 
 
 def test_default_window_looks_like_the_run():
-    # (round 5) the default window is the first one after step 1 000 whose mean m / n / resample rate are the run's to 10 %:
-    # steps 1005..1025 re-observe 1.65 landmarks per step, the run 3.53
+    # (round 5) the default window is the first one after step 1 000 whose mean m / n / resample rate are the run's:
+    # steps 1005..1025 re-observe 1.65 landmarks per step, the run 3.53; (round 6) to 2 % in m and to the nearest achievable count of
+    # resampling steps: at 10^6 particles a step costs 23 + 10.9 m + 46 r microseconds, 10 % of m and r were 7 % of the step
     import numpy as np
     from slam_amd import host
     N = 1000
@@ -33,7 +34,7 @@ def test_default_window_looks_like_the_run():
     for warmup, steps in ((5, 20), (20, 200), (100, 2000)):
         s, info = bench.pick_window(obs, warmup, steps, None)
         m = np.mean([st["zf"].shape[0] for st in obs[s + warmup:s + warmup + steps]])
-        assert abs(m / mbar - 1) <= 0.1 and abs(info["mean_m"] - m) < 1e-12, (warmup, steps, s, m)
+        assert abs(m / mbar - 1) <= 0.02 and abs(info["mean_m"] - m) < 1e-12, (warmup, steps, s, m)
         assert s == bench.pick_window(obs, warmup, steps, None)[0]  # deterministic
         json.dumps(info)
     assert bench.pick_window(obs, 5, 20, None)[0] >= 1000
@@ -41,7 +42,9 @@ def test_default_window_looks_like_the_run():
     res = np.arange(len(obs) - 100) % 5 < 3   # rate 0.6 ...
     res[1000 - 100:1100 - 100] = False          # ... but for steps 1000..1100
     s_r, info_r = bench.pick_window(obs, 5, 20, None, res, 100)
-    assert s_r + 5 >= 1090 and abs(info_r["resample_rate"] / info_r["run_resample_rate"] - 1) <= 0.1
+    lo_r = s_r + 5
+    assert not (1000 - 20 < lo_r < 1100) and info_r["resample_rate"] == 0.6 and int(res[lo_r - 100:lo_r - 100 + 20].sum()) == 12, (s_r, info_r)
+    assert abs(info_r["mean_m"] / mbar - 1) <= 0.02
     assert bench.pick_window(obs, 5, 20, 1000)[0] == 1000 and bench.pick_window(obs, 5, 20, 1000)[1]["mean_m"] < 2.0
 
 
