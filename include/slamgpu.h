@@ -120,7 +120,7 @@ enum {
      * kernel).  Contexts of up to 39 landmarks make the observation inside the update launch and accept slamgpu_step_observe
      * with or without the flag. */
     SLAMGPU_FLAG_DEVICE_OBSERVE = 1,
-    /* (round 5) A strict-build context of at most 8 192 particles that takes the caller's draws (SLAMGPU_RNG_TAPE: the parity
+    /* (round 5) A strict-build context of at most 5 000 particles (the largest set the reference itself can resample: its strata count is exact for N = 50, 100, 500, 1 000, 5 000 only, core.cpp:751-763) that takes the caller's draws (SLAMGPU_RNG_TAPE: the parity
      * configuration) runs its resampling stage in the REFERENCE'S OWN ORDER OF OPERATIONS -- float32 w / sum(w) with Eigen's
      * packet-order sum, Neff the same way, the serial float32 running prefix, `select < cum` (core.cpp:718-824) -- so that Neff,
      * the decision and every ancestor are the reference's bit for bit (two extra small launches per step).  This flag turns that
@@ -443,9 +443,12 @@ int slamgpu_algorithmic_bytes(slamgpu_ctx *ctx, double *update_bytes, double *pr
  * included.  What is here and why:
  *   - slamgpu_shard_*           round 1's exchange path (pack / all-to-all / unpack of migrating offspring, the caller's
  *                               collectives).  Superseded by the distributed contexts above (nothing migrates); kept as the
- *                               fallback of bench.py --mgpu exchange when peer mappings cannot be set up.
- *   - push / fold collectives   hand-made alternatives to the RCCL all-gather of slamgpu_dist_step; have only ever run
- *                               between contexts of ONE physical GPU.  Default everywhere: SLAMGPU_DIST_GATHER.
+ *                               fallback of bench.py --mgpu exchange when peer mappings cannot be set up.  EXPERIMENTAL: has
+ *                               never run across physical GPUs (logical shards on one GPU and gloo ranks on the CPU only).
+ *   - push / fold collectives   hand-made alternatives to the RCCL all-gather of slamgpu_dist_step.  EXPERIMENTAL: have never
+ *                               run across physical GPUs (between contexts of ONE GPU only).  Default everywhere:
+ *                               SLAMGPU_DIST_GATHER.  Which of the three generations stays is a question for the first
+ *                               measured multi-GPU run (no 8-GPU node has been available to this build in six rounds).
  *   - slamgpu_dev_*             raw device buffers for the callers of the exchange path
  *   - slamgpu_debug_stamps      instrumented build only
  * ================================================================================================================= */

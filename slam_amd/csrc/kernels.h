@@ -391,7 +391,8 @@ struct ResampleArgs {
 // sum, Neff = 1 / sum(w^2) the same way, the serial float32 running prefix, `select[ctr] < cum[i]` -- so that Neff, the decision
 // and every ancestor are the reference's bit for bit (a double-precision block scan puts a stratum within a few float32 ulps of a
 // boundary on the other side: 8 of 5 000 ancestors at N = 5 000, rounds 3-4).
-constexpr int kRefResampleMax = 8192;
+constexpr int kRefResampleMax = 5000;  // (the largest N the reference can resample -- stratifiedRandom yields N strata for 50, 100, 500, 1 000, 5 000 only,
+                                       // core.cpp:751-763 -- and the largest the KAT vectors hold: no untested range; 40 KB of dynamic LDS)
 
 // ---- sharded resampling (see kernels.hip) ---------------------------------------------------------------
 constexpr int kMaxShards = 64;

@@ -1810,7 +1810,7 @@ __global__ void __launch_bounds__(kBlock) resample_ref_kernel(Buffers B, WeightS
         }
     }
     __syncthreads();
-    if (t == 0) {  // (n <= 8 192: ~n compare-and-stores; a parallel scan would save ~10 us of the stage's ~40)
+    if (t == 0) {  // (n <= 5 000: ~n compare-and-stores; a parallel scan would save ~10 us of the stage's ~40)
         float m = sel[0];
         for (int i = 1; i < n; i++) {
             m = fmaxf(m, sel[i]);

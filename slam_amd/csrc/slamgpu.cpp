@@ -172,7 +172,7 @@ struct slamgpu_ctx {
     bool scan_ready = false;      // scan_kernel ran on the last update's block totals (large contexts)
     bool mid_compact = false;     // compact layout on a map of more than 39 landmarks (kernels.h: kMidLandmarks): host-made packets only
     bool ref_resample = false;    // the resampling stage replays the reference's order of operations (kernels.h: kRefResampleMax):
-                                  // strict build, the caller's draws (TAPE), a single context of at most 8 192 particles, linear weights
+                                  // strict build, the caller's draws (TAPE), a single context of at most 5 000 particles, linear weights
     bool consolidate = true;      // row consolidation of compact contexts (do_update); SLAMGPU_NO_CONSOLIDATE=1 turns it off
     int consolidate_above = kConsolidateAbove;  // (SLAMGPU_CONSOLIDATE_ABOVE: diagnostic)
     int plain_rows_target = kPlainRowsTarget;   // (SLAMGPU_PLAIN_ROWS_TARGET: diagnostic / tests)
@@ -642,8 +642,11 @@ int flush_stages(slamgpu_ctx *c) {
         c->ws.wpar = c->unplanned.par;
         if (c->ref_resample) {
             // the plan in the reference's own order of operations (one block), then the usual stage for what is left of it
-            Timed t(c, "resample_ref");
-            c->k->resample_ref(c->stream, c->B, c->ws, rng_args(c, c->unplanned.step), ra);
+            {
+                Timed t(c, "resample_ref");
+                c->k->resample_ref(c->stream, c->B, c->ws, rng_args(c, c->unplanned.step), ra);
+            }
+            HIP_TRY(hipGetLastError());  // (a refused launch must not leave `resample` a stale plan: ADVICE r5)
             ra.planned = 1;
         }
         {
@@ -777,6 +780,11 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
     c->ref_resample = cfg->math_mode != SLAMGPU_MATH_FAST && cfg->rng_mode == SLAMGPU_RNG_TAPE && n <= kRefResampleMax && !cfg->log_weights &&
                       c->cfg.n_particles_global == c->cfg.n_particles && !(cfg->flags & SLAMGPU_FLAG_NO_REFERENCE_RESAMPLE) &&
                       getenv("SLAMGPU_NO_REF_RESAMPLE") == nullptr;
+    if (c->ref_resample) {  // (its one block keeps 2 n floats in dynamic LDS: ask the device rather than assume gfx950's 160 KB)
+        int lds_max = 0;
+        if (hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device) != hipSuccess || (size_t) lds_max < sizeof(float) * 2 * (size_t) n + 4096)
+            c->ref_resample = false;
+    }
     c->persist_ok = getenv("SLAMGPU_NO_PERSIST") == nullptr;                               // diagnostic / tests: slamgpu_run_observe as a loop of launches
     if (const char *e = getenv("SLAMGPU_CONSOLIDATE_ABOVE")) c->consolidate_above = atoi(e);
     if (const char *e = getenv("SLAMGPU_PLAIN_ROWS_TARGET")) c->plain_rows_target = atoi(e);
@@ -1180,13 +1188,17 @@ int demote_to_plain(slamgpu_ctx *c) {
     const size_t S = (size_t) c->B.ncap, words = S * (size_t) kSmallRows;
     int32_t *tmp = nullptr;
     HIP_TRY(hipMalloc((void **) &tmp, sizeof(int32_t) * words));
-    for (int b = 0; b < 2; b++) {
-        HIP_TRY(hipMemcpyAsync(tmp, c->B.gen[b], sizeof(int32_t) * words, hipMemcpyDeviceToDevice, c->stream));
+    hipError_t er = hipSuccess;  // (no early return between the allocation and its release: ADVICE r5)
+    for (int b = 0; b < 2 && er == hipSuccess; b++) {
+        er = hipMemcpyAsync(tmp, c->B.gen[b], sizeof(int32_t) * words, hipMemcpyDeviceToDevice, c->stream);
+        if (er != hipSuccess) break;
         c->k->decompact(c->stream, tmp, c->B.gen[b], c->B.ncap, kSmallRows);
-        HIP_TRY(hipGetLastError());
+        er = hipGetLastError();
     }
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    const hipError_t er2 = hipStreamSynchronize(c->stream);
     (void) hipFree(tmp);
+    HIP_TRY(er);
+    HIP_TRY(er2);
     const int old_rows = c->B.cap_rows, new_rows = c->B.cap_nf + 1;
     c->B.compact = 0;
     c->B.cap_rows = new_rows;

@@ -218,8 +218,15 @@ def forced_run(sg, oracle, method, N, seed, nobs, math_mode, philox, window=None
                     eg, er = np.abs(lg / w64 - 1.0), np.abs(le / w64 - 1.0)
                     st.setdefault("y64", []).append((int(ob["zf"].shape[0]), float(np.median(eg)), float(np.median(er)), float(np.quantile(eg, 0.99)),
                                                      float(np.quantile(er, 0.99))))
-                    ensure(np.median(eg) <= yardstick64 * np.median(er) + 1e-3 and np.quantile(eg, 0.99) <= yardstick64 * np.quantile(er, 0.99) + 1e-2,
-                           (tag, "anchored weights vs float64", np.median(eg), np.median(er), np.quantile(eg, 0.99), np.quantile(er, 0.99)))
+                    # yardstick64 = f, or (f, f_outlier, how many): every anchored step within f x the oracle's own error, but for
+                    # `how many` steps that may reach f_outlier (a known outlier is recorded as one, the bound for
+                    # everything else stays where it was)
+                    f, f_out, n_out = yardstick64 if isinstance(yardstick64, tuple) else (yardstick64, yardstick64, 0)
+                    inside = lambda ff: np.median(eg) <= ff * np.median(er) + 1e-3 and np.quantile(eg, 0.99) <= ff * np.quantile(er, 0.99) + 1e-2
+                    if not inside(f) and inside(f_out):
+                        st.setdefault("y64_outliers", []).append((k, int(ob["zf"].shape[0]), float(np.median(eg) / max(np.median(er), 1e-12))))
+                    ensure(inside(f_out) and len(st.get("y64_outliers", [])) <= n_out,
+                           (tag, "anchored weights vs float64", np.median(eg), np.median(er), np.quantile(eg, 0.99), np.quantile(er, 0.99), st.get("y64_outliers")))
                 else:
                     ensure(np.median(rel) <= t2["median"] and np.quantile(rel, 0.99) <= t2["p99"] and rel.max() <= t2["max"],
                            (tag, "anchored weights", np.median(rel), np.quantile(rel, 0.99), rel.max()))
@@ -576,16 +583,19 @@ def test_config5_map_whole_run_ancestor_forced_log_weights(sg_mod, oracle, synma
     # |w / w64 - 1| of the float32 ORACLE 1.2e-2 .. 0.17, of the strict build the same to 2 digits (ratio 0.9 .. 1.14), of the
     # fast build 0.5 .. 2.9 times the oracle's (round 4, -ffp-contract=fast); round 5 (-ffp-contract=on: products fused with sums
     # only where the source says so, so that two kernels that must agree bit for bit do): up to 4.8 times at one of the 25 steps
-    # (step 1729, 938 landmarks: GPU 0.167, oracle 0.035).  Bounds: 1.5x / 6x the oracle's own error.
+    # (step 1729, 938 landmarks: GPU 0.167, oracle 0.035).  Bounds: 1.5x / 4x the oracle's own error -- round 4's -- with ONE anchored
+    # step of the fast build allowed up to 6x (that step; ADVICE r5: the outlier is recorded as one, the bound for the other 24
+    # stays where it was).
     anchor_at = lambda k: k % 32 == 1 and k > 1
     st, inputs, QRdt, hist, final, final_exp = forced_run(sg_mod, oracle, "FASTSLAM2", N, seed, 100000, math_mode, True, threads=threads, args=args,
                                                           log_weights=True, full_at=full_at, on_step=on_step, weights_comparable=False,
                                                           anchor_at=anchor_at, pose_atol=(1.5e-3, 4e-3)[math_mode], lmk_atol=(2e-3, 7.5e-3)[math_mode],
-                                                          yardstick64=(1.5, 6.0)[math_mode],
+                                                          yardstick64=(1.5, (4.0, 6.0, 1))[math_mode],
                                                           # (one update over ~1 k landmarks from identical pre-states; measured 6.1e-5 / 3.7e-4 m)
                                                           anchor_pose_atol=(2e-4, 8e-4)[math_mode],
                                                           est_atol=(1e-3, 3e-3)[math_mode])   # (measured 1.9e-4 / 1.5e-3 m)
     print("anchored steps vs float64 (m, median GPU, median oracle, p99 GPU, p99 oracle):", st.pop("y64", None))
+    print("anchored steps beyond the bound, within the outlier's (step, m, median ratio):", st.get("y64_outliers"))
     print("free-running FASTSLAM2 philox 10k-landmark map N=256 log-weights %s: %s; rows in use: max %d, final %d, target first reached at step %s"
           % (["strict", "fast"][math_mode], st, max(rows), rows[-1], crossed[:1]))
     assert st["steps"] == 2172 and st["resamples"] > 1000, st

@@ -10,7 +10,7 @@ exists:
   inline  the plan at the head of the NEXT update launch (the product's one-launch-per-step pipeline); the ancestors are then
           read off the particles themselves (every particle carries its index in its pose).
 
-Round 5: the STRICT build with the caller's draws (TAPE) and at most 8 192 particles replays the reference's own order of operations
+Round 5: the STRICT build with the caller's draws (TAPE) and at most 5 000 particles replays the reference's own order of operations
 (resample_ref_kernel: float32 w / sum(w) with Eigen's packet-order sum, Neff the same way, the serial float32 running prefix,
 `select[ctr] < cum[i]`): every ancestor, Neff and the normalised weights are the reference's BIT FOR BIT, for all five N, both
 ways the stage is reached.  What follows describes the general path, which the fast build (and every Philox / large / sharded

@@ -76,7 +76,7 @@ def test_logical_shards_tape_draws_and_the_parity_context(tape):
     """The caller's draws (TAPE) through the sharded path, and the ONE rule about shard counts: every run
     through the shard / distributed entry points scans the block totals in double, whatever the number of shards -- G = 1
     included -- so its results do not depend on G; a SINGLE context in the parity configuration (strict build, the caller's
-    draws, at most 8 192 particles, driven through slamgpu_update) replays the reference's float32 order of operations in its
+    draws, at most 5 000 particles, driven through slamgpu_update) replays the reference's float32 order of operations in its
     resampling stage instead (core.cpp:718-824: that is what makes its ancestors the reference's bits), and
     SLAMGPU_FLAG_NO_REFERENCE_RESAMPLE gives it the shards' arithmetic.  All three statements are checked here."""
     import slam_amd as sg
