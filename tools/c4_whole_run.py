@@ -32,7 +32,7 @@ def sclk():
 
 def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 1001472
-    chunk = 100
+    chunk = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     tape = host.make_tape(["-m", os.path.join(ROOT, "data", "example_webmap.mat"), "-method", "FASTSLAM2", "-NPARTICLES", N, "-NEFFECTIVE", int(0.75 * N),
                            "-SWITCH_SEED_RANDOM", 7])
     obs = tape["steps"]
@@ -75,7 +75,7 @@ def main():
         print("%4d-%4d %8.2f %8.2f %8.2f %6.2f %6.0f %4d %6.2f %5d %s" % (c0, min(len(obs), c0 + chunk), r["wall_us"], r.get("fs2_update", 0.0), r.get("scan", 0.0), r["m"], r["n"],
                                                                       r["nf"], r["res"], r["rows"], r["sclk"]))
     w = np.array([rows[c]["wall_us"] for c in sorted(rows)])
-    print("whole run: mean of the chunks %.2f us per step; chunks 1000-1100: %.2f; min chunk %.2f, max chunk %.2f" % (w.mean(), rows[1000]["wall_us"], w.min(), w.max()))
+    print("whole run: mean of the chunks %.2f us per step; chunk at step 1000: %.2f; min chunk %.2f, max chunk %.2f" % (w.mean(), rows[1000 // chunk * chunk]["wall_us"], w.min(), w.max()))
     # what explains a chunk's time: least squares on m, resample rate and landmarks in the map
     A = np.array([[1.0, rows[c]["m"], rows[c]["res"], rows[c]["nf"]] for c in sorted(rows)])
     coef, *_ = np.linalg.lstsq(A, w, rcond=None)

@@ -23,5 +23,6 @@ mkdir -p gpurun_out/profiles_$S && cp profiles/*${S}_c* gpurun_out/profiles_$S/
 # (raw counter dumps are tens of MB per workload: only the condensed files go back)
 for t in c3 c3_strict c2 c5 c6 c4; do rm -rf gpurun_out/prof_${S}_$t/trace gpurun_out/prof_${S}_$t/pmc_fetch gpurun_out/prof_${S}_$t/pmc_write; done
 python bench.py --steps 20 --warmup 5 > gpurun_out/profiles_$S/bench_r06_driver_args.json 2>> gpurun_out/bench_final.err; tail -c 300 gpurun_out/bench_final.err
-python bench.py --config 4 --steps 20 --warmup 5 --no-also --no-cpu-baseline > gpurun_out/profiles_$S/bench_r06_c4.json 2>> gpurun_out/bench_final.err
+# (config 4 with its default window of 2 000 steps: a 20-step window at 10^6 particles ends before the part's sustained state)
+python bench.py --config 4 --no-also --no-cpu-baseline > gpurun_out/profiles_$S/bench_r06_c4.json 2>> gpurun_out/bench_final.err
 ls gpurun_out/profiles_$S
