@@ -146,3 +146,28 @@ def test_multi_gpu_path_every_collective(collective):
     check_common(j, 60, 5)
     assert j["config"]["collective"] == {"fold": "fold", "push": "push", "native": "rccl", "torch": "torch"}[collective]
     assert j["config"]["check_vs_single_context"]["max_abs_diff"] <= 1e-9
+
+
+def test_a_rank_stuck_in_the_distributed_set_up_is_named_with_its_stage():
+    """The breadcrumbs of the REAL multi-GPU path (round 6): one rank on this GPU, told to stay in `peer_mappings` -- the stage in
+    which DistFilter maps the peers' state arrays (hipIpcOpenMemHandle across processes: one of the places a first 8-GPU run can block
+    forever) -- is reported by its watchdog with that stage and its Python stack, the launcher exits 124 well inside the time-out, and
+    the GPU takes the next run as if nothing had happened."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SLAM_BENCH_CRUMBS")}
+    env.update(SLAM_BENCH_TEST_HANG="0:peer_mappings", SLAM_BENCH_STALL_S="10", SLAM_BENCH_TIMEOUT_S="120")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded", "--steps", "20", "--warmup", "5", "--no-also"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    wall = time.time() - t0
+    assert r.returncode == 124, (r.returncode, r.stdout[-500:], r.stderr[-1500:])
+    j = one_line(r.stdout)
+    assert j["value"] is None and j["failed_rank"] == 0 and j["last_stage"] == "peer_mappings" and j["n_gpus"] == 1, j
+    assert j["ranks"][0]["stages_entered"] >= 7 and "in mark" in " | ".join(j["ranks"][0]["where"]), j["ranks"]
+    assert wall < 120
+    # ... and the card is fine: the same command without the hook prints its line
+    env.pop("SLAM_BENCH_TEST_HANG")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-sharded", "--steps", "20", "--warmup", "5", "--no-also", "--no-check"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert one_line(r.stdout)["config"]["preflight"]["hipipc_ok"] is True
