@@ -524,11 +524,13 @@ struct VoteSlot {
     float w;       // sum of the weights of the particles that chose it
 };
 struct AssocGridArgs {
-    const LmkBox *box;            // [nf]
+    LmkBox *box;                  // [nf]; pad[0]: the radial bound of this call's gates (assoc_count_kernel writes it, associate_grid_kernel reads it)
     AssocGeom *geom;
     int32_t *cell_start;          // [nx * ny + 1] exclusive prefix of the cell populations
     int32_t *cell_fill;           // [nx * ny] cursors of the fill pass
-    int32_t *items;               // [cap_items] landmark ids, cell after cell
+    float4 *items;                // [2 cap_items] cell after cell, an entry = two float4: (xmin, xmax, ymin, ymax) of the landmark's box and
+                                  // (radial bound of this call's gates, landmark id as bits, 0, 0): what the walk needs of a landmark in ONE
+                                  // contiguous read (round 6: an id here and the box behind it were two dependent trips per entry)
     int32_t cap_items, nf, nz;
     const float *z;               // [2 nz] observations (range, bearing), device
     float r00, r11, G;            // R diagonal; G = max(gate_reject, gate_augment) with the safety margin

@@ -2675,14 +2675,21 @@ __global__ void __launch_bounds__(kBlock) assoc_geom_kernel(Buffers B, AssocGrid
 // A particle's estimate l of landmark j can pass a gate (nis < G) for an observation (r, b) only if it lies within rho of the
 // world point p the observation implies for that particle.  With d = |l - pose|, e = |d - r| and D the wrapped bearing residual:
 //   |l - p|^2 = (d - r)^2 + 2 d r (1 - cos D) <= e^2 + d r D^2,  so  |l - p| <= e + sqrt(d r) |D| <= e + d |D| + (e / 2) |D|
-//   (r <= d + e), and gate by gate (nis >= v_i^2 / S_ii for a positive definite S):
+//   (r <= d + e; sqrt(d r) <= d + e / 2), and gate by gate (nis >= v_i^2 / S_ii for a positive definite S):
 //   e = |v0| < sqrt(G S00) <= sqrt(G (t + R00)),   d |D| = d |v1| < d sqrt(G S11) <= sqrt(G (t + d^2 R11)),   |D| <= pi,
 // t = tr Pf (>= its largest eigenvalue; the rows of Hf have norms 1 and 1 / d).  Over all particles: t <= tmax_j and
 // d <= the largest distance between the pose box and the landmark's box.
+// (round 6) |D| <= pi is the bound of a landmark the poses stand ON; a landmark whose box is dmin away from the pose box passes the
+// bearing gate only with |D| < sqrt(G (t / dmin^2 + R11)) (S11 <= t / d^2 + R11, d >= dmin): a few hundredths of a radian beyond a
+// few metres, so the third term is e |D| / 2 with THAT |D|, not e pi / 2 -- the radius of a landmark 30 m away falls from 4.9 to
+// 3.7 m on BASELINE config 5's map and a cell holds half as many entries.
 SLAM_DEV float assoc_radius(const LmkBox &bx, const AssocGeom &g, float r00, float r11, float G) {
     const float dx = fmaxf(fabsf(bx.xmax - g.px0), fabsf(g.px1 - bx.xmin)), dy = fmaxf(fabsf(bx.ymax - g.py0), fabsf(g.py1 - bx.ymin));
     const float D2 = dx * dx + dy * dy;
-    const float rho = (1.0f + 0.5f * 3.14159274f) * sqrtf(G * (bx.tmax + r00)) + sqrtf(G * (bx.tmax + D2 * r11));
+    const float gx = fmaxf(fmaxf(bx.xmin - g.px1, g.px0 - bx.xmax), 0.0f), gy = fmaxf(fmaxf(bx.ymin - g.py1, g.py0 - bx.ymax), 0.0f);
+    const float dmin2 = gx * gx + gy * gy;
+    const float Dcap = dmin2 > 0.0f ? fminf(3.14159274f, sqrtf(G * (bx.tmax / dmin2 + r11)) * 1.01f) : 3.14159274f;
+    const float rho = (1.0f + 0.5f * Dcap) * sqrtf(G * (bx.tmax + r00)) + sqrtf(G * (bx.tmax + D2 * r11));
     return rho * 1.01f + 1e-3f;  // (rounding of the bound itself and of the kernels' own arithmetic)
 }
 
@@ -2704,6 +2711,8 @@ __global__ void __launch_bounds__(kBlock) assoc_count_kernel(AssocGridArgs A, in
     if (j >= A.nf) return;
     const AssocGeom g = *A.geom;
     const LmkBox bx = A.box[j];
+    // (the radial bound of this call's gates for landmark j rides in its entries, once per call instead of once per (particle,
+    // observation, entry): a gate needs |d - r| = |v0| < sqrt(G S00) <= sqrt(G (t + R00)): nis >= v0^2 / S00, the range row of Hf has norm 1)
     int cx0, cx1, cy0, cy1;
     if (!assoc_cells(bx, g, assoc_radius(bx, g, A.r00, A.r11, A.G), cx0, cx1, cy0, cy1)) return;
     for (int cy = cy0; cy <= cy1; cy++)
@@ -2713,7 +2722,10 @@ __global__ void __launch_bounds__(kBlock) assoc_count_kernel(AssocGridArgs A, in
                 atomicAdd(&A.cell_start[cell + 1], 1);
             } else {
                 const int at = A.cell_start[cell] + atomicAdd(&A.cell_fill[cell], 1);
-                if (at < A.cap_items) A.items[at] = j;
+                if (at < A.cap_items) {
+                    A.items[2 * (size_t) at] = make_float4(bx.xmin, bx.xmax, bx.ymin, bx.ymax);
+                    A.items[2 * (size_t) at + 1] = make_float4(1.01f * sqrtf(A.G * (bx.tmax + A.r00)) + 1e-3f, __int_as_float(j), 0.0f, 0.0f);
+                }
             }
         }
 }
@@ -2792,7 +2804,6 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
     // thread walking all of them alone (1 300 on the 10 000-landmark map, ~65 dependent record reads each) left the
     // machine two thirds empty and every read exposed: 225 ms per call at 10^5 particles
     const int q_lo = blockIdx.y * kAssocObsPerBlock, q_hi = min(A.nz, q_lo + kAssocObsPerBlock);
-    const float e_gate = (1.0f + 0.5f * 3.14159274f) * 1.01f;
     for (int q = q_lo; q < q_hi; q++) {
         int label = kVoteEmpty;
         if (on) {
@@ -2809,25 +2820,23 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
             const int cell = cy * g.nx + cx;
             float nbest = INFINITY, outer = INFINITY;
             int jbest = -1;
-            for (int at = A.cell_start[cell]; at < A.cell_start[cell + 1]; at++) {
-                const int j = A.items[at];
-                {
-                    // radial pre-test on the landmark's box alone (32 bytes, shared by the wave, before the particle's own
-                    // record is fetched): every estimate of j lies in the box, so its distance d from this pose is within
-                    // [dmin, dmax] of the box; a gate needs |d - r| < sqrt(G (t + R00)) (assoc_radius)
-                    const LmkBox bx = A.box[j];
-                    const float ex = fmaxf(fmaxf(bx.xmin - pa.x, pa.x - bx.xmax), 0.0f), ey = fmaxf(fmaxf(bx.ymin - pa.y, pa.y - bx.ymax), 0.0f);
-                    const float fx = fmaxf(fabsf(bx.xmin - pa.x), fabsf(bx.xmax - pa.x)), fy = fmaxf(fabsf(bx.ymin - pa.y), fabsf(bx.ymax - pa.y));
-                    const float dmin = sqrtf(ex * ex + ey * ey), dmax = sqrtf(fx * fx + fy * fy);
-                    const float e = e_gate * sqrtf(A.G * (bx.tmax + A.r00)) + 1e-3f;
-                    if (zr + e < dmin * 0.999f || zr - e > dmax * 1.001f) continue;
-                }
+            // one entry of the cell: the radial pre-test on the landmark's box alone (every estimate of j lies in the box, so its
+            // distance d from this pose is within [dmin, dmax] of the box; a gate needs |d - r| < the entry's bound), on SQUARED
+            // distances (round 6: no square root per entry, and the bound without the factor (1 + pi / 2) the CELL radius needs and
+            // this test never did -- |d - r| is |v0| exactly: 2.6 times fewer entries reach the gates), then the gates
+            auto visit = [&](const float4 bb, const float4 bt) {
+                const float ex = fmaxf(fmaxf(bb.x - pa.x, pa.x - bb.y), 0.0f), ey = fmaxf(fmaxf(bb.z - pa.y, pa.y - bb.w), 0.0f);
+                const float fx = fmaxf(fabsf(bb.x - pa.x), fabsf(bb.y - pa.x)), fy = fmaxf(fabsf(bb.z - pa.y), fabsf(bb.w - pa.y));
+                const float dmin2 = ex * ex + ey * ey, dmax2 = fx * fx + fy * fy;
+                const float hi = zr + bt.x, lo = zr - bt.x;
+                if ((hi < 0.0f || hi * hi < dmin2 * 0.998f) || (lo > 0.0f && lo * lo > dmax2 * 1.002f)) return;
+                const int j = __float_as_int(bt.y);
                 float4 la;
                 float lb;
                 read_through_genealogy(B, B.lmk_live, cur, S, j, i, la, lb);
-                const AssocLm A = assoc_landmark(pa, la, lb, r00, r01, r10, r11);
+                const AssocLm L = assoc_landmark(pa, la, lb, r00, r01, r10, r11);
                 float nis, nd;
-                assoc_gate(A, zr, zb, nis, nd);
+                assoc_gate(L, zr, zb, nis, nd);
                 pairs++;
                 // (the cell's landmarks come in no particular order: ties go to the lower index, as in the ascending scan)
                 if (nis < gate1 && (nd < nbest || (nd == nbest && j < jbest))) {
@@ -2836,6 +2845,17 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
                 } else if (nis < outer) {
                     outer = nis;
                 }
+            };
+            // the walk: entries are self-contained (box + bound + id: ONE contiguous 32-byte read each, where an id and the box behind
+            // it were two dependent trips), two in flight at a time; SQ counters before: 87 % of the wave cycles waiting, the SIMDs
+            // a third busy (profiles/gated_association_r06.txt)
+            const int c0 = A.cell_start[cell], c1 = A.cell_start[cell + 1];
+            for (int at = c0; at < c1; at += 2) {
+                const float4 b0 = A.items[2 * (size_t) at], t0 = A.items[2 * (size_t) at + 1];
+                const int a1 = min(at + 1, c1 - 1);
+                const float4 b1 = A.items[2 * (size_t) a1], t1 = A.items[2 * (size_t) a1 + 1];
+                visit(b0, t0);
+                if (at + 1 < c1) visit(b1, t1);
             }
             label = jbest > -1 ? jbest : (outer > gate2 ? kAssocNew : kAssocDiscard);
             if (labels) labels[(size_t) i * A.nz + q] = label;

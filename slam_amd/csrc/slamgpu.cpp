@@ -236,7 +236,8 @@ struct slamgpu_ctx {
     std::vector<char> retired;
     uint32_t *retired_dev = nullptr;
     int n_retired = 0;
-    int32_t *assoc_ids_dev = nullptr, *cell_start_dev = nullptr, *cell_fill_dev = nullptr, *items_dev = nullptr;
+    int32_t *assoc_ids_dev = nullptr, *cell_start_dev = nullptr, *cell_fill_dev = nullptr;
+    float4 *items_dev = nullptr;  // [2 cap_items]: kernels.h: AssocGridArgs::items
     AssocGeom *geom_dev = nullptr;
     int32_t cap_items = 0;
     char *peek_dev = nullptr;        // staging of slamgpu_peek, grown on demand
@@ -2844,7 +2845,7 @@ int slamgpu_associate_ex(slamgpu_ctx *c, const float *z, int32_t nz, const float
             step(hipMalloc((void **) &c->assoc_ids_dev, sizeof(int32_t) * (size_t) cap_nf), "hipMalloc");
             step(hipMalloc((void **) &c->cell_start_dev, sizeof(int32_t) * (kAssocMaxCells * kAssocMaxCells + 1)), "hipMalloc");
             step(hipMalloc((void **) &c->cell_fill_dev, sizeof(int32_t) * (kAssocMaxCells * kAssocMaxCells)), "hipMalloc");
-            step(hipMalloc((void **) &c->items_dev, sizeof(int32_t) * (size_t) c->cap_items), "hipMalloc");
+            step(hipMalloc((void **) &c->items_dev, sizeof(float4) * 2 * (size_t) c->cap_items), "hipMalloc");
             step(hipMalloc((void **) &c->geom_dev, sizeof(AssocGeom)), "hipMalloc");
         }
         std::vector<int32_t> ids;
