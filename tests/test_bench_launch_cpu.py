@@ -28,7 +28,15 @@ def test_launcher_reports_a_failing_rank():
     assert rc == 3
 
 
+_WARM = []
+
+
 def _run(cmd, extra_env, timeout=240):
+    if not _WARM:
+        # the bounds below are seconds: they must outlast the stages BEFORE the one under test, and the first `import torch` of a
+        # fresh container takes a minute or two: page it in first
+        subprocess.run([sys.executable, "-c", "import torch, torch.distributed"], cwd=ROOT, capture_output=True, timeout=900)
+        _WARM.append(1)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SLAM_BENCH_CRUMBS")}
     env.update(extra_env)
     import time
@@ -44,7 +52,7 @@ def test_a_rank_that_never_leaves_a_stage_is_named_and_the_launcher_exits_124():
     watchdog -- a child process that touches neither torch nor the GPU -- prints ONE JSON line naming the rank and the last stage it
     reached, every rank is killed, and `python bench.py --gpus 2` exits with 124 well inside the time-out."""
     r, lines, wall = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-plumbing"],
-                          {"SLAM_BENCH_TEST_HANG": "1:first_collective", "SLAM_BENCH_STALL_S": "8", "SLAM_BENCH_TIMEOUT_S": "60"})
+                          {"SLAM_BENCH_TEST_HANG": "1:first_collective", "SLAM_BENCH_STALL_S": "12", "SLAM_BENCH_TIMEOUT_S": "90"})
     assert r.returncode == 124, (r.returncode, r.stdout, r.stderr[-1500:])
     assert len(lines) == 1, r.stdout
     j = lines[0]
@@ -56,18 +64,18 @@ def test_a_rank_that_never_leaves_a_stage_is_named_and_the_launcher_exits_124():
     assert sorted(j["suspects"]) == [0, 1] and j["failed_rank"] in (0, 1)
     w = {x["rank"]: " | ".join(x["where"] or []) for x in j["ranks"]}
     assert "in mark" in w[1] and "all_reduce" in w[0], w
-    assert 8 <= j["seconds_in_stage"] < 30 and wall < 60, (j, wall)
+    assert 12 <= j["seconds_in_stage"] < 40 and wall < 90, (j, wall)
 
 
 def test_the_whole_run_is_bounded_too():
     """... and a run whose ranks keep moving from stage to stage but never finish is stopped at SLAM_BENCH_TIMEOUT_S (here a rank
     that hangs at `rendezvous` with the stall bound out of reach)."""
     r, lines, wall = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-plumbing"],
-                          {"SLAM_BENCH_TEST_HANG": "0:rendezvous", "SLAM_BENCH_STALL_S": "1000", "SLAM_BENCH_TIMEOUT_S": "10"})
+                          {"SLAM_BENCH_TEST_HANG": "0:rendezvous", "SLAM_BENCH_STALL_S": "1000", "SLAM_BENCH_TIMEOUT_S": "20"})
     assert r.returncode == 124 and len(lines) == 1, (r.returncode, r.stdout, r.stderr[-1500:])
-    assert "took longer than 10 s" in lines[0]["error"] and lines[0]["last_stage"] == "rendezvous" and 0 in lines[0]["suspects"]
+    assert "took longer than 20 s" in lines[0]["error"] and lines[0]["last_stage"] == "rendezvous" and 0 in lines[0]["suspects"]
     assert "in mark" in " | ".join(lines[0]["ranks"][0]["where"] or [])
-    assert wall < 45
+    assert wall < 70
 
 
 def test_under_torch_distributed_run_a_hanging_rank_fails_the_job_with_the_line():
@@ -76,12 +84,12 @@ def test_under_torch_distributed_run_a_hanging_rank_fails_the_job_with_the_line(
     import bench
     r, lines, wall = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                            "--master-port", str(bench.free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-plumbing"],
-                          {"SLAM_BENCH_TEST_HANG": "1:rendezvous", "SLAM_BENCH_STALL_S": "8", "SLAM_BENCH_TIMEOUT_S": "60"})
+                          {"SLAM_BENCH_TEST_HANG": "1:rendezvous", "SLAM_BENCH_STALL_S": "12", "SLAM_BENCH_TIMEOUT_S": "90"})
     assert r.returncode != 0, (r.stdout, r.stderr[-1500:])
     assert len(lines) == 1, r.stdout
     assert 1 in lines[0]["suspects"] and lines[0]["last_stage"] == "rendezvous" and lines[0]["value"] is None
     assert "in mark" in " | ".join(lines[0]["ranks"][1]["where"] or [])
-    assert wall < 90
+    assert wall < 120
 
 
 def test_a_rank_that_dies_is_named():
