@@ -2724,7 +2724,7 @@ __global__ void __launch_bounds__(kBlock) assoc_count_kernel(AssocGridArgs A, in
                 const int at = A.cell_start[cell] + atomicAdd(&A.cell_fill[cell], 1);
                 if (at < A.cap_items) {
                     A.items[2 * (size_t) at] = make_float4(bx.xmin, bx.xmax, bx.ymin, bx.ymax);
-                    A.items[2 * (size_t) at + 1] = make_float4(1.01f * sqrtf(A.G * (bx.tmax + A.r00)) + 1e-3f, __int_as_float(j), 0.0f, 0.0f);
+                    A.items[2 * (size_t) at + 1] = make_float4(1.01f * sqrtf(A.G * (bx.tmax + A.r00)) + 1e-3f, __int_as_float(j), bx.tmax, 0.0f);
                 }
             }
         }
@@ -2830,6 +2830,19 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
                 const float dmin2 = ex * ex + ey * ey, dmax2 = fx * fx + fy * fy;
                 const float hi = zr + bt.x, lo = zr - bt.x;
                 if ((hi < 0.0f || hi * hi < dmin2 * 0.998f) || (lo > 0.0f && lo * lo > dmax2 * 1.002f)) return;
+                {
+                    // ... and, for the entries the ring lets through, the same bound as the cell radius (assoc_radius) with THIS pose's
+                    // distances instead of the worst over all poses: an estimate l of j that passes a gate lies within
+                    //   e + sqrt(G (t + d^2 R11)) + (e / 2) min(pi, sqrt(G (t / d^2 + R11)))
+                    // of the point p this observation implies (d in [dmin, dmax] of the box from this pose), and l is in the box: the
+                    // distance from p to the box must not exceed it.  Cuts the entries whose record is fetched (two dependent trips
+                    // each: what the kernel waits for) by the bearing as well as the range
+                    const float t = bt.z, e = bt.x;
+                    const float Dg = dmin2 > 0.0f ? fminf(3.14159274f, sqrtf(A.G * (t * __builtin_amdgcn_rcpf(dmin2) * 1.001f + r11))) : 3.14159274f;
+                    const float rho = (e * (1.0f + 0.5f * Dg) + sqrtf(A.G * (t + dmax2 * r11))) * 1.01f + 1e-3f;
+                    const float qx = fmaxf(fmaxf(bb.x - px, px - bb.y), 0.0f), qy = fmaxf(fmaxf(bb.z - py, py - bb.w), 0.0f);
+                    if (qx * qx + qy * qy > rho * rho) return;
+                }
                 const int j = __float_as_int(bt.y);
                 float4 la;
                 float lb;
