@@ -180,6 +180,26 @@ def test_slam_backend_gated_association_builds_the_same_map(tmp_path, seed, math
     assert err.max() < 2.5, err.max()
 
 
+def test_slam_backend_gated_association_on_the_largest_bundled_map(tmp_path):
+    """... and on example_loop902 (117 landmarks on a loop driven twice, heading observed: the densest of the bundled maps, where the
+    second stage's uniqueness tests have the least room): the map comes out exact and the error is the known-association twin's
+    (all 18 probed runs on the three loop maps do: profiles/gated_association_whole_runs_r06.txt)."""
+    import re
+
+    def run(extra, name):
+        log = str(tmp_path / name)
+        r = subprocess.run([EXE, "-m", os.path.join(DATA, "example_loop902.mat"), "-method", "FASTSLAM2", "-NPARTICLES", "1024", "-NEFFECTIVE", "768",
+                            "-SWITCH_SEED_RANDOM", "7", "-math", "fast", "-log", log] + extra, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+        rows = np.loadtxt(log, delimiter=",", skiprows=1)
+        return r.stdout, np.hypot(rows[:, 4] - rows[:, 1], rows[:, 5] - rows[:, 2])
+    out, err = run(["-assoc", "gated"], "gated902.csv")
+    m = re.search(r"landmarks in map: (\d+) \((\d+) opened, (\d+) retired", out)
+    assert (int(m.group(1)), int(m.group(2)), int(m.group(3))) == (117, 117, 0), out[-400:]
+    _, err_known = run(["-loop", "step"], "known902.csv")
+    assert err.mean() < 0.5 and err.mean() <= 2.0 * err_known.mean() + 0.25 and err.max() < 1.5, (err.mean(), err_known.mean(), err.max())
+
+
 def test_retired_landmarks_take_no_part_in_the_association():
     """slamgpu_retire_landmarks (round 6): a retired landmark is never a label again -- in the exhaustive scan and through the grid
     -- and the decisions about every other landmark are what they were."""
