@@ -301,7 +301,7 @@ int slamgpu_associate_ex(slamgpu_ctx *ctx, const float *z, int32_t nz, const flo
  * re-observed, they are never written again.  They stay in the particles' maps (slamgpu_num_landmarks, slamgpu_download and the
  * landmark capacity count them): what the reference's Particle would allow -- dropping an entry of landmarkXs / landmarkPs,
  * Particle.cpp:61-73 -- is a renumbering of every later landmark, which a per-step association shared by all particles cannot do
- * in the middle of a run.  For a caller whose policy has given a landmark up (a duplicate opened by a wrong vote:
+ * in the middle of a run (slamgpu_upload, which replaces the whole particle set, clears the marks).  For a caller whose policy has given a landmark up (a duplicate opened by a wrong vote:
  * slam-backend -assoc gated, host/gated.h).  Single contexts.  Synchronises. */
 int slamgpu_retire_landmarks(slamgpu_ctx *ctx, const int32_t *ids, int32_t count);
 int slamgpu_num_landmarks(slamgpu_ctx *ctx);

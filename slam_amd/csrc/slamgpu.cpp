@@ -3283,6 +3283,12 @@ int slamgpu_upload(slamgpu_ctx *c, int32_t nf, const float *xv, const float *Pv9
     c->nf = nf;
     rows_reset(c, nf);
     std::fill(c->box_dirty.begin(), c->box_dirty.end(), 1);
+    // (a new particle set is a new map: nothing of it has been retired from the association)
+    if (c->n_retired > 0) {
+        std::fill(c->retired.begin(), c->retired.end(), 0);
+        c->n_retired = 0;
+        if (c->retired_dev) HIP_TRY(hipMemset(c->retired_dev, 0, sizeof(uint32_t) * (((size_t) c->B.cap_nf + 31) / 32)));
+    }
     c->est_fresh = false;
     c->shard_est_fresh = false;
     return 0;

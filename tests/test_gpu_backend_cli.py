@@ -229,6 +229,11 @@ def test_retired_landmarks_take_no_part_in_the_association():
         assert cols.sum() >= 2 and np.array_equal(np.asarray(lab)[:, cols], np.asarray(lab0)[:, cols])
     with pytest.raises(sg.SlamGpuError):
         s.retire_landmarks([s.nf()])
+    # a new particle set is a new map: slamgpu_upload clears the marks
+    s.upload(s.download())
+    for mode in (sg.capi.ASSOC_EXHAUSTIVE, sg.capi.ASSOC_GRID):
+        lab, cons, _ = s.associate(z, tape["R"], g1, g2, mode=mode)[:3]
+        assert victim in set(int(c) for c in cons)
     s.close()
 
 
