@@ -126,7 +126,10 @@ enum {
      * the decision and every ancestor are the reference's bit for bit (two extra small launches per step).  This flag turns that
      * off: the context then scans in double like every other one (what a comparison with a sharded run of the same particles
      * needs: shards always do). */
-    SLAMGPU_FLAG_NO_REFERENCE_RESAMPLE = 2
+    SLAMGPU_FLAG_NO_REFERENCE_RESAMPLE = 2,
+    /* (round 6) The context is going to be stepped with a per-particle association (slamgpu_update_particle /
+     * slamgpu_update_labels): plain genealogy rows and device-memory packets whatever the landmark capacity. */
+    SLAMGPU_FLAG_PARTICLE_MAPS = 4
 };
 
 const char *slamgpu_last_error(void);
@@ -295,6 +298,41 @@ int slamgpu_associate(slamgpu_ctx *ctx, const float *z, int32_t nz, const float 
 enum { SLAMGPU_ASSOC_AUTO = 0, SLAMGPU_ASSOC_EXHAUSTIVE = 1, SLAMGPU_ASSOC_GRID = 2 };
 int slamgpu_associate_ex(slamgpu_ctx *ctx, const float *z, int32_t nz, const float R[4], float gate_reject, float gate_augment, int32_t mode,
                          int32_t *labels, int32_t *consensus, float *support, double stats[4]);
+
+/* (round 6) The per-particle association CARRIED INTO THE UPDATE: every particle acts on its own decisions, on a map of its own
+ * (what the reference's data structure allows -- Particle.cpp:61-73 grows landmarkXs / landmarkPs per particle -- and what
+ * SURVEY.md section 8(f4) asks for: EKFSLAM::dataAssociate, ekfslam.cpp:151-189, applied per particle; the reference has no
+ * FastSLAM implementation of it, so parity is with the EKF's gating decisions and, for particles that agree, with slamgpu_update
+ * bit for bit).  All particles share one index space of landmark SLOTS; a particle that has not opened the landmark of a slot holds
+ * an ABSENT record there (slamgpu_download returns NaN for its xf).  One step:
+ *   - every particle gates the nz observations against its own landmarks (as slamgpu_associate_ex does, with opt->mode);
+ *   - a slot any particle matched is rewritten by every particle: updated with the observation THAT particle matched it with
+ *     (one observation per landmark and particle: the first to claim it), or carried forward unchanged;
+ *   - an observation that at least opt->new_share of the particles call new gets a slot (a dead slot first, otherwise the map
+ *     grows; none left: the observation is dropped): those particles initialise it (core.cpp:479-509), the others hold it absent;
+ *   - an observation a particle leaves unexplained (discarded between the gates, a second claim on one landmark, new) costs that
+ *     particle the weight factor opt->p_new -- FastSLAM's constant likelihood of a new feature -- so that ignoring an
+ *     observation never outweighs explaining it; a particle none of the observations concerns keeps its pose and Pv untouched;
+ *   - every opt->census_every steps the particles holding each slot are counted: a slot nobody holds any more (its hypotheses died
+ *     in a resample) is dead -- out of the association, reused by a later landmark.
+ * Resampling, estimates, history and downloads are the usual ones.  Single contexts on plain genealogy rows only: create the
+ * context with SLAMGPU_FLAG_PARTICLE_MAPS (capacities of 40..256 landmarks are moved to plain rows at the first call).
+ * normals / strata: as slamgpu_update.  report (may be NULL): [0] slots rewritten, [1] slots opened, [2] of them dead slots
+ * reused, [3] observations dropped for want of a slot, [4] slots in use after the step (slamgpu_num_landmarks), [5] dead slots
+ * waiting, [6] particles an observation needs to open a slot, [7] 1 if the holders were counted.  Synchronises. */
+typedef struct slamgpu_particle_assoc {
+    float gate_reject, gate_augment; /* GATE_REJECT / GATE_AUGMENT of the .ini */
+    int32_t mode;                    /* SLAMGPU_ASSOC_AUTO / _EXHAUSTIVE / _GRID */
+    float new_share;                 /* 0: one particle is enough to open a landmark */
+    float p_new;                     /* > 0 */
+    int32_t census_every;            /* 0: never */
+} slamgpu_particle_assoc;
+int slamgpu_update_particle(slamgpu_ctx *ctx, const float *z, int32_t nz, const float R[4], const slamgpu_particle_assoc *opt,
+                            const float *normals, const float *strata, int32_t report[8]);
+/* The same step with the caller's labels[N*nz] (host, particle-major: slot >= 0, SLAMGPU_ASSOC_NEW or SLAMGPU_ASSOC_DISCARD)
+ * instead of the gates' (opt->gate_* / mode are not read): what the tests drive, and the seam for an association made elsewhere. */
+int slamgpu_update_labels(slamgpu_ctx *ctx, const float *z, int32_t nz, const float R[4], const int32_t *labels,
+                          const slamgpu_particle_assoc *opt, const float *normals, const float *strata, int32_t report[8]);
 
 /* Retire landmarks from the gated association (round 6): landmarks ids[0 .. count) take no part in slamgpu_associate /
  * _associate_ex from now on -- no particle gates an observation against them, nothing votes for them -- and, never being

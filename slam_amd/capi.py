@@ -25,17 +25,23 @@ DECLARED_SYMBOLS = [
     "slamgpu_dist_history_fetch", "slamgpu_dist_gather", "slamgpu_dist_set_collective", "slamgpu_dist_handshake_test",
     "slamgpu_dist_collective_status", "slamgpu_dist_comm_id", "slamgpu_dist_comm_init", "slamgpu_dist_group_create", "slamgpu_dist_group_destroy",
     "slamgpu_dist_group_step", "slamgpu_dist_group_settle", "slamgpu_dist_group_history", "slamgpu_dist_group_download",
-    "slamgpu_peek", "slamgpu_step_observe", "slamgpu_run_observe", "slamgpu_observe_fetch", "slamgpu_associate_ex", "slamgpu_dist_comm_info", "slamgpu_dist_remote_reads",
+    "slamgpu_peek", "slamgpu_step_observe", "slamgpu_run_observe", "slamgpu_observe_fetch", "slamgpu_associate_ex", "slamgpu_update_particle", "slamgpu_update_labels", "slamgpu_dist_comm_info", "slamgpu_dist_remote_reads",
 ]
 ASSOC_AUTO, ASSOC_EXHAUSTIVE, ASSOC_GRID = 0, 1, 2
 FLAG_DEVICE_OBSERVE = 1
 FLAG_NO_REFERENCE_RESAMPLE = 2
+FLAG_PARTICLE_MAPS = 4
 
 
 class SlamGpuError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("slamgpu error %d: %s" % (code, msg))
         self.code = code
+
+
+class ParticleAssoc(C.Structure):  # slamgpu_particle_assoc
+    _fields_ = [("gate_reject", C.c_float), ("gate_augment", C.c_float), ("mode", C.c_int32), ("new_share", C.c_float), ("p_new", C.c_float),
+                ("census_every", C.c_int32)]
 
 
 class Config(C.Structure):
@@ -103,6 +109,8 @@ def load_library():
     L.slamgpu_stats.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
     L.slamgpu_ancestors.argtypes = [C.c_void_p, C.c_void_p]
     L.slamgpu_num_landmarks.argtypes = [C.c_void_p]
+    L.slamgpu_update_particle.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.slamgpu_update_labels.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     if hasattr(L, "slamgpu_retire_landmarks"):
         L.slamgpu_retire_landmarks.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     L.slamgpu_genealogy_rows.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -300,7 +308,7 @@ class SlamGpu:
     def __init__(self, n_particles, max_landmarks, method=FASTSLAM2, n_effective=None, resample=True, use_heading=False,
                  add_predict_noise=None, wheel_base=4.0, sigma_phi=0.017453292519943, rng_mode=RNG_TAPE, seed=0,
                  math_mode=MATH_STRICT, device=0, first_particle=0, n_particles_global=0, external_stream=0, log_weights=False,
-                 device_observe=False, reference_resample=True):
+                 device_observe=False, reference_resample=True, particle_maps=False):
         self.L = load_library()
         cfg = Config()
         cfg.struct_size = C.sizeof(Config)
@@ -322,7 +330,8 @@ class SlamGpu:
         cfg.n_particles_global = ng
         cfg.external_stream = external_stream
         cfg.log_weights = int(log_weights)
-        cfg.flags = (FLAG_DEVICE_OBSERVE if device_observe else 0) | (0 if reference_resample else FLAG_NO_REFERENCE_RESAMPLE)
+        cfg.flags = ((FLAG_DEVICE_OBSERVE if device_observe else 0) | (0 if reference_resample else FLAG_NO_REFERENCE_RESAMPLE) |
+                     (FLAG_PARTICLE_MAPS if particle_maps else 0))
         self.cfg = cfg
         self.N = n_particles
         self.h = C.c_void_p()
@@ -739,6 +748,36 @@ class SlamGpu:
         if want_stats:
             return lab, cons, sup, dict(triples=st[0], grid_entries=st[1], ms=st[2], grid=bool(st[3]))
         return lab, cons, sup
+
+    _REPORT = ("rewritten", "opened", "reused", "dropped", "slots", "dead", "need", "census")
+
+    def _particle_opt(self, gate_reject, gate_augment, mode, new_share, p_new, census_every):
+        o = ParticleAssoc()
+        o.gate_reject, o.gate_augment, o.mode = gate_reject, gate_augment, int(mode)
+        o.new_share, o.p_new, o.census_every = new_share, p_new, int(census_every)
+        return o
+
+    def update_particle(self, z, R, gate_reject=4.0, gate_augment=25.0, mode=ASSOC_AUTO, new_share=0.0, p_new=1.0, census_every=1,
+                        normals=None, strata=None):
+        """one observation step in which every particle acts on its own gated association (slamgpu_update_particle); returns the report"""
+        z = _f32(z).reshape(-1, 2)
+        o = self._particle_opt(gate_reject, gate_augment, mode, new_share, p_new, census_every)
+        nm = None if normals is None else _f32(normals, (self.N, 3))
+        st = None if strata is None else _f32(strata)
+        rep = np.zeros(8, np.int32)
+        _chk(self.L.slamgpu_update_particle(self.h, _ptr(z), z.shape[0], _ptr(_f32(R, 4)), C.byref(o), _ptr(nm), _ptr(st), _ptr(rep)))
+        return dict(zip(self._REPORT, (int(v) for v in rep)))
+
+    def update_labels(self, z, R, labels, new_share=0.0, p_new=1.0, census_every=1, normals=None, strata=None):
+        """the same step with the caller's labels [N, nz] (slamgpu_update_labels)"""
+        z = _f32(z).reshape(-1, 2)
+        lab = np.ascontiguousarray(labels, np.int32).reshape(self.N, z.shape[0])
+        o = self._particle_opt(0.0, 0.0, ASSOC_AUTO, new_share, p_new, census_every)
+        nm = None if normals is None else _f32(normals, (self.N, 3))
+        st = None if strata is None else _f32(strata)
+        rep = np.zeros(8, np.int32)
+        _chk(self.L.slamgpu_update_labels(self.h, _ptr(z), z.shape[0], _ptr(_f32(R, 4)), _ptr(lab), C.byref(o), _ptr(nm), _ptr(st), _ptr(rep)))
+        return dict(zip(self._REPORT, (int(v) for v in rep)))
 
     def debug_stamps(self, max_blocks=8192):
         out = np.zeros((max_blocks, 16), np.uint64)

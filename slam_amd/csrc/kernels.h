@@ -312,6 +312,24 @@ struct PersistArgs {
                                         // PCIe read sits in front of a tile's loads on the in-order return path
 };
 
+// Per-particle data association (reference: EKFSLAM::dataAssociate, ekfslam.cpp:151-189, applied by every
+// particle to its own map, which Particle.cpp:61-73 lets grow per particle).  The device layout keeps ONE index space of landmark
+// slots for all particles; what differs per particle is WHICH observation (if any) it associates with a slot, and whether it holds
+// the slot's landmark at all: a particle that has not opened a landmark carries an ABSENT record there (xf = NaN: every gate of the
+// association compares false on it, so such a record is never matched).  One step: the packet lists the union of the slots any
+// particle matched (idf[m], the "re-observed" landmarks: every particle writes a fresh record there, updated by ITS observation or
+// copied unchanged) and the slots opened for observations some particles call new (idn[n]: initialised from the observation by
+// those particles, absent for the others); obs[(k) * ncap + i] = the observation particle i associates with packet entry k
+// (k < m: re-observed entry k; m <= k < m + n: new slot k - m), or -1.
+struct PerParticle {
+    const int16_t *obs;      // [m + n][ncap]
+    const float *z;          // [2 nz] the step's observations (range, bearing)
+    const int32_t *idn;      // [n] slots of the new landmarks (dead slots are reused before the map grows)
+    const float *wf;         // [ncap] weight factor of the observations the particle leaves unexplained: p_new ^ count (log-weights: count * log p_new)
+    const uint8_t *any;      // [ncap] bit 0: the particle matched a landmark, bit 1: it opens one (neither: the step leaves its pose alone)
+};
+constexpr float kAbsent = __builtin_nanf("");  // xf.x / xf.y of an absent record
+
 struct UpdateArgs {
     int32_t method, m, n, nf;
     float R[4];
@@ -543,6 +561,9 @@ struct KernelTable {
     // update + in-block weight prefix / totals  (+ helper blocks: genealogy copy, Ctrl words, estimate reduction)
     void (*update)(hipStream_t, const Buffers &, const PredictArgs &, const UpdateArgs &, const RngArgs &,
                    const WeightScratch &);
+    // the same step with a per-particle association (PerParticle: update_kernel<.., PP = true>; single contexts on plain rows)
+    void (*update_particle)(hipStream_t, const Buffers &, const PredictArgs &, const UpdateArgs &, const RngArgs &, const WeightScratch &,
+                            const PerParticle &);
     // K steps of a compact single context in ONE launch (PersistArgs): U = what every iteration shares (front end on: the map, R)
     void (*update_persist)(hipStream_t, const Buffers &, const PredictArgs &, const UpdateArgs &, const RngArgs &, const WeightScratch &);
     // the resampling stage as a launch of its own (on demand): Neff + decision; normalise, or the ancestors of a
@@ -601,6 +622,13 @@ struct KernelTable {
                            int32_t *labels_dev);
     // seam 1, MULTIPARTICLE_ACCELERATOR form: self-describing records back to back, outputs in place; tab: 3 words per feature
     void (*jacobians_multi)(hipStream_t, float *win_dev, const uint32_t *tab_dev, uint32_t nfeat);
+    // per-particle association (PerParticle): census of the labels [n][nz] (first[l]: lowest observation naming landmark slot l, preset
+    // to INT_MAX; news[j]: particles calling observation j new, preset to 0), the labels resolved into PerParticle::obs / wf / any, and
+    // the number of particles that hold each landmark slot (holders[l], preset to 0; plain set, tables in sync)
+    void (*pp_census)(hipStream_t, const int32_t *labels_dev, int n, int nz, int32_t *first_dev, int32_t *news_dev);
+    void (*pp_resolve)(hipStream_t, const int32_t *labels_dev, int n, int nz, int ncap, const int32_t *uidx_dev, const int32_t *newk_dev, int m, int nn,
+                       float p_new, int logw, int16_t *obs_dev, float *wf_dev, uint8_t *any_dev);
+    void (*pp_holders)(hipStream_t, const Buffers &, int nf, int32_t *holders_dev);
 };
 
 const KernelTable *kernels_strict();

@@ -1343,11 +1343,13 @@ struct StepCarry {
     const float4 *draw_src;   // FastSLAM 1, fast build: this iteration's (V, G) normals, made by the drawer workgroups (or null)
 };
 
-template <int METHOD, int MODE, bool BIG>
+// (PPT: per-particle association, kernels.h: PerParticle -- plain rows, single contexts; every other instantiation compiles the text it always did)
+template <int METHOD, int MODE, bool BIG, bool PPT = false>
 __global__ void __launch_bounds__(kBlock) update_kernel(const float *__restrict__ h_tot, Ctrl *h_ctrl,
                                                          const FrontState *h_front, int h_nb, int h_slot, int h_grid, int h_flags, Buffers B, PredictArgs PA,
-                                                         UpdateArgs U, RngArgs rng, WeightScratch ws) {
-    constexpr bool PERSIST = false;
+                                                         UpdateArgs U, RngArgs rng, WeightScratch ws, PerParticle ppa) {
+    static_assert(!PPT || (BIG && MODE == 0), "per-particle association: plain rows, single contexts");
+    constexpr bool PERSIST = false, PP = PPT;
     const PersistStep *const qe = nullptr;
     StepCarry carry;  // (unused by a per-step launch)
 #define STEP_WPAR ws.wpar
@@ -1370,7 +1372,8 @@ __global__ void __launch_bounds__(kBlock, 3) update_kernel_wide(const float *__r
                                                                  int h_slot, int h_grid, int h_flags, Buffers B, PredictArgs PA, UpdateArgs U,
                                                                  RngArgs rng, WeightScratch ws) {
     constexpr int MODE = 0;
-    constexpr bool BIG = false, PERSIST = false;
+    constexpr bool BIG = false, PERSIST = false, PP = false;
+    [[maybe_unused]] const PerParticle ppa{};
     const PersistStep *const qe = nullptr;
     StepCarry carry;  // (unused by a per-step launch)
 #define STEP_WPAR ws.wpar
@@ -1387,7 +1390,8 @@ template <int METHOD>
 SLAM_DEV void persist_step(const float *__restrict__ h_tot, Ctrl *h_ctrl, const FrontState *h_front, int h_nb, int h_slot, int h_grid, int h_flags,
                            const Buffers &B, const UpdateArgs &U, const RngArgs &rng_k, const WeightScratch &ws, const PersistStep *qe,
                            StepCarry &carry) {
-    constexpr bool PERSIST = true, BIG = false;
+    constexpr bool PERSIST = true, BIG = false, PP = false;
+    [[maybe_unused]] const PerParticle ppa{};
     constexpr int MODE = 0;
     const PredictArgs &PA = qe->PA;
     const int wpar = __builtin_amdgcn_readfirstlane(qe->wpar);
@@ -3175,8 +3179,8 @@ static void launch_shard_finish(hipStream_t st, const Buffers &B, const WeightSc
     hipLaunchKernelGGL(shard_finalize_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B, ws, W, Q, neff, resampled);
 }
 
-static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &PA, const UpdateArgs &U,
-                          const RngArgs &rng, const WeightScratch &ws) {
+static void launch_update_any(hipStream_t st, const Buffers &B, const PredictArgs &PA, const UpdateArgs &U,
+                              const RngArgs &rng, const WeightScratch &ws, const PerParticle &ppa) {
     // compute blocks first (they are the long pole), then -- single-context pipeline only -- the copy blocks of a
     // pending lazy gather (they exit at once when nothing is pending: the host cannot know) and one helper block
     int grid = B.ncap / kBlock;
@@ -3196,10 +3200,15 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
     const int h_flags = (U.plan_inline ? 1 : 0) | (U.scan_global ? 2 : 0) | (U.logw ? 4 : 0) | (U.lazy ? 8 : 0) | (U.front.on ? 16 : 0) | (scan_dma ? 32 : 0) | (U.count_remote ? 64 : 0);
 #define SLAM_LAUNCH_UPDATE(M, A, G)                                                                                              \
     hipLaunchKernelGGL((update_kernel<M, A, G>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid, \
-                       h_flags, B, PA, U, rng, ws)
+                       h_flags, B, PA, U, rng, ws, ppa)
     if (update_is_wide(U.method, U.arrivals, U.big != nullptr, ws.nblocks)) {  // (FastSLAM 1, single context, compact layout, more tiles than two rounds of CUs)
         hipLaunchKernelGGL((update_kernel_wide<1>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid,
                            h_flags, B, PA, U, rng, ws);
+        return;
+    }
+    if (ppa.obs) {  // per-particle association (slamgpu.cpp: do_update_particle guarantees a single context on plain rows)
+        if (U.method == 2) hipLaunchKernelGGL((update_kernel<2, 0, true, true>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid, h_flags, B, PA, U, rng, ws, ppa);
+        else hipLaunchKernelGGL((update_kernel<1, 0, true, true>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid, h_flags, B, PA, U, rng, ws, ppa);
         return;
     }
     switch (sel) {
@@ -3217,6 +3226,14 @@ static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &P
         default: SLAM_LAUNCH_UPDATE(1, 0, false); break;
     }
 #undef SLAM_LAUNCH_UPDATE
+}
+
+static void launch_update(hipStream_t st, const Buffers &B, const PredictArgs &PA, const UpdateArgs &U, const RngArgs &rng, const WeightScratch &ws) {
+    launch_update_any(st, B, PA, U, rng, ws, PerParticle{});
+}
+static void launch_update_particle(hipStream_t st, const Buffers &B, const PredictArgs &PA, const UpdateArgs &U, const RngArgs &rng,
+                                   const WeightScratch &ws, const PerParticle &ppa) {
+    launch_update_any(st, B, PA, U, rng, ws, ppa);
 }
 
 // K iterations in one launch (kernels.h: PersistArgs): kPersistStride x (tiles + 1 helper) workgroups, of which every
@@ -3407,9 +3424,104 @@ static void launch_associate_grid(hipStream_t st, const Buffers &B, const AssocG
                        R4[0], R4[1], R4[2], R4[3], g1, g2, labels);
 }
 
-static const KernelTable kTable = {launch_update, launch_update_persist, launch_resample, launch_resample_ref, launch_scan, launch_gather, launch_flatten, launch_identity, launch_decompact, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat, launch_observe, launch_observe_book, launch_associate,
+// ---------------------------------------------------------------------------------------------------
+// Per-particle association (kernels.h: PerParticle; slamgpu.cpp: do_update_particle): between the association's labels
+// [n][nz] and the update launch.
+// census: which landmark slots ANY particle matched (first[l] = the lowest observation index that names l, INT_MAX: none -- the
+// host orders the packet's entries by it, so that particles which agree meet their landmarks in the order of the observations, as
+// the reference's loop over zf does) and how many particles call each observation new.
+__global__ void __launch_bounds__(kBlock) pp_census_kernel(const int32_t *__restrict__ labels, int n, int nz, int32_t *__restrict__ first,
+                                                            int32_t *__restrict__ news) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool on = i < n;
+    for (int j = 0; j < nz; j++) {
+        const int lab = on ? labels[(size_t) i * nz + j] : kAssocDiscard;
+        // (most particles agree and the word is soon at its final value: a plain look first, the atomic only to lower it)
+        if (lab >= 0 && first[lab] > j) atomicMin(first + lab, j);
+        const unsigned long long nw = __ballot(lab == kAssocNew);
+        if (nw && (threadIdx.x & (kWave - 1)) == (int) __ffsll((long long) __ballot(true)) - 1) atomicAdd(news + j, (int) __popcll(nw));
+    }
+}
+
+// resolve: labels -> PerParticle::obs / wf / any.  uidx[l] = packet entry of landmark slot l (-1: not in the packet), newk[j] = new
+// slot (entry m + newk[j]) opened for observation j (-1: none).  One observation per landmark and particle (the first to name it; a
+// scan sees a landmark once); an observation the particle does not use -- discarded between the gates, a second claim on a
+// landmark, called new without a slot being opened for it, or opening one -- counts as unexplained and costs the factor p_new
+// (FastSLAM's constant likelihood of a new feature: without it a particle that ignores an observation would outweigh one that
+// explains it).
+__global__ void __launch_bounds__(kBlock) pp_resolve_kernel(const int32_t *__restrict__ labels, int n, int nz, size_t S, const int32_t *__restrict__ uidx,
+                                                             const int32_t *__restrict__ newk, int m, int nn, float p_new, int logw,
+                                                             int16_t *__restrict__ obs, float *__restrict__ wf, uint8_t *__restrict__ any) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= (int) S) return;
+    for (int k = 0; k < m + nn; k++) obs[(size_t) k * S + i] = (int16_t) -1;
+    if (i >= n) {
+        wf[i] = logw ? 0.0f : 1.0f;
+        any[i] = 0;
+        return;
+    }
+    int unexplained = 0, flags = 0;
+    for (int j = 0; j < nz; j++) {
+        const int lab = labels[(size_t) i * nz + j];
+        if (lab >= 0) {
+            const int k = uidx[lab];
+            if (k >= 0 && obs[(size_t) k * S + i] < 0) {
+                obs[(size_t) k * S + i] = (int16_t) j;
+                flags |= 1;
+            } else {
+                unexplained++;
+            }
+        } else {
+            unexplained++;
+            const int kn = lab == kAssocNew ? newk[j] : -1;
+            if (kn >= 0) {
+                obs[(size_t) (m + kn) * S + i] = (int16_t) j;
+                flags |= 2;
+            }
+        }
+    }
+    // (repeated multiplication, not powf: the same bits in both builds and on the host's restatement)
+    float f = logw ? 0.0f : 1.0f;
+    const float lp = logw ? logf(p_new) : 0.0f;
+    for (int q = 0; q < unexplained; q++) f = logw ? f + lp : f * p_new;
+    wf[i] = f;
+    any[i] = (uint8_t) flags;
+}
+
+// holders: how many particles of the (plain) set hold landmark slot l, l < nf -- a slot nobody holds any more (its hypotheses died
+// in a resample) is dead: the host takes it out of the association and opens it again for a later landmark
+__global__ void __launch_bounds__(kBlock) pp_holders_kernel(Buffers B, int nf, int32_t *__restrict__ holders) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const bool on = i < B.n;
+    const int cur = B.ctrl->live[B.slot];
+    const size_t S = (size_t) B.ncap;
+    for (int l = 0; l < nf; l++) {
+        bool has = false;
+        if (on) {
+            float4 la;
+            float lb;
+            read_through_genealogy(B, B.lmk_live, cur, S, l, i, la, lb);
+            has = la.x == la.x;
+        }
+        const unsigned long long hm = __ballot(has);
+        if (hm && (threadIdx.x & (kWave - 1)) == (int) __ffsll((long long) __ballot(true)) - 1) atomicAdd(holders + l, (int) __popcll(hm));
+    }
+}
+
+static void launch_pp_census(hipStream_t st, const int32_t *labels, int n, int nz, int32_t *first, int32_t *news) {
+    hipLaunchKernelGGL(pp_census_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, labels, n, nz, first, news);
+}
+static void launch_pp_resolve(hipStream_t st, const int32_t *labels, int n, int nz, int ncap, const int32_t *uidx, const int32_t *newk, int m, int nn,
+                              float p_new, int logw, int16_t *obs, float *wf, uint8_t *any) {
+    hipLaunchKernelGGL(pp_resolve_kernel, dim3(ncap / kBlock), dim3(kBlock), 0, st, labels, n, nz, (size_t) ncap, uidx, newk, m, nn, p_new, logw, obs, wf, any);
+}
+static void launch_pp_holders(hipStream_t st, const Buffers &B, int nf, int32_t *holders) {
+    hipLaunchKernelGGL(pp_holders_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B, nf, holders);
+}
+
+static const KernelTable kTable = {launch_update, launch_update_particle, launch_update_persist, launch_resample, launch_resample_ref, launch_scan, launch_gather, launch_flatten, launch_identity, launch_decompact, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat, launch_observe, launch_observe_book, launch_associate,
                                    launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish, launch_dist_gather, launch_dist_flags, launch_peek, launch_lmk_box, launch_assoc_grid,
-                                   launch_associate_grid, launch_jacobians_multi};
+                                   launch_associate_grid, launch_jacobians_multi, launch_pp_census, launch_pp_resolve, launch_pp_holders};
 
 }  // namespace SLAM_KNS
 

@@ -237,6 +237,20 @@ struct slamgpu_ctx {
     uint32_t *retired_dev = nullptr;
     int n_retired = 0;
     int32_t *assoc_ids_dev = nullptr, *cell_start_dev = nullptr, *cell_fill_dev = nullptr;
+    // per-particle association (slamgpu_update_particle / _labels; kernels.h: PerParticle): device scratch, grown on demand
+    int32_t *pp_lab_dev = nullptr;   // labels [N][nz]
+    size_t pp_lab_cap = 0;
+    int16_t *pp_obs_dev = nullptr;   // PerParticle::obs [rows][ncap]
+    size_t pp_obs_rows = 0;
+    float *pp_z_dev = nullptr;       // [2 pp_nz_cap]
+    int32_t *pp_tab_dev = nullptr;   // [cap_nf] first / uidx | [cap_nf] holders | [pp_nz_cap] news / newk | [pp_nz_cap] idn
+    int pp_nz_cap = 0;
+    float *pp_wf_dev = nullptr;      // [ncap]
+    uint8_t *pp_any_dev = nullptr;   // [ncap]
+    std::vector<char> pp_dead;       // landmark slots no particle holds any more (their hypotheses died in a resample): out of the
+    std::vector<int32_t> pp_dead_list;  // association (retired) until a later landmark opens them again
+    uint64_t pp_steps = 0;
+    const PerParticle *pp_launch = nullptr;  // set around issue_update by do_update_particle: the launch takes update_kernel<.., PP = true>
     float4 *items_dev = nullptr;  // [2 cap_items]: kernels.h: AssocGridArgs::items
     AssocGeom *geom_dev = nullptr;
     int32_t cap_items = 0;
@@ -839,7 +853,7 @@ int slamgpu_create(const slamgpu_config *cfg, slamgpu_ctx **out) {
         c->B.cap_rows = kSmallRows;
         c->mid_compact = true;
     }
-    if (getenv("SLAMGPU_NO_COMPACT")) {  // diagnostic: plain rows for a small map
+    if (getenv("SLAMGPU_NO_COMPACT") || (cfg->flags & SLAMGPU_FLAG_PARTICLE_MAPS)) {  // plain rows for a small map (diagnostic; per-particle association)
         c->B.compact = 0;
         c->B.cap_rows = cap_nf + 1;
         c->mid_compact = false;
@@ -940,6 +954,12 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     if (c->stamps_dev) (void) hipFree(c->stamps_dev);
     if (c->peek_dev) (void) hipFree(c->peek_dev);
     if (c->retired_dev) (void) hipFree(c->retired_dev);
+    if (c->pp_lab_dev) (void) hipFree(c->pp_lab_dev);
+    if (c->pp_obs_dev) (void) hipFree(c->pp_obs_dev);
+    if (c->pp_z_dev) (void) hipFree(c->pp_z_dev);
+    if (c->pp_tab_dev) (void) hipFree(c->pp_tab_dev);
+    if (c->pp_wf_dev) (void) hipFree(c->pp_wf_dev);
+    if (c->pp_any_dev) (void) hipFree(c->pp_any_dev);
     for (void *p_ : {(void *) c->box_dev, (void *) c->assoc_ids_dev, (void *) c->cell_start_dev, (void *) c->cell_fill_dev, (void *) c->items_dev,
                      (void *) c->geom_dev})
         if (p_) (void) hipFree(p_);
@@ -1142,7 +1162,8 @@ int issue_update(slamgpu_ctx *c, UpdateArgs &U, int n_new, int n_rows, bool need
         c->collect->steps.push_back(q);
     } else {
         Timed t(c, c->cfg.method == SLAMGPU_FASTSLAM2 ? "fs2_update" : "fs1_update");
-        c->k->update(c->stream, c->B, PA, U, rng, c->ws);
+        if (c->pp_launch) c->k->update_particle(c->stream, c->B, PA, U, rng, c->ws, *c->pp_launch);
+        else c->k->update(c->stream, c->B, PA, U, rng, c->ws);
     }
     HIP_TRY(hipGetLastError());
     c->slot ^= 1;   // ... and where it left the set (Ctrl.live / pend of the other slot)
@@ -2794,8 +2815,10 @@ void assoc_resolve(int nz, std::vector<int32_t> &best, const std::vector<double>
 }
 }  // namespace
 
-int slamgpu_associate_ex(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4], float gate_reject, float gate_augment, int32_t mode,
-                         int32_t *labels, int32_t *consensus, float *support, double stats[4]) {
+namespace {
+// lab_ext: a device array [N][nz] the labels are left in (slamgpu_update_particle: they never visit the host), or null
+int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4], float gate_reject, float gate_augment, int32_t mode,
+                   int32_t *labels, int32_t *consensus, float *support, double stats[4], int32_t *lab_ext) {
     if (int rc = check_ctx(c)) return rc;
     if (mode < SLAMGPU_ASSOC_AUTO || mode > SLAMGPU_ASSOC_GRID) return fail(SLAMGPU_ERR_INVALID, "unknown association mode %d", mode);
     if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0.0;
@@ -2821,6 +2844,7 @@ int slamgpu_associate_ex(slamgpu_ctx *c, const float *z, int32_t nz, const float
         if (!rc && er != hipSuccess) rc = fail(er == hipErrorOutOfMemory ? SLAMGPU_ERR_ALLOC : SLAMGPU_ERR_HIP, "%s: %s", what, hipGetErrorString(er));
     };
     auto need_labels = [&]() {  // [N][nz] labels on the device: only when the caller wants them, or the vote is taken on the host
+        if (!lab_dev && lab_ext) lab_dev = lab_ext;
         if (!lab_dev) step(hipMalloc((void **) &lab_dev, sizeof(int32_t) * (size_t) N * nz), "hipMalloc(labels)");
     };
     step(hipMalloc((void **) &z_dev, sizeof(float) * 2 * (size_t) nz), "hipMalloc");
@@ -2855,7 +2879,7 @@ int slamgpu_associate_ex(slamgpu_ctx *c, const float *z, int32_t nz, const float
             step(hipMemcpyAsync(c->assoc_ids_dev, ids.data(), sizeof(int32_t) * ids.size(), hipMemcpyHostToDevice, c->stream), "H2D");
             step(hipStreamSynchronize(c->stream), "sync");  // (pageable source)
         }
-        if (labels) need_labels();
+        if (labels || lab_ext) need_labels();
         if (want_vote) {
             step(hipMalloc((void **) &votes_dev, sizeof(VoteSlot) * kVoteSlots * (size_t) nz), "hipMalloc");
             // key = kVoteEmpty (0x80000000), weight = -0.0f (the same bits): -0.0 + w = w
@@ -2946,7 +2970,7 @@ int slamgpu_associate_ex(slamgpu_ctx *c, const float *z, int32_t nz, const float
         }
     }
     std::vector<int32_t> lab;
-    if (!rc && lab_dev) {
+    if (!rc && lab_dev && (labels || (want_vote && !voted))) {
         lab.resize((size_t) N * nz);
         step(hipMemcpyAsync(lab.data(), lab_dev, sizeof(int32_t) * lab.size(), hipMemcpyDeviceToHost, c->stream), "D2H");
     }
@@ -2958,7 +2982,7 @@ int slamgpu_associate_ex(slamgpu_ctx *c, const float *z, int32_t nz, const float
     if (ev0) (void) hipEventDestroy(ev0);
     if (ev1) (void) hipEventDestroy(ev1);
     if (z_dev) (void) hipFree(z_dev);
-    if (lab_dev) (void) hipFree(lab_dev);
+    if (lab_dev && lab_dev != lab_ext) (void) hipFree(lab_dev);
     if (votes_dev) (void) hipFree(votes_dev);
     if (rc) return rc;
     if (labels) memcpy(labels, lab.data(), sizeof(int32_t) * lab.size());
@@ -2992,6 +3016,26 @@ int slamgpu_associate_ex(slamgpu_ctx *c, const float *z, int32_t nz, const float
     if (want_vote) assoc_resolve(nz, best, share, consensus, support);
     return 0;
 }
+}  // namespace
+
+int slamgpu_associate_ex(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4], float gate_reject, float gate_augment, int32_t mode,
+                         int32_t *labels, int32_t *consensus, float *support, double stats[4]) {
+    return associate_impl(c, z, nz, R, gate_reject, gate_augment, mode, labels, consensus, support, stats, nullptr);
+}
+
+namespace {
+int retired_upload(slamgpu_ctx *c) {
+    const size_t words = ((size_t) c->B.cap_nf + 31) / 32;
+    if (c->retired.empty()) c->retired.assign((size_t) c->B.cap_nf, 0);
+    if (!c->retired_dev) HIP_TRY(hipMalloc((void **) &c->retired_dev, sizeof(uint32_t) * words));
+    std::vector<uint32_t> mask(words, 0u);
+    for (int j = 0; j < c->B.cap_nf; j++)
+        if (c->retired[(size_t) j]) mask[(size_t) j >> 5] |= 1u << (j & 31);
+    HIP_TRY(hipStreamSynchronize(c->stream));  // (an association in flight may still read the old mask)
+    HIP_TRY(hipMemcpy(c->retired_dev, mask.data(), sizeof(uint32_t) * words, hipMemcpyHostToDevice));
+    return 0;
+}
+}  // namespace
 
 int slamgpu_retire_landmarks(slamgpu_ctx *c, const int32_t *ids, int32_t count) {
     if (int rc = check_ctx(c)) return rc;
@@ -3010,12 +3054,300 @@ int slamgpu_retire_landmarks(slamgpu_ctx *c, const int32_t *ids, int32_t count) 
         c->retired[(size_t) ids[k]] = 1;
         c->box_dirty[(size_t) ids[k]] = 1;  // (its box becomes the empty one at the next grid call)
     }
-    std::vector<uint32_t> mask(words, 0u);
-    for (int j = 0; j < c->B.cap_nf; j++)
-        if (c->retired[(size_t) j]) mask[(size_t) j >> 5] |= 1u << (j & 31);
-    HIP_TRY(hipStreamSynchronize(c->stream));  // (an association in flight may still read the old mask)
-    HIP_TRY(hipMemcpy(c->retired_dev, mask.data(), sizeof(uint32_t) * words, hipMemcpyHostToDevice));
+    return retired_upload(c);
+}
+
+namespace {
+int pp_reserve(slamgpu_ctx *c, int nz, size_t rows) {
+    const size_t S = (size_t) c->B.ncap, cap_nf = (size_t) c->B.cap_nf;
+    if ((size_t) c->B.n * (size_t) nz > c->pp_lab_cap) {
+        if (c->pp_lab_dev) (void) hipFree(c->pp_lab_dev);
+        c->pp_lab_dev = nullptr;
+        c->pp_lab_cap = 0;
+        HIP_TRY(hipMalloc((void **) &c->pp_lab_dev, sizeof(int32_t) * (size_t) c->B.n * (size_t) nz));
+        c->pp_lab_cap = (size_t) c->B.n * (size_t) nz;
+    }
+    if (nz > c->pp_nz_cap || !c->pp_tab_dev) {
+        const int cap = std::max(64, 2 * nz);
+        if (c->pp_z_dev) (void) hipFree(c->pp_z_dev);
+        if (c->pp_tab_dev) (void) hipFree(c->pp_tab_dev);
+        c->pp_z_dev = nullptr;
+        c->pp_tab_dev = nullptr;
+        c->pp_nz_cap = 0;
+        HIP_TRY(hipMalloc((void **) &c->pp_z_dev, sizeof(float) * 2 * (size_t) cap));
+        HIP_TRY(hipMalloc((void **) &c->pp_tab_dev, sizeof(int32_t) * (2 * cap_nf + 2 * (size_t) cap)));
+        c->pp_nz_cap = cap;
+    }
+    if (rows > c->pp_obs_rows) {
+        const size_t want = std::max<size_t>(rows, 2 * c->pp_obs_rows);
+        if (c->pp_obs_dev) (void) hipFree(c->pp_obs_dev);
+        c->pp_obs_dev = nullptr;
+        c->pp_obs_rows = 0;
+        HIP_TRY(hipMalloc((void **) &c->pp_obs_dev, sizeof(int16_t) * want * S));
+        c->pp_obs_rows = want;
+    }
+    if (!c->pp_wf_dev) HIP_TRY(hipMalloc((void **) &c->pp_wf_dev, sizeof(float) * S));
+    if (!c->pp_any_dev) HIP_TRY(hipMalloc((void **) &c->pp_any_dev, S));
     return 0;
+}
+
+int pp_check(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4], const slamgpu_particle_assoc *opt) {
+    if (int rc = check_ctx(c)) return rc;
+    if (!opt || !R || nz < 0 || (nz > 0 && !z)) return fail(SLAMGPU_ERR_INVALID, "per-particle association: bad arguments");
+    if (nz > 32767) return fail(SLAMGPU_ERR_CAPACITY, "per-particle association: %d observations in one step (at most 32767)", nz);
+    if (!(opt->p_new > 0.0f) || !(opt->new_share >= 0.0f && opt->new_share <= 1.0f) || opt->census_every < 0)
+        return fail(SLAMGPU_ERR_INVALID, "per-particle association: p_new > 0, 0 <= new_share <= 1, census_every >= 0");
+    if (c->dist || c->cfg.n_particles_global != c->cfg.n_particles || c->pool_used != 0)
+        return fail(SLAMGPU_ERR_INVALID, "per-particle association: single contexts only");
+    if (c->mid_compact)
+        if (int rc = demote_to_plain(c)) return rc;
+    if (c->B.compact)
+        return fail(SLAMGPU_ERR_INVALID, "per-particle association needs plain genealogy rows: create the context with SLAMGPU_FLAG_PARTICLE_MAPS");
+    return 0;
+}
+
+// One observation step in which every particle acts on ITS OWN association (kernels.h: PerParticle): labels [N][nz] are in
+// c->pp_lab_dev (landmark slot, SLAMGPU_ASSOC_NEW or _DISCARD per particle and observation).
+int do_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4], const slamgpu_particle_assoc *opt, const float *normals,
+                       const float *strata, int32_t report[8]) {
+    if (report) memset(report, 0, sizeof(int32_t) * 8);
+    if (int rc = book_pull(c)) return rc;
+    if (int rc = flush_predict(c)) return rc;
+    if (int rc = materialize(c)) return rc;  // plain set: particle k in slot k (the holders census reads it through the genealogy)
+    if (int rc = sync_tables(c)) return rc;
+    const bool tape = c->cfg.rng_mode == SLAMGPU_RNG_TAPE;
+    if (tape && !strata) return fail(SLAMGPU_ERR_INVALID, "TAPE mode needs strata[N] (and normals[3N] for FastSLAM2)");
+    const int N = c->B.n, cap_nf = c->B.cap_nf, nf0 = c->nf;
+    c->B.slot = c->slot;
+    int32_t *first_dev = c->pp_tab_dev, *hold_dev = first_dev + cap_nf, *news_dev = hold_dev + cap_nf, *idn_dev = news_dev + c->pp_nz_cap;
+    const bool census = opt->census_every > 0 && nf0 > 0 && (c->pp_steps % (uint64_t) opt->census_every) == 0;
+    c->pp_steps++;
+    std::vector<int32_t> first((size_t) std::max(nf0, 1)), news((size_t) nz), hold((size_t) std::max(nf0, 1), 1);
+    HIP_TRY(hipMemcpyAsync(c->pp_z_dev, z, sizeof(float) * 2 * (size_t) nz, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) first_dev, 0x7fffffff, (size_t) cap_nf, c->stream));
+    HIP_TRY(hipMemsetAsync(hold_dev, 0, sizeof(int32_t) * (size_t) cap_nf, c->stream));
+    HIP_TRY(hipMemsetAsync(news_dev, 0, sizeof(int32_t) * (size_t) nz, c->stream));
+    {
+        Timed t(c, "particle_census");
+        c->k->pp_census(c->stream, c->pp_lab_dev, N, nz, first_dev, news_dev);
+        if (census) c->k->pp_holders(c->stream, c->B, nf0, hold_dev);
+    }
+    HIP_TRY(hipGetLastError());
+    if (nf0 > 0) HIP_TRY(hipMemcpyAsync(first.data(), first_dev, sizeof(int32_t) * (size_t) nf0, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(news.data(), news_dev, sizeof(int32_t) * (size_t) nz, hipMemcpyDeviceToHost, c->stream));
+    if (census) HIP_TRY(hipMemcpyAsync(hold.data(), hold_dev, sizeof(int32_t) * (size_t) nf0, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+
+    // the packet's re-observed entries: every slot some particle matched, in the order of the first observation that names it
+    std::vector<std::pair<int32_t, int32_t>> touched;
+    for (int l = 0; l < nf0; l++)
+        if (first[(size_t) l] != 0x7fffffff) touched.push_back({first[(size_t) l], l});
+    std::sort(touched.begin(), touched.end());
+    const int m = (int) touched.size();
+    if (c->pp_dead.empty()) c->pp_dead.assign((size_t) cap_nf, 0);
+    if (c->retired.empty()) c->retired.assign((size_t) cap_nf, 0);
+    bool mask_dirty = false;
+    if (census) {
+        // a slot nobody holds any more is dead: out of the association, free for a later landmark
+        for (int l = 0; l < nf0; l++)
+            if (hold[(size_t) l] == 0 && !c->pp_dead[(size_t) l] && first[(size_t) l] == 0x7fffffff) {
+                c->pp_dead[(size_t) l] = 1;
+                c->pp_dead_list.push_back(l);
+                if (!c->retired[(size_t) l]) {
+                    c->retired[(size_t) l] = 1;
+                    c->n_retired++;
+                    mask_dirty = true;
+                }
+                c->box_dirty[(size_t) l] = 1;
+            }
+        std::sort(c->pp_dead_list.begin(), c->pp_dead_list.end(), std::greater<int32_t>());  // back() = lowest dead slot
+    }
+    // new landmarks: an observation enough particles call new gets a slot (a dead one first, then the map grows)
+    const int need = std::max(1, (int) ceil((double) opt->new_share * (double) N));
+    std::vector<int32_t> newk((size_t) nz, -1), idn;
+    int reused = 0, fresh = 0, dropped = 0;
+    for (int j = 0; j < nz; j++) {
+        if (news[(size_t) j] < need) continue;
+        int slot = -1;
+        if (!c->pp_dead_list.empty()) {
+            slot = c->pp_dead_list.back();
+            c->pp_dead_list.pop_back();
+            reused++;
+        } else if (nf0 + fresh < cap_nf) {
+            slot = nf0 + fresh++;
+        } else {
+            dropped++;
+            continue;
+        }
+        newk[(size_t) j] = (int32_t) idn.size();
+        idn.push_back(slot);
+    }
+    const int n = (int) idn.size();
+    if (int rc = pp_reserve(c, nz, (size_t) m + n + 1)) return rc;
+    first_dev = c->pp_tab_dev, hold_dev = first_dev + cap_nf, news_dev = hold_dev + cap_nf, idn_dev = news_dev + c->pp_nz_cap;
+    std::vector<int32_t> uidx((size_t) cap_nf, -1);
+    for (int k = 0; k < m; k++) uidx[(size_t) touched[(size_t) k].second] = k;
+    for (int q = 0; q < n; q++)
+        if (idn[(size_t) q] < nf0) {  // a dead slot comes back into the association
+            const int l = idn[(size_t) q];
+            c->pp_dead[(size_t) l] = 0;
+            if (c->retired[(size_t) l]) {
+                c->retired[(size_t) l] = 0;
+                c->n_retired--;
+                mask_dirty = true;
+            }
+        }
+    if (mask_dirty)
+        if (int rc = retired_upload(c)) return rc;
+
+    const bool need_normals = c->cfg.method == SLAMGPU_FASTSLAM2 && (m > 0 || n > 0);
+    if (tape && need_normals && !normals) return fail(SLAMGPU_ERR_INVALID, "TAPE mode needs normals[3N] and strata[N]");
+    c->obs_step++;
+    // genealogy bookkeeping, as do_update's: every packet entry is written by every particle (updated or copied forward) and moves
+    // to the row this update opens
+    int e_new = -1;
+    std::vector<int32_t> rows_of((size_t) m), left;
+    if (m + n > 0) {
+        e_new = c->free_rows.back();
+        c->free_rows.pop_back();
+    }
+    auto leave_row = [&](int l) {
+        const int r = c->erow[(size_t) l];
+        if (--c->refcnt[(size_t) r] == 0) {
+            rows_remove_live(c, r);
+            left.push_back(r);
+        }
+        c->erow[(size_t) l] = e_new;
+        c->refcnt[(size_t) e_new]++;
+        c->box_dirty[(size_t) l] = 1;
+    };
+    for (int k = 0; k < m; k++) {
+        const int l = touched[(size_t) k].second, r = c->erow[(size_t) l];
+        rows_of[(size_t) k] = r | (c->live_flag[(size_t) l] ? kRowLiveBit : 0) | (r == c->fresh_row ? kRowFreshBit : 0);
+        c->live_flag[(size_t) l] ^= 1;
+        c->seen_step[(size_t) l] = c->obs_step;
+        leave_row(l);
+    }
+    for (int q = 0; q < n; q++) {
+        const int l = idn[(size_t) q];
+        if (l < nf0) {
+            leave_row(l);
+        } else {
+            c->erow[(size_t) l] = e_new;
+            c->refcnt[(size_t) e_new]++;
+            c->box_dirty[(size_t) l] = 1;
+        }
+        c->live_flag[(size_t) l] = 0;  // a new landmark's first records go to buffer 0
+    }
+    const int n_rows = (int) c->live_rows.size();
+    c->tables_dirty = true;
+
+    UpdateArgs U{};
+    U.method = c->cfg.method;
+    U.m = m;
+    U.n = n;
+    U.nf = nf0;
+    U.e_new = e_new;
+    U.n_rows = n_rows;
+    {
+        int top = e_new;
+        for (int r : c->live_rows) top = std::max(top, r);
+        U.live_chunks = (top >> 2) + 1;
+    }
+    U.all_fresh = 0;
+    c->fresh_row = e_new;
+    memcpy(U.R, R, sizeof U.R);
+    {
+        const int slot = (int) (c->pkt_seq++ % kRing);
+        if (c->pkt_ev_used[slot]) HIP_TRY(hipEventSynchronize(c->pkt_ev[slot]));
+        char *ph = c->pkt_host + (size_t) slot * c->pkt_bytes;
+        ObsPacket *hp = reinterpret_cast<ObsPacket *>(ph);
+        hp->m = m;
+        hp->n = n;
+        hp->nf = nf0;
+        hp->n_rows = n_rows;
+        hp->e_new = e_new;
+        hp->status = 0;
+        hp->cap = 0;  // dense layout
+        hp->pad = 0;
+        int32_t *hidf = reinterpret_cast<int32_t *>(hp + 1);
+        float *hzf = reinterpret_cast<float *>(hidf + m);
+        float *hzn = hzf + 2 * m;
+        for (int k = 0; k < m; k++) hidf[k] = touched[(size_t) k].second;
+        memset(hzf, 0, sizeof(float) * 2 * ((size_t) m + n));  // (the observations are per particle: PerParticle::z)
+        int32_t *hrow = reinterpret_cast<int32_t *>(hzn + 2 * n);
+        if (m) memcpy(hrow, rows_of.data(), sizeof(int32_t) * (size_t) m);
+        if (n_rows) memcpy(hrow + m, c->live_rows.data(), sizeof(int32_t) * (size_t) n_rows);
+        const size_t used = sizeof(ObsPacket) + sizeof(int32_t) * (size_t) m + sizeof(float) * 2 * ((size_t) m + n) + sizeof(int32_t) * ((size_t) m + n_rows);
+        char *pd = c->pkt_dev + (size_t) slot * c->pkt_bytes;
+        HIP_TRY(hipMemcpyAsync(pd, ph, used, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(c->pkt_ev[slot], c->stream));
+        c->pkt_ev_used[slot] = true;
+        U.big = reinterpret_cast<const ObsPacket *>(pd);
+    }
+    if (e_new >= 0) {
+        if (c->refcnt[(size_t) e_new] > 0) rows_add_live(c, e_new);
+        else c->free_rows.push_back(e_new);
+    }
+    for (int r : left) c->free_rows.push_back(r);
+
+    // the labels resolved into what the launch reads
+    HIP_TRY(hipMemcpyAsync(first_dev, uidx.data(), sizeof(int32_t) * (size_t) cap_nf, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(news_dev, newk.data(), sizeof(int32_t) * (size_t) nz, hipMemcpyHostToDevice, c->stream));
+    if (n) HIP_TRY(hipMemcpyAsync(idn_dev, idn.data(), sizeof(int32_t) * (size_t) n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // (pageable sources)
+    {
+        Timed t(c, "particle_resolve");
+        c->k->pp_resolve(c->stream, c->pp_lab_dev, N, nz, c->B.ncap, first_dev, news_dev, m, n, opt->p_new, c->cfg.log_weights, c->pp_obs_dev,
+                         c->pp_wf_dev, c->pp_any_dev);
+    }
+    HIP_TRY(hipGetLastError());
+    PerParticle ppa{c->pp_obs_dev, c->pp_z_dev, idn_dev, c->pp_wf_dev, c->pp_any_dev};
+    c->pp_launch = &ppa;
+    const int rc = issue_update(c, U, fresh, n_rows, need_normals, normals, strata, false);
+    c->pp_launch = nullptr;
+    if (report) {
+        report[0] = m;
+        report[1] = n;
+        report[2] = reused;
+        report[3] = dropped;
+        report[4] = c->nf;
+        report[5] = (int32_t) c->pp_dead_list.size();
+        report[6] = need;
+        report[7] = census ? 1 : 0;
+    }
+    return rc;
+}
+}  // namespace
+
+int slamgpu_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4], const slamgpu_particle_assoc *opt, const float *normals,
+                            const float *strata, int32_t report[8]) {
+    if (report) memset(report, 0, sizeof(int32_t) * 8);
+    if (int rc = pp_check(c, z, nz, R, opt)) return rc;
+    if (opt->mode < SLAMGPU_ASSOC_AUTO || opt->mode > SLAMGPU_ASSOC_GRID) return fail(SLAMGPU_ERR_INVALID, "unknown association mode %d", opt->mode);
+    if (nz == 0) return 0;  // (no observation, no update: fastslam2wrapper.cpp:84-95)
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = pp_reserve(c, nz, 1)) return rc;
+    if (int rc = associate_impl(c, z, nz, R, opt->gate_reject, opt->gate_augment, opt->mode, nullptr, nullptr, nullptr, nullptr, c->pp_lab_dev)) return rc;
+    return do_update_particle(c, z, nz, R, opt, normals, strata, report);
+}
+
+int slamgpu_update_labels(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4], const int32_t *labels, const slamgpu_particle_assoc *opt,
+                          const float *normals, const float *strata, int32_t report[8]) {
+    if (report) memset(report, 0, sizeof(int32_t) * 8);
+    if (int rc = pp_check(c, z, nz, R, opt)) return rc;
+    if (nz > 0 && !labels) return fail(SLAMGPU_ERR_INVALID, "slamgpu_update_labels: labels[N * nz]");
+    if (nz == 0) return 0;
+    if (int rc = book_pull(c)) return rc;
+    const size_t count = (size_t) c->B.n * (size_t) nz;
+    for (size_t q = 0; q < count; q++)
+        if (labels[q] >= c->nf || labels[q] < SLAMGPU_ASSOC_DISCARD)
+            return fail(SLAMGPU_ERR_INVALID, "slamgpu_update_labels: label %d of particle %d, observation %d (%d landmarks)", (int) labels[q], (int) (q / nz), (int) (q % nz), c->nf);
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    if (int rc = pp_reserve(c, nz, 1)) return rc;
+    HIP_TRY(hipMemcpyAsync(c->pp_lab_dev, labels, sizeof(int32_t) * count, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // (pageable source)
+    return do_update_particle(c, z, nz, R, opt, normals, strata, report);
 }
 
 int slamgpu_num_landmarks(slamgpu_ctx *c) {
@@ -3284,6 +3616,8 @@ int slamgpu_upload(slamgpu_ctx *c, int32_t nf, const float *xv, const float *Pv9
     rows_reset(c, nf);
     std::fill(c->box_dirty.begin(), c->box_dirty.end(), 1);
     // (a new particle set is a new map: nothing of it has been retired from the association)
+    c->pp_dead.clear();
+    c->pp_dead_list.clear();
     if (c->n_retired > 0) {
         std::fill(c->retired.begin(), c->retired.end(), 0);
         c->n_retired = 0;

@@ -1,7 +1,7 @@
 // The body of one observation step: textually included by update_kernel (one step per launch; the kernel's by-value parameters
 // are used in place: taking references to them would make the compiler keep private copies of the argument structs) and by
-// persist_step (one iteration of the persistent loop).  Names the including function provides: METHOD, MODE, BIG, PERSIST
-// (constants); h_tot, h_ctrl, h_front, h_nb, h_slot, h_grid, h_flags, B, PA, U, rng, ws (update_kernel's parameters, or what stands
+// persist_step (one iteration of the persistent loop).  Names the including function provides: METHOD, MODE, BIG, PERSIST,
+// PP (constants); h_tot, h_ctrl, h_front, h_nb, h_slot, h_grid, h_flags, B, PA, U, rng, ws, ppa (update_kernel's parameters, or what stands
 // in for them in an iteration); the macros STEP_WPAR (ws.wpar), STEP_PLAN (U.plan_inline != 0) and STEP_FRONT (U.front), which a per-step
 // launch reads in place (a local copy of each costs the distributed variants a scalar register they do not have); qe (LDS copy of the iteration's queue
 // entry, PERSIST only); carry (StepCarry, PERSIST only).
@@ -480,6 +480,13 @@
         };
         auto buf_of = [&](int k) -> int { return (lrow[k] >> 30) & 1; };
         const float r00 = U.R[0], r01 = U.R[1], r10 = U.R[2], r11 = U.R[3];
+        // Per-particle association (PP; kernels.h: PerParticle): packet entry k is a landmark SOME particle matched; this particle's
+        // observation of it is pp_j(k) (-1: it leaves the landmark alone and copies its record forward).  pp_any: bit 0 it matched a
+        // landmark, bit 1 it opens one; neither: the step leaves its pose and Pv alone (a particle without an observation is not
+        // sampled: fastslam2.cpp:21-48 runs only for a non-empty z).
+        [[maybe_unused]] int pp_any = 3;
+        if constexpr (PP) pp_any = (int) ppa.any[i];
+        [[maybe_unused]] auto pp_j = [&](int k) -> int { return (int) ppa.obs[(size_t) k * S + i]; };
         // Stage the first KS re-observed landmarks in LDS with all their loads in flight together (one HBM latency instead
         // of one per landmark); both passes then read LDS.  Measured before this: 38 % of the wave's cycles were s_waitcnt
         // stalls (profiles/rocprof_sq_counters_r01.txt).  Unconditional loads (index clamped to the last landmark): no
@@ -709,8 +716,15 @@
                 Sym3 P = {q00, q10, q11, q20, q21, q22};
                 const L3r L0 = llt3r(P);  // factor of Pv0 for the prior term (:366)
                 auto first_pass = [&](int k, float4 la, float lb) {
-                    const Obs2 o = observe2(x, y, th, la.x, la.y, la.z, la.w, lb, r00, rl, r11);
-                    proposal_update(x, y, th, P, o, zf[2 * k] - o.zp0, wrap_pi(zf[2 * k + 1] - o.zp1));
+                    if constexpr (PP) {
+                        const int j = pp_j(k);
+                        if (j < 0) return;
+                        const Obs2 o = observe2(x, y, th, la.x, la.y, la.z, la.w, lb, r00, rl, r11);
+                        proposal_update(x, y, th, P, o, ppa.z[2 * j] - o.zp0, wrap_pi(ppa.z[2 * j + 1] - o.zp1));
+                    } else {
+                        const Obs2 o = observe2(x, y, th, la.x, la.y, la.z, la.w, lb, r00, rl, r11);
+                        proposal_update(x, y, th, P, o, zf[2 * k] - o.zp0, wrap_pi(zf[2 * k + 1] - o.zp1));
+                    }
                 };
                 if constexpr (BIG) {
                     pipeline(first_pass);
@@ -731,17 +745,29 @@
                 }
                 SLAM_STAMP(6);  // proposal pass done
                 const L3r Lp = llt3r(P);
-                const float xs = ffma(Lp.l00, g0, x);
-                const float ys = ffma(Lp.l11, g1, ffma(Lp.l10, g0, y));
-                const float ths = ffma(Lp.l22, g2, ffma(Lp.l21, g1, ffma(Lp.l20, g0, th)));
+                // (PP: a particle this step does not concern is not sampled)
+                const float xs = (PP && pp_any == 0) ? x : ffma(Lp.l00, g0, x);
+                const float ys = (PP && pp_any == 0) ? y : ffma(Lp.l11, g1, ffma(Lp.l10, g0, y));
+                const float ths = (PP && pp_any == 0) ? th : ffma(Lp.l22, g2, ffma(Lp.l21, g1, ffma(Lp.l20, g0, th)));
                 float lik = 1.0f;
                 double dl = 0.0;  // log-weight contexts: sum of the log-likelihoods (double: ~1.3 k terms of ~4.5 at config 5)
                 auto second_pass = [&](int k, float4 la, float lb) {
-                    const Obs2 o = observe2(xs, ys, ths, la.x, la.y, la.z, la.w, lb, r00, rl, r11);
-                    const Gauss2 g = feature_update2(la.x, la.y, la.z, la.w, lb, o, zf[2 * k] - o.zp0, wrap_pi(zf[2 * k + 1] - o.zp1));
-                    if (logw) dl += (double) (g.E + __logf(g.norm));
-                    else lik *= __expf(g.E) * g.norm;
-                    store_lmk(idf[k], buf_of(k), la, lb);
+                    if constexpr (PP) {
+                        const int j = pp_j(k);
+                        if (j >= 0) {
+                            const Obs2 o = observe2(xs, ys, ths, la.x, la.y, la.z, la.w, lb, r00, rl, r11);
+                            const Gauss2 g = feature_update2(la.x, la.y, la.z, la.w, lb, o, ppa.z[2 * j] - o.zp0, wrap_pi(ppa.z[2 * j + 1] - o.zp1));
+                            if (logw) dl += (double) (g.E + __logf(g.norm));
+                            else lik *= __expf(g.E) * g.norm;
+                        }  // (else: not this particle's landmark in this step: the record moves on unchanged)
+                        store_lmk(idf[k], buf_of(k), la, lb);
+                    } else {
+                        const Obs2 o = observe2(xs, ys, ths, la.x, la.y, la.z, la.w, lb, r00, rl, r11);
+                        const Gauss2 g = feature_update2(la.x, la.y, la.z, la.w, lb, o, zf[2 * k] - o.zp0, wrap_pi(zf[2 * k + 1] - o.zp1));
+                        if (logw) dl += (double) (g.E + __logf(g.norm));
+                        else lik *= __expf(g.E) * g.norm;
+                        store_lmk(idf[k], buf_of(k), la, lb);
+                    }
                 };
                 if constexpr (BIG) {
                     pipeline(second_pass);
@@ -763,14 +789,28 @@
                 const float E = gauss3_exponent(L0, x0 - xs, y0 - ys, wrap_pi(th0 - ths)) -
                                 gauss3_exponent(Lp, x - xs, y - ys, wrap_pi(th - ths));
                 const float ratio = ((Lp.l00 * Lp.l11) * Lp.l22) * ((L0.r0 * L0.r1) * L0.r2);
-                if (logw) w = (float) ((double) w + dl + (double) (E + __logf(ratio)));
-                else w = w * lik * (__expf(E) * ratio);
-                x = xs;
-                y = ys;
-                th = ths;
-                q00 = q10 = q11 = q20 = q21 = q22 = 0.0f;
-                pose_dirty = true;
-            } else if (n > 0) {
+                if constexpr (PP) {
+                    if (pp_any & 1) {  // (no landmark matched: the proposal IS the prior, the two Gaussians cancel)
+                        if (logw) w = (float) ((double) w + dl + (double) (E + __logf(ratio)));
+                        else w = w * lik * (__expf(E) * ratio);
+                    }
+                    if (pp_any != 0) {
+                        x = xs;
+                        y = ys;
+                        th = ths;
+                        q00 = q10 = q11 = q20 = q21 = q22 = 0.0f;
+                        pose_dirty = true;
+                    }
+                } else {
+                    if (logw) w = (float) ((double) w + dl + (double) (E + __logf(ratio)));
+                    else w = w * lik * (__expf(E) * ratio);
+                    x = xs;
+                    y = ys;
+                    th = ths;
+                    q00 = q10 = q11 = q20 = q21 = q22 = 0.0f;
+                    pose_dirty = true;
+                }
+            } else if (n > 0 && (!PP || pp_any != 0)) {
                 const L3r L = llt3r(Sym3{q00, q10, q11, q20, q21, q22});
                 x = ffma(L.l00, g0, x);
                 y = ffma(L.l11, g1, ffma(L.l10, g0, y));
@@ -781,8 +821,19 @@
             for (int k = 0; k < n; k++) {
                 float4 la;
                 float lb;
-                add_feature_fast(x, y, th, zn[2 * k], zn[2 * k + 1], r00, r01, r10, r11, la.x, la.y, la.z, la.w, lb);
-                store_new(nf + k, la, lb);
+                if constexpr (PP) {
+                    const int j = pp_j(m + k);
+                    if (j >= 0) {
+                        add_feature_fast(x, y, th, ppa.z[2 * j], ppa.z[2 * j + 1], r00, r01, r10, r11, la.x, la.y, la.z, la.w, lb);
+                    } else {  // the particle does not open this landmark: an absent record (kernels.h: kAbsent)
+                        la = make_float4(kAbsent, kAbsent, 0.0f, 0.0f);
+                        lb = 0.0f;
+                    }
+                    store_new(ppa.idn[k], la, lb);
+                } else {
+                    add_feature_fast(x, y, th, zn[2 * k], zn[2 * k + 1], r00, r01, r10, r11, la.x, la.y, la.z, la.w, lb);
+                    store_new(nf + k, la, lb);
+                }
             }
         } else
 #endif
@@ -804,12 +855,17 @@
                 // running proposal covariance, full 3x3 (the reference's Pv stays a full matrix inside the loop)
                 float P[9] = {q00, q10, q20, q10, q11, q21, q20, q21, q22};
                 auto first_pass = [&](int k, float4 la, float lb) {
+                    [[maybe_unused]] int jo = 0;  // (PP: this particle's observation of the landmark; the z reads below stay where they were)
+                    if constexpr (PP) {
+                        jo = pp_j(k);
+                        if (jo < 0) return;
+                    }
                     // Jacobians at the running mean (fastslam2.cpp:320,:348)
                     Jac j = jacobian(x, y, th, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
                     float s00, s01, s10, s11;
                     inverse2(j.s00, j.s01, j.s10, j.s11, s00, s01, s10, s11);  // Sfi (:324)
-                    const float v0 = zf[2 * k] - j.zp0;
-                    const float v1 = trig_offset(zf[2 * k + 1] - j.zp1);
+                    const float v0 = (PP ? ppa.z[2 * jo] : zf[2 * k]) - j.zp0;
+                    const float v1 = trig_offset((PP ? ppa.z[2 * jo + 1] : zf[2 * k + 1]) - j.zp1);
                     float Pinv[9];
                     llt_solve_identity3(llt3(P[0], P[3], P[4], P[6], P[7], P[8]), Pinv);  // (:335)
                     // T1 = Hv^T * Sfi (3x2), T2 = T1 * Hv (3x3); Hv = [[hv00 hv01 0],[hv10 hv11 -1]]
@@ -859,15 +915,27 @@
                 // sample from the proposal (:353) ; weight terms (:360-367)
                 const L3 Lp = llt3(P[0], P[3], P[4], P[6], P[7], P[8]);
                 float xs = x, ys = y, ths = th;
-                mvgauss3(xs, ys, ths, Lp, g0, g1, g2);
+                if constexpr (PP) {
+                    if (pp_any != 0) mvgauss3(xs, ys, ths, Lp, g0, g1, g2);  // (a particle this step does not concern is not sampled)
+                } else {
+                    mvgauss3(xs, ys, ths, Lp, g0, g1, g2);
+                }
                 const float a0 = x0 - xs, a1 = y0 - ys, a2 = trig_offset(th0 - ths);
                 const float b0 = x - xs, b1 = y - ys, b2 = trig_offset(th - ths);
                 float lik = 1.0f;
                 double dl = 0.0;  // log-weight contexts: sum of gaussEvaluate(.., logflag = 1)
                 auto second_pass = [&](int k, float4 la, float lb) {
+                    [[maybe_unused]] int jo = 0;
+                    if constexpr (PP) {
+                        jo = pp_j(k);
+                        if (jo < 0) {  // (not this particle's landmark in this step: the record moves on unchanged)
+                            store_lmk(idf[k], buf_of(k), la, lb);
+                            return;
+                        }
+                    }
                     Jac j = jacobian(xs, ys, ths, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
-                    const float v0 = zf[2 * k] - j.zp0;
-                    const float v1 = trig_offset(zf[2 * k + 1] - j.zp1);
+                    const float v0 = (PP ? ppa.z[2 * jo] : zf[2 * k]) - j.zp0;
+                    const float v1 = trig_offset((PP ? ppa.z[2 * jo + 1] : zf[2 * k + 1]) - j.zp1);
                     if (logw) dl += (double) gauss2_log(v0, v1, j.s00, j.s10, j.s11);
                     else lik = lik * gauss2(v0, v1, j.s00, j.s10, j.s11);
                     cholesky_update2(la.x, la.y, la.z, la.w, lb, v0, v1, r00, r01, r10, r11, j.hf00, j.hf01, j.hf10, j.hf11);
@@ -887,7 +955,10 @@
                         second_pass(k, la, lb);
                     }
                 }
-                if (logw) {
+                // (PP: no landmark matched: the proposal IS the prior, the two Gaussians cancel; nothing at all: pose and Pv stay)
+                const bool weigh = !PP || (pp_any & 1) != 0, moved = !PP || pp_any != 0;
+                if (!weigh) {
+                } else if (logw) {
                     const float prior = gauss3_log(a0, a1, a2, q00, q10, q11, q20, q21, q22);
                     const float prop = gauss3_log(b0, b1, b2, P[0], P[3], P[4], P[6], P[7], P[8]);
                     w = (float) (((double) w + dl) + ((double) prior - (double) prop));
@@ -896,12 +967,14 @@
                     const float prop = gauss3(b0, b1, b2, P[0], P[3], P[4], P[6], P[7], P[8]);
                     w = w * lik * prior / prop;
                 }
-                x = xs;
-                y = ys;
-                th = ths;
-                q00 = q10 = q11 = q20 = q21 = q22 = 0.0f;
-                pose_dirty = true;
-            } else if (n > 0) {
+                if (moved) {
+                    x = xs;
+                    y = ys;
+                    th = ths;
+                    q00 = q10 = q11 = q20 = q21 = q22 = 0.0f;
+                    pose_dirty = true;
+                }
+            } else if (n > 0 && (!PP || pp_any != 0)) {
                 // no re-observed landmark: sample the pose from the predicted Gaussian (fastslam2.cpp:36-42)
                 mvgauss3(x, y, th, llt3(q00, q10, q11, q20, q21, q22), g0, g1, g2);
                 q00 = q10 = q11 = q20 = q21 = q22 = 0.0f;
@@ -919,12 +992,25 @@
                 // choleskyUpdate is the same Kalman update.  ~100 VALU instructions per landmark instead of ~450 (IEEE divisions,
                 // libm atan2f / expf / sqrtf): 1.2 -> ~0.3 us per landmark for a wave that has its SIMD to itself.
                 const float rl1 = 0.5f * (r01 + r10);
+                // (PP: the same operations on the particle's own observation; the other instantiations keep their text to the letter --
+                // routing their z through a pair of temporaries changed the register allocation of the persistent loop)
                 auto one_pass = [&](int k, float4 la, float lb) {
-                    const Obs2 o = observe2(x, y, th, la.x, la.y, la.z, la.w, lb, r00, rl1, r11);
-                    const Gauss2 g = feature_update2(la.x, la.y, la.z, la.w, lb, o, zf[2 * k] - o.zp0, wrap_pi(zf[2 * k + 1] - o.zp1));
-                    if (logw) dl += (double) (g.E + __logf(g.norm));
-                    else wp *= __expf(g.E) * g.norm;
-                    store_lmk(idf[k], buf_of(k), la, lb);
+                    if constexpr (PP) {
+                        const int j = pp_j(k);
+                        if (j >= 0) {
+                            const Obs2 o = observe2(x, y, th, la.x, la.y, la.z, la.w, lb, r00, rl1, r11);
+                            const Gauss2 g = feature_update2(la.x, la.y, la.z, la.w, lb, o, ppa.z[2 * j] - o.zp0, wrap_pi(ppa.z[2 * j + 1] - o.zp1));
+                            if (logw) dl += (double) (g.E + __logf(g.norm));
+                            else wp *= __expf(g.E) * g.norm;
+                        }  // (else: not this particle's landmark in this step: the record moves on unchanged)
+                        store_lmk(idf[k], buf_of(k), la, lb);
+                    } else {
+                        const Obs2 o = observe2(x, y, th, la.x, la.y, la.z, la.w, lb, r00, rl1, r11);
+                        const Gauss2 g = feature_update2(la.x, la.y, la.z, la.w, lb, o, zf[2 * k] - o.zp0, wrap_pi(zf[2 * k + 1] - o.zp1));
+                        if (logw) dl += (double) (g.E + __logf(g.norm));
+                        else wp *= __expf(g.E) * g.norm;
+                        store_lmk(idf[k], buf_of(k), la, lb);
+                    }
                 };
                 // landmarks k and k + 1 in one basic block: the two updates are independent (only the weight product runs
                 // through both, in landmark order), and a wave that has its SIMD to itself issues a DEPENDENT instruction
@@ -947,9 +1033,17 @@
                 };
 #else
                 auto one_pass = [&](int k, float4 la, float lb) {
+                    [[maybe_unused]] int jo = 0;
+                    if constexpr (PP) {
+                        jo = pp_j(k);
+                        if (jo < 0) {  // (not this particle's landmark in this step: the record moves on unchanged)
+                            store_lmk(idf[k], buf_of(k), la, lb);
+                            return;
+                        }
+                    }
                     Jac j = jacobian(x, y, th, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
-                    const float v0 = zf[2 * k] - j.zp0;
-                    const float v1 = trig_offset(zf[2 * k + 1] - j.zp1);
+                    const float v0 = (PP ? ppa.z[2 * jo] : zf[2 * k]) - j.zp0;
+                    const float v1 = trig_offset((PP ? ppa.z[2 * jo + 1] : zf[2 * k + 1]) - j.zp1);
                     const float den = (float) (2 * kPi * (double) sqrtf(determinant2(j.s00, j.s01, j.s10, j.s11)));
                     float i00, i01, i10, i11;
                     inverse2(j.s00, j.s01, j.s10, j.s11, i00, i01, i10, i11);
@@ -1002,8 +1096,19 @@
         for (int k = 0; k < n; k++) {
             float4 la;
             float lb;
-            add_feature(x, y, th, zn[2 * k], zn[2 * k + 1], r00, r01, r10, r11, la.x, la.y, la.z, la.w, lb);
-            store_new(nf + k, la, lb);
+            if constexpr (PP) {
+                const int j = pp_j(m + k);
+                if (j >= 0) {
+                    add_feature(x, y, th, ppa.z[2 * j], ppa.z[2 * j + 1], r00, r01, r10, r11, la.x, la.y, la.z, la.w, lb);
+                } else {  // the particle does not open this landmark: an absent record (kernels.h: kAbsent)
+                    la = make_float4(kAbsent, kAbsent, 0.0f, 0.0f);
+                    lb = 0.0f;
+                }
+                store_new(ppa.idn[k], la, lb);
+            } else {
+                add_feature(x, y, th, zn[2 * k], zn[2 * k + 1], r00, r01, r10, r11, la.x, la.y, la.z, la.w, lb);
+                store_new(nf + k, la, lb);
+            }
         }
         // Row consolidation (slamgpu.cpp: do_update): landmarks out of view whose rows have gone stale are rewritten, unchanged,
         // into this particle's own slot of the row's other buffer and join the row this update opens -- one 40-byte move per
@@ -1057,6 +1162,7 @@
         } else if (e_new >= 0) {
             genO[gen_index(!BIG, S, e_new, (size_t) i)] = B.first + i;
         }
+        if constexpr (PP) w = logw ? w + ppa.wf[i] : w * ppa.wf[i];  // the observations this particle leaves unexplained (PerParticle::wf)
         nt_store(&poseAo[i], make_float4(x, y, th, w));
         if (METHOD == 2 && pose_dirty) {
             nt_store(&poseBo[i], make_float4(q00, q10, q11, q20));

@@ -1,0 +1,184 @@
+"""Per-particle data association carried into the update (slamgpu_update_particle / slamgpu_update_labels; SURVEY.md
+section 8(f4): EKFSLAM::dataAssociate, ekfslam.cpp:151-189, applied by every particle to a map of its own, which the reference's
+Particle lets grow per particle, Particle.cpp:61-73).  The reference has no FastSLAM implementation of it, so the pins are:
+  - particles that all agree with the known association: the step is slamgpu_update's, bit for bit (fastslam{1,2}.cpp's update);
+  - particles that disagree: every particle's pose, covariance and landmarks are those of a filter in which EVERYBODY made that
+    particle's decisions (the per-particle arithmetic does not know about the other particles), bit for bit, slots it did not
+    open are absent, and the weight of an unexplained observation is the stated factor;
+  - whole runs: the map of the best particle against the truth, beside a run with the known association."""
+import numpy as np
+import pytest
+
+from conftest import sim_args
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+NEW, DISCARD = -1, -2
+
+
+@pytest.fixture(scope="module")
+def sg():
+    import slam_amd
+    assert slam_amd.device_count() >= 1
+    return slam_amd
+
+
+def _tape(method, n, steps, seed=3):
+    from slam_amd import host
+    return host.make_tape(sim_args("example_webmap", method, n, seed), max_obs=steps)
+
+
+def _same(a, b, what):
+    for k in ("xv", "Pv", "w", "xf", "Pf"):
+        x, y = np.asarray(a[k]), np.asarray(b[k])
+        assert x.shape == y.shape, (what, k, x.shape, y.shape)
+        assert np.array_equal(x, y, equal_nan=True), (what, k, int((x != y).sum()))
+
+
+def _predicts(s, st, tape):
+    for V, G, phi in np.array(st["controls"], f32).reshape(-1, 3):
+        s.predict(float(V), float(G), tape["Q"], float(tape["dt"]), float(phi))
+
+
+@pytest.mark.parametrize("method,name", [(2, "FASTSLAM2"), (1, "FASTSLAM1")])
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+def test_unanimous_particles_take_the_known_association_step(sg, method, name, math_mode):
+    """Every particle carries the labels dataAssociationKnown would give (core.cpp:91-120): 60 steps of example_webmap through
+    slamgpu_update_labels leave the state slamgpu_update leaves, bit for bit (poses, covariances, weights, every landmark record,
+    Neff and the resampling decisions) -- on plain rows and against the compact layout the known association runs on."""
+    N, steps = 1000, 60
+    tape = _tape(name, N, steps)
+    kw = dict(method=method, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=11, math_mode=math_mode)
+    a = sg.SlamGpu(N, tape["nlm"], **kw)
+    b = sg.SlamGpu(N, tape["nlm"], particle_maps=True, **kw)
+    for t, st in enumerate(tape["steps"]):
+        zf, zn = np.array(st["zf"], f32).reshape(-1, 2), np.array(st["zn"], f32).reshape(-1, 2)
+        idf = np.array(st["idf"], np.int32)
+        _predicts(a, st, tape)
+        _predicts(b, st, tape)
+        if len(zf) + len(zn) == 0:
+            continue
+        a.update(zf, idf, zn, tape["R"])
+        lab = np.tile(np.concatenate([idf, np.full(len(zn), NEW, np.int32)]), (N, 1))
+        rep = b.update_labels(np.concatenate([zf, zn]), tape["R"], lab, p_new=1.0, census_every=4)
+        assert rep["rewritten"] == len(zf) and rep["opened"] == len(zn) and rep["dropped"] == 0 and rep["dead"] == 0, (t, rep)
+        a.estimate_async()
+        b.estimate_async()
+        if t % 20 == 19:
+            _same(a.download(), b.download(), "step %d" % t)
+    ea, na, ra = a.history_fetch()
+    eb, nb, rb = b.history_fetch()
+    da, db = a.download(), b.download()
+    a.close()
+    b.close()
+    assert ra.any(), "the run never resampled: the genealogy was not exercised"
+    assert np.array_equal(ea, eb) and np.array_equal(na, nb) and np.array_equal(ra, rb)
+    _same(da, db, "end of the run")
+    assert da["nf"] == db["nf"] >= 6
+
+
+def _group_labels(N, idf, n_new, nf):
+    """labels [N, nz] for observations [re-observed.., new..]: four kinds of particle"""
+    nz = len(idf) + n_new
+    lab = np.empty((N, nz), np.int32)
+    base = np.concatenate([idf, np.full(n_new, NEW, np.int32)])
+    for i in range(N):
+        v = base.copy()
+        kind = i % 4
+        if kind == 1:      # ignores the first observation, does not open the new landmarks
+            v[0] = DISCARD
+            v[len(idf):] = DISCARD
+        elif kind == 2 and len(idf) >= 2:   # matches the first observation with the SECOND observation's landmark: two claims on it
+            v[0] = idf[1]
+        elif kind == 3:    # calls everything it sees new (opens nothing already there) -- or, with nothing else, ignores the step
+            v[:] = DISCARD
+        lab[i] = v
+    return lab
+
+
+@pytest.mark.parametrize("method,name", [(2, "FASTSLAM2"), (1, "FASTSLAM1")])
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+def test_particles_that_disagree_each_take_their_own_step(sg, method, name, math_mode):
+    """After 20-odd agreed steps the particles split four ways over one step (ignore an observation; claim one landmark twice; ignore
+    everything; the known association).  Every particle's pose, Pv and landmark records must be those of a filter in which ALL
+    particles made its decisions -- run here through slamgpu_update with that kind's (zf, idf, zn), from the same uploaded state --
+    bit for bit; slots a particle did not open hold the absent record (NaN); a particle nothing concerns keeps pose and Pv; and
+    halving p_new halves a particle's weight once per observation it left unexplained."""
+    N = 1024
+    tape = _tape(name, N, 200)
+    # the first step past the 20th with at least two re-observed landmarks and a new one: the agreed steps run up to it
+    warm = next(t for t, st in enumerate(tape["steps"]) if t >= 20 and len(st["idf"]) >= 2 and len(np.array(st["zn"]).reshape(-1, 2)) >= 1)
+    # (the agreed steps resample as usual; the step under test does not, so that particle i stays particle i in every run)
+    kw = dict(method=method, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=5, math_mode=math_mode, resample=False)
+    base = sg.SlamGpu(N, tape["nlm"], particle_maps=True, **dict(kw, resample=True))
+    for st in tape["steps"][:warm]:
+        _predicts(base, st, tape)
+        zf, zn = np.array(st["zf"], f32).reshape(-1, 2), np.array(st["zn"], f32).reshape(-1, 2)
+        if len(zf) + len(zn):
+            base.update(zf, np.array(st["idf"], np.int32), zn, tape["R"])
+    pick = tape["steps"][warm]
+    state = base.download()
+    nf = state["nf"]
+    base.close()
+    zf, zn = np.array(pick["zf"], f32).reshape(-1, 2), np.array(pick["zn"], f32).reshape(-1, 2)
+    idf = np.array(pick["idf"], np.int32)
+    z = np.concatenate([zf, zn])
+    lab = _group_labels(N, idf, len(zn), nf)
+
+    def run(fn, **extra):
+        s = sg.SlamGpu(N, tape["nlm"], particle_maps=True, **dict(kw, **extra))
+        s.upload(state)
+        _predicts(s, pick, tape)
+        out = fn(s)
+        d = s.download()
+        s.close()
+        return d, out
+
+    got, rep = run(lambda s: s.update_labels(z, tape["R"], lab, p_new=1.0, census_every=0))
+    half, _ = run(lambda s: s.update_labels(z, tape["R"], lab, p_new=0.5, census_every=0))
+    assert rep["rewritten"] == len(idf) and rep["opened"] == len(zn) and rep["slots"] == nf + len(zn), rep
+    # what each kind of particle did, as a known-association step of everybody.  One observation per landmark and particle (the
+    # first to claim it); the packet lists the landmarks in the order of the first observation that names them over ALL particles
+    # (ties: by slot), and that is the order every particle meets them in
+    claims, first = {}, {}
+    for kind in range(4):
+        c = {}
+        for j, l in enumerate(lab[kind]):
+            if l >= 0 and l not in c:
+                c[int(l)] = j
+                first[int(l)] = min(first.get(int(l), 1 << 30), j)
+        claims[kind] = c
+    order = sorted(first, key=lambda l: (first[l], l))
+    kinds, unexplained = {}, {}
+    for kind in range(4):
+        ls = [l for l in order if l in claims[kind]]
+        opens = [j for j in range(len(idf), len(z)) if lab[kind][j] == NEW]
+        kinds[kind] = (z[[claims[kind][l] for l in ls]].reshape(-1, 2), np.array(ls, np.int32), z[opens].reshape(-1, 2))
+        unexplained[kind] = len(z) - len(ls)
+    assert len(kinds[0][1]) == len(idf) and len(kinds[2][1]) == len(idf) - 1 and len(kinds[3][1]) == 0 and unexplained[3] == len(z)
+    for kind, (kzf, kidf, kzn) in kinds.items():
+        sel = np.arange(N) % 4 == kind
+        if len(kzf) + len(kzn) == 0:
+            exp, _ = run(lambda s: None)
+        else:
+            exp, _ = run(lambda s: s.update(kzf, kidf, kzn, tape["R"]))
+        assert np.array_equal(got["xv"][sel], exp["xv"][sel]), kind
+        assert np.array_equal(got["Pv"][sel], exp["Pv"][sel]), kind
+        # landmarks the kind holds: the expected run's; (kind 1 / 3 did not open the new slots: absent)
+        nfe = exp["nf"]
+        assert np.array_equal(got["xf"][sel][:, :nfe], exp["xf"][sel][:, :nfe]), kind
+        assert np.array_equal(got["Pf"][sel][:, :nfe], exp["Pf"][sel][:, :nfe]), kind
+        if nfe < rep["slots"]:
+            assert np.isnan(got["xf"][sel][:, nfe:rep["slots"]]).all(), kind
+        # weights: proportional inside the kind (each run normalises by its own total) ...
+        wg, we = got["w"][sel].astype(np.float64), exp["w"][sel].astype(np.float64)
+        ok = wg > 0  # (a particle that matched an observation with the wrong landmark ends at weight 0 in linear weights, both ways)
+        assert np.array_equal(ok, we > 0), kind
+        assert kind == 2 or ok.all(), kind
+        if ok.any():
+            assert np.allclose(wg[ok] / wg[ok].sum(), we[ok] / we[ok].sum(), rtol=2e-5, atol=0), kind
+            # ... and the unexplained observations cost p_new each
+            ratio = half["w"][sel].astype(np.float64)[ok] / wg[ok]
+            ref = (half["w"][0].astype(np.float64) / got["w"][0].astype(np.float64)) * 0.5 ** (unexplained[kind] - unexplained[0])
+            assert np.allclose(ratio, ref, rtol=2e-5), (kind, ratio[:3], ref)
+    assert np.array_equal(half["xv"], got["xv"]) and np.array_equal(half["xf"], got["xf"], equal_nan=True)
