@@ -326,6 +326,14 @@ typedef struct slamgpu_particle_assoc {
     float new_share;                 /* 0: one particle is enough to open a landmark */
     float p_new;                     /* > 0 */
     int32_t census_every;            /* 0: never */
+    /* The EXCLUSION rule (excl_base + excl_per_m = 0: off, the gates alone decide).  The gates measure an observation against
+     * S = Hf Pf Hf^T + R and know nothing of the particle's own pose error (the EKF's S carries it, ekfslam.cpp:160-176; a
+     * particle's pose is a point), so a particle a metre off calls an observation of a mapped landmark new and opens a duplicate
+     * beside it.  With the rule on, an observation no landmark gates is placed in the world from the particle's pose; if a
+     * landmark the particle holds lies within excl_base + excl_per_m * range [m] of that point the observation cannot be new: it
+     * is matched with that landmark when no other lies within unique_ratio times the distance, and discarded otherwise.
+     * SLAMGPU_ASSOC_EXHAUSTIVE / _AUTO (which then scans exhaustively) only. */
+    float excl_base, excl_per_m, unique_ratio;
 } slamgpu_particle_assoc;
 int slamgpu_update_particle(slamgpu_ctx *ctx, const float *z, int32_t nz, const float R[4], const slamgpu_particle_assoc *opt,
                             const float *normals, const float *strata, int32_t report[8]);

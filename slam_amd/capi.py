@@ -41,7 +41,7 @@ class SlamGpuError(RuntimeError):
 
 class ParticleAssoc(C.Structure):  # slamgpu_particle_assoc
     _fields_ = [("gate_reject", C.c_float), ("gate_augment", C.c_float), ("mode", C.c_int32), ("new_share", C.c_float), ("p_new", C.c_float),
-                ("census_every", C.c_int32)]
+                ("census_every", C.c_int32), ("excl_base", C.c_float), ("excl_per_m", C.c_float), ("unique_ratio", C.c_float)]
 
 
 class Config(C.Structure):
@@ -751,17 +751,18 @@ class SlamGpu:
 
     _REPORT = ("rewritten", "opened", "reused", "dropped", "slots", "dead", "need", "census")
 
-    def _particle_opt(self, gate_reject, gate_augment, mode, new_share, p_new, census_every):
+    def _particle_opt(self, gate_reject, gate_augment, mode, new_share, p_new, census_every, excl=(0.0, 0.0, 2.0)):
         o = ParticleAssoc()
+        o.excl_base, o.excl_per_m, o.unique_ratio = (float(v) for v in excl)
         o.gate_reject, o.gate_augment, o.mode = gate_reject, gate_augment, int(mode)
         o.new_share, o.p_new, o.census_every = new_share, p_new, int(census_every)
         return o
 
     def update_particle(self, z, R, gate_reject=4.0, gate_augment=25.0, mode=ASSOC_AUTO, new_share=0.0, p_new=1.0, census_every=1,
-                        normals=None, strata=None):
+                        normals=None, strata=None, excl=(0.0, 0.0, 2.0)):
         """one observation step in which every particle acts on its own gated association (slamgpu_update_particle); returns the report"""
         z = _f32(z).reshape(-1, 2)
-        o = self._particle_opt(gate_reject, gate_augment, mode, new_share, p_new, census_every)
+        o = self._particle_opt(gate_reject, gate_augment, mode, new_share, p_new, census_every, excl)
         nm = None if normals is None else _f32(normals, (self.N, 3))
         st = None if strata is None else _f32(strata)
         rep = np.zeros(8, np.int32)

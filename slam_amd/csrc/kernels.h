@@ -600,8 +600,9 @@ struct KernelTable {
     // per-particle gated nearest-neighbour association of nz observations against every landmark of every particle
     // (slamgpu_associate): labels [n][nz] = landmark index, kAssocNew or kAssocDiscard.  Plain set required (no pending gather).
     // retired (may be null): bit j set = landmark j takes no part (slamgpu_retire_landmarks)
+    // excl3 (may be null): excl_base, excl_per_m, unique_ratio of the exclusion rule (slamgpu_particle_assoc; base + per_m = 0: off)
     void (*associate)(hipStream_t, const Buffers &, int nf, const float *z_dev, int nz, const float *R4, float gate_reject,
-                      float gate_augment, const uint32_t *retired_dev, int32_t *labels_dev);
+                      float gate_augment, const float *excl3, const uint32_t *retired_dev, int32_t *labels_dev);
     // seq_out != null: `out` and `seq_out` are pinned host memory; the kernel stores `seq` there last (system-scope fence)
     void (*shard_plan)(hipStream_t, const ShardPlanArgs &, const RngArgs &, ShardPlan *out, uint32_t *seq_out, uint32_t seq);
     void (*shard_pack)(hipStream_t, const Buffers &, const WeightScratch &, const ShardPackArgs &, const RngArgs &);

@@ -2528,8 +2528,16 @@ SLAM_DEV void assoc_gate(const AssocLm &A, float zr, float zb, float &nis, float
     nd = nis + A.ldet;
 }
 
+// EXCL (slamgpu_particle_assoc::excl_*; slamgpu_associate never): the EXCLUSION rule of a particle's own map.  The gates measure an
+// observation against S = Hf Pf Hf^T + R -- for a converged landmark that is R, half a metre at five sigma -- and know nothing of the
+// particle's own pose error (the EKF's S carries it, ekfslam.cpp:160-176; a particle's pose is a point).  So a particle a metre off
+// calls an observation of a mapped landmark NEW and opens a duplicate next to it.  With the rule on, an observation no landmark
+// gates is placed in the world from the particle's pose; if a landmark of the particle lies within excl_base + excl_per_m * range of
+// that point the observation cannot be new: it is matched with that landmark when no other is within unique_ratio times the distance
+// (the update then pulls pose and landmark together, at the price of the innovation's likelihood), and discarded otherwise.
+template <bool EXCL>
 __global__ void __launch_bounds__(kBlock) associate_kernel(Buffers B, int nf, const float *__restrict__ z, int nz, float r00, float r01,
-                                                            float r10, float r11, float gate1, float gate2,
+                                                            float r10, float r11, float gate1, float gate2, float excl_base, float excl_per_m, float unique_ratio,
                                                             const uint32_t *__restrict__ retired, int32_t *__restrict__ labels) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= B.n) return;
@@ -2539,11 +2547,22 @@ __global__ void __launch_bounds__(kBlock) associate_kernel(Buffers B, int nf, co
     for (int q0 = 0; q0 < nz; q0 += kAssocBatch) {
         float nbest[kAssocBatch], outer[kAssocBatch];
         int jbest[kAssocBatch];
+        [[maybe_unused]] float wx[kAssocBatch], wy[kAssocBatch], d1[kAssocBatch], d2[kAssocBatch];
+        [[maybe_unused]] int j1[kAssocBatch];
 #pragma unroll
         for (int q = 0; q < kAssocBatch; q++) {
             nbest[q] = INFINITY;  // the reference's `float nbest = 1e60` is +inf in float32
             outer[q] = INFINITY;
             jbest[q] = -1;
+            if constexpr (EXCL) {
+                const int qq = min(q0 + q, nz - 1);
+                float sn, cs;
+                sincosf(pa.z + z[2 * qq + 1], &sn, &cs);
+                wx[q] = pa.x + z[2 * qq] * cs;  // where this particle's pose puts the observation
+                wy[q] = pa.y + z[2 * qq] * sn;
+                d1[q] = d2[q] = INFINITY;
+                j1[q] = -1;
+            }
         }
         for (int j = 0; j < nf; j++) {
             // (a retired landmark -- slamgpu_retire_landmarks: a duplicate the caller's policy has given up -- takes no part; uniform)
@@ -2563,12 +2582,29 @@ __global__ void __launch_bounds__(kBlock) associate_kernel(Buffers B, int nf, co
                     } else if (nis < outer[q]) {
                         outer[q] = nis;
                     }
+                    if constexpr (EXCL) {  // (an absent record compares false twice: it is nobody's neighbour)
+                        const float ex = la.x - wx[q], ey = la.y - wy[q], dd = ex * ex + ey * ey;
+                        if (dd < d1[q]) {
+                            d2[q] = d1[q];
+                            d1[q] = dd;
+                            j1[q] = j;
+                        } else if (dd < d2[q]) {
+                            d2[q] = dd;
+                        }
+                    }
                 }
             }
         }
 #pragma unroll
         for (int q = 0; q < kAssocBatch; q++)
-            if (q0 + q < nz) labels[(size_t) i * nz + q0 + q] = jbest[q] > -1 ? jbest[q] : (outer[q] > gate2 ? kAssocNew : kAssocDiscard);
+            if (q0 + q < nz) {
+                int label = jbest[q] > -1 ? jbest[q] : (outer[q] > gate2 ? kAssocNew : kAssocDiscard);
+                if constexpr (EXCL) {
+                    const float rho = excl_base + excl_per_m * z[2 * (q0 + q)];
+                    if (jbest[q] < 0 && d1[q] < rho * rho) label = d2[q] > unique_ratio * unique_ratio * d1[q] ? j1[q] : kAssocDiscard;
+                }
+                labels[(size_t) i * nz + q0 + q] = label;
+            }
     }
 }
 
@@ -3333,10 +3369,14 @@ static void launch_observe_book(hipStream_t st, const ObserveArgs &A) {
     hipLaunchKernelGGL(observe_book_kernel, dim3(1), dim3(kObsThreads), 0, st, A);
 }
 
-static void launch_associate(hipStream_t st, const Buffers &B, int nf, const float *z, int nz, const float *R4, float g1, float g2,
+static void launch_associate(hipStream_t st, const Buffers &B, int nf, const float *z, int nz, const float *R4, float g1, float g2, const float *excl3,
                              const uint32_t *retired, int32_t *labels) {
-    hipLaunchKernelGGL(associate_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B, nf, z, nz, R4[0], R4[1], R4[2], R4[3], g1, g2,
-                       retired, labels);
+    if (excl3 && excl3[0] + excl3[1] > 0.0f)
+        hipLaunchKernelGGL(associate_kernel<true>, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B, nf, z, nz, R4[0], R4[1], R4[2], R4[3], g1, g2, excl3[0],
+                           excl3[1], excl3[2], retired, labels);
+    else
+        hipLaunchKernelGGL(associate_kernel<false>, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B, nf, z, nz, R4[0], R4[1], R4[2], R4[3], g1, g2, 0.0f, 0.0f,
+                           0.0f, retired, labels);
 }
 
 static void launch_kat(hipStream_t st, int op, const float *in, int n, float *out) {

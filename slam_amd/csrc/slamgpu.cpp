@@ -2818,7 +2818,7 @@ void assoc_resolve(int nz, std::vector<int32_t> &best, const std::vector<double>
 namespace {
 // lab_ext: a device array [N][nz] the labels are left in (slamgpu_update_particle: they never visit the host), or null
 int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4], float gate_reject, float gate_augment, int32_t mode,
-                   int32_t *labels, int32_t *consensus, float *support, double stats[4], int32_t *lab_ext) {
+                   int32_t *labels, int32_t *consensus, float *support, double stats[4], int32_t *lab_ext, const float *excl3 = nullptr) {
     if (int rc = check_ctx(c)) return rc;
     if (mode < SLAMGPU_ASSOC_AUTO || mode > SLAMGPU_ASSOC_GRID) return fail(SLAMGPU_ERR_INVALID, "unknown association mode %d", mode);
     if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0.0;
@@ -2833,7 +2833,9 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
     const bool single = !c->dist && c->cfg.n_particles_global == c->cfg.n_particles && c->pool_used == 0;
     if (mode == SLAMGPU_ASSOC_GRID && !single)
         return fail(SLAMGPU_ERR_INVALID, "the association grid needs a single context (shards: SLAMGPU_ASSOC_EXHAUSTIVE)");
-    bool grid = single && (mode == SLAMGPU_ASSOC_GRID || (mode == SLAMGPU_ASSOC_AUTO && c->nf >= 64));
+    const bool excl = excl3 && excl3[0] + excl3[1] > 0.0f;  // (the exclusion rule: the exhaustive scan only)
+    if (excl && mode == SLAMGPU_ASSOC_GRID) return fail(SLAMGPU_ERR_INVALID, "the exclusion rule needs SLAMGPU_ASSOC_EXHAUSTIVE (or _AUTO)");
+    bool grid = single && !excl && (mode == SLAMGPU_ASSOC_GRID || (mode == SLAMGPU_ASSOC_AUTO && c->nf >= 64));
     const bool want_vote = consensus || support;
     float *z_dev = nullptr;
     int32_t *lab_dev = nullptr;
@@ -2962,7 +2964,7 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
             if (ev0) step(hipEventRecord(ev0, c->stream), "event");
             {
                 Timed t(c, "associate");
-                c->k->associate(c->stream, c->B, c->nf, z_dev, nz, R, gate_reject, gate_augment, c->retired_dev, lab_dev);
+                c->k->associate(c->stream, c->B, c->nf, z_dev, nz, R, gate_reject, gate_augment, excl3, c->retired_dev, lab_dev);
             }
             if (ev1) step(hipEventRecord(ev1, c->stream), "event");
             if (stats) stats[0] = (double) N * (double) nz * (double) c->nf;
@@ -3097,6 +3099,8 @@ int pp_check(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4], const
     if (nz > 32767) return fail(SLAMGPU_ERR_CAPACITY, "per-particle association: %d observations in one step (at most 32767)", nz);
     if (!(opt->p_new > 0.0f) || !(opt->new_share >= 0.0f && opt->new_share <= 1.0f) || opt->census_every < 0)
         return fail(SLAMGPU_ERR_INVALID, "per-particle association: p_new > 0, 0 <= new_share <= 1, census_every >= 0");
+    if (!(opt->excl_base >= 0.0f) || !(opt->excl_per_m >= 0.0f) || !(opt->unique_ratio >= 0.0f))
+        return fail(SLAMGPU_ERR_INVALID, "per-particle association: excl_base, excl_per_m, unique_ratio >= 0");
     if (c->dist || c->cfg.n_particles_global != c->cfg.n_particles || c->pool_used != 0)
         return fail(SLAMGPU_ERR_INVALID, "per-particle association: single contexts only");
     if (c->mid_compact)
@@ -3328,7 +3332,8 @@ int slamgpu_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const fl
     if (nz == 0) return 0;  // (no observation, no update: fastslam2wrapper.cpp:84-95)
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = pp_reserve(c, nz, 1)) return rc;
-    if (int rc = associate_impl(c, z, nz, R, opt->gate_reject, opt->gate_augment, opt->mode, nullptr, nullptr, nullptr, nullptr, c->pp_lab_dev)) return rc;
+    const float excl3[3] = {opt->excl_base, opt->excl_per_m, opt->unique_ratio};
+    if (int rc = associate_impl(c, z, nz, R, opt->gate_reject, opt->gate_augment, opt->mode, nullptr, nullptr, nullptr, nullptr, c->pp_lab_dev, excl3)) return rc;
     return do_update_particle(c, z, nz, R, opt, normals, strata, report);
 }
 
