@@ -9,6 +9,11 @@
 //                        FastSLAM wrappers always use (default); gated = per-particle gated nearest neighbour
 //                        (EKFSLAM::dataAssociate, ekfslam.cpp:151-189, applied to every particle with GATE_REJECT /
 //                        GATE_AUGMENT) reduced to one association per step by weighted vote (slamgpu_associate)
+//   -assoc particle      the same gates, but every particle ACTS on its own decisions, on a map of its own (slamgpu_update_particle;
+//                        Particle.cpp:61-73 lets a particle's map grow by itself).  -PARTICLE_SLOTS k (slot capacity = k x the map's
+//                        landmarks, default 4), -PARTICLE_NEW_SHARE (0.02), -PARTICLE_P_NEW (default: the Gaussian at the reject
+//                        gate), -PARTICLE_EXCL_BASE (2.0 m) / -PARTICLE_EXCL_PER_M (0.05) / -PARTICLE_UNIQUE_RATIO (2): the exclusion
+//                        rule of include/slamgpu.h: slamgpu_particle_assoc.  The map reported at the end is the best particle's.
 //   -plot <sinks>        the per-step output the reference sends to slam-gui (plotting/NetworkPlot.cpp), byte for byte:
 //                        tcp://127.0.0.1:4242 (the existing slam-gui) | file:<frames> | gather:<dir> (the GUI's DataGatherer
 //                        files, headless) | none (default); several separated by ','
@@ -58,6 +63,8 @@ static void usage(const char *a0) {
     printf("    -method             [s] SLAM method: EKF1 | FASTSLAM1 | FASTSLAM2\n");
     printf("    -rng parity|philox  -math strict|fast  -log file.csv  -maxsteps n\n");
     printf("    -plot tcp://127.0.0.1:4242|file:<path>|gather:<dir>|none   -plotstride k\n");
+    printf("    -assoc known|gated|particle   FastSLAM data association: the reference's table (default), the per-particle gates reduced to a vote,\n");
+    printf("                        or the per-particle gates acted on by every particle on a map of its own\n");
     printf("    -gpus k             FastSLAM particle set distributed over k GPUs (k > devices: logical shards on device 0)\n");
     printf("    -observe host|device  where the observation of a step is made: host (default) or on the GPU (the packet never leaves\n");
     printf("                        device memory: slamgpu_step_observe; -rng philox, known association, no -plot)\n");
@@ -73,7 +80,7 @@ static void usage(const char *a0) {
 static int run_distributed(Simulator &sim, int k, long maxsteps, FILE *log, Plot &plot) {
     const Conf &c = sim.conf;
     const int N = c.NPARTICLES;
-    if (c.s("rng") == "parity" || c.s("assoc") == "gated") {
+    if (c.s("rng") == "parity" || c.s("assoc") == "gated" || c.s("assoc") == "particle") {
         fprintf(stderr, "-gpus %d needs -rng philox and -assoc known\n", k);
         return EXIT_FAILURE;
     }
@@ -361,8 +368,13 @@ int main(int argc, char **argv) {
     const int N = c.NPARTICLES;
     const bool parity = rng == "parity";
     const bool gated = c.s("assoc") == "gated";
+    const bool particle = c.s("assoc") == "particle";
     const bool observe_dev = c.s("observe") == "device";
-    const bool batched = c.method != 0 && !plot.active() && !parity && !gated && c.s("loop") != "step";
+    const bool batched = c.method != 0 && !plot.active() && !parity && !gated && !particle && c.s("loop") != "step";
+    auto numkey = [&](const char *key, double dflt) { return c.s(key).empty() ? dflt : atof(c.s(key).c_str()); };
+    slamgpu_particle_assoc popt{};
+    long pp_opened = 0, pp_reused = 0, pp_dropped = 0;
+    int pp_most = 0;
     if (observe_dev && !batched) {
         fprintf(stderr, "-observe device needs a FastSLAM method, -rng philox, known association and no -plot / -loop step\n");
         return EXIT_FAILURE;
@@ -374,6 +386,7 @@ int main(int argc, char **argv) {
         g.method = c.method;
         g.n_particles = N;
         g.max_landmarks = gated ? 2 * sim.map.nlm : sim.map.nlm;  // unknown association may open spurious landmarks
+        if (particle) g.max_landmarks = std::max(1, (int) numkey("PARTICLE_SLOTS", 4)) * sim.map.nlm;  // slots: hypotheses of all particles together
         g.use_heading = c.SWITCH_HEADING_KNOWN == 1;
         g.add_predict_noise = c.method == 1 ? 1 : (c.SWITCH_PREDICT_NOISE == 1);
         g.resample = c.SWITCH_RESAMPLE == 1;
@@ -383,7 +396,16 @@ int main(int argc, char **argv) {
         g.rng_mode = parity ? SLAMGPU_RNG_TAPE : SLAMGPU_RNG_PHILOX;
         g.math_mode = math == "strict" ? SLAMGPU_MATH_STRICT : SLAMGPU_MATH_FAST;
         g.seed = (uint64_t) c.SWITCH_SEED_RANDOM;
-        g.flags = observe_dev ? SLAMGPU_FLAG_DEVICE_OBSERVE : 0;
+        g.flags = (observe_dev ? SLAMGPU_FLAG_DEVICE_OBSERVE : 0) | (particle ? SLAMGPU_FLAG_PARTICLE_MAPS : 0);
+        popt.gate_reject = c.GATE_REJECT;
+        popt.gate_augment = c.GATE_AUGMENT;
+        popt.mode = SLAMGPU_ASSOC_AUTO;
+        popt.new_share = (float) numkey("PARTICLE_NEW_SHARE", 0.02);
+        popt.p_new = (float) numkey("PARTICLE_P_NEW", std::exp(-0.5 * c.GATE_REJECT) / (2.0 * 3.14159265358979323846 * std::sqrt(std::max(1e-30, (double) sim.Re[0] * sim.Re[3] - (double) sim.Re[1] * sim.Re[2]))));
+        popt.census_every = (int32_t) numkey("PARTICLE_CENSUS", 1);
+        popt.excl_base = (float) numkey("PARTICLE_EXCL_BASE", 2.0);
+        popt.excl_per_m = (float) numkey("PARTICLE_EXCL_PER_M", 0.05);
+        popt.unique_ratio = (float) numkey("PARTICLE_UNIQUE_RATIO", 2.0);
         if (slamgpu_create(&g, &ctx) != 0) {
             fprintf(stderr, "slamgpu_create: %s\n", slamgpu_last_error());
             return EXIT_FAILURE;
@@ -498,6 +520,29 @@ int main(int argc, char **argv) {
             if (!rc && r == 1) {
                 sim.observe();
                 laser_lines();
+                if (particle) {
+                    // unknown association, per particle all the way: every particle gates the observations against its own map and
+                    // acts on its own decisions (slamgpu_update_particle); nothing of the association visits the host
+                    const int nz = (int) (sim.z.size() / 2);
+                    const float *nm = nullptr, *st = nullptr;
+                    if (parity) {
+                        if (c.method == 2 && nz > 0) {
+                            normals.resize(3 * (size_t) N);
+                            for (int i = 0; i < N; i++) randn(3, 1, &normals[3 * (size_t) i]);
+                            nm = normals.data();
+                        }
+                        strata.resize((size_t) N);
+                        stratified_random(N, strata.data());
+                        st = strata.data();
+                    }
+                    int32_t rep[8] = {0};
+                    rc = slamgpu_update_particle(ctx, sim.z.data(), nz, sim.Re, &popt, nm, st, rep);
+                    pp_opened += rep[1];
+                    pp_reused += rep[2];
+                    pp_dropped += rep[3];
+                    pp_most = std::max(pp_most, (int) rep[0]);
+                    nobs++;
+                } else {
                 if (gated) {
                     // unknown association: every particle gates the observations against its own map; the weighted vote
                     // becomes this step's association (slamgpu_update's association is per step)
@@ -565,6 +610,7 @@ int main(int argc, char **argv) {
                 }
                 rc = slamgpu_update(ctx, zf.data(), idf.data(), (int) idf.size(), zn.data(), (int) (zn.size() / 2), sim.Re, nm, st);
                 nobs++;
+                }
             }
             if (!rc) rc = slamgpu_estimate(ctx, est);
             if (rc) {
@@ -632,6 +678,31 @@ int main(int argc, char **argv) {
         printf("landmarks in map: %d (%d opened, %d retired by the association policy, %d in use; %d observations matched by the second stage, %d "
                "left unused, %d refused as new next to a mapped landmark)\n",
                nfl - policy.n_retired, policy.n_opened, policy.n_retired, nfl - policy.n_retired, policy.n_rescued, policy.n_discarded_votes, policy.n_new_refused);
+    } else if (ctx && particle) {
+        // the map of the best (largest-weight) particle: what a FastSLAM with per-particle association reports
+        const int slots = slamgpu_num_landmarks(ctx);
+        std::vector<float> w((size_t) N);
+        int held = 0, covered = 0, best = 0;
+        if (slots >= 0 && slamgpu_download_range(ctx, 0, N, nullptr, nullptr, w.data(), nullptr, nullptr) == 0) {
+            for (int i = 1; i < N; i++)
+                if (w[(size_t) i] > w[(size_t) best]) best = i;
+            std::vector<float> xf(2 * (size_t) std::max(slots, 1));
+            if (slots > 0 && slamgpu_download_range(ctx, best, 1, nullptr, nullptr, nullptr, xf.data(), nullptr) == 0) {
+                std::vector<char> hit((size_t) sim.map.nlm, 0);
+                for (int j = 0; j < slots; j++) {
+                    if (xf[2 * (size_t) j] != xf[2 * (size_t) j]) continue;  // absent
+                    held++;
+                    for (int t = 0; t < sim.map.nlm; t++) {
+                        const float dx = xf[2 * (size_t) j] - sim.map.lm[(size_t) t], dy = xf[2 * (size_t) j + 1] - sim.map.lm[(size_t) sim.map.nlm + t];
+                        if (dx * dx + dy * dy < 1.0f) hit[(size_t) t] = 1;
+                    }
+                }
+                for (char h : hit) covered += h;
+            }
+        }
+        printf("landmarks in map: %d (the best particle's, number %d; %d of the %d true landmarks within 1 m of one of them; %d slots in use by all particles "
+               "together, %ld opened, %ld of them dead slots reused, %ld observations dropped for want of a slot, at most %d slots rewritten in a step)\n",
+               held, best, covered, sim.map.nlm, slots, pp_opened, pp_reused, pp_dropped, pp_most);
     } else if (ctx) printf("landmarks in map: %d\n", slamgpu_num_landmarks(ctx));
     else printf("landmarks in map: %d\n", ekf.num_features());
     if (plot.active()) {

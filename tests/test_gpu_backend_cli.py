@@ -286,3 +286,31 @@ def test_slam_backend_gpus_k_fastslam1(tmp_path):
     assert len(a) >= 400 and np.array_equal(a[:, :7], b[:, :7])
     err = np.hypot(a[:, 4] - a[:, 1], a[:, 5] - a[:, 2])
     assert err.mean() < 1.5, err.mean()  # tracks the true path (FastSLAM1 at 2 048 particles: well under a metre and a half)
+
+
+@pytest.mark.parametrize("seed,math,rng", [(7, "fast", "philox"), (11, "strict", "philox"), (9, "strict", "parity")])
+def test_slam_backend_per_particle_association(tmp_path, seed, math, rng):
+    """-assoc particle: the same gates, but nothing is reduced to a vote: every particle acts on its own decisions on a map of its
+    own (slamgpu_update_particle; the kernel side is pinned in tests/test_gpu_particle_assoc.py).  The best particle's map must be
+    the map -- 35 landmarks, at most one spurious, all 35 true ones found -- with at most a handful of extra slots ever opened by
+    minorities, and the estimate must be as good as the known-association twin's; also with the reference's libc draws (-rng parity)."""
+    import re
+
+    def run(extra, name):
+        log = str(tmp_path / name)
+        r = subprocess.run([EXE, "-m", os.path.join(DATA, "example_webmap.mat"), "-method", "FASTSLAM2", "-NPARTICLES", "500", "-NEFFECTIVE", "375",
+                            "-SWITCH_SEED_RANDOM", str(seed), "-math", math, "-rng", rng, "-log", log] + extra, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+        rows = np.loadtxt(log, delimiter=",", skiprows=1)
+        err = np.hypot(rows[:, 4] - rows[:, 1], rows[:, 5] - rows[:, 2])
+        assert np.isfinite(err).all()
+        return r.stdout, err
+    out, err = run(["-assoc", "particle"], "particle.csv")
+    m = re.search(r"landmarks in map: (\d+) \(the best particle's, number \d+; (\d+) of the 35 true landmarks within 1 m of one of them; (\d+) slots", out)
+    assert m, out[-500:]
+    held, covered, slots = int(m.group(1)), int(m.group(2)), int(m.group(3))
+    _, err_known = run(["-loop", "step"], "known.csv")
+    assert 35 <= held <= 36 and slots <= 40, out[-500:]
+    assert err.mean() <= 1.2 * err_known.mean() + 0.25 and err.max() < 2.5, (err.mean(), err_known.mean(), err.max())
+    if err_known.mean() < 0.5:
+        assert covered >= 33, out[-500:]   # (a map that has not drifted as a whole covers the true landmarks)

@@ -182,3 +182,28 @@ def test_particles_that_disagree_each_take_their_own_step(sg, method, name, math
             ref = (half["w"][0].astype(np.float64) / got["w"][0].astype(np.float64)) * 0.5 ** (unexplained[kind] - unexplained[0])
             assert np.allclose(ratio, ref, rtol=2e-5), (kind, ratio[:3], ref)
     assert np.array_equal(half["xv"], got["xv"]) and np.array_equal(half["xf"], got["xf"], equal_nan=True)
+
+
+@pytest.mark.parametrize("mapname,N,seed,math_mode,n_true", [("example_webmap", 512, 7, 1, 35), ("example_webmap", 2048, 8, 0, 35),
+                                                             ("example_loop1", 512, 9, 1, 22), ("example_loop902", 1024, 7, 1, 117)])
+def test_whole_runs_with_every_particle_on_its_own_association(sg, mapname, N, seed, math_mode, n_true):
+    """Whole runs of the bundled maps with slamgpu_update_particle (the .ini's gates 4 / 25, the exclusion rule, a slot per
+    observation 2 % of the particles call new): the best particle ends with the map's landmarks (at most two spurious ones), every
+    true landmark within 1 m of one of its entries on the loop maps, and the estimate is as good as the SAME run's with the
+    reference's known association (within 1.2 x + 0.05 m of its mean error).  40 + 28 such runs: profiles/particle_association_r06.txt."""
+    import argparse
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("particle_assoc_probe", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools",
+                                                                                      "particle_assoc_probe.py"))
+    probe = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(probe)
+    from slam_amd import host
+    a = argparse.Namespace(method="FASTSLAM2", gate_reject=4.0, gate_augment=25.0, new_share=0.02, p_new=0.0, census=1, excl_base=2.0, excl_per_m=0.05,
+                           unique_ratio=2.0, slots=4)
+    r = probe.run(sg, host, mapname, N, seed, math_mode, a, False)
+    k = probe.run(sg, host, mapname, N, seed, math_mode, a, True)
+    assert n_true <= r["n_map"] <= n_true + 2 and r["slots"] <= n_true + 6 and r["dropped"] == 0, r
+    assert r["err"] <= 1.2 * k["err"] + 0.05, (r, k)
+    if mapname != "example_webmap":
+        assert r["covered"] == n_true and r["stray"] == 0, r
