@@ -552,6 +552,7 @@ struct AssocGridArgs {
     int32_t cap_items, nf, nz;
     const float *z;               // [2 nz] observations (range, bearing), device
     float r00, r11, G;            // R diagonal; G = max(gate_reject, gate_augment) with the safety margin
+    int32_t lab_by_obs, pad_lab;  // labels laid out [nz][ncap] (the per-particle update's) instead of [n][nz]
     VoteSlot *votes;              // [nz][kVoteSlots] or null: the weighted vote per observation (AssocGeom::overflow bit 1: a table filled up)
     int32_t logw;                 // the context keeps log-weights
 };
@@ -602,7 +603,7 @@ struct KernelTable {
     // retired (may be null): bit j set = landmark j takes no part (slamgpu_retire_landmarks)
     // excl3 (may be null): excl_base, excl_per_m, unique_ratio of the exclusion rule (slamgpu_particle_assoc; base + per_m = 0: off)
     void (*associate)(hipStream_t, const Buffers &, int nf, const float *z_dev, int nz, const float *R4, float gate_reject,
-                      float gate_augment, const float *excl3, const uint32_t *retired_dev, int32_t *labels_dev);
+                      float gate_augment, const float *excl3, const uint32_t *retired_dev, int32_t *labels_dev, int labels_by_obs);
     // seq_out != null: `out` and `seq_out` are pinned host memory; the kernel stores `seq` there last (system-scope fence)
     void (*shard_plan)(hipStream_t, const ShardPlanArgs &, const RngArgs &, ShardPlan *out, uint32_t *seq_out, uint32_t seq);
     void (*shard_pack)(hipStream_t, const Buffers &, const WeightScratch &, const ShardPackArgs &, const RngArgs &);
@@ -623,10 +624,10 @@ struct KernelTable {
                            int32_t *labels_dev);
     // seam 1, MULTIPARTICLE_ACCELERATOR form: self-describing records back to back, outputs in place; tab: 3 words per feature
     void (*jacobians_multi)(hipStream_t, float *win_dev, const uint32_t *tab_dev, uint32_t nfeat);
-    // per-particle association (PerParticle): census of the labels [n][nz] (first[l]: lowest observation naming landmark slot l, preset
+    // per-particle association (PerParticle; labels BY OBSERVATION here, [nz][ncap]): census of the labels (first[l]: lowest observation naming landmark slot l, preset
     // to INT_MAX; news[j]: particles calling observation j new, preset to 0), the labels resolved into PerParticle::obs / wf / any, and
     // the number of particles that hold each landmark slot (holders[l], preset to 0; plain set, tables in sync)
-    void (*pp_census)(hipStream_t, const int32_t *labels_dev, int n, int nz, int32_t *first_dev, int32_t *news_dev);
+    void (*pp_census)(hipStream_t, const int32_t *labels_dev, int n, int nz, int ncap, int32_t *first_dev, int32_t *news_dev);
     void (*pp_resolve)(hipStream_t, const int32_t *labels_dev, int n, int nz, int ncap, const int32_t *uidx_dev, const int32_t *newk_dev, int m, int nn,
                        float p_new, int logw, int16_t *obs_dev, float *wf_dev, uint8_t *any_dev);
     void (*pp_holders)(hipStream_t, const Buffers &, int nf, int32_t *holders_dev);

@@ -2538,7 +2538,7 @@ SLAM_DEV void assoc_gate(const AssocLm &A, float zr, float zb, float &nis, float
 template <bool EXCL>
 __global__ void __launch_bounds__(kBlock) associate_kernel(Buffers B, int nf, const float *__restrict__ z, int nz, float r00, float r01,
                                                             float r10, float r11, float gate1, float gate2, float excl_base, float excl_per_m, float unique_ratio,
-                                                            const uint32_t *__restrict__ retired, int32_t *__restrict__ labels) {
+                                                            const uint32_t *__restrict__ retired, int32_t *__restrict__ labels, int by_obs) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= B.n) return;
     const int cur = B.ctrl->live[B.slot];
@@ -2603,7 +2603,7 @@ __global__ void __launch_bounds__(kBlock) associate_kernel(Buffers B, int nf, co
                     const float rho = excl_base + excl_per_m * z[2 * (q0 + q)];
                     if (jbest[q] < 0 && d1[q] < rho * rho) label = d2[q] > unique_ratio * unique_ratio * d1[q] ? j1[q] : kAssocDiscard;
                 }
-                labels[(size_t) i * nz + q0 + q] = label;
+                labels[by_obs ? (size_t) (q0 + q) * S + i : (size_t) i * nz + q0 + q] = label;  // (by_obs: [nz][ncap], what the per-particle update reads)
             }
     }
 }
@@ -2911,7 +2911,7 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
                 if (at + 1 < c1) visit(b1, t1);
             }
             label = jbest > -1 ? jbest : (outer > gate2 ? kAssocNew : kAssocDiscard);
-            if (labels) labels[(size_t) i * A.nz + q] = label;
+            if (labels) labels[A.lab_by_obs ? (size_t) q * S + i : (size_t) i * A.nz + q] = label;
         }
         if (A.votes) {
             // a wave's particles nearly always agree: one atomic per wave and distinct label, not one per particle
@@ -3370,13 +3370,13 @@ static void launch_observe_book(hipStream_t st, const ObserveArgs &A) {
 }
 
 static void launch_associate(hipStream_t st, const Buffers &B, int nf, const float *z, int nz, const float *R4, float g1, float g2, const float *excl3,
-                             const uint32_t *retired, int32_t *labels) {
+                             const uint32_t *retired, int32_t *labels, int by_obs) {
     if (excl3 && excl3[0] + excl3[1] > 0.0f)
         hipLaunchKernelGGL(associate_kernel<true>, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B, nf, z, nz, R4[0], R4[1], R4[2], R4[3], g1, g2, excl3[0],
-                           excl3[1], excl3[2], retired, labels);
+                           excl3[1], excl3[2], retired, labels, by_obs);
     else
         hipLaunchKernelGGL(associate_kernel<false>, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B, nf, z, nz, R4[0], R4[1], R4[2], R4[3], g1, g2, 0.0f, 0.0f,
-                           0.0f, retired, labels);
+                           0.0f, retired, labels, by_obs);
 }
 
 static void launch_kat(hipStream_t st, int op, const float *in, int n, float *out) {
@@ -3467,17 +3467,26 @@ static void launch_associate_grid(hipStream_t st, const Buffers &B, const AssocG
 // ---------------------------------------------------------------------------------------------------
 // Per-particle association (kernels.h: PerParticle; slamgpu.cpp: do_update_particle): between the association's labels
 // [n][nz] and the update launch.
+// (the labels of this path are laid out BY OBSERVATION, [nz][ncap]: the association writes and these kernels read 256 consecutive
+// particles of one observation at a time; particle-major, every access of a wave touched 64 lines)
 // census: which landmark slots ANY particle matched (first[l] = the lowest observation index that names l, INT_MAX: none -- the
 // host orders the packet's entries by it, so that particles which agree meet their landmarks in the order of the observations, as
 // the reference's loop over zf does) and how many particles call each observation new.
-__global__ void __launch_bounds__(kBlock) pp_census_kernel(const int32_t *__restrict__ labels, int n, int nz, int32_t *__restrict__ first,
-                                                            int32_t *__restrict__ news) {
+__global__ void __launch_bounds__(kBlock) pp_census_kernel(const int32_t *__restrict__ labels, int n, int nz, size_t S, int32_t *first, int32_t *__restrict__ news) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const bool on = i < n;
     for (int j = 0; j < nz; j++) {
-        const int lab = on ? labels[(size_t) i * nz + j] : kAssocDiscard;
-        // (most particles agree and the word is soon at its final value: a plain look first, the atomic only to lower it)
-        if (lab >= 0 && first[lab] > j) atomicMin(first + lab, j);
+        const int lab = on ? labels[(size_t) j * S + i] : kAssocDiscard;
+        // a wave's particles nearly always agree: one atomic per wave and distinct label, and only to LOWER the word (it is soon at its
+        // final value).  One atomic per particle was 10^5 atomics on one address per observation: 1.35 ms of a 1.5 ms step at 10^5
+        // particles on example_webmap (profiles/particle_association_r06.txt)
+        unsigned long long todo = __ballot(lab >= 0);
+        while (todo) {
+            const int src = __ffsll((long long) todo) - 1;
+            const int lab0 = __builtin_amdgcn_readlane(lab, src);
+            if ((int) (threadIdx.x & (kWave - 1)) == src && __hip_atomic_load(first + lab0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > j) atomicMin(first + lab0, j);
+            todo &= ~__ballot(lab == lab0);
+        }
         const unsigned long long nw = __ballot(lab == kAssocNew);
         if (nw && (threadIdx.x & (kWave - 1)) == (int) __ffsll((long long) __ballot(true)) - 1) atomicAdd(news + j, (int) __popcll(nw));
     }
@@ -3502,7 +3511,7 @@ __global__ void __launch_bounds__(kBlock) pp_resolve_kernel(const int32_t *__res
     }
     int unexplained = 0, flags = 0;
     for (int j = 0; j < nz; j++) {
-        const int lab = labels[(size_t) i * nz + j];
+        const int lab = labels[(size_t) j * S + i];
         if (lab >= 0) {
             const int k = uidx[lab];
             if (k >= 0 && obs[(size_t) k * S + i] < 0) {
@@ -3531,25 +3540,38 @@ __global__ void __launch_bounds__(kBlock) pp_resolve_kernel(const int32_t *__res
 // holders: how many particles of the (plain) set hold landmark slot l, l < nf -- a slot nobody holds any more (its hypotheses died
 // in a resample) is dead: the host takes it out of the association and opens it again for a later landmark
 __global__ void __launch_bounds__(kBlock) pp_holders_kernel(Buffers B, int nf, int32_t *__restrict__ holders) {
+    // per block: the waves' counts meet in LDS, a chunk of landmarks at a time; one global atomic per block and landmark (one per wave
+    // and landmark was 55 000 atomics on 35 addresses at 10^5 particles on example_webmap: 0.45 ms)
+    constexpr int kChunk = 1024;
+    __shared__ int32_t sh[kChunk];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const bool on = i < B.n;
     const int cur = B.ctrl->live[B.slot];
     const size_t S = (size_t) B.ncap;
-    for (int l = 0; l < nf; l++) {
-        bool has = false;
-        if (on) {
-            float4 la;
-            float lb;
-            read_through_genealogy(B, B.lmk_live, cur, S, l, i, la, lb);
-            has = la.x == la.x;
+    for (int l0 = 0; l0 < nf; l0 += kChunk) {
+        const int ln = min(kChunk, nf - l0);
+        for (int t = threadIdx.x; t < ln; t += kBlock) sh[t] = 0;
+        __syncthreads();
+        for (int l = l0; l < l0 + ln; l++) {
+            bool has = false;
+            if (on) {
+                float4 la;
+                float lb;
+                read_through_genealogy(B, B.lmk_live, cur, S, l, i, la, lb);
+                has = la.x == la.x;
+            }
+            const unsigned long long hm = __ballot(has);
+            if (hm && (threadIdx.x & (kWave - 1)) == (int) __ffsll((long long) __ballot(true)) - 1) atomicAdd(sh + (l - l0), (int) __popcll(hm));
         }
-        const unsigned long long hm = __ballot(has);
-        if (hm && (threadIdx.x & (kWave - 1)) == (int) __ffsll((long long) __ballot(true)) - 1) atomicAdd(holders + l, (int) __popcll(hm));
+        __syncthreads();
+        for (int t = threadIdx.x; t < ln; t += kBlock)
+            if (sh[t]) atomicAdd(holders + l0 + t, sh[t]);
+        __syncthreads();
     }
 }
 
-static void launch_pp_census(hipStream_t st, const int32_t *labels, int n, int nz, int32_t *first, int32_t *news) {
-    hipLaunchKernelGGL(pp_census_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, labels, n, nz, first, news);
+static void launch_pp_census(hipStream_t st, const int32_t *labels, int n, int nz, int ncap, int32_t *first, int32_t *news) {
+    hipLaunchKernelGGL(pp_census_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, labels, n, nz, (size_t) ncap, first, news);
 }
 static void launch_pp_resolve(hipStream_t st, const int32_t *labels, int n, int nz, int ncap, const int32_t *uidx, const int32_t *newk, int m, int nn,
                               float p_new, int logw, int16_t *obs, float *wf, uint8_t *any) {

@@ -238,7 +238,7 @@ struct slamgpu_ctx {
     int n_retired = 0;
     int32_t *assoc_ids_dev = nullptr, *cell_start_dev = nullptr, *cell_fill_dev = nullptr;
     // per-particle association (slamgpu_update_particle / _labels; kernels.h: PerParticle): device scratch, grown on demand
-    int32_t *pp_lab_dev = nullptr;   // labels [N][nz]
+    int32_t *pp_lab_dev = nullptr;   // labels BY OBSERVATION, [nz][ncap]
     size_t pp_lab_cap = 0;
     int16_t *pp_obs_dev = nullptr;   // PerParticle::obs [rows][ncap]
     size_t pp_obs_rows = 0;
@@ -2816,7 +2816,7 @@ void assoc_resolve(int nz, std::vector<int32_t> &best, const std::vector<double>
 }  // namespace
 
 namespace {
-// lab_ext: a device array [N][nz] the labels are left in (slamgpu_update_particle: they never visit the host), or null
+// lab_ext: a device array the labels are left in BY OBSERVATION, [nz][ncap] (slamgpu_update_particle: they never visit the host), or null
 int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4], float gate_reject, float gate_augment, int32_t mode,
                    int32_t *labels, int32_t *consensus, float *support, double stats[4], int32_t *lab_ext, const float *excl3 = nullptr) {
     if (int rc = check_ctx(c)) return rc;
@@ -2902,6 +2902,7 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
         G.G = std::max(gate_reject, gate_augment) * 1.001f;
         G.votes = votes_dev;
         G.logw = c->cfg.log_weights;
+        G.lab_by_obs = lab_ext ? 1 : 0;
         AssocGeom hg{};
         if (!rc) {
             if (ev0) step(hipEventRecord(ev0, c->stream), "event");
@@ -2964,7 +2965,7 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
             if (ev0) step(hipEventRecord(ev0, c->stream), "event");
             {
                 Timed t(c, "associate");
-                c->k->associate(c->stream, c->B, c->nf, z_dev, nz, R, gate_reject, gate_augment, excl3, c->retired_dev, lab_dev);
+                c->k->associate(c->stream, c->B, c->nf, z_dev, nz, R, gate_reject, gate_augment, excl3, c->retired_dev, lab_dev, lab_ext ? 1 : 0);
             }
             if (ev1) step(hipEventRecord(ev1, c->stream), "event");
             if (stats) stats[0] = (double) N * (double) nz * (double) c->nf;
@@ -3062,12 +3063,12 @@ int slamgpu_retire_landmarks(slamgpu_ctx *c, const int32_t *ids, int32_t count) 
 namespace {
 int pp_reserve(slamgpu_ctx *c, int nz, size_t rows) {
     const size_t S = (size_t) c->B.ncap, cap_nf = (size_t) c->B.cap_nf;
-    if ((size_t) c->B.n * (size_t) nz > c->pp_lab_cap) {
+    if (S * (size_t) nz > c->pp_lab_cap) {  // (by observation: [nz][ncap])
         if (c->pp_lab_dev) (void) hipFree(c->pp_lab_dev);
         c->pp_lab_dev = nullptr;
         c->pp_lab_cap = 0;
-        HIP_TRY(hipMalloc((void **) &c->pp_lab_dev, sizeof(int32_t) * (size_t) c->B.n * (size_t) nz));
-        c->pp_lab_cap = (size_t) c->B.n * (size_t) nz;
+        HIP_TRY(hipMalloc((void **) &c->pp_lab_dev, sizeof(int32_t) * S * (size_t) nz));
+        c->pp_lab_cap = S * (size_t) nz;
     }
     if (nz > c->pp_nz_cap || !c->pp_tab_dev) {
         const int cap = std::max(64, 2 * nz);
@@ -3133,7 +3134,7 @@ int do_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const float R
     HIP_TRY(hipMemsetAsync(news_dev, 0, sizeof(int32_t) * (size_t) nz, c->stream));
     {
         Timed t(c, "particle_census");
-        c->k->pp_census(c->stream, c->pp_lab_dev, N, nz, first_dev, news_dev);
+        c->k->pp_census(c->stream, c->pp_lab_dev, N, nz, c->B.ncap, first_dev, news_dev);
         if (census) c->k->pp_holders(c->stream, c->B, nf0, hold_dev);
     }
     HIP_TRY(hipGetLastError());
@@ -3350,8 +3351,15 @@ int slamgpu_update_labels(slamgpu_ctx *c, const float *z, int32_t nz, const floa
             return fail(SLAMGPU_ERR_INVALID, "slamgpu_update_labels: label %d of particle %d, observation %d (%d landmarks)", (int) labels[q], (int) (q / nz), (int) (q % nz), c->nf);
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = pp_reserve(c, nz, 1)) return rc;
-    HIP_TRY(hipMemcpyAsync(c->pp_lab_dev, labels, sizeof(int32_t) * count, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // (pageable source)
+    {
+        // (the device reads the labels by observation: [nz][ncap])
+        const size_t S = (size_t) c->B.ncap;
+        std::vector<int32_t> t(S * (size_t) nz, SLAMGPU_ASSOC_DISCARD);
+        for (int i = 0; i < c->B.n; i++)
+            for (int q = 0; q < nz; q++) t[(size_t) q * S + i] = labels[(size_t) i * nz + q];
+        HIP_TRY(hipMemcpyAsync(c->pp_lab_dev, t.data(), sizeof(int32_t) * t.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // (pageable source)
+    }
     return do_update_particle(c, z, nz, R, opt, normals, strata, report);
 }
 
