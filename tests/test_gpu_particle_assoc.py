@@ -9,7 +9,7 @@ Particle lets grow per particle, Particle.cpp:61-73).  The reference has no Fast
 import numpy as np
 import pytest
 
-from conftest import sim_args
+from conftest import load_golden as load_golden_, sim_args
 
 pytestmark = pytest.mark.gpu
 f32 = np.float32
@@ -207,3 +207,75 @@ def test_whole_runs_with_every_particle_on_its_own_association(sg, mapname, N, s
     assert r["err"] <= 1.2 * k["err"] + 0.05, (r, k)
     if mapname != "example_webmap":
         assert r["covered"] == n_true and r["stray"] == 0, r
+
+
+@pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
+@pytest.mark.parametrize("name,method", [("traj_fs2_webmap_N100_s7", 2), ("traj_fs1_webmap_N100_s7", 1), ("traj_fs2_loop902_N100_s3", 2)])
+def test_disagreeing_particles_against_the_oracle(sg, oracle, name, method, math_mode):
+    """The same split, held to the ORACLE directly (not through slamgpu_update): from the reference's own pre-update particle sets
+    (tests/golden: the snapshots of the reference objects) and its tape of normals, one slamgpu_update_labels step with four kinds
+    of particle; every kind is compared with the oracle's per-particle stage (orc_update_local: fastslam{1,2}.cpp's update without
+    the resampling, oracle/slam_oracle.c) run with that kind's (zf, idf, zn) -- poses, covariances, landmark records and, inside a
+    kind, the weights, to the tolerances the known-association step is held to (tests/test_gpu_parity.py)."""
+    from oracle import orc
+    from test_gpu_parity import POSE_ATOL, close_cov, sym, compare_weights
+    g = load_golden_(name)
+    cap = max(40, int(g["nf"].max())) + 8
+    algo = orc.Algo(method, int(g["meta_use_heading"]), int(g["meta_add_predict_noise"]), 0, int(g["meta_n_effective"]), float(g["meta_wheel_base"]),
+                    float(g["meta_sigma_phi"]))
+    done = 0
+    for k in g["snap_steps"]:
+        m, n = int(g["m"][k - 1]), int(g["n"][k - 1])
+        if m < 2:
+            continue
+        pre = {key: g["snap%d_pre_%s" % (k, key)] for key in ("xv", "Pv", "w", "xf", "Pf")}
+        N = pre["w"].shape[0]
+        pre["nf"] = nf = pre["xf"].shape[1]
+        zf, idf, zn = g["zf"][k - 1, :m], g["idf"][k - 1, :m].astype(np.int32), g["zn"][k - 1, :n]
+        z = np.concatenate([zf, zn]).reshape(-1, 2)
+        lab = _group_labels(N, idf, n, nf)
+        normals = g["snap%d_normals" % k]
+        s = sg.SlamGpu(N, cap, method=method, n_effective=int(g["meta_n_effective"]), use_heading=bool(g["meta_use_heading"]),
+                       wheel_base=float(g["meta_wheel_base"]), sigma_phi=float(g["meta_sigma_phi"]), rng_mode=sg.RNG_TAPE, math_mode=math_mode,
+                       resample=False, particle_maps=True)
+        s.upload(pre)
+        rep = s.update_labels(z, g["meta_R"], lab, p_new=1.0, census_every=0, normals=normals, strata=g["snap%d_sel" % k])
+        got = s.download()
+        s.close()
+        assert rep["rewritten"] == m and rep["opened"] == n, rep
+        claims, first = {}, {}
+        for kind in range(4):
+            c = {}
+            for j, l in enumerate(lab[kind]):
+                if l >= 0 and int(l) not in c:
+                    c[int(l)] = j
+                    first[int(l)] = min(first.get(int(l), 1 << 30), j)
+            claims[kind] = c
+        order = sorted(first, key=lambda l: (first[l], l))
+        for kind in range(4):
+            sel = np.arange(N) % 4 == kind
+            ls = [l for l in order if l in claims[kind]]
+            opens = [j for j in range(m, len(z)) if lab[kind][j] == NEW]
+            o = orc.Particles(oracle, N, cap)
+            o.set(pre)
+            if ls or opens:
+                o.update_local(algo, z[[claims[kind][l] for l in ls]].reshape(-1, 2), np.array(ls, np.int32), z[opens].reshape(-1, 2), g["meta_R"], normals)
+            exp = o.get()
+            o.close()
+            tag = "%s step %d kind %d" % (name, k, kind)
+            assert np.abs(got["xv"][sel] - exp["xv"][sel]).max() <= POSE_ATOL, tag
+            assert close_cov(got["Pv"][sel], sym(exp["Pv"][sel])), tag
+            nfe = exp["nf"]
+            if nfe:
+                assert np.abs(got["xf"][sel][:, :nfe] - exp["xf"][sel]).max() <= POSE_ATOL * 5, tag
+                assert close_cov(got["Pf"][sel][:, :nfe], sym(exp["Pf"][sel])), tag
+            if nfe < rep["slots"]:
+                assert np.isnan(got["xf"][sel][:, nfe:rep["slots"]]).all(), tag
+            wg, we = got["w"][sel].astype(np.float64), exp["w"][sel].astype(np.float64)
+            ok = (wg > 0) & (we > 0)
+            if kind != 2:
+                assert ok.all(), tag
+            if ok.sum() > 4:
+                compare_weights((wg[ok] / wg[ok].sum()).astype(np.float32), (we[ok] / we[ok].sum()).astype(np.float32), method == 2, tag, math_mode)
+        done += 1
+    assert done >= 2, "no snapshot with two re-observed landmarks"
