@@ -42,6 +42,40 @@ def test_no_gpu_fails_loudly():
     assert e.value.code == -4 and "no CPU fallback" in str(e.value)
 
 
+def test_particle_association_binding_matches_the_header():
+    """slamgpu_particle_assoc as the Python tests pass it is the header's struct, field for field (a C program prints the offsets),
+    and the per-particle entry points refuse a null context through the error channel -- no GPU needed for either."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    from slam_amd import capi
+    root = os.path.dirname(DATA)
+    src = """#include <stdio.h>
+#include <stddef.h>
+#include "slamgpu.h"
+int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %d\\n", sizeof(slamgpu_particle_assoc), offsetof(slamgpu_particle_assoc, gate_reject),
+    offsetof(slamgpu_particle_assoc, gate_augment), offsetof(slamgpu_particle_assoc, mode), offsetof(slamgpu_particle_assoc, new_share),
+    offsetof(slamgpu_particle_assoc, p_new), offsetof(slamgpu_particle_assoc, census_every), offsetof(slamgpu_particle_assoc, excl_base),
+    offsetof(slamgpu_particle_assoc, excl_per_m), offsetof(slamgpu_particle_assoc, unique_ratio), (int) SLAMGPU_FLAG_PARTICLE_MAPS); return 0; }
+"""
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "o.c"), "w").write(src)
+        subprocess.run(["gcc", "-std=c99", "-I" + os.path.join(root, "include"), "-o", os.path.join(d, "o"), os.path.join(d, "o.c")], check=True)
+        got = [int(v) for v in subprocess.run([os.path.join(d, "o")], capture_output=True, text=True, check=True).stdout.split()]
+    P = capi.ParticleAssoc
+    want = [C.sizeof(P)] + [getattr(P, f).offset for f in ("gate_reject", "gate_augment", "mode", "new_share", "p_new", "census_every", "excl_base",
+                                                          "excl_per_m", "unique_ratio")] + [capi.FLAG_PARTICLE_MAPS]
+    assert got == want, (got, want)
+    L = capi.load_library()
+    o = P()
+    o.p_new = 1.0
+    z = np.zeros(2, np.float32)
+    R = np.eye(2, dtype=np.float32)
+    assert L.slamgpu_update_particle(None, z.ctypes.data_as(C.c_void_p), 1, R.ctypes.data_as(C.c_void_p), C.byref(o), None, None, None) < 0
+    assert L.slamgpu_update_labels(None, z.ctypes.data_as(C.c_void_p), 1, R.ctypes.data_as(C.c_void_p), None, C.byref(o), None, None, None) < 0
+    assert L.slamgpu_last_error()
+
+
 def test_multi_window_is_validated_before_any_device_call():
     """slamgpu_jacobians_multi walks the self-describing records on the host first: a malformed window is refused as such with or
     without a GPU, a well-formed one reaches the device (and without a GPU fails loudly there: no CPU fallback)."""
