@@ -332,7 +332,8 @@ typedef struct slamgpu_particle_assoc {
      * beside it.  With the rule on, an observation no landmark gates is placed in the world from the particle's pose; if a
      * landmark the particle holds lies within excl_base + excl_per_m * range [m] of that point the observation cannot be new: it
      * is matched with that landmark when no other lies within unique_ratio times the distance, and discarded otherwise.
-     * SLAMGPU_ASSOC_EXHAUSTIVE / _AUTO (which then scans exhaustively) only. */
+     * SLAMGPU_ASSOC_EXHAUSTIVE / _AUTO (which then scans exhaustively) only: O(N nz Nf), refused with SLAMGPU_ERR_CAPACITY beyond
+     * 4e10 gate evaluations in a step (maps of a few hundred landmarks are its range). */
     float excl_base, excl_per_m, unique_ratio;
 } slamgpu_particle_assoc;
 int slamgpu_update_particle(slamgpu_ctx *ctx, const float *z, int32_t nz, const float R[4], const slamgpu_particle_assoc *opt,

@@ -2835,6 +2835,11 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
         return fail(SLAMGPU_ERR_INVALID, "the association grid needs a single context (shards: SLAMGPU_ASSOC_EXHAUSTIVE)");
     const bool excl = excl3 && excl3[0] + excl3[1] > 0.0f;  // (the exclusion rule: the exhaustive scan only)
     if (excl && mode == SLAMGPU_ASSOC_GRID) return fail(SLAMGPU_ERR_INVALID, "the exclusion rule needs SLAMGPU_ASSOC_EXHAUSTIVE (or _AUTO)");
+    // (... and an exhaustive scan is O(N nz Nf): refused where it would run for seconds -- 10^5 particles x 865 observations x 10 000
+    // landmarks would be 10^12 gate evaluations in one launch -- instead of looking like a hang)
+    if (excl && (double) c->B.n * (double) nz * (double) c->nf > 4e10)
+        return fail(SLAMGPU_ERR_CAPACITY, "the exclusion rule scans exhaustively: %d particles x %d observations x %d landmarks is too much for one launch; "
+                    "turn it off (excl_base = excl_per_m = 0) on maps of this size", c->B.n, nz, c->nf);
     bool grid = single && !excl && (mode == SLAMGPU_ASSOC_GRID || (mode == SLAMGPU_ASSOC_AUTO && c->nf >= 64));
     const bool want_vote = consensus || support;
     float *z_dev = nullptr;
