@@ -3212,6 +3212,17 @@ int do_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const float R
 
     const bool need_normals = c->cfg.method == SLAMGPU_FASTSLAM2 && (m > 0 || n > 0);
     if (tape && need_normals && !normals) return fail(SLAMGPU_ERR_INVALID, "TAPE mode needs normals[3N] and strata[N]");
+    // the labels resolved into what the launch reads (everything that can fail on the way there comes BEFORE the host's bookkeeping moves)
+    HIP_TRY(hipMemcpyAsync(first_dev, uidx.data(), sizeof(int32_t) * (size_t) cap_nf, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(news_dev, newk.data(), sizeof(int32_t) * (size_t) nz, hipMemcpyHostToDevice, c->stream));
+    if (n) HIP_TRY(hipMemcpyAsync(idn_dev, idn.data(), sizeof(int32_t) * (size_t) n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // (pageable sources)
+    {
+        Timed t(c, "particle_resolve");
+        c->k->pp_resolve(c->stream, c->pp_lab_dev, N, nz, c->B.ncap, first_dev, news_dev, m, n, opt->p_new, c->cfg.log_weights, c->pp_obs_dev,
+                         c->pp_wf_dev, c->pp_any_dev);
+    }
+    HIP_TRY(hipGetLastError());
     c->obs_step++;
     // genealogy bookkeeping, as do_update's: every packet entry is written by every particle (updated or copied forward) and moves
     // to the row this update opens
@@ -3301,17 +3312,6 @@ int do_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const float R
     }
     for (int r : left) c->free_rows.push_back(r);
 
-    // the labels resolved into what the launch reads
-    HIP_TRY(hipMemcpyAsync(first_dev, uidx.data(), sizeof(int32_t) * (size_t) cap_nf, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(news_dev, newk.data(), sizeof(int32_t) * (size_t) nz, hipMemcpyHostToDevice, c->stream));
-    if (n) HIP_TRY(hipMemcpyAsync(idn_dev, idn.data(), sizeof(int32_t) * (size_t) n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // (pageable sources)
-    {
-        Timed t(c, "particle_resolve");
-        c->k->pp_resolve(c->stream, c->pp_lab_dev, N, nz, c->B.ncap, first_dev, news_dev, m, n, opt->p_new, c->cfg.log_weights, c->pp_obs_dev,
-                         c->pp_wf_dev, c->pp_any_dev);
-    }
-    HIP_TRY(hipGetLastError());
     PerParticle ppa{c->pp_obs_dev, c->pp_z_dev, idn_dev, c->pp_wf_dev, c->pp_any_dev};
     c->pp_launch = &ppa;
     const int rc = issue_update(c, U, fresh, n_rows, need_normals, normals, strata, false);

@@ -718,7 +718,7 @@
                 auto first_pass = [&](int k, float4 la, float lb) {
                     if constexpr (PP) {
                         const int j = pp_j(k);
-                        if (j < 0) return;
+                        if (j < 0 || la.x != la.x) return;  // (not matched; or -- caller-made labels only -- a landmark this particle does not hold)
                         const Obs2 o = observe2(x, y, th, la.x, la.y, la.z, la.w, lb, r00, rl, r11);
                         proposal_update(x, y, th, P, o, ppa.z[2 * j] - o.zp0, wrap_pi(ppa.z[2 * j + 1] - o.zp1));
                     } else {
@@ -754,7 +754,7 @@
                 auto second_pass = [&](int k, float4 la, float lb) {
                     if constexpr (PP) {
                         const int j = pp_j(k);
-                        if (j >= 0) {
+                        if (j >= 0 && la.x == la.x) {
                             const Obs2 o = observe2(xs, ys, ths, la.x, la.y, la.z, la.w, lb, r00, rl, r11);
                             const Gauss2 g = feature_update2(la.x, la.y, la.z, la.w, lb, o, ppa.z[2 * j] - o.zp0, wrap_pi(ppa.z[2 * j + 1] - o.zp1));
                             if (logw) dl += (double) (g.E + __logf(g.norm));
@@ -858,7 +858,7 @@
                     [[maybe_unused]] int jo = 0;  // (PP: this particle's observation of the landmark; the z reads below stay where they were)
                     if constexpr (PP) {
                         jo = pp_j(k);
-                        if (jo < 0) return;
+                        if (jo < 0 || la.x != la.x) return;  // (not matched; or -- caller-made labels only -- a landmark this particle does not hold)
                     }
                     // Jacobians at the running mean (fastslam2.cpp:320,:348)
                     Jac j = jacobian(x, y, th, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
@@ -928,7 +928,7 @@
                     [[maybe_unused]] int jo = 0;
                     if constexpr (PP) {
                         jo = pp_j(k);
-                        if (jo < 0) {  // (not this particle's landmark in this step: the record moves on unchanged)
+                        if (jo < 0 || la.x != la.x) {  // (not this particle's landmark in this step: the record moves on unchanged)
                             store_lmk(idf[k], buf_of(k), la, lb);
                             return;
                         }
@@ -997,7 +997,7 @@
                 auto one_pass = [&](int k, float4 la, float lb) {
                     if constexpr (PP) {
                         const int j = pp_j(k);
-                        if (j >= 0) {
+                        if (j >= 0 && la.x == la.x) {
                             const Obs2 o = observe2(x, y, th, la.x, la.y, la.z, la.w, lb, r00, rl1, r11);
                             const Gauss2 g = feature_update2(la.x, la.y, la.z, la.w, lb, o, ppa.z[2 * j] - o.zp0, wrap_pi(ppa.z[2 * j + 1] - o.zp1));
                             if (logw) dl += (double) (g.E + __logf(g.norm));
@@ -1036,7 +1036,7 @@
                     [[maybe_unused]] int jo = 0;
                     if constexpr (PP) {
                         jo = pp_j(k);
-                        if (jo < 0) {  // (not this particle's landmark in this step: the record moves on unchanged)
+                        if (jo < 0 || la.x != la.x) {  // (not this particle's landmark in this step: the record moves on unchanged)
                             store_lmk(idf[k], buf_of(k), la, lb);
                             return;
                         }
