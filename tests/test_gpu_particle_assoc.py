@@ -40,15 +40,16 @@ def _predicts(s, st, tape):
         s.predict(float(V), float(G), tape["Q"], float(tape["dt"]), float(phi))
 
 
-@pytest.mark.parametrize("method,name", [(2, "FASTSLAM2"), (1, "FASTSLAM1")])
+@pytest.mark.parametrize("method,name,logw", [(2, "FASTSLAM2", False), (1, "FASTSLAM1", False), (2, "FASTSLAM2", True), (1, "FASTSLAM1", True)])
 @pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
-def test_unanimous_particles_take_the_known_association_step(sg, method, name, math_mode):
+def test_unanimous_particles_take_the_known_association_step(sg, method, name, logw, math_mode):
     """Every particle carries the labels dataAssociationKnown would give (core.cpp:91-120): 60 steps of example_webmap through
     slamgpu_update_labels leave the state slamgpu_update leaves, bit for bit (poses, covariances, weights, every landmark record,
-    Neff and the resampling decisions) -- on plain rows and against the compact layout the known association runs on."""
+    Neff and the resampling decisions) -- on plain rows and against the compact layout the known association runs on; linear and
+    log-weight contexts."""
     N, steps = 1000, 60
     tape = _tape(name, N, steps)
-    kw = dict(method=method, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=11, math_mode=math_mode)
+    kw = dict(method=method, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=11, math_mode=math_mode, log_weights=logw)
     a = sg.SlamGpu(N, tape["nlm"], **kw)
     b = sg.SlamGpu(N, tape["nlm"], particle_maps=True, **kw)
     for t, st in enumerate(tape["steps"]):
