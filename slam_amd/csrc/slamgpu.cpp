@@ -249,6 +249,7 @@ struct slamgpu_ctx {
     uint8_t *pp_any_dev = nullptr;   // [ncap]
     std::vector<char> pp_dead;       // landmark slots no particle holds any more (their hypotheses died in a resample): out of the
     std::vector<int32_t> pp_dead_list;  // association (retired) until a later landmark opens them again
+    bool retired_stale = false;      // the host's retired flags have changed since the device's mask was written (retired_upload clears it)
     uint64_t pp_steps = 0;
     const PerParticle *pp_launch = nullptr;  // set around issue_update by do_update_particle: the launch takes update_kernel<.., PP = true>
     float4 *items_dev = nullptr;  // [2 cap_items]: kernels.h: AssocGridArgs::items
@@ -3041,6 +3042,7 @@ int retired_upload(slamgpu_ctx *c) {
         if (c->retired[(size_t) j]) mask[(size_t) j >> 5] |= 1u << (j & 31);
     HIP_TRY(hipStreamSynchronize(c->stream));  // (an association in flight may still read the old mask)
     HIP_TRY(hipMemcpy(c->retired_dev, mask.data(), sizeof(uint32_t) * words, hipMemcpyHostToDevice));
+    c->retired_stale = false;
     return 0;
 }
 }  // namespace
@@ -3156,7 +3158,7 @@ int do_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const float R
     const int m = (int) touched.size();
     if (c->pp_dead.empty()) c->pp_dead.assign((size_t) cap_nf, 0);
     if (c->retired.empty()) c->retired.assign((size_t) cap_nf, 0);
-    bool mask_dirty = false;
+    bool &mask_dirty = c->retired_stale;  // (sticky: a call that fails between a change of the flags and the upload leaves it set for the next one)
     if (census) {
         // a slot nobody holds any more is dead: out of the association, free for a later landmark
         for (int l = 0; l < nf0; l++)

@@ -67,6 +67,11 @@ def test_default_line_single_gpu():
     r5 = also[(5, "fast")]["roofline"]
     assert r5["algorithmic_frac"] > 0.9 and r5["algorithmic_frac"] > 1.5 * r5["frac"]
     assert also[(3, "strict")]["ms_per_step"] > j["ms_per_step"]
+    # the association unknown and carried into the update per particle, beside the headline (same map, same particle count)
+    pa = j["particle_association"]
+    assert "error" not in pa, pa
+    assert pa["config"]["slots_in_use"] == 35 and pa["config"]["best_of_first_256_particles_holds"] == 35 and pa["config"]["mean_abs_pose_error_m"] < 1.0
+    assert pa["ms_per_step"] > j["ms_per_step"] and {"associate", "particle_census", "particle_resolve", "fs2_update"} <= set(pa["kernels"])
     c = j["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 1e4 and "sample" in c and c["unit"] == j["unit"]
     assert j["config"]["degenerate_steps"] == 0
