@@ -2855,7 +2855,10 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
         if (!lab_dev && lab_ext) lab_dev = lab_ext;
         if (!lab_dev) step(hipMalloc((void **) &lab_dev, sizeof(int32_t) * (size_t) N * nz), "hipMalloc(labels)");
     };
-    step(hipMalloc((void **) &z_dev, sizeof(float) * 2 * (size_t) nz), "hipMalloc");
+    // (the per-particle update keeps the observations in a buffer of the context: no allocation per step)
+    const bool z_own = !(lab_ext && c->pp_z_dev && nz <= c->pp_nz_cap);
+    if (z_own) step(hipMalloc((void **) &z_dev, sizeof(float) * 2 * (size_t) nz), "hipMalloc");
+    else z_dev = c->pp_z_dev;
     step(hipMemcpyAsync(z_dev, z, sizeof(float) * 2 * (size_t) nz, hipMemcpyHostToDevice, c->stream), "H2D");
     step(hipStreamSynchronize(c->stream), "sync");
     if (stats) {
@@ -2990,7 +2993,7 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
     }
     if (ev0) (void) hipEventDestroy(ev0);
     if (ev1) (void) hipEventDestroy(ev1);
-    if (z_dev) (void) hipFree(z_dev);
+    if (z_dev && z_own) (void) hipFree(z_dev);
     if (lab_dev && lab_dev != lab_ext) (void) hipFree(lab_dev);
     if (votes_dev) (void) hipFree(votes_dev);
     if (rc) return rc;
@@ -3134,7 +3137,9 @@ int do_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const float R
     int32_t *first_dev = c->pp_tab_dev, *hold_dev = first_dev + cap_nf, *news_dev = hold_dev + cap_nf, *idn_dev = news_dev + c->pp_nz_cap;
     const bool census = opt->census_every > 0 && nf0 > 0 && (c->pp_steps % (uint64_t) opt->census_every) == 0;
     c->pp_steps++;
-    std::vector<int32_t> first((size_t) std::max(nf0, 1)), news((size_t) nz), hold((size_t) std::max(nf0, 1), 1);
+    // (first | holders | news are one stretch of the table: one copy down)
+    std::vector<int32_t> down(2 * (size_t) cap_nf + (size_t) nz);
+    int32_t *const first = down.data(), *const hold = first + cap_nf, *const news = hold + cap_nf;
     HIP_TRY(hipMemcpyAsync(c->pp_z_dev, z, sizeof(float) * 2 * (size_t) nz, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) first_dev, 0x7fffffff, (size_t) cap_nf, c->stream));
     HIP_TRY(hipMemsetAsync(hold_dev, 0, sizeof(int32_t) * (size_t) cap_nf, c->stream));
@@ -3145,15 +3150,13 @@ int do_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const float R
         if (census) c->k->pp_holders(c->stream, c->B, nf0, hold_dev);
     }
     HIP_TRY(hipGetLastError());
-    if (nf0 > 0) HIP_TRY(hipMemcpyAsync(first.data(), first_dev, sizeof(int32_t) * (size_t) nf0, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(news.data(), news_dev, sizeof(int32_t) * (size_t) nz, hipMemcpyDeviceToHost, c->stream));
-    if (census) HIP_TRY(hipMemcpyAsync(hold.data(), hold_dev, sizeof(int32_t) * (size_t) nf0, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(down.data(), first_dev, sizeof(int32_t) * down.size(), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
 
     // the packet's re-observed entries: every slot some particle matched, in the order of the first observation that names it
     std::vector<std::pair<int32_t, int32_t>> touched;
     for (int l = 0; l < nf0; l++)
-        if (first[(size_t) l] != 0x7fffffff) touched.push_back({first[(size_t) l], l});
+        if (first[l] != 0x7fffffff) touched.push_back({first[l], l});
     std::sort(touched.begin(), touched.end());
     const int m = (int) touched.size();
     if (c->pp_dead.empty()) c->pp_dead.assign((size_t) cap_nf, 0);
@@ -3162,7 +3165,7 @@ int do_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const float R
     if (census) {
         // a slot nobody holds any more is dead: out of the association, free for a later landmark
         for (int l = 0; l < nf0; l++)
-            if (hold[(size_t) l] == 0 && !c->pp_dead[(size_t) l] && first[(size_t) l] == 0x7fffffff) {
+            if (hold[l] == 0 && !c->pp_dead[(size_t) l] && first[l] == 0x7fffffff) {
                 c->pp_dead[(size_t) l] = 1;
                 c->pp_dead_list.push_back(l);
                 if (!c->retired[(size_t) l]) {
@@ -3179,7 +3182,7 @@ int do_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const float R
     std::vector<int32_t> newk((size_t) nz, -1), idn;
     int reused = 0, fresh = 0, dropped = 0;
     for (int j = 0; j < nz; j++) {
-        if (news[(size_t) j] < need) continue;
+        if (news[j] < need) continue;
         int slot = -1;
         if (!c->pp_dead_list.empty()) {
             slot = c->pp_dead_list.back();
@@ -3197,8 +3200,12 @@ int do_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const float R
     const int n = (int) idn.size();
     if (int rc = pp_reserve(c, nz, (size_t) m + n + 1)) return rc;
     first_dev = c->pp_tab_dev, hold_dev = first_dev + cap_nf, news_dev = hold_dev + cap_nf, idn_dev = news_dev + c->pp_nz_cap;
-    std::vector<int32_t> uidx((size_t) cap_nf, -1);
-    for (int k = 0; k < m; k++) uidx[(size_t) touched[(size_t) k].second] = k;
+    // (uidx | holders (not read again) | newk | idn: the table's layout, one copy up)
+    std::vector<int32_t> up(2 * (size_t) cap_nf + 2 * (size_t) c->pp_nz_cap, -1);
+    int32_t *const uidx = up.data(), *const newk_up = uidx + 2 * (size_t) cap_nf, *const idn_up = newk_up + c->pp_nz_cap;
+    for (int k = 0; k < m; k++) uidx[touched[(size_t) k].second] = k;
+    for (int j = 0; j < nz; j++) newk_up[j] = newk[(size_t) j];
+    for (int q = 0; q < n; q++) idn_up[q] = idn[(size_t) q];
     for (int q = 0; q < n; q++)
         if (idn[(size_t) q] < nf0) {  // a dead slot comes back into the association
             const int l = idn[(size_t) q];
@@ -3215,10 +3222,8 @@ int do_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const float R
     const bool need_normals = c->cfg.method == SLAMGPU_FASTSLAM2 && (m > 0 || n > 0);
     if (tape && need_normals && !normals) return fail(SLAMGPU_ERR_INVALID, "TAPE mode needs normals[3N] and strata[N]");
     // the labels resolved into what the launch reads (everything that can fail on the way there comes BEFORE the host's bookkeeping moves)
-    HIP_TRY(hipMemcpyAsync(first_dev, uidx.data(), sizeof(int32_t) * (size_t) cap_nf, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(news_dev, newk.data(), sizeof(int32_t) * (size_t) nz, hipMemcpyHostToDevice, c->stream));
-    if (n) HIP_TRY(hipMemcpyAsync(idn_dev, idn.data(), sizeof(int32_t) * (size_t) n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));  // (pageable sources)
+    HIP_TRY(hipMemcpyAsync(first_dev, up.data(), sizeof(int32_t) * up.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // (pageable source)
     {
         Timed t(c, "particle_resolve");
         c->k->pp_resolve(c->stream, c->pp_lab_dev, N, nz, c->B.ncap, first_dev, news_dev, m, n, opt->p_new, c->cfg.log_weights, c->pp_obs_dev,
