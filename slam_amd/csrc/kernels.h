@@ -529,10 +529,12 @@ struct AssocGeom {
     int32_t nx, ny;
     float px0, px1, py0, py1;     // bounding box of the particle poses
     float zmax;                   // largest observed range
+    float th_ref, dth0, dth1;     // headings of the particle poses: th_ref + [dth0, dth1] (dth1 - dth0 >= 2 pi: no bound)
     int32_t total, overflow;      // grid entries written / the entry buffer was too small (the caller falls back to brute force)
     unsigned long long pairs;     // (particle, observation, landmark) triples evaluated by associate_grid_kernel
 };
 constexpr int kAssocMaxCells = 64;  // per axis
+constexpr int kAssocObsPerBlock = 4;  // AssocGridArgs::obs_per_block
 // weighted vote per observation, on the device: a small open-addressing table per observation (the labels one observation
 // draws from 10^5 particles are the handful of landmarks of one grid cell, NEW and DISCARD)
 constexpr int kVoteSlots = 32;
@@ -547,12 +549,16 @@ struct AssocGridArgs {
     int32_t *cell_start;          // [nx * ny + 1] exclusive prefix of the cell populations
     int32_t *cell_fill;           // [nx * ny] cursors of the fill pass
     float4 *items;                // [2 cap_items] cell after cell, an entry = two float4: (xmin, xmax, ymin, ymax) of the landmark's box and
-                                  // (radial bound of this call's gates, landmark id as bits, 0, 0): what the walk needs of a landmark in ONE
+                                  // (radial bound of this call's gates, landmark id as bits, tmax, the same bound for G1): what the walk needs of a landmark in ONE
                                   // contiguous read (round 6: an id here and the box behind it were two dependent trips per entry)
     int32_t cap_items, nf, nz;
     const float *z;               // [2 nz] observations (range, bearing), device
     float r00, r11, G;            // R diagonal; G = max(gate_reject, gate_augment) with the safety margin
-    int32_t lab_by_obs, pad_lab;  // labels laid out [nz][ncap] (the per-particle update's) instead of [n][nz]
+    float G1;                     // gate_reject with the safety margin: the bound of the walk's FIRST pass (associate_grid_kernel)
+    int32_t obs_per_block;        // observations one thread of associate_grid_kernel works through (blockIdx.y = a group of that many)
+    int32_t lab_by_obs;           // labels laid out [nz][ncap] (the per-particle update's) instead of [n][nz]
+    int32_t lcap;                 // candidate LISTS per observation instead of grid cells (assoc_lists_kernel): entries of observation q at
+                                  // items[2 (q lcap + k)], k < cell_start[q]; 0: the grid
     VoteSlot *votes;              // [nz][kVoteSlots] or null: the weighted vote per observation (AssocGeom::overflow bit 1: a table filled up)
     int32_t logw;                 // the context keeps log-weights
 };
@@ -618,6 +624,8 @@ struct KernelTable {
     void (*lmk_box)(hipStream_t, const Buffers &, const int32_t *ids_dev, int count, const uint32_t *retired_dev, LmkBox *box_dev);
     // geometry + grid of the landmark boxes for one association call (four small launches)
     void (*assoc_grid)(hipStream_t, const Buffers &, const AssocGridArgs &);
+    // ... or geometry + one candidate list per observation (AssocGridArgs::lcap > 0; nz <= kAssocMaxCells^2)
+    void (*assoc_lists)(hipStream_t, const Buffers &, const AssocGridArgs &);
     // slamgpu_associate through the grid: the same labels as `associate`, evaluating only the landmarks of one cell per
     // (particle, observation)
     void (*associate_grid)(hipStream_t, const Buffers &, const AssocGridArgs &, const float *R4, float gate_reject, float gate_augment,

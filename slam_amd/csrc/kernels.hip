@@ -2662,15 +2662,20 @@ __global__ void __launch_bounds__(kBlock) lmk_box_kernel(Buffers B, const int32_
 // one block: bounding box of the particle poses, largest observed range => the grid over the region the observations can
 // point into (pose box grown by the largest range)
 __global__ void __launch_bounds__(kBlock) assoc_geom_kernel(Buffers B, AssocGridArgs A) {
-    __shared__ float sh[5][kBlock / kWave];
+    __shared__ float sh[7][kBlock / kWave];
     const int cur = B.ctrl->live[B.slot];
-    float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY, zm = 0.0f;
+    float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY, zm = 0.0f, t0 = INFINITY, t1 = -INFINITY;
+    const float th_ref = B.n > 0 ? B.poseA[cur][0].z : 0.0f;
     for (int k = threadIdx.x; k < B.n; k += kBlock) {
         const float4 v = B.poseA[cur][k];
         x0 = fminf(x0, v.x);
         x1 = fmaxf(x1, v.x);
         y0 = fminf(y0, v.y);
         y1 = fmaxf(y1, v.y);
+        // heading relative to particle 0's, wrapped to [-pi, pi] (exactly: remainder): the set's headings are th_ref + [t0, t1] modulo 2 pi
+        const float dt = remainderf(v.z - th_ref, 6.28318530717958648f);
+        t0 = fminf(t0, dt);
+        t1 = fmaxf(t1, dt);
     }
     for (int q = threadIdx.x; q < A.nz; q += kBlock) zm = fmaxf(zm, fabsf(A.z[2 * q]));
 #pragma unroll
@@ -2680,10 +2685,12 @@ __global__ void __launch_bounds__(kBlock) assoc_geom_kernel(Buffers B, AssocGrid
         y0 = fminf(y0, __shfl_xor(y0, d, kWave));
         y1 = fmaxf(y1, __shfl_xor(y1, d, kWave));
         zm = fmaxf(zm, __shfl_xor(zm, d, kWave));
+        t0 = fminf(t0, __shfl_xor(t0, d, kWave));
+        t1 = fmaxf(t1, __shfl_xor(t1, d, kWave));
     }
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     if (lane == 0) {
-        sh[0][wv] = x0; sh[1][wv] = x1; sh[2][wv] = y0; sh[3][wv] = y1; sh[4][wv] = zm;
+        sh[0][wv] = x0; sh[1][wv] = x1; sh[2][wv] = y0; sh[3][wv] = y1; sh[4][wv] = zm; sh[5][wv] = t0; sh[6][wv] = t1;
     }
     __syncthreads();
     for (int cidx = threadIdx.x; cidx < kAssocMaxCells * kAssocMaxCells + 1; cidx += kBlock) {
@@ -2697,6 +2704,13 @@ __global__ void __launch_bounds__(kBlock) assoc_geom_kernel(Buffers B, AssocGrid
         g.py0 = fminf(fminf(sh[2][0], sh[2][1]), fminf(sh[2][2], sh[2][3]));
         g.py1 = fmaxf(fmaxf(sh[3][0], sh[3][1]), fmaxf(sh[3][2], sh[3][3]));
         g.zmax = fmaxf(fmaxf(sh[4][0], sh[4][1]), fmaxf(sh[4][2], sh[4][3]));
+        g.th_ref = th_ref;
+        g.dth0 = fminf(fminf(sh[5][0], sh[5][1]), fminf(sh[5][2], sh[5][3]));
+        g.dth1 = fmaxf(fmaxf(sh[6][0], sh[6][1]), fmaxf(sh[6][2], sh[6][3]));
+        if (!(g.dth0 <= g.dth1)) {  // (no particle)
+            g.dth0 = -3.14159274f;
+            g.dth1 = 3.14159274f;
+        }
         const float margin = 1.0f + 1e-3f * (fabsf(g.px0) + fabsf(g.px1) + fabsf(g.py0) + fabsf(g.py1) + g.zmax);
         g.x0 = g.px0 - g.zmax - margin;
         g.y0 = g.py0 - g.zmax - margin;
@@ -2764,7 +2778,8 @@ __global__ void __launch_bounds__(kBlock) assoc_count_kernel(AssocGridArgs A, in
                 const int at = A.cell_start[cell] + atomicAdd(&A.cell_fill[cell], 1);
                 if (at < A.cap_items) {
                     A.items[2 * (size_t) at] = make_float4(bx.xmin, bx.xmax, bx.ymin, bx.ymax);
-                    A.items[2 * (size_t) at + 1] = make_float4(1.01f * sqrtf(A.G * (bx.tmax + A.r00)) + 1e-3f, __int_as_float(j), bx.tmax, 0.0f);
+                    A.items[2 * (size_t) at + 1] = make_float4(1.01f * sqrtf(A.G * (bx.tmax + A.r00)) + 1e-3f, __int_as_float(j), bx.tmax,
+                                                               1.01f * sqrtf(A.G1 * (bx.tmax + A.r00)) + 1e-3f);
                 }
             }
         }
@@ -2806,7 +2821,73 @@ __global__ void __launch_bounds__(kBlock) assoc_scan_kernel(AssocGridArgs A) {
     }
 }
 
-constexpr int kAssocObsPerBlock = 4;
+// Candidate lists per observation (round 6), in place of the grid when there are few enough observations.  A grid cell serves every
+// observation whose point falls into it, so it holds every landmark within (cell + 2 radii) -- ~33 entries on the 10 000-landmark map
+// at MAX_RANGE 60, where the bearing gate alone is 5 m wide at 60 m -- and each (particle, observation) pair walks all of them to
+// evaluate ~3.  One block per observation knows the observation: the landmarks it keeps are those whose box lies within the cell
+// bound (assoc_radius) of the box of the points the observation implies over ALL particle poses (pose box + range x the arc of the
+// set's headings) AND within the radial ring of the range -- the entry's own pre-test, taken over the pose box instead of one pose.
+// Both are necessary for a gate to pass for any particle, so the labels stay those of the exhaustive scan.
+SLAM_DEV void arc_range(float a0, float a1, bool cosine, float &lo, float &hi) {
+    // min / max of cos (or sin) over [a0, a1], a1 >= a0
+    const float sh = cosine ? 0.0f : 1.57079632679489662f;  // sin x = cos(x - pi / 2)
+    const float b0 = a0 - sh, b1 = a1 - sh;
+    const float c0 = cosf(b0), c1 = cosf(b1);
+    lo = fminf(c0, c1);
+    hi = fmaxf(c0, c1);
+    if (b1 - b0 >= 6.28318530717958648f) {
+        lo = -1.0f;
+        hi = 1.0f;
+        return;
+    }
+    // a maximum (angle = 2 pi k) or a minimum (angle = pi + 2 pi k) inside the interval?
+    const float inv = 0.159154943091895336f;
+    if (floorf(b1 * inv) > floorf(b0 * inv) || b0 * inv == floorf(b0 * inv)) hi = 1.0f;
+    if (floorf((b1 - 3.14159265358979324f) * inv) > floorf((b0 - 3.14159265358979324f) * inv)) lo = -1.0f;
+}
+__global__ void __launch_bounds__(kBlock) assoc_lists_kernel(AssocGridArgs A) {
+    __shared__ int32_t sh_n;
+    const int q = blockIdx.x;
+    const AssocGeom g = *A.geom;
+    if (threadIdx.x == 0) sh_n = 0;
+    __syncthreads();
+    const float zr = A.z[2 * q], zb = A.z[2 * q + 1];
+    // the points this observation implies: pose + zr (cos, sin)(theta + zb), theta in th_ref + [dth0, dth1] (a little wider: rounding)
+    const float a0 = g.th_ref + g.dth0 + zb - 1e-3f, a1 = g.th_ref + g.dth1 + zb + 1e-3f;
+    float cl, ch, sl, shh;
+    arc_range(a0, a1, true, cl, ch);
+    arc_range(a0, a1, false, sl, shh);
+    const float slack = 1e-3f * (1.0f + fabsf(zr)) + 1e-4f * (fabsf(g.px0) + fabsf(g.px1) + fabsf(g.py0) + fabsf(g.py1));
+    const float qx0 = g.px0 + fminf(zr * cl, zr * ch) - slack, qx1 = g.px1 + fmaxf(zr * cl, zr * ch) + slack;
+    const float qy0 = g.py0 + fminf(zr * sl, zr * shh) - slack, qy1 = g.py1 + fmaxf(zr * sl, zr * shh) + slack;
+    for (int j = threadIdx.x; j < A.nf; j += kBlock) {
+        const LmkBox bx = A.box[j];
+        if (!(bx.xmin <= bx.xmax)) continue;  // (no estimate / retired: the empty box)
+        const float rho = assoc_radius(bx, g, A.r00, A.r11, A.G);
+        const float gx = fmaxf(fmaxf(bx.xmin - qx1, qx0 - bx.xmax), 0.0f), gy = fmaxf(fmaxf(bx.ymin - qy1, qy0 - bx.ymax), 0.0f);
+        if (gx * gx + gy * gy > rho * rho) continue;
+        // the radial ring over the pose box: some pose's distance to some estimate in the box must be within e of the range
+        const float e = 1.01f * sqrtf(A.G * (bx.tmax + A.r00)) + 1e-3f;
+        const float ex = fmaxf(fmaxf(bx.xmin - g.px1, g.px0 - bx.xmax), 0.0f), ey = fmaxf(fmaxf(bx.ymin - g.py1, g.py0 - bx.ymax), 0.0f);
+        const float fx = fmaxf(fabsf(bx.xmax - g.px0), fabsf(g.px1 - bx.xmin)), fy = fmaxf(fabsf(bx.ymax - g.py0), fabsf(g.py1 - bx.ymin));
+        const float dmin2 = ex * ex + ey * ey, dmax2 = fx * fx + fy * fy;
+        const float hi = zr + e, lo = zr - e;
+        if ((hi < 0.0f || hi * hi < dmin2 * 0.998f) || (lo > 0.0f && lo * lo > dmax2 * 1.002f)) continue;
+        const int at = atomicAdd(&sh_n, 1);
+        if (at < A.lcap) {
+            const size_t w = 2 * ((size_t) q * A.lcap + at);
+            A.items[w] = make_float4(bx.xmin, bx.xmax, bx.ymin, bx.ymax);
+            A.items[w + 1] = make_float4(e, __int_as_float(j), bx.tmax, 1.01f * sqrtf(A.G1 * (bx.tmax + A.r00)) + 1e-3f);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        A.cell_start[q] = min(sh_n, A.lcap);
+        atomicAdd(&A.geom->total, min(sh_n, A.lcap));
+        if (sh_n > A.lcap) atomicOr(&A.geom->overflow, 1);  // (the caller takes the grid)
+    }
+}
+
 
 // one vote into the table of an observation: open addressing, linear probing; returns false if the table is full
 SLAM_DEV bool vote_add(VoteSlot *tab, int label, float w) {
@@ -2827,6 +2908,7 @@ SLAM_DEV bool vote_add(VoteSlot *tab, int label, float w) {
     return false;
 }
 
+template <bool LISTS>
 __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, AssocGridArgs A, float r00, float r01, float r10, float r11, float gate1,
                                                                  float gate2, int32_t *__restrict__ labels) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -2840,10 +2922,10 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
     const float wi = on ? (A.logw ? expf(pa.w) : pa.w) : 0.0f;
     const int lane = threadIdx.x & (kWave - 1);
     bool full = false;
-    // blockIdx.y = a group of kAssocObsPerBlock observations: a particle's observations are independent of each other, and one
+    // blockIdx.y = a group of A.obs_per_block observations: a particle's observations are independent of each other, and one
     // thread walking all of them alone (1 300 on the 10 000-landmark map, ~65 dependent record reads each) left the
     // machine two thirds empty and every read exposed: 225 ms per call at 10^5 particles
-    const int q_lo = blockIdx.y * kAssocObsPerBlock, q_hi = min(A.nz, q_lo + kAssocObsPerBlock);
+    const int q_lo = blockIdx.y * A.obs_per_block, q_hi = min(A.nz, q_lo + A.obs_per_block);
     for (int q = q_lo; q < q_hi; q++) {
         int label = kVoteEmpty;
         if (on) {
@@ -2855,20 +2937,24 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
             sincosf(pa.z + zb, &sn, &cs);
 #endif
             const float px = pa.x + zr * cs, py = pa.y + zr * sn;
-            const int cx = min(max((int) floorf((px - g.x0) * g.inv_cs), 0), g.nx - 1);
-            const int cy = min(max((int) floorf((py - g.y0) * g.inv_cs), 0), g.ny - 1);
-            const int cell = cy * g.nx + cx;
+            int cell = 0;
+            if constexpr (!LISTS) {
+                const int cx = min(max((int) floorf((px - g.x0) * g.inv_cs), 0), g.nx - 1);
+                const int cy = min(max((int) floorf((py - g.y0) * g.inv_cs), 0), g.ny - 1);
+                cell = cy * g.nx + cx;
+            }
             float nbest = INFINITY, outer = INFINITY;
             int jbest = -1;
             // one entry of the cell: the radial pre-test on the landmark's box alone (every estimate of j lies in the box, so its
             // distance d from this pose is within [dmin, dmax] of the box; a gate needs |d - r| < the entry's bound), on SQUARED
             // distances (round 6: no square root per entry, and the bound without the factor (1 + pi / 2) the CELL radius needs and
             // this test never did -- |d - r| is |v0| exactly: 2.6 times fewer entries reach the gates), then the gates
-            auto visit = [&](const float4 bb, const float4 bt) {
+            // Gb / e: the gate bound of this pass of the walk and the entry's radial bound for it (see the passes below)
+            auto visit = [&](const float4 bb, const float4 bt, const float Gb, const float e) {
                 const float ex = fmaxf(fmaxf(bb.x - pa.x, pa.x - bb.y), 0.0f), ey = fmaxf(fmaxf(bb.z - pa.y, pa.y - bb.w), 0.0f);
                 const float fx = fmaxf(fabsf(bb.x - pa.x), fabsf(bb.y - pa.x)), fy = fmaxf(fabsf(bb.z - pa.y), fabsf(bb.w - pa.y));
                 const float dmin2 = ex * ex + ey * ey, dmax2 = fx * fx + fy * fy;
-                const float hi = zr + bt.x, lo = zr - bt.x;
+                const float hi = zr + e, lo = zr - e;
                 if ((hi < 0.0f || hi * hi < dmin2 * 0.998f) || (lo > 0.0f && lo * lo > dmax2 * 1.002f)) return;
                 {
                     // ... and, for the entries the ring lets through, the same bound as the cell radius (assoc_radius) with THIS pose's
@@ -2877,9 +2963,9 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
                     // of the point p this observation implies (d in [dmin, dmax] of the box from this pose), and l is in the box: the
                     // distance from p to the box must not exceed it.  Cuts the entries whose record is fetched (two dependent trips
                     // each: what the kernel waits for) by the bearing as well as the range
-                    const float t = bt.z, e = bt.x;
-                    const float Dg = dmin2 > 0.0f ? fminf(3.14159274f, sqrtf(A.G * (t * __builtin_amdgcn_rcpf(dmin2) * 1.001f + r11))) : 3.14159274f;
-                    const float rho = (e * (1.0f + 0.5f * Dg) + sqrtf(A.G * (t + dmax2 * r11))) * 1.01f + 1e-3f;
+                    const float t = bt.z;
+                    const float Dg = dmin2 > 0.0f ? fminf(3.14159274f, sqrtf(Gb * (t * __builtin_amdgcn_rcpf(dmin2) * 1.001f + r11))) : 3.14159274f;
+                    const float rho = (e * (1.0f + 0.5f * Dg) + sqrtf(Gb * (t + dmax2 * r11))) * 1.01f + 1e-3f;
                     const float qx = fmaxf(fmaxf(bb.x - px, px - bb.y), 0.0f), qy = fmaxf(fmaxf(bb.z - py, py - bb.w), 0.0f);
                     if (qx * qx + qy * qy > rho * rho) return;
                 }
@@ -2902,13 +2988,30 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
             // the walk: entries are self-contained (box + bound + id: ONE contiguous 32-byte read each, where an id and the box behind
             // it were two dependent trips), two in flight at a time; SQ counters before: 87 % of the wave cycles waiting, the SIMDs
             // a third busy (profiles/gated_association_r06.txt)
-            const int c0 = A.cell_start[cell], c1 = A.cell_start[cell + 1];
+            // (LISTS: the observation's own candidate list, assoc_lists_kernel)
+            const int c0 = LISTS ? q * A.lcap : A.cell_start[cell], c1 = LISTS ? c0 + A.cell_start[q] : A.cell_start[cell + 1];
+            // Two passes.  Whatever an observation is MATCHED with passes gate_reject, so a first walk bounded by gate_reject alone (G1:
+            // radii ~ sqrt(G1 / G) of the full ones) sees every landmark that can become jbest -- same candidates, same ties: the same
+            // label.  The wider bound of gate_augment is only needed to tell "new" from "discard" for an observation NOTHING matched: a
+            // second walk for those pairs alone (`outer` then runs over every candidate, as in a single pass).  With the grid this did
+            // not pay (the walk over a cell's ~33 entries was the cost: 8.52 against 8.32 ms at config 5); with the lists' ~3 entries
+            // the records fetched through the genealogy are the cost again, and the first pass fetches 40 % fewer.
             for (int at = c0; at < c1; at += 2) {
                 const float4 b0 = A.items[2 * (size_t) at], t0 = A.items[2 * (size_t) at + 1];
                 const int a1 = min(at + 1, c1 - 1);
                 const float4 b1 = A.items[2 * (size_t) a1], t1 = A.items[2 * (size_t) a1 + 1];
-                visit(b0, t0);
-                if (at + 1 < c1) visit(b1, t1);
+                visit(b0, t0, A.G1, t0.w);
+                if (at + 1 < c1) visit(b1, t1, A.G1, t1.w);
+            }
+            if (jbest < 0 && A.G1 < A.G) {
+                outer = INFINITY;
+                for (int at = c0; at < c1; at += 2) {
+                    const float4 b0 = A.items[2 * (size_t) at], t0 = A.items[2 * (size_t) at + 1];
+                    const int a1 = min(at + 1, c1 - 1);
+                    const float4 b1 = A.items[2 * (size_t) a1], t1 = A.items[2 * (size_t) a1 + 1];
+                    visit(b0, t0, A.G, t0.x);
+                    if (at + 1 < c1) visit(b1, t1, A.G, t1.x);
+                }
             }
             label = jbest > -1 ? jbest : (outer > gate2 ? kAssocNew : kAssocDiscard);
             if (labels) labels[A.lab_by_obs ? (size_t) q * S + i : (size_t) i * A.nz + q] = label;
@@ -3460,8 +3563,16 @@ static void launch_assoc_grid(hipStream_t st, const Buffers &B, const AssocGridA
 }
 
 static void launch_associate_grid(hipStream_t st, const Buffers &B, const AssocGridArgs &A, const float *R4, float g1, float g2, int32_t *labels) {
-    hipLaunchKernelGGL(associate_grid_kernel, dim3(B.ncap / kBlock, (A.nz + kAssocObsPerBlock - 1) / kAssocObsPerBlock), dim3(kBlock), 0, st, B, A,
-                       R4[0], R4[1], R4[2], R4[3], g1, g2, labels);
+    if (A.lcap > 0)
+        hipLaunchKernelGGL(associate_grid_kernel<true>, dim3(B.ncap / kBlock, (A.nz + A.obs_per_block - 1) / A.obs_per_block), dim3(kBlock), 0, st, B, A,
+                           R4[0], R4[1], R4[2], R4[3], g1, g2, labels);
+    else
+        hipLaunchKernelGGL(associate_grid_kernel<false>, dim3(B.ncap / kBlock, (A.nz + A.obs_per_block - 1) / A.obs_per_block), dim3(kBlock), 0, st, B, A,
+                           R4[0], R4[1], R4[2], R4[3], g1, g2, labels);
+}
+static void launch_assoc_lists(hipStream_t st, const Buffers &B, const AssocGridArgs &A) {
+    hipLaunchKernelGGL(assoc_geom_kernel, dim3(1), dim3(kBlock), 0, st, B, A);
+    hipLaunchKernelGGL(assoc_lists_kernel, dim3(A.nz), dim3(kBlock), 0, st, A);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -3582,7 +3693,7 @@ static void launch_pp_holders(hipStream_t st, const Buffers &B, int nf, int32_t 
 }
 
 static const KernelTable kTable = {launch_update, launch_update_particle, launch_update_persist, launch_resample, launch_resample_ref, launch_scan, launch_gather, launch_flatten, launch_identity, launch_decompact, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat, launch_observe, launch_observe_book, launch_associate,
-                                   launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish, launch_dist_gather, launch_dist_flags, launch_peek, launch_lmk_box, launch_assoc_grid,
+                                   launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish, launch_dist_gather, launch_dist_flags, launch_peek, launch_lmk_box, launch_assoc_grid, launch_assoc_lists,
                                    launch_associate_grid, launch_jacobians_multi, launch_pp_census, launch_pp_resolve, launch_pp_holders};
 
 }  // namespace SLAM_KNS

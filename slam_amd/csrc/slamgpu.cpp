@@ -2909,16 +2909,36 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
         G.r00 = R[0];
         G.r11 = R[3];
         G.G = std::max(gate_reject, gate_augment) * 1.001f;
+        G.G1 = std::min(gate_reject * 1.001f, G.G);
+        // observations per thread: as many as still leave ~2 000 workgroups (a workgroup's head -- Ctrl word, pose, geometry: dependent
+        // trips -- is paid once per group: at config 5, 10^5 particles x 865 observations, groups of 1 / 4 / 32 / 128 take 16.9 / 5.1 / 3.6 /
+        // 3.5 ms; round 5's fixed 4 dated from the grid's long walks)
+        G.obs_per_block = (int) std::min<int64_t>(64, std::max<int64_t>(kAssocObsPerBlock, (int64_t) (c->B.ncap / kBlock) * nz / 2048));
+        if (const char *e = getenv("SLAMGPU_ASSOC_OBS_PER_BLOCK")) G.obs_per_block = std::max(1, atoi(e));  // (diagnostic)
         G.votes = votes_dev;
         G.logw = c->cfg.log_weights;
         G.lab_by_obs = lab_ext ? 1 : 0;
         AssocGeom hg{};
+        // few enough observations: a candidate list per observation instead of the grid (kernels.hip: assoc_lists_kernel); a list that
+        // does not fit its share of the entry buffer sends the call to the grid (SLAMGPU_NO_ASSOC_LISTS=1: always the grid -- A/B, tests)
+        const int lcap = (nz > 0 && nz <= kAssocMaxCells * kAssocMaxCells && (double) nz * (double) c->nf <= 4e8 && getenv("SLAMGPU_NO_ASSOC_LISTS") == nullptr)
+                             ? (int) std::min<int64_t>(2048, (int64_t) c->cap_items / nz) : 0;
         if (!rc) {
             if (ev0) step(hipEventRecord(ev0, c->stream), "event");
             Timed t(c, "associate");
             if (!ids.empty()) c->k->lmk_box(c->stream, c->B, c->assoc_ids_dev, (int) ids.size(), c->retired_dev, c->box_dev);
-            c->k->assoc_grid(c->stream, c->B, G);
-            c->k->associate_grid(c->stream, c->B, G, R, gate_reject, gate_augment, lab_dev);
+            for (int attempt = lcap >= 16 ? 0 : 1; attempt < 2 && !rc; attempt++) {
+                G.lcap = attempt == 0 ? lcap : 0;
+                if (G.lcap) c->k->assoc_lists(c->stream, c->B, G);
+                else c->k->assoc_grid(c->stream, c->B, G);
+                c->k->associate_grid(c->stream, c->B, G, R, gate_reject, gate_augment, lab_dev);
+                step(hipGetLastError(), "launch");
+                if (attempt == 0) {  // (did every list fit?  the association kernel has left at once if not)
+                    step(hipMemcpyAsync(&hg, c->geom_dev, sizeof hg, hipMemcpyDeviceToHost, c->stream), "D2H");
+                    step(hipStreamSynchronize(c->stream), "sync");
+                    if (!(hg.overflow & 1)) break;
+                }
+            }
         }
         step(hipGetLastError(), "launch");
         if (ev1) step(hipEventRecord(ev1, c->stream), "event");
@@ -2960,7 +2980,7 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
                     // (more than 32 distinct labels for one observation: take the vote on the host from the full label array)
                     need_labels();
                     if (!rc) {
-                        G.votes = nullptr;
+                        G.votes = nullptr;  // (G.lcap: whichever of lists / grid the call ended with)
                         c->k->associate_grid(c->stream, c->B, G, R, gate_reject, gate_augment, lab_dev);
                         step(hipGetLastError(), "launch");
                     }

@@ -72,12 +72,16 @@ def test_device_association_matches_the_reference_decisions(kat_assoc, math_mode
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prefilter", ["lists", "grid"])
 @pytest.mark.parametrize("math_mode", [0, 1], ids=["strict", "fast"])
-def test_grid_prefilter_never_changes_a_reference_decision(kat_assoc, math_mode):
+def test_grid_prefilter_never_changes_a_reference_decision(kat_assoc, math_mode, prefilter, monkeypatch):
     """slamgpu_associate_ex, SLAMGPU_ASSOC_GRID against SLAMGPU_ASSOC_EXHAUSTIVE on the reference's decision vectors: the
     prefilter skips a landmark only where a bound that holds for every particle rules both gates out, so the label arrays must
-    be identical -- every group, every particle, every observation, borderline cases included."""
+    be identical -- every group, every particle, every observation, borderline cases included.  Both forms of the prefilter: one
+    candidate list per observation (round 6: what a call with at most 4 096 observations takes) and the uniform grid."""
     import slam_amd as sg
+    if prefilter == "grid":
+        monkeypatch.setenv("SLAMGPU_NO_ASSOC_LISTS", "1")
     g1, g2 = (float(x) for x in kat_assoc["gates"])
     R = np.array([[0.1 ** 2, 0], [0, 0.017453292519943 ** 2]], f32)
     same = 0
@@ -95,13 +99,16 @@ def test_grid_prefilter_never_changes_a_reference_decision(kat_assoc, math_mode)
 
 
 @pytest.mark.gpu
-def test_grid_prefilter_on_a_running_filter(tmp_path):
+@pytest.mark.parametrize("prefilter", ["lists", "grid"])
+def test_grid_prefilter_on_a_running_filter(tmp_path, prefilter, monkeypatch):
     """The same identity on the state of a running filter, where it is meant to pay: 4 096 particles on a synthetic
     1 000-landmark map (MAX_RANGE 30), the step's real observations plus shifted ones (new-landmark and discard outcomes);
     the grid evaluates a small fraction of the N * nz * Nf triples of the exhaustive scan."""
     import slam_amd as sg
     from conftest import DATA, sim_args
     from slam_amd import host
+    if prefilter == "grid":
+        monkeypatch.setenv("SLAMGPU_NO_ASSOC_LISTS", "1")
     lm = host.synthetic_landmarks(777, 1000, -130, 100, -100, 90)
     h0 = host.HostSim(sim_args("example_webmap", "FASTSLAM2", 100, 7))
     _, wp = h0.map()
