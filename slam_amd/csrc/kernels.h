@@ -546,6 +546,7 @@ struct VoteSlot {
 struct AssocGridArgs {
     LmkBox *box;                  // [nf]; pad[0]: the radial bound of this call's gates (assoc_count_kernel writes it, associate_grid_kernel reads it)
     AssocGeom *geom;
+    float *geom_part;             // [64][8] partial pose boxes / heading ranges (assoc_geom_partial_kernel)
     int32_t *cell_start;          // [nx * ny + 1] exclusive prefix of the cell populations
     int32_t *cell_fill;           // [nx * ny] cursors of the fill pass
     float4 *items;                // [2 cap_items] cell after cell, an entry = two float4: (xmin, xmax, ymin, ymax) of the landmark's box and

@@ -2881,7 +2881,7 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
             step(hipMalloc((void **) &c->cell_start_dev, sizeof(int32_t) * (kAssocMaxCells * kAssocMaxCells + 1)), "hipMalloc");
             step(hipMalloc((void **) &c->cell_fill_dev, sizeof(int32_t) * (kAssocMaxCells * kAssocMaxCells)), "hipMalloc");
             step(hipMalloc((void **) &c->items_dev, sizeof(float4) * 2 * (size_t) c->cap_items), "hipMalloc");
-            step(hipMalloc((void **) &c->geom_dev, sizeof(AssocGeom)), "hipMalloc");
+            step(hipMalloc((void **) &c->geom_dev, sizeof(AssocGeom) + sizeof(float) * 8 * 64), "hipMalloc");  // (+ the partial boxes behind it)
         }
         std::vector<int32_t> ids;
         for (int j = 0; j < c->nf; j++)
@@ -2899,6 +2899,7 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
         AssocGridArgs G{};
         G.box = c->box_dev;
         G.geom = c->geom_dev;
+        G.geom_part = reinterpret_cast<float *>(c->geom_dev + 1);
         G.cell_start = c->cell_start_dev;
         G.cell_fill = c->cell_fill_dev;
         G.items = c->items_dev;
