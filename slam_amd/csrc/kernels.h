@@ -639,7 +639,7 @@ struct KernelTable {
     void (*pp_census)(hipStream_t, const int32_t *labels_dev, int n, int nz, int ncap, int32_t *first_dev, int32_t *news_dev);
     void (*pp_resolve)(hipStream_t, const int32_t *labels_dev, int n, int nz, int ncap, const int32_t *uidx_dev, const int32_t *newk_dev, int m, int nn,
                        float p_new, int logw, int16_t *obs_dev, float *wf_dev, uint8_t *any_dev);
-    void (*pp_holders)(hipStream_t, const Buffers &, int nf, int32_t *holders_dev);
+    void (*pp_holders)(hipStream_t, const Buffers &, int count, const int32_t *ids_dev, int32_t *holders_dev);  // ids (may be null: 0 .. count - 1)
 };
 
 const KernelTable *kernels_strict();

@@ -3621,11 +3621,18 @@ static void launch_assoc_lists(hipStream_t st, const Buffers &B, const AssocGrid
 // census: which landmark slots ANY particle matched (first[l] = the lowest observation index that names l, INT_MAX: none -- the
 // host orders the packet's entries by it, so that particles which agree meet their landmarks in the order of the observations, as
 // the reference's loop over zf does) and how many particles call each observation new.
+constexpr int kCensusObs = 16;  // observations per workgroup of pp_census_kernel (blockIdx.y): one thread walking all 865 of a config-5 step
+                                // alone was 865 dependent loads, ~1 ms of a 6.7 ms step
 __global__ void __launch_bounds__(kBlock) pp_census_kernel(const int32_t *__restrict__ labels, int n, int nz, size_t S, int32_t *first, int32_t *__restrict__ news) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     const bool on = i < n;
-    for (int j = 0; j < nz; j++) {
-        const int lab = on ? labels[(size_t) j * S + i] : kAssocDiscard;
+    const int j0 = blockIdx.y * kCensusObs, jn = min(kCensusObs, nz - j0);
+    int labs[kCensusObs];
+#pragma unroll
+    for (int q = 0; q < kCensusObs; q++) labs[q] = (on && q < jn) ? labels[(size_t) (j0 + min(q, jn - 1)) * S + i] : kAssocDiscard;  // (all in flight together)
+#pragma unroll
+    for (int q = 0; q < kCensusObs; q++) {
+        const int j = j0 + q, lab = q < jn ? labs[q] : kAssocDiscard;  // (past the end: no label, no atomic)
         // a wave's particles nearly always agree: one atomic per wave and distinct label, and only to LOWER the word (it is soon at its
         // final value).  One atomic per particle was 10^5 atomics on one address per observation: 1.35 ms of a 1.5 ms step at 10^5
         // particles on example_webmap (profiles/particle_association_r06.txt)
@@ -3633,48 +3640,73 @@ __global__ void __launch_bounds__(kBlock) pp_census_kernel(const int32_t *__rest
         while (todo) {
             const int src = __ffsll((long long) todo) - 1;
             const int lab0 = __builtin_amdgcn_readlane(lab, src);
-            if ((int) (threadIdx.x & (kWave - 1)) == src && __hip_atomic_load(first + lab0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > j) atomicMin(first + lab0, j);
+            // (a plain look: a stale word is only ever too HIGH and costs one atomic more, at most one per wave and observation)
+            if ((int) (threadIdx.x & (kWave - 1)) == src && first[lab0] > j) atomicMin(first + lab0, j);
             todo &= ~__ballot(lab == lab0);
         }
         const unsigned long long nw = __ballot(lab == kAssocNew);
         if (nw && (threadIdx.x & (kWave - 1)) == (int) __ffsll((long long) __ballot(true)) - 1) atomicAdd(news + j, (int) __popcll(nw));
     }
 }
-
 // resolve: labels -> PerParticle::obs / wf / any.  uidx[l] = packet entry of landmark slot l (-1: not in the packet), newk[j] = new
 // slot (entry m + newk[j]) opened for observation j (-1: none).  One observation per landmark and particle (the first to name it; a
 // scan sees a landmark once); an observation the particle does not use -- discarded between the gates, a second claim on a
 // landmark, called new without a slot being opened for it, or opening one -- counts as unexplained and costs the factor p_new
 // (FastSLAM's constant likelihood of a new feature: without it a particle that ignores an observation would outweigh one that
 // explains it).
+// (The walk is sequential per particle -- the first claim on a landmark wins -- but nothing in it needs to wait for memory: the labels
+// and their packet entries come eight observations at a time, all in flight together, and "has this particle claimed entry k yet"
+// is a bit in LDS (one column of words per thread) instead of a read of the obs row it has just initialised; contexts whose packet
+// has more entries than the LDS holds bits for -- lds_words = 0 -- read the row.  Before: 865 x two dependent trips, 0.92 ms.)
+constexpr int kResolveBatch = 8;
 __global__ void __launch_bounds__(kBlock) pp_resolve_kernel(const int32_t *__restrict__ labels, int n, int nz, size_t S, const int32_t *__restrict__ uidx,
-                                                             const int32_t *__restrict__ newk, int m, int nn, float p_new, int logw,
+                                                             const int32_t *__restrict__ newk, int m, int nn, float p_new, int logw, int lds_words,
                                                              int16_t *__restrict__ obs, float *__restrict__ wf, uint8_t *__restrict__ any) {
+    extern __shared__ uint32_t sh_claim[];  // [lds_words][kBlock]
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= (int) S) return;
     for (int k = 0; k < m + nn; k++) obs[(size_t) k * S + i] = (int16_t) -1;
+    for (int w = 0; w < lds_words; w++) sh_claim[w * kBlock + threadIdx.x] = 0u;
     if (i >= n) {
         wf[i] = logw ? 0.0f : 1.0f;
         any[i] = 0;
         return;
     }
     int unexplained = 0, flags = 0;
-    for (int j = 0; j < nz; j++) {
-        const int lab = labels[(size_t) j * S + i];
-        if (lab >= 0) {
-            const int k = uidx[lab];
-            if (k >= 0 && obs[(size_t) k * S + i] < 0) {
-                obs[(size_t) k * S + i] = (int16_t) j;
-                flags |= 1;
+    for (int j0 = 0; j0 < nz; j0 += kResolveBatch) {
+        int labs[kResolveBatch], ks[kResolveBatch];
+#pragma unroll
+        for (int q = 0; q < kResolveBatch; q++) labs[q] = labels[(size_t) min(j0 + q, nz - 1) * S + i];
+#pragma unroll
+        for (int q = 0; q < kResolveBatch; q++) ks[q] = labs[q] >= 0 ? uidx[labs[q]] : (labs[q] == kAssocNew ? newk[min(j0 + q, nz - 1)] : -1);
+#pragma unroll
+        for (int q = 0; q < kResolveBatch; q++) {
+            const int j = j0 + q;
+            if (j >= nz) break;
+            const int lab = labs[q], k = ks[q];
+            if (lab >= 0) {
+                bool fresh = false;
+                if (k >= 0) {
+                    if (lds_words) {
+                        uint32_t &word = sh_claim[(k >> 5) * kBlock + threadIdx.x];
+                        fresh = !((word >> (k & 31)) & 1u);
+                        word |= 1u << (k & 31);
+                    } else {
+                        fresh = obs[(size_t) k * S + i] < 0;
+                    }
+                }
+                if (fresh) {
+                    obs[(size_t) k * S + i] = (int16_t) j;
+                    flags |= 1;
+                } else {
+                    unexplained++;
+                }
             } else {
                 unexplained++;
-            }
-        } else {
-            unexplained++;
-            const int kn = lab == kAssocNew ? newk[j] : -1;
-            if (kn >= 0) {
-                obs[(size_t) (m + kn) * S + i] = (int16_t) j;
-                flags |= 2;
+                if (k >= 0) {  // (called new, and a slot was opened for this observation)
+                    obs[(size_t) (m + k) * S + i] = (int16_t) j;
+                    flags |= 2;
+                }
             }
         }
     }
@@ -3688,7 +3720,9 @@ __global__ void __launch_bounds__(kBlock) pp_resolve_kernel(const int32_t *__res
 
 // holders: how many particles of the (plain) set hold landmark slot l, l < nf -- a slot nobody holds any more (its hypotheses died
 // in a resample) is dead: the host takes it out of the association and opens it again for a later landmark
-__global__ void __launch_bounds__(kBlock) pp_holders_kernel(Buffers B, int nf, int32_t *__restrict__ holders) {
+// (ids: the slots to count -- the host lists the PARTIAL ones: a slot every particle opened is held by every descendant for good --
+// or null: slots 0 .. nf - 1)
+__global__ void __launch_bounds__(kBlock) pp_holders_kernel(Buffers B, int nf, const int32_t *__restrict__ ids, int32_t *__restrict__ holders) {
     // per block: the waves' counts meet in LDS, a chunk of landmarks at a time; one global atomic per block and landmark (one per wave
     // and landmark was 55 000 atomics on 35 addresses at 10^5 particles on example_webmap: 0.45 ms)
     constexpr int kChunk = 1024;
@@ -3702,11 +3736,12 @@ __global__ void __launch_bounds__(kBlock) pp_holders_kernel(Buffers B, int nf, i
         for (int t = threadIdx.x; t < ln; t += kBlock) sh[t] = 0;
         __syncthreads();
         for (int l = l0; l < l0 + ln; l++) {
+            const int slot = ids ? ids[l] : l;
             bool has = false;
             if (on) {
                 float4 la;
                 float lb;
-                read_through_genealogy(B, B.lmk_live, cur, S, l, i, la, lb);
+                read_through_genealogy(B, B.lmk_live, cur, S, slot, i, la, lb);
                 has = la.x == la.x;
             }
             const unsigned long long hm = __ballot(has);
@@ -3714,20 +3749,23 @@ __global__ void __launch_bounds__(kBlock) pp_holders_kernel(Buffers B, int nf, i
         }
         __syncthreads();
         for (int t = threadIdx.x; t < ln; t += kBlock)
-            if (sh[t]) atomicAdd(holders + l0 + t, sh[t]);
+            if (sh[t]) atomicAdd(holders + (ids ? ids[l0 + t] : l0 + t), sh[t]);
         __syncthreads();
     }
 }
 
 static void launch_pp_census(hipStream_t st, const int32_t *labels, int n, int nz, int ncap, int32_t *first, int32_t *news) {
-    hipLaunchKernelGGL(pp_census_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, labels, n, nz, (size_t) ncap, first, news);
+    hipLaunchKernelGGL(pp_census_kernel, dim3((n + kBlock - 1) / kBlock, (nz + kCensusObs - 1) / kCensusObs), dim3(kBlock), 0, st, labels, n, nz, (size_t) ncap, first, news);
 }
 static void launch_pp_resolve(hipStream_t st, const int32_t *labels, int n, int nz, int ncap, const int32_t *uidx, const int32_t *newk, int m, int nn,
                               float p_new, int logw, int16_t *obs, float *wf, uint8_t *any) {
-    hipLaunchKernelGGL(pp_resolve_kernel, dim3(ncap / kBlock), dim3(kBlock), 0, st, labels, n, nz, (size_t) ncap, uidx, newk, m, nn, p_new, logw, obs, wf, any);
+    // claimed-entry bits in LDS while the packet's re-observed entries fit 48 KB of them (m <= 1 536: every step of the 10 000-landmark map)
+    const int words = (m + 31) / 32, lds_words = words * kBlock * 4 <= 48 * 1024 ? words : 0;
+    hipLaunchKernelGGL(pp_resolve_kernel, dim3(ncap / kBlock), dim3(kBlock), (size_t) lds_words * kBlock * sizeof(uint32_t), st, labels, n, nz, (size_t) ncap, uidx, newk, m,
+                       nn, p_new, logw, lds_words, obs, wf, any);
 }
-static void launch_pp_holders(hipStream_t st, const Buffers &B, int nf, int32_t *holders) {
-    hipLaunchKernelGGL(pp_holders_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B, nf, holders);
+static void launch_pp_holders(hipStream_t st, const Buffers &B, int count, const int32_t *ids, int32_t *holders) {
+    hipLaunchKernelGGL(pp_holders_kernel, dim3(B.ncap / kBlock), dim3(kBlock), 0, st, B, count, ids, holders);
 }
 
 static const KernelTable kTable = {launch_update, launch_update_particle, launch_update_persist, launch_resample, launch_resample_ref, launch_scan, launch_gather, launch_flatten, launch_identity, launch_decompact, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat, launch_observe, launch_observe_book, launch_associate,

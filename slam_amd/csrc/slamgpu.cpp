@@ -247,6 +247,8 @@ struct slamgpu_ctx {
     int pp_nz_cap = 0;
     float *pp_wf_dev = nullptr;      // [ncap]
     uint8_t *pp_any_dev = nullptr;   // [ncap]
+    std::vector<char> pp_partial;    // slots that NOT every particle opened: the only ones that can lose their last holder (a slot every particle
+                                     // opened is held by every descendant for good): what the holders census counts
     std::vector<char> pp_dead;       // landmark slots no particle holds any more (their hypotheses died in a resample): out of the
     std::vector<int32_t> pp_dead_list;  // association (retired) until a later landmark opens them again
     bool retired_stale = false;      // the host's retired flags have changed since the device's mask was written (retired_upload clears it)
@@ -3156,7 +3158,14 @@ int do_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const float R
     const int N = c->B.n, cap_nf = c->B.cap_nf, nf0 = c->nf;
     c->B.slot = c->slot;
     int32_t *first_dev = c->pp_tab_dev, *hold_dev = first_dev + cap_nf, *news_dev = hold_dev + cap_nf, *idn_dev = news_dev + c->pp_nz_cap;
-    const bool census = opt->census_every > 0 && nf0 > 0 && (c->pp_steps % (uint64_t) opt->census_every) == 0;
+    if (c->pp_partial.empty()) c->pp_partial.assign((size_t) cap_nf, 0);
+    if (c->pp_dead.empty()) c->pp_dead.assign((size_t) cap_nf, 0);
+    std::vector<int32_t> partial;  // the slots whose holders are counted: partial ones that are not dead already
+    const bool due = opt->census_every > 0 && nf0 > 0 && (c->pp_steps % (uint64_t) opt->census_every) == 0;
+    if (due)
+        for (int l = 0; l < nf0; l++)
+            if (c->pp_partial[(size_t) l] && !c->pp_dead[(size_t) l]) partial.push_back(l);
+    const bool census = due && !partial.empty();
     c->pp_steps++;
     // (first | holders | news are one stretch of the table: one copy down)
     std::vector<int32_t> down(2 * (size_t) cap_nf + (size_t) nz);
@@ -3165,10 +3174,15 @@ int do_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const float R
     HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) first_dev, 0x7fffffff, (size_t) cap_nf, c->stream));
     HIP_TRY(hipMemsetAsync(hold_dev, 0, sizeof(int32_t) * (size_t) cap_nf, c->stream));
     HIP_TRY(hipMemsetAsync(news_dev, 0, sizeof(int32_t) * (size_t) nz, c->stream));
+    if (census) {  // (the list rides in the words the new slots' ids will take later in this call)
+        if ((int) partial.size() > c->pp_nz_cap) partial.resize((size_t) c->pp_nz_cap);  // (more partial slots than the table has words: the rest next time)
+        HIP_TRY(hipMemcpyAsync(idn_dev, partial.data(), sizeof(int32_t) * partial.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // (pageable source)
+    }
     {
         Timed t(c, "particle_census");
         c->k->pp_census(c->stream, c->pp_lab_dev, N, nz, c->B.ncap, first_dev, news_dev);
-        if (census) c->k->pp_holders(c->stream, c->B, nf0, hold_dev);
+        if (census) c->k->pp_holders(c->stream, c->B, (int) partial.size(), idn_dev, hold_dev);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(down.data(), first_dev, sizeof(int32_t) * down.size(), hipMemcpyDeviceToHost, c->stream));
@@ -3180,12 +3194,13 @@ int do_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const float R
         if (first[l] != 0x7fffffff) touched.push_back({first[l], l});
     std::sort(touched.begin(), touched.end());
     const int m = (int) touched.size();
-    if (c->pp_dead.empty()) c->pp_dead.assign((size_t) cap_nf, 0);
     if (c->retired.empty()) c->retired.assign((size_t) cap_nf, 0);
     bool &mask_dirty = c->retired_stale;  // (sticky: a call that fails between a change of the flags and the upload leaves it set for the next one)
     if (census) {
         // a slot nobody holds any more is dead: out of the association, free for a later landmark
-        for (int l = 0; l < nf0; l++)
+        for (int l : partial)
+            if (hold[l] == N) c->pp_partial[(size_t) l] = 0;  // (every particle holds it: so will every descendant)
+        for (int l : partial)
             if (hold[l] == 0 && !c->pp_dead[(size_t) l] && first[l] == 0x7fffffff) {
                 c->pp_dead[(size_t) l] = 1;
                 c->pp_dead_list.push_back(l);
@@ -3217,6 +3232,7 @@ int do_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const float R
         }
         newk[(size_t) j] = (int32_t) idn.size();
         idn.push_back(slot);
+        c->pp_partial[(size_t) slot] = news[j] < N ? 1 : 0;
     }
     const int n = (int) idn.size();
     if (int rc = pp_reserve(c, nz, (size_t) m + n + 1)) return rc;
@@ -3664,6 +3680,8 @@ int slamgpu_upload(slamgpu_ctx *c, int32_t nf, const float *xv, const float *Pv9
     // (a new particle set is a new map: nothing of it has been retired from the association)
     c->pp_dead.clear();
     c->pp_dead_list.clear();
+    // (an uploaded set may hold absent records anywhere: every slot counts as partial until a census has seen it)
+    c->pp_partial.assign((size_t) c->B.cap_nf, 1);
     if (c->n_retired > 0) {
         std::fill(c->retired.begin(), c->retired.end(), 0);
         c->n_retired = 0;
