@@ -327,7 +327,9 @@ struct PerParticle {
     const int32_t *idn;      // [n] slots of the new landmarks (dead slots are reused before the map grows)
     const float *wf;         // [ncap] weight factor of the observations the particle leaves unexplained: p_new ^ count (log-weights: count * log p_new)
     const uint8_t *any;      // [ncap] bit 0: the particle matched a landmark, bit 1: it opens one (neither: the step leaves its pose alone)
+    int32_t nz, z_lds;       // observations of the step; 1: the launch stages z in LDS (2 nz floats fit: launch_update_any)
 };
+constexpr int kPpLdsObs = 2048;  // most observations a launch stages in LDS (16 KB)
 constexpr float kAbsent = __builtin_nanf("");  // xf.x / xf.y of an absent record
 
 struct UpdateArgs {

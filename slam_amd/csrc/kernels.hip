@@ -3382,8 +3382,12 @@ static void launch_update_any(hipStream_t st, const Buffers &B, const PredictArg
         return;
     }
     if (ppa.obs) {  // per-particle association (slamgpu.cpp: do_update_particle guarantees a single context on plain rows)
-        if (U.method == 2) hipLaunchKernelGGL((update_kernel<2, 0, true, true>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid, h_flags, B, PA, U, rng, ws, ppa);
-        else hipLaunchKernelGGL((update_kernel<1, 0, true, true>), dim3(grid), dim3(kBlock), lds, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid, h_flags, B, PA, U, rng, ws, ppa);
+        // + the staged observation indices (update_step.inl: shJ) and, when they fit, the observations (shZ)
+        PerParticle pq = ppa;
+        pq.z_lds = pq.nz <= kPpLdsObs ? 1 : 0;
+        const size_t lds_pp = lds + (size_t) kBigChunk * kBlock * sizeof(int32_t) + (pq.z_lds ? sizeof(float) * 2 * (size_t) pq.nz : 0);
+        if (U.method == 2) hipLaunchKernelGGL((update_kernel<2, 0, true, true>), dim3(grid), dim3(kBlock), lds_pp, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid, h_flags, B, PA, U, rng, ws, pq);
+        else hipLaunchKernelGGL((update_kernel<1, 0, true, true>), dim3(grid), dim3(kBlock), lds_pp, st, h_tot, B.ctrl, U.front.state_in, ws.nblocks, B.slot, grid, h_flags, B, PA, U, rng, ws, pq);
         return;
     }
     switch (sel) {

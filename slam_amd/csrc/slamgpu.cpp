@@ -3359,7 +3359,7 @@ int do_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const float R
     }
     for (int r : left) c->free_rows.push_back(r);
 
-    PerParticle ppa{c->pp_obs_dev, c->pp_z_dev, idn_dev, c->pp_wf_dev, c->pp_any_dev};
+    PerParticle ppa{c->pp_obs_dev, c->pp_z_dev, idn_dev, c->pp_wf_dev, c->pp_any_dev, nz, 0};
     c->pp_launch = &ppa;
     const int rc = issue_update(c, U, fresh, n_rows, need_normals, normals, strata, false);
     c->pp_launch = nullptr;

@@ -30,6 +30,11 @@
     float4 *const shA = reinterpret_cast<float4 *>(dyn_lds + off_bytes + win_bytes);
     const int nslots = staging_slots(METHOD, BIG, U.m);
     float *const shB = reinterpret_cast<float *>(dyn_lds + off_bytes + win_bytes + (size_t) nslots * kBlock * sizeof(float4));
+    // per-particle association (PP): behind the staged records, the particle's observation index of every staged entry and -- when
+    // they fit -- the step's observations themselves (a load from global memory inside the passes' bodies makes the wave wait for
+    // every record prefetch in flight as well: the note on the packet below)
+    [[maybe_unused]] int32_t *const shJ = PP ? reinterpret_cast<int32_t *>(shB + (size_t) nslots * kBlock) : nullptr;
+    [[maybe_unused]] float *const shZ = PP ? reinterpret_cast<float *>(shJ + (size_t) nslots * kBlock) : nullptr;
     __shared__ double sh_a[kBlock / kWave], sh_q[kBlock / kWave];
     __shared__ EstItem sh_est[kBlock / kWave];
     SLAM_STAMP(0);  // kernel entry
@@ -336,6 +341,12 @@
             return;
         }
     }
+    if constexpr (PP) {
+        if (ppa.z_lds) {  // (uniform; every thread of a compute block gets here)
+            for (int t = threadIdx.x; t < 2 * ppa.nz; t += kBlock) shZ[t] = ppa.z[t];
+            __syncthreads();
+        }
+    }
     const int i = bt * kBlock + threadIdx.x;
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     // select (not index) the buffers: an indexed read of the pointer table in the kernel-argument segment
@@ -486,7 +497,11 @@
         // sampled: fastslam2.cpp:21-48 runs only for a non-empty z).
         [[maybe_unused]] int pp_any = 3;
         if constexpr (PP) pp_any = (int) ppa.any[i];
-        [[maybe_unused]] auto pp_j = [&](int k) -> int { return (int) ppa.obs[(size_t) k * S + i]; };
+        // (re-observed entries, k < m: staged by the pipeline with the records, one chunk ahead; the new slots behind them: read in place)
+        [[maybe_unused]] auto pp_j = [&](int k) -> int {
+            return k < m ? shJ[(k & (kBigChunk - 1)) * kBlock + threadIdx.x] : (int) ppa.obs[(size_t) k * S + i];
+        };
+        [[maybe_unused]] auto pp_z = [&](int t) -> float { return ppa.z_lds ? shZ[t] : ppa.z[t]; };
         // Stage the first KS re-observed landmarks in LDS with all their loads in flight together (one HBM latency instead
         // of one per landmark); both passes then read LDS.  Measured before this: 38 % of the wave's cycles were s_waitcnt
         // stalls (profiles/rocprof_sq_counters_r01.txt).  Unconditional loads (index clamped to the last landmark): no
@@ -530,6 +545,8 @@
             int sl[CH];
             float4 ta[CH];
             float tb[CH];
+            [[maybe_unused]] int tj[CH];
+            static_assert(CH == kBigChunk && (kBigChunk & (kBigChunk - 1)) == 0, "pp_j indexes the staged chunk by k mod kBigChunk");
             auto load_slots = [&](int k0) {
 #pragma unroll
                 for (int k = 0; k < CH; k++) sl[k] = slot_of(min(k0 + k, m - 1));
@@ -540,6 +557,7 @@
                     const Rec r = load_rec(idf[min(k0 + k, m - 1)], sl[k], buf_of(min(k0 + k, m - 1)));
                     ta[k] = r.a;
                     tb[k] = r.b;
+                    if constexpr (PP) tj[k] = (int) ppa.obs[(size_t) min(k0 + k, m - 1) * S + i];
                 }
             };
             load_slots(0);
@@ -550,6 +568,7 @@
                 for (int k = 0; k < CH; k++) {
                     shA[(k) * kBlock + threadIdx.x] = ta[k];
                     shB[(k) * kBlock + threadIdx.x] = tb[k];
+                    if constexpr (PP) shJ[(k) * kBlock + threadIdx.x] = tj[k];
                 }
                 if (k0 + CH < m) {
                     load_recs(k0 + CH);       // slots of this chunk were requested one chunk of compute ago
@@ -720,7 +739,7 @@
                         const int j = pp_j(k);
                         if (j < 0 || la.x != la.x) return;  // (not matched; or -- caller-made labels only -- a landmark this particle does not hold)
                         const Obs2 o = observe2(x, y, th, la.x, la.y, la.z, la.w, lb, r00, rl, r11);
-                        proposal_update(x, y, th, P, o, ppa.z[2 * j] - o.zp0, wrap_pi(ppa.z[2 * j + 1] - o.zp1));
+                        proposal_update(x, y, th, P, o, pp_z(2 * j) - o.zp0, wrap_pi(pp_z(2 * j + 1) - o.zp1));
                     } else {
                         const Obs2 o = observe2(x, y, th, la.x, la.y, la.z, la.w, lb, r00, rl, r11);
                         proposal_update(x, y, th, P, o, zf[2 * k] - o.zp0, wrap_pi(zf[2 * k + 1] - o.zp1));
@@ -756,7 +775,7 @@
                         const int j = pp_j(k);
                         if (j >= 0 && la.x == la.x) {
                             const Obs2 o = observe2(xs, ys, ths, la.x, la.y, la.z, la.w, lb, r00, rl, r11);
-                            const Gauss2 g = feature_update2(la.x, la.y, la.z, la.w, lb, o, ppa.z[2 * j] - o.zp0, wrap_pi(ppa.z[2 * j + 1] - o.zp1));
+                            const Gauss2 g = feature_update2(la.x, la.y, la.z, la.w, lb, o, pp_z(2 * j) - o.zp0, wrap_pi(pp_z(2 * j + 1) - o.zp1));
                             if (logw) dl += (double) (g.E + __logf(g.norm));
                             else lik *= __expf(g.E) * g.norm;
                         }  // (else: not this particle's landmark in this step: the record moves on unchanged)
@@ -824,7 +843,7 @@
                 if constexpr (PP) {
                     const int j = pp_j(m + k);
                     if (j >= 0) {
-                        add_feature_fast(x, y, th, ppa.z[2 * j], ppa.z[2 * j + 1], r00, r01, r10, r11, la.x, la.y, la.z, la.w, lb);
+                        add_feature_fast(x, y, th, pp_z(2 * j), pp_z(2 * j + 1), r00, r01, r10, r11, la.x, la.y, la.z, la.w, lb);
                     } else {  // the particle does not open this landmark: an absent record (kernels.h: kAbsent)
                         la = make_float4(kAbsent, kAbsent, 0.0f, 0.0f);
                         lb = 0.0f;
@@ -864,8 +883,8 @@
                     Jac j = jacobian(x, y, th, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
                     float s00, s01, s10, s11;
                     inverse2(j.s00, j.s01, j.s10, j.s11, s00, s01, s10, s11);  // Sfi (:324)
-                    const float v0 = (PP ? ppa.z[2 * jo] : zf[2 * k]) - j.zp0;
-                    const float v1 = trig_offset((PP ? ppa.z[2 * jo + 1] : zf[2 * k + 1]) - j.zp1);
+                    const float v0 = (PP ? pp_z(2 * jo) : zf[2 * k]) - j.zp0;
+                    const float v1 = trig_offset((PP ? pp_z(2 * jo + 1) : zf[2 * k + 1]) - j.zp1);
                     float Pinv[9];
                     llt_solve_identity3(llt3(P[0], P[3], P[4], P[6], P[7], P[8]), Pinv);  // (:335)
                     // T1 = Hv^T * Sfi (3x2), T2 = T1 * Hv (3x3); Hv = [[hv00 hv01 0],[hv10 hv11 -1]]
@@ -934,8 +953,8 @@
                         }
                     }
                     Jac j = jacobian(xs, ys, ths, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
-                    const float v0 = (PP ? ppa.z[2 * jo] : zf[2 * k]) - j.zp0;
-                    const float v1 = trig_offset((PP ? ppa.z[2 * jo + 1] : zf[2 * k + 1]) - j.zp1);
+                    const float v0 = (PP ? pp_z(2 * jo) : zf[2 * k]) - j.zp0;
+                    const float v1 = trig_offset((PP ? pp_z(2 * jo + 1) : zf[2 * k + 1]) - j.zp1);
                     if (logw) dl += (double) gauss2_log(v0, v1, j.s00, j.s10, j.s11);
                     else lik = lik * gauss2(v0, v1, j.s00, j.s10, j.s11);
                     cholesky_update2(la.x, la.y, la.z, la.w, lb, v0, v1, r00, r01, r10, r11, j.hf00, j.hf01, j.hf10, j.hf11);
@@ -999,7 +1018,7 @@
                         const int j = pp_j(k);
                         if (j >= 0 && la.x == la.x) {
                             const Obs2 o = observe2(x, y, th, la.x, la.y, la.z, la.w, lb, r00, rl1, r11);
-                            const Gauss2 g = feature_update2(la.x, la.y, la.z, la.w, lb, o, ppa.z[2 * j] - o.zp0, wrap_pi(ppa.z[2 * j + 1] - o.zp1));
+                            const Gauss2 g = feature_update2(la.x, la.y, la.z, la.w, lb, o, pp_z(2 * j) - o.zp0, wrap_pi(pp_z(2 * j + 1) - o.zp1));
                             if (logw) dl += (double) (g.E + __logf(g.norm));
                             else wp *= __expf(g.E) * g.norm;
                         }  // (else: not this particle's landmark in this step: the record moves on unchanged)
@@ -1042,8 +1061,8 @@
                         }
                     }
                     Jac j = jacobian(x, y, th, la.x, la.y, la.z, la.w, lb, r00, r01, r10, r11);
-                    const float v0 = (PP ? ppa.z[2 * jo] : zf[2 * k]) - j.zp0;
-                    const float v1 = trig_offset((PP ? ppa.z[2 * jo + 1] : zf[2 * k + 1]) - j.zp1);
+                    const float v0 = (PP ? pp_z(2 * jo) : zf[2 * k]) - j.zp0;
+                    const float v1 = trig_offset((PP ? pp_z(2 * jo + 1) : zf[2 * k + 1]) - j.zp1);
                     const float den = (float) (2 * kPi * (double) sqrtf(determinant2(j.s00, j.s01, j.s10, j.s11)));
                     float i00, i01, i10, i11;
                     inverse2(j.s00, j.s01, j.s10, j.s11, i00, i01, i10, i11);
@@ -1099,7 +1118,7 @@
             if constexpr (PP) {
                 const int j = pp_j(m + k);
                 if (j >= 0) {
-                    add_feature(x, y, th, ppa.z[2 * j], ppa.z[2 * j + 1], r00, r01, r10, r11, la.x, la.y, la.z, la.w, lb);
+                    add_feature(x, y, th, pp_z(2 * j), pp_z(2 * j + 1), r00, r01, r10, r11, la.x, la.y, la.z, la.w, lb);
                 } else {  // the particle does not open this landmark: an absent record (kernels.h: kAbsent)
                     la = make_float4(kAbsent, kAbsent, 0.0f, 0.0f);
                     lb = 0.0f;
