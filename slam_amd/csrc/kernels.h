@@ -563,6 +563,10 @@ struct AssocGridArgs {
     int32_t lcap;                 // candidate LISTS per observation instead of grid cells (assoc_lists_kernel): entries of observation q at
                                   // items[2 (q lcap + k)], k < cell_start[q]; 0: the grid
     VoteSlot *votes;              // [nz][kVoteSlots] or null: the weighted vote per observation (AssocGeom::overflow bit 1: a table filled up)
+    float *vote_w;                // candidate lists only (lcap > 0), or null: [nz][lcap + 2] weights addressed DIRECTLY -- [0] new, [1] discard,
+                                  // [2 + k] entry k of the observation's list -- so that a vote is one atomic add nobody waits for (the hash
+                                  // table's look-up was a trip to L2 in every wave's dependent chain, once per observation: 1.2 ms of a
+                                  // 3.4 ms association at config 5); vote_compact_kernel turns them into `votes` afterwards
     int32_t logw;                 // the context keeps log-weights
 };
 
@@ -629,6 +633,8 @@ struct KernelTable {
     void (*assoc_grid)(hipStream_t, const Buffers &, const AssocGridArgs &);
     // ... or geometry + one candidate list per observation (AssocGridArgs::lcap > 0; nz <= kAssocMaxCells^2)
     void (*assoc_lists)(hipStream_t, const Buffers &, const AssocGridArgs &);
+    // AssocGridArgs::vote_w -> votes (after associate_grid; one block per observation)
+    void (*vote_compact)(hipStream_t, const AssocGridArgs &);
     // slamgpu_associate through the grid: the same labels as `associate`, evaluating only the landmarks of one cell per
     // (particle, observation)
     void (*associate_grid)(hipStream_t, const Buffers &, const AssocGridArgs &, const float *R4, float gate_reject, float gate_augment,

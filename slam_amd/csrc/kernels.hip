@@ -2964,6 +2964,7 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
     const int q_lo = blockIdx.y * A.obs_per_block, q_hi = min(A.nz, q_lo + A.obs_per_block);
     for (int q = q_lo; q < q_hi; q++) {
         int label = kVoteEmpty;
+        [[maybe_unused]] int pbest = -1;  // (LISTS: position of jbest in the observation's list: where its vote goes)
         if (on) {
             const float zr = A.z[2 * q], zb = A.z[2 * q + 1];
             float sn, cs;
@@ -2981,6 +2982,7 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
             }
             float nbest = INFINITY, outer = INFINITY;
             int jbest = -1;
+            [[maybe_unused]] int pcur = 0;  // (LISTS: position of the entry being visited in the observation's list)
             // one entry of the cell: the radial pre-test on the landmark's box alone (every estimate of j lies in the box, so its
             // distance d from this pose is within [dmin, dmax] of the box; a gate needs |d - r| < the entry's bound), on SQUARED
             // distances (round 6: no square root per entry, and the bound without the factor (1 + pi / 2) the CELL radius needs and
@@ -3017,6 +3019,7 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
                 if (nis < gate1 && (nd < nbest || (nd == nbest && j < jbest))) {
                     nbest = nd;
                     jbest = j;
+                    if constexpr (LISTS) pbest = pcur;
                 } else if (nis < outer) {
                     outer = nis;
                 }
@@ -3036,7 +3039,9 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
                 const float4 b0 = A.items[2 * (size_t) at], t0 = A.items[2 * (size_t) at + 1];
                 const int a1 = min(at + 1, c1 - 1);
                 const float4 b1 = A.items[2 * (size_t) a1], t1 = A.items[2 * (size_t) a1 + 1];
+                pcur = at - c0;
                 visit(b0, t0, A.G1, t0.w);
+                pcur = at + 1 - c0;
                 if (at + 1 < c1) visit(b1, t1, A.G1, t1.w);
             }
             if (jbest < 0 && A.G1 < A.G) {
@@ -3045,14 +3050,30 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
                     const float4 b0 = A.items[2 * (size_t) at], t0 = A.items[2 * (size_t) at + 1];
                     const int a1 = min(at + 1, c1 - 1);
                     const float4 b1 = A.items[2 * (size_t) a1], t1 = A.items[2 * (size_t) a1 + 1];
+                    pcur = at - c0;
                     visit(b0, t0, A.G, t0.x);
+                    pcur = at + 1 - c0;
                     if (at + 1 < c1) visit(b1, t1, A.G, t1.x);
                 }
             }
             label = jbest > -1 ? jbest : (outer > gate2 ? kAssocNew : kAssocDiscard);
             if (labels) labels[A.lab_by_obs ? (size_t) q * S + i : (size_t) i * A.nz + q] = label;
         }
-        if (A.votes) {
+        bool direct = false;
+        if constexpr (LISTS) direct = A.vote_w != nullptr;
+        if (direct) {
+            // (candidate lists: the label's place in the observation's table is known -- no look-up, nothing to wait for)
+            const int place = label >= 0 ? 2 + pbest : (label == kAssocNew ? 0 : 1);
+            unsigned long long todo = __ballot(on);
+            while (todo) {
+                const int src = __ffsll((long long) todo) - 1;
+                const int p0 = __builtin_amdgcn_readlane(place, src);
+                const bool mine = on && place == p0;
+                const float ws = wave_sum_f(mine ? wi : 0.0f);
+                if (lane == src) atomicAdd(A.vote_w + (size_t) q * (A.lcap + 2) + p0, ws);
+                todo &= ~__ballot(mine);
+            }
+        } else if (A.votes) {
             // a wave's particles nearly always agree: one atomic per wave and distinct label, not one per particle
             unsigned long long todo = __ballot(on);
             while (todo) {
@@ -3603,6 +3624,31 @@ static void launch_assoc_grid(hipStream_t st, const Buffers &B, const AssocGridA
     hipLaunchKernelGGL(assoc_count_kernel, dim3(gb), dim3(kBlock), 0, st, A, 1);
 }
 
+// the directly addressed votes of the candidate lists -> the per-observation tables the host reads (label, weight), at most kVoteSlots
+// labels with a vote each (more: AssocGeom::overflow bit 1, as when the hash table fills up)
+__global__ void __launch_bounds__(kWave) vote_compact_kernel(AssocGridArgs A) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const int cnt = A.cell_start[q] + 2;
+    const float *w = A.vote_w + (size_t) q * (A.lcap + 2);
+    VoteSlot *out = A.votes + (size_t) q * kVoteSlots;
+    int used = 0;
+    for (int p0 = 0; p0 < cnt; p0 += kWave) {
+        const int p = p0 + lane;
+        const float v = p < cnt ? w[p] : 0.0f;
+        const bool has = v > 0.0f;
+        const unsigned long long mk = __ballot(has);
+        const int at = used + __popcll(mk & ((1ull << lane) - 1ull));
+        if (has && at < kVoteSlots) {
+            const int label = p == 0 ? kAssocNew : (p == 1 ? kAssocDiscard : __float_as_int(A.items[2 * ((size_t) q * A.lcap + (p - 2)) + 1].y));
+            out[at].key = label;
+            out[at].w = v;
+        }
+        used += __popcll(mk);
+    }
+    if (lane == 0 && used > kVoteSlots) atomicOr(&A.geom->overflow, 2);
+}
+static void launch_vote_compact(hipStream_t st, const AssocGridArgs &A) { hipLaunchKernelGGL(vote_compact_kernel, dim3(A.nz), dim3(kWave), 0, st, A); }
+
 static void launch_associate_grid(hipStream_t st, const Buffers &B, const AssocGridArgs &A, const float *R4, float g1, float g2, int32_t *labels) {
     if (A.lcap > 0)
         hipLaunchKernelGGL(associate_grid_kernel<true>, dim3(B.ncap / kBlock, (A.nz + A.obs_per_block - 1) / A.obs_per_block), dim3(kBlock), 0, st, B, A,
@@ -3773,7 +3819,7 @@ static void launch_pp_holders(hipStream_t st, const Buffers &B, int count, const
 }
 
 static const KernelTable kTable = {launch_update, launch_update_particle, launch_update_persist, launch_resample, launch_resample_ref, launch_scan, launch_gather, launch_flatten, launch_identity, launch_decompact, launch_finish, launch_predict, launch_estimate, launch_jacobians, launch_kat, launch_observe, launch_observe_book, launch_associate,
-                                   launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish, launch_dist_gather, launch_dist_flags, launch_peek, launch_lmk_box, launch_assoc_grid, launch_assoc_lists,
+                                   launch_shard_plan, launch_shard_pack, launch_shard_unpack, launch_shard_finish, launch_dist_gather, launch_dist_flags, launch_peek, launch_lmk_box, launch_assoc_grid, launch_assoc_lists, launch_vote_compact,
                                    launch_associate_grid, launch_jacobians_multi, launch_pp_census, launch_pp_resolve, launch_pp_holders};
 
 }  // namespace SLAM_KNS

@@ -251,6 +251,8 @@ struct slamgpu_ctx {
                                      // opened is held by every descendant for good): what the holders census counts
     std::vector<char> pp_dead;       // landmark slots no particle holds any more (their hypotheses died in a resample): out of the
     std::vector<int32_t> pp_dead_list;  // association (retired) until a later landmark opens them again
+    float *vote_w_dev = nullptr;     // AssocGridArgs::vote_w, grown on demand
+    size_t vote_w_cap = 0;
     bool retired_stale = false;      // the host's retired flags have changed since the device's mask was written (retired_upload clears it)
     uint64_t pp_steps = 0;
     const PerParticle *pp_launch = nullptr;  // set around issue_update by do_update_particle: the launch takes update_kernel<.., PP = true>
@@ -957,6 +959,7 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     if (c->stamps_dev) (void) hipFree(c->stamps_dev);
     if (c->peek_dev) (void) hipFree(c->peek_dev);
     if (c->retired_dev) (void) hipFree(c->retired_dev);
+    if (c->vote_w_dev) (void) hipFree(c->vote_w_dev);
     if (c->pp_lab_dev) (void) hipFree(c->pp_lab_dev);
     if (c->pp_obs_dev) (void) hipFree(c->pp_obs_dev);
     if (c->pp_z_dev) (void) hipFree(c->pp_z_dev);
@@ -2932,12 +2935,27 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
             if (!ids.empty()) c->k->lmk_box(c->stream, c->B, c->assoc_ids_dev, (int) ids.size(), c->retired_dev, c->box_dev);
             for (int attempt = lcap >= 16 ? 0 : 1; attempt < 2 && !rc; attempt++) {
                 G.lcap = attempt == 0 ? lcap : 0;
+                G.vote_w = nullptr;
+                if (G.lcap && want_vote) {  // the lists' votes are addressed directly: [nz][lcap + 2] weights, compacted into `votes` afterwards
+                    const size_t words = (size_t) nz * ((size_t) G.lcap + 2);
+                    if (words > c->vote_w_cap) {
+                        if (c->vote_w_dev) (void) hipFree(c->vote_w_dev);
+                        c->vote_w_dev = nullptr;
+                        c->vote_w_cap = 0;
+                        step(hipMalloc((void **) &c->vote_w_dev, sizeof(float) * words), "hipMalloc(votes)");
+                        if (!rc) c->vote_w_cap = words;
+                    }
+                    if (!rc) step(hipMemsetAsync(c->vote_w_dev, 0, sizeof(float) * words, c->stream), "memset");
+                    if (rc) break;
+                    G.vote_w = c->vote_w_dev;
+                }
                 // (the first pass bounded by the match gate pays on the lists' short walks; on the grid's long ones it cost more than
                 // it saved -- 8.52 against 8.32 ms at config 5 --: there the one wide pass)
                 G.G1 = G.lcap ? std::min(gate_reject * 1.001f, G.G) : G.G;
                 if (G.lcap) c->k->assoc_lists(c->stream, c->B, G);
                 else c->k->assoc_grid(c->stream, c->B, G);
                 c->k->associate_grid(c->stream, c->B, G, R, gate_reject, gate_augment, lab_dev);
+                if (G.vote_w) c->k->vote_compact(c->stream, G);
                 step(hipGetLastError(), "launch");
                 if (attempt == 0) {  // (did every list fit?  the association kernel has left at once if not)
                     step(hipMemcpyAsync(&hg, c->geom_dev, sizeof hg, hipMemcpyDeviceToHost, c->stream), "D2H");
