@@ -2966,7 +2966,9 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
         int label = kVoteEmpty;
         [[maybe_unused]] int pbest = -1;  // (LISTS: position of jbest in the observation's list: where its vote goes)
         if (on) {
-            const float zr = A.z[2 * q], zb = A.z[2 * q + 1];
+            // (uniform and written before the launch: scalar loads)
+            const auto *zc = (const __attribute__((address_space(4))) float *) reinterpret_cast<uintptr_t>(A.z);
+            const float zr = zc[2 * q], zb = zc[2 * q + 1];
             float sn, cs;
 #ifdef SLAM_FAST_MATH
             sincos_cw(pa.z + zb, sn, cs);  // (a bounded angle; the cell the point falls in has a cell of slack on every side)
@@ -3028,7 +3030,14 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
             // it were two dependent trips), two in flight at a time; SQ counters before: 87 % of the wave cycles waiting, the SIMDs
             // a third busy (profiles/gated_association_r06.txt)
             // (LISTS: the observation's own candidate list, assoc_lists_kernel)
-            const int c0 = LISTS ? q * A.lcap : A.cell_start[cell], c1 = LISTS ? c0 + A.cell_start[q] : A.cell_start[cell + 1];
+            // (LISTS: the list is the same for every lane -- q is the block's -- and was written before this launch: read it through the constant
+            // address space, as SCALAR loads that sit outside the vector memory pipeline the record fetches use)
+            using ItemP = std::conditional_t<LISTS, const __attribute__((address_space(4))) float *, const float *>;
+            using CntP = std::conditional_t<LISTS, const __attribute__((address_space(4))) int32_t *, const int32_t *>;
+            const ItemP items_f = (ItemP) reinterpret_cast<uintptr_t>(A.items);
+            auto item_at = [&](size_t w) -> float4 { return make_float4(items_f[4 * w], items_f[4 * w + 1], items_f[4 * w + 2], items_f[4 * w + 3]); };
+            const CntP counts = (CntP) reinterpret_cast<uintptr_t>(A.cell_start);
+            const int c0 = LISTS ? q * A.lcap : counts[cell], c1 = LISTS ? c0 + counts[q] : counts[cell + 1];
             // Two passes.  Whatever an observation is MATCHED with passes gate_reject, so a first walk bounded by gate_reject alone (G1:
             // radii ~ sqrt(G1 / G) of the full ones) sees every landmark that can become jbest -- same candidates, same ties: the same
             // label.  The wider bound of gate_augment is only needed to tell "new" from "discard" for an observation NOTHING matched: a
@@ -3036,9 +3045,9 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
             // not pay (the walk over a cell's ~33 entries was the cost: 8.52 against 8.32 ms at config 5); with the lists' ~3 entries
             // the records fetched through the genealogy are the cost again, and the first pass fetches 40 % fewer.
             for (int at = c0; at < c1; at += 2) {
-                const float4 b0 = A.items[2 * (size_t) at], t0 = A.items[2 * (size_t) at + 1];
+                const float4 b0 = item_at(2 * (size_t) at), t0 = item_at(2 * (size_t) at + 1);
                 const int a1 = min(at + 1, c1 - 1);
-                const float4 b1 = A.items[2 * (size_t) a1], t1 = A.items[2 * (size_t) a1 + 1];
+                const float4 b1 = item_at(2 * (size_t) a1), t1 = item_at(2 * (size_t) a1 + 1);
                 pcur = at - c0;
                 visit(b0, t0, A.G1, t0.w);
                 pcur = at + 1 - c0;
@@ -3047,9 +3056,9 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
             if (jbest < 0 && A.G1 < A.G) {
                 outer = INFINITY;
                 for (int at = c0; at < c1; at += 2) {
-                    const float4 b0 = A.items[2 * (size_t) at], t0 = A.items[2 * (size_t) at + 1];
+                    const float4 b0 = item_at(2 * (size_t) at), t0 = item_at(2 * (size_t) at + 1);
                     const int a1 = min(at + 1, c1 - 1);
-                    const float4 b1 = A.items[2 * (size_t) a1], t1 = A.items[2 * (size_t) a1 + 1];
+                    const float4 b1 = item_at(2 * (size_t) a1), t1 = item_at(2 * (size_t) a1 + 1);
                     pcur = at - c0;
                     visit(b0, t0, A.G, t0.x);
                     pcur = at + 1 - c0;
