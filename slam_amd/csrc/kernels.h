@@ -559,6 +559,8 @@ struct AssocGridArgs {
     float r00, r11, G;            // R diagonal; G = max(gate_reject, gate_augment) with the safety margin
     float G1;                     // gate_reject with the safety margin: the bound of the walk's FIRST pass (associate_grid_kernel)
     int32_t obs_per_block;        // observations one thread of associate_grid_kernel works through (blockIdx.y = a group of that many)
+    float g1_ratio, pad_r;        // sqrt(G1 / G): a LIST entry's radial bound for the first pass is derived from its bound for G (its fourth word
+                                  // carries the landmark's genealogy row | live buffer << 30 instead: one dependent trip less per evaluated triple)
     int32_t lab_by_obs;           // labels laid out [nz][ncap] (the per-particle update's) instead of [n][nz]
     int32_t lcap;                 // candidate LISTS per observation instead of grid cells (assoc_lists_kernel): entries of observation q at
                                   // items[2 (q lcap + k)], k < cell_start[q]; 0: the grid

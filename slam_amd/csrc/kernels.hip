@@ -2881,7 +2881,7 @@ SLAM_DEV void arc_range(float a0, float a1, bool cosine, float &lo, float &hi) {
     if (floorf(b1 * inv) > floorf(b0 * inv) || b0 * inv == floorf(b0 * inv)) hi = 1.0f;
     if (floorf((b1 - 3.14159265358979324f) * inv) > floorf((b0 - 3.14159265358979324f) * inv)) lo = -1.0f;
 }
-__global__ void __launch_bounds__(kBlock) assoc_lists_kernel(AssocGridArgs A) {
+__global__ void __launch_bounds__(kBlock) assoc_lists_kernel(AssocGridArgs A, const int32_t *__restrict__ erow, const int32_t *__restrict__ live) {
     __shared__ int32_t sh_n;
     const int q = blockIdx.x;
     const AssocGeom g = *A.geom;
@@ -2913,7 +2913,8 @@ __global__ void __launch_bounds__(kBlock) assoc_lists_kernel(AssocGridArgs A) {
         if (at < A.lcap) {
             const size_t w = 2 * ((size_t) q * A.lcap + at);
             A.items[w] = make_float4(bx.xmin, bx.xmax, bx.ymin, bx.ymax);
-            A.items[w + 1] = make_float4(e, __int_as_float(j), bx.tmax, 1.01f * sqrtf(A.G1 * (bx.tmax + A.r00)) + 1e-3f);
+            // (fourth word: where the landmark's records are found -- genealogy row | live buffer << 30 -- so that the walk need not look them up)
+            A.items[w + 1] = make_float4(e, __int_as_float(j), bx.tmax, __int_as_float(erow[j] | (live[j] ? kRowLiveBit : 0)));
         }
     }
     __syncthreads();
@@ -3012,7 +3013,16 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
                 const int j = __float_as_int(bt.y);
                 float4 la;
                 float lb;
-                read_through_genealogy(B, B.lmk_live, cur, S, j, i, la, lb);
+                if constexpr (LISTS) {
+                    // (single contexts without arrivals: the slot is this GPU's; row and live buffer ride in the entry)
+                    const int rw = __float_as_int(bt.w);
+                    const int sl = B.gen[cur][gen_index(B.compact, S, rw & kRowMask, (size_t) i)];
+                    const size_t at = (size_t) j * S + (size_t) sl;
+                    la = B.lmkA[(rw >> 30) & 1][at];
+                    lb = B.lmkB[(rw >> 30) & 1][at];
+                } else {
+                    read_through_genealogy(B, B.lmk_live, cur, S, j, i, la, lb);
+                }
                 const AssocLm L = assoc_landmark(pa, la, lb, r00, r01, r10, r11);
                 float nis, nd;
                 assoc_gate(L, zr, zb, nis, nd);
@@ -3048,10 +3058,11 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
                 const float4 b0 = item_at(2 * (size_t) at), t0 = item_at(2 * (size_t) at + 1);
                 const int a1 = min(at + 1, c1 - 1);
                 const float4 b1 = item_at(2 * (size_t) a1), t1 = item_at(2 * (size_t) a1 + 1);
+                // (first-pass radial bound: the grid's entries carry it; a list's is derived from the bound for G -- 1 % of slack covers the rounding)
                 pcur = at - c0;
-                visit(b0, t0, A.G1, t0.w);
+                visit(b0, t0, A.G1, LISTS ? (t0.x - 1e-3f) * A.g1_ratio + 1.1e-3f : t0.w);
                 pcur = at + 1 - c0;
-                if (at + 1 < c1) visit(b1, t1, A.G1, t1.w);
+                if (at + 1 < c1) visit(b1, t1, A.G1, LISTS ? (t1.x - 1e-3f) * A.g1_ratio + 1.1e-3f : t1.w);
             }
             if (jbest < 0 && A.G1 < A.G) {
                 outer = INFINITY;
@@ -3669,7 +3680,7 @@ static void launch_associate_grid(hipStream_t st, const Buffers &B, const AssocG
 static void launch_assoc_lists(hipStream_t st, const Buffers &B, const AssocGridArgs &A) {
     hipLaunchKernelGGL(assoc_geom_partial_kernel, dim3(kGeomBlocks), dim3(kBlock), 0, st, B, A.geom_part);
     hipLaunchKernelGGL(assoc_geom_kernel, dim3(1), dim3(kBlock), 0, st, B, A, A.geom_part);
-    hipLaunchKernelGGL(assoc_lists_kernel, dim3(A.nz), dim3(kBlock), 0, st, A);
+    hipLaunchKernelGGL(assoc_lists_kernel, dim3(A.nz), dim3(kBlock), 0, st, A, B.erow, B.lmk_live);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -2952,6 +2952,7 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
                 // (the first pass bounded by the match gate pays on the lists' short walks; on the grid's long ones it cost more than
                 // it saved -- 8.52 against 8.32 ms at config 5 --: there the one wide pass)
                 G.G1 = G.lcap ? std::min(gate_reject * 1.001f, G.G) : G.G;
+                G.g1_ratio = sqrtf(G.G1 / G.G);
                 if (G.lcap) c->k->assoc_lists(c->stream, c->B, G);
                 else c->k->assoc_grid(c->stream, c->B, G);
                 c->k->associate_grid(c->stream, c->B, G, R, gate_reject, gate_augment, lab_dev);
