@@ -21,6 +21,7 @@
 // The reference's Particle could drop an entry (landmarkXs / landmarkPs are per-particle vectors: Particle.cpp:61-73); a shared
 // landmark count cannot renumber in the middle of a run, so a retired landmark stays in the maps, inert.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <limits>
 #include <cstdint>
@@ -104,18 +105,83 @@ struct GatedPolicy {
             ox[(size_t) q] = xv[0] + z[2 * q] * std::cos(xv[2] + z[2 * q + 1]);
             oy[(size_t) q] = xv[1] + z[2 * q] * std::sin(xv[2] + z[2 * q + 1]);
         }
+        // (round 6, end: the candidates of a pending observation come from a uniform grid over the mapped landmarks and over this step's
+        // points instead of a scan of all of them -- 250 pending observations x (9 814 landmarks + 865 points) with a square root each
+        // were 2.7 ms of a 5.4 ms step on the 10 000-landmark map.  Every test below compares d1 / d2 with bounds of at most
+        // B = max(unique_ratio, new_factor, 1) x rho; the grid's cells are at least the largest B wide, so the 3 x 3 cells around the
+        // point hold everything within B, candidates are visited in index order (ties as before), and a distance beyond B reads as
+        // "further than B" either way: the decisions are those of the full scan.)
+        struct Grid {
+            float x0 = 0, y0 = 0, inv = 0;
+            int nx = 1, ny = 1;
+            std::vector<int32_t> start, item;
+            void build(const float *px, const float *py, int stride, int n, const std::vector<char> *skip, float cs, float bx0, float by0, float bx1, float by1) {
+                x0 = bx0;
+                y0 = by0;
+                inv = 1.0f / cs;
+                nx = std::max(1, std::min(1024, (int) ((bx1 - bx0) * inv) + 1));
+                ny = std::max(1, std::min(1024, (int) ((by1 - by0) * inv) + 1));
+                start.assign((size_t) nx * ny + 1, 0);
+                std::vector<int32_t> cell((size_t) n, -1);
+                for (int k = 0; k < n; k++) {
+                    if (skip && (*skip)[(size_t) k]) continue;
+                    const float x = px[(size_t) k * stride], y = py[(size_t) k * stride];
+                    if (!(x == x) || !(y == y)) continue;
+                    cell[(size_t) k] = cy(y) * nx + cx(x);
+                    start[(size_t) cell[(size_t) k] + 1]++;
+                }
+                for (size_t c = 0; c + 1 < start.size(); c++) start[c + 1] += start[c];
+                item.assign((size_t) start.back(), 0);
+                std::vector<int32_t> fill(start.begin(), start.end() - 1);
+                for (int k = 0; k < n; k++)  // (ascending k inside every cell)
+                    if (cell[(size_t) k] >= 0) item[(size_t) fill[(size_t) cell[(size_t) k]]++] = k;
+            }
+            int cx(float x) const { return std::max(0, std::min(nx - 1, (int) std::floor((x - x0) * inv))); }
+            int cy(float y) const { return std::max(0, std::min(ny - 1, (int) std::floor((y - y0) * inv))); }
+            // the members of the 3 x 3 cells around (x, y), ascending
+            void around(float x, float y, std::vector<int32_t> &out) const {
+                out.clear();
+                const int ax = cx(x), ay = cy(y);
+                for (int yy = std::max(0, ay - 1); yy <= std::min(ny - 1, ay + 1); yy++)
+                    for (int xx = std::max(0, ax - 1); xx <= std::min(nx - 1, ax + 1); xx++)
+                        out.insert(out.end(), item.begin() + start[(size_t) yy * nx + xx], item.begin() + start[(size_t) yy * nx + xx + 1]);
+                std::sort(out.begin(), out.end());
+            }
+        };
+        Grid glm, gob;
+        std::vector<int32_t> cand;
+        if (!pending.empty()) {
+            float rmax = 0.0f, bx0 = INFINITY, by0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY;
+            for (int q : pending) rmax = std::max(rmax, std::fabs(z[2 * q]));
+            for (int q = 0; q < nz; q++) {
+                bx0 = std::min(bx0, ox[(size_t) q]); bx1 = std::max(bx1, ox[(size_t) q]);
+                by0 = std::min(by0, oy[(size_t) q]); by1 = std::max(by1, oy[(size_t) q]);
+            }
+            for (int j = 0; j < nf; j++) {
+                if (retired[(size_t) j] || !(xf[2 * j] == xf[2 * j])) continue;
+                bx0 = std::min(bx0, xf[2 * j]); bx1 = std::max(bx1, xf[2 * j]);
+                by0 = std::min(by0, xf[2 * j + 1]); by1 = std::max(by1, xf[2 * j + 1]);
+            }
+            // (cells at least the largest B wide -- and wide enough that the grid has at most 1 024 x 1 024 of them; a cell wider than
+            // B only means more candidates)
+            float cs = std::max(1e-3f, std::max(std::max(unique_ratio, new_factor), 1.0f) * (rescue_base + rescue_per_m * rmax)) * 1.0001f;
+            cs = std::max(cs, std::max(bx1 - bx0, by1 - by0) / 1000.0f);
+            glm.build(xf, xf + 1, 2, nf, &retired, cs, bx0, by0, bx1, by1);
+            gob.build(ox.data(), oy.data(), 1, nz, nullptr, cs, bx0, by0, bx1, by1);
+        }
         for (int q : pending) {
             const float r = z[2 * q], b = z[2 * q + 1];
             const float px = ox[(size_t) q], py = oy[(size_t) q];
             float d1 = INFINITY, d2 = INFINITY;
             int j1 = -1;
-            for (int o = 0; o < nz; o++) {
+            gob.around(px, py, cand);
+            for (int o : cand) {
                 if (o == q) continue;
                 const float dx = ox[(size_t) o] - px, dy = oy[(size_t) o] - py;
                 d2 = std::min(d2, std::sqrt(dx * dx + dy * dy));
             }
-            for (int j = 0; j < nf; j++) {
-                if (retired[(size_t) j]) continue;
+            glm.around(px, py, cand);
+            for (int j : cand) {
                 const float dx = xf[2 * j] - px, dy = xf[2 * j + 1] - py;
                 const float d = std::sqrt(dx * dx + dy * dy);
                 if (d < d1) {
