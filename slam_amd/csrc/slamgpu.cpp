@@ -253,6 +253,9 @@ struct slamgpu_ctx {
     std::vector<int32_t> pp_dead_list;  // association (retired) until a later landmark opens them again
     float *vote_w_dev = nullptr;     // AssocGridArgs::vote_w, grown on demand
     size_t vote_w_cap = 0;
+    float *assoc_z_dev = nullptr;    // the observations of an association call / its vote tables: kept between calls (an allocation and a release
+    VoteSlot *assoc_votes_dev = nullptr;  // per call each), grown on demand
+    int assoc_nz_cap = 0;
     bool retired_stale = false;      // the host's retired flags have changed since the device's mask was written (retired_upload clears it)
     uint64_t pp_steps = 0;
     const PerParticle *pp_launch = nullptr;  // set around issue_update by do_update_particle: the launch takes update_kernel<.., PP = true>
@@ -960,6 +963,8 @@ void slamgpu_destroy(slamgpu_ctx *c) {
     if (c->peek_dev) (void) hipFree(c->peek_dev);
     if (c->retired_dev) (void) hipFree(c->retired_dev);
     if (c->vote_w_dev) (void) hipFree(c->vote_w_dev);
+    if (c->assoc_z_dev) (void) hipFree(c->assoc_z_dev);
+    if (c->assoc_votes_dev) (void) hipFree(c->assoc_votes_dev);
     if (c->pp_lab_dev) (void) hipFree(c->pp_lab_dev);
     if (c->pp_obs_dev) (void) hipFree(c->pp_obs_dev);
     if (c->pp_z_dev) (void) hipFree(c->pp_z_dev);
@@ -2861,9 +2866,19 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
         if (!lab_dev) step(hipMalloc((void **) &lab_dev, sizeof(int32_t) * (size_t) N * nz), "hipMalloc(labels)");
     };
     // (the per-particle update keeps the observations in a buffer of the context: no allocation per step)
-    const bool z_own = !(lab_ext && c->pp_z_dev && nz <= c->pp_nz_cap);
-    if (z_own) step(hipMalloc((void **) &z_dev, sizeof(float) * 2 * (size_t) nz), "hipMalloc");
-    else z_dev = c->pp_z_dev;
+    if (nz > c->assoc_nz_cap) {  // (the call's observations and vote tables live in buffers of the context)
+        if (c->assoc_z_dev) (void) hipFree(c->assoc_z_dev);
+        if (c->assoc_votes_dev) (void) hipFree(c->assoc_votes_dev);
+        c->assoc_z_dev = nullptr;
+        c->assoc_votes_dev = nullptr;
+        c->assoc_nz_cap = 0;
+        const int cap = std::max(64, 2 * nz);
+        step(hipMalloc((void **) &c->assoc_z_dev, sizeof(float) * 2 * (size_t) cap), "hipMalloc");
+        step(hipMalloc((void **) &c->assoc_votes_dev, sizeof(VoteSlot) * kVoteSlots * (size_t) cap), "hipMalloc");
+        if (!rc) c->assoc_nz_cap = cap;
+    }
+    const bool z_own = false;
+    z_dev = (lab_ext && c->pp_z_dev && nz <= c->pp_nz_cap) ? c->pp_z_dev : c->assoc_z_dev;
     step(hipMemcpyAsync(z_dev, z, sizeof(float) * 2 * (size_t) nz, hipMemcpyHostToDevice, c->stream), "H2D");
     step(hipStreamSynchronize(c->stream), "sync");
     if (stats) {
@@ -2897,7 +2912,7 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
         }
         if (labels || lab_ext) need_labels();
         if (want_vote) {
-            step(hipMalloc((void **) &votes_dev, sizeof(VoteSlot) * kVoteSlots * (size_t) nz), "hipMalloc");
+            votes_dev = c->assoc_votes_dev;
             // key = kVoteEmpty (0x80000000), weight = -0.0f (the same bits): -0.0 + w = w
             if (!rc) step(hipMemsetD32Async((hipDeviceptr_t) votes_dev, (int) 0x80000000, 2 * kVoteSlots * (size_t) nz, c->stream), "memset");
         }
@@ -3040,7 +3055,6 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
     if (ev1) (void) hipEventDestroy(ev1);
     if (z_dev && z_own) (void) hipFree(z_dev);
     if (lab_dev && lab_dev != lab_ext) (void) hipFree(lab_dev);
-    if (votes_dev) (void) hipFree(votes_dev);
     if (rc) return rc;
     if (labels) memcpy(labels, lab.data(), sizeof(int32_t) * lab.size());
     if (want_vote && !voted) {
