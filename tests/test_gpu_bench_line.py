@@ -82,6 +82,7 @@ def test_default_line_single_gpu():
     assert d["window_start"] == j["config"]["window_start"] and d["steps"] == 60 and d["rccl_ranks"] == 1 and d["particles"] == 100096
     assert 1e9 < d["value"] < 2e10 and 0.9 < d["ratio_to_single_context"] < 2.5, d
     assert 5.0 < d["update_launch_us"] < 100.0 and 0.5 < d["allgather_us_in_step"] < 1e3 and d["preflight"]["hipipc_ok"] is True
+    assert len(d["passes_ms_per_step"]) == 3 and d["ms_per_step"] == sorted(d["passes_ms_per_step"])[1]   # the median of three child runs
 
 
 def test_multi_gpu_path_with_one_rank():
