@@ -648,7 +648,9 @@ int main(int argc, char **argv) {
                     px.push_back(dxv[3 * (size_t) i]);
                     py.push_back(dxv[3 * (size_t) i + 1]);
                     for (int j = 0; j < nfl; j++) {
-                        fx.push_back(dxf[2 * ((size_t) i * nfl + j)]);
+                        const float lx = dxf[2 * ((size_t) i * nfl + j)];
+                        if (lx != lx) continue;  // (-assoc particle: a landmark this particle does not hold)
+                        fx.push_back(lx);
                         fy.push_back(dxf[2 * ((size_t) i * nfl + j) + 1]);
                     }
                 }
