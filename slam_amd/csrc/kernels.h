@@ -565,6 +565,9 @@ struct AssocGridArgs {
     int32_t lcap;                 // candidate LISTS per observation instead of grid cells (assoc_lists_kernel): entries of observation q at
                                   // items[2 (q lcap + k)], k < cell_start[q]; 0: the grid
     VoteSlot *votes;              // [nz][kVoteSlots] or null: the weighted vote per observation (AssocGeom::overflow bit 1: a table filled up)
+    int32_t *census_first, *census_news;  // per-particle update (or null): the census of the labels taken right here, where they are made --
+                                  // first[l] = the lowest observation naming landmark slot l (preset to INT_MAX), news[q] = particles calling
+                                  // observation q new (preset to 0): what pp_census_kernel works out from the label array otherwise
     float *vote_w;                // candidate lists only (lcap > 0), or null: [nz][lcap + 2] weights addressed DIRECTLY -- [0] new, [1] discard,
                                   // [2 + k] entry k of the observation's list -- so that a vote is one atomic add nobody waits for (the hash
                                   // table's look-up was a trip to L2 in every wave's dependent chain, once per observation: 1.2 ms of a

@@ -3079,6 +3079,18 @@ __global__ void __launch_bounds__(kBlock) associate_grid_kernel(Buffers B, Assoc
             label = jbest > -1 ? jbest : (outer > gate2 ? kAssocNew : kAssocDiscard);
             if (labels) labels[A.lab_by_obs ? (size_t) q * S + i : (size_t) i * A.nz + q] = label;
         }
+        if (A.census_first) {
+            // (slamgpu_update_particle: a wave's particles nearly always agree: one atomic per wave and distinct label, nobody waits for it)
+            unsigned long long todo = __ballot(on && label >= 0);
+            while (todo) {
+                const int src = __ffsll((long long) todo) - 1;
+                const int lab0 = __builtin_amdgcn_readlane(label, src);
+                if (lane == src) atomicMin(A.census_first + lab0, q);
+                todo &= ~__ballot(label == lab0);
+            }
+            const unsigned long long nw = __ballot(on && label == kAssocNew);
+            if (nw && lane == (int) __ffsll((long long) nw) - 1) atomicAdd(A.census_news + q, (int) __popcll(nw));
+        }
         bool direct = false;
         if constexpr (LISTS) direct = A.vote_w != nullptr;
         if (direct) {

@@ -258,6 +258,7 @@ struct slamgpu_ctx {
     int assoc_nz_cap = 0;
     bool retired_stale = false;      // the host's retired flags have changed since the device's mask was written (retired_upload clears it)
     uint64_t pp_steps = 0;
+    bool pp_census_done = false;     // the association kernel took the census of the labels itself (AssocGridArgs::census_first): pp_census_kernel is skipped
     const PerParticle *pp_launch = nullptr;  // set around issue_update by do_update_particle: the launch takes update_kernel<.., PP = true>
     float4 *items_dev = nullptr;  // [2 cap_items]: kernels.h: AssocGridArgs::items
     AssocGeom *geom_dev = nullptr;
@@ -2833,6 +2834,7 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
     if (int rc = check_ctx(c)) return rc;
     if (mode < SLAMGPU_ASSOC_AUTO || mode > SLAMGPU_ASSOC_GRID) return fail(SLAMGPU_ERR_INVALID, "unknown association mode %d", mode);
     if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0.0;
+    c->pp_census_done = false;
     if (nz < 0 || (nz > 0 && !z) || !R) return fail(SLAMGPU_ERR_INVALID, "bad observation list");
     if (nz == 0) return 0;
     static_assert(SLAMGPU_ASSOC_NEW == kAssocNew && SLAMGPU_ASSOC_DISCARD == kAssocDiscard, "public / device labels");
@@ -2939,6 +2941,13 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
         G.votes = votes_dev;
         G.logw = c->cfg.log_weights;
         G.lab_by_obs = lab_ext ? 1 : 0;
+        if (lab_ext && c->pp_tab_dev && nz <= c->pp_nz_cap) {
+            // the per-particle update's census rides in this launch: first | holders | news of the context's table (do_update_particle's layout)
+            G.census_first = c->pp_tab_dev;
+            G.census_news = c->pp_tab_dev + 2 * (size_t) c->B.cap_nf;
+            step(hipMemsetD32Async((hipDeviceptr_t) G.census_first, 0x7fffffff, (size_t) c->B.cap_nf, c->stream), "memset");
+            step(hipMemsetAsync(G.census_news, 0, sizeof(int32_t) * (size_t) nz, c->stream), "memset");
+        }
         AssocGeom hg{};
         // few enough observations: a candidate list per observation instead of the grid (kernels.hip: assoc_lists_kernel); a list that
         // does not fit its share of the entry buffer sends the call to the grid (SLAMGPU_NO_ASSOC_LISTS=1: always the grid -- A/B, tests)
@@ -2990,6 +2999,7 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
                 if (mode == SLAMGPU_ASSOC_GRID) rc = fail(SLAMGPU_ERR_CAPACITY, "association grid: %d entries exceed the buffer of %d", hg.total, c->cap_items);
                 grid = false;  // (auto: the exhaustive scan instead)
             } else {
+                c->pp_census_done = G.census_first != nullptr;
                 if (stats) {
                     stats[0] = (double) hg.pairs;
                     stats[1] = (double) hg.total;
@@ -3207,9 +3217,13 @@ int do_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const float R
     std::vector<int32_t> down(2 * (size_t) cap_nf + (size_t) nz);
     int32_t *const first = down.data(), *const hold = first + cap_nf, *const news = hold + cap_nf;
     HIP_TRY(hipMemcpyAsync(c->pp_z_dev, z, sizeof(float) * 2 * (size_t) nz, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) first_dev, 0x7fffffff, (size_t) cap_nf, c->stream));
+    const bool census_taken = c->pp_census_done;  // (by the association kernel itself: slamgpu_update_particle through the grid / lists)
+    c->pp_census_done = false;
+    if (!census_taken) {
+        HIP_TRY(hipMemsetD32Async((hipDeviceptr_t) first_dev, 0x7fffffff, (size_t) cap_nf, c->stream));
+        HIP_TRY(hipMemsetAsync(news_dev, 0, sizeof(int32_t) * (size_t) nz, c->stream));
+    }
     HIP_TRY(hipMemsetAsync(hold_dev, 0, sizeof(int32_t) * (size_t) cap_nf, c->stream));
-    HIP_TRY(hipMemsetAsync(news_dev, 0, sizeof(int32_t) * (size_t) nz, c->stream));
     if (census) {  // (the list rides in the words the new slots' ids will take later in this call)
         if ((int) partial.size() > c->pp_nz_cap) partial.resize((size_t) c->pp_nz_cap);  // (more partial slots than the table has words: the rest next time)
         HIP_TRY(hipMemcpyAsync(idn_dev, partial.data(), sizeof(int32_t) * partial.size(), hipMemcpyHostToDevice, c->stream));
@@ -3217,7 +3231,7 @@ int do_update_particle(slamgpu_ctx *c, const float *z, int32_t nz, const float R
     }
     {
         Timed t(c, "particle_census");
-        c->k->pp_census(c->stream, c->pp_lab_dev, N, nz, c->B.ncap, first_dev, news_dev);
+        if (!census_taken) c->k->pp_census(c->stream, c->pp_lab_dev, N, nz, c->B.ncap, first_dev, news_dev);
         if (census) c->k->pp_holders(c->stream, c->B, (int) partial.size(), idn_dev, hold_dev);
     }
     HIP_TRY(hipGetLastError());
@@ -3436,6 +3450,7 @@ int slamgpu_update_labels(slamgpu_ctx *c, const float *z, int32_t nz, const floa
             return fail(SLAMGPU_ERR_INVALID, "slamgpu_update_labels: label %d of particle %d, observation %d (%d landmarks)", (int) labels[q], (int) (q / nz), (int) (q % nz), c->nf);
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (int rc = pp_reserve(c, nz, 1)) return rc;
+    c->pp_census_done = false;  // (the caller's labels: nobody has taken their census)
     {
         // (the device reads the labels by observation: [nz][ncap])
         const size_t S = (size_t) c->B.ncap;
