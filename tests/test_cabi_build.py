@@ -56,6 +56,21 @@ def test_integration_md_shows_the_compiled_bindings():
     assert adapter[adapter.index("template <class Particle, class VectorXf, class MatrixXf>"):adapter.index("#endif")].rstrip() in doc
 
 
+def test_integration_md_per_particle_snippet_compiles(tmp_path):
+    """The per-particle association call INTEGRATION.md shows (slamgpu_particle_assoc + slamgpu_update_particle) is cut out of the
+    document and compiled against the header: the field names and the argument list a maintainer copies are the real ones."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    a = doc.index("slamgpu_particle_assoc opt = {};")
+    b = doc.index("```", a)
+    body = doc[a:b]
+    assert "slamgpu_update_particle(ctx, z, nz, R, &opt, normals, strata, report)" in body
+    tu = tmp_path / "pp_snippet.cpp"
+    tu.write_text("#include <cmath>\n#include <cstdint>\n#include <slamgpu.h>\nstatic int check(int rc) { return rc; }\n"
+                  "int run(slamgpu_ctx *ctx, const float *z, int nz, const float R[4], float GATE_REJECT, float GATE_AUGMENT, const float *normals,\n"
+                  "        const float *strata) {\n" + body + "  return report[0];\n}\n")
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-c", str(tu), "-o", str(tmp_path / "pp_snippet.o")])
+
+
 def test_headers_are_plain_c(tmp_path):
     """The boundary is a C ABI: include/slamgpu.h (stable part and experimental block) and include/slamhost.h compile as C99 with
     -pedantic, and a C program links against the library's version symbol."""
