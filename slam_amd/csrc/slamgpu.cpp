@@ -2951,13 +2951,18 @@ int associate_impl(slamgpu_ctx *c, const float *z, int32_t nz, const float R[4],
         AssocGeom hg{};
         // few enough observations: a candidate list per observation instead of the grid (kernels.hip: assoc_lists_kernel); a list that
         // does not fit its share of the entry buffer sends the call to the grid (SLAMGPU_NO_ASSOC_LISTS=1: always the grid -- A/B, tests)
-        const int lcap = (nz > 0 && nz <= kAssocMaxCells * kAssocMaxCells && (double) nz * (double) c->nf <= 4e8 && getenv("SLAMGPU_NO_ASSOC_LISTS") == nullptr)
-                             ? (int) std::min<int64_t>(2048, (int64_t) c->cap_items / nz) : 0;
+        int lcap = (nz > 0 && nz <= kAssocMaxCells * kAssocMaxCells && (double) nz * (double) c->nf <= 4e8 && getenv("SLAMGPU_NO_ASSOC_LISTS") == nullptr)
+                       ? (int) std::min<int64_t>(2048, (int64_t) c->cap_items / nz) : 0;
+        bool lcap_forced = false;
+        if (const char *e = getenv("SLAMGPU_ASSOC_LCAP")) {  // (tests: lists too short -> the call must take the grid by itself)
+            lcap = std::min(lcap, std::max(1, atoi(e)));
+            lcap_forced = lcap >= 1;
+        }
         if (!rc) {
             if (ev0) step(hipEventRecord(ev0, c->stream), "event");
             Timed t(c, "associate");
             if (!ids.empty()) c->k->lmk_box(c->stream, c->B, c->assoc_ids_dev, (int) ids.size(), c->retired_dev, c->box_dev);
-            for (int attempt = lcap >= 16 ? 0 : 1; attempt < 2 && !rc; attempt++) {
+            for (int attempt = (lcap >= 16 || lcap_forced) ? 0 : 1; attempt < 2 && !rc; attempt++) {
                 G.lcap = attempt == 0 ? lcap : 0;
                 G.vote_w = nullptr;
                 if (G.lcap && want_vote) {  // the lists' votes are addressed directly: [nz][lcap + 2] weights, compacted into `votes` afterwards

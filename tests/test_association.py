@@ -99,16 +99,19 @@ def test_grid_prefilter_never_changes_a_reference_decision(kat_assoc, math_mode,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("prefilter", ["lists", "grid"])
+@pytest.mark.parametrize("prefilter", ["lists", "grid", "lists-overflow"])
 def test_grid_prefilter_on_a_running_filter(tmp_path, prefilter, monkeypatch):
     """The same identity on the state of a running filter, where it is meant to pay: 4 096 particles on a synthetic
     1 000-landmark map (MAX_RANGE 30), the step's real observations plus shifted ones (new-landmark and discard outcomes);
-    the grid evaluates a small fraction of the N * nz * Nf triples of the exhaustive scan."""
+    the grid evaluates a small fraction of the N * nz * Nf triples of the exhaustive scan.  Three ways: the candidate lists, the grid, and
+    lists made too short on purpose (the call must fall back to the grid by itself)."""
     import slam_amd as sg
     from conftest import DATA, sim_args
     from slam_amd import host
     if prefilter == "grid":
         monkeypatch.setenv("SLAMGPU_NO_ASSOC_LISTS", "1")
+    if prefilter == "lists-overflow":  # lists of ONE entry overflow at once: the call must notice and take the grid, same labels
+        monkeypatch.setenv("SLAMGPU_ASSOC_LCAP", "1")
     lm = host.synthetic_landmarks(777, 1000, -130, 100, -100, 90)
     h0 = host.HostSim(sim_args("example_webmap", "FASTSLAM2", 100, 7))
     _, wp = h0.map()
@@ -133,6 +136,8 @@ def test_grid_prefilter_on_a_running_filter(tmp_path, prefilter, monkeypatch):
             b, cb, _, sb = s.associate(zz, R, 4.0, 25.0, mode=sg.capi.ASSOC_GRID, want_stats=True)
             assert sb["grid"] and np.array_equal(a, b) and np.array_equal(ca, cb), i
             assert sb["triples"] < 0.1 * sa["triples"], (i, sb, sa)
+            # (entries: a list holds a handful per observation, the grid hundreds per cell: which form answered shows here)
+            assert (sb["grid_entries"] < 40 * zz.shape[0]) == (prefilter == "lists"), (i, prefilter, sb)
             checked += a.size
             kinds |= (1 if (a >= 0).any() else 0) | (2 if (a == -1).any() else 0) | (4 if (a == -2).any() else 0)
         s.step(np.array(st["controls"], f32).reshape(-1, 3), tape["Q"], float(tape["dt"]), st["zf"], st["idf"], st["zn"], R)
