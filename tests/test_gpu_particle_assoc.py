@@ -280,3 +280,46 @@ def test_disagreeing_particles_against_the_oracle(sg, oracle, name, method, math
                 compare_weights((wg[ok] / wg[ok].sum()).astype(np.float32), (we[ok] / we[ok].sum()).astype(np.float32), method == 2, tag, math_mode)
         done += 1
     assert done >= 2, "no snapshot with two re-observed landmarks"
+
+
+def test_a_slot_whose_holders_died_is_found_dead_and_reused(sg):
+    """A landmark only a minority opened lives as long as the minority does.  Ten of 1 024 particles (weight 0, so that the next
+    resampling drops them) open a slot for an observation the others discard; after the resample nobody holds it: the holders census
+    (every step here) finds it dead -- out of the association, reported -- and the next landmark everybody opens REUSES the slot
+    instead of growing the map; every particle then holds it."""
+    N = 1024
+    tape = _tape("FASTSLAM2", N, 40)
+    kw = dict(method=2, n_effective=N, rng_mode=sg.RNG_PHILOX, seed=3, math_mode=1, particle_maps=True)   # NEFFECTIVE = N: every step resamples
+    s = sg.SlamGpu(N, 64, **kw)
+    for st in tape["steps"][:20]:
+        _predicts(s, st, tape)
+        zf, zn = np.array(st["zf"], f32).reshape(-1, 2), np.array(st["zn"], f32).reshape(-1, 2)
+        if len(zf) + len(zn):
+            s.update(zf, np.array(st["idf"], np.int32), zn, tape["R"])
+    d = s.download()
+    nf = d["nf"]
+    minority = np.arange(10)
+    d["w"] = d["w"].copy()
+    d["w"][minority] = 0.0
+    d["w"] /= d["w"].sum()
+    s.upload(d)
+    # one observation far from everything: the minority calls it new, everybody else discards it
+    z = np.array([[25.0, 0.3]], f32)
+    lab = np.full((N, 1), DISCARD, np.int32)
+    lab[minority, 0] = NEW
+    r1 = s.update_labels(z, tape["R"], lab, new_share=0.0, p_new=1.0, census_every=1)
+    assert r1["opened"] == 1 and r1["slots"] == nf + 1 and r1["dead"] == 0, r1
+    after = s.download()   # (materialises: the resample has happened, the weightless minority is gone)
+    assert after["nf"] == nf + 1 and np.isnan(after["xf"][:, nf, 0]).all(), "somebody still holds the minority's landmark"
+    # a step that opens nothing: the census sees the slot without holders
+    lab2 = np.full((N, 1), DISCARD, np.int32)
+    r2 = s.update_labels(z, tape["R"], lab2, new_share=0.0, p_new=1.0, census_every=1)
+    assert r2["census"] == 1 and r2["dead"] == 1 and r2["opened"] == 0 and r2["slots"] == nf + 1, r2
+    # everybody opens a landmark: the dead slot is taken, the map does not grow
+    lab3 = np.full((N, 1), NEW, np.int32)
+    r3 = s.update_labels(z, tape["R"], lab3, new_share=0.5, p_new=1.0, census_every=1)
+    assert r3["opened"] == 1 and r3["reused"] == 1 and r3["dead"] == 0 and r3["slots"] == nf + 1, r3
+    end = s.download()
+    s.close()
+    assert end["nf"] == nf + 1 and not np.isnan(end["xf"][:, nf, 0]).any()
+    assert np.isfinite(end["xv"]).all() and abs(end["w"].sum(dtype=np.float64) - 1.0) < 1e-4
