@@ -323,3 +323,59 @@ def test_a_slot_whose_holders_died_is_found_dead_and_reused(sg):
     s.close()
     assert end["nf"] == nf + 1 and not np.isnan(end["xf"][:, nf, 0]).any()
     assert np.isfinite(end["xv"]).all() and abs(end["w"].sum(dtype=np.float64) - 1.0) < 1e-4
+
+
+def test_capacity_layout_and_argument_errors_are_return_codes(sg):
+    """The per-particle entry points on the edges: a context of 40..256 landmarks created WITHOUT the flag is moved to plain rows at
+    the first call and works; a small compact context is refused with the flag's name; an observation that needs a slot when none is
+    left is dropped and reported, not an error; bad options are SLAMGPU_ERR_INVALID; an exhaustive exclusion scan that would run for
+    seconds is SLAMGPU_ERR_CAPACITY."""
+    N = 512
+    tape = _tape("FASTSLAM2", N, 25)
+    R = tape["R"]
+    kw = dict(method=2, n_effective=int(0.75 * N), rng_mode=sg.RNG_PHILOX, seed=2, math_mode=1)
+    # (i) mid-size capacity without the flag: demoted on the fly
+    s = sg.SlamGpu(N, 100, **kw)
+    for st in tape["steps"]:
+        _predicts(s, st, tape)
+        z = np.concatenate([np.array(st["zf"], f32).reshape(-1, 2), np.array(st["zn"], f32).reshape(-1, 2)])
+        if len(z):
+            s.update_particle(z, R, 4.0, 25.0, new_share=0.02, p_new=10.0, excl=(2.0, 0.05, 2.0))
+    d = s.download()
+    assert 3 <= d["nf"] <= 12 and np.isfinite(d["xv"]).all()
+    # (ii) bad options
+    z1 = np.array([[10.0, 0.1]], f32)
+    for bad in (dict(p_new=0.0), dict(new_share=1.5), dict(census_every=-1), dict(excl=(-1.0, 0.0, 2.0))):
+        with pytest.raises(sg.SlamGpuError) as e:
+            s.update_particle(z1, R, 4.0, 25.0, **dict(dict(p_new=1.0), **bad))
+        assert e.value.code == -1, (bad, e.value)
+    with pytest.raises(sg.SlamGpuError) as e:      # the exclusion rule scans exhaustively: not through the grid
+        s.update_particle(z1, R, 4.0, 25.0, mode=sg.capi.ASSOC_GRID, p_new=1.0, excl=(2.0, 0.05, 2.0))
+    assert e.value.code == -1 and "exclusion" in str(e.value)
+    s.close()
+    # (iii) a compact context (capacity below 40) is refused, by name
+    s = sg.SlamGpu(N, 35, **kw)
+    with pytest.raises(sg.SlamGpuError) as e:
+        s.update_particle(z1, R, 4.0, 25.0, p_new=1.0)
+    assert e.value.code == -1 and "SLAMGPU_FLAG_PARTICLE_MAPS" in str(e.value)
+    s.close()
+    # (iv) no slot left: the observation is dropped and said so
+    s = sg.SlamGpu(N, 40, particle_maps=True, **kw)
+    lab = np.full((N, 50), NEW, np.int32)
+    z50 = np.stack([np.linspace(5, 50, 50), np.linspace(-1, 1, 50)], axis=1).astype(f32)
+    r = s.update_labels(z50, R, lab, new_share=0.5, p_new=1.0)
+    assert r["opened"] == 40 and r["dropped"] == 10 and r["slots"] == 40, r
+    r = s.update_labels(z50[:3], R, lab[:, :3], new_share=0.5, p_new=1.0)
+    assert r["opened"] == 0 and r["dropped"] == 3 and r["slots"] == 40, r
+    d = s.download()
+    assert d["nf"] == 40 and np.isfinite(d["xf"]).all()
+    s.close()
+    # (v) an exhaustive exclusion scan of 4 096 x 4 000 x 4 000 gates is refused before it is launched
+    s = sg.SlamGpu(4096, 4000, particle_maps=True, **dict(kw, n_effective=3072))
+    lab = np.full((4096, 4000), NEW, np.int32)
+    zbig = np.stack([np.linspace(5, 60, 4000), np.linspace(-3, 3, 4000)], axis=1).astype(f32)
+    s.update_labels(zbig, R, lab, new_share=0.5, p_new=1.0)
+    with pytest.raises(sg.SlamGpuError) as e:
+        s.update_particle(zbig, R, 4.0, 25.0, p_new=1.0, excl=(2.0, 0.05, 2.0))
+    assert e.value.code == -3 and "exclusion" in str(e.value), e.value
+    s.close()
