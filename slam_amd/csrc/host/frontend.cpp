@@ -466,6 +466,7 @@ int slamhost_gated_set(slamhost_gated *g, const char *name, double v) {
     else if (k == "rescue_per_m") p.rescue_per_m = (float) v;
     else if (k == "unique_ratio") p.unique_ratio = (float) v;
     else if (k == "new_factor") p.new_factor = (float) v;
+    else if (k == "grid") p.grid = v != 0;
     else return -1;
     return 0;
 }

@@ -45,6 +45,7 @@ struct GatedPolicy {
     // radius -- BASELINE config 5: 10 000 landmarks, ~2 m apart -- and the gates decide alone)
     float rescue_base = 2.0f, rescue_per_m = 0.05f, unique_ratio = 2.0f, new_factor = 2.0f;
     bool rescue = true;
+    bool grid = true;  // the second stage's candidates from a uniform grid (false: every landmark and point, in one cell: the same decisions, tests)
     int n_rescued = 0, n_new_refused = 0;
 
     std::vector<int32_t> decision;  // of the last step, per observation: landmark index, -1 opened as new, -2 left unused; +1000000 = by the second stage
@@ -166,6 +167,7 @@ struct GatedPolicy {
             // B only means more candidates)
             float cs = std::max(1e-3f, std::max(std::max(unique_ratio, new_factor), 1.0f) * (rescue_base + rescue_per_m * rmax)) * 1.0001f;
             cs = std::max(cs, std::max(bx1 - bx0, by1 - by0) / 1000.0f);
+            if (!grid) cs = 4.0f * (std::max(bx1 - bx0, by1 - by0) + 1.0f);  // (one cell)
             glm.build(xf, xf + 1, 2, nf, &retired, cs, bx0, by0, bx1, by1);
             gob.build(ox.data(), oy.data(), 1, nz, nullptr, cs, bx0, by0, bx1, by1);
         }
