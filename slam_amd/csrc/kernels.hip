@@ -2564,34 +2564,54 @@ __global__ void __launch_bounds__(kBlock) associate_kernel(Buffers B, int nf, co
                 j1[q] = -1;
             }
         }
-        for (int j = 0; j < nf; j++) {
+        // Several landmarks per trip through the loop (kTogether).  The scan is bound by dependent issue, not by memory: 12 700 VALU instructions per wave on
+        // example_webmap's 35 landmarks with a wave and a half per SIMD, and a wave alone on its SIMD issues a DEPENDENT instruction every
+        // ~9.6 cycles but two interleaved chains at ~5.6 each (tools/microbench/valu_latency.hip; SQ counters:
+        // profiles/rocprof_sq_r06_assoc_exhaustive_c3.txt).  The gate arithmetic of landmarks j and j + 1 is independent; only the
+        // comparisons run through both, in landmark order: the same decisions.
+        auto take = [&](int q, int j, float nis, float nd, const float4 &la) {
+            if (nis < gate1 && nd < nbest[q]) {
+                nbest[q] = nd;
+                jbest[q] = j;
+            } else if (nis < outer[q]) {
+                outer[q] = nis;
+            }
+            if constexpr (EXCL) {  // (an absent record compares false twice: it is nobody's neighbour)
+                const float ex = la.x - wx[q], ey = la.y - wy[q], dd = ex * ex + ey * ey;
+                if (dd < d1[q]) {
+                    d2[q] = d1[q];
+                    d1[q] = dd;
+                    j1[q] = j;
+                } else if (dd < d2[q]) {
+                    d2[q] = dd;
+                }
+            }
+        };
+        constexpr int kTogether = 4;
+        for (int j = 0; j < nf; j += kTogether) {
             // (a retired landmark -- slamgpu_retire_landmarks: a duplicate the caller's policy has given up -- takes no part; uniform)
-            if (retired && ((retired[j >> 5] >> (j & 31)) & 1u)) continue;
-            float4 la;
-            float lb;
-            read_through_genealogy(B, B.lmk_live, cur, S, j, i, la, lb);
-            const AssocLm A = assoc_landmark(pa, la, lb, r00, r01, r10, r11);
+            int jj[kTogether];
+            bool onj[kTogether];
+            float4 las[kTogether];
+            float lbs[kTogether];
+            AssocLm As[kTogether];
+#pragma unroll
+            for (int t = 0; t < kTogether; t++) {
+                jj[t] = min(j + t, nf - 1);
+                onj[t] = j + t < nf && !(retired && ((retired[jj[t] >> 5] >> (jj[t] & 31)) & 1u));
+                read_through_genealogy(B, B.lmk_live, cur, S, jj[t], i, las[t], lbs[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < kTogether; t++) As[t] = assoc_landmark(pa, las[t], lbs[t], r00, r01, r10, r11);
 #pragma unroll
             for (int q = 0; q < kAssocBatch; q++) {
                 if (q0 + q < nz) {
-                    float nis, nd;
-                    assoc_gate(A, z[2 * (q0 + q)], z[2 * (q0 + q) + 1], nis, nd);
-                    if (nis < gate1 && nd < nbest[q]) {
-                        nbest[q] = nd;
-                        jbest[q] = j;
-                    } else if (nis < outer[q]) {
-                        outer[q] = nis;
-                    }
-                    if constexpr (EXCL) {  // (an absent record compares false twice: it is nobody's neighbour)
-                        const float ex = la.x - wx[q], ey = la.y - wy[q], dd = ex * ex + ey * ey;
-                        if (dd < d1[q]) {
-                            d2[q] = d1[q];
-                            d1[q] = dd;
-                            j1[q] = j;
-                        } else if (dd < d2[q]) {
-                            d2[q] = dd;
-                        }
-                    }
+                    float nis[kTogether], nd[kTogether];
+#pragma unroll
+                    for (int t = 0; t < kTogether; t++) assoc_gate(As[t], z[2 * (q0 + q)], z[2 * (q0 + q) + 1], nis[t], nd[t]);
+#pragma unroll
+                    for (int t = 0; t < kTogether; t++)
+                        if (onj[t]) take(q, jj[t], nis[t], nd[t], las[t]);
                 }
             }
         }
