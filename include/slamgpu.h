@@ -316,8 +316,10 @@ int slamgpu_associate_ex(slamgpu_ctx *ctx, const float *z, int32_t nz, const flo
  *   - an observation a particle leaves unexplained (discarded between the gates, a second claim on one landmark, new) costs that
  *     particle the weight factor opt->p_new -- FastSLAM's constant likelihood of a new feature -- so that ignoring an
  *     observation never outweighs explaining it; a particle none of the observations concerns keeps its pose and Pv untouched;
- *   - every opt->census_every steps the particles holding each slot are counted: a slot nobody holds any more (its hypotheses died
- *     in a resample) is dead -- out of the association, reused by a later landmark.
+ *   - every opt->census_every steps the particles holding each PARTIAL slot are counted (a slot every particle opened is held by
+ *     every descendant for good and needs no counting): a slot nobody holds any more (its hypotheses died in a resample) is dead
+ *     -- out of the association, reused by a later landmark.
+ * At most 32 767 observations a step.
  * Resampling, estimates, history and downloads are the usual ones.  Single contexts on plain genealogy rows only: create the
  * context with SLAMGPU_FLAG_PARTICLE_MAPS (capacities of 40..256 landmarks are moved to plain rows at the first call).
  * normals / strata: as slamgpu_update.  report (may be NULL): [0] slots rewritten, [1] slots opened, [2] of them dead slots
